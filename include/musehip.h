@@ -1,0 +1,239 @@
+/* musehip.h -- C ABI of libmusehip.so: the MI355X (gfx950) kernels behind the MuseDiffusion
+ * hot path (GaussianDiffusion sampling / training losses over the TransformerNetModel denoiser).
+ *
+ * The reference (YAIxPOZAlabs/MuseDiffusion) has no native code and no FFI: its boundary for this
+ * path is the Python surface MuseDiffusion.models.{network,diffusion,rounding}.  Each entry point
+ * below replaces one torch-op group of that surface; the comment on each names the reference
+ * file:line it stands in for.  The Python host (musediffusion_amd/) binds these with ctypes; the
+ * binding a reference maintainer would add is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - plain pointers + sizes, no torch types; all pointers are DEVICE pointers unless named host_*.
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*), allocates nothing,
+ *     never synchronises, and is hipGraph-capture safe.
+ *   - return 0 on success, negative mh_status otherwise; mh_last_error() gives the message
+ *     (thread-local).
+ *   - `dtype` selects the activation/weight element type of the compute path:
+ *     MH_F32 (fp32 storage, fp32-input MFMA / VALU: the parity mode) or MH_BF16 (bf16 storage,
+ *     bf16 MFMA with fp32 accumulation: the throughput mode).  Latents, biases, LayerNorm
+ *     parameters, embeddings used for rounding / logits and all diffusion arithmetic are fp32 in
+ *     both modes.
+ *   - "ld*" arguments are leading dimensions in ELEMENTS.
+ */
+#ifndef MUSEHIP_H
+#define MUSEHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* mh_stream_t; /* hipStream_t */
+
+enum mh_status { MH_OK = 0, MH_ERR_INVALID = -1, MH_ERR_HIP = -2, MH_ERR_UNSUPPORTED = -3 };
+enum mh_dtype { MH_F32 = 0, MH_BF16 = 1 };
+enum mh_act { MH_ACT_NONE = 0, MH_ACT_TANH = 1, MH_ACT_GELU_ERF = 2, MH_ACT_SILU = 3 };
+
+const char* mh_last_error(void);
+int mh_abi_version(void);
+/* name of the device the library sees as device `ordinal` (diagnostics) */
+int mh_device_name(int ordinal, char* buf, int buflen);
+
+/* ------------------------------------------------------------------ layout / packing helpers */
+
+/* out[r, c] = (T) in[r, c] for r < rows, c < cols; zero elsewhere in the [rows_out, ld_out] image.
+ * Used to pack nn.Linear weights ([out,in] row-major, y = x W^T + b) into the weight
+ * arena with K padded to the GEMM tile depth, and to cast the fp32 latent to the compute dtype
+ * (models/network.py:141-144 input of input_up_proj). */
+int mh_cast_pad(const float* in, int64_t ld_in, void* out, int64_t ld_out, int64_t rows, int64_t cols,
+                int64_t rows_out, int dtype, mh_stream_t stream);
+
+/* out[r, c] = (float) in[r, c]: compute dtype -> fp32 (network.py:157 `h.type(x.dtype)` when E == H). */
+int mh_cast_to_f32(const void* in, int64_t ld_in, float* out, int64_t ld_out, int64_t rows, int64_t cols,
+                   int dtype, mh_stream_t stream);
+
+/* out[r] = sum_c table[r,c]^2  (rounding.py:22: emb_norm) */
+int mh_row_sqnorm(const float* table, float* out, int V, int E, mh_stream_t stream);
+
+/* ------------------------------------------------------------------ denoiser building blocks */
+
+/* K11  word_embedding(ids): out[n,:] = table[ids[n],:]   (models/network.py:88-89) */
+int mh_embed_gather(const float* table, const int32_t* ids, float* out, int64_t n_tokens, int E, int V,
+                    mh_stream_t stream);
+
+/* K1   sinusoidal timestep embedding, fractional t allowed: out[b] = [cos(t f) | sin(t f) | 0 pad]
+ *      f_i = exp(-ln(max_period) i / half)               (models/network.py:108-129)
+ *      out is [B, ld_out] of `dtype`, columns >= dim are zero-filled up to ld_out. */
+int mh_timestep_embedding(const float* t, void* out, int B, int dim, int64_t ld_out, float max_period,
+                          int dtype, mh_stream_t stream);
+
+/* K2/K3/K5/K7/K8/K9  out = act(A W^T + bias) [+ residual]   (nn.Linear sites: models/network.py:60-72,
+ *      :81-86 and the HF BertSelfAttention / BertSelfOutput / BertIntermediate / BertOutput dense
+ *      layers reached from network.py:151).
+ *      A [M, lda] and W [N, ldw] are `dtype`; K must be a multiple of 64 (bf16) / 16 (f32) and the
+ *      padded columns of A and W must be zero.  bias [N] fp32 or NULL.  residual [M, ldr] `dtype`
+ *      or NULL (added after the activation).  out is `dtype`, or fp32 when out_f32 != 0. */
+int mh_gemm_bias_act(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
+                     const void* residual, int64_t ldr, void* out, int64_t ldo, int out_f32,
+                     int64_t M, int N, int K, int act, int dtype, mh_stream_t stream);
+
+/* K5   fused Q/K/V projection: [q|k|v] = A Wqkv^T + bqkv with Wqkv = [Wq; Wk; Wv] ([3H, ldw]);
+ *      scatters heads: q,k -> [B, nh, L, dh], v -> TRANSPOSED [B, nh, dh, L] (the layout the
+ *      attention kernel's P.V product wants).  HF BertSelfAttention.{query,key,value} +
+ *      transpose_for_scores.  L must be a multiple of 8. */
+int mh_gemm_qkv(const void* A, int64_t lda, const void* Wqkv, int64_t ldw, const float* bqkv, void* q,
+                void* k, void* vt, int B, int L, int H, int nh, int dtype, mh_stream_t stream);
+
+/* K6   ctx = softmax(q k^T * scale) v, no mask (none is ever passed: diffusion.py:309, network.py:151),
+ *      flash-style (scores never materialised).  q,k [B,nh,L,dh], vt [B,nh,dh,L], ctx [B*L, ld_ctx]
+ *      with head h at columns [h*dh, (h+1)*dh).  dh in {32,64,128} (bf16) / {16,32,64,128} (f32). */
+int mh_attention_fwd(const void* q, const void* k, const void* vt, void* ctx, int64_t ld_ctx, int B, int L,
+                     int nh, int dh, float scale, int dtype, mh_stream_t stream);
+
+/* K7/K8 tail  out = LayerNorm(x) * gamma + beta over the last dim (eps 1e-12 in the reference,
+ *      network.py:79 and HF BertSelfOutput/BertOutput).  x, out [rows, H] `dtype`. */
+int mh_layernorm(const void* x, const float* gamma, const float* beta, void* out, int64_t rows, int H,
+                 float eps, int dtype, mh_stream_t stream);
+
+/* K4   out[b,l,:] = LayerNorm(pos[l,:] + x[b,l,:] + emb_t[emb_row[b],:])   (models/network.py:146-149)
+ *      x is `dtype` [B*L, ldx], or the fp32 latent itself when x_is_f32 (E == H: no up-projection).
+ *      pos [L,H] fp32, emb_t [*,H] fp32, emb_row [B] int32 (NULL: row b). */
+int mh_add_pos_time_layernorm(const void* x, int64_t ldx, int x_is_f32, const float* pos, const float* emb_t,
+                              const int32_t* emb_row, const float* gamma, const float* beta, void* out,
+                              int B, int L, int H, float eps, int dtype, mh_stream_t stream);
+
+/* ------------------------------------------------------------------ rounding / logits (always fp32) */
+
+/* K10  idx[n] = argmin_v clamp(|W_v|^2 + |x_n|^2 - 2 W_v.x_n, 0), first index on ties
+ *      (models/rounding.py:21-28).  table [V,E], table_norm [V] from mh_row_sqnorm. */
+int mh_round_to_embedding(const float* x, const float* table, const float* table_norm, int32_t* idx,
+                          int64_t n_tokens, int E, int V, mh_stream_t stream);
+
+/* K16  idx[n] = argmax_v (x_n . W_v + bias_v), first index on ties (run/sample.py:219-220 on
+ *      models/network.py:91-93). */
+int mh_logits_argmax(const float* x, const float* table, const float* bias, int32_t* idx, int64_t n_tokens,
+                     int E, int V, mh_stream_t stream);
+
+/* ------------------------------------------------------------------ diffusion arithmetic (fp32) */
+
+/* K15  out = where(mask == 0, x0, a[b] * x0 + s[b] * noise)       (models/diffusion.py:229-255)
+ *      a = sqrt_alphas_cumprod[t], s = sqrt_one_minus_alphas_cumprod[t] (host-extracted, [B] fp32).
+ *      mask is int32 per TOKEN [B*L] (mask_per_elem == 0) or per ELEMENT [B*L*E], or NULL. */
+int mh_q_sample(const float* x0, const float* noise, const float* a, const float* s, const int32_t* mask,
+                int mask_per_elem, float* out, int B, int64_t per_batch, int E, mh_stream_t stream);
+
+/* Per-step scalar coefficients of one reverse step, one struct per batch row or one shared row. */
+typedef struct mh_step_coef {
+  float coef1;      /* posterior_mean_coef1[t]                      (diffusion.py:265) */
+  float coef2;      /* posterior_mean_coef2[t]                      (diffusion.py:266) */
+  float sigma;      /* p_sample: (t != 0) * exp(0.5 * log_variance[t])   (diffusion.py:390-393)
+                       ddim:     (t != 0) * sigma_t                      (diffusion.py:732-747) */
+  float recip;      /* sqrt_recip_alphas_cumprod[t]                 (diffusion.py:203) */
+  float recipm1;    /* sqrt_recipm1_alphas_cumprod[t]               (diffusion.py:205) */
+  float sqrt_abp;   /* sqrt(alphas_cumprod_prev[t])                 (diffusion.py:740) */
+  float dir;        /* sqrt(1 - alphas_cumprod_prev[t] - sigma_t^2) (diffusion.py:741) */
+  float pad;
+} mh_step_coef;
+
+/* K10+K12  fused p_sample tail (models/diffusion.py:319-347, :390-397):
+ *      x0   = round_idx ? table[round_idx[n]] : model_out       (denoised_fn, rounding.py:45)
+ *      x0   = clip ? clamp(x0, -1, 1) : x0
+ *      mean = coef1 * x0 + coef2 * x_t
+ *      out  = mean + sigma * noise ;  out = where(mask == 0, x_start, out)
+ *      coef is [1] (coef_per_batch == 0) or [B].  pred_xstart / mean_out may be NULL.
+ *      out may alias x_t (in-place step). */
+int mh_p_sample_epilogue(const float* model_out, const float* x_t, const float* noise, const int32_t* round_idx,
+                         const float* table, const mh_step_coef* coef, int coef_per_batch, int clip,
+                         const int32_t* mask, int mask_per_elem, const float* x_start, float* out,
+                         float* pred_xstart, float* mean_out, int B, int64_t per_batch, int E,
+                         mh_stream_t stream);
+
+/* K10+K13  fused ddim_sample tail (models/diffusion.py:729-757):
+ *      eps  = (recip * x_t - x0) / recipm1
+ *      out  = x0 * sqrt_abp + dir * eps + sigma * noise ; anchoring as above. */
+int mh_ddim_epilogue(const float* model_out, const float* x_t, const float* noise, const int32_t* round_idx,
+                     const float* table, const mh_step_coef* coef, int coef_per_batch, int clip,
+                     const int32_t* mask, int mask_per_elem, const float* x_start, float* out,
+                     float* pred_xstart, int B, int64_t per_batch, int E, mh_stream_t stream);
+
+/* K14  truncated standard normal, counter-based (Philox4x32-10): element n of call (seed, stream_id,
+ *      *step_counter) is a pure function of those numbers, rejection (|z| > bound, bound <= 0: none)
+ *      is resolved per element in registers: no host sync (models/diffusion.py:378-388).
+ *      step_counter: device uint32 (may be NULL = 0); lets a captured graph advance the stream. */
+int mh_trunc_normal(float* out, int64_t n, float bound, uint64_t seed, uint32_t stream_id,
+                    const uint32_t* step_counter, mh_stream_t stream);
+
+/* ------------------------------------------------------------------ captured reverse step support */
+
+/* Device-side loop state of a replayed reverse-diffusion step.  `steps` holds the timestep index
+ * of every iteration in loop order (diffusion.py:508 / :878); pos advances once per replay. */
+typedef struct mh_loop_state {
+  uint32_t pos;        /* iteration counter (also the RNG step counter) */
+  uint32_t n_steps;
+  int32_t cur_t;       /* steps[pos], written by mh_step_begin */
+  uint32_t pad;
+} mh_loop_state;
+
+/* Reads state->pos, looks up t = steps[pos], writes state->cur_t, emb_row[0..B) = t and
+ * *cur_coef = coef_table[t].  First node of a captured step. */
+int mh_step_begin(mh_loop_state* state, const int32_t* steps, const mh_step_coef* coef_table,
+                  mh_step_coef* cur_coef, int32_t* emb_row, int B, mh_stream_t stream);
+/* state->pos += 1.  Last node of a captured step. */
+int mh_step_end(mh_loop_state* state, mh_stream_t stream);
+
+/* Thin hipGraph wrappers so the host can capture a sequence of the calls above on `stream` and
+ * replay it (hipStreamBeginCapture / EndCapture / GraphInstantiate / GraphLaunch). */
+/* A/B switch for the bf16 GEMM operand staging: 0 = register-staged, 1 = global_load_lds. */
+int mh_gemm_set_glds(int on);
+
+int mh_graph_begin_capture(mh_stream_t stream);
+int mh_graph_end_capture(mh_stream_t stream, void** graph_exec_out);
+int mh_graph_launch(void* graph_exec, mh_stream_t stream);
+int mh_graph_destroy(void* graph_exec);
+
+/* ------------------------------------------------------------------ whole denoiser forward */
+
+typedef struct mh_layer_weights {
+  const void* w_qkv;   const float* b_qkv;     /* [3H, H]  query/key/value stacked */
+  const void* w_ao;    const float* b_ao;      /* attention.output.dense [H, H] */
+  const float* ln1_g;  const float* ln1_b;     /* attention.output.LayerNorm */
+  const void* w_ff1;   const float* b_ff1;     /* intermediate.dense [F, H] */
+  const void* w_ff2;   const float* b_ff2;     /* output.dense [H, F] */
+  const float* ln2_g;  const float* ln2_b;     /* output.LayerNorm */
+} mh_layer_weights;
+
+typedef struct mh_denoiser {
+  int dtype;           /* mh_dtype of every `const void*` weight and of the activations */
+  int E, H, F, nh, nL, Tt, Tt_pad, T4_pad, E_pad, L_max;  /* *_pad: padded to a multiple of 64 */
+  int has_proj;        /* E != H: input_up_proj / output_down_proj present (network.py:67-72, :81-86) */
+  float ln_eps;
+  const void* w_t0;    const float* b_t0;      /* time_embed.0 [4Tt, Tt_pad] */
+  const void* w_t2;    const float* b_t2;      /* time_embed.2 [H, T4_pad] */
+  const void* w_up0;   const float* b_up0;     /* input_up_proj.0 [H, E_pad] */
+  const void* w_up2;   const float* b_up2;     /* input_up_proj.2 [H, H] */
+  const float* pos;                            /* position_embeddings [L_max, H] fp32 */
+  const float* ln0_g;  const float* ln0_b;     /* LayerNorm */
+  const void* w_dn0;   const float* b_dn0;     /* output_down_proj.0 [H, H] */
+  const void* w_dn2;   const float* b_dn2;     /* output_down_proj.2 [E, H] */
+  const mh_layer_weights* layers;              /* HOST array of nL entries */
+} mh_denoiser;
+
+/* bytes of scratch mh_denoiser_forward needs for a [B, L] batch */
+size_t mh_denoiser_workspace_bytes(const mh_denoiser* m, int B, int L);
+
+/* emb_t[b,:] = time_embed(timestep_embedding(t[b]))   (models/network.py:139).  out [B,H] fp32. */
+int mh_time_embed(const mh_denoiser* m, const float* t, float* emb_t_out, int B, void* workspace,
+                  size_t workspace_bytes, mh_stream_t stream);
+
+/* TransformerNetModel.forward (models/network.py:131-158) given emb_t rows:
+ *   x [B,L,E] fp32 -> out [B,L,E] fp32.  emb_t [*,H] fp32, emb_row [B] int32 or NULL (row b). */
+int mh_denoiser_forward(const mh_denoiser* m, const float* x, const float* emb_t, const int32_t* emb_row,
+                        float* out, int B, int L, void* workspace, size_t workspace_bytes,
+                        mh_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MUSEHIP_H */

@@ -1,0 +1,131 @@
+"""ctypes binding of libmusehip.so (C ABI: include/musehip.h).
+
+There is no fallback: `lib()` raises if the shared library is absent or does not export the
+symbols the header declares.  Build it with `python -c "import __graft_entry__ as g; g.build()"`
+or `make -C musediffusion_amd/csrc`.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libmusehip.so")
+
+MH_F32, MH_BF16 = 0, 1
+ACT_NONE, ACT_TANH, ACT_GELU_ERF, ACT_SILU = 0, 1, 2, 3
+
+c_i32p = C.POINTER(C.c_int32)
+c_f32p = C.POINTER(C.c_float)
+VP = C.c_void_p
+I64 = C.c_int64
+INT = C.c_int
+F32 = C.c_float
+
+
+class StepCoef(C.Structure):
+    """mh_step_coef"""
+    _fields_ = [("coef1", F32), ("coef2", F32), ("sigma", F32), ("recip", F32), ("recipm1", F32),
+                ("sqrt_abp", F32), ("dir", F32), ("pad", F32)]
+
+
+class LoopState(C.Structure):
+    """mh_loop_state"""
+    _fields_ = [("pos", C.c_uint32), ("n_steps", C.c_uint32), ("cur_t", C.c_int32), ("pad", C.c_uint32)]
+
+
+class LayerWeights(C.Structure):
+    """mh_layer_weights"""
+    _fields_ = [(n, VP) for n in ("w_qkv", "b_qkv", "w_ao", "b_ao", "ln1_g", "ln1_b", "w_ff1", "b_ff1",
+                                  "w_ff2", "b_ff2", "ln2_g", "ln2_b")]
+
+
+class Denoiser(C.Structure):
+    """mh_denoiser"""
+    _fields_ = ([("dtype", INT)] +
+                [(n, INT) for n in ("E", "H", "F", "nh", "nL", "Tt", "Tt_pad", "T4_pad", "E_pad", "L_max")] +
+                [("has_proj", INT), ("ln_eps", F32)] +
+                [(n, VP) for n in ("w_t0", "b_t0", "w_t2", "b_t2", "w_up0", "b_up0", "w_up2", "b_up2", "pos",
+                                   "ln0_g", "ln0_b", "w_dn0", "b_dn0", "w_dn2", "b_dn2")] +
+                [("layers", C.POINTER(LayerWeights))])
+
+
+# name -> (restype, argtypes); every symbol include/musehip.h declares
+SIGNATURES = {
+    "mh_last_error": (C.c_char_p, []),
+    "mh_abi_version": (INT, []),
+    "mh_device_name": (INT, [INT, C.c_char_p, INT]),
+    "mh_cast_pad": (INT, [VP, I64, VP, I64, I64, I64, I64, INT, VP]),
+    "mh_cast_to_f32": (INT, [VP, I64, VP, I64, I64, I64, INT, VP]),
+    "mh_row_sqnorm": (INT, [VP, VP, INT, INT, VP]),
+    "mh_embed_gather": (INT, [VP, VP, VP, I64, INT, INT, VP]),
+    "mh_timestep_embedding": (INT, [VP, VP, INT, INT, I64, F32, INT, VP]),
+    "mh_gemm_bias_act": (INT, [VP, I64, VP, I64, VP, VP, I64, VP, I64, INT, I64, INT, INT, INT, INT, VP]),
+    "mh_gemm_qkv": (INT, [VP, I64, VP, I64, VP, VP, VP, VP, INT, INT, INT, INT, INT, VP]),
+    "mh_attention_fwd": (INT, [VP, VP, VP, VP, I64, INT, INT, INT, INT, F32, INT, VP]),
+    "mh_layernorm": (INT, [VP, VP, VP, VP, I64, INT, F32, INT, VP]),
+    "mh_add_pos_time_layernorm": (INT, [VP, I64, INT, VP, VP, VP, VP, VP, VP, INT, INT, INT, F32, INT, VP]),
+    "mh_round_to_embedding": (INT, [VP, VP, VP, VP, I64, INT, INT, VP]),
+    "mh_logits_argmax": (INT, [VP, VP, VP, VP, I64, INT, INT, VP]),
+    "mh_q_sample": (INT, [VP, VP, VP, VP, VP, INT, VP, INT, I64, INT, VP]),
+    "mh_p_sample_epilogue": (INT, [VP, VP, VP, VP, VP, VP, INT, INT, VP, INT, VP, VP, VP, VP, INT, I64, INT, VP]),
+    "mh_ddim_epilogue": (INT, [VP, VP, VP, VP, VP, VP, INT, INT, VP, INT, VP, VP, VP, INT, I64, INT, VP]),
+    "mh_trunc_normal": (INT, [VP, I64, F32, C.c_uint64, C.c_uint32, VP, VP]),
+    "mh_step_begin": (INT, [VP, VP, VP, VP, VP, INT, VP]),
+    "mh_step_end": (INT, [VP, VP]),
+    "mh_gemm_set_glds": (INT, [INT]),
+    "mh_graph_begin_capture": (INT, [VP]),
+    "mh_graph_end_capture": (INT, [VP, C.POINTER(VP)]),
+    "mh_graph_launch": (INT, [VP, VP]),
+    "mh_graph_destroy": (INT, [VP]),
+    "mh_denoiser_workspace_bytes": (C.c_size_t, [C.POINTER(Denoiser), INT, INT]),
+    "mh_time_embed": (INT, [C.POINTER(Denoiser), VP, VP, INT, VP, C.c_size_t, VP]),
+    "mh_denoiser_forward": (INT, [C.POINTER(Denoiser), VP, VP, VP, VP, INT, INT, VP, C.c_size_t, VP]),
+}
+
+_lib = None
+
+
+class MuseHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """The loaded library (cached).  Raises MuseHipError when it cannot be loaded."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise MuseHipError(
+                "libmusehip.so not found at %s: the HIP kernels are the only compute path "
+                "(build with `make -C musediffusion_amd/csrc` or __graft_entry__.build())" % LIB_PATH)
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            try:
+                fn = getattr(handle, name)
+            except AttributeError:
+                raise MuseHipError("libmusehip.so does not export %s (stale build?)" % name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().mh_last_error()
+        raise MuseHipError("%s failed (%d): %s" % (what or "libmusehip call", rc, msg.decode() if msg else "?"))
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def current_stream():
+    import torch
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_device(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise MuseHipError("musediffusion_amd runs on the GPU only: got a %s tensor "
+                               "(move the model and inputs to cuda; there is no CPU path)" % t.device)

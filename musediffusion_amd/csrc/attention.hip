@@ -1,0 +1,387 @@
+// Unmasked multi-head self-attention, flash style (the L x L scores never reach memory).
+// Reference op group: HF BertSelfAttention reached from models/network.py:151 — no mask is ever
+// passed (diffusion.py:309 / :624 drop model_kwargs), attention runs over padding too.
+//
+// bf16 kernel (CDNA4): one workgroup = 4 waves = 128 queries of one (batch, head); each wave owns 32
+// queries and walks the keys in tiles of 64.
+//   S^T = K Q^T   v_mfma_f32_32x32x16_bf16 with A = K tile (LDS), B = Q (registers, loaded once):
+//                 the accumulator then has the QUERY on the lane and 16 keys in registers, so the
+//                 softmax row reduction is in-lane + one cross-half shuffle, and
+//   O^T += V^T P^T uses the bf16-converted S^T accumulator DIRECTLY as the B operand (no LDS round
+//                 trip, no transpose): registers 8s..8s+7 are k-step s, whose k order is
+//                 key = 16s + 8(j>>2) + 4h + (j&3).  The V^T tile in LDS is stored in exactly that
+//                 key order per 16-B chunk, so the A operand is one ds_read_b128.
+//   V arrives already transposed ([B,nh,dh,L]) from the QKV GEMM epilogue.
+//   LDS chunk swizzles (K: chunk ^ ((row / rows_per_256B) & (chunks-1)), V^T: chunk ^ ((d>>1)&7))
+//   make every ds_read_b128 fragment read conflict-free.  K/V tiles are double-buffered and
+//   register-staged (loads for tile t+1 are issued before the MFMAs of tile t).
+// f32 kernel: plain VALU fp32 (the f32 MFMA rate equals the VALU rate on gfx950), 64 queries per
+// workgroup, exact expf; this is the parity path, kept simple on purpose.
+#include "common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------ bf16 / MFMA
+template <int DH>
+__global__ __launch_bounds__(256) void attn_bf16_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K,
+                                                        const bf16* __restrict__ VT, bf16* __restrict__ ctx,
+                                                        int64_t ld_ctx, int L, int nh, float scale_log2e) {
+  constexpr int CH = DH / 8;            // 16-B chunks per K row
+  constexpr int RPB = 128 / DH;         // K rows per 256-B bank row (DH <= 128)
+  constexpr int KROWB = DH * 2;
+  constexpr int KT_BYTES = 64 * KROWB, VT_BYTES = DH * 128, BUF = KT_BYTES + VT_BYTES;
+  constexpr int KS = DH / 16;           // k-steps of QK^T
+  constexpr int DT = DH / 32;           // 32-row d tiles of O^T
+  constexpr int KCH = (64 * CH) / 256 > 0 ? (64 * CH) / 256 : 1;   // K chunks per thread
+  constexpr int VCH = DH / 32;          // V^T 16-B global chunks per thread
+  __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = lane >> 5, lq = lane & 31;
+  const int bh = blockIdx.y, b = bh / nh, head = bh % nh;
+  const int q0 = blockIdx.x * 128 + wave * 32;
+  const bf16* Qb = Q + (int64_t)bh * L * DH;
+  const bf16* Kb = K + (int64_t)bh * L * DH;
+  const bf16* Vb = VT + (int64_t)bh * DH * L;
+
+  // Q fragments (B operand): lane holds Q[q0+lq][16ks + 8h .. +8]
+  bf16x8 qf[KS];
+  {
+    int qr = q0 + lq; if (qr >= L) qr = L - 1;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(Qb + (int64_t)qr * DH + 16 * ks + 8 * h);
+  }
+
+  f32x16 o[DT];
+#pragma unroll
+  for (int i = 0; i < DT; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+
+  f32x4 stK[KCH], stV[VCH];
+  const int ntiles = (L + 63) / 64;
+
+  auto issue = [&](int t) {
+    const int k0 = t * 64;
+#pragma unroll
+    for (int j = 0; j < KCH; ++j) {
+      const int qd = tid + 256 * j;
+      if (qd < 64 * CH) {
+        const int row = qd / CH, c = qd % CH;
+        int kr = k0 + row; if (kr >= L) kr = L - 1;
+        stK[j] = *reinterpret_cast<const f32x4*>(Kb + (int64_t)kr * DH + c * 8);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < VCH; ++j) {
+      const int qd = tid + 256 * j, d = qd >> 3, c = qd & 7;
+      const int key = k0 + c * 8;
+      if (key < L) stV[j] = *reinterpret_cast<const f32x4*>(Vb + (int64_t)d * L + key);
+      else stV[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  auto commit = [&](int buf) {
+    char* kb = smem + buf * BUF;
+    char* vb = kb + KT_BYTES;
+#pragma unroll
+    for (int j = 0; j < KCH; ++j) {
+      const int qd = tid + 256 * j;
+      if (qd < 64 * CH) {
+        const int row = qd / CH, c = qd % CH;
+        *reinterpret_cast<f32x4*>(kb + row * KROWB + ((c ^ ((row / RPB) & (CH - 1))) << 4)) = stK[j];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < VCH; ++j) {
+      const int qd = tid + 256 * j, d = qd >> 3, c = qd & 7;
+      const int sblk = c >> 1, sw = (d >> 1) & 7, half = (c & 1) * 8;
+      // first 8 B (keys 8c..8c+3) -> chunk 2*sblk+0, second 8 B (keys 8c+4..8c+7) -> chunk 2*sblk+1
+      typedef __attribute__((ext_vector_type(2))) float f32x2;
+      f32x2 lo = {stV[j][0], stV[j][1]}, hi = {stV[j][2], stV[j][3]};
+      *reinterpret_cast<f32x2*>(vb + d * 128 + (((2 * sblk) ^ sw) << 4) + half) = lo;
+      *reinterpret_cast<f32x2*>(vb + d * 128 + (((2 * sblk + 1) ^ sw) << 4) + half) = hi;
+    }
+  };
+
+  issue(0);
+  commit(0);
+  __syncthreads();
+
+  for (int t = 0; t < ntiles; ++t) {
+    const int cur = t & 1;
+    if (t + 1 < ntiles) issue(t + 1);
+    const char* kb = smem + cur * BUF;
+    const char* vb = kb + KT_BYTES;
+
+    // ---- S^T tiles: [2 x 32 keys][32 queries]
+    f32x16 s[2];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
+      const int row = kt * 32 + lq;
+      const int sw = (row / RPB) & (CH - 1);
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kb + row * KROWB + (((2 * ks + h) ^ sw) << 4));
+        s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[kt], 0, 0, 0);
+      }
+    }
+    // ---- online softmax; register r of tile kt is key t*64 + kt*32 + (r&3) + 8(r>>2) + 4h
+    const int k0 = t * 64;
+    if (k0 + 64 > L) {
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (k0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h >= L) s[kt][r] = -INFINITY;
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kt][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * scale_log2e);
+    const float mb = m_new * scale_log2e;
+    float psum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float p = __builtin_amdgcn_exp2f(s[kt][r] * scale_log2e - mb);
+        s[kt][r] = p;
+        psum += p;
+      }
+    l_run = l_run * alpha + psum;
+    m_run = m_new;
+#pragma unroll
+    for (int i = 0; i < DT; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+
+    // ---- O^T += V^T P^T : k-step sp = 2kt + s2 takes registers 8*s2 .. 8*s2+7 of s[kt]
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        bf16x8 pf;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pf[j] = (bf16)s[kt][8 * s2 + j];
+        const int sp = 2 * kt + s2;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+          const int d = dt * 32 + lq;
+          const bf16x8 vf = *reinterpret_cast<const bf16x8*>(vb + d * 128 + (((2 * sp + h) ^ ((d >> 1) & 7)) << 4));
+          o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[dt], 0, 0, 0);
+        }
+      }
+    if (t + 1 < ntiles) commit(cur ^ 1);
+    __syncthreads();
+  }
+
+  // ---- normalise and store: lane holds query q0+lq, d = dt*32 + 8*(r>>2) + 4h + (r&3)
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = 1.0f / l_tot;
+  const int qr = q0 + lq;
+  if (qr < L) {
+    bf16* dst = ctx + ((int64_t)b * L + qr) * ld_ctx + head * DH;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        bf16x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (bf16)(o[dt][rg * 4 + e] * inv);
+        *reinterpret_cast<bf16x4*>(dst + dt * 32 + 8 * rg + 4 * h) = v;
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------ f32 / VALU
+// 256 threads = 16 (ty: 4 queries each) x 16 (tx: keys tx+16b for S, head dims tx+16i for O).
+template <int DH>
+__global__ __launch_bounds__(256) void attn_f32_kernel(const float* __restrict__ Q, const float* __restrict__ K,
+                                                       const float* __restrict__ VT, float* __restrict__ ctx,
+                                                       int64_t ld_ctx, int L, int nh, float scale) {
+  constexpr int QLD = DH + 4, PLD = 68, ND = (DH + 15) / 16;
+  extern __shared__ __attribute__((aligned(16))) char smem_dyn[];
+  float* Qs = reinterpret_cast<float*>(smem_dyn);          // [64][QLD]
+  float* Ks = Qs + 64 * QLD;                               // [64][QLD]
+  float* Vs = Ks + 64 * QLD;                               // [DH][PLD]   (V^T tile: [d][key])
+  float* Ps = Vs + DH * PLD;                               // [64][PLD]
+
+  const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+  const int bh = blockIdx.y, b = bh / nh, head = bh % nh;
+  const int q0 = blockIdx.x * 64;
+  const float* Qb = Q + (int64_t)bh * L * DH;
+  const float* Kb = K + (int64_t)bh * L * DH;
+  const float* Vb = VT + (int64_t)bh * DH * L;
+
+  for (int i = tid; i < 64 * (DH / 4); i += 256) {
+    const int row = i / (DH / 4), c = i % (DH / 4);
+    int qr = q0 + row; if (qr >= L) qr = L - 1;
+    *reinterpret_cast<f32x4*>(Qs + row * QLD + c * 4) = *reinterpret_cast<const f32x4*>(Qb + (int64_t)qr * DH + c * 4);
+  }
+  float o[4][ND];
+  float m_run[4], l_run[4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    m_run[a] = -INFINITY; l_run[a] = 0.f;
+#pragma unroll
+    for (int i = 0; i < ND; ++i) o[a][i] = 0.f;
+  }
+  const int ntiles = (L + 63) / 64;
+  for (int t = 0; t < ntiles; ++t) {
+    const int k0 = t * 64;
+    __syncthreads();  // previous tile fully consumed (also covers the Q load on t == 0)
+    for (int i = tid; i < 64 * (DH / 4); i += 256) {
+      const int row = i / (DH / 4), c = i % (DH / 4);
+      int kr = k0 + row; if (kr >= L) kr = L - 1;
+      *reinterpret_cast<f32x4*>(Ks + row * QLD + c * 4) = *reinterpret_cast<const f32x4*>(Kb + (int64_t)kr * DH + c * 4);
+    }
+    for (int i = tid; i < DH * 16; i += 256) {
+      const int d = i >> 4, c = i & 15;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (k0 + c * 4 < L) v = *reinterpret_cast<const f32x4*>(Vb + (int64_t)d * L + k0 + c * 4);
+      *reinterpret_cast<f32x4*>(Vs + d * PLD + c * 4) = v;
+    }
+    __syncthreads();
+    // scores: queries 4ty+a, keys tx+16b
+    float s[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int bb = 0; bb < 4; ++bb) s[a][bb] = 0.f;
+#pragma unroll 2
+    for (int d = 0; d < DH; d += 4) {
+      f32x4 qv[4], kv[4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) qv[a] = *reinterpret_cast<const f32x4*>(Qs + (4 * ty + a) * QLD + d);
+#pragma unroll
+      for (int bb = 0; bb < 4; ++bb) kv[bb] = *reinterpret_cast<const f32x4*>(Ks + (tx + 16 * bb) * QLD + d);
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int bb = 0; bb < 4; ++bb)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) s[a][bb] = fmaf(qv[a][e], kv[bb][e], s[a][bb]);
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      float mx = -INFINITY;
+#pragma unroll
+      for (int bb = 0; bb < 4; ++bb) {
+        s[a][bb] = (k0 + tx + 16 * bb < L) ? s[a][bb] * scale : -INFINITY;
+        mx = fmaxf(mx, s[a][bb]);
+      }
+#pragma unroll
+      for (int off = 8; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+      const float m_new = fmaxf(m_run[a], mx);
+      const float alpha = expf(m_run[a] - m_new);
+      float ps = 0.f;
+#pragma unroll
+      for (int bb = 0; bb < 4; ++bb) {
+        const float p = expf(s[a][bb] - m_new);
+        Ps[(4 * ty + a) * PLD + tx + 16 * bb] = p;
+        ps += p;
+      }
+#pragma unroll
+      for (int off = 8; off > 0; off >>= 1) ps += __shfl_xor(ps, off, 64);
+      l_run[a] = l_run[a] * alpha + ps;
+      m_run[a] = m_new;
+#pragma unroll
+      for (int i = 0; i < ND; ++i) o[a][i] *= alpha;
+    }
+    __syncthreads();
+#pragma unroll 2
+    for (int kk = 0; kk < 64; kk += 4) {
+      f32x4 pv[4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) pv[a] = *reinterpret_cast<const f32x4*>(Ps + (4 * ty + a) * PLD + kk);
+#pragma unroll
+      for (int i = 0; i < ND; ++i) {
+        const int d = tx + 16 * i;
+        if (d < DH) {
+          const f32x4 vv = *reinterpret_cast<const f32x4*>(Vs + d * PLD + kk);
+#pragma unroll
+          for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[a][i] = fmaf(pv[a][e], vv[e], o[a][i]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    const int qr = q0 + 4 * ty + a;
+    if (qr < L) {
+      const float inv = 1.0f / l_run[a];
+      float* dst = ctx + ((int64_t)b * L + qr) * ld_ctx + head * DH;
+#pragma unroll
+      for (int i = 0; i < ND; ++i) {
+        const int d = tx + 16 * i;
+        if (d < DH) dst[d] = o[a][i] * inv;
+      }
+    }
+  }
+}
+
+template <int DH>
+int launch_f32(const float* q, const float* k, const float* vt, float* ctx, int64_t ld, int B, int L, int nh,
+               float scale, hipStream_t s) {
+  constexpr size_t bytes = (size_t)(2 * 64 * (DH + 4) + DH * 68 + 64 * 68) * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    MH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_f32_kernel<DH>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    attr_set = true;
+  }
+  dim3 grid(ceil_div(L, 64), B * nh), block(256);
+  hipLaunchKernelGGL((attn_f32_kernel<DH>), grid, block, bytes, s, q, k, vt, ctx, ld, L, nh, scale);
+  MH_CHECK_LAUNCH();
+  return MH_OK;
+}
+
+template <int DH>
+int launch_bf16(const bf16* q, const bf16* k, const bf16* vt, bf16* ctx, int64_t ld, int B, int L, int nh,
+                float scale, hipStream_t s) {
+  dim3 grid(ceil_div(L, 128), B * nh), block(256);
+  hipLaunchKernelGGL((attn_bf16_kernel<DH>), grid, block, 0, s, q, k, vt, ctx, ld, L, nh,
+                     scale * 1.4426950408889634f);
+  MH_CHECK_LAUNCH();
+  return MH_OK;
+}
+
+}  // namespace
+
+extern "C" int mh_attention_fwd(const void* q, const void* k, const void* vt, void* ctx, int64_t ld_ctx, int B,
+                                int L, int nh, int dh, float scale, int dtype, mh_stream_t stream) {
+  MH_CHECK_ARG(q && k && vt && ctx, "attention: null pointer");
+  MH_CHECK_ARG(B > 0 && L > 0 && nh > 0, "attention: empty problem");
+  MH_CHECK_ARG(L % 8 == 0, "attention: seq_len %d must be a multiple of 8", L);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == MH_BF16) {
+    MH_CHECK_ARG(ld_ctx % 4 == 0, "attention(bf16): ld_ctx must be a multiple of 4");
+    const bf16 *Q = (const bf16*)q, *K = (const bf16*)k, *V = (const bf16*)vt;
+    switch (dh) {
+      case 32: return launch_bf16<32>(Q, K, V, (bf16*)ctx, ld_ctx, B, L, nh, scale, s);
+      case 64: return launch_bf16<64>(Q, K, V, (bf16*)ctx, ld_ctx, B, L, nh, scale, s);
+      case 128: return launch_bf16<128>(Q, K, V, (bf16*)ctx, ld_ctx, B, L, nh, scale, s);
+      default: mh_set_error("attention(bf16): head dim %d not in {32,64,128}", dh); return MH_ERR_UNSUPPORTED;
+    }
+  } else if (dtype == MH_F32) {
+    const float *Q = (const float*)q, *K = (const float*)k, *V = (const float*)vt;
+    switch (dh) {
+      case 16: return launch_f32<16>(Q, K, V, (float*)ctx, ld_ctx, B, L, nh, scale, s);
+      case 32: return launch_f32<32>(Q, K, V, (float*)ctx, ld_ctx, B, L, nh, scale, s);
+      case 64: return launch_f32<64>(Q, K, V, (float*)ctx, ld_ctx, B, L, nh, scale, s);
+      case 128: return launch_f32<128>(Q, K, V, (float*)ctx, ld_ctx, B, L, nh, scale, s);
+      default: mh_set_error("attention(f32): head dim %d not in {16,32,64,128}", dh); return MH_ERR_UNSUPPORTED;
+    }
+  }
+  mh_set_error("attention: unknown dtype %d", dtype);
+  return MH_ERR_INVALID;
+}

@@ -1,0 +1,328 @@
+// HBM-bound streaming kernels: packing / casts, embedding gather, timestep embedding, the fp32
+// diffusion arithmetic (q_sample, fused p_sample / ddim tails), the counter-based truncated-normal
+// generator and the device-side loop state of a captured reverse step.
+//
+// The diffusion arithmetic is written to be BIT-EXACT against the reference's fp32 torch ops given
+// identical inputs: every product and sum is rounded separately (FP contraction is switched off for
+// this file; torch never fuses a*b+c on CPU) and all per-step scalars arrive pre-computed by the
+// host with the same fp32 torch expressions the reference evaluates (models/diffusion.py:904-917).
+#include "common.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+constexpr int EW_BLOCK = 256;
+inline int ew_grid(int64_t n_items) {
+  int64_t b = (n_items + EW_BLOCK - 1) / EW_BLOCK;
+  return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b));  // grid-stride beyond 8192 blocks (32 per CU)
+}
+
+// ---------------------------------------------------------------- packing
+template <typename T>
+__global__ void cast_pad_kernel(const float* __restrict__ in, int64_t ld_in, T* __restrict__ out, int64_t ld_out,
+                                int64_t rows, int64_t cols, int64_t rows_out) {
+  const int64_t total = rows_out * ld_out;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / ld_out, c = i % ld_out;
+    const float v = (r < rows && c < cols) ? in[r * ld_in + c] : 0.f;
+    out[i] = from_f32<T>(v);
+  }
+}
+
+template <typename T>
+__global__ void cast_to_f32_kernel(const T* __restrict__ in, int64_t ld_in, float* __restrict__ out, int64_t ld_out,
+                                   int64_t rows, int64_t cols) {
+  const int64_t total = rows * cols;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / cols, c = i % cols;
+    out[r * ld_out + c] = to_f32(in[r * ld_in + c]);
+  }
+}
+
+__global__ void row_sqnorm_kernel(const float* __restrict__ table, float* __restrict__ out, int V, int E) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= V) return;
+  // sequential-in-lane then wave tree; rounding differs from torch's pairwise sum by O(1e-7) relative
+  float s = 0.f;
+  for (int c = lane; c < E; c += 64) {
+    const float v = table[(int64_t)row * E + c];
+    s += v * v;
+  }
+  s = wave_sum(s);
+  if (lane == 0) out[row] = s;
+}
+
+__global__ void embed_gather_kernel(const float* __restrict__ table, const int32_t* __restrict__ ids,
+                                    float* __restrict__ out, int64_t n_tokens, int E, int V) {
+  const int64_t total = n_tokens * E;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t n = i / E;
+    const int e = (int)(i % E);
+    int id = ids[n];
+    id = id < 0 ? 0 : (id >= V ? V - 1 : id);
+    out[i] = table[(int64_t)id * E + e];
+  }
+}
+
+template <typename T>
+__global__ void timestep_embedding_kernel(const float* __restrict__ t, T* __restrict__ out, int B, int dim,
+                                          int64_t ld_out, float neg_log_period) {
+  const int half = dim / 2;
+  const int64_t total = (int64_t)B * ld_out;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int b = (int)(i / ld_out), c = (int)(i % ld_out);
+    float v = 0.f;
+    if (c < 2 * half) {
+      const int k = c < half ? c : c - half;
+      // freqs = exp(-ln(max_period) * k / half), args = t * freqs   (network.py:119-125)
+      const float f = expf(neg_log_period * (float)k / (float)half);
+      const float a = t[b] * f;
+      v = c < half ? cosf(a) : sinf(a);
+    }
+    out[i] = from_f32<T>(v);
+  }
+}
+
+// ---------------------------------------------------------------- diffusion arithmetic
+__device__ __forceinline__ bool anchored(const int32_t* mask, int mask_per_elem, int64_t i, int E) {
+  if (!mask) return false;
+  return (mask_per_elem ? mask[i] : mask[i / E]) == 0;
+}
+
+__global__ void q_sample_kernel(const float* __restrict__ x0, const float* __restrict__ noise,
+                                const float* __restrict__ a, const float* __restrict__ s,
+                                const int32_t* __restrict__ mask, int mask_per_elem, float* __restrict__ out, int B,
+                                int64_t per_batch, int E) {
+  const int64_t total = (int64_t)B * per_batch;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int b = (int)(i / per_batch);
+    const float x = x0[i];
+    const float xt = a[b] * x + s[b] * noise[i];
+    out[i] = anchored(mask, mask_per_elem, i, E) ? x : xt;
+  }
+}
+
+template <bool DDIM>
+__global__ void step_epilogue_kernel(const float* __restrict__ model_out, const float* __restrict__ x_t,
+                                     const float* __restrict__ noise, const int32_t* __restrict__ round_idx,
+                                     const float* __restrict__ table, const mh_step_coef* __restrict__ coef,
+                                     int coef_per_batch, int clip, const int32_t* __restrict__ mask, int mask_per_elem,
+                                     const float* __restrict__ x_start, float* __restrict__ out,
+                                     float* __restrict__ pred_xstart, float* __restrict__ mean_out, int B,
+                                     int64_t per_batch, int E) {
+  const int64_t total = (int64_t)B * per_batch;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int b = (int)(i / per_batch);
+    const mh_step_coef c = coef[coef_per_batch ? b : 0];
+    float x0;
+    if (round_idx) x0 = table[(int64_t)round_idx[i / E] * E + (i % E)];
+    else x0 = model_out[i];
+    if (clip) x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
+    const float xt = x_t[i];
+    const float nz = noise ? noise[i] : 0.f;
+    float mean, sample;
+    if constexpr (DDIM) {
+      const float eps = (c.recip * xt - x0) / c.recipm1;
+      mean = x0 * c.sqrt_abp + c.dir * eps;
+      sample = mean + c.sigma * nz;
+    } else {
+      mean = c.coef1 * x0 + c.coef2 * xt;
+      sample = mean + c.sigma * nz;
+    }
+    if (anchored(mask, mask_per_elem, i, E)) sample = x_start[i];
+    if (pred_xstart) pred_xstart[i] = x0;
+    if (mean_out) mean_out[i] = mean;
+    out[i] = sample;
+  }
+}
+
+// ---------------------------------------------------------------- Philox4x32-10 truncated normal
+__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+  const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+  const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+  const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
+  const uint32_t n1 = (uint32_t)p1;
+  const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+  const uint32_t n3 = (uint32_t)p0;
+  c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+}
+__device__ __forceinline__ void philox10(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    philox_round(c, k0, k1);
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+}
+__device__ __forceinline__ float u01(uint32_t r) { return ((float)(r >> 8) + 0.5f) * (1.0f / 16777216.0f); }
+
+__global__ void trunc_normal_kernel(float* __restrict__ out, int64_t n, float bound, uint32_t seed_lo,
+                                    uint32_t seed_hi, uint32_t stream_id, const uint32_t* __restrict__ step_counter) {
+  const uint32_t step = step_counter ? *step_counter : 0u;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    float z = 0.f;
+    bool done = false;
+    for (uint32_t attempt = 0; attempt < 64 && !done; ++attempt) {
+      uint32_t c[4] = {(uint32_t)i, (uint32_t)(i >> 32), step, (stream_id << 8) | attempt};
+      philox10(c, seed_lo, seed_hi);
+      const float r0 = sqrtf(-2.0f * logf(u01(c[0]))), r1 = sqrtf(-2.0f * logf(u01(c[2])));
+      const float a0 = 6.283185307179586f * u01(c[1]), a1 = 6.283185307179586f * u01(c[3]);
+      const float cand[4] = {r0 * cosf(a0), r0 * sinf(a0), r1 * cosf(a1), r1 * sinf(a1)};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (!done && (bound <= 0.f || fabsf(cand[k]) <= bound)) {
+          z = cand[k];
+          done = true;
+        }
+      }
+    }
+    out[i] = z;  // 64 x 4 rejected candidates has probability < 1e-100 for bound >= 0.1
+  }
+}
+
+// ---------------------------------------------------------------- captured-step loop state
+__global__ void step_begin_kernel(mh_loop_state* state, const int32_t* __restrict__ steps,
+                                  const mh_step_coef* __restrict__ coef_table, mh_step_coef* cur_coef,
+                                  int32_t* emb_row, int B) {
+  uint32_t pos = state->pos;
+  if (pos >= state->n_steps) pos = state->n_steps - 1;
+  const int32_t t = steps[pos];
+  for (int b = threadIdx.x; b < B; b += blockDim.x) emb_row[b] = t;
+  if (threadIdx.x == 0) {
+    state->cur_t = t;
+    *cur_coef = coef_table[t];
+  }
+}
+__global__ void step_end_kernel(mh_loop_state* state) { state->pos += 1; }
+
+}  // namespace
+
+extern "C" int mh_cast_pad(const float* in, int64_t ld_in, void* out, int64_t ld_out, int64_t rows, int64_t cols,
+                           int64_t rows_out, int dtype, mh_stream_t stream) {
+  MH_CHECK_ARG(in && out, "cast_pad: null pointer");
+  MH_CHECK_ARG(rows >= 0 && cols >= 0 && rows_out >= rows && ld_out >= cols && ld_in >= cols, "cast_pad: bad shape");
+  if (rows_out * ld_out == 0) return MH_OK;
+  hipStream_t s = (hipStream_t)stream;
+  const int grid = ew_grid(rows_out * ld_out);
+  if (dtype == MH_BF16) hipLaunchKernelGGL((cast_pad_kernel<bf16>), dim3(grid), dim3(EW_BLOCK), 0, s, in, ld_in, (bf16*)out, ld_out, rows, cols, rows_out);
+  else if (dtype == MH_F32) hipLaunchKernelGGL((cast_pad_kernel<float>), dim3(grid), dim3(EW_BLOCK), 0, s, in, ld_in, (float*)out, ld_out, rows, cols, rows_out);
+  else { mh_set_error("cast_pad: unknown dtype %d", dtype); return MH_ERR_INVALID; }
+  MH_CHECK_LAUNCH();
+  return MH_OK;
+}
+
+extern "C" int mh_cast_to_f32(const void* in, int64_t ld_in, float* out, int64_t ld_out, int64_t rows, int64_t cols,
+                              int dtype, mh_stream_t stream) {
+  MH_CHECK_ARG(in && out && rows >= 0 && cols >= 0 && ld_in >= cols && ld_out >= cols, "cast_to_f32: bad arguments");
+  if (rows * cols == 0) return MH_OK;
+  hipStream_t s = (hipStream_t)stream;
+  const int grid = ew_grid(rows * cols);
+  if (dtype == MH_BF16) hipLaunchKernelGGL((cast_to_f32_kernel<bf16>), dim3(grid), dim3(EW_BLOCK), 0, s, (const bf16*)in, ld_in, out, ld_out, rows, cols);
+  else if (dtype == MH_F32) hipLaunchKernelGGL((cast_to_f32_kernel<float>), dim3(grid), dim3(EW_BLOCK), 0, s, (const float*)in, ld_in, out, ld_out, rows, cols);
+  else { mh_set_error("cast_to_f32: unknown dtype %d", dtype); return MH_ERR_INVALID; }
+  MH_CHECK_LAUNCH();
+  return MH_OK;
+}
+
+extern "C" int mh_row_sqnorm(const float* table, float* out, int V, int E, mh_stream_t stream) {
+  MH_CHECK_ARG(table && out && V > 0 && E > 0, "row_sqnorm: bad arguments");
+  hipLaunchKernelGGL(row_sqnorm_kernel, dim3((V + 3) / 4), dim3(256), 0, (hipStream_t)stream, table, out, V, E);
+  MH_CHECK_LAUNCH();
+  return MH_OK;
+}
+
+extern "C" int mh_embed_gather(const float* table, const int32_t* ids, float* out, int64_t n_tokens, int E, int V,
+                               mh_stream_t stream) {
+  MH_CHECK_ARG(table && ids && out, "embed_gather: null pointer");
+  MH_CHECK_ARG(n_tokens >= 0 && E > 0 && V > 0, "embed_gather: bad shape");
+  if (n_tokens == 0) return MH_OK;
+  hipLaunchKernelGGL(embed_gather_kernel, dim3(ew_grid(n_tokens * E)), dim3(EW_BLOCK), 0, (hipStream_t)stream, table,
+                     ids, out, n_tokens, E, V);
+  MH_CHECK_LAUNCH();
+  return MH_OK;
+}
+
+extern "C" int mh_timestep_embedding(const float* t, void* out, int B, int dim, int64_t ld_out, float max_period,
+                                     int dtype, mh_stream_t stream) {
+  MH_CHECK_ARG(t && out && B > 0 && dim > 0 && ld_out >= dim, "timestep_embedding: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  const float nlp = -logf(max_period);
+  const int grid = ew_grid((int64_t)B * ld_out);
+  if (dtype == MH_BF16) hipLaunchKernelGGL((timestep_embedding_kernel<bf16>), dim3(grid), dim3(EW_BLOCK), 0, s, t, (bf16*)out, B, dim, ld_out, nlp);
+  else if (dtype == MH_F32) hipLaunchKernelGGL((timestep_embedding_kernel<float>), dim3(grid), dim3(EW_BLOCK), 0, s, t, (float*)out, B, dim, ld_out, nlp);
+  else { mh_set_error("timestep_embedding: unknown dtype %d", dtype); return MH_ERR_INVALID; }
+  MH_CHECK_LAUNCH();
+  return MH_OK;
+}
+
+extern "C" int mh_q_sample(const float* x0, const float* noise, const float* a, const float* s, const int32_t* mask,
+                           int mask_per_elem, float* out, int B, int64_t per_batch, int E, mh_stream_t stream) {
+  MH_CHECK_ARG(x0 && noise && a && s && out, "q_sample: null pointer");
+  MH_CHECK_ARG(B > 0 && per_batch > 0 && E > 0 && per_batch % E == 0, "q_sample: bad shape");
+  hipLaunchKernelGGL(q_sample_kernel, dim3(ew_grid((int64_t)B * per_batch)), dim3(EW_BLOCK), 0, (hipStream_t)stream, x0,
+                     noise, a, s, mask, mask_per_elem, out, B, per_batch, E);
+  MH_CHECK_LAUNCH();
+  return MH_OK;
+}
+
+extern "C" int mh_p_sample_epilogue(const float* model_out, const float* x_t, const float* noise,
+                                    const int32_t* round_idx, const float* table, const mh_step_coef* coef,
+                                    int coef_per_batch, int clip, const int32_t* mask, int mask_per_elem,
+                                    const float* x_start, float* out, float* pred_xstart, float* mean_out, int B,
+                                    int64_t per_batch, int E, mh_stream_t stream) {
+  MH_CHECK_ARG(x_t && coef && out, "p_sample_epilogue: null pointer");
+  MH_CHECK_ARG(model_out || round_idx, "p_sample_epilogue: need model_out or round_idx");
+  MH_CHECK_ARG(!round_idx || table, "p_sample_epilogue: round_idx needs the embedding table");
+  MH_CHECK_ARG(!mask || x_start, "p_sample_epilogue: mask needs x_start");
+  MH_CHECK_ARG(B > 0 && per_batch > 0 && E > 0 && per_batch % E == 0, "p_sample_epilogue: bad shape");
+  hipLaunchKernelGGL((step_epilogue_kernel<false>), dim3(ew_grid((int64_t)B * per_batch)), dim3(EW_BLOCK), 0,
+                     (hipStream_t)stream, model_out, x_t, noise, round_idx, table, coef, coef_per_batch, clip, mask,
+                     mask_per_elem, x_start, out, pred_xstart, mean_out, B, per_batch, E);
+  MH_CHECK_LAUNCH();
+  return MH_OK;
+}
+
+extern "C" int mh_ddim_epilogue(const float* model_out, const float* x_t, const float* noise, const int32_t* round_idx,
+                                const float* table, const mh_step_coef* coef, int coef_per_batch, int clip,
+                                const int32_t* mask, int mask_per_elem, const float* x_start, float* out,
+                                float* pred_xstart, int B, int64_t per_batch, int E, mh_stream_t stream) {
+  MH_CHECK_ARG(x_t && coef && out, "ddim_epilogue: null pointer");
+  MH_CHECK_ARG(model_out || round_idx, "ddim_epilogue: need model_out or round_idx");
+  MH_CHECK_ARG(!round_idx || table, "ddim_epilogue: round_idx needs the embedding table");
+  MH_CHECK_ARG(!mask || x_start, "ddim_epilogue: mask needs x_start");
+  MH_CHECK_ARG(B > 0 && per_batch > 0 && E > 0 && per_batch % E == 0, "ddim_epilogue: bad shape");
+  hipLaunchKernelGGL((step_epilogue_kernel<true>), dim3(ew_grid((int64_t)B * per_batch)), dim3(EW_BLOCK), 0,
+                     (hipStream_t)stream, model_out, x_t, noise, round_idx, table, coef, coef_per_batch, clip, mask,
+                     mask_per_elem, x_start, out, pred_xstart, (float*)nullptr, B, per_batch, E);
+  MH_CHECK_LAUNCH();
+  return MH_OK;
+}
+
+extern "C" int mh_trunc_normal(float* out, int64_t n, float bound, uint64_t seed, uint32_t stream_id,
+                               const uint32_t* step_counter, mh_stream_t stream) {
+  MH_CHECK_ARG(out && n >= 0, "trunc_normal: bad arguments");
+  MH_CHECK_ARG(bound <= 0.f || bound >= 0.1f, "trunc_normal: bound %g too tight for rejection sampling", (double)bound);
+  if (n == 0) return MH_OK;
+  hipLaunchKernelGGL(trunc_normal_kernel, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, (hipStream_t)stream, out, n, bound,
+                     (uint32_t)seed, (uint32_t)(seed >> 32), stream_id, step_counter);
+  MH_CHECK_LAUNCH();
+  return MH_OK;
+}
+
+extern "C" int mh_step_begin(mh_loop_state* state, const int32_t* steps, const mh_step_coef* coef_table,
+                             mh_step_coef* cur_coef, int32_t* emb_row, int B, mh_stream_t stream) {
+  MH_CHECK_ARG(state && steps && coef_table && cur_coef && emb_row && B > 0, "step_begin: bad arguments");
+  hipLaunchKernelGGL(step_begin_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, state, steps, coef_table, cur_coef,
+                     emb_row, B);
+  MH_CHECK_LAUNCH();
+  return MH_OK;
+}
+
+extern "C" int mh_step_end(mh_loop_state* state, mh_stream_t stream) {
+  MH_CHECK_ARG(state, "step_end: null state");
+  hipLaunchKernelGGL(step_end_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, state);
+  MH_CHECK_LAUNCH();
+  return MH_OK;
+}

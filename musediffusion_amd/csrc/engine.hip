@@ -1,0 +1,183 @@
+// Library plumbing (errors, version, hipGraph wrappers) and the whole-denoiser forward:
+// TransformerNetModel.forward (models/network.py:131-158) as one stream-ordered sequence of the
+// kernels in this library.  No allocation, no synchronisation: safe to capture into a hipGraph.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "common.h"
+
+static thread_local char g_err[512] = "";
+
+void mh_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" const char* mh_last_error(void) { return g_err; }
+extern "C" int mh_abi_version(void) { return 1; }
+
+extern "C" int mh_device_name(int ordinal, char* buf, int buflen) {
+  MH_CHECK_ARG(buf && buflen > 0, "device_name: bad buffer");
+  hipDeviceProp_t p;
+  MH_HIP(hipGetDeviceProperties(&p, ordinal));
+  snprintf(buf, buflen, "%s|%s|cus=%d", p.name, p.gcnArchName, p.multiProcessorCount);
+  return MH_OK;
+}
+
+// ---------------------------------------------------------------- hipGraph wrappers
+extern "C" int mh_graph_begin_capture(mh_stream_t stream) {
+  MH_HIP(hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeThreadLocal));
+  return MH_OK;
+}
+extern "C" int mh_graph_end_capture(mh_stream_t stream, void** graph_exec_out) {
+  MH_CHECK_ARG(graph_exec_out, "graph_end_capture: null out pointer");
+  hipGraph_t graph = nullptr;
+  MH_HIP(hipStreamEndCapture((hipStream_t)stream, &graph));
+  hipGraphExec_t exec = nullptr;
+  hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+  hipGraphDestroy(graph);
+  if (e != hipSuccess) {
+    mh_set_error("hipGraphInstantiate: %s", hipGetErrorString(e));
+    return MH_ERR_HIP;
+  }
+  *graph_exec_out = (void*)exec;
+  return MH_OK;
+}
+extern "C" int mh_graph_launch(void* graph_exec, mh_stream_t stream) {
+  MH_CHECK_ARG(graph_exec, "graph_launch: null graph");
+  MH_HIP(hipGraphLaunch((hipGraphExec_t)graph_exec, (hipStream_t)stream));
+  return MH_OK;
+}
+extern "C" int mh_graph_destroy(void* graph_exec) {
+  if (graph_exec) MH_HIP(hipGraphExecDestroy((hipGraphExec_t)graph_exec));
+  return MH_OK;
+}
+
+// ---------------------------------------------------------------- denoiser forward
+namespace {
+
+inline size_t esize(int dtype) { return dtype == MH_BF16 ? 2 : 4; }
+inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+struct Workspace {
+  char *xin, *buf0, *buf1, *bufX, *bufX1, *q, *k, *vt, *ffn;
+  size_t total;
+};
+
+Workspace carve(const mh_denoiser* m, int B, int L, char* base) {
+  const size_t N = (size_t)B * L, es = esize(m->dtype);
+  Workspace w{};
+  size_t off = 0;
+  auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += align256(bytes); return p; };
+  w.xin = take(N * (size_t)m->E_pad * es);
+  w.buf0 = take(N * m->H * es);
+  w.buf1 = take(N * m->H * es);
+  w.bufX = take(N * m->H * es);
+  w.bufX1 = take(N * m->H * es);
+  w.q = take(N * m->H * es);
+  w.k = take(N * m->H * es);
+  w.vt = take(N * m->H * es + 256);  // slack: the last V^T row may be over-read by one 16-B chunk
+  w.ffn = take(N * (size_t)m->F * es);
+  w.total = off;
+  return w;
+}
+
+int check_model(const mh_denoiser* m) {
+  MH_CHECK_ARG(m, "denoiser: null descriptor");
+  MH_CHECK_ARG(m->dtype == MH_F32 || m->dtype == MH_BF16, "denoiser: unknown dtype %d", m->dtype);
+  MH_CHECK_ARG(m->H > 0 && m->H % 64 == 0 && m->H <= 2048, "denoiser: hidden size %d must be a multiple of 64, <= 2048", m->H);
+  MH_CHECK_ARG(m->F > 0 && m->F % 64 == 0, "denoiser: ffn size %d must be a multiple of 64", m->F);
+  MH_CHECK_ARG(m->nh > 0 && m->H % m->nh == 0, "denoiser: heads %d must divide hidden %d", m->nh, m->H);
+  MH_CHECK_ARG(m->E_pad % 64 == 0 && m->E_pad >= m->E && m->Tt_pad % 64 == 0 && m->Tt_pad >= m->Tt &&
+                   m->T4_pad % 64 == 0 && m->T4_pad >= 4 * m->Tt,
+               "denoiser: bad padded sizes");
+  MH_CHECK_ARG(m->has_proj == (m->E != m->H), "denoiser: has_proj must equal (E != H)");
+  MH_CHECK_ARG(m->layers || m->nL == 0, "denoiser: null layer table");
+  return MH_OK;
+}
+
+}  // namespace
+
+extern "C" size_t mh_denoiser_workspace_bytes(const mh_denoiser* m, int B, int L) {
+  if (!m || B <= 0 || L <= 0) return 0;
+  const size_t fwd = carve(m, B, L, nullptr).total;
+  const size_t te = align256((size_t)B * m->Tt_pad * 4) + align256((size_t)B * m->T4_pad * 4);
+  return fwd > te ? fwd : te;
+}
+
+extern "C" int mh_time_embed(const mh_denoiser* m, const float* t, float* emb_t_out, int B, void* workspace,
+                             size_t workspace_bytes, mh_stream_t stream) {
+  int rc = check_model(m);
+  if (rc) return rc;
+  MH_CHECK_ARG(t && emb_t_out && B > 0 && workspace, "time_embed: bad arguments");
+  const size_t es = esize(m->dtype);
+  const size_t need = align256((size_t)B * m->Tt_pad * es) + align256((size_t)B * m->T4_pad * es);
+  MH_CHECK_ARG(workspace_bytes >= need, "time_embed: workspace too small (%zu < %zu)", workspace_bytes, need);
+  char* sin_buf = (char*)workspace;
+  char* hid = sin_buf + align256((size_t)B * m->Tt_pad * es);
+  if ((rc = mh_timestep_embedding(t, sin_buf, B, m->Tt, m->Tt_pad, 10000.0f, m->dtype, stream))) return rc;
+  if (m->T4_pad != 4 * m->Tt) MH_HIP(hipMemsetAsync(hid, 0, (size_t)B * m->T4_pad * es, (hipStream_t)stream));
+  if ((rc = mh_gemm_bias_act(sin_buf, m->Tt_pad, m->w_t0, m->Tt_pad, m->b_t0, nullptr, 0, hid, m->T4_pad, 0, B,
+                             4 * m->Tt, m->Tt_pad, MH_ACT_SILU, m->dtype, stream)))
+    return rc;
+  return mh_gemm_bias_act(hid, m->T4_pad, m->w_t2, m->T4_pad, m->b_t2, nullptr, 0, emb_t_out, m->H, 1, B, m->H,
+                          m->T4_pad, MH_ACT_NONE, m->dtype, stream);
+}
+
+extern "C" int mh_denoiser_forward(const mh_denoiser* m, const float* x, const float* emb_t, const int32_t* emb_row,
+                                   float* out, int B, int L, void* workspace, size_t workspace_bytes,
+                                   mh_stream_t stream) {
+  int rc = check_model(m);
+  if (rc) return rc;
+  MH_CHECK_ARG(x && emb_t && out && workspace, "denoiser_forward: null pointer");
+  MH_CHECK_ARG(B > 0 && L > 0 && L <= m->L_max, "denoiser_forward: seq_len %d exceeds position table %d", L, m->L_max);
+  MH_CHECK_ARG(L % 8 == 0, "denoiser_forward: seq_len %d must be a multiple of 8", L);
+  const Workspace w = carve(m, B, L, (char*)workspace);
+  MH_CHECK_ARG(workspace_bytes >= w.total, "denoiser_forward: workspace too small (%zu < %zu)", workspace_bytes, w.total);
+  const int64_t N = (int64_t)B * L;
+  const int H = m->H, F = m->F, dt = m->dtype, dh = m->H / m->nh;
+  const float scale = 1.0f / sqrtf((float)dh);
+
+  // ---- embeddings: (up-projection) + position + time, LayerNorm          network.py:141-149
+  if (m->has_proj) {
+    if ((rc = mh_cast_pad(x, m->E, w.xin, m->E_pad, N, m->E, N, dt, stream))) return rc;
+    if ((rc = mh_gemm_bias_act(w.xin, m->E_pad, m->w_up0, m->E_pad, m->b_up0, nullptr, 0, w.buf0, H, 0, N, H, m->E_pad,
+                               MH_ACT_TANH, dt, stream)))
+      return rc;
+    if ((rc = mh_gemm_bias_act(w.buf0, H, m->w_up2, H, m->b_up2, nullptr, 0, w.buf1, H, 0, N, H, H, MH_ACT_NONE, dt,
+                               stream)))
+      return rc;
+    if ((rc = mh_add_pos_time_layernorm(w.buf1, H, 0, m->pos, emb_t, emb_row, m->ln0_g, m->ln0_b, w.bufX, B, L, H,
+                                        m->ln_eps, dt, stream)))
+      return rc;
+  } else {
+    if ((rc = mh_add_pos_time_layernorm(x, H, 1, m->pos, emb_t, emb_row, m->ln0_g, m->ln0_b, w.bufX, B, L, H, m->ln_eps,
+                                        dt, stream)))
+      return rc;
+  }
+  // ---- encoder layers (HF BertLayer, post-LN)                            network.py:151
+  for (int l = 0; l < m->nL; ++l) {
+    const mh_layer_weights& lw = m->layers[l];
+    if ((rc = mh_gemm_qkv(w.bufX, H, lw.w_qkv, H, lw.b_qkv, w.q, w.k, w.vt, B, L, H, m->nh, dt, stream))) return rc;
+    if ((rc = mh_attention_fwd(w.q, w.k, w.vt, w.buf0, H, B, L, m->nh, dh, scale, dt, stream))) return rc;
+    if ((rc = mh_gemm_bias_act(w.buf0, H, lw.w_ao, H, lw.b_ao, w.bufX, H, w.buf1, H, 0, N, H, H, MH_ACT_NONE, dt, stream)))
+      return rc;
+    if ((rc = mh_layernorm(w.buf1, lw.ln1_g, lw.ln1_b, w.bufX1, N, H, m->ln_eps, dt, stream))) return rc;
+    if ((rc = mh_gemm_bias_act(w.bufX1, H, lw.w_ff1, H, lw.b_ff1, nullptr, 0, w.ffn, F, 0, N, F, H, MH_ACT_GELU_ERF, dt,
+                               stream)))
+      return rc;
+    if ((rc = mh_gemm_bias_act(w.ffn, F, lw.w_ff2, F, lw.b_ff2, w.bufX1, H, w.buf1, H, 0, N, H, F, MH_ACT_NONE, dt, stream)))
+      return rc;
+    if ((rc = mh_layernorm(w.buf1, lw.ln2_g, lw.ln2_b, w.bufX, N, H, m->ln_eps, dt, stream))) return rc;
+  }
+  // ---- output down-projection                                            network.py:153-157
+  if (m->has_proj) {
+    if ((rc = mh_gemm_bias_act(w.bufX, H, m->w_dn0, H, m->b_dn0, nullptr, 0, w.buf0, H, 0, N, H, H, MH_ACT_TANH, dt, stream)))
+      return rc;
+    return mh_gemm_bias_act(w.buf0, H, m->w_dn2, H, m->b_dn2, nullptr, 0, out, m->E, 1, N, m->E, H, MH_ACT_NONE, dt, stream);
+  }
+  return mh_cast_to_f32(w.bufX, H, out, m->E, N, m->E, dt, stream);
+}

@@ -1,0 +1,173 @@
+"""Weight arena + denoiser engine: the host object behind TransformerNetModel.forward.
+
+The reference keeps ~200 separate fp32 parameter tensors and walks them through
+torch ops; here they are packed ONCE into one contiguous device arena laid out for the kernels
+(nn.Linear weights [out,in] cast to the compute dtype with K zero-padded to 64, Q/K/V stacked into one
+[3H,H] matrix, fp32 vectors as they are).  The arena is a single `torch.uint8` tensor, which also
+makes it the unit of the multi-GPU weight broadcast (one RCCL broadcast instead of the reference's
+per-tensor `sync_params`, utils/dist_util.py:141-152).
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib, ops
+from ._lib import MH_BF16, MH_F32, Denoiser, LayerWeights, check, current_stream, lib, ptr
+
+
+def _align(n, a=256):
+    return (n + a - 1) // a * a
+
+
+class DenoiserEngine:
+    """Packed weights + scratch for `mh_denoiser_forward` (models/network.py:131-158)."""
+
+    def __init__(self, cfg, dtype, device):
+        # cfg: dict(E, H, F, nh, nL, Tt, L_max)
+        self.cfg = dict(cfg)
+        self.dtype = ops.dtype_code(dtype)
+        self.device = torch.device(device)
+        self.es = 2 if self.dtype == MH_BF16 else 4
+        c = self.cfg
+        c["E_pad"], c["Tt_pad"], c["T4_pad"] = ops.pad64(c["E"]), ops.pad64(c["Tt"]), ops.pad64(4 * c["Tt"])
+        c["has_proj"] = int(c["E"] != c["H"])
+        self._plan = self._make_plan()
+        self.arena = torch.zeros(self._plan["total"], dtype=torch.uint8, device=self.device)
+        self._ws = None
+        self._layers = (LayerWeights * max(1, c["nL"]))()
+        self._desc = Denoiser()
+        self._fill_descriptor()
+
+    # ------------------------------------------------------------------ arena layout
+    def _make_plan(self):
+        c, es = self.cfg, self.es
+        H, F, E, Tt = c["H"], c["F"], c["E"], c["Tt"]
+        plan, off = {}, 0
+
+        def mat(name, rows, kpad):          # compute-dtype matrix [rows, kpad]
+            nonlocal off
+            plan[name] = ("mat", off, rows, kpad)
+            off = _align(off + rows * kpad * es)
+
+        def vec(name, n):                   # fp32 vector / table
+            nonlocal off
+            plan[name] = ("vec", off, n, 0)
+            off = _align(off + n * 4)
+
+        mat("w_t0", 4 * Tt, c["Tt_pad"]); vec("b_t0", 4 * Tt)
+        mat("w_t2", H, c["T4_pad"]); vec("b_t2", H)
+        if c["has_proj"]:
+            mat("w_up0", H, c["E_pad"]); vec("b_up0", H)
+            mat("w_up2", H, H); vec("b_up2", H)
+            mat("w_dn0", H, H); vec("b_dn0", H)
+            mat("w_dn2", E, H); vec("b_dn2", E)
+        vec("pos", c["L_max"] * H); vec("ln0_g", H); vec("ln0_b", H)
+        for l in range(c["nL"]):
+            p = "l%d." % l
+            mat(p + "w_qkv", 3 * H, H); vec(p + "b_qkv", 3 * H)
+            mat(p + "w_ao", H, H); vec(p + "b_ao", H)
+            vec(p + "ln1_g", H); vec(p + "ln1_b", H)
+            mat(p + "w_ff1", F, H); vec(p + "b_ff1", F)
+            mat(p + "w_ff2", H, F); vec(p + "b_ff2", H)
+            vec(p + "ln2_g", H); vec(p + "ln2_b", H)
+        plan["total"] = off
+        return plan
+
+    def _addr(self, name):
+        return self.arena.data_ptr() + self._plan[name][1]
+
+    def _fill_descriptor(self):
+        c, d = self.cfg, self._desc
+        d.dtype = self.dtype
+        for k in ("E", "H", "F", "nh", "nL", "Tt", "Tt_pad", "T4_pad", "E_pad", "L_max", "has_proj"):
+            setattr(d, k, int(c[k]))
+        d.ln_eps = 1e-12
+        for k in ("w_t0", "b_t0", "w_t2", "b_t2", "pos", "ln0_g", "ln0_b"):
+            setattr(d, k, self._addr(k))
+        for k in ("w_up0", "b_up0", "w_up2", "b_up2", "w_dn0", "b_dn0", "w_dn2", "b_dn2"):
+            setattr(d, k, self._addr(k) if c["has_proj"] else None)
+        for l in range(c["nL"]):
+            for k, _ in LayerWeights._fields_:
+                setattr(self._layers[l], k, self._addr("l%d.%s" % (l, k)))
+        d.layers = C.cast(self._layers, C.POINTER(LayerWeights))
+
+    # ------------------------------------------------------------------ packing
+    def _put_mat(self, name, w, row0=0):
+        _, off, rows, kpad = self._plan[name]
+        w = w.detach().to(self.device, torch.float32).contiguous()
+        r, k = w.shape
+        dst = self.arena.data_ptr() + off + row0 * kpad * self.es
+        check(lib().mh_cast_pad(ptr(w), k, dst, kpad, r, k, r, self.dtype, current_stream()), "mh_cast_pad")
+
+    def _put_vec(self, name, v, elem0=0):
+        _, off, n, _ = self._plan[name]
+        v = v.detach().to(self.device, torch.float32).reshape(-1)
+        view = self.arena[off + elem0 * 4: off + (elem0 + v.numel()) * 4].view(torch.float32)
+        view.copy_(v)
+
+    def load_state_dict(self, sd):
+        """Pack a reference-format state_dict (key names of SURVEY.md §3.4) into the arena."""
+        c = self.cfg
+        H = c["H"]
+        self._put_mat("w_t0", sd["time_embed.0.weight"]); self._put_vec("b_t0", sd["time_embed.0.bias"])
+        self._put_mat("w_t2", sd["time_embed.2.weight"]); self._put_vec("b_t2", sd["time_embed.2.bias"])
+        if c["has_proj"]:
+            self._put_mat("w_up0", sd["input_up_proj.0.weight"]); self._put_vec("b_up0", sd["input_up_proj.0.bias"])
+            self._put_mat("w_up2", sd["input_up_proj.2.weight"]); self._put_vec("b_up2", sd["input_up_proj.2.bias"])
+            self._put_mat("w_dn0", sd["output_down_proj.0.weight"]); self._put_vec("b_dn0", sd["output_down_proj.0.bias"])
+            self._put_mat("w_dn2", sd["output_down_proj.2.weight"]); self._put_vec("b_dn2", sd["output_down_proj.2.bias"])
+        self._put_vec("pos", sd["position_embeddings.weight"][: c["L_max"]])
+        self._put_vec("ln0_g", sd["LayerNorm.weight"]); self._put_vec("ln0_b", sd["LayerNorm.bias"])
+        for l in range(c["nL"]):
+            s, p = "input_transformers.layer.%d." % l, "l%d." % l
+            for i, nm in enumerate(("query", "key", "value")):
+                self._put_mat(p + "w_qkv", sd[s + "attention.self.%s.weight" % nm], row0=i * H)
+                self._put_vec(p + "b_qkv", sd[s + "attention.self.%s.bias" % nm], elem0=i * H)
+            self._put_mat(p + "w_ao", sd[s + "attention.output.dense.weight"])
+            self._put_vec(p + "b_ao", sd[s + "attention.output.dense.bias"])
+            self._put_vec(p + "ln1_g", sd[s + "attention.output.LayerNorm.weight"])
+            self._put_vec(p + "ln1_b", sd[s + "attention.output.LayerNorm.bias"])
+            self._put_mat(p + "w_ff1", sd[s + "intermediate.dense.weight"]); self._put_vec(p + "b_ff1", sd[s + "intermediate.dense.bias"])
+            self._put_mat(p + "w_ff2", sd[s + "output.dense.weight"]); self._put_vec(p + "b_ff2", sd[s + "output.dense.bias"])
+            self._put_vec(p + "ln2_g", sd[s + "output.LayerNorm.weight"])
+            self._put_vec(p + "ln2_b", sd[s + "output.LayerNorm.bias"])
+        return self
+
+    # ------------------------------------------------------------------ execution
+    def _workspace(self, B, L):
+        need = int(lib().mh_denoiser_workspace_bytes(C.byref(self._desc), B, L))
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def reserve(self, B, L):
+        """Allocate scratch up front (call before hipGraph capture: nothing may allocate inside)."""
+        self._workspace(B, L)
+        return self
+
+    def time_embed(self, t, out=None):
+        """emb_t = time_embed(timestep_embedding(t)) -> [B,H] fp32   (models/network.py:139)."""
+        t = t.to(self.device, torch.float32).contiguous()
+        B = t.numel()
+        out = torch.empty(B, self.cfg["H"], device=self.device, dtype=torch.float32) if out is None else out
+        ws = self._workspace(max(B, 1), 8)
+        check(lib().mh_time_embed(C.byref(self._desc), ptr(t), ptr(out), B, ptr(ws), ws.numel(), current_stream()),
+              "mh_time_embed")
+        return out
+
+    def forward(self, x, emb_t, emb_row=None, out=None):
+        """x [B,L,E] fp32 -> [B,L,E] fp32 (models/network.py:131-158).  emb_t [*,H] fp32,
+        emb_row [B] int32 selecting the emb_t row of each batch element (None: row b)."""
+        _lib.require_device(x, emb_t, emb_row)
+        B, L, E = x.shape
+        if E != self.cfg["E"]:
+            raise ValueError("latent width %d != model input_dims %d" % (E, self.cfg["E"]))
+        x = x.to(torch.float32).contiguous()
+        out = torch.empty_like(x) if out is None else out
+        ws = self._workspace(B, L)
+        check(lib().mh_denoiser_forward(C.byref(self._desc), ptr(x), ptr(emb_t), ptr(emb_row), ptr(out), B, L, ptr(ws),
+                                        ws.numel(), current_stream()), "mh_denoiser_forward")
+        return out
+
+    def arena_bytes(self):
+        return self.arena.numel()

@@ -1,0 +1,253 @@
+"""Kernel-level parity tests (GPU): every C-ABI entry point against a plain torch fp32 CPU
+reference of the same op (fp32 mode: tight tolerance; bf16 mode: inputs rounded to bf16 first,
+tolerance = bf16 output rounding).  Integer / index outputs are compared exactly."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from musediffusion_amd import ops  # noqa: E402
+from musediffusion_amd._lib import MH_BF16, MH_F32, lib  # noqa: E402
+
+DEV = "cuda"
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * scale
+
+
+def q(t, dtype):
+    """Round a CPU fp32 tensor the way the device storage type does."""
+    return t.bfloat16().float() if dtype == MH_BF16 else t
+
+
+def to_dev(t, dtype):
+    return t.to(DEV, ops.TORCH_DTYPE[dtype])
+
+
+def assert_close(got, ref, atol, rtol=0.0, what=""):
+    got = got.detach().float().cpu()
+    ref = ref.detach().float()
+    err = (got - ref).abs()
+    tol = atol + rtol * ref.abs()
+    bad = err > tol
+    if bad.any():
+        i = int(torch.argmax(err - tol))
+        raise AssertionError("%s: %d/%d elements off, max err %.3e at flat %d (got %.6f ref %.6f), ref absmax %.3e"
+                             % (what, int(bad.sum()), bad.numel(), float(err.max()), i,
+                                float(got.flatten()[i]), float(ref.flatten()[i]), float(ref.abs().max())))
+
+
+def test_library_sees_gfx950():
+    import ctypes
+    buf = ctypes.create_string_buffer(256)
+    assert lib().mh_device_name(0, buf, 256) == 0
+    assert b"gfx950" in buf.value, buf.value
+
+
+def test_cast_pad_and_norms():
+    x = rnd(37, 50, seed=1)
+    for dt in (MH_F32, MH_BF16):
+        out = ops.cast_pad(x.to(DEV), 64, dt, rows_out=40).float().cpu()
+        ref = torch.zeros(40, 64)
+        ref[:37, :50] = q(x, dt)
+        assert torch.equal(out, ref)
+    tbl = rnd(729, 128, seed=2)
+    assert_close(ops.row_sqnorm(tbl.to(DEV)), (tbl ** 2).sum(-1), 1e-4, what="row_sqnorm")
+
+
+def test_embed_gather_exact():
+    tbl = rnd(729, 32, seed=3)
+    ids = torch.randint(0, 729, (4, 24), generator=torch.Generator().manual_seed(4))
+    for idt in (torch.int32, torch.int64):
+        out = ops.embed_gather(tbl.to(DEV), ids.to(DEV, idt)).cpu()
+        assert torch.equal(out, tbl[ids])
+
+
+@pytest.mark.parametrize("dim", [128, 32, 33])
+def test_timestep_embedding(dim):
+    from oracle.denoiser import timestep_embedding
+    t = torch.tensor([0.0, 0.5, 3.0, 499.5, 999.5, 12.25])
+    ref = timestep_embedding(t, dim)
+    out = ops.timestep_embedding(t.to(DEV), dim, MH_F32, ld_out=ops.pad64(dim)).cpu()
+    assert_close(out[:, :dim], ref, 2e-4, what="timestep_embedding")  # |t f| up to 1e3: cos/sin arg ulp ~6e-5
+    assert torch.all(out[:, dim:] == 0)
+
+
+GEMM_CASES = [
+    # M, N, K, act, residual, out_f32
+    (200, 128, 64, None, False, False),
+    (128, 192, 128, "tanh", False, False),
+    (300, 64, 256, "gelu", False, False),
+    (77, 320, 64, "silu", False, False),
+    (256, 128, 512, None, True, False),
+    (130, 729, 128, None, False, True),     # ragged N, fp32 out with odd leading dimension
+    (64, 32, 64, None, False, True),        # N smaller than a tile (down-projection to E)
+    (1000, 512, 2048, None, True, False),
+]
+
+
+@pytest.mark.parametrize("dtype", [MH_F32, MH_BF16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("glds", [0, 1])
+@pytest.mark.parametrize("case", GEMM_CASES)
+def test_gemm_bias_act(case, dtype, glds):
+    M, N, K, act, use_res, out_f32 = case
+    if dtype == MH_F32 and glds:
+        pytest.skip("global_load_lds staging exists for bf16 only")
+    lib().mh_gemm_set_glds(glds)
+    try:
+        A = rnd(M, K, seed=10, scale=0.5)
+        W = rnd(N, K, seed=11, scale=1.0 / math.sqrt(K))
+        b = rnd(N, seed=12, scale=0.1)
+        R = rnd(M, N, seed=13) if use_res else None
+        ref = q(A, dtype) @ q(W, dtype).T + b
+        ref = {None: lambda v: v, "tanh": torch.tanh, "gelu": torch.nn.functional.gelu,
+               "silu": torch.nn.functional.silu}[act](ref)
+        if use_res:
+            ref = ref + q(R, dtype)
+        out = ops.gemm_bias_act(to_dev(A, dtype), to_dev(W, dtype), b.to(DEV), to_dev(R, dtype) if use_res else None,
+                                act, dtype, out_f32=out_f32)
+        atol = 2e-5 * max(1.0, math.sqrt(K) / 8) if dtype == MH_F32 else (2e-5 if out_f32 else 0.0)
+        rtol = 1e-5 if dtype == MH_F32 else (1e-4 if out_f32 else 2 ** -8)
+        if dtype == MH_BF16:
+            atol += 2e-3  # fp32 accumulation-order noise on top of the output rounding
+        assert_close(out, ref, atol, rtol, what="gemm %s" % (case,))
+    finally:
+        lib().mh_gemm_set_glds(0)
+
+
+@pytest.mark.parametrize("dtype", [MH_F32, MH_BF16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("shape", [(2, 16, 64, 4), (3, 136, 128, 4), (2, 128, 512, 8)])
+def test_gemm_qkv_layout(shape, dtype):
+    B, L, H, nh = shape
+    dh = H // nh
+    X = rnd(B * L, H, seed=20, scale=0.5)
+    W = rnd(3 * H, H, seed=21, scale=1.0 / math.sqrt(H))
+    b = rnd(3 * H, seed=22, scale=0.1)
+    ref = q(X, dtype) @ q(W, dtype).T + b
+    rq, rk, rv = (ref[:, i * H:(i + 1) * H].view(B, L, nh, dh).permute(0, 2, 1, 3) for i in range(3))
+    qd, kd, vt = ops.gemm_qkv(to_dev(X, dtype), to_dev(W, dtype), b.to(DEV), B, L, nh, dtype)
+    atol, rtol = (5e-5, 1e-5) if dtype == MH_F32 else (2e-3, 2 ** -8)
+    assert_close(qd, rq, atol, rtol, what="q")
+    assert_close(kd, rk, atol, rtol, what="k")
+    assert_close(vt, rv.transpose(-1, -2), atol, rtol, what="v^T")
+
+
+def _attn_ref(qh, kh, vh, scale):
+    s = (qh @ kh.transpose(-1, -2)) * scale
+    return torch.softmax(s, -1) @ vh
+
+
+@pytest.mark.parametrize("dtype,dh", [(MH_F32, 16), (MH_F32, 32), (MH_F32, 64), (MH_F32, 128),
+                                      (MH_BF16, 32), (MH_BF16, 64), (MH_BF16, 128)])
+@pytest.mark.parametrize("L", [64, 136, 512])
+def test_attention(dtype, dh, L):
+    B, nh = 2, 3
+    qh, kh, vh = (rnd(B, nh, L, dh, seed=30 + i) for i in range(3))
+    kh = kh * 1.5
+    kh[:, :, 5] *= 4.0  # a dominant key: exercises the running-max rescale
+    scale = 1.0 / math.sqrt(dh)
+    ref = _attn_ref(q(qh, dtype), q(kh, dtype), q(vh, dtype), scale).permute(0, 2, 1, 3).reshape(B * L, nh * dh)
+    vt = vh.transpose(-1, -2).contiguous()
+    vt_dev = torch.zeros(vt.numel() + 128, device=DEV, dtype=ops.TORCH_DTYPE[dtype])
+    vt_dev[: vt.numel()] = to_dev(vt, dtype).flatten()
+    out = ops.attention(to_dev(qh, dtype), to_dev(kh, dtype), vt_dev, scale, dtype)
+    atol = 2e-5 if dtype == MH_F32 else 2e-2   # bf16: P is rounded to bf16 before P.V
+    assert_close(out, ref, atol, what="attention dh=%d L=%d" % (dh, L))
+
+
+@pytest.mark.parametrize("dtype", [MH_F32, MH_BF16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("H", [64, 512, 768])
+def test_layernorm(H, dtype):
+    x = rnd(50, H, seed=40, scale=2.0) + 0.3
+    g, b = 1 + 0.1 * rnd(H, seed=41), 0.1 * rnd(H, seed=42)
+    ref = torch.nn.functional.layer_norm(q(x, dtype), (H,), g, b, 1e-12)
+    out = ops.layernorm(to_dev(x, dtype), g.to(DEV), b.to(DEV), 1e-12, dtype)
+    assert_close(out, ref, 5e-6 if dtype == MH_F32 else 0.0, 1e-6 if dtype == MH_F32 else 2 ** -8, what="layernorm")
+
+
+@pytest.mark.parametrize("dtype", [MH_F32, MH_BF16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("from_latent", [False, True])
+def test_add_pos_time_layernorm(dtype, from_latent):
+    B, L, H = 3, 24, 128
+    x = rnd(B * L, H, seed=43)
+    pos, emb = rnd(L, H, seed=44), rnd(7, H, seed=45)
+    rows = torch.tensor([6, 0, 3], dtype=torch.int32)
+    g, b = 1 + 0.1 * rnd(H, seed=46), 0.1 * rnd(H, seed=47)
+    xin = x if from_latent else q(x, dtype)
+    pre = (pos[None] + xin.view(B, L, H)) + emb[rows.long()][:, None]
+    ref = torch.nn.functional.layer_norm(pre, (H,), g, b, 1e-12).view(B * L, H)
+    xd = x.to(DEV) if from_latent else to_dev(x, dtype)
+    out = ops.add_pos_time_layernorm(xd, pos.to(DEV), emb.to(DEV), rows.to(DEV), g.to(DEV), b.to(DEV), B, L, 1e-12, dtype)
+    assert_close(out, ref, 5e-6 if dtype == MH_F32 else 0.0, 1e-6 if dtype == MH_F32 else 2 ** -8, what="add_pos_time_ln")
+    out2 = ops.add_pos_time_layernorm(xd, pos.to(DEV), emb[rows.long()].contiguous().to(DEV), None, g.to(DEV), b.to(DEV), B, L, 1e-12, dtype)
+    assert torch.equal(out2, out)
+
+
+@pytest.mark.parametrize("V,E", [(729, 128), (729, 32), (97, 64), (729, 500)])
+def test_rounding_and_logits_exact(V, E):
+    from oracle import sampling as osa
+    tbl = rnd(V, E, seed=50, scale=0.5)
+    ids = torch.randint(0, V, (700,), generator=torch.Generator().manual_seed(51))
+    x = tbl[ids] + 0.3 * rnd(700, E, seed=52)
+    ref_idx = osa.nearest_token(tbl, x)
+    got = ops.round_to_embedding(x.to(DEV), tbl.to(DEV)).cpu().long()
+    assert torch.equal(got, ref_idx), "rounding: %d mismatches" % int((got != ref_idx).sum())
+    bias = rnd(V, seed=53, scale=0.1)
+    ref_tok = torch.argmax(x @ tbl.T + bias, dim=-1)
+    got = ops.logits_argmax(x.to(DEV), tbl.to(DEV), bias.to(DEV)).cpu().long()
+    assert torch.equal(got, ref_tok), "logits argmax: %d mismatches" % int((got != ref_tok).sum())
+
+
+def test_rounding_ties_pick_first_index():
+    tbl = rnd(40, 16, seed=54)
+    tbl[17] = tbl[3]          # duplicate row: distance ties exactly
+    tbl[30] = tbl[3]
+    x = tbl[[3, 17, 30, 5]].clone()
+    got = ops.round_to_embedding(x.to(DEV), tbl.to(DEV)).cpu().tolist()
+    assert got == [3, 3, 3, 5]
+    bias = torch.zeros(40)
+    got = ops.logits_argmax(x.to(DEV), tbl.to(DEV), bias.to(DEV)).cpu()
+    ref = torch.argmax(x @ tbl.T, -1)
+    assert torch.equal(got.long(), ref)
+
+
+def test_q_sample_bit_exact():
+    from oracle import sampling as osa, schedule as osc
+    d = osc.make_diffusion()
+    B, L, E = 4, 16, 32
+    x0, nz = rnd(B, L, E, seed=60), rnd(B, L, E, seed=61)
+    t = torch.tensor([0, 5, 1000, 1999])
+    mask = (torch.arange(L)[None] >= torch.tensor([3, 0, 8, 16])[:, None]).long()
+    ref = osa.q_sample(d, x0, t, noise=nz, mask=mask)
+    a = torch.tensor(d.sqrt_alphas_cumprod, dtype=torch.float)[t]
+    s = torch.tensor(d.sqrt_one_minus_alphas_cumprod, dtype=torch.float)[t]
+    out = ops.q_sample(x0.to(DEV), nz.to(DEV), a.to(DEV), s.to(DEV), mask.to(DEV)).cpu()
+    assert torch.equal(out, ref)
+    mask3 = torch.broadcast_to(mask.unsqueeze(-1), x0.shape)
+    out = ops.q_sample(x0.to(DEV), nz.to(DEV), a.to(DEV), s.to(DEV), mask3.contiguous().to(DEV)).cpu()
+    assert torch.equal(out, ref)
+    out = ops.q_sample(x0.to(DEV), nz.to(DEV), a.to(DEV), s.to(DEV), None).cpu()
+    assert torch.equal(out, osa.q_sample(d, x0, t, noise=nz))
+
+
+def test_trunc_normal_statistics_and_determinism():
+    n = 1 << 20
+    a = ops.trunc_normal((n,), 1.0, seed=105, stream_id=3)
+    b = ops.trunc_normal((n,), 1.0, seed=105, stream_id=3)
+    c = ops.trunc_normal((n,), 1.0, seed=106, stream_id=3)
+    assert torch.equal(a, b) and not torch.equal(a, c)
+    assert float(a.abs().max()) <= 1.0
+    assert abs(float(a.mean())) < 3e-3
+    assert abs(float(a.var()) - 0.29112) < 3e-3      # Var[z | |z|<=1] = 1 - 2 phi(1) / (2 Phi(1) - 1)
+    u = ops.trunc_normal((n,), 0.0, seed=7)
+    assert abs(float(u.mean())) < 4e-3 and abs(float(u.var()) - 1.0) < 6e-3
+    assert abs(float((u.abs() > 1).float().mean()) - 0.3173) < 3e-3
+    ctr = torch.tensor([5], dtype=torch.int32, device=DEV)
+    s5 = ops.trunc_normal((4096,), 1.0, seed=1, step_counter=ctr)
+    ctr += 1
+    s6 = ops.trunc_normal((4096,), 1.0, seed=1, step_counter=ctr)
+    assert not torch.equal(s5, s6)
