@@ -96,6 +96,10 @@ def lib():
             raise MuseHipError(
                 "libmusehip.so not found at %s: the HIP kernels are the only compute path "
                 "(build with `make -C musediffusion_amd/csrc` or __graft_entry__.build())" % LIB_PATH)
+        # PyTorch-ROCm wheels bundle their own libamdhip64 (same SONAME as /opt/rocm's).  Import torch
+        # FIRST so the library's DT_NEEDED entry resolves to that already-loaded runtime: two HIP
+        # runtimes in one process do not share devices, streams or allocations.
+        import torch  # noqa: F401
         handle = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             try:

@@ -340,7 +340,7 @@ int launch_f32(const float* q, const float* k, const float* vt, float* ctx, int6
     attr_set = true;
   }
   dim3 grid(ceil_div(L, 64), B * nh), block(256);
-  hipLaunchKernelGGL((attn_f32_kernel<DH>), grid, block, bytes, s, q, k, vt, ctx, ld, L, nh, scale);
+  MH_LAUNCH((attn_f32_kernel<DH>), grid, block, bytes, s, q, k, vt, ctx, ld, L, nh, scale);
   MH_CHECK_LAUNCH();
   return MH_OK;
 }
@@ -349,7 +349,7 @@ template <int DH>
 int launch_bf16(const bf16* q, const bf16* k, const bf16* vt, bf16* ctx, int64_t ld, int B, int L, int nh,
                 float scale, hipStream_t s) {
   dim3 grid(ceil_div(L, 128), B * nh), block(256);
-  hipLaunchKernelGGL((attn_bf16_kernel<DH>), grid, block, 0, s, q, k, vt, ctx, ld, L, nh,
+  MH_LAUNCH((attn_bf16_kernel<DH>), grid, block, 0, s, q, k, vt, ctx, ld, L, nh,
                      scale * 1.4426950408889634f);
   MH_CHECK_LAUNCH();
   return MH_OK;

@@ -22,6 +22,13 @@ void mh_set_error(const char* fmt, ...);
       return MH_ERR_INVALID;           \
     }                                  \
   } while (0)
+// A launch site clears any stale (sticky) runtime error first so that the check after it reports
+// only this launch's status.
+#define MH_LAUNCH(...)                      \
+  do {                                      \
+    (void)hipGetLastError();                \
+    hipLaunchKernelGGL(__VA_ARGS__);        \
+  } while (0)
 #define MH_CHECK_LAUNCH()                                        \
   do {                                                           \
     hipError_t e__ = hipGetLastError();                          \

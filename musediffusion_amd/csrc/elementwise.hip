@@ -206,8 +206,8 @@ extern "C" int mh_cast_pad(const float* in, int64_t ld_in, void* out, int64_t ld
   if (rows_out * ld_out == 0) return MH_OK;
   hipStream_t s = (hipStream_t)stream;
   const int grid = ew_grid(rows_out * ld_out);
-  if (dtype == MH_BF16) hipLaunchKernelGGL((cast_pad_kernel<bf16>), dim3(grid), dim3(EW_BLOCK), 0, s, in, ld_in, (bf16*)out, ld_out, rows, cols, rows_out);
-  else if (dtype == MH_F32) hipLaunchKernelGGL((cast_pad_kernel<float>), dim3(grid), dim3(EW_BLOCK), 0, s, in, ld_in, (float*)out, ld_out, rows, cols, rows_out);
+  if (dtype == MH_BF16) MH_LAUNCH((cast_pad_kernel<bf16>), dim3(grid), dim3(EW_BLOCK), 0, s, in, ld_in, (bf16*)out, ld_out, rows, cols, rows_out);
+  else if (dtype == MH_F32) MH_LAUNCH((cast_pad_kernel<float>), dim3(grid), dim3(EW_BLOCK), 0, s, in, ld_in, (float*)out, ld_out, rows, cols, rows_out);
   else { mh_set_error("cast_pad: unknown dtype %d", dtype); return MH_ERR_INVALID; }
   MH_CHECK_LAUNCH();
   return MH_OK;
@@ -219,8 +219,8 @@ extern "C" int mh_cast_to_f32(const void* in, int64_t ld_in, float* out, int64_t
   if (rows * cols == 0) return MH_OK;
   hipStream_t s = (hipStream_t)stream;
   const int grid = ew_grid(rows * cols);
-  if (dtype == MH_BF16) hipLaunchKernelGGL((cast_to_f32_kernel<bf16>), dim3(grid), dim3(EW_BLOCK), 0, s, (const bf16*)in, ld_in, out, ld_out, rows, cols);
-  else if (dtype == MH_F32) hipLaunchKernelGGL((cast_to_f32_kernel<float>), dim3(grid), dim3(EW_BLOCK), 0, s, (const float*)in, ld_in, out, ld_out, rows, cols);
+  if (dtype == MH_BF16) MH_LAUNCH((cast_to_f32_kernel<bf16>), dim3(grid), dim3(EW_BLOCK), 0, s, (const bf16*)in, ld_in, out, ld_out, rows, cols);
+  else if (dtype == MH_F32) MH_LAUNCH((cast_to_f32_kernel<float>), dim3(grid), dim3(EW_BLOCK), 0, s, (const float*)in, ld_in, out, ld_out, rows, cols);
   else { mh_set_error("cast_to_f32: unknown dtype %d", dtype); return MH_ERR_INVALID; }
   MH_CHECK_LAUNCH();
   return MH_OK;
@@ -228,7 +228,7 @@ extern "C" int mh_cast_to_f32(const void* in, int64_t ld_in, float* out, int64_t
 
 extern "C" int mh_row_sqnorm(const float* table, float* out, int V, int E, mh_stream_t stream) {
   MH_CHECK_ARG(table && out && V > 0 && E > 0, "row_sqnorm: bad arguments");
-  hipLaunchKernelGGL(row_sqnorm_kernel, dim3((V + 3) / 4), dim3(256), 0, (hipStream_t)stream, table, out, V, E);
+  MH_LAUNCH(row_sqnorm_kernel, dim3((V + 3) / 4), dim3(256), 0, (hipStream_t)stream, table, out, V, E);
   MH_CHECK_LAUNCH();
   return MH_OK;
 }
@@ -238,7 +238,7 @@ extern "C" int mh_embed_gather(const float* table, const int32_t* ids, float* ou
   MH_CHECK_ARG(table && ids && out, "embed_gather: null pointer");
   MH_CHECK_ARG(n_tokens >= 0 && E > 0 && V > 0, "embed_gather: bad shape");
   if (n_tokens == 0) return MH_OK;
-  hipLaunchKernelGGL(embed_gather_kernel, dim3(ew_grid(n_tokens * E)), dim3(EW_BLOCK), 0, (hipStream_t)stream, table,
+  MH_LAUNCH(embed_gather_kernel, dim3(ew_grid(n_tokens * E)), dim3(EW_BLOCK), 0, (hipStream_t)stream, table,
                      ids, out, n_tokens, E, V);
   MH_CHECK_LAUNCH();
   return MH_OK;
@@ -250,8 +250,8 @@ extern "C" int mh_timestep_embedding(const float* t, void* out, int B, int dim, 
   hipStream_t s = (hipStream_t)stream;
   const float nlp = -logf(max_period);
   const int grid = ew_grid((int64_t)B * ld_out);
-  if (dtype == MH_BF16) hipLaunchKernelGGL((timestep_embedding_kernel<bf16>), dim3(grid), dim3(EW_BLOCK), 0, s, t, (bf16*)out, B, dim, ld_out, nlp);
-  else if (dtype == MH_F32) hipLaunchKernelGGL((timestep_embedding_kernel<float>), dim3(grid), dim3(EW_BLOCK), 0, s, t, (float*)out, B, dim, ld_out, nlp);
+  if (dtype == MH_BF16) MH_LAUNCH((timestep_embedding_kernel<bf16>), dim3(grid), dim3(EW_BLOCK), 0, s, t, (bf16*)out, B, dim, ld_out, nlp);
+  else if (dtype == MH_F32) MH_LAUNCH((timestep_embedding_kernel<float>), dim3(grid), dim3(EW_BLOCK), 0, s, t, (float*)out, B, dim, ld_out, nlp);
   else { mh_set_error("timestep_embedding: unknown dtype %d", dtype); return MH_ERR_INVALID; }
   MH_CHECK_LAUNCH();
   return MH_OK;
@@ -261,7 +261,7 @@ extern "C" int mh_q_sample(const float* x0, const float* noise, const float* a, 
                            int mask_per_elem, float* out, int B, int64_t per_batch, int E, mh_stream_t stream) {
   MH_CHECK_ARG(x0 && noise && a && s && out, "q_sample: null pointer");
   MH_CHECK_ARG(B > 0 && per_batch > 0 && E > 0 && per_batch % E == 0, "q_sample: bad shape");
-  hipLaunchKernelGGL(q_sample_kernel, dim3(ew_grid((int64_t)B * per_batch)), dim3(EW_BLOCK), 0, (hipStream_t)stream, x0,
+  MH_LAUNCH(q_sample_kernel, dim3(ew_grid((int64_t)B * per_batch)), dim3(EW_BLOCK), 0, (hipStream_t)stream, x0,
                      noise, a, s, mask, mask_per_elem, out, B, per_batch, E);
   MH_CHECK_LAUNCH();
   return MH_OK;
@@ -277,7 +277,7 @@ extern "C" int mh_p_sample_epilogue(const float* model_out, const float* x_t, co
   MH_CHECK_ARG(!round_idx || table, "p_sample_epilogue: round_idx needs the embedding table");
   MH_CHECK_ARG(!mask || x_start, "p_sample_epilogue: mask needs x_start");
   MH_CHECK_ARG(B > 0 && per_batch > 0 && E > 0 && per_batch % E == 0, "p_sample_epilogue: bad shape");
-  hipLaunchKernelGGL((step_epilogue_kernel<false>), dim3(ew_grid((int64_t)B * per_batch)), dim3(EW_BLOCK), 0,
+  MH_LAUNCH((step_epilogue_kernel<false>), dim3(ew_grid((int64_t)B * per_batch)), dim3(EW_BLOCK), 0,
                      (hipStream_t)stream, model_out, x_t, noise, round_idx, table, coef, coef_per_batch, clip, mask,
                      mask_per_elem, x_start, out, pred_xstart, mean_out, B, per_batch, E);
   MH_CHECK_LAUNCH();
@@ -293,7 +293,7 @@ extern "C" int mh_ddim_epilogue(const float* model_out, const float* x_t, const 
   MH_CHECK_ARG(!round_idx || table, "ddim_epilogue: round_idx needs the embedding table");
   MH_CHECK_ARG(!mask || x_start, "ddim_epilogue: mask needs x_start");
   MH_CHECK_ARG(B > 0 && per_batch > 0 && E > 0 && per_batch % E == 0, "ddim_epilogue: bad shape");
-  hipLaunchKernelGGL((step_epilogue_kernel<true>), dim3(ew_grid((int64_t)B * per_batch)), dim3(EW_BLOCK), 0,
+  MH_LAUNCH((step_epilogue_kernel<true>), dim3(ew_grid((int64_t)B * per_batch)), dim3(EW_BLOCK), 0,
                      (hipStream_t)stream, model_out, x_t, noise, round_idx, table, coef, coef_per_batch, clip, mask,
                      mask_per_elem, x_start, out, pred_xstart, (float*)nullptr, B, per_batch, E);
   MH_CHECK_LAUNCH();
@@ -305,7 +305,7 @@ extern "C" int mh_trunc_normal(float* out, int64_t n, float bound, uint64_t seed
   MH_CHECK_ARG(out && n >= 0, "trunc_normal: bad arguments");
   MH_CHECK_ARG(bound <= 0.f || bound >= 0.1f, "trunc_normal: bound %g too tight for rejection sampling", (double)bound);
   if (n == 0) return MH_OK;
-  hipLaunchKernelGGL(trunc_normal_kernel, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, (hipStream_t)stream, out, n, bound,
+  MH_LAUNCH(trunc_normal_kernel, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, (hipStream_t)stream, out, n, bound,
                      (uint32_t)seed, (uint32_t)(seed >> 32), stream_id, step_counter);
   MH_CHECK_LAUNCH();
   return MH_OK;
@@ -314,7 +314,7 @@ extern "C" int mh_trunc_normal(float* out, int64_t n, float bound, uint64_t seed
 extern "C" int mh_step_begin(mh_loop_state* state, const int32_t* steps, const mh_step_coef* coef_table,
                              mh_step_coef* cur_coef, int32_t* emb_row, int B, mh_stream_t stream) {
   MH_CHECK_ARG(state && steps && coef_table && cur_coef && emb_row && B > 0, "step_begin: bad arguments");
-  hipLaunchKernelGGL(step_begin_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, state, steps, coef_table, cur_coef,
+  MH_LAUNCH(step_begin_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, state, steps, coef_table, cur_coef,
                      emb_row, B);
   MH_CHECK_LAUNCH();
   return MH_OK;
@@ -322,7 +322,7 @@ extern "C" int mh_step_begin(mh_loop_state* state, const int32_t* steps, const m
 
 extern "C" int mh_step_end(mh_loop_state* state, mh_stream_t stream) {
   MH_CHECK_ARG(state, "step_end: null state");
-  hipLaunchKernelGGL(step_end_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, state);
+  MH_LAUNCH(step_end_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, state);
   MH_CHECK_LAUNCH();
   return MH_OK;
 }

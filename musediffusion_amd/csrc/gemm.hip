@@ -295,12 +295,12 @@ int launch(const GemmArgs& g, int dtype, hipStream_t s) {
   if (dtype == MH_BF16) {
     MH_CHECK_ARG(g.K % 64 == 0 && g.K > 0, "gemm(bf16): K=%d must be a positive multiple of 64", g.K);
     MH_CHECK_ARG(g.lda % 8 == 0 && g.ldw % 8 == 0, "gemm(bf16): lda/ldw must be multiples of 8");
-    if (g_use_glds) hipLaunchKernelGGL((gemm_kernel<bf16, EPI, 1>), grid, block, 0, s, g);
-    else hipLaunchKernelGGL((gemm_kernel<bf16, EPI, 0>), grid, block, 0, s, g);
+    if (g_use_glds) MH_LAUNCH((gemm_kernel<bf16, EPI, 1>), grid, block, 0, s, g);
+    else MH_LAUNCH((gemm_kernel<bf16, EPI, 0>), grid, block, 0, s, g);
   } else if (dtype == MH_F32) {
     MH_CHECK_ARG(g.K % 16 == 0 && g.K > 0, "gemm(f32): K=%d must be a positive multiple of 16", g.K);
     MH_CHECK_ARG(g.lda % 4 == 0 && g.ldw % 4 == 0, "gemm(f32): lda/ldw must be multiples of 4");
-    hipLaunchKernelGGL((gemm_kernel<float, EPI, 0>), grid, block, 0, s, g);
+    MH_LAUNCH((gemm_kernel<float, EPI, 0>), grid, block, 0, s, g);
   } else {
     MH_CHECK_ARG(false, "gemm: unknown dtype %d", dtype);
   }

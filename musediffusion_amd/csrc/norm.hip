@@ -81,10 +81,10 @@ int launch_ln(const void* x, int64_t ldx, const float* xf32, const float* pos, c
               float eps, bool add, hipStream_t s) {
   dim3 grid((unsigned)((rows + 3) / 4)), block(256);
   if (add)
-    hipLaunchKernelGGL((ln_kernel<T, true>), grid, block, 0, s, (const T*)x, ldx, xf32, pos, emb_t, emb_row, gamma,
+    MH_LAUNCH((ln_kernel<T, true>), grid, block, 0, s, (const T*)x, ldx, xf32, pos, emb_t, emb_row, gamma,
                        beta, (T*)out, rows, L, H, eps);
   else
-    hipLaunchKernelGGL((ln_kernel<T, false>), grid, block, 0, s, (const T*)x, ldx, xf32, pos, emb_t, emb_row, gamma,
+    MH_LAUNCH((ln_kernel<T, false>), grid, block, 0, s, (const T*)x, ldx, xf32, pos, emb_t, emb_row, gamma,
                        beta, (T*)out, rows, L, H, eps);
   MH_CHECK_LAUNCH();
   return MH_OK;

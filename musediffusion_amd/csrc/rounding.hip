@@ -118,7 +118,7 @@ extern "C" int mh_round_to_embedding(const float* x, const float* table, const f
                                      int64_t n_tokens, int E, int V, mh_stream_t stream) {
   MH_CHECK_ARG(x && table && table_norm && idx, "round_to_embedding: null pointer");
   MH_CHECK_ARG(n_tokens > 0 && E > 0 && V > 0, "round_to_embedding: bad shape");
-  hipLaunchKernelGGL((vocab_argmax_kernel<0>), dim3((unsigned)((n_tokens + 63) / 64)), dim3(256), 0,
+  MH_LAUNCH((vocab_argmax_kernel<0>), dim3((unsigned)((n_tokens + 63) / 64)), dim3(256), 0,
                      (hipStream_t)stream, x, table, table_norm, idx, n_tokens, E, V);
   MH_CHECK_LAUNCH();
   return MH_OK;
@@ -128,7 +128,7 @@ extern "C" int mh_logits_argmax(const float* x, const float* table, const float*
                                 int E, int V, mh_stream_t stream) {
   MH_CHECK_ARG(x && table && bias && idx, "logits_argmax: null pointer");
   MH_CHECK_ARG(n_tokens > 0 && E > 0 && V > 0, "logits_argmax: bad shape");
-  hipLaunchKernelGGL((vocab_argmax_kernel<1>), dim3((unsigned)((n_tokens + 63) / 64)), dim3(256), 0,
+  MH_LAUNCH((vocab_argmax_kernel<1>), dim3((unsigned)((n_tokens + 63) / 64)), dim3(256), 0,
                      (hipStream_t)stream, x, table, bias, idx, n_tokens, E, V);
   MH_CHECK_LAUNCH();
   return MH_OK;

@@ -161,6 +161,8 @@ def _mask_args(mask, x):
     """mask -> (int32 tensor, per_elem flag).  Accepts [B,L] (per token) or x-shaped (per element)."""
     if mask is None:
         return None, 0
+    if mask.dim() == x.dim() and mask.shape == x.shape and mask.stride(-1) == 0:
+        mask = mask[..., 0]  # broadcast view of a per-token mask (run/sample.py:186): keep it per token
     m = _c(mask, torch.int32)
     if m.numel() == x.numel():
         return m, 1

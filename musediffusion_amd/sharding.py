@@ -1,0 +1,65 @@
+"""Multi-GPU plumbing of the sampling path: one process per GPU, torch.distributed over RCCL.
+
+The path shards over independent sequences: the reference round-robins whole
+batches over ranks and has every rank load the checkpoint itself (run/sample.py:85, :169).  Here
+rank `src` owns the weights and ONE flat-buffer broadcast distributes them (instead of ~200
+per-tensor broadcasts, utils/dist_util.py:141-152); each rank then samples its contiguous slice of
+the batch with no per-step communication, and the int tokens are all-gathered once at the end
+(replacing the per-rank broadcast+barrier loop at run/sample.py:222-291).
+"""
+import torch
+import torch.distributed as dist
+
+
+def world():
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def rank():
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
+def broadcast_weights(model, src=0):
+    """Make every rank's parameters equal rank `src`'s with a single broadcast of one flat buffer."""
+    if world() == 1:
+        return model
+    params = [p.data for p in model.parameters()]
+    flat = torch.cat([p.reshape(-1) for p in params])
+    dist.broadcast(flat, src=src)
+    off = 0
+    for p in params:
+        n = p.numel()
+        p.copy_(flat[off:off + n].view_as(p))
+        off += n
+    return model
+
+
+def shard_bounds(n, r=None, w=None):
+    """Contiguous slice [lo, hi) of n items owned by rank r of w (remainder spread over the first ranks)."""
+    r = rank() if r is None else r
+    w = world() if w is None else w
+    base, extra = divmod(n, w)
+    lo = r * base + min(r, extra)
+    return lo, lo + base + (1 if r < extra else 0)
+
+
+def shard_batch(batch, r=None, w=None):
+    """Slice every [B, ...] tensor of a model_kwargs batch to this rank's rows."""
+    n = next(iter(batch.values())).shape[0]
+    lo, hi = shard_bounds(n, r, w)
+    return {k: v[lo:hi] for k, v in batch.items()}
+
+
+def gather_rows(local, total_rows):
+    """All-gather row shards produced under `shard_bounds` back into one [total_rows, ...] tensor
+    (ragged shards are padded to the largest one for the collective)."""
+    w = world()
+    if w == 1:
+        return local
+    sizes = [shard_bounds(total_rows, r, w) for r in range(w)]
+    max_rows = max(hi - lo for lo, hi in sizes)
+    pad = torch.zeros((max_rows,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[: local.shape[0]] = local
+    parts = [torch.empty_like(pad) for _ in range(w)]
+    dist.all_gather(parts, pad)
+    return torch.cat([p[: hi - lo] for p, (lo, hi) in zip(parts, sizes)], dim=0)

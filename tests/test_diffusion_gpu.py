@@ -1,0 +1,260 @@
+"""Sampling-path parity (GPU): TransformerNetModel + SpacedDiffusion of the product against the
+reference's recorded outputs (tests/golden/model_*.npz, made by tools/make_golden.py) and the
+CPU oracle, with the oracle's noise draws injected.
+
+Tolerances (fp32 compute mode, `compute_dtype="fp32"`):
+  * model output / un-rounded samples: 2e-4 abs (fp32 reductions in a different order than MKL)
+  * rounded quantities (pred_xstart, rounded loops' final latents): the rounding snaps to embedding
+    rows, so they are compared bit-exactly wherever the token decision agrees — and the token
+    decisions (rounding indices, final argmax tokens) must agree EXACTLY.
+bf16 compute mode: final-token agreement rate is asserted (>= 99%), not exactness."""
+from functools import partial
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from conftest import load_golden  # noqa: E402
+from musediffusion_amd.models.diffusion import SpacedDiffusion, get_named_beta_schedule, space_timesteps  # noqa: E402
+from musediffusion_amd.models.network import TransformerNetModel  # noqa: E402
+from musediffusion_amd.models.rounding import denoised_fn_round, get_efficient_knn  # noqa: E402
+from oracle import fixtures as fx  # noqa: E402
+from oracle import sampling as osa  # noqa: E402
+
+DEV = "cuda"
+
+
+def build(tag, compute_dtype="fp32"):
+    c = fx.CONFIGS[tag]
+    m = TransformerNetModel(c["E"], c["E"], c["Tt"], c["V"], c["L"], dropout=0.0, bert_hidden=c["H"],
+                            bert_layers=c["nL"], bert_heads=c["nh"], bert_ffn=c["F"], compute_dtype=compute_dtype)
+    sd = fx.state_dict(tag)
+    m.load_state_dict(sd)
+    m.eval().requires_grad_(False).to(DEV)
+    diff = SpacedDiffusion(use_timesteps=space_timesteps(2000, [2000]), betas=get_named_beta_schedule("sqrt", 2000),
+                           rescale_timesteps=True, predict_xstart=True)
+    model_emb = torch.nn.Embedding(c["V"], c["E"], _weight=m.word_embedding.weight.clone()).eval().requires_grad_(False)
+    inp = fx.case_inputs(tag, sd["word_embedding.weight"])
+    return m, diff, model_emb, inp, c
+
+
+def G(g, name):
+    return torch.from_numpy(g[name])
+
+
+def sub(t, tag):
+    t = t.detach().float().cpu()
+    return t[:, ::8] if (tag == "c1" and t.dim() == 3) else t
+
+
+def maxerr(a, b):
+    return float((a - b).abs().max())
+
+
+def step_noise(seed, shape, top_p):
+    torch.manual_seed(seed)
+    z = torch.zeros(shape)
+    return osa.truncated_noise(z, top_p) if top_p else torch.randn_like(z)
+
+
+def loop_noises(seed, shape, n, top_p):
+    torch.manual_seed(seed)
+    z = torch.zeros(shape)
+    return [osa.truncated_noise(z, top_p) if top_p else torch.randn_like(z) for _ in range(n)]
+
+
+@pytest.mark.parametrize("tag", ["tiny", "same", "c1"])
+def test_model_surface(tag):
+    m, diff, model_emb, inp, c = build(tag)
+    g = load_golden("model_%s.npz" % tag)
+    y = m(inp["fwd_x"].to(DEV), inp["fwd_t"].to(DEV), input_ids="ignored", anything_else=1)   # **_ is dropped
+    assert maxerr(sub(y, tag), G(g, "fwd_y")) < 1e-4
+    ids = inp["batch"]["correct_ids"]
+    assert torch.equal(m.get_embeds(ids.to(DEV)).cpu(), inp["x_start"])
+    assert torch.equal(m.get_embeds(ids.int().to(DEV)).cpu(), inp["x_start"])
+    logits = m.get_logits(y)
+    assert logits.shape == (c["B"], c["L"], c["V"])
+    assert maxerr(sub(logits, tag), G(g, "logits")) < 5e-4
+    assert torch.equal(m.argmax_tokens(y).cpu(), logits.argmax(-1).cpu())
+    emb = TransformerNetModel.timestep_embedding(inp["fwd_t"].to(DEV), c["Tt"])
+    from oracle.denoiser import timestep_embedding
+    assert maxerr(emb.cpu(), timestep_embedding(inp["fwd_t"], c["Tt"])) < 2e-4
+    # rounding entry points
+    r = denoised_fn_round(model_emb.to(DEV), inp["round_in"].to(DEV), None)
+    assert torch.equal(sub(r, tag), G(g, "round_out"))
+    vals, idx = get_efficient_knn(model_emb.weight.to(DEV), inp["round_in"].to(DEV).reshape(-1, c["E"]))
+    assert idx.shape[0] == 1 and torch.equal(idx[0].cpu(), G(g, "round_idx").long())
+
+
+@pytest.mark.parametrize("tag", ["tiny", "same", "c1"])
+def test_start_latents_and_q_sample_bit_exact(tag):
+    m, diff, model_emb, inp, c = build(tag)
+    g = load_golden("model_%s.npz" % tag)
+    x_start = inp["x_start"].to(DEV)
+    mask3 = inp["mask3"].to(DEV)
+    B = c["B"]
+    tt = torch.full((B, 1), fx.NOISING_T - 1, device=DEV)
+    x_mod = diff.q_sample(x_start.unsqueeze(-1), tt, noise=inp["mod_noise"].to(DEV).unsqueeze(-1), mask=mask3).squeeze(-1)
+    assert torch.equal(sub(x_mod, tag), G(g, "mod_start"))
+    q = diff.q_sample(x_start, inp["q_t"].to(DEV), noise=inp["q_noise"].to(DEV), mask=inp["batch"]["input_mask"].to(DEV))
+    assert torch.equal(sub(q, tag), G(g, "q_out"))
+
+
+@pytest.mark.parametrize("tag", ["tiny", "same", "c1"])
+def test_single_reverse_steps(tag):
+    m, diff, model_emb, inp, c = build(tag)
+    g = load_golden("model_%s.npz" % tag)
+    B, L, E = c["B"], c["L"], c["E"]
+    x_start, mask3 = inp["x_start"].to(DEV), inp["mask3"].to(DEV)
+    x_gen = osa.start_latent_generation(inp["x_start"], inp["mask3"], inp["gen_noise0"]).to(DEV)
+    fn = partial(denoised_fn_round, model_emb.to(DEV), dist=None)
+    for name, tval in (("hi", 1999), ("mid", 700), ("zero", 0)):
+        tvec = torch.tensor([tval] * B, device=DEV)
+        nz = step_noise(fx.step_seed(tag), (B, L, E), 1).to(DEV)
+        diff.noise_fn = lambda k, i, x: nz
+        r = diff.p_sample(m, x_gen, tvec, clip_denoised=True, denoised_fn=fn, model_kwargs={}, top_p=1, mask=mask3,
+                          x_start=x_start)
+        assert torch.equal(sub(r["pred_xstart"], tag), G(g, "ps_%s_x0" % name)), "rounded x0 differs"
+        assert maxerr(sub(r["greedy_mean"], tag), G(g, "ps_%s_mean" % name)) < 1e-6
+        assert maxerr(sub(r["sample"], tag), G(g, "ps_%s_sample" % name)) < 1e-6
+        assert set(r) == {"sample", "pred_xstart", "greedy_mean", "out"}
+        nz2 = step_noise(fx.step_seed(tag), (B, L, E), None).to(DEV)
+        diff.noise_fn = lambda k, i, x: nz2
+        r = diff.ddim_sample(m, x_gen, tvec, clip_denoised=True, denoised_fn=fn, model_kwargs={}, mask=mask3,
+                             x_start=x_start)
+        assert maxerr(sub(r["sample"], tag), G(g, "dd_%s_sample" % name)) < 2e-6
+    # per-row timesteps, no rounding, no clipping, no anchoring, eta != 0
+    tfree = inp["free_t"].to(DEV)
+    nz = step_noise(fx.free_seed(tag), (B, L, E), None).to(DEV)
+    diff.noise_fn = lambda k, i, x: nz
+    r = diff.p_sample(m, x_gen, tfree, clip_denoised=False, denoised_fn=None, model_kwargs={}, top_p=None)
+    assert maxerr(sub(r["sample"], tag), G(g, "ps_free_sample")) < 3e-4
+    r = diff.ddim_sample(m, x_gen, tfree, clip_denoised=False, denoised_fn=None, model_kwargs={}, eta=0.5)
+    ref = G(g, "dd_free_sample")
+    assert maxerr(sub(r["sample"], tag), ref) < 5e-3 * max(1.0, float(ref.abs().max()))  # eps=(.)/sqrt_recipm1 amplifies
+    out = diff.p_mean_variance(m, x_gen, tfree, clip_denoised=True, denoised_fn=fn, model_kwargs={})
+    assert set(out) == {"mean", "variance", "log_variance", "pred_xstart"} and out["variance"].shape == x_gen.shape
+
+
+def run_loops(tag, m, diff, model_emb, inp, c, use_graph):
+    B, L, E = c["B"], c["L"], c["E"]
+    x_start, mask3 = inp["x_start"].to(DEV), inp["mask3"].to(DEV)
+    x_gen = osa.start_latent_generation(inp["x_start"], inp["mask3"], inp["gen_noise0"]).to(DEV)
+    from oracle import schedule as osc
+    x_mod = osa.start_latent_modification(osc.make_diffusion(), inp["x_start"], inp["mask3"], fx.NOISING_T,
+                                          noise=inp["mod_noise"]).to(DEV)
+    fn = partial(denoised_fn_round, model_emb.to(DEV), dist=None)
+    common = dict(model=m, shape=(B, L, E), clip_denoised=True, denoised_fn=fn, model_kwargs={}, top_p=1, clamp_step=0,
+                  clamp_first=True, mask=mask3, x_start=x_start, only_last=True)
+    diff.use_graph = use_graph
+    res = {}
+    nz = loop_noises(fx.loop_seed(tag, "ddim50"), (B, L, E), 50, None)
+    diff.noise_fn = lambda k, i, x: nz[k].to(DEV)
+    res["ddim50"] = diff.ddim_sample_loop(noise=x_gen, gap=40, t_enc=None, **common)[-1]
+    nz2 = loop_noises(fx.loop_seed(tag, "p12"), (B, L, E), 12, 1)
+    diff.noise_fn = lambda k, i, x: nz2[k].to(DEV)
+    res["p12"] = diff.p_sample_loop(noise=x_gen, gap=1, t_enc=12, **common)[-1]
+    nz3 = loop_noises(fx.loop_seed(tag, "mod"), (B, L, E), fx.NOISING_T, None)
+    diff.noise_fn = lambda k, i, x: nz3[k].to(DEV)
+    res["mod"] = diff.ddim_sample_loop(noise=x_mod, gap=10, t_enc=fx.NOISING_T, **common)[-1]
+    return res
+
+
+@pytest.mark.parametrize("use_graph", [False, True], ids=["eager", "hipgraph"])
+@pytest.mark.parametrize("tag", ["tiny", "same", "c1"])
+def test_loops_final_tokens_exact_fp32(tag, use_graph):
+    m, diff, model_emb, inp, c = build(tag)
+    g = load_golden("model_%s.npz" % tag)
+    res = run_loops(tag, m, diff, model_emb, inp, c, use_graph)
+    for key in ("ddim50", "p12", "mod"):
+        s = res[key]
+        tokens = m.argmax_tokens(s).cpu()
+        ref_tokens = G(g, "loop_%s_tokens" % key).long()
+        assert torch.equal(tokens, ref_tokens), "%s: %d token mismatches" % (key, int((tokens != ref_tokens).sum()))
+        assert torch.equal(torch.argmax(m.get_logits(s), dim=-1).cpu(), ref_tokens)
+        # final step is t == 0 for ddim50 / p12: sample = mean of rounded rows -> tight; mod ends at t>0
+        assert maxerr(sub(s, tag), G(g, "loop_%s" % key)) < 2e-5, key
+
+
+def test_loops_bf16_token_agreement():
+    tag = "c1"
+    m, diff, model_emb, inp, c = build(tag, "bf16")
+    g = load_golden("model_%s.npz" % tag)
+    res = run_loops(tag, m, diff, model_emb, inp, c, True)
+    for key in ("ddim50", "p12", "mod"):
+        tokens = m.argmax_tokens(res[key]).cpu()
+        ref = G(g, "loop_%s_tokens" % key).long()
+        agree = float((tokens == ref).float().mean())
+        print("bf16 %s token agreement %.4f" % (key, agree))
+        assert agree >= 0.99, (key, agree)
+
+
+def test_progressive_and_full_history_match_only_last():
+    tag = "tiny"
+    m, diff, model_emb, inp, c = build(tag)
+    B, L, E = c["B"], c["L"], c["E"]
+    x_start, mask3 = inp["x_start"].to(DEV), inp["mask3"].to(DEV)
+    x_gen = osa.start_latent_generation(inp["x_start"], inp["mask3"], inp["gen_noise0"]).to(DEV)
+    fn = partial(denoised_fn_round, model_emb.to(DEV), dist=None)
+    nz = loop_noises(5, (B, L, E), 6, 1)
+    diff.noise_fn = lambda k, i, x: nz[k].to(DEV)
+    kw = dict(clip_denoised=True, denoised_fn=fn, model_kwargs={}, top_p=1, clamp_step=0, clamp_first=True,
+              mask=mask3, x_start=x_start, t_enc=6)
+    last = diff.p_sample_loop(m, (B, L, E), noise=x_gen, only_last=True, **kw)
+    full = diff.p_sample_loop(m, (B, L, E), noise=x_gen, only_last=False, **kw)
+    assert len(last) == 1 and len(full) == 6 and torch.equal(last[0], full[-1])
+    outs = list(diff.p_sample_loop_progressive(m, (B, L, E), noise=x_gen, **kw))
+    assert len(outs) == 6 and torch.equal(outs[-1]["sample"], last[0])
+    assert {"sample", "pred_xstart", "greedy_mean", "out"} <= set(outs[0])
+    assert diff.p_sample_loop(m, (B, L, E), noise=x_gen, only_last=True, **{**kw, "t_enc": 0}) == []
+    # clamp gating: clamp_step above every index with clamp_first=False disables rounding -> general path result
+    kw2 = dict(kw, clamp_step=-1, clamp_first=False)
+    a = diff.p_sample_loop(m, (B, L, E), noise=x_gen, only_last=True, **kw2)[0]
+    kw3 = dict(kw, denoised_fn=None)
+    b = diff.p_sample_loop(m, (B, L, E), noise=x_gen, only_last=True, **kw3)[0]
+    assert torch.equal(a, b)
+    # an arbitrary denoised_fn callable takes the general per-step path and is honoured
+    calls = []
+    def custom(x, t):
+        calls.append(int(t[0]))
+        return x * 0.5
+    c_out = diff.p_sample_loop(m, (B, L, E), noise=x_gen, only_last=True, **dict(kw, denoised_fn=custom))[0]
+    assert calls == [1999, 1998, 1997, 1996, 1995, 1994] and c_out.shape == x_gen.shape
+
+
+def test_rng_modes():
+    tag = "tiny"
+    m, diff, model_emb, inp, c = build(tag)
+    B, L, E = c["B"], c["L"], c["E"]
+    x_start, mask3 = inp["x_start"].to(DEV), inp["mask3"].to(DEV)
+    x_gen = osa.start_latent_generation(inp["x_start"], inp["mask3"], inp["gen_noise0"]).to(DEV)
+    fn = partial(denoised_fn_round, model_emb.to(DEV), dist=None)
+    kw = dict(model=m, shape=(B, L, E), noise=x_gen, clip_denoised=True, denoised_fn=fn, model_kwargs={}, top_p=1,
+              clamp_step=0, clamp_first=True, mask=mask3, x_start=x_start, t_enc=8, only_last=True)
+    diff.noise_fn = None
+    diff.rng_mode, diff.rng_seed = "philox", 105
+    a = diff.p_sample_loop(**kw)[0].clone()
+    b = diff.p_sample_loop(**kw)[0].clone()
+    assert torch.equal(a, b), "philox loop must be a pure function of (seed, stream)"
+    diff.rng_stream = 1
+    c2 = diff.p_sample_loop(**kw)[0].clone()
+    assert not torch.equal(a, c2)
+    diff.use_graph = False
+    diff.rng_stream = 0
+    d = diff.p_sample_loop(**kw)[0].clone()
+    assert torch.equal(a, d), "graph replay and eager launches must agree bit for bit"
+    # torch mode: seeded device generator, same call sequence as the reference
+    diff.rng_mode = "torch"
+    for ug in (True, False):
+        diff.use_graph = ug
+        torch.manual_seed(7)
+        e1 = diff.p_sample_loop(**kw)[0].clone()
+        torch.manual_seed(7)
+        n0 = torch.randn_like(x_gen)          # first draw of the loop (before any redraw)
+        torch.manual_seed(7)
+        e2 = diff.p_sample_loop(**kw)[0].clone()
+        assert torch.equal(e1, e2) and n0.shape == x_gen.shape
+    anchored = (mask3 == 0)
+    assert torch.equal(a[anchored], x_start[anchored])

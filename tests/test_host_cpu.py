@@ -1,0 +1,162 @@
+"""CPU tests of the product's host logic (no kernels run): float64 tables, respacing and samplers
+against the reference fixtures; state_dict layout; the C-ABI library loads and exports every symbol
+of include/musehip.h; the product path refuses CPU tensors instead of falling back."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import REPO, load_golden
+
+from musediffusion_amd.models import diffusion as D
+from musediffusion_amd.models import step_sample as S
+from oracle import fixtures as fx
+
+TABLES = ("betas", "alphas_cumprod", "alphas_cumprod_prev", "alphas_cumprod_next",
+          "sqrt_alphas_cumprod", "sqrt_one_minus_alphas_cumprod", "log_one_minus_alphas_cumprod",
+          "sqrt_recip_alphas_cumprod", "sqrt_recipm1_alphas_cumprod", "posterior_variance",
+          "posterior_log_variance_clipped", "posterior_mean_coef1", "posterior_mean_coef2")
+
+
+def test_tables_match_reference_bit_for_bit():
+    g = load_golden("schedules.npz")
+    d = D.GaussianDiffusion(betas=D.get_named_beta_schedule("sqrt", 2000), predict_xstart=True)
+    for name in TABLES:
+        np.testing.assert_array_equal(getattr(d, name)[g["sqrt2000_idx"]], g["sqrt2000_" + name], err_msg=name)
+    for sched in ("linear", "cosine", "sqrt", "trunc_cos", "trunc_lin", "pw_lin"):
+        b = D.get_named_beta_schedule(sched, 50)
+        np.testing.assert_array_equal(b, g["betas50_" + sched])
+        gd = D.GaussianDiffusion(betas=b, predict_xstart=True)
+        np.testing.assert_array_equal(gd.posterior_mean_coef1, g["pmc1_50_" + sched])
+        np.testing.assert_array_equal(gd.posterior_log_variance_clipped, g["plvc_50_" + sched])
+    with pytest.raises(NotImplementedError):
+        D.get_named_beta_schedule("nope", 10)
+    with pytest.raises(AssertionError):
+        D.GaussianDiffusion(betas=np.array([[0.1]]), predict_xstart=True)
+
+
+def test_respacing_matches_reference():
+    g = load_golden("schedules.npz")
+    for key, (T, spec) in {"ddim50": (2000, "ddim50"), "sec": (300, "10,15,20"), "full": (2000, [2000]),
+                           "odd": (100, [7, 3])}.items():
+        use = D.space_timesteps(T, spec)
+        np.testing.assert_array_equal(np.array(sorted(use)), g["space_" + key])
+        sp = D.SpacedDiffusion(use_timesteps=use, betas=D.get_named_beta_schedule("sqrt", T),
+                               rescale_timesteps=True, predict_xstart=True)
+        np.testing.assert_array_equal(sp.betas, g["spaced_betas_" + key])
+        np.testing.assert_array_equal(np.array(sp.timestep_map), g["spaced_map_" + key])
+        assert sp.num_timesteps == len(use) and sp.original_num_steps == T
+    with pytest.raises(ValueError):
+        D.space_timesteps(10, [11])
+    with pytest.raises(ValueError):
+        D.space_timesteps(2000, "ddim1999")
+
+
+def test_schedule_samplers_match_reference():
+    from types import SimpleNamespace
+    g = load_golden("schedules.npz")
+    fake = SimpleNamespace(num_timesteps=6)
+    rs = S.LossSecondMomentResampler(fake, history_per_term=3)
+    ts, ls = g["lsr_ts"].tolist(), g["lsr_ls"].tolist()
+    rs.update_with_all_losses(ts[:10], ls[:10])
+    np.testing.assert_array_equal(rs.weights(), g["lsr_w_cold"])
+    rs.update_with_all_losses(ts[10:], ls[10:])
+    np.testing.assert_array_equal(rs.weights(), g["lsr_w_warm"])
+    np.random.seed(11)
+    idx, w = rs.sample(16, "cpu")
+    np.testing.assert_array_equal(idx.numpy(), g["lsr_sample_idx"])
+    np.testing.assert_array_equal(w.numpy(), g["lsr_sample_w"])
+    np.random.seed(11)
+    idx, w = S.UniformSampler(fake).sample(16, "cpu")
+    np.testing.assert_array_equal(idx.numpy(), g["uni_sample_idx"])
+    np.testing.assert_array_equal(w.numpy(), g["uni_sample_w"])
+    np.testing.assert_array_equal(S.FixSampler(SimpleNamespace(num_timesteps=10)).weights(), g["fix_w"])
+    with pytest.raises(NotImplementedError):
+        S.create_named_schedule_sampler("nope", fake)
+    with pytest.raises(RuntimeError):
+        S.create_named_schedule_sampler("lossaware", fake)   # needs an initialised process group
+    assert isinstance(S.create_named_schedule_sampler("uniform", fake), S.UniformSampler)
+    # single-process update path (no process group): same state as update_with_all_losses
+    rs2 = S.LossSecondMomentResampler(fake, history_per_term=3)
+    rs2.update_with_local_losses(torch.tensor(ts), torch.tensor(ls, dtype=torch.float64))
+    np.testing.assert_array_equal(rs2.weights(), g["lsr_w_warm"])
+
+
+def test_state_dict_layout_is_the_reference_checkpoint_format():
+    from musediffusion_amd.models.network import TransformerNetModel
+    for tag in ("tiny", "same"):
+        c = fx.CONFIGS[tag]
+        m = TransformerNetModel(c["E"], c["E"], c["Tt"], c["V"], c["L"], dropout=0.0, bert_hidden=c["H"],
+                                bert_layers=c["nL"], bert_heads=c["nh"], bert_ffn=c["F"])
+        ref_sd = fx.state_dict(tag)      # key names / shapes recorded from the reference
+        sd = m.state_dict()
+        assert set(sd) == set(ref_sd), set(sd) ^ set(ref_sd)
+        for k in sd:
+            assert tuple(sd[k].shape) == tuple(ref_sd[k].shape), k
+        assert m.lm_head.weight is m.word_embedding.weight        # tied (network.py:56-58)
+        m.load_state_dict(ref_sd)                                  # strict load of a reference checkpoint
+        g = load_golden("model_%s.npz" % tag)
+        for k, v in m.state_dict().items():
+            np.testing.assert_array_equal(v.numpy(), g["sd." + k])
+    with pytest.raises(ValueError):
+        TransformerNetModel(32, 16, 32, 729, 16)
+
+
+def test_alias_modules_and_factory():
+    from types import SimpleNamespace
+    from musediffusion_amd.models import denoising_model, gaussian_diffusion, nn as mnn
+    from musediffusion_amd.models.network import TransformerNetModel
+    from musediffusion_amd.utils.initialization import create_model_and_diffusion
+    assert denoising_model.TransformerNetModel is TransformerNetModel
+    assert gaussian_diffusion.GaussianDiffusion is D.GaussianDiffusion
+    assert mnn.timestep_embedding is TransformerNetModel.timestep_embedding
+    args = SimpleNamespace(hidden_dim=32, hidden_t_dim=32, vocab_size=729, seq_len=16, dropout=0.1,
+                           noise_schedule="sqrt", diffusion_steps=2000, timestep_respacing="",
+                           rescale_timesteps=True, predict_xstart=True)
+    model, diff = create_model_and_diffusion(args, bert_hidden=64, bert_layers=2, bert_heads=4, bert_ffn=256)
+    assert isinstance(diff, D.SpacedDiffusion) and diff.num_timesteps == 2000
+    assert diff.timestep_map == list(range(2000)) and diff.rescale_timesteps
+    assert model.hidden_size == 64 and len(model.input_transformers.layer) == 2
+    default = create_model_and_diffusion(SimpleNamespace(**{**vars(args), "seq_len": 8}))[0]
+    assert default.hidden_size == 768 and len(default.input_transformers.layer) == 12   # bert-base like network.py:44
+
+
+def test_library_exports_every_declared_symbol():
+    from musediffusion_amd import _lib
+    header = open(os.path.join(REPO, "include", "musehip.h")).read()
+    declared = set(re.findall(r"\b(mh_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no prototypes parsed"
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    handle = _lib.lib()
+    for name in declared:
+        assert hasattr(handle, name), name
+    assert handle.mh_abi_version() == 1
+
+
+def test_product_path_refuses_cpu_instead_of_falling_back():
+    from musediffusion_amd import _lib
+    from musediffusion_amd.models.network import TransformerNetModel
+    from musediffusion_amd.models.rounding import denoised_fn_round
+    c = fx.CONFIGS["tiny"]
+    m = TransformerNetModel(c["E"], c["E"], c["Tt"], c["V"], c["L"], bert_hidden=c["H"], bert_layers=c["nL"],
+                            bert_heads=c["nh"], bert_ffn=c["F"]).eval().requires_grad_(False)
+    x = torch.zeros(2, c["L"], c["E"])
+    with pytest.raises(_lib.MuseHipError):
+        m(x, torch.zeros(2))
+    with pytest.raises(_lib.MuseHipError):
+        m.get_embeds(torch.zeros(2, 4, dtype=torch.long))
+    d = D.GaussianDiffusion(betas=D.get_named_beta_schedule("sqrt", 50), predict_xstart=True)
+    with pytest.raises(_lib.MuseHipError):
+        d.q_sample(x, torch.zeros(2, dtype=torch.long))
+    with pytest.raises(_lib.MuseHipError):
+        denoised_fn_round(torch.nn.Embedding(8, 4), torch.zeros(3, 4), None)
+    # nothing under the product package imports the oracle
+    import musediffusion_amd
+    root = os.path.dirname(musediffusion_amd.__file__)
+    for dp, _, files in os.walk(root):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dp, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), os.path.join(dp, f)
