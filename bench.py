@@ -162,7 +162,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
-    ap.add_argument("--glds", type=int, default=None, help="bf16 GEMM staging: 1 global_load_lds, 0 register")
+    ap.add_argument("--gemm", type=int, default=None, help="bf16 GEMM kernel variant 0/1/2 (see mh_gemm_set_variant)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -182,8 +182,8 @@ def main():
     from musediffusion_amd.models.rounding import denoised_fn_round
     from musediffusion_amd.sharding import broadcast_weights
 
-    if args.glds is not None:
-        _lib.lib().mh_gemm_set_glds(args.glds)
+    if args.gemm is not None:
+        _lib.lib().mh_gemm_set_variant(args.gemm)
     c = WORKLOADS[args.workload]
     model, diff = build(c, args.dtype, device, seed=0)
     if world > 1:

@@ -185,8 +185,12 @@ int mh_step_end(mh_loop_state* state, mh_stream_t stream);
 
 /* Thin hipGraph wrappers so the host can capture a sequence of the calls above on `stream` and
  * replay it (hipStreamBeginCapture / EndCapture / GraphInstantiate / GraphLaunch). */
-/* A/B switch for the bf16 GEMM operand staging: 0 = register-staged, 1 = global_load_lds. */
-int mh_gemm_set_glds(int on);
+/* A/B switch between the bf16 GEMM kernels: 0 = 128x128 tile, register-staged; 1 = 128x128 tile,
+ * global_load_lds; 2 (default) = 256x128 tile, 3-stage global_load_lds ring. */
+int mh_gemm_set_variant(int variant);
+/* Timing-only ablation of the big-tile kernel (results are WRONG when non-zero): bit 0 skips the
+ * DMA loads, bit 1 the MFMAs, bit 2 the epilogue stores.  Used by tools/gemm_bench.py only. */
+int mh_gemm_set_debug(int bits);
 
 int mh_graph_begin_capture(mh_stream_t stream);
 int mh_graph_end_capture(mh_stream_t stream, void** graph_exec_out);

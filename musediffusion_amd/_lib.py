@@ -71,7 +71,8 @@ SIGNATURES = {
     "mh_trunc_normal": (INT, [VP, I64, F32, C.c_uint64, C.c_uint32, VP, VP]),
     "mh_step_begin": (INT, [VP, VP, VP, VP, VP, INT, VP]),
     "mh_step_end": (INT, [VP, VP]),
-    "mh_gemm_set_glds": (INT, [INT]),
+    "mh_gemm_set_variant": (INT, [INT]),
+    "mh_gemm_set_debug": (INT, [INT]),
     "mh_graph_begin_capture": (INT, [VP]),
     "mh_graph_end_capture": (INT, [VP, C.POINTER(VP)]),
     "mh_graph_launch": (INT, [VP, VP]),

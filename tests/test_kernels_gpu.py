@@ -91,13 +91,13 @@ GEMM_CASES = [
 
 
 @pytest.mark.parametrize("dtype", [MH_F32, MH_BF16], ids=["f32", "bf16"])
-@pytest.mark.parametrize("glds", [0, 1])
+@pytest.mark.parametrize("glds", [0, 1, 2])
 @pytest.mark.parametrize("case", GEMM_CASES)
 def test_gemm_bias_act(case, dtype, glds):
     M, N, K, act, use_res, out_f32 = case
     if dtype == MH_F32 and glds:
-        pytest.skip("global_load_lds staging exists for bf16 only")
-    lib().mh_gemm_set_glds(glds)
+        pytest.skip("kernel variants exist for bf16 only")
+    lib().mh_gemm_set_variant(glds)
     try:
         A = rnd(M, K, seed=10, scale=0.5)
         W = rnd(N, K, seed=11, scale=1.0 / math.sqrt(K))
@@ -116,7 +116,7 @@ def test_gemm_bias_act(case, dtype, glds):
             atol += 2e-3  # fp32 accumulation-order noise on top of the output rounding
         assert_close(out, ref, atol, rtol, what="gemm %s" % (case,))
     finally:
-        lib().mh_gemm_set_glds(0)
+        lib().mh_gemm_set_variant(2)
 
 
 @pytest.mark.parametrize("dtype", [MH_F32, MH_BF16], ids=["f32", "bf16"])

@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of the denoiser's GEMM shapes (used alone and under rocprofv3 --pmc)."""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from musediffusion_amd import _lib, ops  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--variant", type=int, default=2)
+ap.add_argument("--reps", type=int, default=10)
+ap.add_argument("--M", type=int, default=32768)
+ap.add_argument("--H", type=int, default=512)
+ap.add_argument("--F", type=int, default=2048)
+ap.add_argument("--shapes", default="ao,ffn1,ffn2,qkv")
+ap.add_argument("--dbg", type=int, default=0)
+ap.add_argument("--pad", type=int, default=0, help="extra elements on every leading dimension")
+a = ap.parse_args()
+_lib.lib().mh_gemm_set_variant(a.variant)
+_lib.lib().mh_gemm_set_debug(a.dbg)
+dev = "cuda"
+M, H, F = a.M, a.H, a.F
+bf = torch.bfloat16
+
+
+def t(*s):
+    return (torch.randn(*s, device=dev) * (1.0 / s[-1] ** 0.5 if len(s) == 2 and s[0] != M else 1.0)).to(bf)
+
+
+P = a.pad
+X, Xf = t(M, H + P), t(M, F + P)
+shapes = {
+    "ao": lambda: ops.gemm_bias_act(X, Wao, b_h, X, None, 1, N=H, K=H, out=o_h),
+    "ffn1": lambda: ops.gemm_bias_act(X, W1, b_f, None, "gelu", 1, N=F, K=H, out=o_f),
+    "ffn2": lambda: ops.gemm_bias_act(Xf, W2, b_h, X, None, 1, N=H, K=F, out=o_h),
+    "qkv": lambda: _lib.check(_lib.lib().mh_gemm_qkv(X.data_ptr(), H, Wqkv.data_ptr(), H, b_q.data_ptr(), q.data_ptr(),
+                                                      k.data_ptr(), vt.data_ptr(), M // 512, 512, H, H // 64, 1,
+                                                      _lib.current_stream())),
+}
+Wao, W1, W2, Wqkv = t(H, H + P), t(F, H + P), t(H, F + P), t(3 * H, H)
+b_h, b_f, b_q = torch.zeros(H, device=dev), torch.zeros(F, device=dev), torch.zeros(3 * H, device=dev)
+o_h, o_f = torch.empty(M, H + P, device=dev, dtype=bf), torch.empty(M, F + P, device=dev, dtype=bf)
+q, k, vt = (torch.empty(M * H + 256, device=dev, dtype=bf) for _ in range(3))
+flops = {"ao": 2.0 * M * H * H, "ffn1": 2.0 * M * H * F, "ffn2": 2.0 * M * H * F, "qkv": 2.0 * M * H * 3 * H}
+for name in a.shapes.split(","):
+    fn = shapes[name]
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(a.reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / a.reps
+    print("dbg %d %-5s variant %d: %8.1f us  %7.1f TFLOP/s" % (a.dbg, name, a.variant, ms * 1e3, flops[name] / ms / 1e9), flush=True)
