@@ -79,6 +79,16 @@ int mh_gemm_bias_act(const void* A, int64_t lda, const void* W, int64_t ldw, con
                      const void* residual, int64_t ldr, void* out, int64_t ldo, int out_f32,
                      int64_t M, int N, int K, int act, int dtype, mh_stream_t stream);
 
+/* Same with explicit operand layouts (bf16 big-tile kernel only).  `*_panel != 0` selects the K32-PANEL
+ * layout for that operand: element (r, c) of an [R, C] matrix lives at ((c / 32) * ld + r) * 32 + c % 32
+ * with ld = allocated rows per panel (C padded to a multiple of 32).  In that layout every K-step of a
+ * 256-row tile is one contiguous 16 KiB run, so each global_load_lds instruction moves 1 KiB of whole
+ * cache lines (row-major needs sixteen 64-byte row segments per instruction) and epilogue stores of
+ * adjacent rows are adjacent in memory. */
+int mh_gemm_bias_act_ex(const void* A, int64_t lda, int a_panel, const void* W, int64_t ldw, int w_panel,
+                        const float* bias, const void* residual, int64_t ldr, int r_panel, void* out, int64_t ldo,
+                        int o_panel, int out_f32, int64_t M, int N, int K, int act, int dtype, mh_stream_t stream);
+
 /* K5   fused Q/K/V projection: [q|k|v] = A Wqkv^T + bqkv with Wqkv = [Wq; Wk; Wv] ([3H, ldw]);
  *      scatters heads: q,k -> [B, nh, L, dh], v -> TRANSPOSED [B, nh, dh, L] (the layout the
  *      attention kernel's P.V product wants).  HF BertSelfAttention.{query,key,value} +
@@ -110,6 +120,15 @@ int mh_add_pos_time_layernorm(const void* x, int64_t ldx, int x_is_f32, const fl
  *      (models/rounding.py:21-28).  table [V,E], table_norm [V] from mh_row_sqnorm. */
 int mh_round_to_embedding(const float* x, const float* table, const float* table_norm, int32_t* idx,
                           int64_t n_tokens, int E, int V, mh_stream_t stream);
+
+/* K10 on the exact-fp32 MFMA (the per-step path): same result as mh_round_to_embedding, computed as a
+ * 128x128-tiled v_mfma_f32_16x16x4_f32 GEMM whose epilogue keeps, per token, the best (score, first index)
+ * of every 64-column slot, followed by a tiny cross-slot reduce.  table_pad is the table with rows
+ * zero-padded to a multiple of 16 columns (the table itself when E % 16 == 0). */
+size_t mh_round_workspace_bytes(int64_t n_tokens, int E, int V);
+int mh_round_to_embedding_mfma(const float* x, const float* table_pad, const float* table_norm, int32_t* idx,
+                               int64_t n_tokens, int E, int V, void* workspace, size_t workspace_bytes,
+                               mh_stream_t stream);
 
 /* K16  idx[n] = argmax_v (x_n . W_v + bias_v), first index on ties (run/sample.py:219-220 on
  *      models/network.py:91-93). */

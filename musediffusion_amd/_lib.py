@@ -59,11 +59,14 @@ SIGNATURES = {
     "mh_embed_gather": (INT, [VP, VP, VP, I64, INT, INT, VP]),
     "mh_timestep_embedding": (INT, [VP, VP, INT, INT, I64, F32, INT, VP]),
     "mh_gemm_bias_act": (INT, [VP, I64, VP, I64, VP, VP, I64, VP, I64, INT, I64, INT, INT, INT, INT, VP]),
+    "mh_gemm_bias_act_ex": (INT, [VP, I64, INT, VP, I64, INT, VP, VP, I64, INT, VP, I64, INT, INT, I64, INT, INT, INT, INT, VP]),
     "mh_gemm_qkv": (INT, [VP, I64, VP, I64, VP, VP, VP, VP, INT, INT, INT, INT, INT, VP]),
     "mh_attention_fwd": (INT, [VP, VP, VP, VP, I64, INT, INT, INT, INT, F32, INT, VP]),
     "mh_layernorm": (INT, [VP, VP, VP, VP, I64, INT, F32, INT, VP]),
     "mh_add_pos_time_layernorm": (INT, [VP, I64, INT, VP, VP, VP, VP, VP, VP, INT, INT, INT, F32, INT, VP]),
     "mh_round_to_embedding": (INT, [VP, VP, VP, VP, I64, INT, INT, VP]),
+    "mh_round_workspace_bytes": (C.c_size_t, [I64, INT, INT]),
+    "mh_round_to_embedding_mfma": (INT, [VP, VP, VP, VP, I64, INT, INT, VP, C.c_size_t, VP]),
     "mh_logits_argmax": (INT, [VP, VP, VP, VP, I64, INT, INT, VP]),
     "mh_q_sample": (INT, [VP, VP, VP, VP, VP, INT, VP, INT, I64, INT, VP]),
     "mh_p_sample_epilogue": (INT, [VP, VP, VP, VP, VP, VP, INT, INT, VP, INT, VP, VP, VP, VP, INT, I64, INT, VP]),

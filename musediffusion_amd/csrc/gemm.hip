@@ -32,6 +32,10 @@ struct GemmArgs {
   // QKV scatter
   void* q; void* k; void* vt;
   int L, H, nh, dh;
+  // EPI 2 (nearest-embedding scores): aux[col] = |W_col|^2, rown[row] = |x_row|^2, partial best per (row, slot)
+  const float* aux; const float* rown; float* pbest; int32_t* pidx; int nslots;
+  int a_panel, w_panel, o_panel, r_panel;  // operand stored as K32 panels: [cols/32][ld rows][32]
+  int stagger;
   int dbg;  // timing-only ablation bits (mh_gemm_set_debug): 1 no DMA, 2 no MFMA, 4 no stores
 };
 
@@ -244,6 +248,40 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
           }
         }
       }
+    } else if constexpr (EPI == 2) {
+      // rounding scores (models/rounding.py:21-28): -(clamp((|W_v|^2 + |x_n|^2) - 2 x.W_v, 0)); every row keeps
+      // the best (score, first index) of this wave's 64 columns -> one partial per (row, column-slot)
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int idx = it * 64 + lane, rl = idx >> 3, c8 = (idx & 7) * 8;
+        const int64_t row = wrow0 + rl;
+        const int col = wcol0 + c8;
+        float best = -INFINITY;
+        int bi = 0x7fffffff;
+        if (row < g.M) {
+          const float xn = g.rown[row];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            if (col + e < g.N) {
+              float dist = (g.aux[col + e] + xn) - 2.0f * Cs[rl * CS_LD + c8 + e];
+              dist = fmaxf(dist, 0.0f);
+              const float sc = -dist;
+              if (sc > best) { best = sc; bi = col + e; }
+            }
+          }
+        }
+#pragma unroll
+        for (int off = 1; off < 8; off <<= 1) {
+          const float so = __shfl_xor(best, off, 64);
+          const int io = __shfl_xor(bi, off, 64);
+          if (so > best || (so == best && io < bi)) { best = so; bi = io; }
+        }
+        if ((lane & 7) == 0 && row < g.M) {
+          const int slot = (n0 / BN) * 2 + wn;
+          g.pbest[row * g.nslots + slot] = best;
+          g.pidx[row * g.nslots + slot] = bi;
+        }
+      }
     } else {
 #pragma unroll
       for (int it = 0; it < 4; ++it) {
@@ -309,23 +347,29 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
 constexpr int B2M = 256, B2N = 128, B2K = 32, B2STAGES = 3;
 constexpr int B2_STAGE_BYTES = (B2M + B2N) * 64;
 
-template <bool SWAP, int DBG>
+template <bool SWAP, int DBG, bool PP, bool INTERLEAVE = false>
 __device__ __forceinline__ void big_mainloop(f32x4 (&acc)[8][4], const char* smem, const char* const (&srcA)[4],
                                              const char* const (&srcW)[2], const int (&ldsA)[4], const int (&ldsW)[2],
-                                             int nk, int a_off, int b_off) {
-  auto issue = [&](int kt) {
+                                             int nk, int a_off, const int (&b_offs)[4], int64_t kstepA, int64_t kstepW, int group) {
+  auto issue_one = [&](int kt, int idx) {   // idx 0..3: A pieces, 4..5: W pieces (one 1-KiB DMA each)
     if constexpr ((DBG & 1) != 0) return;
     char* base = const_cast<char*>(smem) + (kt % B2STAGES) * B2_STAGE_BYTES;
-    const int koff = kt * (B2K * 2);
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcA[j] + koff),
-                                       (__attribute__((address_space(3))) void*)(base + ldsA[j]), 16, 0, 0);
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcW[j] + koff),
-                                       (__attribute__((address_space(3))) void*)(base + B2M * 64 + ldsW[j]), 16, 0, 0);
+    if (idx < 4)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcA[idx] + kt * kstepA),
+                                       (__attribute__((address_space(3))) void*)(base + ldsA[idx]), 16, 0, 0);
+    else
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcW[idx - 4] + kt * kstepW),
+                                       (__attribute__((address_space(3))) void*)(base + B2M * 64 + ldsW[idx - 4]), 16, 0, 0);
   };
+  auto issue = [&](int kt) {
+#pragma unroll
+    for (int idx = 0; idx < 6; ++idx) issue_one(kt, idx);
+  };
+  // PP (ping-pong): two 4-wave groups share one workgroup, each with its own tile and LDS ring.  Every
+  // K-step has TWO workgroup barriers (after the DMA wait, after the fragment reads) and group 1 runs one
+  // barrier behind group 0, so on every SIMD one wave is in its MFMA segment while its partner is in its
+  // load segment (DMA issue + ds_reads): the matrix pipe never waits for LDS / DMA latency.
+  if constexpr (PP) { if (group == 1) __builtin_amdgcn_s_barrier(); }
   issue(0);
   if (nk > 1) issue(1);
   for (int kt = 0; kt < nk; ++kt) {
@@ -333,14 +377,29 @@ __device__ __forceinline__ void big_mainloop(f32x4 (&acc)[8][4], const char* sme
     if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();   // everyone's share of stage kt is in LDS; stage kt-1 is fully consumed
-    if (kt + 2 < nk) issue(kt + 2); // refill the slot stage kt-1 occupied
+    const bool refill = kt + 2 < nk;   // stage kt+2 goes into the slot stage kt-1 occupied
+    if constexpr (!INTERLEAVE) { if (refill) issue(kt + 2); }
     const char* As = smem + (kt % B2STAGES) * B2_STAGE_BYTES;
     const char* Ws = As + B2M * 64;
+    // all 12 fragment reads are issued up front (W first: every MFMA row needs all four of them), then the
+    // scheduler is fenced so the MFMAs drain them behind counted lgkmcnt waits instead of four full stalls
     bf16x8 a[8], b[4];
+    if constexpr ((DBG & 8) != 0) {   // ablation: no LDS fragment reads (operands are whatever the registers hold)
 #pragma unroll
-    for (int i = 0; i < 8; ++i) a[i] = *reinterpret_cast<const bf16x8*>(As + a_off + i * (16 * 64));
+      for (int j = 0; j < 4; ++j) asm volatile("" : "=v"(b[j]));
 #pragma unroll
-    for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const bf16x8*>(Ws + b_off + j * (16 * 64));
+      for (int i = 0; i < 8; ++i) asm volatile("" : "=v"(a[i]));
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const bf16x8*>(Ws + b_offs[j]);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) a[i] = *reinterpret_cast<const bf16x8*>(As + a_off + i * (16 * 64));
+    }
+    if constexpr (PP) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+    __builtin_amdgcn_sched_barrier(0);
     if constexpr ((DBG & 2) != 0) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) asm volatile("" ::"v"(a[i]));
@@ -349,33 +408,63 @@ __device__ __forceinline__ void big_mainloop(f32x4 (&acc)[8][4], const char* sme
       continue;
     }
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < 8; ++i) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         if constexpr (SWAP) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
         else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
       }
+      if constexpr (INTERLEAVE) {
+        // one DMA piece in the shadow of every 4 MFMAs: its ~100-cycle issue cost hides behind the matrix pipe
+        if (i >= 1 && i <= 6) {
+          __builtin_amdgcn_sched_barrier(0);
+          if (refill) issue_one(kt + 2, i - 1);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
   }
+  if constexpr (PP) { if (group == 0) __builtin_amdgcn_s_barrier(); }
 }
 
-template <int EPI, int ACT, int DBG = 0>
-__global__ __launch_bounds__(256, 2) void gemm_big_kernel(const GemmArgs g) {
-  __shared__ __attribute__((aligned(16))) char smem[B2STAGES * B2_STAGE_BYTES];
+template <int EPI, int ACT, int DBG = 0, bool PP = false>
+__global__ __launch_bounds__(PP ? 512 : 256, PP ? 1 : 2) void gemm_big_kernel(const GemmArgs g) {
+  __shared__ __attribute__((aligned(16))) char smem_all[(PP ? 2 : 1) * B2STAGES * B2_STAGE_BYTES];
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int group = PP ? (wave_all >> 2) : 0, wave = wave_all & 3;
+  const char* smem = smem_all + group * (B2STAGES * B2_STAGE_BYTES);
   const int wm = wave >> 1, wn = wave & 1;
   const int tiles_n = (g.N + B2N - 1) / B2N;
-  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int tiles_total = tiles_n * (int)((g.M + B2M - 1) / B2M);
+  int bid;
+  bool tile_valid = true;
+  if constexpr (PP) {
+    bid = 2 * xcd_remap(blockIdx.x, gridDim.x) + group;   // the two groups take adjacent column tiles: same A panel
+    if (bid >= tiles_total) { bid = tiles_total - 1; tile_valid = false; }
+  } else {
+    bid = xcd_remap(blockIdx.x, gridDim.x);
+  }
   const int64_t m0 = (int64_t)(bid / tiles_n) * B2M;
   const int n0 = (bid % tiles_n) * B2N;
   const int nk = g.K / B2K;
   const int fr = lane & 15, fg = lane >> 4;
   constexpr int GSW[4] = {0, 2, 3, 1};
+  if (g.stagger > 0 && (int)blockIdx.x < 512 && ((g.stagger & 1) ? (((int)blockIdx.x >> 3) & 1) : ((int)blockIdx.x >= 256))) {
+    // experiment: phase-shift the second resident block of every CU so that its epilogue (VALU + stores)
+    // overlaps the first block's main loop (MFMA + DMA) instead of running in lockstep with it
+    const uint64_t t0 = __builtin_readcyclecounter();
+    while (__builtin_readcyclecounter() - t0 < (uint64_t)g.stagger) __builtin_amdgcn_s_sleep(8);
+  }
 
   // DMA coordinates: one instruction covers 16 rows x 64 B; lane i lands at row i/4, physical chunk i%4
   const char* srcA[4];
   const char* srcW[2];
   int ldsA[4], ldsW[2];
+  // row-major operand: rows lda elements apart, a K-step advances 32 elements; K32-panel operand
+  // ([K/32][ld rows][32]): rows 32 elements apart, a K-step advances one whole panel (ld * 32)
+  const int64_t a_row = g.a_panel ? 32 : g.lda, w_row = g.w_panel ? 32 : g.ldw;
+  const int64_t kstepA = g.a_panel ? g.lda * 64 : 64, kstepW = g.w_panel ? g.ldw * 64 : 64;
   {
     const int rl = lane >> 2, pc = lane & 3;
     const int lc = pc ^ GSW[(rl >> 2) & 3];          // logical chunk stored at this physical slot
@@ -383,19 +472,30 @@ __global__ __launch_bounds__(256, 2) void gemm_big_kernel(const GemmArgs g) {
     for (int j = 0; j < 4; ++j) {
       const int r16 = (wave * 4 + j) * 16;
       int64_t ra = m0 + r16 + rl; if (ra >= g.M) ra = g.M - 1;
-      srcA[j] = reinterpret_cast<const char*>(g.A) + (ra * g.lda + lc * 8) * 2;
+      srcA[j] = reinterpret_cast<const char*>(g.A) + (ra * a_row + lc * 8) * 2;
       ldsA[j] = r16 * 64;
     }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int r16 = (wave * 2 + j) * 16;
       int rw = n0 + r16 + rl; if (rw >= g.N) rw = g.N - 1;
-      srcW[j] = reinterpret_cast<const char*>(g.W) + ((int64_t)rw * g.ldw + lc * 8) * 2;
+      srcW[j] = reinterpret_cast<const char*>(g.W) + ((int64_t)rw * w_row + lc * 8) * 2;
       ldsW[j] = r16 * 64;
     }
   }
   const int frag_off = fr * 64 + ((fg ^ GSW[(fr >> 2) & 3]) << 4);
-  const int a_off = wm * (128 * 64) + frag_off, b_off = wn * (64 * 64) + frag_off;
+  const int a_off = wm * (128 * 64) + frag_off;
+  // W fragment rows.  Un-swapped MFMA (V^T waves): tile j takes rows 16j + fr.  Swapped MFMA: tile j, input
+  // row p = fr takes W row 32(j>>1) + 8(p>>2) + 4(j&1) + (p&3), so that a lane's accumulators (output rows
+  // 4fg + r of tiles 2h, 2h+1) are the 8 CONSECUTIVE output columns 32h + 8fg .. +7: 16-byte epilogue
+  // accesses, four lanes covering 64 contiguous bytes of a row.  Still conflict-free under the same swizzle.
+  int b_offs[4];
+  const bool v_wave = (EPI == 1) && ((n0 + wn * 64) / g.H == 2);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int row = v_wave ? 16 * j + fr : 32 * (j >> 1) + 8 * (fr >> 2) + 4 * (j & 1) + (fr & 3);
+    b_offs[j] = wn * (64 * 64) + row * 64 + ((fg ^ GSW[(row >> 2) & 3]) << 4);
+  }
 
   f32x4 acc[8][4];
 #pragma unroll
@@ -409,7 +509,8 @@ __global__ __launch_bounds__(256, 2) void gemm_big_kernel(const GemmArgs g) {
     const int which = wcol0 / g.H;   // wave-uniform: 0 q, 1 k, 2 v
     const int M32 = (int)g.M, r0 = (int)wrow0;
     if (which == 2) {
-      big_mainloop<false, DBG>(acc, smem, srcA, srcW, ldsA, ldsW, nk, a_off, b_off);
+      big_mainloop<false, DBG, PP>(acc, smem, srcA, srcW, ldsA, ldsW, nk, a_off, b_offs, kstepA, kstepW, group);
+      if (!tile_valid) return;
       // acc[i][j][r] = D[m = 16i + 4fg + r][n = 16j + fr]: 4 consecutive tokens per lane -> V^T rows
       bf16* dst = reinterpret_cast<bf16*>(g.vt);
       float bv[4];
@@ -440,18 +541,19 @@ __global__ __launch_bounds__(256, 2) void gemm_big_kernel(const GemmArgs g) {
         }
       }
     } else {
-      big_mainloop<true, DBG>(acc, smem, srcA, srcW, ldsA, ldsW, nk, a_off, b_off);
-      // acc[i][j][r] = D[n = 16j + 4fg + r][m = 16i + fr]: 4 consecutive head dims per lane
+      big_mainloop<true, DBG, PP>(acc, smem, srcA, srcW, ldsA, ldsW, nk, a_off, b_offs, kstepA, kstepW, group);
+      if (!tile_valid) return;
+      // acc[i][2h + q][r] = D[n = 32h + 8fg + 4q + r][m = 16i + fr]: 8 consecutive head dims per lane
       bf16* dst = reinterpret_cast<bf16*>(which == 0 ? g.q : g.k);
-      f32x4 bv[4];
-      int64_t coloff[4];
+      float bv[2][8];
+      int64_t coloff[2];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int col = wcol0 + 16 * j + 4 * fg;
-        const int cc = col < g.N ? col : g.N - 4;
-        bv[j] = *reinterpret_cast<const f32x4*>(g.bias + cc);
+      for (int h = 0; h < 2; ++h) {
+        const int col = wcol0 + 32 * h + 8 * fg;
+        const int cc = col < g.N ? col : g.N - 8;
+        load8(g.bias + cc, bv[h]);
         const int c = cc - which * g.H, head = c / g.dh, d = c % g.dh;
-        coloff[j] = col < g.N ? (int64_t)head * g.L * g.dh + d : -1;
+        coloff[h] = col < g.N ? (int64_t)head * g.L * g.dh + d : -1;
       }
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
@@ -460,19 +562,20 @@ __global__ __launch_bounds__(256, 2) void gemm_big_kernel(const GemmArgs g) {
           const int b = row / g.L, l = row - b * g.L;
           bf16* base = dst + ((int64_t)b * g.nh * g.L + l) * g.dh;
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            if (coloff[j] >= 0) {
-              bf16x4 v;
+          for (int h = 0; h < 2; ++h) {
+            if (coloff[h] >= 0) {
+              float v[8];
 #pragma unroll
-              for (int r = 0; r < 4; ++r) v[r] = (bf16)(acc[i][j][r] + bv[j][r]);
-              *reinterpret_cast<bf16x4*>(base + coloff[j]) = v;
+              for (int e = 0; e < 8; ++e) v[e] = acc[i][2 * h + (e >> 2)][e & 3] + bv[h][e];
+              store8(base + coloff[h], v);
             }
           }
         }
       }
     }
   } else {
-    big_mainloop<true, DBG>(acc, smem, srcA, srcW, ldsA, ldsW, nk, a_off, b_off);
+    big_mainloop<true, DBG, PP>(acc, smem, srcA, srcW, ldsA, ldsW, nk, a_off, b_offs, kstepA, kstepW, group);
+    if (!tile_valid) return;
     bf16* outT = reinterpret_cast<bf16*>(g.out);
     float* outF = reinterpret_cast<float*>(g.out);
     const bf16* res = reinterpret_cast<const bf16*>(g.residual);
@@ -486,34 +589,34 @@ __global__ __launch_bounds__(256, 2) void gemm_big_kernel(const GemmArgs g) {
       return;
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int col = wcol0 + 16 * j + 4 * fg;
-      if (col < g.N) {   // N % 4 == 0 (checked by the launcher): a lane's 4 columns are all valid
-        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-        if (g.bias) bv = *reinterpret_cast<const f32x4*>(g.bias + col);
+    for (int h = 0; h < 2; ++h) {
+      const int col = wcol0 + 32 * h + 8 * fg;
+      if (col < g.N) {   // N % 8 == 0 (checked by the launcher): a lane's 8 columns are all valid
+        float bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (g.bias) load8(g.bias + col, bv);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
           const int64_t row = wrow0 + 16 * i + fr;
           if (row < g.M) {
-            float v[4];
+            float v[8];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] + bv[r];
+            for (int e = 0; e < 8; ++e) v[e] = acc[i][2 * h + (e >> 2)][e & 3] + bv[e];
             if constexpr (ACT != MH_ACT_NONE) {
 #pragma unroll
-              for (int r = 0; r < 4; ++r) v[r] = apply_act<bf16>(v[r], ACT);
+              for (int e = 0; e < 8; ++e) v[e] = apply_act<bf16>(v[e], ACT);
             }
             if (res) {
-              const bf16x4 rv = *reinterpret_cast<const bf16x4*>(res + row * g.ldr + col);
+              const int64_t ro = g.r_panel ? ((int64_t)(col >> 5) * g.ldr + row) * 32 + (col & 31) : row * g.ldr + col;
+              float rv[8];
+              load8(res + ro, rv);
 #pragma unroll
-              for (int r = 0; r < 4; ++r) v[r] += (float)rv[r];
+              for (int e = 0; e < 8; ++e) v[e] += rv[e];
             }
             if (g.out_f32) {
-              *reinterpret_cast<f32x4*>(outF + row * g.ldo + col) = f32x4{v[0], v[1], v[2], v[3]};
+              store8(outF + row * g.ldo + col, v);
             } else {
-              bf16x4 o;
-#pragma unroll
-              for (int r = 0; r < 4; ++r) o[r] = (bf16)v[r];
-              *reinterpret_cast<bf16x4*>(outT + row * g.ldo + col) = o;
+              const int64_t oo = g.o_panel ? ((int64_t)(col >> 5) * g.ldo + row) * 32 + (col & 31) : row * g.ldo + col;
+              store8(outT + oo, v);
             }
           }
         }
@@ -523,6 +626,7 @@ __global__ __launch_bounds__(256, 2) void gemm_big_kernel(const GemmArgs g) {
 }
 
 int g_dbg = 0;
+int g_stagger = 0;
 int g_variant = 2;  // bf16 kernel choice: 0 small-tile register-staged, 1 small-tile global_load_lds, 2 big tile  // bf16 staging mode, switchable for A/B runs (mh_gemm_set_glds)
 
 template <int EPI>
@@ -532,23 +636,47 @@ int launch(const GemmArgs& g, int dtype, hipStream_t s) {
   dim3 grid((unsigned)tiles), block(256);
   if (dtype == MH_BF16) {
     MH_CHECK_ARG(g.K % 64 == 0 && g.K > 0, "gemm(bf16): K=%d must be a positive multiple of 64", g.K);
-    MH_CHECK_ARG(g.lda % 8 == 0 && g.ldw % 8 == 0, "gemm(bf16): lda/ldw must be multiples of 8");
-    const bool big_ok = g.N % 4 == 0 && g.K % B2K == 0 && g.ldo % 4 == 0 && g.ldr % 4 == 0;
-    if (g_variant == 2 && big_ok) {
+    MH_CHECK_ARG((g.a_panel || g.lda % 8 == 0) && (g.w_panel || g.ldw % 8 == 0), "gemm(bf16): lda/ldw must be multiples of 8");
+    const bool any_panel = g.a_panel || g.w_panel || g.o_panel || g.r_panel;
+    const bool big_ok = g.N % 8 == 0 && g.K % B2K == 0 && (g.o_panel || g.ldo % 8 == 0 || (g.out_f32 && g.ldo % 4 == 0)) &&
+                        (g.r_panel || g.ldr % 8 == 0);
+    MH_CHECK_ARG(!any_panel || (big_ok && g_variant >= 2), "gemm: panel layouts need the big-tile bf16 kernel");
+    if (g_variant == 3 && big_ok && !g.dbg) {
+      const int64_t t2 = (int64_t)ceil_div(g.M, B2M) * ceil_div(g.N, B2N);
+      const dim3 grid3((unsigned)((t2 + 1) / 2)), block3(512);
+      if constexpr (EPI == 1) {
+        MH_LAUNCH((gemm_big_kernel<1, MH_ACT_NONE, 0, true>), grid3, block3, 0, s, g);
+      } else {
+        switch (g.act) {
+          case MH_ACT_TANH: MH_LAUNCH((gemm_big_kernel<0, MH_ACT_TANH, 0, true>), grid3, block3, 0, s, g); break;
+          case MH_ACT_GELU_ERF: MH_LAUNCH((gemm_big_kernel<0, MH_ACT_GELU_ERF, 0, true>), grid3, block3, 0, s, g); break;
+          case MH_ACT_SILU: MH_LAUNCH((gemm_big_kernel<0, MH_ACT_SILU, 0, true>), grid3, block3, 0, s, g); break;
+          default: MH_LAUNCH((gemm_big_kernel<0, MH_ACT_NONE, 0, true>), grid3, block3, 0, s, g); break;
+        }
+      }
+    } else if (g_variant == 3 && big_ok) {
+      const int64_t t2 = (int64_t)ceil_div(g.M, B2M) * ceil_div(g.N, B2N);
+      const dim3 grid3((unsigned)((t2 + 1) / 2)), block3(512);
+      if ((g.dbg & 15) == 4) MH_LAUNCH((gemm_big_kernel<0, MH_ACT_NONE, 4, true>), grid3, block3, 0, s, g);
+      else MH_LAUNCH((gemm_big_kernel<0, MH_ACT_NONE, 5, true>), grid3, block3, 0, s, g);
+    } else if (g_variant >= 2 && big_ok) {
       const int64_t t2 = (int64_t)ceil_div(g.M, B2M) * ceil_div(g.N, B2N);
       const dim3 grid2((unsigned)t2);
       if constexpr (EPI == 1) {
         MH_LAUNCH((gemm_big_kernel<1, MH_ACT_NONE>), grid2, block, 0, s, g);
       } else {
         if (g.dbg) {   // timing-only ablations (tools/gemm_bench.py)
-          switch (g.dbg & 7) {
+          switch (g.dbg & 15) {
             case 1: MH_LAUNCH((gemm_big_kernel<0, MH_ACT_NONE, 1>), grid2, block, 0, s, g); break;
             case 2: MH_LAUNCH((gemm_big_kernel<0, MH_ACT_NONE, 2>), grid2, block, 0, s, g); break;
             case 3: MH_LAUNCH((gemm_big_kernel<0, MH_ACT_NONE, 3>), grid2, block, 0, s, g); break;
             case 4: MH_LAUNCH((gemm_big_kernel<0, MH_ACT_NONE, 4>), grid2, block, 0, s, g); break;
             case 5: MH_LAUNCH((gemm_big_kernel<0, MH_ACT_NONE, 5>), grid2, block, 0, s, g); break;
             case 6: MH_LAUNCH((gemm_big_kernel<0, MH_ACT_NONE, 6>), grid2, block, 0, s, g); break;
-            default: MH_LAUNCH((gemm_big_kernel<0, MH_ACT_NONE, 7>), grid2, block, 0, s, g); break;
+            case 7: MH_LAUNCH((gemm_big_kernel<0, MH_ACT_NONE, 7>), grid2, block, 0, s, g); break;
+            case 12: MH_LAUNCH((gemm_big_kernel<0, MH_ACT_NONE, 12>), grid2, block, 0, s, g); break;
+            case 13: MH_LAUNCH((gemm_big_kernel<0, MH_ACT_NONE, 13>), grid2, block, 0, s, g); break;
+            default: MH_LAUNCH((gemm_big_kernel<0, MH_ACT_NONE, 14>), grid2, block, 0, s, g); break;
           }
         } else switch (g.act) {
           case MH_ACT_TANH: MH_LAUNCH((gemm_big_kernel<0, MH_ACT_TANH>), grid2, block, 0, s, g); break;
@@ -563,6 +691,7 @@ int launch(const GemmArgs& g, int dtype, hipStream_t s) {
       MH_LAUNCH((gemm_kernel<bf16, EPI, 0>), grid, block, 0, s, g);
     }
   } else if (dtype == MH_F32) {
+    MH_CHECK_ARG(!(g.a_panel || g.w_panel || g.o_panel || g.r_panel), "gemm(f32): panel layouts are bf16 only");
     MH_CHECK_ARG(g.K % 16 == 0 && g.K > 0, "gemm(f32): K=%d must be a positive multiple of 16", g.K);
     MH_CHECK_ARG(g.lda % 4 == 0 && g.ldw % 4 == 0, "gemm(f32): lda/ldw must be multiples of 4");
     MH_LAUNCH((gemm_kernel<float, EPI, 0>), grid, block, 0, s, g);
@@ -576,12 +705,13 @@ int launch(const GemmArgs& g, int dtype, hipStream_t s) {
 }  // namespace
 
 extern "C" int mh_gemm_set_debug(int bits) {
-  g_dbg = bits;
+  g_dbg = bits & 15;
+  g_stagger = bits >> 4;   // shader cycles
   return MH_OK;
 }
 
 extern "C" int mh_gemm_set_variant(int variant) {
-  MH_CHECK_ARG(variant >= 0 && variant <= 2, "gemm_set_variant: variant must be 0, 1 or 2");
+  MH_CHECK_ARG(variant >= 0 && variant <= 3, "gemm_set_variant: variant must be 0..3");
   g_variant = variant;
   return MH_OK;
 }
@@ -595,7 +725,24 @@ extern "C" int mh_gemm_bias_act(const void* A, int64_t lda, const void* W, int64
   GemmArgs g{};
   g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.bias = bias;
   g.residual = residual; g.ldr = residual ? ldr : 8; g.out = out; g.ldo = ldo; g.out_f32 = out_f32;
-  g.M = M; g.N = N; g.K = K; g.act = act; g.dbg = g_dbg;
+  g.M = M; g.N = N; g.K = K; g.act = act; g.dbg = g_dbg & 15; g.stagger = g_stagger;
+  return launch<0>(g, dtype, (hipStream_t)stream);
+}
+
+extern "C" int mh_gemm_bias_act_ex(const void* A, int64_t lda, int a_panel, const void* W, int64_t ldw, int w_panel,
+                                   const float* bias, const void* residual, int64_t ldr, int r_panel, void* out,
+                                   int64_t ldo, int o_panel, int out_f32, int64_t M, int N, int K, int act, int dtype,
+                                   mh_stream_t stream) {
+  MH_CHECK_ARG(A && W && out, "gemm: null pointer");
+  MH_CHECK_ARG(M > 0 && N > 0, "gemm: empty problem M=%lld N=%d", (long long)M, N);
+  MH_CHECK_ARG(act >= MH_ACT_NONE && act <= MH_ACT_SILU, "gemm: unknown activation %d", act);
+  MH_CHECK_ARG(!(o_panel && out_f32), "gemm: fp32 output is row-major only");
+  MH_CHECK_ARG(!o_panel || N % 32 == 0 || true, "gemm: bad panel output");
+  GemmArgs g{};
+  g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.bias = bias;
+  g.residual = residual; g.ldr = residual ? ldr : 8; g.out = out; g.ldo = ldo; g.out_f32 = out_f32;
+  g.M = M; g.N = N; g.K = K; g.act = act; g.dbg = g_dbg & 15; g.stagger = g_stagger;
+  g.a_panel = a_panel; g.w_panel = w_panel; g.o_panel = o_panel; g.r_panel = residual ? r_panel : 0;
   return launch<0>(g, dtype, (hipStream_t)stream);
 }
 
@@ -607,7 +754,85 @@ extern "C" int mh_gemm_qkv(const void* A, int64_t lda, const void* Wqkv, int64_t
   MH_CHECK_ARG(L % 8 == 0, "gemm_qkv: seq_len %d must be a multiple of 8", L);
   GemmArgs g{};
   g.A = A; g.lda = lda; g.W = Wqkv; g.ldw = ldw; g.bias = bqkv; g.ldr = 8; g.ldo = 8;
-  g.M = (int64_t)B * L; g.N = 3 * H; g.K = H;
+  g.M = (int64_t)B * L; g.N = 3 * H; g.K = H; g.stagger = g_stagger;
   g.q = q; g.k = k; g.vt = vt; g.L = L; g.H = H; g.nh = nh; g.dh = H / nh;
   return launch<1>(g, dtype, (hipStream_t)stream);
+}
+
+
+// ---------------------------------------------------------------- nearest-embedding rounding on the fp32 MFMA
+namespace {
+
+#pragma clang fp contract(off)
+__global__ void row_sqnorm_f32_kernel(const float* __restrict__ x, int64_t ldx, float* __restrict__ out, int64_t rows, int E) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  float s = 0.f;
+  for (int c = lane; c < E; c += 64) {
+    const float v = x[row * ldx + c];
+    s += v * v;
+  }
+  s = wave_sum(s);
+  if (lane == 0) out[row] = s;
+}
+
+__global__ void argbest_reduce_kernel(const float* __restrict__ pbest, const int32_t* __restrict__ pidx, int nslots,
+                                      int32_t* __restrict__ idx_out, int64_t rows) {
+  const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= rows) return;
+  float best = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int s = 0; s < nslots; ++s) {   // slots are in increasing column order: strict > keeps the first index
+    const float v = pbest[row * nslots + s];
+    const int i = pidx[row * nslots + s];
+    if (v > best || (v == best && i < bi)) { best = v; bi = i; }
+  }
+  idx_out[row] = bi == 0x7fffffff ? 0 : bi;
+}
+
+}  // namespace
+
+extern "C" size_t mh_round_workspace_bytes(int64_t n_tokens, int E, int V) {
+  const int64_t nslots = 2 * ((V + BN - 1) / BN);
+  const int64_t Ep = (E + 15) / 16 * 16;
+  size_t b = (size_t)n_tokens * 4;                         // |x_n|^2
+  b += (size_t)n_tokens * nslots * 8;                      // partial (score, index)
+  if (Ep != E) b += (size_t)n_tokens * Ep * 4;             // zero-padded copy of x
+  return b + 1024;
+}
+
+// table_pad: [V, E_pad16] fp32 (rows zero-padded to a multiple of 16 columns; == table when E % 16 == 0)
+extern "C" int mh_round_to_embedding_mfma(const float* x, const float* table_pad, const float* table_norm, int32_t* idx,
+                                          int64_t n_tokens, int E, int V, void* workspace, size_t workspace_bytes,
+                                          mh_stream_t stream) {
+  MH_CHECK_ARG(x && table_pad && table_norm && idx && workspace, "round_to_embedding_mfma: null pointer");
+  MH_CHECK_ARG(n_tokens > 0 && E > 0 && V > 0, "round_to_embedding_mfma: bad shape");
+  MH_CHECK_ARG(workspace_bytes >= mh_round_workspace_bytes(n_tokens, E, V), "round_to_embedding_mfma: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  const int nslots = 2 * ceil_div(V, BN);
+  const int Ep = (E + 15) / 16 * 16;
+  char* ws = (char*)workspace;
+  float* rown = (float*)ws; ws += ((size_t)n_tokens * 4 + 255) & ~(size_t)255;
+  float* pbest = (float*)ws; ws += ((size_t)n_tokens * nslots * 4 + 255) & ~(size_t)255;
+  int32_t* pidx = (int32_t*)ws; ws += ((size_t)n_tokens * nslots * 4 + 255) & ~(size_t)255;
+  const float* xa = x;
+  int64_t lda = E;
+  if (Ep != E) {
+    float* xp = (float*)ws;
+    int rc = mh_cast_pad(x, E, xp, Ep, n_tokens, E, n_tokens, MH_F32, stream);
+    if (rc) return rc;
+    xa = xp; lda = Ep;
+  }
+  MH_LAUNCH(row_sqnorm_f32_kernel, dim3((unsigned)((n_tokens + 3) / 4)), dim3(256), 0, s, x, (int64_t)E, rown, n_tokens, E);
+  MH_CHECK_LAUNCH();
+  GemmArgs g{};
+  g.A = xa; g.lda = lda; g.W = table_pad; g.ldw = Ep; g.ldr = 8; g.ldo = 8;
+  g.M = n_tokens; g.N = V; g.K = Ep;
+  g.aux = table_norm; g.rown = rown; g.pbest = pbest; g.pidx = pidx; g.nslots = nslots;
+  int rc = launch<2>(g, MH_F32, s);
+  if (rc) return rc;
+  MH_LAUNCH(argbest_reduce_kernel, dim3((unsigned)((n_tokens + 255) / 256)), dim3(256), 0, s, pbest, pidx, nslots, idx, n_tokens);
+  MH_CHECK_LAUNCH();
+  return MH_OK;
 }

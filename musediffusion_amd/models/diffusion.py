@@ -589,6 +589,8 @@ class _ReverseLoop:
         self.x_start = None if x_start is None else x_start.detach().to(torch.float32).contiguous()
         self.table32 = None if table is None else table.detach().to(torch.float32).contiguous()
         self.table_norm = None if table is None else ops.row_sqnorm(self.table32)
+        self.table_pad = None if table is None else ops.pad_table16(self.table32)
+        self.round_ws = None if table is None else ops.round_workspace(B * L, E, self.table32.shape[0], dev)
         # per-timestep tables on the device
         T = diff.num_timesteps
         self.coef_table = diff._coef_table(kind, eta, dev)
@@ -609,8 +611,10 @@ class _ReverseLoop:
                                     self.B, st), "mh_step_begin")
         self.eng.forward(self.x, self.emb_table, self.emb_row, out=self.model_out)
         if use_round:
-            _lib.check(L_.mh_round_to_embedding(P(self.model_out), P(self.table32), P(self.table_norm), P(self.round_idx),
-                                                self.B * self.L, self.E, self.table32.shape[0], st), "mh_round_to_embedding")
+            _lib.check(L_.mh_round_to_embedding_mfma(P(self.model_out), P(self.table_pad), P(self.table_norm),
+                                                     P(self.round_idx), self.B * self.L, self.E, self.table32.shape[0],
+                                                     P(self.round_ws), self.round_ws.numel(), st),
+                       "mh_round_to_embedding_mfma")
         if in_graph_rng:
             _lib.check(L_.mh_trunc_normal(P(self.noise), self.noise.numel(), float(self.top_p), int(self.diff.rng_seed),
                                           int(self.diff.rng_stream), P(self.state), st), "mh_trunc_normal")

@@ -136,15 +136,35 @@ def add_pos_time_layernorm(x, pos, emb_t, emb_row, gamma, beta, B, L, eps, dtype
     return out
 
 
-def round_to_embedding(x, table, table_norm=None):
+def pad_table16(table):
+    """[V, E] fp32 -> [V, E_pad16] (zero columns); the table itself when E % 16 == 0."""
+    table = _c(table, torch.float32)
+    E = table.shape[1]
+    Ep = (E + 15) // 16 * 16
+    return table if Ep == E else cast_pad(table, Ep, MH_F32)
+
+
+def round_workspace(n_tokens, E, V, device):
+    return torch.empty(int(lib().mh_round_workspace_bytes(n_tokens, E, V)), dtype=torch.uint8, device=device)
+
+
+def round_to_embedding(x, table, table_norm=None, table_pad=None, workspace=None, out=None, mfma=True):
+    """idx[n] = nearest embedding row of x[n] (models/rounding.py:21-28), int32.  mfma=True runs the
+    exact-fp32 MFMA GEMM with the fused arg-best epilogue, mfma=False the plain fp32 VALU kernel."""
     x, table = _c(x, torch.float32), _c(table, torch.float32)
     V, E = table.shape
     n = x.numel() // E
     if table_norm is None:
         table_norm = row_sqnorm(table)
-    idx = torch.empty(n, device=x.device, dtype=torch.int32)
-    check(lib().mh_round_to_embedding(ptr(x), ptr(table), ptr(table_norm), ptr(idx), n, E, V, current_stream()),
-          "mh_round_to_embedding")
+    idx = torch.empty(n, device=x.device, dtype=torch.int32) if out is None else out
+    if mfma:
+        table_pad = pad_table16(table) if table_pad is None else table_pad
+        ws = round_workspace(n, E, V, x.device) if workspace is None else workspace
+        check(lib().mh_round_to_embedding_mfma(ptr(x), ptr(table_pad), ptr(table_norm), ptr(idx), n, E, V, ptr(ws),
+                                               ws.numel(), current_stream()), "mh_round_to_embedding_mfma")
+    else:
+        check(lib().mh_round_to_embedding(ptr(x), ptr(table), ptr(table_norm), ptr(idx), n, E, V, current_stream()),
+              "mh_round_to_embedding")
     return idx
 
 

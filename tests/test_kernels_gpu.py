@@ -91,7 +91,7 @@ GEMM_CASES = [
 
 
 @pytest.mark.parametrize("dtype", [MH_F32, MH_BF16], ids=["f32", "bf16"])
-@pytest.mark.parametrize("glds", [0, 1, 2])
+@pytest.mark.parametrize("glds", [0, 1, 2, 3])
 @pytest.mark.parametrize("case", GEMM_CASES)
 def test_gemm_bias_act(case, dtype, glds):
     M, N, K, act, use_res, out_f32 = case
@@ -194,8 +194,9 @@ def test_rounding_and_logits_exact(V, E):
     ids = torch.randint(0, V, (700,), generator=torch.Generator().manual_seed(51))
     x = tbl[ids] + 0.3 * rnd(700, E, seed=52)
     ref_idx = osa.nearest_token(tbl, x)
-    got = ops.round_to_embedding(x.to(DEV), tbl.to(DEV)).cpu().long()
-    assert torch.equal(got, ref_idx), "rounding: %d mismatches" % int((got != ref_idx).sum())
+    for mfma in (True, False):
+        got = ops.round_to_embedding(x.to(DEV), tbl.to(DEV), mfma=mfma).cpu().long()
+        assert torch.equal(got, ref_idx), "rounding(mfma=%s): %d mismatches" % (mfma, int((got != ref_idx).sum()))
     bias = rnd(V, seed=53, scale=0.1)
     ref_tok = torch.argmax(x @ tbl.T + bias, dim=-1)
     got = ops.logits_argmax(x.to(DEV), tbl.to(DEV), bias.to(DEV)).cpu().long()
@@ -207,8 +208,9 @@ def test_rounding_ties_pick_first_index():
     tbl[17] = tbl[3]          # duplicate row: distance ties exactly
     tbl[30] = tbl[3]
     x = tbl[[3, 17, 30, 5]].clone()
-    got = ops.round_to_embedding(x.to(DEV), tbl.to(DEV)).cpu().tolist()
-    assert got == [3, 3, 3, 5]
+    for mfma in (True, False):
+        got = ops.round_to_embedding(x.to(DEV), tbl.to(DEV), mfma=mfma).cpu().tolist()
+        assert got == [3, 3, 3, 5], (mfma, got)
     bias = torch.zeros(40)
     got = ops.logits_argmax(x.to(DEV), tbl.to(DEV), bias.to(DEV)).cpu()
     ref = torch.argmax(x @ tbl.T, -1)

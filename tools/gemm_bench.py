@@ -17,6 +17,8 @@ ap.add_argument("--H", type=int, default=512)
 ap.add_argument("--F", type=int, default=2048)
 ap.add_argument("--shapes", default="ao,ffn1,ffn2,qkv")
 ap.add_argument("--dbg", type=int, default=0)
+ap.add_argument("--noact", action="store_true")
+ap.add_argument("--panel", type=int, default=0, help="bit0 A, bit1 W, bit2 out, bit3 residual in K32-panel layout (timing only)")
 ap.add_argument("--pad", type=int, default=0, help="extra elements on every leading dimension")
 a = ap.parse_args()
 _lib.lib().mh_gemm_set_variant(a.variant)
@@ -32,10 +34,22 @@ def t(*s):
 
 P = a.pad
 X, Xf = t(M, H + P), t(M, F + P)
+pb = a.panel
+
+
+def gx(A, W, b, R, act, N, K, out):
+    """timing-only launch with selectable operand layouts (buffers are reinterpreted, values are garbage)"""
+    ap_, wp, op_, rp = pb & 1, (pb >> 1) & 1, (pb >> 2) & 1, (pb >> 3) & 1
+    _lib.check(_lib.lib().mh_gemm_bias_act_ex(A.data_ptr(), M if ap_ else A.shape[1], ap_, W.data_ptr(), N if wp else W.shape[1], wp,
+                                              b.data_ptr(), R.data_ptr() if R is not None else None, M if rp else (R.shape[1] if R is not None else 0), rp,
+                                              out.data_ptr(), M if op_ else out.shape[1], op_, 0, M, N, K, {None: 0, "gelu": 2}[act], 1,
+                                              _lib.current_stream()))
+
+
 shapes = {
-    "ao": lambda: ops.gemm_bias_act(X, Wao, b_h, X, None, 1, N=H, K=H, out=o_h),
-    "ffn1": lambda: ops.gemm_bias_act(X, W1, b_f, None, "gelu", 1, N=F, K=H, out=o_f),
-    "ffn2": lambda: ops.gemm_bias_act(Xf, W2, b_h, X, None, 1, N=H, K=F, out=o_h),
+    "ao": lambda: gx(X, Wao, b_h, X, None, H, H, o_h),
+    "ffn1": lambda: gx(X, W1, b_f, None, None if a.noact else "gelu", F, H, o_f),
+    "ffn2": lambda: gx(Xf, W2, b_h, X, None, H, F, o_h),
     "qkv": lambda: _lib.check(_lib.lib().mh_gemm_qkv(X.data_ptr(), H, Wqkv.data_ptr(), H, b_q.data_ptr(), q.data_ptr(),
                                                       k.data_ptr(), vt.data_ptr(), M // 512, 512, H, H // 64, 1,
                                                       _lib.current_stream())),
@@ -56,4 +70,4 @@ for name in a.shapes.split(","):
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / a.reps
-    print("dbg %d %-5s variant %d: %8.1f us  %7.1f TFLOP/s" % (a.dbg, name, a.variant, ms * 1e3, flops[name] / ms / 1e9), flush=True)
+    print("panel %d dbg %d %-5s variant %d: %8.1f us  %7.1f TFLOP/s" % (a.panel, a.dbg, name, a.variant, ms * 1e3, flops[name] / ms / 1e9), flush=True)
