@@ -54,6 +54,13 @@ int mh_cast_pad(const float* in, int64_t ld_in, void* out, int64_t ld_out, int64
 int mh_cast_to_f32(const void* in, int64_t ld_in, float* out, int64_t ld_out, int64_t rows, int64_t cols,
                    int dtype, mh_stream_t stream);
 
+/* Row-major fp32 [rows, cols] -> K32-panel bf16 ([cols_pad/32][ld_rows][32], zero fill) and back
+ * (panel bf16 -> row-major fp32).  The panel layout is described at mh_gemm_bias_act_ex. */
+int mh_pack_panel(const float* in, int64_t ld_in, void* out, int64_t ld_rows, int64_t rows, int64_t cols,
+                  int64_t cols_pad, mh_stream_t stream);
+int mh_unpack_panel_f32(const void* in, int64_t ld_rows, float* out, int64_t ld_out, int64_t rows, int64_t cols,
+                        mh_stream_t stream);
+
 /* out[r] = sum_c table[r,c]^2  (rounding.py:22: emb_norm) */
 int mh_row_sqnorm(const float* table, float* out, int V, int E, mh_stream_t stream);
 
@@ -96,11 +103,20 @@ int mh_gemm_bias_act_ex(const void* A, int64_t lda, int a_panel, const void* W, 
 int mh_gemm_qkv(const void* A, int64_t lda, const void* Wqkv, int64_t ldw, const float* bqkv, void* q,
                 void* k, void* vt, int B, int L, int H, int nh, int dtype, mh_stream_t stream);
 
+/* mh_gemm_qkv with A and/or Wqkv in the K32-panel layout (bf16 big-tile kernel). */
+int mh_gemm_qkv_ex(const void* A, int64_t lda, int a_panel, const void* Wqkv, int64_t ldw, int w_panel,
+                   const float* bqkv, void* q, void* k, void* vt, int B, int L, int H, int nh, int dtype,
+                   mh_stream_t stream);
+
 /* K6   ctx = softmax(q k^T * scale) v, no mask (none is ever passed: diffusion.py:309, network.py:151),
  *      flash-style (scores never materialised).  q,k [B,nh,L,dh], vt [B,nh,dh,L], ctx [B*L, ld_ctx]
  *      with head h at columns [h*dh, (h+1)*dh).  dh in {32,64,128} (bf16) / {16,32,64,128} (f32). */
 int mh_attention_fwd(const void* q, const void* k, const void* vt, void* ctx, int64_t ld_ctx, int B, int L,
                      int nh, int dh, float scale, int dtype, mh_stream_t stream);
+
+/* mh_attention_fwd writing ctx in the K32-panel layout when ctx_panel != 0 (ld_ctx = rows per panel). */
+int mh_attention_fwd_ex(const void* q, const void* k, const void* vt, void* ctx, int64_t ld_ctx, int ctx_panel, int B,
+                        int L, int nh, int dh, float scale, int dtype, mh_stream_t stream);
 
 /* K7/K8 tail  out = LayerNorm(x) * gamma + beta over the last dim (eps 1e-12 in the reference,
  *      network.py:79 and HF BertSelfOutput/BertOutput).  x, out [rows, H] `dtype`. */
@@ -113,6 +129,14 @@ int mh_layernorm(const void* x, const float* gamma, const float* beta, void* out
 int mh_add_pos_time_layernorm(const void* x, int64_t ldx, int x_is_f32, const float* pos, const float* emb_t,
                               const int32_t* emb_row, const float* gamma, const float* beta, void* out,
                               int B, int L, int H, float eps, int dtype, mh_stream_t stream);
+
+/* The two LayerNorm entry points on K32-panel bf16 activations (x may also be the row-major fp32 latent for
+ * the add variant).  One wave normalises 16 rows; every access is a 1-KiB contiguous run. */
+int mh_layernorm_panel(const void* x, int64_t ldx, const float* gamma, const float* beta, void* out, int64_t ldo,
+                       int64_t rows, int H, float eps, mh_stream_t stream);
+int mh_add_pos_time_layernorm_panel(const void* x, int64_t ldx, int x_is_f32, const float* pos, const float* emb_t,
+                                    const int32_t* emb_row, const float* gamma, const float* beta, void* out,
+                                    int64_t ldo, int B, int L, int H, float eps, mh_stream_t stream);
 
 /* ------------------------------------------------------------------ rounding / logits (always fp32) */
 
@@ -230,6 +254,7 @@ typedef struct mh_layer_weights {
 typedef struct mh_denoiser {
   int dtype;           /* mh_dtype of every `const void*` weight and of the activations */
   int E, H, F, nh, nL, Tt, Tt_pad, T4_pad, E_pad, L_max;  /* *_pad: padded to a multiple of 64 */
+  int panel;           /* bf16 only: weights and activations in the K32-panel layout (see mh_gemm_bias_act_ex) */
   int has_proj;        /* E != H: input_up_proj / output_down_proj present (network.py:67-72, :81-86) */
   float ln_eps;
   const void* w_t0;    const float* b_t0;      /* time_embed.0 [4Tt, Tt_pad] */

@@ -42,7 +42,7 @@ class Denoiser(C.Structure):
     """mh_denoiser"""
     _fields_ = ([("dtype", INT)] +
                 [(n, INT) for n in ("E", "H", "F", "nh", "nL", "Tt", "Tt_pad", "T4_pad", "E_pad", "L_max")] +
-                [("has_proj", INT), ("ln_eps", F32)] +
+                [("panel", INT), ("has_proj", INT), ("ln_eps", F32)] +
                 [(n, VP) for n in ("w_t0", "b_t0", "w_t2", "b_t2", "w_up0", "b_up0", "w_up2", "b_up2", "pos",
                                    "ln0_g", "ln0_b", "w_dn0", "b_dn0", "w_dn2", "b_dn2")] +
                 [("layers", C.POINTER(LayerWeights))])
@@ -55,14 +55,20 @@ SIGNATURES = {
     "mh_device_name": (INT, [INT, C.c_char_p, INT]),
     "mh_cast_pad": (INT, [VP, I64, VP, I64, I64, I64, I64, INT, VP]),
     "mh_cast_to_f32": (INT, [VP, I64, VP, I64, I64, I64, INT, VP]),
+    "mh_pack_panel": (INT, [VP, I64, VP, I64, I64, I64, I64, VP]),
+    "mh_unpack_panel_f32": (INT, [VP, I64, VP, I64, I64, I64, VP]),
     "mh_row_sqnorm": (INT, [VP, VP, INT, INT, VP]),
     "mh_embed_gather": (INT, [VP, VP, VP, I64, INT, INT, VP]),
     "mh_timestep_embedding": (INT, [VP, VP, INT, INT, I64, F32, INT, VP]),
     "mh_gemm_bias_act": (INT, [VP, I64, VP, I64, VP, VP, I64, VP, I64, INT, I64, INT, INT, INT, INT, VP]),
     "mh_gemm_bias_act_ex": (INT, [VP, I64, INT, VP, I64, INT, VP, VP, I64, INT, VP, I64, INT, INT, I64, INT, INT, INT, INT, VP]),
     "mh_gemm_qkv": (INT, [VP, I64, VP, I64, VP, VP, VP, VP, INT, INT, INT, INT, INT, VP]),
+    "mh_gemm_qkv_ex": (INT, [VP, I64, INT, VP, I64, INT, VP, VP, VP, VP, INT, INT, INT, INT, INT, VP]),
+    "mh_attention_fwd_ex": (INT, [VP, VP, VP, VP, I64, INT, INT, INT, INT, INT, F32, INT, VP]),
     "mh_attention_fwd": (INT, [VP, VP, VP, VP, I64, INT, INT, INT, INT, F32, INT, VP]),
     "mh_layernorm": (INT, [VP, VP, VP, VP, I64, INT, F32, INT, VP]),
+    "mh_layernorm_panel": (INT, [VP, I64, VP, VP, VP, I64, I64, INT, F32, VP]),
+    "mh_add_pos_time_layernorm_panel": (INT, [VP, I64, INT, VP, VP, VP, VP, VP, VP, I64, INT, INT, INT, F32, VP]),
     "mh_add_pos_time_layernorm": (INT, [VP, I64, INT, VP, VP, VP, VP, VP, VP, INT, INT, INT, F32, INT, VP]),
     "mh_round_to_embedding": (INT, [VP, VP, VP, VP, I64, INT, INT, VP]),
     "mh_round_workspace_bytes": (C.c_size_t, [I64, INT, INT]),

@@ -25,7 +25,7 @@ namespace {
 template <int DH>
 __global__ __launch_bounds__(256) void attn_bf16_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K,
                                                         const bf16* __restrict__ VT, bf16* __restrict__ ctx,
-                                                        int64_t ld_ctx, int L, int nh, float scale_log2e) {
+                                                        int64_t ld_ctx, int L, int nh, float scale_log2e, int ctx_panel) {
   constexpr int CH = DH / 8;            // 16-B chunks per K row
   constexpr int RPB = 128 / DH;         // K rows per 256-B bank row (DH <= 128)
   constexpr int KROWB = DH * 2;
@@ -187,16 +187,20 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const bf16* __restrict__
   const float inv = 1.0f / l_tot;
   const int qr = q0 + lq;
   if (qr < L) {
-    bf16* dst = ctx + ((int64_t)b * L + qr) * ld_ctx + head * DH;
+    const int64_t tok = (int64_t)b * L + qr;
 #pragma unroll
-    for (int dt = 0; dt < DT; ++dt)
+    for (int dt = 0; dt < DT; ++dt) {
+      // row-major: [tok][head*DH + d];  K32-panel: [(head*DH)/32 + dt][ld rows][32] (DH is a multiple of 32)
+      bf16* dst = ctx_panel ? ctx + (((int64_t)(head * DT + dt)) * ld_ctx + tok) * 32
+                            : ctx + tok * ld_ctx + head * DH + dt * 32;
 #pragma unroll
       for (int rg = 0; rg < 4; ++rg) {
         bf16x4 v;
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = (bf16)(o[dt][rg * 4 + e] * inv);
-        *reinterpret_cast<bf16x4*>(dst + dt * 32 + 8 * rg + 4 * h) = v;
+        *reinterpret_cast<bf16x4*>(dst + 8 * rg + 4 * h) = v;
       }
+    }
   }
 }
 
@@ -347,32 +351,41 @@ int launch_f32(const float* q, const float* k, const float* vt, float* ctx, int6
 
 template <int DH>
 int launch_bf16(const bf16* q, const bf16* k, const bf16* vt, bf16* ctx, int64_t ld, int B, int L, int nh,
-                float scale, hipStream_t s) {
+                float scale, int ctx_panel, hipStream_t s) {
   dim3 grid(ceil_div(L, 128), B * nh), block(256);
   MH_LAUNCH((attn_bf16_kernel<DH>), grid, block, 0, s, q, k, vt, ctx, ld, L, nh,
-                     scale * 1.4426950408889634f);
+                     scale * 1.4426950408889634f, ctx_panel);
   MH_CHECK_LAUNCH();
   return MH_OK;
 }
 
 }  // namespace
 
+extern "C" int mh_attention_fwd_ex(const void* q, const void* k, const void* vt, void* ctx, int64_t ld_ctx,
+                                   int ctx_panel, int B, int L, int nh, int dh, float scale, int dtype, mh_stream_t stream);
+
 extern "C" int mh_attention_fwd(const void* q, const void* k, const void* vt, void* ctx, int64_t ld_ctx, int B,
                                 int L, int nh, int dh, float scale, int dtype, mh_stream_t stream) {
+  return mh_attention_fwd_ex(q, k, vt, ctx, ld_ctx, 0, B, L, nh, dh, scale, dtype, stream);
+}
+
+extern "C" int mh_attention_fwd_ex(const void* q, const void* k, const void* vt, void* ctx, int64_t ld_ctx,
+                                   int ctx_panel, int B, int L, int nh, int dh, float scale, int dtype, mh_stream_t stream) {
   MH_CHECK_ARG(q && k && vt && ctx, "attention: null pointer");
   MH_CHECK_ARG(B > 0 && L > 0 && nh > 0, "attention: empty problem");
   MH_CHECK_ARG(L % 8 == 0, "attention: seq_len %d must be a multiple of 8", L);
   hipStream_t s = (hipStream_t)stream;
   if (dtype == MH_BF16) {
-    MH_CHECK_ARG(ld_ctx % 4 == 0, "attention(bf16): ld_ctx must be a multiple of 4");
+    MH_CHECK_ARG(ctx_panel || ld_ctx % 4 == 0, "attention(bf16): ld_ctx must be a multiple of 4");
     const bf16 *Q = (const bf16*)q, *K = (const bf16*)k, *V = (const bf16*)vt;
     switch (dh) {
-      case 32: return launch_bf16<32>(Q, K, V, (bf16*)ctx, ld_ctx, B, L, nh, scale, s);
-      case 64: return launch_bf16<64>(Q, K, V, (bf16*)ctx, ld_ctx, B, L, nh, scale, s);
-      case 128: return launch_bf16<128>(Q, K, V, (bf16*)ctx, ld_ctx, B, L, nh, scale, s);
+      case 32: return launch_bf16<32>(Q, K, V, (bf16*)ctx, ld_ctx, B, L, nh, scale, ctx_panel, s);
+      case 64: return launch_bf16<64>(Q, K, V, (bf16*)ctx, ld_ctx, B, L, nh, scale, ctx_panel, s);
+      case 128: return launch_bf16<128>(Q, K, V, (bf16*)ctx, ld_ctx, B, L, nh, scale, ctx_panel, s);
       default: mh_set_error("attention(bf16): head dim %d not in {32,64,128}", dh); return MH_ERR_UNSUPPORTED;
     }
   } else if (dtype == MH_F32) {
+    MH_CHECK_ARG(!ctx_panel, "attention(f32): panel output is bf16 only");
     const float *Q = (const float*)q, *K = (const float*)k, *V = (const float*)vt;
     switch (dh) {
       case 16: return launch_f32<16>(Q, K, V, (float*)ctx, ld_ctx, B, L, nh, scale, s);

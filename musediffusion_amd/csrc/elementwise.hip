@@ -40,6 +40,24 @@ __global__ void cast_to_f32_kernel(const T* __restrict__ in, int64_t ld_in, floa
   }
 }
 
+// row-major fp32 [rows, cols] -> K32-panel bf16 [cols_pad/32][ld rows][32] (zero fill outside rows x cols)
+__global__ void pack_panel_kernel(const float* __restrict__ in, int64_t ld_in, bf16* __restrict__ out, int64_t ld_rows,
+                                  int64_t rows, int64_t cols, int64_t cols_pad) {
+  const int64_t total = (cols_pad / 32) * ld_rows * 32;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t kb = i / (ld_rows * 32), rem = i % (ld_rows * 32), r = rem / 32, c = kb * 32 + rem % 32;
+    out[i] = (bf16)((r < rows && c < cols) ? in[r * ld_in + c] : 0.f);
+  }
+}
+__global__ void unpack_panel_kernel(const bf16* __restrict__ in, int64_t ld_rows, float* __restrict__ out, int64_t ld_out,
+                                    int64_t rows, int64_t cols) {
+  const int64_t total = rows * cols;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / cols, c = i % cols;
+    out[r * ld_out + c] = (float)in[((c >> 5) * ld_rows + r) * 32 + (c & 31)];
+  }
+}
+
 __global__ void row_sqnorm_kernel(const float* __restrict__ table, float* __restrict__ out, int V, int E) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -222,6 +240,27 @@ extern "C" int mh_cast_to_f32(const void* in, int64_t ld_in, float* out, int64_t
   if (dtype == MH_BF16) MH_LAUNCH((cast_to_f32_kernel<bf16>), dim3(grid), dim3(EW_BLOCK), 0, s, (const bf16*)in, ld_in, out, ld_out, rows, cols);
   else if (dtype == MH_F32) MH_LAUNCH((cast_to_f32_kernel<float>), dim3(grid), dim3(EW_BLOCK), 0, s, (const float*)in, ld_in, out, ld_out, rows, cols);
   else { mh_set_error("cast_to_f32: unknown dtype %d", dtype); return MH_ERR_INVALID; }
+  MH_CHECK_LAUNCH();
+  return MH_OK;
+}
+
+extern "C" int mh_pack_panel(const float* in, int64_t ld_in, void* out, int64_t ld_rows, int64_t rows, int64_t cols,
+                             int64_t cols_pad, mh_stream_t stream) {
+  MH_CHECK_ARG(in && out && rows >= 0 && cols >= 0 && ld_rows >= rows && cols_pad >= cols && cols_pad % 32 == 0 && ld_in >= cols,
+               "pack_panel: bad arguments");
+  if (cols_pad * ld_rows == 0) return MH_OK;
+  MH_LAUNCH(pack_panel_kernel, dim3(ew_grid(cols_pad * ld_rows)), dim3(EW_BLOCK), 0, (hipStream_t)stream, in, ld_in,
+            (bf16*)out, ld_rows, rows, cols, cols_pad);
+  MH_CHECK_LAUNCH();
+  return MH_OK;
+}
+
+extern "C" int mh_unpack_panel_f32(const void* in, int64_t ld_rows, float* out, int64_t ld_out, int64_t rows, int64_t cols,
+                                   mh_stream_t stream) {
+  MH_CHECK_ARG(in && out && rows >= 0 && cols >= 0 && ld_rows >= rows && ld_out >= cols, "unpack_panel_f32: bad arguments");
+  if (rows * cols == 0) return MH_OK;
+  MH_LAUNCH(unpack_panel_kernel, dim3(ew_grid(rows * cols)), dim3(EW_BLOCK), 0, (hipStream_t)stream, (const bf16*)in,
+            ld_rows, out, ld_out, rows, cols);
   MH_CHECK_LAUNCH();
   return MH_OK;
 }

@@ -95,6 +95,7 @@ int check_model(const mh_denoiser* m) {
                    m->T4_pad % 64 == 0 && m->T4_pad >= 4 * m->Tt,
                "denoiser: bad padded sizes");
   MH_CHECK_ARG(m->has_proj == (m->E != m->H), "denoiser: has_proj must equal (E != H)");
+  MH_CHECK_ARG(!m->panel || (m->dtype == MH_BF16 && m->E % 8 == 0 && (m->H / m->nh) % 32 == 0), "denoiser: panel layout needs bf16, E %% 8 == 0 and head dim %% 32 == 0");
   MH_CHECK_ARG(m->layers || m->nL == 0, "denoiser: null layer table");
   return MH_OK;
 }
@@ -141,6 +142,41 @@ extern "C" int mh_denoiser_forward(const mh_denoiser* m, const float* x, const f
   const int H = m->H, F = m->F, dt = m->dtype, dh = m->H / m->nh;
   const float scale = 1.0f / sqrtf((float)dh);
 
+  if (m->panel) {
+    // ---- bf16 throughput path: every activation and weight in the K32-panel layout (ld = rows per panel)
+    const int P = 1;
+    auto gemm = [&](const void* A, const void* W, int64_t w_rows, const float* bias, const void* res, void* o, int of32,
+                    int64_t ldo, int Nout, int K, int act) {
+      return mh_gemm_bias_act_ex(A, N, P, W, w_rows, P, bias, res, N, P, o, ldo, of32 ? 0 : P, of32, N, Nout, K, act, dt, stream);
+    };
+    if (m->has_proj) {
+      if ((rc = mh_pack_panel(x, m->E, w.xin, N, N, m->E, m->E_pad, stream))) return rc;
+      if ((rc = gemm(w.xin, m->w_up0, H, m->b_up0, nullptr, w.buf0, 0, N, H, m->E_pad, MH_ACT_TANH))) return rc;
+      if ((rc = gemm(w.buf0, m->w_up2, H, m->b_up2, nullptr, w.buf1, 0, N, H, H, MH_ACT_NONE))) return rc;
+      if ((rc = mh_add_pos_time_layernorm_panel(w.buf1, N, 0, m->pos, emb_t, emb_row, m->ln0_g, m->ln0_b, w.bufX, N, B, L, H,
+                                                m->ln_eps, stream)))
+        return rc;
+    } else {
+      if ((rc = mh_add_pos_time_layernorm_panel(x, H, 1, m->pos, emb_t, emb_row, m->ln0_g, m->ln0_b, w.bufX, N, B, L, H,
+                                                m->ln_eps, stream)))
+        return rc;
+    }
+    for (int l = 0; l < m->nL; ++l) {
+      const mh_layer_weights& lw = m->layers[l];
+      if ((rc = mh_gemm_qkv_ex(w.bufX, N, P, lw.w_qkv, 3 * H, P, lw.b_qkv, w.q, w.k, w.vt, B, L, H, m->nh, dt, stream))) return rc;
+      if ((rc = mh_attention_fwd_ex(w.q, w.k, w.vt, w.buf0, N, P, B, L, m->nh, dh, scale, dt, stream))) return rc;
+      if ((rc = gemm(w.buf0, lw.w_ao, H, lw.b_ao, w.bufX, w.buf1, 0, N, H, H, MH_ACT_NONE))) return rc;
+      if ((rc = mh_layernorm_panel(w.buf1, N, lw.ln1_g, lw.ln1_b, w.bufX1, N, N, H, m->ln_eps, stream))) return rc;
+      if ((rc = gemm(w.bufX1, lw.w_ff1, F, lw.b_ff1, nullptr, w.ffn, 0, N, F, H, MH_ACT_GELU_ERF))) return rc;
+      if ((rc = gemm(w.ffn, lw.w_ff2, H, lw.b_ff2, w.bufX1, w.buf1, 0, N, H, F, MH_ACT_NONE))) return rc;
+      if ((rc = mh_layernorm_panel(w.buf1, N, lw.ln2_g, lw.ln2_b, w.bufX, N, N, H, m->ln_eps, stream))) return rc;
+    }
+    if (m->has_proj) {
+      if ((rc = gemm(w.bufX, m->w_dn0, H, m->b_dn0, nullptr, w.buf0, 0, N, H, H, MH_ACT_TANH))) return rc;
+      return gemm(w.buf0, m->w_dn2, m->E, m->b_dn2, nullptr, out, 1, m->E, m->E, H, MH_ACT_NONE);
+    }
+    return mh_unpack_panel_f32(w.bufX, N, out, m->E, N, m->E, stream);
+  }
   // ---- embeddings: (up-projection) + position + time, LayerNorm          network.py:141-149
   if (m->has_proj) {
     if ((rc = mh_cast_pad(x, m->E, w.xin, m->E_pad, N, m->E, N, dt, stream))) return rc;

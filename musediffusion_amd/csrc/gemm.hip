@@ -746,8 +746,18 @@ extern "C" int mh_gemm_bias_act_ex(const void* A, int64_t lda, int a_panel, cons
   return launch<0>(g, dtype, (hipStream_t)stream);
 }
 
+extern "C" int mh_gemm_qkv_ex(const void* A, int64_t lda, int a_panel, const void* Wqkv, int64_t ldw, int w_panel,
+                              const float* bqkv, void* q, void* k, void* vt, int B, int L, int H, int nh, int dtype,
+                              mh_stream_t stream);
+
 extern "C" int mh_gemm_qkv(const void* A, int64_t lda, const void* Wqkv, int64_t ldw, const float* bqkv, void* q,
                            void* k, void* vt, int B, int L, int H, int nh, int dtype, mh_stream_t stream) {
+  return mh_gemm_qkv_ex(A, lda, 0, Wqkv, ldw, 0, bqkv, q, k, vt, B, L, H, nh, dtype, stream);
+}
+
+extern "C" int mh_gemm_qkv_ex(const void* A, int64_t lda, int a_panel, const void* Wqkv, int64_t ldw, int w_panel,
+                              const float* bqkv, void* q, void* k, void* vt, int B, int L, int H, int nh, int dtype,
+                              mh_stream_t stream) {
   MH_CHECK_ARG(A && Wqkv && bqkv && q && k && vt, "gemm_qkv: null pointer");
   MH_CHECK_ARG(H % 64 == 0, "gemm_qkv: hidden size %d must be a multiple of 64", H);
   MH_CHECK_ARG(nh > 0 && H % nh == 0 && (H / nh) % 8 == 0, "gemm_qkv: head dim must be a multiple of 8");
@@ -755,6 +765,7 @@ extern "C" int mh_gemm_qkv(const void* A, int64_t lda, const void* Wqkv, int64_t
   GemmArgs g{};
   g.A = A; g.lda = lda; g.W = Wqkv; g.ldw = ldw; g.bias = bqkv; g.ldr = 8; g.ldo = 8;
   g.M = (int64_t)B * L; g.N = 3 * H; g.K = H; g.stagger = g_stagger;
+  g.a_panel = a_panel; g.w_panel = w_panel;
   g.q = q; g.k = k; g.vt = vt; g.L = L; g.H = H; g.nh = nh; g.dh = H / nh;
   return launch<1>(g, dtype, (hipStream_t)stream);
 }

@@ -90,7 +90,110 @@ int launch_ln(const void* x, int64_t ldx, const float* xf32, const float* pos, c
   return MH_OK;
 }
 
+// ---- K32-panel layout ([H/32][ld rows][32], bf16): one wave = 16 rows; lane (r = lane>>2, c = lane&3) owns
+// 8 elements of every panel, so each wave-instruction moves 16 rows x 64 B = 1 KiB of contiguous memory.
+template <int NKB, bool ADD>
+__global__ __launch_bounds__(256) void ln_panel_kernel(const bf16* __restrict__ x, int64_t ldx, const float* __restrict__ xf32,
+                                                       const float* __restrict__ pos, const float* __restrict__ emb_t,
+                                                       const int32_t* __restrict__ emb_row, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, bf16* __restrict__ out, int64_t ldo,
+                                                       int64_t rows, int L, float eps) {
+  constexpr int H = NKB * 32;
+  const int lane = threadIdx.x & 63, r = lane >> 2, c = lane & 3;
+  const int64_t row0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16;
+  if (row0 >= rows) return;
+  int64_t row = row0 + r;
+  const bool valid = row < rows;
+  if (!valid) row = rows - 1;
+  float v[NKB][8];
+  float sum = 0.f;
+  const float* prow = nullptr;
+  const float* trow = nullptr;
+  if constexpr (ADD) {
+    const int64_t b = row / L, l = row % L;
+    prow = pos + l * H;
+    trow = emb_t + (int64_t)(emb_row ? emb_row[b] : (int)b) * H;
+  }
+#pragma unroll
+  for (int kb = 0; kb < NKB; ++kb) {
+    if constexpr (ADD) {
+      if (xf32) load8(xf32 + row * ldx + kb * 32 + c * 8, v[kb]);
+      else load8(x + ((int64_t)kb * ldx + row) * 32 + c * 8, v[kb]);
+      float p[8], t[8];
+      load8(prow + kb * 32 + c * 8, p);
+      load8(trow + kb * 32 + c * 8, t);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[kb][e] = (p[e] + v[kb][e]) + t[e];
+    } else {
+      load8(x + ((int64_t)kb * ldx + row) * 32 + c * 8, v[kb]);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) sum += v[kb][e];
+  }
+  sum += __shfl_xor(sum, 1, 64);
+  sum += __shfl_xor(sum, 2, 64);
+  const float mean = sum / (float)H;
+  float sq = 0.f;
+#pragma unroll
+  for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float d = v[kb][e] - mean;
+      sq += d * d;
+    }
+  sq += __shfl_xor(sq, 1, 64);
+  sq += __shfl_xor(sq, 2, 64);
+  const float rstd = 1.0f / sqrtf(sq / (float)H + eps);
+  if (!valid) return;
+#pragma unroll
+  for (int kb = 0; kb < NKB; ++kb) {
+    float g[8], bt[8], y[8];
+    load8(gamma + kb * 32 + c * 8, g);
+    load8(beta + kb * 32 + c * 8, bt);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) y[e] = (v[kb][e] - mean) * rstd * g[e] + bt[e];
+    store8(out + ((int64_t)kb * ldo + row) * 32 + c * 8, y);
+  }
+}
+
+template <bool ADD>
+int launch_ln_panel(const void* x, int64_t ldx, const float* xf32, const float* pos, const float* emb_t,
+                    const int32_t* emb_row, const float* gamma, const float* beta, void* out, int64_t ldo, int64_t rows,
+                    int L, int H, float eps, hipStream_t s) {
+  dim3 grid((unsigned)((rows + 63) / 64)), block(256);
+#define MH_LNP(N)                                                                                                      \
+  case N:                                                                                                              \
+    MH_LAUNCH((ln_panel_kernel<N, ADD>), grid, block, 0, s, (const bf16*)x, ldx, xf32, pos, emb_t, emb_row, gamma, beta, \
+              (bf16*)out, ldo, rows, L, eps);                                                                          \
+    break;
+  switch (H / 32) {
+    MH_LNP(2) MH_LNP(4) MH_LNP(8) MH_LNP(12) MH_LNP(16) MH_LNP(24)
+    default:
+      mh_set_error("layernorm(panel): hidden size %d not in {64,128,256,384,512,768}", H);
+      return MH_ERR_UNSUPPORTED;
+  }
+#undef MH_LNP
+  MH_CHECK_LAUNCH();
+  return MH_OK;
+}
+
 }  // namespace
+
+extern "C" int mh_layernorm_panel(const void* x, int64_t ldx, const float* gamma, const float* beta, void* out,
+                                  int64_t ldo, int64_t rows, int H, float eps, mh_stream_t stream) {
+  MH_CHECK_ARG(x && gamma && beta && out && rows > 0, "layernorm_panel: bad arguments");
+  return launch_ln_panel<false>(x, ldx, nullptr, nullptr, nullptr, nullptr, gamma, beta, out, ldo, rows, 1, H, eps,
+                                (hipStream_t)stream);
+}
+
+extern "C" int mh_add_pos_time_layernorm_panel(const void* x, int64_t ldx, int x_is_f32, const float* pos,
+                                               const float* emb_t, const int32_t* emb_row, const float* gamma,
+                                               const float* beta, void* out, int64_t ldo, int B, int L, int H, float eps,
+                                               mh_stream_t stream) {
+  MH_CHECK_ARG(x && pos && emb_t && gamma && beta && out && B > 0 && L > 0, "add_pos_time_layernorm_panel: bad arguments");
+  return launch_ln_panel<true>(x_is_f32 ? nullptr : x, ldx, x_is_f32 ? (const float*)x : nullptr, pos, emb_t, emb_row,
+                               gamma, beta, out, ldo, (int64_t)B * L, L, H, eps, (hipStream_t)stream);
+}
 
 extern "C" int mh_layernorm(const void* x, const float* gamma, const float* beta, void* out, int64_t rows, int H,
                             float eps, int dtype, mh_stream_t stream) {

@@ -22,7 +22,7 @@ def _align(n, a=256):
 class DenoiserEngine:
     """Packed weights + scratch for `mh_denoiser_forward` (models/network.py:131-158)."""
 
-    def __init__(self, cfg, dtype, device):
+    def __init__(self, cfg, dtype, device, panel=True):
         # cfg: dict(E, H, F, nh, nL, Tt, L_max)
         self.cfg = dict(cfg)
         self.dtype = ops.dtype_code(dtype)
@@ -31,6 +31,10 @@ class DenoiserEngine:
         c = self.cfg
         c["E_pad"], c["Tt_pad"], c["T4_pad"] = ops.pad64(c["E"]), ops.pad64(c["Tt"]), ops.pad64(4 * c["Tt"])
         c["has_proj"] = int(c["E"] != c["H"])
+        # K32-panel layout for every bf16 weight / activation when the shapes allow it
+        dh = c["H"] // c["nh"]
+        c["panel"] = int(self.dtype == MH_BF16 and panel and c["E"] % 8 == 0 and dh % 32 == 0 and
+                         c["H"] // 32 in (2, 4, 8, 12, 16, 24))
         self._plan = self._make_plan()
         self.arena = torch.zeros(self._plan["total"], dtype=torch.uint8, device=self.device)
         self._ws = None
@@ -79,7 +83,7 @@ class DenoiserEngine:
     def _fill_descriptor(self):
         c, d = self.cfg, self._desc
         d.dtype = self.dtype
-        for k in ("E", "H", "F", "nh", "nL", "Tt", "Tt_pad", "T4_pad", "E_pad", "L_max", "has_proj"):
+        for k in ("E", "H", "F", "nh", "nL", "Tt", "Tt_pad", "T4_pad", "E_pad", "L_max", "has_proj", "panel"):
             setattr(d, k, int(c[k]))
         d.ln_eps = 1e-12
         for k in ("w_t0", "b_t0", "w_t2", "b_t2", "pos", "ln0_g", "ln0_b"):
@@ -92,12 +96,16 @@ class DenoiserEngine:
         d.layers = C.cast(self._layers, C.POINTER(LayerWeights))
 
     # ------------------------------------------------------------------ packing
-    def _put_mat(self, name, w, row0=0):
+    def _put_mat(self, name, w):
         _, off, rows, kpad = self._plan[name]
         w = w.detach().to(self.device, torch.float32).contiguous()
         r, k = w.shape
-        dst = self.arena.data_ptr() + off + row0 * kpad * self.es
-        check(lib().mh_cast_pad(ptr(w), k, dst, kpad, r, k, r, self.dtype, current_stream()), "mh_cast_pad")
+        assert r == rows and k <= kpad, (name, w.shape, rows, kpad)
+        dst = self.arena.data_ptr() + off
+        if self.cfg["panel"] and not name.startswith("w_t"):   # time MLP runs once per table build: row-major kernel
+            check(lib().mh_pack_panel(ptr(w), k, dst, rows, r, k, kpad, current_stream()), "mh_pack_panel")
+        else:
+            check(lib().mh_cast_pad(ptr(w), k, dst, kpad, r, k, r, self.dtype, current_stream()), "mh_cast_pad")
 
     def _put_vec(self, name, v, elem0=0):
         _, off, n, _ = self._plan[name]
@@ -120,8 +128,9 @@ class DenoiserEngine:
         self._put_vec("ln0_g", sd["LayerNorm.weight"]); self._put_vec("ln0_b", sd["LayerNorm.bias"])
         for l in range(c["nL"]):
             s, p = "input_transformers.layer.%d." % l, "l%d." % l
+            qkv = [sd[s + "attention.self.%s.weight" % nm].detach().to(self.device, torch.float32) for nm in ("query", "key", "value")]
+            self._put_mat(p + "w_qkv", torch.cat(qkv, dim=0))          # one [3H, H] matrix: a single projection GEMM
             for i, nm in enumerate(("query", "key", "value")):
-                self._put_mat(p + "w_qkv", sd[s + "attention.self.%s.weight" % nm], row0=i * H)
                 self._put_vec(p + "b_qkv", sd[s + "attention.self.%s.bias" % nm], elem0=i * H)
             self._put_mat(p + "w_ao", sd[s + "attention.output.dense.weight"])
             self._put_vec(p + "b_ao", sd[s + "attention.output.dense.bias"])
