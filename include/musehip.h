@@ -118,6 +118,10 @@ int mh_attention_fwd(const void* q, const void* k, const void* vt, void* ctx, in
 int mh_attention_fwd_ex(const void* q, const void* k, const void* vt, void* ctx, int64_t ld_ctx, int ctx_panel, int B,
                         int L, int nh, int dh, float scale, int dtype, mh_stream_t stream);
 
+/* A/B switch: 1 (default) lets the bf16 kernel keep K and V^T of a (batch, head) resident in LDS when they
+ * fit (<= 128 KiB), 0 forces the tiled double-buffered kernel. */
+int mh_attention_set_variant(int resident);
+
 /* K7/K8 tail  out = LayerNorm(x) * gamma + beta over the last dim (eps 1e-12 in the reference,
  *      network.py:79 and HF BertSelfOutput/BertOutput).  x, out [rows, H] `dtype`. */
 int mh_layernorm(const void* x, const float* gamma, const float* beta, void* out, int64_t rows, int H,

@@ -17,6 +17,8 @@
 //   register-staged (loads for tile t+1 are issued before the MFMAs of tile t).
 // f32 kernel: plain VALU fp32 (the f32 MFMA rate equals the VALU rate on gfx950), 64 queries per
 // workgroup, exact expf; this is the parity path, kept simple on purpose.
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -114,6 +116,7 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const bf16* __restrict__
     const char* kb = smem + cur * BUF;
     const char* vb = kb + KT_BYTES;
 
+    auto compute = [&](auto masked) {
     // ---- S^T tiles: [2 x 32 keys][32 queries]
     f32x16 s[2];
 #pragma unroll
@@ -130,7 +133,7 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const bf16* __restrict__
     }
     // ---- online softmax; register r of tile kt is key t*64 + kt*32 + (r&3) + 8(r>>2) + 4h
     const int k0 = t * 64;
-    if (k0 + 64 > L) {
+    if constexpr (decltype(masked)::value) {
 #pragma unroll
       for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -178,6 +181,9 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const bf16* __restrict__
           o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[dt], 0, 0, 0);
         }
       }
+    };
+    if (t * 64 + 64 > L) compute(std::true_type{});
+    else compute(std::false_type{});
     if (t + 1 < ntiles) commit(cur ^ 1);
     __syncthreads();
   }
@@ -199,6 +205,197 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const bf16* __restrict__
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = (bf16)(o[dt][rg * 4 + e] * inv);
         *reinterpret_cast<bf16x4*>(dst + 8 * rg + 4 * h) = v;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------ bf16 / MFMA, K and V resident
+// When the whole K and V^T of one (batch, head) fit in LDS (2 * L * dh * 2 bytes <= 128 KiB: L <= 512 at dh 64)
+// one 8-wave workgroup per (batch, head) loads them ONCE (the tiled kernel re-reads them for every 128-query block
+// and pays a barrier per 64-key tile), then every wave walks its 32-query tiles over all keys with no further
+// synchronisation.  Same fragment layouts / swizzles / online softmax as attn_bf16_kernel.
+template <int DH>
+__global__ __launch_bounds__(512) void attn_res_bf16_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K,
+                                                            const bf16* __restrict__ VT, bf16* __restrict__ ctx,
+                                                            int64_t ld_ctx, int L, int nh, float scale_log2e, int ctx_panel) {
+  constexpr int CH = DH / 8, RPB = 128 / DH, KROWB = DH * 2;
+  constexpr int KT_BYTES = 64 * KROWB, VT_BYTES = DH * 128;
+  constexpr int KS = DH / 16, DT = DH / 32;
+  extern __shared__ __attribute__((aligned(16))) char smem_dyn[];
+  const int ntiles = (L + 63) / 64;
+  char* kbase = smem_dyn;
+  char* vbase = smem_dyn + ntiles * KT_BYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = lane >> 5, lq = lane & 31;
+  const int bh = blockIdx.x, b = bh / nh, head = bh % nh;
+  const bf16* Qb = Q + (int64_t)bh * L * DH;
+  const bf16* Kb = K + (int64_t)bh * L * DH;
+  const bf16* Vb = VT + (int64_t)bh * DH * L;
+
+  // ---- stage all of K ([keys][DH], swizzled 16-B chunks) and V^T (per 64-key tile [DH][64 keys], key-permuted)
+  // all global loads are issued before the first LDS write (8 + 8 independent 16-B loads per thread at L = 512):
+  // a load -> store loop would expose one full memory latency per iteration
+  const int Lp = ntiles * 64;
+  constexpr int MAXIT = (64 * 1024 / 16) / 512;   // 16-B chunks per thread per operand when the operand fills 64 KiB
+  const int cpr = Lp / 8;                          // 16-B chunks per V^T row
+  f32x4 kreg[MAXIT], vreg[MAXIT];
+#pragma unroll
+  for (int i = 0; i < MAXIT; ++i) {
+    const int qd = tid + 512 * i;
+    if (qd < Lp * CH) {
+      const int row = qd / CH, c = qd % CH;
+      const int kr = row < L ? row : L - 1;
+      kreg[i] = *reinterpret_cast<const f32x4*>(Kb + (int64_t)kr * DH + c * 8);
+    }
+    if (qd < DH * cpr) {
+      const int d = qd / cpr, key = (qd % cpr) * 8;
+      vreg[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (key < L) vreg[i] = *reinterpret_cast<const f32x4*>(Vb + (int64_t)d * L + key);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < MAXIT; ++i) {
+    const int qd = tid + 512 * i;
+    if (qd < Lp * CH) {
+      const int row = qd / CH, c = qd % CH;
+      *reinterpret_cast<f32x4*>(kbase + row * KROWB + ((c ^ ((row / RPB) & (CH - 1))) << 4)) = kreg[i];
+    }
+    if (qd < DH * cpr) {
+      const int d = qd / cpr, cg = qd % cpr;
+      const int t = cg >> 3, c = cg & 7, sblk = c >> 1, sw = (d >> 1) & 7, half = (c & 1) * 8;
+      typedef __attribute__((ext_vector_type(2))) float f32x2;
+      char* vb = vbase + t * VT_BYTES + d * 128;
+      *reinterpret_cast<f32x2*>(vb + (((2 * sblk) ^ sw) << 4) + half) = f32x2{vreg[i][0], vreg[i][1]};
+      *reinterpret_cast<f32x2*>(vb + (((2 * sblk + 1) ^ sw) << 4) + half) = f32x2{vreg[i][2], vreg[i][3]};
+    }
+  }
+  __syncthreads();
+
+  // Each wave walks TWO 32-query tiles at once (tiles wave and wave + 8, ...): two independent
+  // S -> softmax -> PV chains in one instruction stream, so the MFMAs of one hide the exp / max / sum latency
+  // of the other.  Row max and row sum are reduced as 4-way trees, not 32-long dependent chains.
+  const int nq = (L + 31) / 32;
+  for (int qt0 = wave; qt0 < nq; qt0 += 16) {
+    int q0[2];
+    bool act[2];
+    bf16x8 qf[2][KS];
+    f32x16 o[2][DT];
+    float m_run[2], l_run[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int qt = qt0 + 8 * u;
+      act[u] = qt < nq;
+      q0[u] = (act[u] ? qt : qt0) * 32;
+      int qr = q0[u] + lq; if (qr >= L) qr = L - 1;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) qf[u][ks] = *reinterpret_cast<const bf16x8*>(Qb + (int64_t)qr * DH + 16 * ks + 8 * h);
+#pragma unroll
+      for (int i = 0; i < DT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[u][i][r] = 0.f;
+      m_run[u] = -INFINITY; l_run[u] = 0.f;
+    }
+    auto tile = [&](int t, auto masked) {   // masked: compile-time flag, only the ragged last tile pays for key masking
+      const char* kb = kbase + t * KT_BYTES;
+      const char* vb = vbase + t * VT_BYTES;
+      const int k0 = t * 64;
+      f32x16 s[2][2];
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt) {
+        const int row = kt * 32 + lq;
+        const int sw = (row / RPB) & (CH - 1);
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) s[u][kt][r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kb + row * KROWB + (((2 * ks + h) ^ sw) << 4));
+#pragma unroll
+          for (int u = 0; u < 2; ++u) s[u][kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[u][ks], s[u][kt], 0, 0, 0);
+        }
+      }
+      float alpha[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        if constexpr (decltype(masked)::value) {
+#pragma unroll
+          for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+              if (k0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h >= L) s[u][kt][r] = -INFINITY;
+        }
+        float mx4[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+          for (int r = 0; r < 16; r += 4)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) mx4[e] = fmaxf(mx4[e], s[u][kt][r + e]);
+        float mx = fmaxf(fmaxf(mx4[0], mx4[1]), fmaxf(mx4[2], mx4[3]));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run[u], mx);
+        alpha[u] = __builtin_amdgcn_exp2f((m_run[u] - m_new) * scale_log2e);
+        const float mb = m_new * scale_log2e;
+        float ps4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float p = __builtin_amdgcn_exp2f(s[u][kt][r] * scale_log2e - mb);
+            s[u][kt][r] = p;
+            ps4[r & 3] += p;
+          }
+        l_run[u] = l_run[u] * alpha[u] + ((ps4[0] + ps4[1]) + (ps4[2] + ps4[3]));
+        m_run[u] = m_new;
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int i = 0; i < DT; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o[u][i][r] *= alpha[u];
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          bf16x8 pf[2];
+#pragma unroll
+          for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pf[u][j] = (bf16)s[u][kt][8 * s2 + j];
+          const int sp = 2 * kt + s2;
+#pragma unroll
+          for (int dt = 0; dt < DT; ++dt) {
+            const int d = dt * 32 + lq;
+            const bf16x8 vf = *reinterpret_cast<const bf16x8*>(vb + d * 128 + (((2 * sp + h) ^ ((d >> 1) & 7)) << 4));
+#pragma unroll
+            for (int u = 0; u < 2; ++u) o[u][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[u], o[u][dt], 0, 0, 0);
+          }
+        }
+    };
+    const int nfull = L / 64;
+    for (int t = 0; t < nfull; ++t) tile(t, std::false_type{});
+    if (nfull < ntiles) tile(nfull, std::true_type{});
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const float inv = 1.0f / (l_run[u] + __shfl_xor(l_run[u], 32, 64));
+      const int qr = q0[u] + lq;
+      if (act[u] && qr < L) {
+        const int64_t tok = (int64_t)b * L + qr;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+          bf16* dst = ctx_panel ? ctx + (((int64_t)(head * DT + dt)) * ld_ctx + tok) * 32 : ctx + tok * ld_ctx + head * DH + dt * 32;
+#pragma unroll
+          for (int rg = 0; rg < 4; ++rg) {
+            bf16x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = (bf16)(o[u][dt][rg * 4 + e] * inv);
+            *reinterpret_cast<bf16x4*>(dst + 8 * rg + 4 * h) = v;
+          }
+        }
       }
     }
   }
@@ -333,6 +530,8 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(const float* __restrict__
   }
 }
 
+int g_attn_resident = 1;
+
 template <int DH>
 int launch_f32(const float* q, const float* k, const float* vt, float* ctx, int64_t ld, int B, int L, int nh,
                float scale, hipStream_t s) {
@@ -352,6 +551,19 @@ int launch_f32(const float* q, const float* k, const float* vt, float* ctx, int6
 template <int DH>
 int launch_bf16(const bf16* q, const bf16* k, const bf16* vt, bf16* ctx, int64_t ld, int B, int L, int nh,
                 float scale, int ctx_panel, hipStream_t s) {
+  const size_t res_bytes = (size_t)ceil_div(L, 64) * 64 * DH * 4;   // K + V^T of one (batch, head)
+  if (g_attn_resident && res_bytes <= 128 * 1024 && L >= 128) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      MH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_res_bf16_kernel<DH>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+      attr_set = true;
+    }
+    MH_LAUNCH((attn_res_bf16_kernel<DH>), dim3(B * nh), dim3(512), res_bytes, s, q, k, vt, ctx, ld, L, nh,
+              scale * 1.4426950408889634f, ctx_panel);
+    MH_CHECK_LAUNCH();
+    return MH_OK;
+  }
   dim3 grid(ceil_div(L, 128), B * nh), block(256);
   MH_LAUNCH((attn_bf16_kernel<DH>), grid, block, 0, s, q, k, vt, ctx, ld, L, nh,
                      scale * 1.4426950408889634f, ctx_panel);
@@ -360,6 +572,11 @@ int launch_bf16(const bf16* q, const bf16* k, const bf16* vt, bf16* ctx, int64_t
 }
 
 }  // namespace
+
+extern "C" int mh_attention_set_variant(int resident) {
+  g_attn_resident = resident ? 1 : 0;
+  return MH_OK;
+}
 
 extern "C" int mh_attention_fwd_ex(const void* q, const void* k, const void* vt, void* ctx, int64_t ld_ctx,
                                    int ctx_panel, int B, int L, int nh, int dh, float scale, int dtype, mh_stream_t stream);
