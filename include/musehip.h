@@ -103,6 +103,12 @@ int mh_gemm_bias_act_ex(const void* A, int64_t lda, int a_panel, const void* W, 
 int mh_gemm_qkv(const void* A, int64_t lda, const void* Wqkv, int64_t ldw, const float* bqkv, void* q,
                 void* k, void* vt, int B, int L, int H, int nh, int dtype, mh_stream_t stream);
 
+/* Batched out[b] = A[b] W[b]^T (+ bias): `batch` independent problems `stride*` elements apart (training path:
+ * per-(batch, head) attention backward products).  Row-major operands. */
+int mh_gemm_batched(const void* A, int64_t lda, int64_t strideA, const void* W, int64_t ldw, int64_t strideW,
+                    const float* bias, void* out, int64_t ldo, int64_t strideO, int out_f32, int batch, int64_t M, int N,
+                    int K, int dtype, mh_stream_t stream);
+
 /* mh_gemm_qkv with A and/or Wqkv in the K32-panel layout (bf16 big-tile kernel). */
 int mh_gemm_qkv_ex(const void* A, int64_t lda, int a_panel, const void* Wqkv, int64_t ldw, int w_panel,
                    const float* bqkv, void* q, void* k, void* vt, int B, int L, int H, int nh, int dtype,
@@ -211,6 +217,50 @@ int mh_ddim_epilogue(const float* model_out, const float* x_t, const float* nois
  *      step_counter: device uint32 (may be NULL = 0); lets a captured graph advance the stream. */
 int mh_trunc_normal(float* out, int64_t n, float bound, uint64_t seed, uint32_t stream_id,
                     const uint32_t* step_counter, mh_stream_t stream);
+
+/* ------------------------------------------------------------------ training path (forward + backward pieces)
+ * training_losses (models/diffusion.py:594-699) under utils/train_util.py:188-232.  Every backward matrix
+ * product is brought to the forward's "A W^T" form by the permutes / transposes below and runs on the same
+ * GEMM kernels; reductions are fp32 and deterministic (two-stage) except the embedding scatter-add. */
+
+/* out[b][c][r] = in[b][r][c] */
+int mh_transpose(const void* in, int64_t ld_in, int64_t stride_in, void* out, int64_t ld_out, int64_t stride_out, int rows,
+                 int cols, int batch, int dtype, mh_stream_t stream);
+/* mode 0: tokens [B*L, ld_tok] -> heads [B,nh,L,dh]; 1: heads -> tokens; 2: tokens -> transposed heads [B,nh,dh,L] */
+int mh_head_permute(const void* in, void* out, int64_t ld_tok, int B, int L, int nh, int dh, int mode, int dtype,
+                    mh_stream_t stream);
+/* out[b, c] (+)= sum_r in[b][r, c]  (bias / LayerNorm-parameter / position / time-embedding gradients);
+ * partial: [batch, n_partial, cols] fp32 scratch */
+int mh_col_sum(const void* in, int64_t ld, int64_t rows, int cols, int batch, int64_t stride_in, float* partial, int n_partial,
+               float* out, int accumulate, int dtype, mh_stream_t stream);
+/* out[b,l,:] = pos[l,:] + x[b,l,:] + emb[b,:]  (network.py:146-148; the training path keeps this pre-LayerNorm sum) */
+int mh_add_pos_time(const void* x, int64_t ldx, const float* pos, const float* emb, void* out, int B, int L, int H, int dtype,
+                    mh_stream_t stream);
+/* y = act(x) and dx = dy * act'(x) with x the saved PRE-activation (tanh / exact-erf GELU / SiLU) */
+int mh_act_fwd(const void* x, void* y, int64_t n, int act, int dtype, mh_stream_t stream);
+int mh_act_bwd(const void* dy, const void* x, void* dx, int64_t n, int act, int dtype, mh_stream_t stream);
+/* LayerNorm backward: dx, and dgamma / dbeta (+)= ...; partial: [2, n_partial, H] fp32 scratch */
+int mh_layernorm_bwd(const void* x, const void* dy, const float* gamma, void* dx, float* partial, int n_partial, float* dgamma,
+                     float* dbeta, int accumulate, int64_t rows, int H, float eps, int dtype, mh_stream_t stream);
+/* attention probabilities: P = softmax(S * scale) in place; dS = P o (dP - rowsum(dP o P)) * scale in place on dP */
+int mh_softmax_rows(void* s_inout, int64_t rows, int L, int64_t ld, float scale, int dtype, mh_stream_t stream);
+int mh_softmax_bwd_rows(const void* p, void* dp_inout, int64_t rows, int L, int64_t ld, float scale, int dtype, mh_stream_t stream);
+/* token cross-entropy over fp32 logits [n, V] (diffusion.py:556-575): loss[n] = lse - logit[target];
+ * dlogits = (softmax - onehot) * grad[n], written in `dtype` with columns [V, Vpad) zeroed */
+int mh_cross_entropy_fwd(const float* logits, int64_t ld, const int32_t* target, float* loss, float* lse, int64_t n, int V,
+                         mh_stream_t stream);
+int mh_cross_entropy_bwd(const float* logits, int64_t ld, const int32_t* target, const float* lse, const float* grad, void* dlogits,
+                         int64_t ldd, int64_t n, int V, int Vpad, int dtype, mh_stream_t stream);
+/* mean_flat((scale_a * a - b)^2) per batch row (diffusion.py:627-639; b NULL = 0) and its gradient */
+int mh_sqdiff_mean(const float* a, const float* b, float scale_a, float* out, int B, int64_t per_batch, mh_stream_t stream);
+int mh_sqdiff_bwd(const float* a, const float* b, float scale_a, const float* grad, float* da, float* db, int accumulate, int B,
+                  int64_t per_batch, mh_stream_t stream);
+int mh_add_inplace(void* dst, const void* src, int64_t n, int dtype, mh_stream_t stream);
+/* table[ids[n], :] += src[n, :]  (word_embedding gradient; fp32 atomics) */
+int mh_scatter_add_rows(const float* src, const int32_t* ids, float* table, int64_t n, int E, int V, mh_stream_t stream);
+/* q_sample backward: dst[b,i] (+)= src[b,i] * (mask[token] == 0 ? 1 : scale[b]) */
+int mh_scale_rows(const float* src, const float* scale, const int32_t* mask, float* dst, int accumulate, int B, int64_t per_batch,
+                  int E, mh_stream_t stream);
 
 /* ------------------------------------------------------------------ captured reverse step support */
 

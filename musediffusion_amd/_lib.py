@@ -62,6 +62,7 @@ SIGNATURES = {
     "mh_timestep_embedding": (INT, [VP, VP, INT, INT, I64, F32, INT, VP]),
     "mh_gemm_bias_act": (INT, [VP, I64, VP, I64, VP, VP, I64, VP, I64, INT, I64, INT, INT, INT, INT, VP]),
     "mh_gemm_bias_act_ex": (INT, [VP, I64, INT, VP, I64, INT, VP, VP, I64, INT, VP, I64, INT, INT, I64, INT, INT, INT, INT, VP]),
+    "mh_gemm_batched": (INT, [VP, I64, I64, VP, I64, I64, VP, VP, I64, I64, INT, INT, I64, INT, INT, INT, VP]),
     "mh_gemm_qkv": (INT, [VP, I64, VP, I64, VP, VP, VP, VP, INT, INT, INT, INT, INT, VP]),
     "mh_gemm_qkv_ex": (INT, [VP, I64, INT, VP, I64, INT, VP, VP, VP, VP, INT, INT, INT, INT, INT, VP]),
     "mh_attention_fwd_ex": (INT, [VP, VP, VP, VP, I64, INT, INT, INT, INT, INT, F32, INT, VP]),
@@ -79,6 +80,22 @@ SIGNATURES = {
     "mh_p_sample_epilogue": (INT, [VP, VP, VP, VP, VP, VP, INT, INT, VP, INT, VP, VP, VP, VP, INT, I64, INT, VP]),
     "mh_ddim_epilogue": (INT, [VP, VP, VP, VP, VP, VP, INT, INT, VP, INT, VP, VP, VP, INT, I64, INT, VP]),
     "mh_trunc_normal": (INT, [VP, I64, F32, C.c_uint64, C.c_uint32, VP, VP]),
+    "mh_transpose": (INT, [VP, I64, I64, VP, I64, I64, INT, INT, INT, INT, VP]),
+    "mh_head_permute": (INT, [VP, VP, I64, INT, INT, INT, INT, INT, INT, VP]),
+    "mh_col_sum": (INT, [VP, I64, I64, INT, INT, I64, VP, INT, VP, INT, INT, VP]),
+    "mh_add_pos_time": (INT, [VP, I64, VP, VP, VP, INT, INT, INT, INT, VP]),
+    "mh_act_fwd": (INT, [VP, VP, I64, INT, INT, VP]),
+    "mh_act_bwd": (INT, [VP, VP, VP, I64, INT, INT, VP]),
+    "mh_layernorm_bwd": (INT, [VP, VP, VP, VP, VP, INT, VP, VP, INT, I64, INT, F32, INT, VP]),
+    "mh_softmax_rows": (INT, [VP, I64, INT, I64, F32, INT, VP]),
+    "mh_softmax_bwd_rows": (INT, [VP, VP, I64, INT, I64, F32, INT, VP]),
+    "mh_cross_entropy_fwd": (INT, [VP, I64, VP, VP, VP, I64, INT, VP]),
+    "mh_cross_entropy_bwd": (INT, [VP, I64, VP, VP, VP, VP, I64, I64, INT, INT, INT, VP]),
+    "mh_sqdiff_mean": (INT, [VP, VP, F32, VP, INT, I64, VP]),
+    "mh_sqdiff_bwd": (INT, [VP, VP, F32, VP, VP, VP, INT, INT, I64, VP]),
+    "mh_add_inplace": (INT, [VP, VP, I64, INT, VP]),
+    "mh_scatter_add_rows": (INT, [VP, VP, VP, I64, INT, INT, VP]),
+    "mh_scale_rows": (INT, [VP, VP, VP, VP, INT, INT, I64, INT, VP]),
     "mh_step_begin": (INT, [VP, VP, VP, VP, VP, INT, VP]),
     "mh_step_end": (INT, [VP, VP]),
     "mh_gemm_set_variant": (INT, [INT]),

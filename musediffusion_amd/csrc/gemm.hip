@@ -35,6 +35,7 @@ struct GemmArgs {
   // EPI 2 (nearest-embedding scores): aux[col] = |W_col|^2, rown[row] = |x_row|^2, partial best per (row, slot)
   const float* aux; const float* rown; float* pbest; int32_t* pidx; int nslots;
   int a_panel, w_panel, o_panel, r_panel;  // operand stored as K32 panels: [cols/32][ld rows][32]
+  int64_t sA, sW, sO, sR;  // batch strides in elements (grid.y = batch index)
   int stagger;
   int dbg;  // timing-only ablation bits (mh_gemm_set_debug): 1 no DMA, 2 no MFMA, 4 no stores
 };
@@ -76,8 +77,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
   const int bid = xcd_remap(blockIdx.x, gridDim.x);
   const int64_t m0 = (int64_t)(bid / tiles_n) * BM;
   const int n0 = (bid % tiles_n) * BN;
-  const T* __restrict__ A = reinterpret_cast<const T*>(g.A);
-  const T* __restrict__ W = reinterpret_cast<const T*>(g.W);
+  const T* __restrict__ A = reinterpret_cast<const T*>(g.A) + (int64_t)blockIdx.y * g.sA;
+  const T* __restrict__ W = reinterpret_cast<const T*>(g.W) + (int64_t)blockIdx.y * g.sW;
   const int nk = g.K / BK;
   constexpr int EPC = 16 / sizeof(T);  // elements per 16-B chunk
 
@@ -195,9 +196,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
   // ---- epilogue: each wave stages 32 rows x 64 cols of fp32 at a time in its own LDS region
   float* Cs = reinterpret_cast<float*>(smem) + wave * (32 * CS_LD);
   const bool vec_ok = (g.ldo % 8 == 0) && (g.ldr % 8 == 0);
-  T* outT = reinterpret_cast<T*>(g.out);
-  float* outF = reinterpret_cast<float*>(g.out);
-  const T* res = reinterpret_cast<const T*>(g.residual);
+  T* outT = reinterpret_cast<T*>(g.out) + (int64_t)blockIdx.y * g.sO;
+  float* outF = reinterpret_cast<float*>(g.out) + (int64_t)blockIdx.y * g.sO;
+  const T* res = g.residual ? reinterpret_cast<const T*>(g.residual) + (int64_t)blockIdx.y * g.sR : nullptr;
   const int wcol0 = n0 + wn * 64;                      // first column of this wave's region
 #pragma unroll
   for (int p = 0; p < 2; ++p) {
@@ -472,14 +473,14 @@ __global__ __launch_bounds__(PP ? 512 : 256, PP ? 1 : 2) void gemm_big_kernel(co
     for (int j = 0; j < 4; ++j) {
       const int r16 = (wave * 4 + j) * 16;
       int64_t ra = m0 + r16 + rl; if (ra >= g.M) ra = g.M - 1;
-      srcA[j] = reinterpret_cast<const char*>(g.A) + (ra * a_row + lc * 8) * 2;
+      srcA[j] = reinterpret_cast<const char*>(g.A) + ((int64_t)blockIdx.y * g.sA + ra * a_row + lc * 8) * 2;
       ldsA[j] = r16 * 64;
     }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int r16 = (wave * 2 + j) * 16;
       int rw = n0 + r16 + rl; if (rw >= g.N) rw = g.N - 1;
-      srcW[j] = reinterpret_cast<const char*>(g.W) + ((int64_t)rw * w_row + lc * 8) * 2;
+      srcW[j] = reinterpret_cast<const char*>(g.W) + ((int64_t)blockIdx.y * g.sW + (int64_t)rw * w_row + lc * 8) * 2;
       ldsW[j] = r16 * 64;
     }
   }
@@ -576,9 +577,9 @@ __global__ __launch_bounds__(PP ? 512 : 256, PP ? 1 : 2) void gemm_big_kernel(co
   } else {
     big_mainloop<true, DBG, PP>(acc, smem, srcA, srcW, ldsA, ldsW, nk, a_off, b_offs, kstepA, kstepW, group);
     if (!tile_valid) return;
-    bf16* outT = reinterpret_cast<bf16*>(g.out);
-    float* outF = reinterpret_cast<float*>(g.out);
-    const bf16* res = reinterpret_cast<const bf16*>(g.residual);
+    bf16* outT = reinterpret_cast<bf16*>(g.out) + (int64_t)blockIdx.y * g.sO;
+    float* outF = reinterpret_cast<float*>(g.out) + (int64_t)blockIdx.y * g.sO;
+    const bf16* res = g.residual ? reinterpret_cast<const bf16*>(g.residual) + (int64_t)blockIdx.y * g.sR : nullptr;
     if constexpr ((DBG & 4) != 0) {
       float sacc = 0.f;
 #pragma unroll
@@ -630,20 +631,22 @@ int g_stagger = 0;
 int g_variant = 2;  // bf16 kernel choice: 0 small-tile register-staged, 1 small-tile global_load_lds, 2 big tile  // bf16 staging mode, switchable for A/B runs (mh_gemm_set_glds)
 
 template <int EPI>
-int launch(const GemmArgs& g, int dtype, hipStream_t s) {
+int launch(const GemmArgs& g, int dtype, hipStream_t s, int batch = 1) {
   const int64_t tiles = (int64_t)ceil_div(g.M, BM) * ceil_div(g.N, BN);
   MH_CHECK_ARG(tiles > 0 && tiles < (1ll << 31), "gemm: bad grid (M=%lld N=%d)", (long long)g.M, g.N);
-  dim3 grid((unsigned)tiles), block(256);
+  MH_CHECK_ARG(batch >= 1 && batch <= 65535, "gemm: batch %d out of range", batch);
+  dim3 grid((unsigned)tiles, (unsigned)batch), block(256);
   if (dtype == MH_BF16) {
-    MH_CHECK_ARG(g.K % 64 == 0 && g.K > 0, "gemm(bf16): K=%d must be a positive multiple of 64", g.K);
     MH_CHECK_ARG((g.a_panel || g.lda % 8 == 0) && (g.w_panel || g.ldw % 8 == 0), "gemm(bf16): lda/ldw must be multiples of 8");
     const bool any_panel = g.a_panel || g.w_panel || g.o_panel || g.r_panel;
     const bool big_ok = g.N % 8 == 0 && g.K % B2K == 0 && (g.o_panel || g.ldo % 8 == 0 || (g.out_f32 && g.ldo % 4 == 0)) &&
                         (g.r_panel || g.ldr % 8 == 0);
     MH_CHECK_ARG(!any_panel || (big_ok && g_variant >= 2), "gemm: panel layouts need the big-tile bf16 kernel");
+    MH_CHECK_ARG(g.K > 0 && (g.K % 64 == 0 || (g.K % B2K == 0 && big_ok && g_variant >= 2)),
+                 "gemm(bf16): K=%d must be a positive multiple of 64 (32 with the big-tile kernel)", g.K);
     if (g_variant == 3 && big_ok && !g.dbg) {
       const int64_t t2 = (int64_t)ceil_div(g.M, B2M) * ceil_div(g.N, B2N);
-      const dim3 grid3((unsigned)((t2 + 1) / 2)), block3(512);
+      const dim3 grid3((unsigned)((t2 + 1) / 2), (unsigned)batch), block3(512);
       if constexpr (EPI == 1) {
         MH_LAUNCH((gemm_big_kernel<1, MH_ACT_NONE, 0, true>), grid3, block3, 0, s, g);
       } else {
@@ -656,12 +659,12 @@ int launch(const GemmArgs& g, int dtype, hipStream_t s) {
       }
     } else if (g_variant == 3 && big_ok) {
       const int64_t t2 = (int64_t)ceil_div(g.M, B2M) * ceil_div(g.N, B2N);
-      const dim3 grid3((unsigned)((t2 + 1) / 2)), block3(512);
+      const dim3 grid3((unsigned)((t2 + 1) / 2), (unsigned)batch), block3(512);
       if ((g.dbg & 15) == 4) MH_LAUNCH((gemm_big_kernel<0, MH_ACT_NONE, 4, true>), grid3, block3, 0, s, g);
       else MH_LAUNCH((gemm_big_kernel<0, MH_ACT_NONE, 5, true>), grid3, block3, 0, s, g);
     } else if (g_variant >= 2 && big_ok) {
       const int64_t t2 = (int64_t)ceil_div(g.M, B2M) * ceil_div(g.N, B2N);
-      const dim3 grid2((unsigned)t2);
+      const dim3 grid2((unsigned)t2, (unsigned)batch);
       if constexpr (EPI == 1) {
         MH_LAUNCH((gemm_big_kernel<1, MH_ACT_NONE>), grid2, block, 0, s, g);
       } else {
@@ -744,6 +747,17 @@ extern "C" int mh_gemm_bias_act_ex(const void* A, int64_t lda, int a_panel, cons
   g.M = M; g.N = N; g.K = K; g.act = act; g.dbg = g_dbg & 15; g.stagger = g_stagger;
   g.a_panel = a_panel; g.w_panel = w_panel; g.o_panel = o_panel; g.r_panel = residual ? r_panel : 0;
   return launch<0>(g, dtype, (hipStream_t)stream);
+}
+
+extern "C" int mh_gemm_batched(const void* A, int64_t lda, int64_t strideA, const void* W, int64_t ldw, int64_t strideW,
+                               const float* bias, void* out, int64_t ldo, int64_t strideO, int out_f32, int batch, int64_t M,
+                               int N, int K, int dtype, mh_stream_t stream) {
+  MH_CHECK_ARG(A && W && out, "gemm_batched: null pointer");
+  MH_CHECK_ARG(M > 0 && N > 0 && batch > 0, "gemm_batched: empty problem");
+  GemmArgs g{};
+  g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.bias = bias; g.ldr = 8; g.out = out; g.ldo = ldo; g.out_f32 = out_f32;
+  g.M = M; g.N = N; g.K = K; g.act = MH_ACT_NONE; g.sA = strideA; g.sW = strideW; g.sO = strideO;
+  return launch<0>(g, dtype, (hipStream_t)stream, batch);
 }
 
 extern "C" int mh_gemm_qkv_ex(const void* A, int64_t lda, int a_panel, const void* Wqkv, int64_t ldw, int w_panel,

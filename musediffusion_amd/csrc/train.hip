@@ -1,0 +1,509 @@
+// Kernels of the training path (training_losses forward + backward, models/diffusion.py:594-699 driven by
+// utils/train_util.py:188-232): layout permutes and transposes that turn every backward product into the
+// same "A W^T" GEMM the forward uses, activation / LayerNorm / softmax / cross-entropy / squared-error
+// backward, column sums for bias and LayerNorm-parameter gradients, embedding scatter-add.
+// All HBM-bound streaming kernels; element type T in {float, bf16}, reductions always in fp32.
+#include "common.h"
+
+namespace {
+
+constexpr int TB = 256;
+inline int tgrid(int64_t n) {
+  int64_t b = (n + TB - 1) / TB;
+  return (int)(b < 1 ? 1 : (b > 16384 ? 16384 : b));
+}
+
+// ------------------------------------------------------------------ transposes / head permutes
+// out[b][c][r] = in[b][r][c]  (32 x 32 tiles through LDS, +1 padding)
+template <typename T>
+__global__ void transpose_kernel(const T* __restrict__ in, int64_t ld_in, int64_t s_in, T* __restrict__ out, int64_t ld_out,
+                                 int64_t s_out, int rows, int cols) {
+  __shared__ T tile[32][33];
+  const T* src = in + (int64_t)blockIdx.z * s_in;
+  T* dst = out + (int64_t)blockIdx.z * s_out;
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  for (int i = ty; i < 32; i += 8) {
+    const int r = r0 + i, c = c0 + tx;
+    tile[i][tx] = (r < rows && c < cols) ? src[(int64_t)r * ld_in + c] : from_f32<T>(0.f);
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    const int c = c0 + i, r = r0 + tx;
+    if (c < cols && r < rows) dst[(int64_t)c * ld_out + r] = tile[tx][i];
+  }
+}
+
+// mode 0: tokens [B*L, ld] (head h at cols [h*dh,(h+1)*dh)) -> heads [B, nh, L, dh]
+// mode 1: heads -> tokens;  mode 2: tokens -> heads transposed [B, nh, dh, L]
+template <typename T>
+__global__ void head_permute_kernel(const T* __restrict__ in, T* __restrict__ out, int64_t ld_tok, int B, int L, int nh,
+                                    int dh, int mode) {
+  const int64_t total = (int64_t)B * L * nh * dh;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    // i enumerates the OUTPUT in its natural order (coalesced writes)
+    if (mode == 0) {
+      const int d = (int)(i % dh); int64_t r = i / dh;
+      const int l = (int)(r % L); r /= L;
+      const int h = (int)(r % nh); const int64_t b = r / nh;
+      out[i] = in[(b * L + l) * ld_tok + h * dh + d];
+    } else if (mode == 1) {
+      const int c = (int)(i % (nh * dh)); const int64_t tok = i / (nh * dh);
+      const int h = c / dh, d = c % dh;
+      const int64_t b = tok / L, l = tok % L;
+      out[tok * ld_tok + c] = in[((b * nh + h) * L + l) * dh + d];
+    } else {
+      const int l = (int)(i % L); int64_t r = i / L;
+      const int d = (int)(r % dh); r /= dh;
+      const int h = (int)(r % nh); const int64_t b = r / nh;
+      out[i] = in[(b * L + l) * ld_tok + h * dh + d];
+    }
+  }
+}
+
+// ------------------------------------------------------------------ column sums (deterministic two-stage)
+// out[b, l, :] = pos[l, :] + x[b, l, :] + emb[b, :]   (network.py:146-148, kept as a tensor for the backward)
+template <typename T>
+__global__ void add_pos_time_kernel(const T* __restrict__ x, int64_t ldx, const float* __restrict__ pos, const float* __restrict__ emb,
+                                    T* __restrict__ out, int B, int L, int H) {
+  const int64_t total = (int64_t)B * L * H;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % H); const int64_t tok = i / H;
+    const int64_t b = tok / L, l = tok % L;
+    out[i] = from_f32<T>((pos[l * H + c] + to_f32(x[tok * ldx + c])) + emb[b * H + c]);
+  }
+}
+
+template <typename T>
+__global__ void colsum_partial_kernel(const T* __restrict__ in_all, int64_t ld, int64_t rows, int cols, float* __restrict__ part_all,
+                                      int64_t s_in) {
+  // grid (ceil(cols/64), P, batch): block handles 64 columns over rows p, p+P, ... ; 4 row-lanes x 64 cols
+  const T* in = in_all + (int64_t)blockIdx.z * s_in;
+  float* part = part_all + (int64_t)blockIdx.z * gridDim.y * cols;
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6, P = gridDim.y;
+  __shared__ float red[4][64];
+  float s = 0.f;
+  if (c < cols)
+    for (int64_t r = (int64_t)blockIdx.y * 4 + rl; r < rows; r += (int64_t)P * 4) s += to_f32(in[r * ld + c]);
+  red[rl][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (rl == 0 && c < cols) part[(int64_t)blockIdx.y * cols + c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+__global__ void colsum_final_kernel(const float* __restrict__ part_all, int P, int cols, float* __restrict__ out_all, int accumulate) {
+  const float* part = part_all + (int64_t)blockIdx.y * P * cols;
+  float* out = out_all + (int64_t)blockIdx.y * cols;
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= cols) return;
+  float s = 0.f;
+  for (int p = 0; p < P; ++p) s += part[(int64_t)p * cols + c];
+  out[c] = accumulate ? out[c] + s : s;
+}
+
+// ------------------------------------------------------------------ activations
+template <typename T>
+__global__ void act_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t n, int act) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float v = to_f32(x[i]);
+    float r = v;
+    if (act == MH_ACT_TANH) r = tanhf(v);
+    else if (act == MH_ACT_GELU_ERF) r = gelu_erf(v);
+    else if (act == MH_ACT_SILU) r = silu(v);
+    y[i] = from_f32<T>(r);
+  }
+}
+// dx = dy * act'(x)   (x = saved PRE-activation)
+template <typename T>
+__global__ void act_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x, T* __restrict__ dx, int64_t n, int act) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float v = to_f32(x[i]), g = to_f32(dy[i]);
+    float d = 1.f;
+    if (act == MH_ACT_TANH) { const float t = tanhf(v); d = 1.f - t * t; }
+    else if (act == MH_ACT_GELU_ERF) d = 0.5f * (1.f + erff(v * 0.70710678118654752440f)) + v * 0.3989422804014327f * expf(-0.5f * v * v);
+    else if (act == MH_ACT_SILU) { const float sg = 1.f / (1.f + expf(-v)); d = sg * (1.f + v * (1.f - sg)); }
+    dx[i] = from_f32<T>(g * d);
+  }
+}
+
+// ------------------------------------------------------------------ LayerNorm backward
+// one wave per row (H <= 2048); block = 4 waves walking rows blockIdx.x*4 + w, + gridDim.x*4, ...;
+// dgamma / dbeta partials accumulate in registers over the block's rows and are written per block.
+constexpr int LNCH = 4;
+template <typename T>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, const float* __restrict__ gamma,
+                                                     T* __restrict__ dx, float* __restrict__ pg, float* __restrict__ pb,
+                                                     int64_t rows, int H, float eps) {
+  __shared__ float red[2][4][2048 / 1];  // [dgamma|dbeta][wave][col]  (32 KiB)
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int nch = H >> 3;
+  float ag[LNCH][8], ab[LNCH][8];
+#pragma unroll
+  for (int i = 0; i < LNCH; ++i)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { ag[i][e] = 0.f; ab[i][e] = 0.f; }
+  for (int64_t row = (int64_t)blockIdx.x * 4 + w; row < rows; row += (int64_t)gridDim.x * 4) {
+    float xv[LNCH][8], gv[LNCH][8];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < LNCH; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nch) {
+        load8(x + row * H + c * 8, xv[i]);
+        load8(dy + row * H + c * 8, gv[i]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sum += xv[i][e];
+      }
+    }
+    const float mean = wave_sum(sum) / (float)H;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < LNCH; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nch)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float d = xv[i][e] - mean; sq += d * d; }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(sq) / (float)H + eps);
+    float s1 = 0.f, s2 = 0.f;   // sum(dy*g), sum(dy*g*xhat)
+#pragma unroll
+    for (int i = 0; i < LNCH; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nch) {
+        float g[8];
+        load8(gamma + c * 8, g);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float xh = (xv[i][e] - mean) * rstd;
+          const float dg = gv[i][e] * g[e];
+          s1 += dg; s2 += dg * xh;
+          ag[i][e] += gv[i][e] * xh;
+          ab[i][e] += gv[i][e];
+          xv[i][e] = xh; gv[i][e] = dg;
+        }
+      }
+    }
+    s1 = wave_sum(s1) / (float)H; s2 = wave_sum(s2) / (float)H;
+#pragma unroll
+    for (int i = 0; i < LNCH; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nch) {
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = rstd * (gv[i][e] - s1 - xv[i][e] * s2);
+        store8(dx + row * H + c * 8, o);
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < LNCH; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nch)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { red[0][w][c * 8 + e] = ag[i][e]; red[1][w][c * 8 + e] = ab[i][e]; }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < H; c += 256) {
+    pg[(int64_t)blockIdx.x * H + c] = (red[0][0][c] + red[0][1][c]) + (red[0][2][c] + red[0][3][c]);
+    pb[(int64_t)blockIdx.x * H + c] = (red[1][0][c] + red[1][1][c]) + (red[1][2][c] + red[1][3][c]);
+  }
+}
+
+// ------------------------------------------------------------------ row softmax forward / backward (attention probabilities)
+template <typename T>
+__global__ void softmax_rows_kernel(T* __restrict__ s, int64_t rows, int L, int64_t ld, float scale) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  T* p = s + row * ld;
+  float mx = -INFINITY;
+  for (int c = lane; c < L; c += 64) mx = fmaxf(mx, to_f32(p[c]) * scale);
+  mx = wave_max(mx);
+  float sum = 0.f;
+  for (int c = lane; c < L; c += 64) sum += expf(to_f32(p[c]) * scale - mx);
+  sum = wave_sum(sum);
+  const float inv = 1.0f / sum;
+  for (int c = lane; c < L; c += 64) p[c] = from_f32<T>(expf(to_f32(p[c]) * scale - mx) * inv);
+}
+// ds = p * (dp - sum(dp * p)) * scale   (in place on dp)
+template <typename T>
+__global__ void softmax_bwd_rows_kernel(const T* __restrict__ p, T* __restrict__ dp, int64_t rows, int L, int64_t ld, float scale) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const T* pr = p + row * ld;
+  T* dr = dp + row * ld;
+  float dot = 0.f;
+  for (int c = lane; c < L; c += 64) dot += to_f32(pr[c]) * to_f32(dr[c]);
+  dot = wave_sum(dot);
+  for (int c = lane; c < L; c += 64) dr[c] = from_f32<T>(to_f32(pr[c]) * (to_f32(dr[c]) - dot) * scale);
+}
+
+// ------------------------------------------------------------------ token cross-entropy over logits [N, V] fp32
+__global__ void ce_fwd_kernel(const float* __restrict__ logits, int64_t ld, const int32_t* __restrict__ target,
+                              float* __restrict__ loss, float* __restrict__ lse, int64_t n, int V) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= n) return;
+  const float* p = logits + row * ld;
+  float mx = -INFINITY;
+  for (int c = lane; c < V; c += 64) mx = fmaxf(mx, p[c]);
+  mx = wave_max(mx);
+  float sum = 0.f;
+  for (int c = lane; c < V; c += 64) sum += expf(p[c] - mx);
+  sum = wave_sum(sum);
+  const float l = mx + logf(sum);
+  if (lane == 0) {
+    int t = target[row];
+    t = t < 0 ? 0 : (t >= V ? V - 1 : t);
+    lse[row] = l;
+    loss[row] = l - p[t];
+  }
+}
+// dlogits[n, v] = (softmax - onehot) * g[n]   (written in the compute dtype for the following GEMMs)
+template <typename T>
+__global__ void ce_bwd_kernel(const float* __restrict__ logits, int64_t ld, const int32_t* __restrict__ target,
+                              const float* __restrict__ lse, const float* __restrict__ g, T* __restrict__ dl, int64_t ldd,
+                              int64_t n, int V, int Vpad) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= n) return;
+  const float* p = logits + row * ld;
+  const float l = lse[row], gs = g[row];
+  int t = target[row];
+  t = t < 0 ? 0 : (t >= V ? V - 1 : t);
+  for (int c = lane; c < Vpad; c += 64) {
+    float v = 0.f;
+    if (c < V) v = (expf(p[c] - l) - (c == t ? 1.f : 0.f)) * gs;
+    dl[row * ldd + c] = from_f32<T>(v);
+  }
+}
+
+// ------------------------------------------------------------------ squared error: per-batch mean and gradient
+// out[b] = mean_i (scale_a * a[b,i] - b[b,i])^2        (b may be NULL = 0)
+__global__ void sqdiff_mean_kernel(const float* __restrict__ a, const float* __restrict__ bb, float scale_a, float* __restrict__ out,
+                                   int64_t per_batch) {
+  __shared__ float red[4];
+  const int b = blockIdx.x;
+  float s = 0.f;
+  for (int64_t i = threadIdx.x; i < per_batch; i += blockDim.x) {
+    const float d = scale_a * a[(int64_t)b * per_batch + i] - (bb ? bb[(int64_t)b * per_batch + i] : 0.f);
+    s += d * d;
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) out[b] = ((red[0] + red[1]) + (red[2] + red[3])) / (float)per_batch;
+}
+// da[b,i] (+)= g[b] * 2 * scale_a * (scale_a*a - b) / per_batch ;  db = -da / scale_a (optional)
+__global__ void sqdiff_bwd_kernel(const float* __restrict__ a, const float* __restrict__ bb, float scale_a, const float* __restrict__ g,
+                                  float* __restrict__ da, float* __restrict__ db, int accumulate, int B, int64_t per_batch) {
+  const int64_t total = (int64_t)B * per_batch;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int b = (int)(i / per_batch);
+    const float d = scale_a * a[i] - (bb ? bb[i] : 0.f);
+    const float base = g[b] * 2.0f * d / (float)per_batch;
+    if (da) da[i] = (accumulate ? da[i] : 0.f) + base * scale_a;
+    if (db) db[i] = (accumulate ? db[i] : 0.f) - base;
+  }
+}
+
+// ------------------------------------------------------------------ misc
+template <typename T>
+__global__ void add_inplace_kernel(T* __restrict__ dst, const T* __restrict__ src, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    dst[i] = from_f32<T>(to_f32(dst[i]) + to_f32(src[i]));
+}
+__global__ void scatter_add_rows_kernel(const float* __restrict__ src, const int32_t* __restrict__ ids, float* __restrict__ table,
+                                        int64_t n, int E, int V) {
+  const int64_t total = n * E;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int id = ids[i / E];
+    id = id < 0 ? 0 : (id >= V ? V - 1 : id);
+    atomicAdd(table + (int64_t)id * E + (i % E), src[i]);
+  }
+}
+// q_sample backward (diffusion.py:245-255): dst[b,i] (+)= src[b,i] * (mask[token] == 0 ? 1 : scale[b])
+__global__ void scale_rows_kernel(const float* __restrict__ src, const float* __restrict__ scale, const int32_t* __restrict__ mask,
+                                  float* __restrict__ dst, int accumulate, int B, int64_t per_batch, int E) {
+  const int64_t total = (int64_t)B * per_batch;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int b = (int)(i / per_batch);
+    const bool anchored = mask && mask[i / E] == 0;
+    const float v = src[i] * (anchored ? 1.0f : (scale ? scale[b] : 1.0f));
+    dst[i] = (accumulate ? dst[i] : 0.f) + v;
+  }
+}
+
+}  // namespace
+
+#define MH_DTYPE_SWITCH(dtype, CALL_BF16, CALL_F32, what)                                 \
+  if ((dtype) == MH_BF16) { CALL_BF16; } else if ((dtype) == MH_F32) { CALL_F32; } else { \
+    mh_set_error(what ": unknown dtype %d", (dtype)); return MH_ERR_INVALID; }
+
+extern "C" int mh_transpose(const void* in, int64_t ld_in, int64_t stride_in, void* out, int64_t ld_out, int64_t stride_out,
+                            int rows, int cols, int batch, int dtype, mh_stream_t stream) {
+  MH_CHECK_ARG(in && out && rows > 0 && cols > 0 && batch > 0 && batch <= 65535, "transpose: bad arguments");
+  dim3 grid((cols + 31) / 32, (rows + 31) / 32, batch);
+  hipStream_t s = (hipStream_t)stream;
+  MH_DTYPE_SWITCH(dtype,
+                  MH_LAUNCH((transpose_kernel<bf16>), grid, dim3(256), 0, s, (const bf16*)in, ld_in, stride_in, (bf16*)out, ld_out, stride_out, rows, cols),
+                  MH_LAUNCH((transpose_kernel<float>), grid, dim3(256), 0, s, (const float*)in, ld_in, stride_in, (float*)out, ld_out, stride_out, rows, cols),
+                  "transpose");
+  MH_CHECK_LAUNCH();
+  return MH_OK;
+}
+
+extern "C" int mh_head_permute(const void* in, void* out, int64_t ld_tok, int B, int L, int nh, int dh, int mode, int dtype,
+                               mh_stream_t stream) {
+  MH_CHECK_ARG(in && out && B > 0 && L > 0 && nh > 0 && dh > 0 && mode >= 0 && mode <= 2, "head_permute: bad arguments");
+  const int grid = tgrid((int64_t)B * L * nh * dh);
+  hipStream_t s = (hipStream_t)stream;
+  MH_DTYPE_SWITCH(dtype,
+                  MH_LAUNCH((head_permute_kernel<bf16>), dim3(grid), dim3(TB), 0, s, (const bf16*)in, (bf16*)out, ld_tok, B, L, nh, dh, mode),
+                  MH_LAUNCH((head_permute_kernel<float>), dim3(grid), dim3(TB), 0, s, (const float*)in, (float*)out, ld_tok, B, L, nh, dh, mode),
+                  "head_permute");
+  MH_CHECK_LAUNCH();
+  return MH_OK;
+}
+
+extern "C" int mh_col_sum(const void* in, int64_t ld, int64_t rows, int cols, int batch, int64_t stride_in, float* partial,
+                          int n_partial, float* out, int accumulate, int dtype, mh_stream_t stream) {
+  MH_CHECK_ARG(in && partial && out && rows > 0 && cols > 0 && n_partial > 0 && n_partial <= 1024 && batch > 0 && batch <= 65535,
+               "col_sum: bad arguments");
+  dim3 grid((cols + 63) / 64, n_partial, batch);
+  hipStream_t s = (hipStream_t)stream;
+  MH_DTYPE_SWITCH(dtype, MH_LAUNCH((colsum_partial_kernel<bf16>), grid, dim3(256), 0, s, (const bf16*)in, ld, rows, cols, partial, stride_in),
+                  MH_LAUNCH((colsum_partial_kernel<float>), grid, dim3(256), 0, s, (const float*)in, ld, rows, cols, partial, stride_in), "col_sum");
+  MH_CHECK_LAUNCH();
+  MH_LAUNCH(colsum_final_kernel, dim3((cols + 255) / 256, batch), dim3(256), 0, s, partial, n_partial, cols, out, accumulate);
+  MH_CHECK_LAUNCH();
+  return MH_OK;
+}
+
+extern "C" int mh_add_pos_time(const void* x, int64_t ldx, const float* pos, const float* emb, void* out, int B, int L, int H,
+                               int dtype, mh_stream_t stream) {
+  MH_CHECK_ARG(x && pos && emb && out && B > 0 && L > 0 && H > 0, "add_pos_time: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  const int grid = tgrid((int64_t)B * L * H);
+  MH_DTYPE_SWITCH(dtype, MH_LAUNCH((add_pos_time_kernel<bf16>), dim3(grid), dim3(TB), 0, s, (const bf16*)x, ldx, pos, emb, (bf16*)out, B, L, H),
+                  MH_LAUNCH((add_pos_time_kernel<float>), dim3(grid), dim3(TB), 0, s, (const float*)x, ldx, pos, emb, (float*)out, B, L, H), "add_pos_time");
+  MH_CHECK_LAUNCH();
+  return MH_OK;
+}
+
+extern "C" int mh_act_fwd(const void* x, void* y, int64_t n, int act, int dtype, mh_stream_t stream) {
+  MH_CHECK_ARG(x && y && n > 0, "act_fwd: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  MH_DTYPE_SWITCH(dtype, MH_LAUNCH((act_fwd_kernel<bf16>), dim3(tgrid(n)), dim3(TB), 0, s, (const bf16*)x, (bf16*)y, n, act),
+                  MH_LAUNCH((act_fwd_kernel<float>), dim3(tgrid(n)), dim3(TB), 0, s, (const float*)x, (float*)y, n, act), "act_fwd");
+  MH_CHECK_LAUNCH();
+  return MH_OK;
+}
+
+extern "C" int mh_act_bwd(const void* dy, const void* x, void* dx, int64_t n, int act, int dtype, mh_stream_t stream) {
+  MH_CHECK_ARG(dy && x && dx && n > 0, "act_bwd: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  MH_DTYPE_SWITCH(dtype, MH_LAUNCH((act_bwd_kernel<bf16>), dim3(tgrid(n)), dim3(TB), 0, s, (const bf16*)dy, (const bf16*)x, (bf16*)dx, n, act),
+                  MH_LAUNCH((act_bwd_kernel<float>), dim3(tgrid(n)), dim3(TB), 0, s, (const float*)dy, (const float*)x, (float*)dx, n, act), "act_bwd");
+  MH_CHECK_LAUNCH();
+  return MH_OK;
+}
+
+extern "C" int mh_layernorm_bwd(const void* x, const void* dy, const float* gamma, void* dx, float* partial, int n_partial,
+                                float* dgamma, float* dbeta, int accumulate, int64_t rows, int H, float eps, int dtype,
+                                mh_stream_t stream) {
+  MH_CHECK_ARG(x && dy && gamma && dx && partial && dgamma && dbeta, "layernorm_bwd: null pointer");
+  MH_CHECK_ARG(rows > 0 && H % 8 == 0 && H <= 2048 && n_partial > 0 && n_partial <= 1024, "layernorm_bwd: bad shape");
+  hipStream_t s = (hipStream_t)stream;
+  float* pg = partial;
+  float* pb = partial + (int64_t)n_partial * H;
+  MH_DTYPE_SWITCH(dtype,
+                  MH_LAUNCH((ln_bwd_kernel<bf16>), dim3(n_partial), dim3(256), 0, s, (const bf16*)x, (const bf16*)dy, gamma, (bf16*)dx, pg, pb, rows, H, eps),
+                  MH_LAUNCH((ln_bwd_kernel<float>), dim3(n_partial), dim3(256), 0, s, (const float*)x, (const float*)dy, gamma, (float*)dx, pg, pb, rows, H, eps),
+                  "layernorm_bwd");
+  MH_CHECK_LAUNCH();
+  MH_LAUNCH(colsum_final_kernel, dim3((H + 255) / 256, 1), dim3(256), 0, s, pg, n_partial, H, dgamma, accumulate);
+  MH_CHECK_LAUNCH();
+  MH_LAUNCH(colsum_final_kernel, dim3((H + 255) / 256, 1), dim3(256), 0, s, pb, n_partial, H, dbeta, accumulate);
+  MH_CHECK_LAUNCH();
+  return MH_OK;
+}
+
+extern "C" int mh_softmax_rows(void* s_inout, int64_t rows, int L, int64_t ld, float scale, int dtype, mh_stream_t stream) {
+  MH_CHECK_ARG(s_inout && rows > 0 && L > 0, "softmax_rows: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid((unsigned)((rows + 3) / 4));
+  MH_DTYPE_SWITCH(dtype, MH_LAUNCH((softmax_rows_kernel<bf16>), grid, dim3(256), 0, s, (bf16*)s_inout, rows, L, ld, scale),
+                  MH_LAUNCH((softmax_rows_kernel<float>), grid, dim3(256), 0, s, (float*)s_inout, rows, L, ld, scale), "softmax_rows");
+  MH_CHECK_LAUNCH();
+  return MH_OK;
+}
+
+extern "C" int mh_softmax_bwd_rows(const void* p, void* dp_inout, int64_t rows, int L, int64_t ld, float scale, int dtype,
+                                   mh_stream_t stream) {
+  MH_CHECK_ARG(p && dp_inout && rows > 0 && L > 0, "softmax_bwd_rows: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid((unsigned)((rows + 3) / 4));
+  MH_DTYPE_SWITCH(dtype, MH_LAUNCH((softmax_bwd_rows_kernel<bf16>), grid, dim3(256), 0, s, (const bf16*)p, (bf16*)dp_inout, rows, L, ld, scale),
+                  MH_LAUNCH((softmax_bwd_rows_kernel<float>), grid, dim3(256), 0, s, (const float*)p, (float*)dp_inout, rows, L, ld, scale), "softmax_bwd_rows");
+  MH_CHECK_LAUNCH();
+  return MH_OK;
+}
+
+extern "C" int mh_cross_entropy_fwd(const float* logits, int64_t ld, const int32_t* target, float* loss, float* lse, int64_t n,
+                                    int V, mh_stream_t stream) {
+  MH_CHECK_ARG(logits && target && loss && lse && n > 0 && V > 0, "cross_entropy_fwd: bad arguments");
+  MH_LAUNCH(ce_fwd_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, logits, ld, target, loss, lse, n, V);
+  MH_CHECK_LAUNCH();
+  return MH_OK;
+}
+
+extern "C" int mh_cross_entropy_bwd(const float* logits, int64_t ld, const int32_t* target, const float* lse, const float* grad,
+                                    void* dlogits, int64_t ldd, int64_t n, int V, int Vpad, int dtype, mh_stream_t stream) {
+  MH_CHECK_ARG(logits && target && lse && grad && dlogits && n > 0 && V > 0 && Vpad >= V && ldd >= Vpad, "cross_entropy_bwd: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid((unsigned)((n + 3) / 4));
+  MH_DTYPE_SWITCH(dtype, MH_LAUNCH((ce_bwd_kernel<bf16>), grid, dim3(256), 0, s, logits, ld, target, lse, grad, (bf16*)dlogits, ldd, n, V, Vpad),
+                  MH_LAUNCH((ce_bwd_kernel<float>), grid, dim3(256), 0, s, logits, ld, target, lse, grad, (float*)dlogits, ldd, n, V, Vpad), "cross_entropy_bwd");
+  MH_CHECK_LAUNCH();
+  return MH_OK;
+}
+
+extern "C" int mh_sqdiff_mean(const float* a, const float* b, float scale_a, float* out, int B, int64_t per_batch, mh_stream_t stream) {
+  MH_CHECK_ARG(a && out && B > 0 && per_batch > 0, "sqdiff_mean: bad arguments");
+  MH_LAUNCH(sqdiff_mean_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, a, b, scale_a, out, per_batch);
+  MH_CHECK_LAUNCH();
+  return MH_OK;
+}
+
+extern "C" int mh_sqdiff_bwd(const float* a, const float* b, float scale_a, const float* grad, float* da, float* db, int accumulate,
+                             int B, int64_t per_batch, mh_stream_t stream) {
+  MH_CHECK_ARG(a && grad && (da || db) && B > 0 && per_batch > 0, "sqdiff_bwd: bad arguments");
+  MH_LAUNCH(sqdiff_bwd_kernel, dim3(tgrid((int64_t)B * per_batch)), dim3(TB), 0, (hipStream_t)stream, a, b, scale_a, grad, da, db, accumulate, B, per_batch);
+  MH_CHECK_LAUNCH();
+  return MH_OK;
+}
+
+extern "C" int mh_add_inplace(void* dst, const void* src, int64_t n, int dtype, mh_stream_t stream) {
+  MH_CHECK_ARG(dst && src && n > 0, "add_inplace: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  MH_DTYPE_SWITCH(dtype, MH_LAUNCH((add_inplace_kernel<bf16>), dim3(tgrid(n)), dim3(TB), 0, s, (bf16*)dst, (const bf16*)src, n),
+                  MH_LAUNCH((add_inplace_kernel<float>), dim3(tgrid(n)), dim3(TB), 0, s, (float*)dst, (const float*)src, n), "add_inplace");
+  MH_CHECK_LAUNCH();
+  return MH_OK;
+}
+
+extern "C" int mh_scatter_add_rows(const float* src, const int32_t* ids, float* table, int64_t n, int E, int V, mh_stream_t stream) {
+  MH_CHECK_ARG(src && ids && table && n > 0 && E > 0 && V > 0, "scatter_add_rows: bad arguments");
+  MH_LAUNCH(scatter_add_rows_kernel, dim3(tgrid(n * E)), dim3(TB), 0, (hipStream_t)stream, src, ids, table, n, E, V);
+  MH_CHECK_LAUNCH();
+  return MH_OK;
+}
+
+extern "C" int mh_scale_rows(const float* src, const float* scale, const int32_t* mask, float* dst, int accumulate, int B,
+                             int64_t per_batch, int E, mh_stream_t stream) {
+  MH_CHECK_ARG(src && dst && B > 0 && per_batch > 0 && E > 0, "scale_rows: bad arguments");
+  MH_LAUNCH(scale_rows_kernel, dim3(tgrid((int64_t)B * per_batch)), dim3(TB), 0, (hipStream_t)stream, src, scale, mask, dst,
+            accumulate, B, per_batch, E);
+  MH_CHECK_LAUNCH();
+  return MH_OK;
+}

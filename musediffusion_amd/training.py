@@ -1,0 +1,448 @@
+"""Training path: `training_losses` (MuseDiffusion/models/diffusion.py:594-699) with gradients, as
+called from TrainLoop._forward_backward_logic (utils/train_util.py:188-232).
+
+The reference relies on torch autograd over ~500 ATen kernels per micro-batch.  Here every tensor
+operation — forward and backward — is a libmusehip kernel; torch.autograd is only the tape that
+connects them, so `.backward()`, DDP's gradient all-reduce hooks (RCCL), optimizers, EMA and
+checkpointing keep working on the model's ordinary fp32 `nn.Parameter`s.
+
+Backward matrix products are brought to the forward's "A W^T" GEMM form:
+    dX = dY W          -> gemm(dY, W^T)            (weight transposed once per call)
+    dW = dY^T X        -> gemm(dY^T, X^T)          (activations transposed; reduction over tokens)
+and attention backward recomputes P = softmax(Q K^T) per (batch, head) with batched GEMMs.
+Activations are kept in the compute dtype (fp32 = the reference's precision, bf16 optional), all
+parameter gradients are produced in fp32.
+"""
+import math
+
+import torch
+from torch.autograd import Function
+
+from . import _lib, ops
+from ._lib import MH_BF16, MH_F32, check, current_stream, lib, ptr
+
+NPART = 64  # rows of the two-stage column-sum scratch
+
+
+def _td(dt):
+    return ops.TORCH_DTYPE[dt]
+
+
+def _zeros(rows, cols, dt, dev):
+    return torch.zeros(rows, cols, device=dev, dtype=_td(dt))
+
+
+def _gemm(A, W, bias, dt, N, K, out=None, out_f32=False, residual=None):
+    return ops.gemm_bias_act(A, W, bias, residual, None, dt, out_f32=out_f32, N=N, K=K, out=out)
+
+
+def _transpose(x, rows, cols, dt, ld_out=None, batch=1, stride_in=0, stride_out=0, ld_in=None):
+    """[batch][rows, cols] (row pitch ld_in, default x.shape[-1]) -> [batch][cols, ld_out] zero-padded."""
+    ld_out = ops.pad64(rows) if ld_out is None else ld_out
+    ld_in = x.shape[-1] if ld_in is None else ld_in
+    out = torch.zeros(batch * cols, ld_out, device=x.device, dtype=x.dtype)
+    check(lib().mh_transpose(ptr(x), ld_in, stride_in, ptr(out), ld_out, stride_out or cols * ld_out, rows, cols, batch, dt,
+                             current_stream()), "mh_transpose")
+    return out
+
+
+def _col_sum(x, rows, cols, dt, batch=1, stride_in=0):
+    part = torch.empty(batch * NPART * cols, device=x.device, dtype=torch.float32)
+    out = torch.empty(batch, cols, device=x.device, dtype=torch.float32)
+    check(lib().mh_col_sum(ptr(x), x.shape[-1], rows, cols, batch, stride_in, ptr(part), NPART, ptr(out), 0, dt,
+                           current_stream()), "mh_col_sum")
+    return out if batch > 1 else out[0]
+
+
+# ---------------------------------------------------------------------------------------------- Functions
+class _Cast(Function):
+    """fp32 [M, C] <-> compute dtype [M, pad64(C)] (zero padded columns)."""
+
+    @staticmethod
+    def forward(ctx, x, dt, to_compute):
+        ctx.dt, ctx.to_compute, ctx.cols = dt, to_compute, x.shape[1]
+        if to_compute:
+            return ops.cast_pad(x, ops.pad64(x.shape[1]), dt)
+        raise AssertionError
+
+    @staticmethod
+    def backward(ctx, g):
+        return ops.cast_to_f32(g.contiguous(), ctx.cols, ctx.dt), None, None
+
+
+class _ToF32(Function):
+    """compute dtype [M, ld] -> fp32 [M, C]."""
+
+    @staticmethod
+    def forward(ctx, x, cols, dt):
+        ctx.dt, ctx.ld = dt, x.shape[1]
+        return ops.cast_to_f32(x, cols, dt)
+
+    @staticmethod
+    def backward(ctx, g):
+        return ops.cast_pad(g.contiguous(), ctx.ld, ctx.dt), None, None
+
+
+class _Linear(Function):
+    """y = act(x W^T + b) (+ residual).  x [M, Kp] compute dtype (padding columns zero), W [N, K] fp32, b [N] fp32.
+    Output [M, pad64(N)] with zero padding columns."""
+
+    @staticmethod
+    def forward(ctx, x, W, b, act, residual, dt):
+        M, Kp = x.shape
+        N, K = W.shape
+        Np = ops.pad64(N)
+        Wc = ops.cast_pad(W.detach(), Kp, dt)                         # [N, Kp]
+        pre = _zeros(M, Np, dt, x.device)
+        _gemm(x, Wc, b.detach() if b is not None else None, dt, N, Kp, out=pre, residual=residual if act is None else None)
+        if act is None:
+            y = pre
+        else:
+            y = torch.empty_like(pre)
+            check(lib().mh_act_fwd(ptr(pre), ptr(y), pre.numel(), ops.ACT[act], dt, current_stream()), "mh_act_fwd")
+            assert residual is None
+        ctx.save_for_backward(x, Wc, pre if act is not None else None)
+        ctx.meta = (act, dt, N, K, Kp, Np, residual is not None, b is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, Wc, pre = ctx.saved_tensors
+        act, dt, N, K, Kp, Np, has_res, has_b = ctx.meta
+        M = x.shape[0]
+        dy = dy.contiguous()
+        if act is not None:
+            dpre = torch.empty_like(dy)
+            check(lib().mh_act_bwd(ptr(dy), ptr(pre), ptr(dpre), dy.numel(), ops.ACT[act], dt, current_stream()), "mh_act_bwd")
+        else:
+            dpre = dy
+        db = _col_sum(dpre, M, N, dt) if has_b else None
+        # dX = dpre W : reduction over the N outputs
+        WT = _transpose(Wc, N, Kp, dt, ld_out=Np)                      # [Kp, Np]
+        dx = _zeros(M, Kp, dt, x.device)
+        _gemm(dpre, WT, None, dt, Kp, Np, out=dx)
+        # dW = dpre^T X : reduction over the M rows
+        Mp = ops.pad64(M)
+        dT = _transpose(dpre, M, N, dt, ld_out=Mp)                      # [N, Mp]
+        xT = _transpose(x, M, Kp, dt, ld_out=Mp)                        # [Kp, Mp]
+        dW = torch.empty(N, Kp, device=x.device, dtype=torch.float32)
+        _gemm(dT, xT, None, dt, Kp, Mp, out=dW, out_f32=True)
+        return dx, dW[:, :K].contiguous(), db, None, (dy if has_res else None), None
+
+
+class _LayerNorm(Function):
+    @staticmethod
+    def forward(ctx, x, g, b, eps, dt):
+        y = ops.layernorm(x, g.detach(), b.detach(), eps, dt)
+        ctx.save_for_backward(x, g.detach())
+        ctx.meta = (eps, dt)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, g = ctx.saved_tensors
+        eps, dt = ctx.meta
+        M, H = x.shape
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        nb = min(512, (M + 3) // 4)
+        part = torch.empty(2 * nb * H, device=x.device, dtype=torch.float32)
+        dg = torch.empty(H, device=x.device, dtype=torch.float32)
+        db = torch.empty(H, device=x.device, dtype=torch.float32)
+        check(lib().mh_layernorm_bwd(ptr(x), ptr(dy), ptr(g), ptr(dx), ptr(part), nb, ptr(dg), ptr(db), 0, M, H, eps, dt,
+                                     current_stream()), "mh_layernorm_bwd")
+        return dx, dg, db, None, None
+
+
+class _AddPosTime(Function):
+    """pre[b,l,:] = pos[l,:] + x[b,l,:] + emb_t[b,:]   (network.py:146-148)."""
+
+    @staticmethod
+    def forward(ctx, x, pos, emb_t, B, L, dt):
+        H = pos.shape[1]
+        out = torch.empty(B * L, H, device=x.device, dtype=_td(dt))
+        check(lib().mh_add_pos_time(ptr(x), x.shape[1], ptr(pos.detach()[:L].contiguous()), ptr(emb_t.contiguous()), ptr(out),
+                                    B, L, H, dt, current_stream()), "mh_add_pos_time")
+        ctx.meta = (B, L, H, dt, x.shape[1], pos.shape[0])
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        B, L, H, dt, ldx, Lmax = ctx.meta
+        g = g.contiguous()
+        dx = g if ldx == H else torch.nn.functional.pad(g, (0, ldx - H))
+        dpos_l = _col_sum(g.view(B, L * H), B, L * H, dt).view(L, H)                 # sum over the batch
+        dpos = torch.zeros(Lmax, H, device=g.device, dtype=torch.float32)
+        dpos[:L] = dpos_l
+        demb = _col_sum(g, L, H, dt, batch=B, stride_in=L * H)                        # sum over positions, per sequence
+        return dx, dpos, demb, None, None, None
+
+
+class _Attention(Function):
+    """ctx = softmax(q k^T / sqrt(dh)) v over [M, 3H] = [q | k | v] token-major projections (HF BertSelfAttention)."""
+
+    @staticmethod
+    def forward(ctx, qkv, B, L, nh, dt):
+        M, ld = qkv.shape
+        H = ld // 3 if ld % 3 == 0 else None
+        assert H is not None
+        dh = H // nh
+        td = _td(dt)
+        L_ = lib()
+        st = current_stream()
+        es = qkv.element_size()
+        q = torch.empty(B, nh, L, dh, device=qkv.device, dtype=td)
+        k = torch.empty_like(q)
+        vt = torch.zeros(B * nh * dh * L + 256, device=qkv.device, dtype=td)
+        check(L_.mh_head_permute(qkv.data_ptr(), ptr(q), ld, B, L, nh, dh, 0, dt, st), "mh_head_permute")
+        check(L_.mh_head_permute(qkv.data_ptr() + H * es, ptr(k), ld, B, L, nh, dh, 0, dt, st), "mh_head_permute")
+        check(L_.mh_head_permute(qkv.data_ptr() + 2 * H * es, ptr(vt), ld, B, L, nh, dh, 2, dt, st), "mh_head_permute")
+        scale = 1.0 / math.sqrt(dh)
+        out = ops.attention(q, k, vt, scale, dt)
+        ctx.save_for_backward(q, k, vt)
+        ctx.meta = (B, L, nh, dh, H, dt, scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, dctx):
+        q, k, vt = ctx.saved_tensors
+        B, L, nh, dh, H, dt, scale = ctx.meta
+        dev, td = q.device, q.dtype
+        L_ = lib()
+        st = current_stream()
+        BH, Lp = B * nh, ops.pad64(L)
+        dctx = dctx.contiguous()
+        dO = torch.empty(B, nh, L, dh, device=dev, dtype=td)
+        dOT = torch.zeros(BH * dh, Lp, device=dev, dtype=td)
+        check(L_.mh_head_permute(ptr(dctx), ptr(dO), H, B, L, nh, dh, 0, dt, st), "mh_head_permute")
+        tmp = torch.empty(BH * dh * L, device=dev, dtype=td)
+        check(L_.mh_head_permute(ptr(dctx), ptr(tmp), H, B, L, nh, dh, 2, dt, st), "mh_head_permute")
+        dOT.view(BH, dh, Lp)[:, :, :L] = tmp.view(BH, dh, L)                                    # pad the reduction dim
+        # P = softmax(q k^T * scale)   [BH, L, Lp]
+        P = torch.zeros(BH * L, Lp, device=dev, dtype=td)
+        check(L_.mh_gemm_batched(ptr(q), dh, L * dh, ptr(k), dh, L * dh, None, ptr(P), Lp, L * Lp, 0, BH, L, L, dh, dt, st),
+              "mh_gemm_batched")
+        check(L_.mh_softmax_rows(ptr(P), BH * L, L, Lp, scale, dt, st), "mh_softmax_rows")
+        # dV = P^T dO : A = P^T [L(keys), Lp(q)], W = dO^T [dh, Lp(q)]
+        PT = _transpose(P, L, L, dt, ld_out=Lp, batch=BH, stride_in=L * Lp, stride_out=L * Lp)
+        dV = torch.empty(B, nh, L, dh, device=dev, dtype=td)
+        check(L_.mh_gemm_batched(ptr(PT), Lp, L * Lp, ptr(dOT), Lp, dh * Lp, None, ptr(dV), dh, L * dh, 0, BH, L, dh, Lp, dt, st),
+              "mh_gemm_batched")
+        # dP = dO V^T : W = V [L(keys), dh]
+        V = _transpose(vt, dh, L, dt, ld_out=dh, batch=BH, stride_in=dh * L, stride_out=L * dh, ld_in=L)
+        dP = torch.zeros(BH * L, Lp, device=dev, dtype=td)
+        check(L_.mh_gemm_batched(ptr(dO), dh, L * dh, ptr(V), dh, L * dh, None, ptr(dP), Lp, L * Lp, 0, BH, L, L, dh, dt, st),
+              "mh_gemm_batched")
+        check(L_.mh_softmax_bwd_rows(ptr(P), ptr(dP), BH * L, L, Lp, scale, dt, st), "mh_softmax_bwd_rows")   # dP := dS
+        # dQ = dS K : W = K^T [dh, Lp(keys)]
+        KT = _transpose(k.view(BH * L, dh), L, dh, dt, ld_out=Lp, batch=BH, stride_in=L * dh, stride_out=dh * Lp)
+        dQ = torch.empty(B, nh, L, dh, device=dev, dtype=td)
+        check(L_.mh_gemm_batched(ptr(dP), Lp, L * Lp, ptr(KT), Lp, dh * Lp, None, ptr(dQ), dh, L * dh, 0, BH, L, dh, Lp, dt, st),
+              "mh_gemm_batched")
+        # dK = dS^T Q : A = dS^T [L(keys), Lp(q)], W = Q^T [dh, Lp(q)]
+        dST = _transpose(dP, L, L, dt, ld_out=Lp, batch=BH, stride_in=L * Lp, stride_out=L * Lp)
+        QT = _transpose(q.view(BH * L, dh), L, dh, dt, ld_out=Lp, batch=BH, stride_in=L * dh, stride_out=dh * Lp)
+        dK = torch.empty(B, nh, L, dh, device=dev, dtype=td)
+        check(L_.mh_gemm_batched(ptr(dST), Lp, L * Lp, ptr(QT), Lp, dh * Lp, None, ptr(dK), dh, L * dh, 0, BH, L, dh, Lp, dt, st),
+              "mh_gemm_batched")
+        dqkv = torch.empty(B * L, 3 * H, device=dev, dtype=td)
+        es = dqkv.element_size()
+        for i, t in enumerate((dQ, dK, dV)):
+            check(L_.mh_head_permute(ptr(t), dqkv.data_ptr() + i * H * es, 3 * H, B, L, nh, dh, 1, dt, st), "mh_head_permute")
+        return dqkv, None, None, None, None
+
+
+class _Embed(Function):
+    @staticmethod
+    def forward(ctx, W, ids):
+        ids32 = ids.to(torch.int32).contiguous()
+        ctx.save_for_backward(ids32)
+        ctx.shape = W.shape
+        return ops.embed_gather(W.detach(), ids32)
+
+    @staticmethod
+    def backward(ctx, g):
+        (ids32,) = ctx.saved_tensors
+        V, E = ctx.shape
+        dW = torch.zeros(V, E, device=g.device, dtype=torch.float32)
+        g = g.contiguous()
+        check(lib().mh_scatter_add_rows(ptr(g), ptr(ids32), ptr(dW), ids32.numel(), E, V, current_stream()), "mh_scatter_add_rows")
+        return dW, None
+
+
+class _QSample(Function):
+    """where(mask == 0, x0, a[b] x0 + s[b] noise)   (diffusion.py:229-255); gradient flows to x0 only."""
+
+    @staticmethod
+    def forward(ctx, x0, noise, a, s, mask):
+        m32 = None if mask is None else mask.to(torch.int32).contiguous()
+        ctx.save_for_backward(a, m32)
+        return ops.q_sample(x0, noise, a, s, m32)
+
+    @staticmethod
+    def backward(ctx, g):
+        a, m32 = ctx.saved_tensors
+        g = g.contiguous()
+        B = g.shape[0]
+        dx = torch.empty_like(g)
+        check(lib().mh_scale_rows(ptr(g), ptr(a), ptr(m32), ptr(dx), 0, B, g.numel() // B, g.shape[-1], current_stream()),
+              "mh_scale_rows")
+        return dx, None, None, None, None
+
+
+class _SqDiffMean(Function):
+    """mean_flat((scale * a - b)^2) per batch row (diffusion.py:15-19 applied at :627-639)."""
+
+    @staticmethod
+    def forward(ctx, a, b, scale):
+        B = a.shape[0]
+        a = a.contiguous()
+        b = None if b is None else b.contiguous()
+        out = torch.empty(B, device=a.device, dtype=torch.float32)
+        check(lib().mh_sqdiff_mean(ptr(a), ptr(b), float(scale), ptr(out), B, a.numel() // B, current_stream()), "mh_sqdiff_mean")
+        ctx.save_for_backward(a, b)
+        ctx.scale = float(scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        B = a.shape[0]
+        g = g.contiguous()
+        da = torch.empty_like(a) if ctx.needs_input_grad[0] else None
+        db = torch.empty_like(a) if (b is not None and ctx.needs_input_grad[1]) else None
+        if da is None and db is None:
+            return None, None, None
+        check(lib().mh_sqdiff_bwd(ptr(a), ptr(b), ctx.scale, ptr(g), ptr(da), ptr(db), 0, B, a.numel() // B, current_stream()),
+              "mh_sqdiff_bwd")
+        return da, db, None
+
+
+class _TokenCE(Function):
+    """Per-token cross-entropy of fp32 logits [N, V] against ids [N] (diffusion.py:556-566)."""
+
+    @staticmethod
+    def forward(ctx, logits, ids, V):
+        n = logits.shape[0]
+        ids32 = ids.reshape(-1).to(torch.int32).contiguous()
+        loss = torch.empty(n, device=logits.device, dtype=torch.float32)
+        lse = torch.empty_like(loss)
+        check(lib().mh_cross_entropy_fwd(ptr(logits), logits.shape[1], ptr(ids32), ptr(loss), ptr(lse), n, V, current_stream()),
+              "mh_cross_entropy_fwd")
+        ctx.save_for_backward(logits, ids32, lse)
+        ctx.V = V
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, ids32, lse = ctx.saved_tensors
+        n, ld = logits.shape
+        dl = torch.empty_like(logits)
+        check(lib().mh_cross_entropy_bwd(ptr(logits), ld, ptr(ids32), ptr(lse), ptr(g.contiguous()), ptr(dl), ld, n, ctx.V, ld,
+                                         MH_F32, current_stream()), "mh_cross_entropy_bwd")
+        return dl, None, None
+
+
+# ---------------------------------------------------------------------------------------------- composites
+def _linear(x, lin, act, dt, residual=None):
+    return _Linear.apply(x, lin.weight, lin.bias, act, residual, dt)
+
+
+def denoiser_forward_with_grad(model, x, timesteps):
+    """TransformerNetModel.forward (network.py:131-158) with a gradient tape made of libmusehip kernels."""
+    _lib.require_device(x)
+    dt = ops.dtype_code(model.compute_dtype)
+    B, L, E = x.shape
+    H = model.hidden_size
+    dev = x.device
+    # time MLP (network.py:139): sinusoid (no parameters) -> Linear -> SiLU -> Linear, kept in fp32 compute dtype
+    t = timesteps.to(dev).float()
+    temb = ops.timestep_embedding(t, model.hidden_t_dim, dt, ops.pad64(model.hidden_t_dim))
+    h = _linear(temb, model.time_embed[0], "silu", dt)
+    emb_t = _ToF32.apply(_linear(h, model.time_embed[2], None, dt), H, dt)                       # [B, H] fp32
+    xin = _Cast.apply(x.reshape(B * L, E).float(), dt, True)                                      # [N, pad64(E)]
+    if model.input_dims != H:
+        h = _linear(xin, model.input_up_proj[0], "tanh", dt)
+        h = _linear(h, model.input_up_proj[2], None, dt)
+    else:
+        h = xin
+    pre = _AddPosTime.apply(h, model.position_embeddings.weight, emb_t, B, L, dt)
+    X = _LayerNorm.apply(pre, model.LayerNorm.weight, model.LayerNorm.bias, model.LayerNorm.eps, dt)
+    for layer in model.input_transformers.layer:
+        sa = getattr(layer.attention, "self")
+        Wqkv = torch.cat([sa.query.weight, sa.key.weight, sa.value.weight], dim=0)
+        bqkv = torch.cat([sa.query.bias, sa.key.bias, sa.value.bias], dim=0)
+        qkv = _Linear.apply(X, Wqkv, bqkv, None, None, dt)                                       # [N, 3H]
+        ctxv = _Attention.apply(qkv, B, L, model.num_heads, dt)
+        y1 = _linear(ctxv, layer.attention.output.dense, None, dt, residual=X)
+        X1 = _LayerNorm.apply(y1, layer.attention.output.LayerNorm.weight, layer.attention.output.LayerNorm.bias,
+                              layer.attention.output.LayerNorm.eps, dt)
+        f = _linear(X1, layer.intermediate.dense, "gelu", dt)
+        y2 = _linear(f, layer.output.dense, None, dt, residual=X1)
+        X = _LayerNorm.apply(y2, layer.output.LayerNorm.weight, layer.output.LayerNorm.bias, layer.output.LayerNorm.eps, dt)
+    if model.output_dims != H:
+        h = _linear(X, model.output_down_proj[0], "tanh", dt)
+        h = _linear(h, model.output_down_proj[2], None, dt)
+    else:
+        h = X
+    out = _ToF32.apply(h, E, dt)
+    return out.view(B, L, E).type(x.dtype)
+
+
+def _token_nll(net, x, ids, mask=None):
+    """_token_discrete_loss (diffusion.py:556-575): CE of get_logits(x) against ids, averaged over positions
+    (mask-weighted when a mask is given).  The logits GEMM runs in fp32 on the exact-fp32 MFMA."""
+    B, L, E = x.shape
+    V = net.lm_head.weight.shape[0]
+    xin = _Cast.apply(x.reshape(B * L, E).float(), MH_F32, True)
+    logits = _Linear.apply(xin, net.lm_head.weight, net.lm_head.bias, None, None, MH_F32)         # [N, pad64(V)] fp32
+    nll = _TokenCE.apply(logits, ids, V).view(B, L)
+    if mask is not None:
+        m = mask.to(nll.device, torch.float32)
+        return (nll * m).sum(dim=-1) / m.sum(dim=-1)
+    return nll.mean(dim=-1)
+
+
+def training_losses(diffusion, model, t, model_kwargs, noise=None, with_corruption=False):
+    """training_losses_seq2seq / ..._with_corruption (diffusion.py:594-699).  `model` may be a DDP / _WrappedModel
+    shell; returns {'mse', 'nll', 'loss'} as [B] fp32 tensors attached to the kernel-level gradient tape."""
+    from .models.diffusion import _device_table, unwrap_model
+    assert "input_ids" in model_kwargs
+    dev = t.device
+    net = unwrap_model(model)
+    ids = model_kwargs["input_ids"].to(dev)
+    mask = model_kwargs["input_mask"].to(dev)
+    x_start_mean = _Embed.apply(net.word_embedding.weight, ids)                                   # diffusion.py:608
+    B = x_start_mean.shape[0]
+    ones = torch.ones(B, device=dev)
+    std0 = _device_table(diffusion.sqrt_one_minus_alphas_cumprod, dev)[0].expand(B).contiguous()  # diffusion.py:610-612
+
+    def jitter(mean):                                                                              # _get_x_start, :542-554
+        return _QSample.apply(mean, torch.randn_like(mean), ones, std0, None)
+
+    x_start = jitter(x_start_mean)
+    if with_corruption:
+        tgt_ids = model_kwargs["correct_ids"].to(dev)
+        tgt_mean = _Embed.apply(net.word_embedding.weight, tgt_ids)
+        tgt_start = jitter(tgt_mean)
+    else:
+        tgt_ids, tgt_mean, tgt_start = ids, x_start_mean, x_start
+    if noise is None:
+        noise = torch.randn_like(x_start)
+    a = _device_table(diffusion.sqrt_alphas_cumprod, dev)[t]
+    s = _device_table(diffusion.sqrt_one_minus_alphas_cumprod, dev)[t]
+    x_t = _QSample.apply(x_start, noise, a, s, mask)                                               # diffusion.py:618
+    model_output = model(x_t, diffusion._scale_timesteps(t), **model_kwargs)                        # diffusion.py:624
+    assert model_output.shape == x_start.shape
+    if not diffusion.predict_xstart:
+        raise NotImplementedError("training with predict_xstart=False (the reference never builds it, "
+                                  "utils/initialization.py:129-134)")
+    t_loss = _SqDiffMean.apply(tgt_start, model_output, 1.0)                                       # :627 / :679
+    t0_loss = _SqDiffMean.apply(tgt_mean, model_output, 1.0)                                       # :630 / :682
+    terms = {"mse": torch.where(t == 0, t0_loss, t_loss)}
+    sqrt_ab_T = float(diffusion.sqrt_alphas_cumprod[diffusion.num_timesteps - 1].astype("float32"))
+    tT_loss = _SqDiffMean.apply(x_start, None, sqrt_ab_T)                                          # :634-639
+    decoder_nll = _token_nll(net, x_start, ids)                                                    # :641
+    terms["nll"] = _token_nll(net, model_output, tgt_ids, mask=mask)                               # :642 / :694
+    terms["loss"] = terms["mse"] + decoder_nll + tT_loss                                           # :645
+    return terms

@@ -1,0 +1,106 @@
+"""Training-path parity (GPU): training_losses of the product (fp32 compute mode) against the reference's
+recorded losses and gradients (tests/golden/losses_tiny.npz, made with dropout 0), with the reference's random
+draws reproduced by seeding the CPU generator and feeding the same tensors through `torch.randn_like` patches.
+
+Tolerances: losses 5e-4 rel, gradients 2e-3 of the gradient's max-abs (fp32 kernels, different summation
+orders than MKL / autograd)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from conftest import load_golden  # noqa: E402
+from musediffusion_amd.models.diffusion import SpacedDiffusion, get_named_beta_schedule, space_timesteps  # noqa: E402
+from musediffusion_amd.models.network import TransformerNetModel  # noqa: E402
+from oracle import fixtures as fx  # noqa: E402
+
+DEV = "cuda"
+
+
+def build(tag, compute_dtype="fp32"):
+    c = fx.CONFIGS[tag]
+    m = TransformerNetModel(c["E"], c["E"], c["Tt"], c["V"], c["L"], dropout=0.0, bert_hidden=c["H"],
+                            bert_layers=c["nL"], bert_heads=c["nh"], bert_ffn=c["F"], compute_dtype=compute_dtype)
+    m.load_state_dict(fx.state_dict(tag))
+    m.train().requires_grad_(True).to(DEV)
+    diff = SpacedDiffusion(use_timesteps=space_timesteps(2000, [2000]), betas=get_named_beta_schedule("sqrt", 2000),
+                           rescale_timesteps=True, predict_xstart=True)
+    return m, diff, c
+
+
+class CpuDraws:
+    """Makes torch.randn_like(x) on the device return the draws a seeded CPU generator produces (the reference
+    fixture was generated on CPU): same call order, same shapes."""
+
+    def __init__(self, seed):
+        self.g = torch.Generator().manual_seed(seed)
+        self.orig = torch.randn_like
+
+    def __enter__(self):
+        def fake(x, **kw):
+            return torch.randn(x.shape, generator=self.g, dtype=torch.float32).to(x.device)
+        torch.randn_like = fake
+        return self
+
+    def __exit__(self, *a):
+        torch.randn_like = self.orig
+
+
+def close(name, got, ref, rel):
+    got = got.detach().float().cpu()
+    ref = torch.from_numpy(np.asarray(ref))
+    err = float((got - ref).abs().max())
+    scale = float(ref.abs().max()) + 1e-12
+    print("%s: max abs err %.3e (ref absmax %.3e)" % (name, err, scale))
+    assert err <= rel * scale, "%s: err %.3e > %.1e * %.3e" % (name, err, rel, scale)
+
+
+@pytest.mark.parametrize("variant", ["plain", "corrupt"])
+def test_training_losses_and_grads_match_reference(variant):
+    tag = "tiny"
+    g = load_golden("losses_tiny.npz")
+    m, diff, c = build(tag)
+    li = fx.loss_inputs(tag)
+    batch, t, w = li["batch"], li["t"].to(DEV), li["w"].to(DEV)
+    kw = {k: v for k, v in batch.items() if variant == "corrupt" or k != "correct_ids"}
+    # the fixture seeded the GLOBAL cpu generator: torch.manual_seed(s) then randn_like in reference order
+    with CpuDraws(fx.loss_seed(tag)) as d:
+        d.g = torch.Generator().manual_seed(fx.loss_seed(tag))
+        terms = diff.training_losses(m, t, model_kwargs=kw)
+    for k in ("mse", "nll", "loss"):
+        close("%s %s" % (variant, k), terms[k], g["%s_%s" % (variant, k)], 5e-4)
+    (terms["loss"] * w).mean().backward()
+    close(variant + " grad word_embedding", m.word_embedding.weight.grad, g[variant + "_g_word"], 2e-3)
+    close(variant + " grad layer0.query", m.input_transformers.layer[0].attention.self.query.weight.grad, g[variant + "_g_q0"], 2e-3)
+    close(variant + " grad time_embed.0", m.time_embed[0].weight.grad, g[variant + "_g_te0"], 2e-3)
+    close(variant + " grad lm_head.bias", m.lm_head.bias.grad, g[variant + "_g_lmb"], 2e-3)
+    for n, p in m.named_parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all(), n
+
+
+def test_training_forward_matches_inference_engine():
+    m, diff, c = build("tiny")
+    inp = fx.case_inputs("tiny", fx.state_dict("tiny")["word_embedding.weight"])
+    x, t = inp["fwd_x"].to(DEV), inp["fwd_t"].to(DEV)
+    y_train = m(x, t)                       # grad enabled -> tape path
+    assert y_train.requires_grad
+    with torch.no_grad():
+        y_inf = m(x, t)                     # engine path
+    assert float((y_train - y_inf).abs().max()) < 5e-5
+
+
+def test_bf16_training_runs_and_tracks_fp32():
+    m32, diff, c = build("same", "fp32")
+    m16, _, _ = build("same", "bf16")
+    li = fx.loss_inputs("same")
+    batch, t = li["batch"], li["t"].to(DEV)
+    outs = []
+    for m in (m32, m16):
+        with CpuDraws(5):
+            terms = diff.training_losses(m, t, model_kwargs=batch)
+        terms["loss"].mean().backward()
+        outs.append((terms["loss"].detach().cpu(), m.word_embedding.weight.grad.detach().cpu()))
+    assert torch.allclose(outs[0][0], outs[1][0], rtol=3e-2, atol=3e-2)
+    cos = torch.nn.functional.cosine_similarity(outs[0][1].flatten(), outs[1][1].flatten(), dim=0)
+    assert float(cos) > 0.99, float(cos)
