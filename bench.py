@@ -37,6 +37,8 @@ WORKLOADS = {
     "c2-bertbase": dict(L=512, B=64, E=128, H=768, nL=12, nh=12, F=3072, V=729, Tt=128, T=2000),
     # BASELINE.json configs[0] shape (plumbing)
     "c1": dict(L=128, B=8, E=128, H=128, nL=2, nh=4, F=512, V=729, Tt=128, T=2000),
+    # BASELINE.json configs[4]: training_losses, seq_len 1024, global batch 256 = 32 per GPU x 8 (DDP, RCCL all-reduce)
+    "train": dict(L=1024, B=32, E=128, H=512, nL=12, nh=8, F=2048, V=729, Tt=128, T=2000),
 }
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}   # dense peaks, MI355X_MICROARCH.md
 
@@ -151,6 +153,65 @@ def cpu_baseline(c, seconds_budget=25.0):
                       % (cores, Bs, c["B"], n, el, Bs, c["B"])}
 
 
+def train_main(args, world, rank, local_rank, device):
+    """`--workload train`: one step = training_losses forward + backward over one micro-batch (the reference's
+    _forward_backward_logic, utils/train_util.py:188-232) with DDP gradient all-reduce when N > 1.  Reported
+    separately from the headline sampling metric."""
+    import torch.distributed as dist
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    from musediffusion_amd import synthetic
+    c = WORKLOADS["train"]
+    model, diff = build(c, args.dtype, device, seed=0)
+    model.train().requires_grad_(True)
+    net = model
+    if world > 1:
+        model = DDP(model, device_ids=[local_rank], broadcast_buffers=False, bucket_cap_mb=128, find_unused_parameters=False)
+    batch = {k: v.to(device) for k, v in synthetic.training_batch(c["B"], c["L"], seed=1 + rank).items()}
+    g = torch.Generator().manual_seed(7 + rank)
+
+    def step():
+        t = torch.randint(0, c["T"], (c["B"],), generator=g).to(device)
+        net.zero_grad(set_to_none=True)
+        terms = diff.training_losses(model, t, model_kwargs=batch)
+        terms["loss"].mean().backward()
+        return terms
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        terms = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    el = torch.tensor([time.perf_counter() - t0], device=device, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    elapsed = float(el.item())
+    assert bool(torch.isfinite(terms["loss"]).all())
+    if rank == 0:
+        N = c["B"] * c["L"]
+        fwd = step_flops(dict(c)) - 2 * N * c["V"] * c["E"] + 2 * 2 * N * c["V"] * c["E"]   # denoiser + two CE heads
+        out = {"metric": "training-steps/sec (training_losses fwd+bwd, seq_len=%d, batch=%d/GPU)" % (c["L"], c["B"]),
+               "value": round(world * args.steps / elapsed, 3), "unit": "micro-batch steps/s", "n_gpus": world,
+               "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+               "config": {"workload": "training_losses_seq2seq_with_corruption fwd+bwd, seq_len=%d batch=%d/GPU d_model=%d "
+                                      "layers=%d" % (c["L"], c["B"], c["H"], c["nL"]),
+                          "global_batch": c["B"] * world, "seq_len": c["L"], "parallelism": "ddp x%d" % world,
+                          "tokens_per_s": round(world * args.steps * N / elapsed, 1),
+                          "approx_tflops": round(3 * fwd / (elapsed / args.steps) / 1e12, 2)}}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -176,6 +237,8 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=device)
 
+    if args.workload == "train":
+        return train_main(args, world, rank, local_rank, device)
     from functools import partial
     from musediffusion_amd import _lib, synthetic
     from musediffusion_amd.models.diffusion import _ReverseLoop

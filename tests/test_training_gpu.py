@@ -104,3 +104,41 @@ def test_bf16_training_runs_and_tracks_fp32():
     assert torch.allclose(outs[0][0], outs[1][0], rtol=3e-2, atol=3e-2)
     cos = torch.nn.functional.cosine_similarity(outs[0][1].flatten(), outs[1][1].flatten(), dim=0)
     assert float(cos) > 0.99, float(cos)
+
+
+def test_ddp_wrapped_training_step_single_rank_nccl():
+    """DistributedDataParallel over RCCL (backend 'nccl') wraps the model exactly like the reference's TrainLoop
+    (utils/train_util.py:106-116); gradients through DDP equal the plain ones."""
+    import os
+    import torch.distributed as dist
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1)
+        created = True
+    try:
+        m, diff, c = build("tiny")
+        li = fx.loss_inputs("tiny")
+        batch, t = li["batch"], li["t"].to(DEV)
+        with CpuDraws(9):
+            ref_terms = diff.training_losses(m, t, model_kwargs=batch)
+        ref_terms["loss"].mean().backward()
+        ref_grads = {n: p.grad.clone() for n, p in m.named_parameters()}
+        m.zero_grad(set_to_none=True)
+        ddp = DDP(m, device_ids=[torch.cuda.current_device()], broadcast_buffers=False, bucket_cap_mb=128,
+                  find_unused_parameters=False)
+        with CpuDraws(9):
+            terms = diff.training_losses(ddp, t, model_kwargs=batch)
+        terms["loss"].mean().backward()
+        for n, p in m.named_parameters():
+            assert torch.allclose(p.grad, ref_grads[n], rtol=1e-5, atol=1e-7), n
+        # the loss-aware sampler's packed all_gather on the device
+        from musediffusion_amd.models.step_sample import create_named_schedule_sampler
+        s = create_named_schedule_sampler("lossaware", diff)
+        ts, w = s.sample(4, DEV)
+        s.update_with_local_losses(ts, terms["loss"].detach()[:4] if terms["loss"].numel() >= 4 else terms["loss"].detach().repeat(2))
+    finally:
+        if created:
+            dist.destroy_process_group()
