@@ -235,166 +235,176 @@ __global__ __launch_bounds__(512) void attn_res_bf16_kernel(const bf16* __restri
   const bf16* Vb = VT + (int64_t)bh * DH * L;
 
   // ---- stage all of K ([keys][DH], swizzled 16-B chunks) and V^T (per 64-key tile [DH][64 keys], key-permuted)
-  // all global loads are issued before the first LDS write (8 + 8 independent 16-B loads per thread at L = 512):
-  // a load -> store loop would expose one full memory latency per iteration
+  // K, then V^T: within each, all of a thread's global loads are issued before its first LDS write (a
+  // load -> store loop would expose one full memory latency per iteration)
   const int Lp = ntiles * 64;
   constexpr int MAXIT = (64 * 1024 / 16) / 512;   // 16-B chunks per thread per operand when the operand fills 64 KiB
   const int cpr = Lp / 8;                          // 16-B chunks per V^T row
-  f32x4 kreg[MAXIT], vreg[MAXIT];
+  {
+    f32x4 reg[MAXIT];
 #pragma unroll
-  for (int i = 0; i < MAXIT; ++i) {
-    const int qd = tid + 512 * i;
-    if (qd < Lp * CH) {
-      const int row = qd / CH, c = qd % CH;
-      const int kr = row < L ? row : L - 1;
-      kreg[i] = *reinterpret_cast<const f32x4*>(Kb + (int64_t)kr * DH + c * 8);
+    for (int i = 0; i < MAXIT; ++i) {
+      const int qd = tid + 512 * i;
+      if (qd < Lp * CH) {
+        const int row = qd / CH, c = qd % CH;
+        reg[i] = *reinterpret_cast<const f32x4*>(Kb + (int64_t)(row < L ? row : L - 1) * DH + c * 8);
+      }
     }
-    if (qd < DH * cpr) {
-      const int d = qd / cpr, key = (qd % cpr) * 8;
-      vreg[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (key < L) vreg[i] = *reinterpret_cast<const f32x4*>(Vb + (int64_t)d * L + key);
+#pragma unroll
+    for (int i = 0; i < MAXIT; ++i) {
+      const int qd = tid + 512 * i;
+      if (qd < Lp * CH) {
+        const int row = qd / CH, c = qd % CH;
+        *reinterpret_cast<f32x4*>(kbase + row * KROWB + ((c ^ ((row / RPB) & (CH - 1))) << 4)) = reg[i];
+      }
     }
   }
+  {
+    f32x4 reg[MAXIT];
 #pragma unroll
-  for (int i = 0; i < MAXIT; ++i) {
-    const int qd = tid + 512 * i;
-    if (qd < Lp * CH) {
-      const int row = qd / CH, c = qd % CH;
-      *reinterpret_cast<f32x4*>(kbase + row * KROWB + ((c ^ ((row / RPB) & (CH - 1))) << 4)) = kreg[i];
+    for (int i = 0; i < MAXIT; ++i) {
+      const int qd = tid + 512 * i;
+      if (qd < DH * cpr) {
+        const int d = qd / cpr, key = (qd % cpr) * 8;
+        reg[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (key < L) reg[i] = *reinterpret_cast<const f32x4*>(Vb + (int64_t)d * L + key);
+      }
     }
-    if (qd < DH * cpr) {
-      const int d = qd / cpr, cg = qd % cpr;
-      const int t = cg >> 3, c = cg & 7, sblk = c >> 1, sw = (d >> 1) & 7, half = (c & 1) * 8;
-      typedef __attribute__((ext_vector_type(2))) float f32x2;
-      char* vb = vbase + t * VT_BYTES + d * 128;
-      *reinterpret_cast<f32x2*>(vb + (((2 * sblk) ^ sw) << 4) + half) = f32x2{vreg[i][0], vreg[i][1]};
-      *reinterpret_cast<f32x2*>(vb + (((2 * sblk + 1) ^ sw) << 4) + half) = f32x2{vreg[i][2], vreg[i][3]};
+#pragma unroll
+    for (int i = 0; i < MAXIT; ++i) {
+      const int qd = tid + 512 * i;
+      if (qd < DH * cpr) {
+        const int d = qd / cpr, cg = qd % cpr;
+        const int t = cg >> 3, c = cg & 7, sblk = c >> 1, sw = (d >> 1) & 7, half = (c & 1) * 8;
+        typedef __attribute__((ext_vector_type(2))) float f32x2;
+        char* vb = vbase + t * VT_BYTES + d * 128;
+        *reinterpret_cast<f32x2*>(vb + (((2 * sblk) ^ sw) << 4) + half) = f32x2{reg[i][0], reg[i][1]};
+        *reinterpret_cast<f32x2*>(vb + (((2 * sblk + 1) ^ sw) << 4) + half) = f32x2{reg[i][2], reg[i][3]};
+      }
     }
   }
   __syncthreads();
 
-  // Each wave walks TWO 32-query tiles at once (tiles wave and wave + 8, ...): two independent
-  // S -> softmax -> PV chains in one instruction stream, so the MFMAs of one hide the exp / max / sum latency
-  // of the other.  Row max and row sum are reduced as 4-way trees, not 32-long dependent chains.
+  // One 32-query tile per wave at a time, software-pipelined fragment loads: the eight K fragments of tile t+1
+  // are read from LDS while tile t's softmax / P.V run, the eight V^T fragments of tile t while its K.Q^T
+  // MFMAs run, so no MFMA waits on an LDS round trip (two waves per SIMD cannot hide sixteen exposed
+  // ds_read latencies per tile).  Row max / row sum are 4-way trees.
   const int nq = (L + 31) / 32;
-  for (int qt0 = wave; qt0 < nq; qt0 += 16) {
-    int q0[2];
-    bool act[2];
-    bf16x8 qf[2][KS];
-    f32x16 o[2][DT];
-    float m_run[2], l_run[2];
+  const int krow0 = lq, krow1 = 32 + lq;
+  const int ksw0 = (krow0 / RPB) & (CH - 1), ksw1 = (krow1 / RPB) & (CH - 1);
+  for (int qt = wave; qt < nq; qt += 8) {
+    const int q0 = qt * 32;
+    bf16x8 qf[KS];
+    {
+      int qr = q0 + lq; if (qr >= L) qr = L - 1;
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int qt = qt0 + 8 * u;
-      act[u] = qt < nq;
-      q0[u] = (act[u] ? qt : qt0) * 32;
-      int qr = q0[u] + lq; if (qr >= L) qr = L - 1;
+      for (int ks = 0; ks < KS; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(Qb + (int64_t)qr * DH + 16 * ks + 8 * h);
+    }
+    f32x16 o[DT];
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) qf[u][ks] = *reinterpret_cast<const bf16x8*>(Qb + (int64_t)qr * DH + 16 * ks + 8 * h);
+    for (int i = 0; i < DT; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+    bf16x8 kf[2][KS];
+    auto load_k = [&](int t, bf16x8 (&dst)[2][KS]) {
+      const char* kb = kbase + t * KT_BYTES;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        dst[0][ks] = *reinterpret_cast<const bf16x8*>(kb + krow0 * KROWB + (((2 * ks + h) ^ ksw0) << 4));
+        dst[1][ks] = *reinterpret_cast<const bf16x8*>(kb + krow1 * KROWB + (((2 * ks + h) ^ ksw1) << 4));
+      }
+    };
+    load_k(0, kf);
+    auto tile = [&](int t, auto masked) {
+      const char* vb = vbase + t * VT_BYTES;
+      const int k0 = t * 64;
+      // V^T fragments for this tile: in flight during the S MFMAs and the softmax
+      bf16x8 vf[4][DT];
+#pragma unroll
+      for (int sp = 0; sp < 4; ++sp)
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+          const int d = dt * 32 + lq;
+          vf[sp][dt] = *reinterpret_cast<const bf16x8*>(vb + d * 128 + (((2 * sp + h) ^ ((d >> 1) & 7)) << 4));
+        }
+      f32x16 s[2];
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kt][ks], qf[ks], s[kt], 0, 0, 0);
+      }
+      // next tile's K fragments: in flight during the softmax and the P.V MFMAs
+      bf16x8 kn[2][KS];
+      const int tn = t + 1 < ntiles ? t + 1 : t;
+      load_k(tn, kn);
+      if constexpr (decltype(masked)::value) {
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            if (k0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h >= L) s[kt][r] = -INFINITY;
+      }
+      float mx4[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; r += 4)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) mx4[e] = fmaxf(mx4[e], s[kt][r + e]);
+      float mx = fmaxf(fmaxf(mx4[0], mx4[1]), fmaxf(mx4[2], mx4[3]));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * scale_log2e);
+      const float mb = m_new * scale_log2e;
+      float ps4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float p = __builtin_amdgcn_exp2f(s[kt][r] * scale_log2e - mb);
+          s[kt][r] = p;
+          ps4[r & 3] += p;
+        }
+      l_run = l_run * alpha + ((ps4[0] + ps4[1]) + (ps4[2] + ps4[3]));
+      m_run = m_new;
 #pragma unroll
       for (int i = 0; i < DT; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) o[u][i][r] = 0.f;
-      m_run[u] = -INFINITY; l_run[u] = 0.f;
-    }
-    auto tile = [&](int t, auto masked) {   // masked: compile-time flag, only the ragged last tile pays for key masking
-      const char* kb = kbase + t * KT_BYTES;
-      const char* vb = vbase + t * VT_BYTES;
-      const int k0 = t * 64;
-      f32x16 s[2][2];
-#pragma unroll
-      for (int kt = 0; kt < 2; ++kt) {
-        const int row = kt * 32 + lq;
-        const int sw = (row / RPB) & (CH - 1);
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) s[u][kt][r] = 0.f;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-          const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kb + row * KROWB + (((2 * ks + h) ^ sw) << 4));
-#pragma unroll
-          for (int u = 0; u < 2; ++u) s[u][kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[u][ks], s[u][kt], 0, 0, 0);
-        }
-      }
-      float alpha[2];
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        if constexpr (decltype(masked)::value) {
-#pragma unroll
-          for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-              if (k0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h >= L) s[u][kt][r] = -INFINITY;
-        }
-        float mx4[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-          for (int r = 0; r < 16; r += 4)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) mx4[e] = fmaxf(mx4[e], s[u][kt][r + e]);
-        float mx = fmaxf(fmaxf(mx4[0], mx4[1]), fmaxf(mx4[2], mx4[3]));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run[u], mx);
-        alpha[u] = __builtin_amdgcn_exp2f((m_run[u] - m_new) * scale_log2e);
-        const float mb = m_new * scale_log2e;
-        float ps4[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const float p = __builtin_amdgcn_exp2f(s[u][kt][r] * scale_log2e - mb);
-            s[u][kt][r] = p;
-            ps4[r & 3] += p;
-          }
-        l_run[u] = l_run[u] * alpha[u] + ((ps4[0] + ps4[1]) + (ps4[2] + ps4[3]));
-        m_run[u] = m_new;
-      }
-#pragma unroll
-      for (int u = 0; u < 2; ++u)
-#pragma unroll
-        for (int i = 0; i < DT; ++i)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) o[u][i][r] *= alpha[u];
+        for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
 #pragma unroll
       for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
-          bf16x8 pf[2];
+          bf16x8 pf;
 #pragma unroll
-          for (int u = 0; u < 2; ++u)
+          for (int j = 0; j < 8; ++j) pf[j] = (bf16)s[kt][8 * s2 + j];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) pf[u][j] = (bf16)s[u][kt][8 * s2 + j];
-          const int sp = 2 * kt + s2;
-#pragma unroll
-          for (int dt = 0; dt < DT; ++dt) {
-            const int d = dt * 32 + lq;
-            const bf16x8 vf = *reinterpret_cast<const bf16x8*>(vb + d * 128 + (((2 * sp + h) ^ ((d >> 1) & 7)) << 4));
-#pragma unroll
-            for (int u = 0; u < 2; ++u) o[u][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[u], o[u][dt], 0, 0, 0);
-          }
+          for (int dt = 0; dt < DT; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[2 * kt + s2][dt], pf, o[dt], 0, 0, 0);
         }
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) kf[kt][ks] = kn[kt][ks];
     };
     const int nfull = L / 64;
     for (int t = 0; t < nfull; ++t) tile(t, std::false_type{});
     if (nfull < ntiles) tile(nfull, std::true_type{});
+    const float inv = 1.0f / (l_run + __shfl_xor(l_run, 32, 64));
+    const int qr = q0 + lq;
+    if (qr < L) {
+      const int64_t tok = (int64_t)b * L + qr;
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const float inv = 1.0f / (l_run[u] + __shfl_xor(l_run[u], 32, 64));
-      const int qr = q0[u] + lq;
-      if (act[u] && qr < L) {
-        const int64_t tok = (int64_t)b * L + qr;
+      for (int dt = 0; dt < DT; ++dt) {
+        bf16* dst = ctx_panel ? ctx + (((int64_t)(head * DT + dt)) * ld_ctx + tok) * 32 : ctx + tok * ld_ctx + head * DH + dt * 32;
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt) {
-          bf16* dst = ctx_panel ? ctx + (((int64_t)(head * DT + dt)) * ld_ctx + tok) * 32 : ctx + tok * ld_ctx + head * DH + dt * 32;
+        for (int rg = 0; rg < 4; ++rg) {
+          bf16x4 v;
 #pragma unroll
-          for (int rg = 0; rg < 4; ++rg) {
-            bf16x4 v;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = (bf16)(o[u][dt][rg * 4 + e] * inv);
-            *reinterpret_cast<bf16x4*>(dst + 8 * rg + 4 * h) = v;
-          }
+          for (int e = 0; e < 4; ++e) v[e] = (bf16)(o[dt][rg * 4 + e] * inv);
+          *reinterpret_cast<bf16x4*>(dst + 8 * rg + 4 * h) = v;
         }
       }
     }
@@ -552,7 +562,7 @@ template <int DH>
 int launch_bf16(const bf16* q, const bf16* k, const bf16* vt, bf16* ctx, int64_t ld, int B, int L, int nh,
                 float scale, int ctx_panel, hipStream_t s) {
   const size_t res_bytes = (size_t)ceil_div(L, 64) * 64 * DH * 4;   // K + V^T of one (batch, head)
-  if (g_attn_resident && res_bytes <= 128 * 1024 && L >= 128) {
+  if (g_attn_resident && DH <= 64 && res_bytes <= 128 * 1024 && L >= 128) {
     static bool attr_set = false;
     if (!attr_set) {
       MH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_res_bf16_kernel<DH>),
