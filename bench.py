@@ -51,7 +51,7 @@ def step_flops(c):
     return N * per_tok + 2 * B * (4 * Tt * Tt + 4 * Tt * H)
 
 
-def gemm_launches(c):
+def _unused_gemm_launches(c):
     """(M, N, K) of every launch of the generic GEMM kernel (gemm_kernel<bf16, EPI=0>) in one step."""
     N, H, F, E = c["B"] * c["L"], c["H"], c["F"], c["E"]
     Ep = (E + 63) // 64 * 64
@@ -78,20 +78,39 @@ def build(c, dtype, device, seed=0):
 
 
 def time_dominant_kernel(c, dtype, device, reps):
-    """Average launch duration of the generic bf16/f32 GEMM kernel over the launches one step makes,
-    measured with HIP events on the launch stream (back-to-back launches of the real shapes)."""
-    from musediffusion_amd import ops
+    """Average launch duration of the generic GEMM kernel over the launches one step makes, measured with HIP
+    events on the launch stream: back-to-back launches of the real shapes in the layout the engine uses
+    (K32 panels for bf16, row-major for fp32), bias + the step's epilogues included."""
+    from musediffusion_amd import _lib, ops
     code = ops.dtype_code(dtype)
     td = ops.TORCH_DTYPE[code]
-    shapes = gemm_launches(c)
-    bufs = {}
-    for (M, N, K) in set(shapes):
-        bufs[(M, N, K)] = (torch.randn(M, K, device=device).to(td), (torch.randn(N, K, device=device) / K ** 0.5).to(td),
-                           torch.zeros(N, device=device), torch.empty(M, N, device=device, dtype=td))
+    panel = 1 if code == _lib.MH_BF16 else 0
+    N_tok, H, F, E = c["B"] * c["L"], c["H"], c["F"], c["E"]
+    Ep = (E + 63) // 64 * 64
+    # (N_out, K, act, residual, fp32 out) of every generic-GEMM launch of one step (engine.hip order)
+    launches = []
+    if E != H:
+        launches += [(H, Ep, 1, False, False), (H, H, 0, False, False)]
+    for _ in range(c["nL"]):
+        launches += [(H, H, 0, True, False), (F, H, 2, False, False), (H, F, 0, True, False)]
+    if E != H:
+        launches += [(H, H, 1, False, False), (E, H, 0, False, True)]
+    Kmax, Nmax = max(k for _, k, _, _, _ in launches), max(n for n, _, _, _, _ in launches)
+    A = torch.randn(N_tok * Kmax, device=device).to(td)
+    W = (torch.randn(Nmax * Kmax, device=device) / 32).to(td)
+    R = torch.randn(N_tok * Nmax, device=device).to(td)
+    O = torch.empty(N_tok * max(Nmax, 1) * 2, device=device, dtype=td)
+    bias = torch.zeros(Nmax, device=device)
+    lib, st = _lib.lib(), _lib.current_stream
+
     def one_pass():
-        for s in shapes:
-            A, W, b, o = bufs[s]
-            ops.gemm_bias_act(A, W, b, None, None, code, out=o)
+        for (n, k, act, res, f32) in launches:
+            lda = N_tok if panel else k
+            ldw = n if panel else k
+            ldo = n if f32 else (N_tok if panel else n)
+            _lib.check(lib.mh_gemm_bias_act_ex(A.data_ptr(), lda, panel, W.data_ptr(), ldw, panel, bias.data_ptr(),
+                                               R.data_ptr() if res else None, N_tok if panel else n, panel, O.data_ptr(), ldo,
+                                               0 if f32 else panel, int(f32), N_tok, n, k, act, code, st()))
     one_pass()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -100,9 +119,9 @@ def time_dominant_kernel(c, dtype, device, reps):
         one_pass()
     e1.record()
     torch.cuda.synchronize()
-    avg_ms = e0.elapsed_time(e1) / (reps * len(shapes))
-    flops_per_launch = sum(2.0 * M * N * K for (M, N, K) in shapes) / len(shapes)
-    return avg_ms, flops_per_launch, len(shapes)
+    avg_ms = e0.elapsed_time(e1) / (reps * len(launches))
+    flops_per_launch = sum(2.0 * N_tok * n * k for (n, k, _, _, _) in launches) / len(launches)
+    return avg_ms, flops_per_launch, len(launches)
 
 
 def cpu_baseline(c, seconds_budget=25.0):
@@ -313,7 +332,8 @@ def main():
             avg_ms, fpl, nl = time_dominant_kernel(c, args.dtype, device, reps=5)
             ach = fpl / (avg_ms * 1e-3) / 1e12
             peak = MFMA_PEAK_TFLOPS[args.dtype]
-            out["roofline"] = {"bound": "mfma", "kernel": "gemm_kernel<%s,EPI=0> (%d launches/step)" % (args.dtype, nl),
+            kname = "gemm_big_kernel<EPI=0> bf16 256x128 tile" if args.dtype == "bf16" else "gemm_kernel<float,EPI=0>"
+            out["roofline"] = {"bound": "mfma", "kernel": "%s (%d launches/step)" % (kname, nl),
                                "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                                "traffic": None, "avg_launch_ms": round(avg_ms, 5), "flops_per_launch": fpl}
         if not args.no_cpu_baseline:

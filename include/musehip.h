@@ -262,6 +262,30 @@ int mh_scatter_add_rows(const float* src, const int32_t* ids, float* table, int6
 int mh_scale_rows(const float* src, const float* scale, const int32_t* mask, float* dst, int accumulate, int B, int64_t per_batch,
                   int E, mh_stream_t stream);
 
+/* ------------------------------------------------------------------ optimizer step
+ * Fused multi-tensor AdamW + up to 4 EMA copies (+ gradient L2 norm) over every parameter tensor in one
+ * launch each: utils/train_util.py:246-280 (optimize, _log_grad_norm) and :21-31 (update_ema).
+ * `tensors` / `chunks` are DEVICE tables built once by the host. */
+typedef struct mh_opt_tensor {
+  float* param; const float* grad; float* exp_avg; float* exp_avg_sq; float* ema[4];
+} mh_opt_tensor;
+typedef struct mh_opt_chunk { int32_t tensor; int32_t count; int64_t offset; } mh_opt_chunk;
+typedef struct mh_opt_hparams {   /* all derived scalars are evaluated in double by the host (as torch does) */
+  float beta1, beta2, eps;
+  float one_minus_beta1, one_minus_beta2;
+  float decay_mul;   /* 1 - lr * weight_decay */
+  float step_size;   /* lr / (1 - beta1^step) */
+  float bias2_sqrt;  /* sqrt(1 - beta2^step) */
+  int n_ema;
+  float ema_rate[4];
+  float ema_one_minus[4];
+} mh_opt_hparams;
+int mh_adamw_ema_step(const mh_opt_tensor* tensors, const mh_opt_chunk* chunks, int n_chunks, const mh_opt_hparams* hp,
+                      mh_stream_t stream);
+/* out[0] = sqrt(sum over all gradient elements of g^2); partial: [n_chunks] fp32 scratch */
+int mh_grad_norm(const mh_opt_tensor* tensors, const mh_opt_chunk* chunks, int n_chunks, float* partial, float* out,
+                 mh_stream_t stream);
+
 /* ------------------------------------------------------------------ captured reverse step support */
 
 /* Device-side loop state of a replayed reverse-diffusion step.  `steps` holds the timestep index

@@ -32,6 +32,13 @@ class LoopState(C.Structure):
     _fields_ = [("pos", C.c_uint32), ("n_steps", C.c_uint32), ("cur_t", C.c_int32), ("pad", C.c_uint32)]
 
 
+class OptHParams(C.Structure):
+    """mh_opt_hparams"""
+    _fields_ = [("beta1", F32), ("beta2", F32), ("eps", F32), ("one_minus_beta1", F32), ("one_minus_beta2", F32),
+                ("decay_mul", F32), ("step_size", F32), ("bias2_sqrt", F32), ("n_ema", INT), ("ema_rate", F32 * 4),
+                ("ema_one_minus", F32 * 4)]
+
+
 class LayerWeights(C.Structure):
     """mh_layer_weights"""
     _fields_ = [(n, VP) for n in ("w_qkv", "b_qkv", "w_ao", "b_ao", "ln1_g", "ln1_b", "w_ff1", "b_ff1",
@@ -96,6 +103,8 @@ SIGNATURES = {
     "mh_add_inplace": (INT, [VP, VP, I64, INT, VP]),
     "mh_scatter_add_rows": (INT, [VP, VP, VP, I64, INT, INT, VP]),
     "mh_scale_rows": (INT, [VP, VP, VP, VP, INT, INT, I64, INT, VP]),
+    "mh_adamw_ema_step": (INT, [VP, VP, INT, C.POINTER(OptHParams), VP]),
+    "mh_grad_norm": (INT, [VP, VP, INT, VP, VP, VP]),
     "mh_step_begin": (INT, [VP, VP, VP, VP, VP, INT, VP]),
     "mh_step_end": (INT, [VP, VP]),
     "mh_gemm_set_variant": (INT, [INT]),

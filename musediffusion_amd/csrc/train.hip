@@ -333,6 +333,56 @@ __global__ void scale_rows_kernel(const float* __restrict__ src, const float* __
   }
 }
 
+// ------------------------------------------------------------------ fused AdamW + EMA + grad-norm (multi-tensor)
+// One launch updates EVERY parameter tensor: block b handles chunk b = (tensor, offset) from a device table.
+// Replaces the reference's per-tensor foreach: AdamW.step + 3 x update_ema + grad-norm = ~600 launches and
+// ~200 .item() syncs per optimizer step (utils/train_util.py:246-280, :21-31).
+#pragma clang fp contract(off)
+__global__ void adamw_ema_kernel(const mh_opt_tensor* __restrict__ tensors, const mh_opt_chunk* __restrict__ chunks,
+                                 mh_opt_hparams hp) {
+  const mh_opt_chunk ck = chunks[blockIdx.x];
+  const mh_opt_tensor t = tensors[ck.tensor];
+  const int64_t end = ck.offset + ck.count;
+  for (int64_t i = ck.offset + threadIdx.x; i < end; i += blockDim.x) {
+    float p = t.param[i];
+    const float g = t.grad[i];
+    // torch.optim.AdamW (decoupled weight decay), single-tensor order of operations
+    // (every host-side scalar - 1-beta, 1-lr*wd, lr/bias1, 1-rate - is evaluated in double by the host like torch does)
+    p = p * hp.decay_mul;
+    const float m = t.exp_avg[i] * hp.beta1 + g * hp.one_minus_beta1;
+    const float v = t.exp_avg_sq[i] * hp.beta2 + (g * g) * hp.one_minus_beta2;
+    t.exp_avg[i] = m;
+    t.exp_avg_sq[i] = v;
+    const float denom = sqrtf(v) / hp.bias2_sqrt + hp.eps;
+    p = p - hp.step_size * (m / denom);
+    t.param[i] = p;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (e < hp.n_ema) t.ema[e][i] = t.ema[e][i] * hp.ema_rate[e] + p * hp.ema_one_minus[e];   // update_ema, train_util.py:21-31
+  }
+}
+__global__ void sumsq_chunks_kernel(const mh_opt_tensor* __restrict__ tensors, const mh_opt_chunk* __restrict__ chunks,
+                                    float* __restrict__ partial) {
+  __shared__ float red[4];
+  const mh_opt_chunk ck = chunks[blockIdx.x];
+  const float* g = tensors[ck.tensor].grad;
+  float s = 0.f;
+  for (int64_t i = ck.offset + threadIdx.x; i < ck.offset + ck.count; i += blockDim.x) s += g[i] * g[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ void sum_partials_kernel(const float* __restrict__ partial, int n, float* __restrict__ out) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) s += partial[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] = sqrtf((red[0] + red[1]) + (red[2] + red[3]));
+}
+
 }  // namespace
 
 #define MH_DTYPE_SWITCH(dtype, CALL_BF16, CALL_F32, what)                                 \
@@ -504,6 +554,25 @@ extern "C" int mh_scale_rows(const float* src, const float* scale, const int32_t
   MH_CHECK_ARG(src && dst && B > 0 && per_batch > 0 && E > 0, "scale_rows: bad arguments");
   MH_LAUNCH(scale_rows_kernel, dim3(tgrid((int64_t)B * per_batch)), dim3(TB), 0, (hipStream_t)stream, src, scale, mask, dst,
             accumulate, B, per_batch, E);
+  MH_CHECK_LAUNCH();
+  return MH_OK;
+}
+
+extern "C" int mh_adamw_ema_step(const mh_opt_tensor* tensors, const mh_opt_chunk* chunks, int n_chunks,
+                                 const mh_opt_hparams* hp, mh_stream_t stream) {
+  MH_CHECK_ARG(tensors && chunks && hp && n_chunks > 0, "adamw_ema_step: bad arguments");
+  MH_CHECK_ARG(hp->n_ema >= 0 && hp->n_ema <= 4, "adamw_ema_step: at most 4 EMA copies");
+  MH_LAUNCH(adamw_ema_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, tensors, chunks, *hp);
+  MH_CHECK_LAUNCH();
+  return MH_OK;
+}
+
+extern "C" int mh_grad_norm(const mh_opt_tensor* tensors, const mh_opt_chunk* chunks, int n_chunks, float* partial,
+                            float* out, mh_stream_t stream) {
+  MH_CHECK_ARG(tensors && chunks && partial && out && n_chunks > 0, "grad_norm: bad arguments");
+  MH_LAUNCH(sumsq_chunks_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, tensors, chunks, partial);
+  MH_CHECK_LAUNCH();
+  MH_LAUNCH(sum_partials_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partial, n_chunks, out);
   MH_CHECK_LAUNCH();
   return MH_OK;
 }

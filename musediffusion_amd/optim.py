@@ -1,0 +1,141 @@
+"""Fused AdamW + EMA optimizer step.
+
+The reference's `TrainLoop.optimize` (utils/train_util.py:246-280) runs torch.optim.AdamW over ~200 parameter
+tensors, then `update_ema` (:21-31) over each of 3 EMA copies, then a grad-norm loop with one `.item()` per
+tensor.  Here one kernel launch (`mh_adamw_ema_step`) updates every parameter, its Adam moments and all EMA
+copies, and one more (`mh_grad_norm`) produces the gradient norm on the device.
+
+`state_dict()` / `load_state_dict()` use torch.optim.AdamW's format, and `ema_state_dict(i, model)` returns an
+EMA copy under the model's state_dict keys, so checkpoints stay in the reference's on-disk format
+(`model_*.pt`, `ema_{rate}_*.pt`, `opt_*.pt`; utils/train_util.py:294-319).
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import OptHParams, check, current_stream, lib, ptr
+
+CHUNK = 1 << 16
+
+
+class FusedAdamWEMA:
+    def __init__(self, params, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, ema_rates=()):
+        self.params = [p for p in params]
+        if not self.params:
+            raise ValueError("optimizer got an empty parameter list")
+        if len(ema_rates) > 4:
+            raise ValueError("at most 4 EMA rates")
+        for p in self.params:
+            _lib.require_device(p)
+            if p.dtype != torch.float32 or not p.is_contiguous():
+                raise ValueError("parameters must be contiguous fp32 tensors")
+        self.lr, self.betas, self.eps, self.weight_decay = float(lr), tuple(betas), float(eps), float(weight_decay)
+        self.ema_rates = [float(r) for r in ema_rates]
+        self.step_count = 0
+        dev = self.params[0].device
+        self.exp_avg = [torch.zeros_like(p) for p in self.params]
+        self.exp_avg_sq = [torch.zeros_like(p) for p in self.params]
+        self.ema = [[p.detach().clone() for p in self.params] for _ in self.ema_rates]   # copy.deepcopy(master_params), :102
+        chunks = []
+        for i, p in enumerate(self.params):
+            n = p.numel()
+            for off in range(0, n, CHUNK):
+                chunks.append((i, min(CHUNK, n - off), off))
+        arr = np.zeros(len(chunks), dtype=[("tensor", "<i4"), ("count", "<i4"), ("offset", "<i8")])
+        for k, (i, c, o) in enumerate(chunks):
+            arr[k] = (i, c, o)
+        self.n_chunks = len(chunks)
+        self._chunks = torch.from_numpy(arr.view(np.uint8).copy()).to(dev)
+        self._partial = torch.empty(self.n_chunks, device=dev, dtype=torch.float32)
+        self._norm = torch.zeros(1, device=dev, dtype=torch.float32)
+        self._table = None
+        self._table_key = None
+
+    def _tensor_table(self):
+        grads = [p.grad for p in self.params]
+        if any(g is None for g in grads):
+            raise RuntimeError("every parameter needs a gradient (the reference runs DDP with find_unused_parameters=False)")
+        key = tuple(g.data_ptr() for g in grads)
+        if self._table is None or key != self._table_key:
+            rows = np.zeros((len(self.params), 8), dtype=np.int64)
+            for i, p in enumerate(self.params):
+                g = grads[i]
+                if g.dtype != torch.float32 or not g.is_contiguous():
+                    raise ValueError("gradients must be contiguous fp32")
+                rows[i, 0], rows[i, 1] = p.data_ptr(), g.data_ptr()
+                rows[i, 2], rows[i, 3] = self.exp_avg[i].data_ptr(), self.exp_avg_sq[i].data_ptr()
+                for e in range(len(self.ema_rates)):
+                    rows[i, 4 + e] = self.ema[e][i].data_ptr()
+            self._table = torch.from_numpy(rows).to(self.params[0].device)
+            self._table_key = key
+        return self._table
+
+    def grad_norm(self):
+        """sqrt(sum g^2) as a 1-element device tensor (train_util.py:274-280 without the per-tensor .item())."""
+        t = self._tensor_table()
+        check(lib().mh_grad_norm(ptr(t), ptr(self._chunks), self.n_chunks, ptr(self._partial), ptr(self._norm),
+                                 current_stream()), "mh_grad_norm")
+        return self._norm
+
+    @torch.no_grad()
+    def step(self, lr=None):
+        """One optimizer step: AdamW on every parameter + all EMA copies, one launch."""
+        if lr is not None:
+            self.lr = float(lr)
+        t = self._tensor_table()
+        self.step_count += 1
+        b1, b2 = self.betas
+        hp = OptHParams()
+        hp.beta1, hp.beta2, hp.eps = b1, b2, self.eps
+        hp.one_minus_beta1, hp.one_minus_beta2 = 1.0 - b1, 1.0 - b2
+        hp.decay_mul = 1.0 - self.lr * self.weight_decay
+        hp.step_size = self.lr / (1.0 - b1 ** self.step_count)
+        hp.bias2_sqrt = math.sqrt(1.0 - b2 ** self.step_count)
+        hp.n_ema = len(self.ema_rates)
+        for e, r in enumerate(self.ema_rates):
+            hp.ema_rate[e] = r
+            hp.ema_one_minus[e] = 1.0 - r
+        check(lib().mh_adamw_ema_step(ptr(t), ptr(self._chunks), self.n_chunks, C.byref(hp), current_stream()),
+              "mh_adamw_ema_step")
+        # the kernel wrote the parameters behind autograd's back: bump their version counters (no launch) so the
+        # packed weight arena (network.TransformerNetModel.engine) is rebuilt on the next inference call
+        torch._C._autograd._unsafe_set_version_counter(tuple(self.params), tuple(p._version + 1 for p in self.params))
+
+    def zero_grad(self, set_to_none=False):
+        for p in self.params:
+            if p.grad is not None:
+                if set_to_none:
+                    p.grad = None
+                else:
+                    p.grad.zero_()
+
+    # ------------------------------------------------------------------ checkpoint format of the reference
+    def state_dict(self):
+        """torch.optim.AdamW layout (what `opt_{step}.pt` holds, train_util.py:310-315)."""
+        state = {i: {"step": torch.tensor(float(self.step_count)), "exp_avg": self.exp_avg[i], "exp_avg_sq": self.exp_avg_sq[i]}
+                 for i in range(len(self.params))} if self.step_count else {}
+        group = {"lr": self.lr, "betas": self.betas, "eps": self.eps, "weight_decay": self.weight_decay, "amsgrad": False,
+                 "maximize": False, "params": list(range(len(self.params)))}
+        return {"state": state, "param_groups": [group]}
+
+    def load_state_dict(self, sd):
+        g = sd["param_groups"][0]
+        self.lr, self.betas, self.eps, self.weight_decay = float(g["lr"]), tuple(g["betas"]), float(g["eps"]), float(g["weight_decay"])
+        for i, st in sd["state"].items():
+            i = int(i)
+            self.exp_avg[i].copy_(st["exp_avg"])
+            self.exp_avg_sq[i].copy_(st["exp_avg_sq"])
+            self.step_count = int(float(st["step"]))
+
+    def ema_state_dict(self, index, model):
+        """EMA copy `index` under the model's state_dict keys (`_master_params_to_state_dict`, train_util.py:321-333)."""
+        sd = model.state_dict()
+        by_ptr = {p.data_ptr(): i for i, p in enumerate(self.params)}
+        for name, p in model.named_parameters():
+            sd[name] = self.ema[index][by_ptr[p.data_ptr()]]
+        if "lm_head.weight" in sd and "word_embedding.weight" in sd:
+            sd["lm_head.weight"] = sd["word_embedding.weight"]
+        return sd
