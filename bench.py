@@ -242,7 +242,9 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--split", type=int, default=1, help="batch slices run as concurrent graph branches")
     ap.add_argument("--gemm", type=int, default=None, help="bf16 GEMM kernel variant 0/1/2 (see mh_gemm_set_variant)")
+    ap.add_argument("--no-fuse-ln", action="store_true", help="A/B: separate GEMM and LayerNorm kernels")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -266,12 +268,15 @@ def main():
 
     if args.gemm is not None:
         _lib.lib().mh_gemm_set_variant(args.gemm)
+    if args.no_fuse_ln:
+        _lib.lib().mh_denoiser_set_fuse_ln(0)
     c = WORKLOADS[args.workload]
     model, diff = build(c, args.dtype, device, seed=0)
     if world > 1:
         broadcast_weights(model, src=0)   # ONE RCCL broadcast of the packed arena
     diff.rng_mode, diff.rng_seed, diff.rng_stream = args.rng, 105, rank
     diff.use_graph = not args.no_graph
+    diff.batch_split = args.split
 
     batch = synthetic.generation_batch(c["B"], c["L"], seed=1 + rank)
     ids, mask = batch["input_ids"].to(device), batch["input_mask"].to(device)

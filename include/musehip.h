@@ -307,11 +307,27 @@ int mh_step_end(mh_loop_state* state, mh_stream_t stream);
 /* Thin hipGraph wrappers so the host can capture a sequence of the calls above on `stream` and
  * replay it (hipStreamBeginCapture / EndCapture / GraphInstantiate / GraphLaunch). */
 /* A/B switch between the bf16 GEMM kernels: 0 = 128x128 tile, register-staged; 1 = 128x128 tile,
- * global_load_lds; 2 (default) = 256x128 tile, 3-stage global_load_lds ring. */
+ * global_load_lds; 2 (default) = big tile chosen per shape; 3 = always 256x128 (4 waves, 3-stage
+ * global_load_lds ring); 4 = always 256x256 (8 waves, 4-stage ring). */
 int mh_gemm_set_variant(int variant);
+/* out = LayerNorm(A W^T + bias + residual) * gamma + beta, bf16, the whole row normalised inside the
+ * GEMM epilogue (one block owns all N columns: N must be 128, 256 or 512 - see ..._supported).
+ * Replaces BertSelfOutput / BertOutput (dense -> LayerNorm(hidden + input)) of the encoder that
+ * models/network.py:150 calls.  Operands row-major or K32-panel as in mh_gemm_bias_act_ex. */
+int mh_gemm_bias_res_ln(const void* A, int64_t lda, int a_panel, const void* W, int64_t ldw, int w_panel,
+                        const float* bias, const void* residual, int64_t ldr, int r_panel, const float* gamma,
+                        const float* beta, float eps, void* out, int64_t ldo, int o_panel, int64_t M, int N,
+                        int K, mh_stream_t stream);
+int mh_gemm_bias_res_ln_supported(int N);
+/* A/B switch: mh_denoiser_forward's panel path uses mh_gemm_bias_res_ln for the two post-LN dense layers of an
+ * encoder block when the hidden size allows it (default 1) or the separate GEMM + LayerNorm kernels (0). */
+int mh_denoiser_set_fuse_ln(int on);
 /* Timing-only ablation of the big-tile kernel (results are WRONG when non-zero): bit 0 skips the
- * DMA loads, bit 1 the MFMAs, bit 2 the epilogue stores.  Used by tools/gemm_bench.py only. */
+ * DMA loads, bit 1 the MFMAs, bit 2 the epilogue stores, bit 3 the LDS fragment reads.  Used by tools/gemm_bench.py only. */
 int mh_gemm_set_debug(int bits);
+/* Start delay (100 MHz ticks) of the blocks in a CU's second slot of the persistent big-tile kernel:
+ * 0 = none (default), -1 = derived from K, > 0 = as given.  A/B knob for tools/gemm_bench.py. */
+int mh_gemm_set_stagger(int ticks);
 
 int mh_graph_begin_capture(mh_stream_t stream);
 int mh_graph_end_capture(mh_stream_t stream, void** graph_exec_out);

@@ -16,6 +16,12 @@ void mh_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
+namespace { int g_fuse_ln = 1; }
+extern "C" int mh_denoiser_set_fuse_ln(int on) {
+  g_fuse_ln = on != 0;
+  return MH_OK;
+}
+
 extern "C" const char* mh_last_error(void) { return g_err; }
 extern "C" int mh_abi_version(void) { return 1; }
 
@@ -149,6 +155,11 @@ extern "C" int mh_denoiser_forward(const mh_denoiser* m, const float* x, const f
                     int64_t ldo, int Nout, int K, int act) {
       return mh_gemm_bias_act_ex(A, N, P, W, w_rows, P, bias, res, N, P, o, ldo, of32 ? 0 : P, of32, N, Nout, K, act, dt, stream);
     };
+    auto gemm_ln = [&](const void* A, const void* W, const float* bias, const void* res, const float* gamma, const float* beta,
+                       void* o, int K) {
+      return mh_gemm_bias_res_ln(A, N, P, W, H, P, bias, res, N, P, gamma, beta, m->ln_eps, o, N, P, N, H, K, stream);
+    };
+    const bool fuse_ln = g_fuse_ln && mh_gemm_bias_res_ln_supported(H);
     if (m->has_proj) {
       if ((rc = mh_pack_panel(x, m->E, w.xin, N, N, m->E, m->E_pad, stream))) return rc;
       if ((rc = gemm(w.xin, m->w_up0, H, m->b_up0, nullptr, w.buf0, 0, N, H, m->E_pad, MH_ACT_TANH))) return rc;
@@ -165,11 +176,19 @@ extern "C" int mh_denoiser_forward(const mh_denoiser* m, const float* x, const f
       const mh_layer_weights& lw = m->layers[l];
       if ((rc = mh_gemm_qkv_ex(w.bufX, N, P, lw.w_qkv, 3 * H, P, lw.b_qkv, w.q, w.k, w.vt, B, L, H, m->nh, dt, stream))) return rc;
       if ((rc = mh_attention_fwd_ex(w.q, w.k, w.vt, w.buf0, N, P, B, L, m->nh, dh, scale, dt, stream))) return rc;
-      if ((rc = gemm(w.buf0, lw.w_ao, H, lw.b_ao, w.bufX, w.buf1, 0, N, H, H, MH_ACT_NONE))) return rc;
-      if ((rc = mh_layernorm_panel(w.buf1, N, lw.ln1_g, lw.ln1_b, w.bufX1, N, N, H, m->ln_eps, stream))) return rc;
+      if (fuse_ln) {   // dense + residual + LayerNorm in one kernel: the block owns complete rows
+        if ((rc = gemm_ln(w.buf0, lw.w_ao, lw.b_ao, w.bufX, lw.ln1_g, lw.ln1_b, w.bufX1, H))) return rc;
+      } else {
+        if ((rc = gemm(w.buf0, lw.w_ao, H, lw.b_ao, w.bufX, w.buf1, 0, N, H, H, MH_ACT_NONE))) return rc;
+        if ((rc = mh_layernorm_panel(w.buf1, N, lw.ln1_g, lw.ln1_b, w.bufX1, N, N, H, m->ln_eps, stream))) return rc;
+      }
       if ((rc = gemm(w.bufX1, lw.w_ff1, F, lw.b_ff1, nullptr, w.ffn, 0, N, F, H, MH_ACT_GELU_ERF))) return rc;
-      if ((rc = gemm(w.ffn, lw.w_ff2, H, lw.b_ff2, w.bufX1, w.buf1, 0, N, H, F, MH_ACT_NONE))) return rc;
-      if ((rc = mh_layernorm_panel(w.buf1, N, lw.ln2_g, lw.ln2_b, w.bufX, N, N, H, m->ln_eps, stream))) return rc;
+      if (fuse_ln) {
+        if ((rc = gemm_ln(w.ffn, lw.w_ff2, lw.b_ff2, w.bufX1, lw.ln2_g, lw.ln2_b, w.bufX, F))) return rc;
+      } else {
+        if ((rc = gemm(w.ffn, lw.w_ff2, H, lw.b_ff2, w.bufX1, w.buf1, 0, N, H, F, MH_ACT_NONE))) return rc;
+        if ((rc = mh_layernorm_panel(w.buf1, N, lw.ln2_g, lw.ln2_b, w.bufX, N, N, H, m->ln_eps, stream))) return rc;
+      }
     }
     if (m->has_proj) {
       if ((rc = gemm(w.bufX, m->w_dn0, H, m->b_dn0, nullptr, w.buf0, 0, N, H, H, MH_ACT_TANH))) return rc;

@@ -36,8 +36,12 @@ struct GemmArgs {
   const float* aux; const float* rown; float* pbest; int32_t* pidx; int nslots;
   int a_panel, w_panel, o_panel, r_panel;  // operand stored as K32 panels: [cols/32][ld rows][32]
   int64_t sA, sW, sO, sR;  // batch strides in elements (grid.y = batch index)
-  int stagger;
+  const float* ln_gamma; const float* ln_beta; float ln_eps;   // EPI 3
   int dbg;  // timing-only ablation bits (mh_gemm_set_debug): 1 no DMA, 2 no MFMA, 4 no stores
+  // persistent big-tile launch: ntiles output tiles walked by gridDim.x blocks; blocks that land in a CU's
+  // second slot ((blockIdx.x / 8) / cus_per_xcd odd) start `stagger` ticks (100 MHz) late so that one
+  // block's epilogue stores run under its neighbour's main loop instead of beside its epilogue
+  int ntiles, cus_per_xcd, stagger;
 };
 
 template <typename T> struct Tile;
@@ -328,196 +332,311 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
 
 
 // =====================================================================================================
-// bf16 "big tile" kernel (the throughput path).  The first kernel above is latency-bound at the
-// denoiser's shapes (K = 512: eight K-steps, one tile of prefetch): rocprof showed ~14 us per 128x128
-// tile against 1.7 us of MFMA time.  This one is built around keeping loads in flight:
-//   * 256(M) x 128(N) block tile, 4 waves as 2 x 2, each wave 128 x 64 (8 x 4 MFMA tiles of
-//     16x16x32 = 128 accumulator registers): per K-step 12 ds_read_b128 feed 32 MFMAs.
-//   * K-step 32, THREE-stage LDS ring filled by global_load_lds_dwordx4 (24 KiB per stage, 6 DMA
-//     instructions per wave), counted `s_waitcnt vmcnt(6)` + raw s_barrier so that the next stage
-//     stays in flight ACROSS the barrier (a __syncthreads() would drain it); 72 KiB per block ->
-//     two blocks per CU, whose prologues / epilogues overlap each other's main loops.
-//   * 64-B LDS rows, chunk c of row r stored at c ^ G[(r>>2)&3], G = {0,2,3,1}: every 16-lane group
-//     of a ds_read_b128 fragment read hits 16 distinct 16-B slots (conflict-free); the DMA writes LDS
+// bf16 "big tile" kernels (the throughput path).  The kernel above is latency-bound at the denoiser's
+// shapes (K = 512: eight K-steps, one tile of prefetch): rocprof showed ~14 us per 128x128 tile against
+// 1.7 us of MFMA time.  These are built around keeping loads in flight:
+//   * block tile BM x BN, WM x WN waves, each wave (BM/WM) x (BN/WN) = TI x TJ MFMA tiles of 16x16x32;
+//     K-step 32; NST-stage LDS ring filled by global_load_lds_dwordx4 (one 1-KiB DMA piece = 16 rows x 64 B),
+//     counted `s_waitcnt vmcnt(pieces x stages-in-flight)` + raw s_barrier so that younger stages stay in
+//     flight ACROSS the barrier (a __syncthreads() would drain them).
+//   * 64-B LDS rows, chunk c of row r stored at c ^ G[(r>>2)&3], G = {0,2,3,1}: every 16-lane group of a
+//     ds_read_b128 fragment read hits 16 distinct 16-B slots (SQ_LDS_BANK_CONFLICT = 0); the DMA writes LDS
 //     linearly, so the swizzle is applied to the per-lane global SOURCE address.
-//   * the MFMA is issued with the operands SWAPPED (D = W_tile . A_tile^T): a lane then owns 4
-//     consecutive output columns of one row, so bias / activation / residual / store work straight
-//     from the accumulators with 8-byte accesses - no LDS round trip, no barrier in the epilogue.
-//     (V^T of the QKV projection wants 4 consecutive TOKENS per lane instead: those waves issue the
-//     MFMA un-swapped.)
-constexpr int B2M = 256, B2N = 128, B2K = 32, B2STAGES = 3;
-constexpr int B2_STAGE_BYTES = (B2M + B2N) * 64;
+//   * the MFMA is issued with the operands SWAPPED (D = W_tile . A_tile^T) and the W rows of each 64-column
+//     group are dealt to the MFMA input rows as 32(jj>>1) + 8(p>>2) + 4(jj&1) + (p&3): a lane then owns 8
+//     CONSECUTIVE output columns of one row per (group, half), so bias / activation / residual / LayerNorm /
+//     stores work straight from the accumulators with 16-byte accesses - no LDS round trip.
+//     (V^T of the QKV projection wants consecutive TOKENS per lane instead: those waves issue the MFMA
+//     un-swapped with the plain row order.)
+//   * operands row-major or K32-panel (runtime strides only).
+// Configurations:  Std 256x128 / 4 waves / 3 stages (72 KiB: two blocks per CU);  Wide 256x256 / 8 waves /
+// 4 stages (128 KiB, 1.5x fewer DMA bytes per flop);  Row 128x512 / 8 waves / 3 stages (120 KiB): one block
+// owns complete rows of an N = 512 output, which lets bias + residual + LayerNorm run in the epilogue.
+template <int BM_, int BN_, int WM_, int WN_, int NST_, bool PP_ = false>
+struct BigCfg {
+  static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, NST = NST_;
+  static constexpr bool PP = PP_;   // ping-pong main loop (two wave groups half a K-step apart)
+  static constexpr int NW = WM * WN, THREADS = NW * 64;
+  static constexpr int TI = BM / WM / 16, TJ = BN / WN / 16;
+  static constexpr int STAGE = (BM + BN) * 64;
+  static constexpr int PA = BM / 16 / NW, PW = BN / 16 / NW, PIECES = PA + PW;
+  static_assert(PA >= 1 && PW >= 1 && TJ % 4 == 0 && NST >= 3, "unsupported big-tile configuration");
+};
+using CfgStd = BigCfg<256, 128, 2, 2, 3>;
+using CfgWide = BigCfg<256, 256, 2, 4, 4>;
+using CfgRow = BigCfg<128, 512, 2, 4, 3>;
+using CfgWidePP = BigCfg<256, 256, 2, 4, 4, true>;
+constexpr int B2K = 32;
 
-template <bool SWAP, int DBG, bool PP, bool INTERLEAVE = false>
-__device__ __forceinline__ void big_mainloop(f32x4 (&acc)[8][4], const char* smem, const char* const (&srcA)[4],
-                                             const char* const (&srcW)[2], const int (&ldsA)[4], const int (&ldsW)[2],
-                                             int nk, int a_off, const int (&b_offs)[4], int64_t kstepA, int64_t kstepW, int group) {
-  auto issue_one = [&](int kt, int idx) {   // idx 0..3: A pieces, 4..5: W pieces (one 1-KiB DMA each)
-    if constexpr ((DBG & 1) != 0) return;
-    char* base = const_cast<char*>(smem) + (kt % B2STAGES) * B2_STAGE_BYTES;
-    if (idx < 4)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcA[idx] + kt * kstepA),
-                                       (__attribute__((address_space(3))) void*)(base + ldsA[idx]), 16, 0, 0);
-    else
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcW[idx - 4] + kt * kstepW),
-                                       (__attribute__((address_space(3))) void*)(base + B2M * 64 + ldsW[idx - 4]), 16, 0, 0);
-  };
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// wait until all but the youngest `stages` DMA stages (PIECES loads each) of this wave have landed
+template <int PIECES> __device__ __forceinline__ void wait_stages(int stages) {
+  if (stages >= 3) wait_vmcnt<3 * PIECES>();
+  else if (stages == 2) wait_vmcnt<2 * PIECES>();
+  else if (stages == 1) wait_vmcnt<PIECES>();
+  else wait_vmcnt<0>();
+}
+
+// Main loop.  Fragments of K-step kt live in registers while its MFMAs run; the fragments of kt+1 are read
+// from LDS underneath them (W into a second register set up front, the A row-fragment i into its own
+// registers right after the last MFMA that uses it), so neither the LDS latency nor its bandwidth
+// (12 KiB per wave per K-step) sits between two MFMA phases.  All NST ring slots hold DMA stages: slot
+// kt % NST is refilled with stage kt + NST as soon as the barrier says every wave has read stage kt out of it.
+template <class C, bool SWAP, int DBG>
+__device__ __forceinline__ void big_mainloop(f32x4 (&acc)[C::TI][C::TJ], const char* smem, const char* const (&srcA)[C::PA],
+                                             const char* const (&srcW)[C::PW], const int (&ldsA)[C::PA], const int (&ldsW)[C::PW],
+                                             int nk, int a_off, const int (&b_offs)[C::TJ], int64_t kstepA, int64_t kstepW,
+                                             unsigned* prof = nullptr) {
+  constexpr int TI = C::TI, TJ = C::TJ;
+  // DBG bit 4 (tools/gemm_bench.py --dbg 28): per-wave shader-clock totals of the three phases of a K-step
+  unsigned long long pt_wait = 0, pt_bar = 0, pt_work = 0, pt0 = 0, pt1 = 0;
+  auto tick = [&]() -> unsigned long long { if constexpr ((DBG & 16) != 0) return __builtin_amdgcn_s_memtime(); else return 0ull; };
   auto issue = [&](int kt) {
+    if constexpr ((DBG & 1) != 0) return;
+    char* base = const_cast<char*>(smem) + (kt % C::NST) * C::STAGE;
 #pragma unroll
-    for (int idx = 0; idx < 6; ++idx) issue_one(kt, idx);
+    for (int j = 0; j < C::PA; ++j)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcA[j] + kt * kstepA),
+                                       (__attribute__((address_space(3))) void*)(base + ldsA[j]), 16, 0, 0);
+#pragma unroll
+    for (int j = 0; j < C::PW; ++j)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcW[j] + kt * kstepW),
+                                       (__attribute__((address_space(3))) void*)(base + C::BM * 64 + ldsW[j]), 16, 0, 0);
   };
-  // PP (ping-pong): two 4-wave groups share one workgroup, each with its own tile and LDS ring.  Every
-  // K-step has TWO workgroup barriers (after the DMA wait, after the fragment reads) and group 1 runs one
-  // barrier behind group 0, so on every SIMD one wave is in its MFMA segment while its partner is in its
-  // load segment (DMA issue + ds_reads): the matrix pipe never waits for LDS / DMA latency.
-  if constexpr (PP) { if (group == 1) __builtin_amdgcn_s_barrier(); }
-  issue(0);
-  if (nk > 1) issue(1);
-  for (int kt = 0; kt < nk; ++kt) {
-    // stage kt must have landed; stage kt+1 (6 DMA ops of this wave) may stay in flight
-    if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();   // everyone's share of stage kt is in LDS; stage kt-1 is fully consumed
-    const bool refill = kt + 2 < nk;   // stage kt+2 goes into the slot stage kt-1 occupied
-    if constexpr (!INTERLEAVE) { if (refill) issue(kt + 2); }
-    const char* As = smem + (kt % B2STAGES) * B2_STAGE_BYTES;
-    const char* Ws = As + B2M * 64;
-    // all 12 fragment reads are issued up front (W first: every MFMA row needs all four of them), then the
-    // scheduler is fenced so the MFMAs drain them behind counted lgkmcnt waits instead of four full stalls
-    bf16x8 a[8], b[4];
-    if constexpr ((DBG & 8) != 0) {   // ablation: no LDS fragment reads (operands are whatever the registers hold)
+  auto read_frag = [&](const char* p) -> bf16x8 {
+    if constexpr ((DBG & 8) != 0) { bf16x8 v; asm volatile("" : "=v"(v)); return v; }   // ablation: no LDS reads
+    else return *reinterpret_cast<const bf16x8*>(p);
+  };
+  unsigned long long pc0 = 0, pr0 = 0;
+  if constexpr ((DBG & 16) != 0) { pc0 = __builtin_amdgcn_s_memtime(); pr0 = __builtin_amdgcn_s_memrealtime(); }
+  const int npro = nk < C::NST ? nk : C::NST;
+  for (int st = 0; st < npro; ++st) issue(st);
+  wait_stages<C::PIECES>(npro - 1);
+  __builtin_amdgcn_s_barrier();
+  bf16x8 a[TI], b[TJ], bn[TJ];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) asm volatile("" : "=v"(b[j]));
+  for (int j = 0; j < TJ; ++j) b[j] = read_frag(smem + C::BM * 64 + b_offs[j]);
 #pragma unroll
-      for (int i = 0; i < 8; ++i) asm volatile("" : "=v"(a[i]));
+  for (int i = 0; i < TI; ++i) a[i] = read_frag(smem + a_off + i * (16 * 64));
+  auto mfma_row = [&](int i) {
+    if constexpr ((DBG & 2) != 0) {
+      asm volatile("" ::"v"(a[i]));
+#pragma unroll
+      for (int j = 0; j < TJ; ++j) asm volatile("" ::"v"(b[j]));
     } else {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const bf16x8*>(Ws + b_offs[j]);
-#pragma unroll
-      for (int i = 0; i < 8; ++i) a[i] = *reinterpret_cast<const bf16x8*>(As + a_off + i * (16 * 64));
-    }
-    if constexpr (PP) {
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    if constexpr ((DBG & 2) != 0) {
-#pragma unroll
-      for (int i = 0; i < 8; ++i) asm volatile("" ::"v"(a[i]));
-#pragma unroll
-      for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(b[j]));
-      continue;
-    }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int j = 0; j < TJ; ++j) {
         if constexpr (SWAP) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
         else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
       }
-      if constexpr (INTERLEAVE) {
-        // one DMA piece in the shadow of every 4 MFMAs: its ~100-cycle issue cost hides behind the matrix pipe
-        if (i >= 1 && i <= 6) {
-          __builtin_amdgcn_sched_barrier(0);
-          if (refill) issue_one(kt + 2, i - 1);
-          __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  for (int kt = 0; kt + 1 < nk; ++kt) {
+    const char* As = smem + ((kt + 1) % C::NST) * C::STAGE;
+    const char* Ws = As + C::BM * 64;
+    // stage kt+1 must have landed (stages kt+2 .. kt+NST-1 stay in flight across the barrier); this wave's
+    // reads of stage kt were issued a whole MFMA phase ago, so the lgkmcnt wait is free
+    const int younger = nk - 2 - kt < C::NST - 2 ? nk - 2 - kt : C::NST - 2;
+    pt0 = tick();
+    if (kt > 0) pt_work += pt0 - pt1;
+    wait_stages<C::PIECES>(younger);
+    __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0)
+    pt1 = tick();
+    pt_wait += pt1 - pt0;
+    __builtin_amdgcn_s_barrier();
+    pt0 = tick();
+    pt_bar += pt0 - pt1;
+    pt1 = pt0;
+    if (kt + C::NST < nk) issue(kt + C::NST);   // slot kt % NST: every wave has read stage kt out of it
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) bn[j] = read_frag(Ws + b_offs[j]);
+#pragma unroll
+    for (int i = 0; i < TI; ++i) {
+      mfma_row(i);
+      a[i] = read_frag(As + a_off + i * (16 * 64));
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) b[j] = bn[j];
+  }
+#pragma unroll
+  for (int i = 0; i < TI; ++i) mfma_row(i);
+  if constexpr ((DBG & 16) != 0) {
+    const unsigned long long pc1 = __builtin_amdgcn_s_memtime(), pr1 = __builtin_amdgcn_s_memrealtime();
+    if (prof && (threadIdx.x & 63) == 0) {
+      prof[0] = (unsigned)pt_wait; prof[1] = (unsigned)pt_bar; prof[2] = (unsigned)pt_work; prof[3] = (unsigned)nk;
+      prof[4] = (unsigned)(pc1 - pc0); prof[5] = (unsigned)(pr1 - pr0);
+    }
+  }
+}
+
+// Ping-pong main loop (one block of 8 waves per CU).  The two wave rows (group = wm) run half a K-step
+// apart: while one group issues its 32 MFMAs at raised priority, the other - its partner wave on every SIMD -
+// reads its 12 fragments of the next K-step from LDS and issues its share of the DMA (an LDS-DMA piece
+// costs the ISSUING wave ~100 cycles; put behind the partner's MFMAs it costs the matrix pipe nothing).
+// Slots are separated by block-wide raw barriers; group 1 enters one barrier late and group 0 leaves one late.
+//   group 0: slot 2kt = LOAD(kt), slot 2kt+1 = MFMA(kt);   group 1: slot 2kt+1 = LOAD(kt), slot 2kt+2 = MFMA(kt)
+//   LOAD(kt) reads stage kt and issues stage kt+NST-1 into the ring slot of stage kt-1, whose last readers
+//   (group 1, slot 2kt-1) drained lgkmcnt before the barrier that opens slot 2kt;
+//   every wave retires its pieces of stage kt+1 at the end of slot 2kt+1, before the barrier that opens the
+//   slot in which group 0 reads it - two younger stages stay in flight across that barrier.
+template <class C, bool SWAP, int DBG>
+__device__ __forceinline__ void pp_mainloop(f32x4 (&acc)[C::TI][C::TJ], const char* smem, const char* const (&srcA)[C::PA],
+                                            const char* const (&srcW)[C::PW], const int (&ldsA)[C::PA], const int (&ldsW)[C::PW],
+                                            int nk, int a_off, const int (&b_offs)[C::TJ], int64_t kstepA, int64_t kstepW,
+                                            int group) {
+  constexpr int TI = C::TI, TJ = C::TJ, D = C::NST - 1;
+  static_assert(C::WM == 2, "ping-pong needs exactly two wave rows");
+  auto issue = [&](int kt) {
+    if constexpr ((DBG & 1) != 0) return;
+    char* base = const_cast<char*>(smem) + (kt % C::NST) * C::STAGE;
+#pragma unroll
+    for (int j = 0; j < C::PA; ++j)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcA[j] + kt * kstepA),
+                                       (__attribute__((address_space(3))) void*)(base + ldsA[j]), 16, 0, 0);
+#pragma unroll
+    for (int j = 0; j < C::PW; ++j)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcW[j] + kt * kstepW),
+                                       (__attribute__((address_space(3))) void*)(base + C::BM * 64 + ldsW[j]), 16, 0, 0);
+  };
+  auto read_frag = [&](const char* p) -> bf16x8 {
+    if constexpr ((DBG & 8) != 0) { bf16x8 v; asm volatile("" : "=v"(v)); return v; }
+    else return *reinterpret_cast<const bf16x8*>(p);
+  };
+  const int npro = nk < D ? nk : D;
+  for (int st = 0; st < npro; ++st) issue(st);
+  wait_stages<C::PIECES>(npro - 1);
+  __builtin_amdgcn_s_barrier();
+  if (group == 1) __builtin_amdgcn_s_barrier();
+  bf16x8 a[TI], b[TJ];
+  for (int kt = 0; kt < nk; ++kt) {
+    const char* As = smem + (kt % C::NST) * C::STAGE;
+    const char* Ws = As + C::BM * 64;
+    const int younger = nk - 2 - kt < D - 1 ? nk - 2 - kt : D - 1;   // stages issued after kt+1 by the end of slot 2kt+1
+    // ---- LOAD(kt)
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) b[j] = read_frag(Ws + b_offs[j]);
+#pragma unroll
+    for (int i = 0; i < TI; ++i) a[i] = read_frag(As + a_off + i * (16 * 64));
+    if (kt + D < nk) issue(kt + D);
+    if (group == 1 && kt + 1 < nk) wait_stages<C::PIECES>(younger);
+    __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): fragments in registers, ring slot released
+    __builtin_amdgcn_s_barrier();
+    // ---- MFMA(kt)
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < TI; ++i) {
+      if constexpr ((DBG & 2) != 0) {
+        asm volatile("" ::"v"(a[i]));
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) asm volatile("" ::"v"(b[j]));
+      } else {
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) {
+          if constexpr (SWAP) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+          else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
         }
       }
     }
+    __builtin_amdgcn_s_setprio(0);
+    if (group == 0 && kt + 1 < nk) wait_stages<C::PIECES>(younger);
+    __builtin_amdgcn_s_barrier();
   }
-  if constexpr (PP) { if (group == 0) __builtin_amdgcn_s_barrier(); }
+  if (group == 0) __builtin_amdgcn_s_barrier();
 }
 
-template <int EPI, int ACT, int DBG = 0, bool PP = false>
-__global__ __launch_bounds__(PP ? 512 : 256, PP ? 1 : 2) void gemm_big_kernel(const GemmArgs g) {
-  __shared__ __attribute__((aligned(16))) char smem_all[(PP ? 2 : 1) * B2STAGES * B2_STAGE_BYTES];
+template <class C, bool SWAP, int DBG>
+__device__ __forceinline__ void run_mainloop(f32x4 (&acc)[C::TI][C::TJ], const char* smem, const char* const (&srcA)[C::PA],
+                                             const char* const (&srcW)[C::PW], const int (&ldsA)[C::PA], const int (&ldsW)[C::PW],
+                                             int nk, int a_off, const int (&b_offs)[C::TJ], int64_t kstepA, int64_t kstepW,
+                                             int group, unsigned* prof = nullptr) {
+  if constexpr (C::PP) pp_mainloop<C, SWAP, DBG>(acc, smem, srcA, srcW, ldsA, ldsW, nk, a_off, b_offs, kstepA, kstepW, group);
+  else big_mainloop<C, SWAP, DBG>(acc, smem, srcA, srcW, ldsA, ldsW, nk, a_off, b_offs, kstepA, kstepW, prof);
+}
+
+// EPI: 0 generic (bias / act / residual), 1 QKV head scatter, 3 bias + residual + LayerNorm over complete rows
+template <class C, int EPI, int ACT, int DBG = 0>
+__global__ __launch_bounds__(C::THREADS, C::STAGE * C::NST <= 80 * 1024 ? 2 : 1) void gemm_big_kernel(const GemmArgs g) {
+  __shared__ __attribute__((aligned(16))) char smem[C::NST * C::STAGE];
+  constexpr int TI = C::TI, TJ = C::TJ;
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int group = PP ? (wave_all >> 2) : 0, wave = wave_all & 3;
-  const char* smem = smem_all + group * (B2STAGES * B2_STAGE_BYTES);
-  const int wm = wave >> 1, wn = wave & 1;
-  const int tiles_n = (g.N + B2N - 1) / B2N;
-  const int tiles_total = tiles_n * (int)((g.M + B2M - 1) / B2M);
-  int bid;
-  bool tile_valid = true;
-  if constexpr (PP) {
-    bid = 2 * xcd_remap(blockIdx.x, gridDim.x) + group;   // the two groups take adjacent column tiles: same A panel
-    if (bid >= tiles_total) { bid = tiles_total - 1; tile_valid = false; }
-  } else {
-    bid = xcd_remap(blockIdx.x, gridDim.x);
-  }
-  const int64_t m0 = (int64_t)(bid / tiles_n) * B2M;
-  const int n0 = (bid % tiles_n) * B2N;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / C::WN, wn = wave % C::WN;
+  const int tiles_n = (g.N + C::BN - 1) / C::BN;
   const int nk = g.K / B2K;
   const int fr = lane & 15, fg = lane >> 4;
   constexpr int GSW[4] = {0, 2, 3, 1};
-  if (g.stagger > 0 && (int)blockIdx.x < 512 && ((g.stagger & 1) ? (((int)blockIdx.x >> 3) & 1) : ((int)blockIdx.x >= 256))) {
-    // experiment: phase-shift the second resident block of every CU so that its epilogue (VALU + stores)
-    // overlaps the first block's main loop (MFMA + DMA) instead of running in lockstep with it
-    const uint64_t t0 = __builtin_readcyclecounter();
-    while (__builtin_readcyclecounter() - t0 < (uint64_t)g.stagger) __builtin_amdgcn_s_sleep(8);
+  if (g.stagger > 0 && (((blockIdx.x >> 3) / g.cus_per_xcd) & 1)) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)g.stagger) __builtin_amdgcn_s_sleep(16);
   }
+  for (int vt = blockIdx.x; vt < g.ntiles; vt += gridDim.x) {
+  if (vt != (int)blockIdx.x) {   // the ring is reused: every wave must be done reading the previous tile's last stage
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_s_barrier();
+  }
+  const int bid = xcd_remap(vt, g.ntiles);
+  const int64_t m0 = (int64_t)(bid / tiles_n) * C::BM;
+  const int n0 = (bid % tiles_n) * C::BN;
 
-  // DMA coordinates: one instruction covers 16 rows x 64 B; lane i lands at row i/4, physical chunk i%4
-  const char* srcA[4];
-  const char* srcW[2];
-  int ldsA[4], ldsW[2];
-  // row-major operand: rows lda elements apart, a K-step advances 32 elements; K32-panel operand
+  // DMA coordinates: one piece covers 16 rows x 64 B; lane i lands at row i/4, physical chunk i%4.
+  // row-major operand: rows ld elements apart, a K-step advances 32 elements; K32-panel operand
   // ([K/32][ld rows][32]): rows 32 elements apart, a K-step advances one whole panel (ld * 32)
+  const char* srcA[C::PA];
+  const char* srcW[C::PW];
+  int ldsA[C::PA], ldsW[C::PW];
   const int64_t a_row = g.a_panel ? 32 : g.lda, w_row = g.w_panel ? 32 : g.ldw;
   const int64_t kstepA = g.a_panel ? g.lda * 64 : 64, kstepW = g.w_panel ? g.ldw * 64 : 64;
   {
     const int rl = lane >> 2, pc = lane & 3;
     const int lc = pc ^ GSW[(rl >> 2) & 3];          // logical chunk stored at this physical slot
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int r16 = (wave * 4 + j) * 16;
+    for (int j = 0; j < C::PA; ++j) {
+      const int r16 = (wave * C::PA + j) * 16;
       int64_t ra = m0 + r16 + rl; if (ra >= g.M) ra = g.M - 1;
       srcA[j] = reinterpret_cast<const char*>(g.A) + ((int64_t)blockIdx.y * g.sA + ra * a_row + lc * 8) * 2;
       ldsA[j] = r16 * 64;
     }
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int r16 = (wave * 2 + j) * 16;
+    for (int j = 0; j < C::PW; ++j) {
+      const int r16 = (wave * C::PW + j) * 16;
       int rw = n0 + r16 + rl; if (rw >= g.N) rw = g.N - 1;
       srcW[j] = reinterpret_cast<const char*>(g.W) + ((int64_t)blockIdx.y * g.sW + (int64_t)rw * w_row + lc * 8) * 2;
       ldsW[j] = r16 * 64;
     }
   }
   const int frag_off = fr * 64 + ((fg ^ GSW[(fr >> 2) & 3]) << 4);
-  const int a_off = wm * (128 * 64) + frag_off;
-  // W fragment rows.  Un-swapped MFMA (V^T waves): tile j takes rows 16j + fr.  Swapped MFMA: tile j, input
-  // row p = fr takes W row 32(j>>1) + 8(p>>2) + 4(j&1) + (p&3), so that a lane's accumulators (output rows
-  // 4fg + r of tiles 2h, 2h+1) are the 8 CONSECUTIVE output columns 32h + 8fg .. +7: 16-byte epilogue
-  // accesses, four lanes covering 64 contiguous bytes of a row.  Still conflict-free under the same swizzle.
-  int b_offs[4];
-  const bool v_wave = (EPI == 1) && ((n0 + wn * 64) / g.H == 2);
+  const int a_off = wm * (TI * 16 * 64) + frag_off;
+  const int wcol0 = n0 + wn * (TJ * 16);
+  const int64_t wrow0 = m0 + wm * (TI * 16);
+  const bool v_wave = (EPI == 1) && (wcol0 / g.H == 2);
+  int b_offs[TJ];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int row = v_wave ? 16 * j + fr : 32 * (j >> 1) + 8 * (fr >> 2) + 4 * (j & 1) + (fr & 3);
-    b_offs[j] = wn * (64 * 64) + row * 64 + ((fg ^ GSW[(row >> 2) & 3]) << 4);
+  for (int j = 0; j < TJ; ++j) {
+    const int jj = j & 3;
+    const int row = (j >> 2) * 64 + (v_wave ? 16 * jj + fr : 32 * (jj >> 1) + 8 * (fr >> 2) + 4 * (jj & 1) + (fr & 3));
+    b_offs[j] = wn * (TJ * 16 * 64) + row * 64 + ((fg ^ GSW[(row >> 2) & 3]) << 4);
   }
 
-  f32x4 acc[8][4];
+  f32x4 acc[TI][TJ];
 #pragma unroll
-  for (int i = 0; i < 8; ++i)
+  for (int i = 0; i < TI; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < TJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int wcol0 = n0 + wn * 64;
-  const int64_t wrow0 = m0 + wm * 128;
+  // lane's 8 consecutive output columns for (64-column group q, half h): wcol0 + 64q + 32h + 8fg, values
+  // acc[i][4q + 2h + (e>>2)][e&3], e = 0..7
   if constexpr (EPI == 1) {
     const int which = wcol0 / g.H;   // wave-uniform: 0 q, 1 k, 2 v
     const int M32 = (int)g.M, r0 = (int)wrow0;
     if (which == 2) {
-      big_mainloop<false, DBG, PP>(acc, smem, srcA, srcW, ldsA, ldsW, nk, a_off, b_offs, kstepA, kstepW, group);
-      if (!tile_valid) return;
+      run_mainloop<C, false, DBG>(acc, smem, srcA, srcW, ldsA, ldsW, nk, a_off, b_offs, kstepA, kstepW, wm);
       // acc[i][j][r] = D[m = 16i + 4fg + r][n = 16j + fr]: 4 consecutive tokens per lane -> V^T rows
       bf16* dst = reinterpret_cast<bf16*>(g.vt);
-      float bv[4];
-      int64_t coloff[4];
+      float bv[TJ];
+      int64_t coloff[TJ];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int j = 0; j < TJ; ++j) {
         const int col = wcol0 + 16 * j + fr;
         const int cc = col < g.N ? col : g.N - 1;
         bv[j] = g.bias[cc];
@@ -525,13 +644,13 @@ __global__ __launch_bounds__(PP ? 512 : 256, PP ? 1 : 2) void gemm_big_kernel(co
         coloff[j] = col < g.N ? ((int64_t)head * g.dh + d) * g.L : -1;
       }
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
+      for (int i = 0; i < TI; ++i) {
         const int row = r0 + 16 * i + 4 * fg;
         if (row < M32) {
           const int b = row / g.L, l = row - b * g.L;
           bf16* base = dst + (int64_t)b * g.H * g.L + l;
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
+          for (int j = 0; j < TJ; ++j) {
             if (coloff[j] >= 0) {
               bf16x4 v;
 #pragma unroll
@@ -542,93 +661,233 @@ __global__ __launch_bounds__(PP ? 512 : 256, PP ? 1 : 2) void gemm_big_kernel(co
         }
       }
     } else {
-      big_mainloop<true, DBG, PP>(acc, smem, srcA, srcW, ldsA, ldsW, nk, a_off, b_offs, kstepA, kstepW, group);
-      if (!tile_valid) return;
-      // acc[i][2h + q][r] = D[n = 32h + 8fg + 4q + r][m = 16i + fr]: 8 consecutive head dims per lane
+      run_mainloop<C, true, DBG>(acc, smem, srcA, srcW, ldsA, ldsW, nk, a_off, b_offs, kstepA, kstepW, wm);
       bf16* dst = reinterpret_cast<bf16*>(which == 0 ? g.q : g.k);
-      float bv[2][8];
-      int64_t coloff[2];
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int col = wcol0 + 32 * h + 8 * fg;
-        const int cc = col < g.N ? col : g.N - 8;
-        load8(g.bias + cc, bv[h]);
-        const int c = cc - which * g.H, head = c / g.dh, d = c % g.dh;
-        coloff[h] = col < g.N ? (int64_t)head * g.L * g.dh + d : -1;
-      }
+      for (int qh = 0; qh < TJ / 2; ++qh) {
+        const int col = wcol0 + 32 * qh + 8 * fg;
+        if (col < g.N) {
+          float bv[8];
+          load8(g.bias + col, bv);
+          const int c = col - which * g.H, head = c / g.dh, d = c % g.dh;
+          const int64_t coloff = (int64_t)head * g.L * g.dh + d;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int row = r0 + 16 * i + fr;
-        if (row < M32) {
-          const int b = row / g.L, l = row - b * g.L;
-          bf16* base = dst + ((int64_t)b * g.nh * g.L + l) * g.dh;
-#pragma unroll
-          for (int h = 0; h < 2; ++h) {
-            if (coloff[h] >= 0) {
+          for (int i = 0; i < TI; ++i) {
+            const int row = r0 + 16 * i + fr;
+            if (row < M32) {
+              const int b = row / g.L, l = row - b * g.L;
               float v[8];
 #pragma unroll
-              for (int e = 0; e < 8; ++e) v[e] = acc[i][2 * h + (e >> 2)][e & 3] + bv[h][e];
-              store8(base + coloff[h], v);
+              for (int e = 0; e < 8; ++e) v[e] = acc[i][2 * qh + (e >> 2)][e & 3] + bv[e];
+              store8(dst + ((int64_t)b * g.nh * g.L + l) * g.dh + coloff, v);
             }
           }
         }
       }
     }
   } else {
-    big_mainloop<true, DBG, PP>(acc, smem, srcA, srcW, ldsA, ldsW, nk, a_off, b_offs, kstepA, kstepW, group);
-    if (!tile_valid) return;
+    run_mainloop<C, true, DBG>(acc, smem, srcA, srcW, ldsA, ldsW, nk, a_off, b_offs, kstepA, kstepW, wm,
+                               reinterpret_cast<unsigned*>(g.out) + 64 + ((int64_t)bid * C::NW + wave) * 8);
     bf16* outT = reinterpret_cast<bf16*>(g.out) + (int64_t)blockIdx.y * g.sO;
     float* outF = reinterpret_cast<float*>(g.out) + (int64_t)blockIdx.y * g.sO;
     const bf16* res = g.residual ? reinterpret_cast<const bf16*>(g.residual) + (int64_t)blockIdx.y * g.sR : nullptr;
     if constexpr ((DBG & 4) != 0) {
       float sacc = 0.f;
 #pragma unroll
-      for (int i = 0; i < 8; ++i)
+      for (int i = 0; i < TI; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) sacc += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+        for (int j = 0; j < TJ; ++j) sacc += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
       if (sacc == 12345.678f) outF[0] = sacc;
-      return;
+      continue;
     }
+    if constexpr (EPI == 3) {
+      // ---- bias + residual, then LayerNorm over the complete row (the block owns all N columns): two-pass
+      // statistics, in-lane -> across the 4 lanes of a row (xor 16, 32) -> across the WN waves through LDS
+      float* red = reinterpret_cast<float*>(smem);     // [BM][WN] floats, reused for both passes
+      __builtin_amdgcn_s_barrier();                      // every wave is done with the ring before it is reused
+      float rs[TI];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int col = wcol0 + 32 * h + 8 * fg;
-      if (col < g.N) {   // N % 8 == 0 (checked by the launcher): a lane's 8 columns are all valid
-        float bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        if (g.bias) load8(g.bias + col, bv);
+      for (int i = 0; i < TI; ++i) rs[i] = 0.f;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+      for (int qh = 0; qh < TJ / 2; ++qh) {
+        const int col = wcol0 + 32 * qh + 8 * fg;
+        float bv[8];
+        load8(g.bias + col, bv);
+#pragma unroll
+        for (int i = 0; i < TI; ++i) {
+          int64_t row = wrow0 + 16 * i + fr; if (row >= g.M) row = g.M - 1;
+          const int64_t ro = g.r_panel ? ((int64_t)(col >> 5) * g.ldr + row) * 32 + (col & 31) : row * g.ldr + col;
+          float rv[8];
+          load8(res + ro, rv);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float v = (acc[i][2 * qh + (e >> 2)][e & 3] + bv[e]) + rv[e];
+            acc[i][2 * qh + (e >> 2)][e & 3] = v;
+            rs[i] += v;
+          }
+        }
+      }
+      const float invN = 1.0f / (float)g.N;
+      float mean[TI], rstd[TI];
+#pragma unroll
+      for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+        for (int i = 0; i < TI; ++i) {
+          float v = rs[i];
+          v += __shfl_xor(v, 16, 64);
+          v += __shfl_xor(v, 32, 64);
+          if (fg == 0) red[(wm * (TI * 16) + 16 * i + fr) * C::WN + wn] = v;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int i = 0; i < TI; ++i) {
+          float t = 0.f;
+#pragma unroll
+          for (int w = 0; w < C::WN; ++w) t += red[(wm * (TI * 16) + 16 * i + fr) * C::WN + w];
+          if (pass == 0) {
+            mean[i] = t * invN;
+            float sq = 0.f;
+#pragma unroll
+            for (int j = 0; j < TJ; ++j)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) { const float d = acc[i][j][r] - mean[i]; sq += d * d; }
+            rs[i] = sq;
+          } else {
+            rstd[i] = 1.0f / sqrtf(t * invN + g.ln_eps);
+          }
+        }
+        __builtin_amdgcn_s_barrier();                    // reads done before the second pass overwrites `red`
+      }
+#pragma unroll
+      for (int qh = 0; qh < TJ / 2; ++qh) {
+        const int col = wcol0 + 32 * qh + 8 * fg;
+        float gv[8], bt[8];
+        load8(g.ln_gamma + col, gv);
+        load8(g.ln_beta + col, bt);
+#pragma unroll
+        for (int i = 0; i < TI; ++i) {
           const int64_t row = wrow0 + 16 * i + fr;
           if (row < g.M) {
             float v[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = acc[i][2 * h + (e >> 2)][e & 3] + bv[e];
-            if constexpr (ACT != MH_ACT_NONE) {
+            for (int e = 0; e < 8; ++e) v[e] = (acc[i][2 * qh + (e >> 2)][e & 3] - mean[i]) * rstd[i] * gv[e] + bt[e];
+            const int64_t oo = g.o_panel ? ((int64_t)(col >> 5) * g.ldo + row) * 32 + (col & 31) : row * g.ldo + col;
+            store8(outT + oo, v);
+          }
+        }
+      }
+    } else {
 #pragma unroll
-              for (int e = 0; e < 8; ++e) v[e] = apply_act<bf16>(v[e], ACT);
-            }
-            if (res) {
-              const int64_t ro = g.r_panel ? ((int64_t)(col >> 5) * g.ldr + row) * 32 + (col & 31) : row * g.ldr + col;
-              float rv[8];
-              load8(res + ro, rv);
+      for (int qh = 0; qh < TJ / 2; ++qh) {
+        const int col = wcol0 + 32 * qh + 8 * fg;
+        if (col < g.N) {   // N % 8 == 0 (checked by the launcher): a lane's 8 columns are all valid
+          float bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+          if (g.bias) load8(g.bias + col, bv);
 #pragma unroll
-              for (int e = 0; e < 8; ++e) v[e] += rv[e];
-            }
-            if (g.out_f32) {
-              store8(outF + row * g.ldo + col, v);
-            } else {
-              const int64_t oo = g.o_panel ? ((int64_t)(col >> 5) * g.ldo + row) * 32 + (col & 31) : row * g.ldo + col;
-              store8(outT + oo, v);
+          for (int i = 0; i < TI; ++i) {
+            const int64_t row = wrow0 + 16 * i + fr;
+            if (row < g.M) {
+              float v[8];
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] = acc[i][2 * qh + (e >> 2)][e & 3] + bv[e];
+              if constexpr (ACT != MH_ACT_NONE) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = apply_act<bf16>(v[e], ACT);
+              }
+              if (res) {
+                const int64_t ro = g.r_panel ? ((int64_t)(col >> 5) * g.ldr + row) * 32 + (col & 31) : row * g.ldr + col;
+                float rv[8];
+                load8(res + ro, rv);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += rv[e];
+              }
+              if (g.out_f32) {
+                store8(outF + row * g.ldo + col, v);
+              } else {
+                const int64_t oo = g.o_panel ? ((int64_t)(col >> 5) * g.ldo + row) * 32 + (col & 31) : row * g.ldo + col;
+                store8(outT + oo, v);
+              }
             }
           }
         }
       }
     }
   }
+  }   // persistent tile loop
 }
 
 int g_dbg = 0;
-int g_stagger = 0;
-int g_variant = 2;  // bf16 kernel choice: 0 small-tile register-staged, 1 small-tile global_load_lds, 2 big tile  // bf16 staging mode, switchable for A/B runs (mh_gemm_set_glds)
+int g_variant = 2;  // bf16 kernel choice: 0 small-tile register-staged, 1 small-tile global_load_lds, 2 big tile (auto), 3 big Std, 4 big Wide
+
+int g_stagger = 0;   // second-slot start delay in 100 MHz ticks: 0 off, -1 derived from K, > 0 as given
+
+int device_cus() {
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cus = n;
+    else cus = 256;
+  }
+  return cus;
+}
+
+template <class C, int EPI>
+int launch_big(const GemmArgs& g0, hipStream_t s, int batch) {
+  GemmArgs g = g0;
+  const int64_t t2 = (int64_t)ceil_div(g.M, C::BM) * ceil_div(g.N, C::BN);
+  MH_CHECK_ARG(t2 > 0 && t2 < (1ll << 31), "gemm: bad grid (M=%lld N=%d)", (long long)g.M, g.N);
+  // persistent: one block per CU slot walks the tiles (no re-launch, the ring stays allocated)
+  const int cus = device_cus();
+  const int per_cu = C::STAGE * C::NST <= 80 * 1024 ? 2 : 1;
+  const int64_t slots = (int64_t)cus * per_cu;
+  g.ntiles = (int)t2;
+  g.cus_per_xcd = cus / 8 > 0 ? cus / 8 : 1;
+  g.stagger = 0;
+  if (per_cu == 2 && t2 >= slots && batch == 1 && g_stagger != 0)
+    g.stagger = g_stagger > 0 ? g_stagger : ((g.K / B2K) * 80 + 500) / 2;
+  const dim3 grid((unsigned)(t2 < slots ? t2 : slots), (unsigned)batch), block(C::THREADS);
+  if constexpr (EPI == 1) {
+    MH_LAUNCH((gemm_big_kernel<C, 1, MH_ACT_NONE>), grid, block, 0, s, g);
+  } else if constexpr (EPI == 3) {
+    MH_LAUNCH((gemm_big_kernel<C, 3, MH_ACT_NONE>), grid, block, 0, s, g);
+  } else {
+    if (g.dbg) {   // timing-only ablations (tools/gemm_bench.py): 1 no DMA, 2 no MFMA, 4 no epilogue, 8 no LDS reads
+      switch (g.dbg & 31) {
+        case 1: MH_LAUNCH((gemm_big_kernel<C, 0, MH_ACT_NONE, 1>), grid, block, 0, s, g); break;
+        case 2: MH_LAUNCH((gemm_big_kernel<C, 0, MH_ACT_NONE, 2>), grid, block, 0, s, g); break;
+        case 4: MH_LAUNCH((gemm_big_kernel<C, 0, MH_ACT_NONE, 4>), grid, block, 0, s, g); break;
+        case 5: MH_LAUNCH((gemm_big_kernel<C, 0, MH_ACT_NONE, 5>), grid, block, 0, s, g); break;
+        case 6: MH_LAUNCH((gemm_big_kernel<C, 0, MH_ACT_NONE, 6>), grid, block, 0, s, g); break;
+        case 12: MH_LAUNCH((gemm_big_kernel<C, 0, MH_ACT_NONE, 12>), grid, block, 0, s, g); break;
+        case 13: MH_LAUNCH((gemm_big_kernel<C, 0, MH_ACT_NONE, 13>), grid, block, 0, s, g); break;
+        case 20: MH_LAUNCH((gemm_big_kernel<C, 0, MH_ACT_NONE, 20>), grid, block, 0, s, g); break;
+        case 28: MH_LAUNCH((gemm_big_kernel<C, 0, MH_ACT_NONE, 28>), grid, block, 0, s, g); break;
+        default: MH_LAUNCH((gemm_big_kernel<C, 0, MH_ACT_NONE, 14>), grid, block, 0, s, g); break;
+      }
+    } else switch (g.act) {
+      case MH_ACT_TANH: MH_LAUNCH((gemm_big_kernel<C, 0, MH_ACT_TANH>), grid, block, 0, s, g); break;
+      case MH_ACT_GELU_ERF: MH_LAUNCH((gemm_big_kernel<C, 0, MH_ACT_GELU_ERF>), grid, block, 0, s, g); break;
+      case MH_ACT_SILU: MH_LAUNCH((gemm_big_kernel<C, 0, MH_ACT_SILU>), grid, block, 0, s, g); break;
+      default: MH_LAUNCH((gemm_big_kernel<C, 0, MH_ACT_NONE>), grid, block, 0, s, g); break;
+    }
+  }
+  MH_CHECK_LAUNCH();
+  return MH_OK;
+}
+
+bool big_tile_ok(const GemmArgs& g) {
+  return g.N % 8 == 0 && g.K % B2K == 0 && (g.o_panel || g.ldo % 8 == 0 || (g.out_f32 && g.ldo % 4 == 0)) &&
+         (g.r_panel || g.ldr % 8 == 0);
+}
+
+// the wide tile moves 1.5x fewer operand bytes per flop but holds one block per CU: worth it once the grid
+// still covers the chip (>= 256 blocks) and N fills its 256 columns
+bool want_wide(const GemmArgs& g, int batch) {
+  if (g_variant == 3) return false;
+  if (g_variant >= 4) return true;
+  return g.N % 256 == 0 && (int64_t)ceil_div(g.M, CfgWide::BM) * (g.N / 256) * batch >= 256;
+}
 
 template <int EPI>
 int launch(const GemmArgs& g, int dtype, hipStream_t s, int batch = 1) {
@@ -639,54 +898,17 @@ int launch(const GemmArgs& g, int dtype, hipStream_t s, int batch = 1) {
   if (dtype == MH_BF16) {
     MH_CHECK_ARG((g.a_panel || g.lda % 8 == 0) && (g.w_panel || g.ldw % 8 == 0), "gemm(bf16): lda/ldw must be multiples of 8");
     const bool any_panel = g.a_panel || g.w_panel || g.o_panel || g.r_panel;
-    const bool big_ok = g.N % 8 == 0 && g.K % B2K == 0 && (g.o_panel || g.ldo % 8 == 0 || (g.out_f32 && g.ldo % 4 == 0)) &&
-                        (g.r_panel || g.ldr % 8 == 0);
+    const bool big_ok = big_tile_ok(g);
     MH_CHECK_ARG(!any_panel || (big_ok && g_variant >= 2), "gemm: panel layouts need the big-tile bf16 kernel");
     MH_CHECK_ARG(g.K > 0 && (g.K % 64 == 0 || (g.K % B2K == 0 && big_ok && g_variant >= 2)),
                  "gemm(bf16): K=%d must be a positive multiple of 64 (32 with the big-tile kernel)", g.K);
-    if (g_variant == 3 && big_ok && !g.dbg) {
-      const int64_t t2 = (int64_t)ceil_div(g.M, B2M) * ceil_div(g.N, B2N);
-      const dim3 grid3((unsigned)((t2 + 1) / 2), (unsigned)batch), block3(512);
-      if constexpr (EPI == 1) {
-        MH_LAUNCH((gemm_big_kernel<1, MH_ACT_NONE, 0, true>), grid3, block3, 0, s, g);
-      } else {
-        switch (g.act) {
-          case MH_ACT_TANH: MH_LAUNCH((gemm_big_kernel<0, MH_ACT_TANH, 0, true>), grid3, block3, 0, s, g); break;
-          case MH_ACT_GELU_ERF: MH_LAUNCH((gemm_big_kernel<0, MH_ACT_GELU_ERF, 0, true>), grid3, block3, 0, s, g); break;
-          case MH_ACT_SILU: MH_LAUNCH((gemm_big_kernel<0, MH_ACT_SILU, 0, true>), grid3, block3, 0, s, g); break;
-          default: MH_LAUNCH((gemm_big_kernel<0, MH_ACT_NONE, 0, true>), grid3, block3, 0, s, g); break;
-        }
-      }
-    } else if (g_variant == 3 && big_ok) {
-      const int64_t t2 = (int64_t)ceil_div(g.M, B2M) * ceil_div(g.N, B2N);
-      const dim3 grid3((unsigned)((t2 + 1) / 2), (unsigned)batch), block3(512);
-      if ((g.dbg & 15) == 4) MH_LAUNCH((gemm_big_kernel<0, MH_ACT_NONE, 4, true>), grid3, block3, 0, s, g);
-      else MH_LAUNCH((gemm_big_kernel<0, MH_ACT_NONE, 5, true>), grid3, block3, 0, s, g);
-    } else if (g_variant >= 2 && big_ok) {
-      const int64_t t2 = (int64_t)ceil_div(g.M, B2M) * ceil_div(g.N, B2N);
-      const dim3 grid2((unsigned)t2, (unsigned)batch);
-      if constexpr (EPI == 1) {
-        MH_LAUNCH((gemm_big_kernel<1, MH_ACT_NONE>), grid2, block, 0, s, g);
-      } else {
-        if (g.dbg) {   // timing-only ablations (tools/gemm_bench.py)
-          switch (g.dbg & 15) {
-            case 1: MH_LAUNCH((gemm_big_kernel<0, MH_ACT_NONE, 1>), grid2, block, 0, s, g); break;
-            case 2: MH_LAUNCH((gemm_big_kernel<0, MH_ACT_NONE, 2>), grid2, block, 0, s, g); break;
-            case 3: MH_LAUNCH((gemm_big_kernel<0, MH_ACT_NONE, 3>), grid2, block, 0, s, g); break;
-            case 4: MH_LAUNCH((gemm_big_kernel<0, MH_ACT_NONE, 4>), grid2, block, 0, s, g); break;
-            case 5: MH_LAUNCH((gemm_big_kernel<0, MH_ACT_NONE, 5>), grid2, block, 0, s, g); break;
-            case 6: MH_LAUNCH((gemm_big_kernel<0, MH_ACT_NONE, 6>), grid2, block, 0, s, g); break;
-            case 7: MH_LAUNCH((gemm_big_kernel<0, MH_ACT_NONE, 7>), grid2, block, 0, s, g); break;
-            case 12: MH_LAUNCH((gemm_big_kernel<0, MH_ACT_NONE, 12>), grid2, block, 0, s, g); break;
-            case 13: MH_LAUNCH((gemm_big_kernel<0, MH_ACT_NONE, 13>), grid2, block, 0, s, g); break;
-            default: MH_LAUNCH((gemm_big_kernel<0, MH_ACT_NONE, 14>), grid2, block, 0, s, g); break;
-          }
-        } else switch (g.act) {
-          case MH_ACT_TANH: MH_LAUNCH((gemm_big_kernel<0, MH_ACT_TANH>), grid2, block, 0, s, g); break;
-          case MH_ACT_GELU_ERF: MH_LAUNCH((gemm_big_kernel<0, MH_ACT_GELU_ERF>), grid2, block, 0, s, g); break;
-          case MH_ACT_SILU: MH_LAUNCH((gemm_big_kernel<0, MH_ACT_SILU>), grid2, block, 0, s, g); break;
-          default: MH_LAUNCH((gemm_big_kernel<0, MH_ACT_NONE>), grid2, block, 0, s, g); break;
-        }
+    if (EPI != 2 && g_variant >= 2 && big_ok) {
+      if constexpr (EPI == 2) return MH_OK;
+      // QKV scatter: a wave's columns must not straddle the q/k/v boundary (H % 64 == 0 for the wide tile)
+      else {
+        if (want_wide(g, batch) && (EPI != 1 || g.H % 64 == 0))
+          return g_variant == 4 ? launch_big<CfgWide, EPI>(g, s, batch) : launch_big<CfgWidePP, EPI>(g, s, batch);
+        return launch_big<CfgStd, EPI>(g, s, batch);
       }
     } else if (g_variant == 1) {
       MH_LAUNCH((gemm_kernel<bf16, EPI, 1>), grid, block, 0, s, g);
@@ -707,14 +929,20 @@ int launch(const GemmArgs& g, int dtype, hipStream_t s, int batch = 1) {
 
 }  // namespace
 
+extern "C" int mh_gemm_bias_res_ln_supported(int N) { return N == 128 || N == 256 || N == 512; }
+
+extern "C" int mh_gemm_set_stagger(int ticks) {
+  g_stagger = ticks;
+  return MH_OK;
+}
+
 extern "C" int mh_gemm_set_debug(int bits) {
-  g_dbg = bits & 15;
-  g_stagger = bits >> 4;   // shader cycles
+  g_dbg = bits & 31;
   return MH_OK;
 }
 
 extern "C" int mh_gemm_set_variant(int variant) {
-  MH_CHECK_ARG(variant >= 0 && variant <= 3, "gemm_set_variant: variant must be 0..3");
+  MH_CHECK_ARG(variant >= 0 && variant <= 5, "gemm_set_variant: variant must be 0..5");
   g_variant = variant;
   return MH_OK;
 }
@@ -728,7 +956,7 @@ extern "C" int mh_gemm_bias_act(const void* A, int64_t lda, const void* W, int64
   GemmArgs g{};
   g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.bias = bias;
   g.residual = residual; g.ldr = residual ? ldr : 8; g.out = out; g.ldo = ldo; g.out_f32 = out_f32;
-  g.M = M; g.N = N; g.K = K; g.act = act; g.dbg = g_dbg & 15; g.stagger = g_stagger;
+  g.M = M; g.N = N; g.K = K; g.act = act; g.dbg = g_dbg & 31;
   return launch<0>(g, dtype, (hipStream_t)stream);
 }
 
@@ -744,9 +972,32 @@ extern "C" int mh_gemm_bias_act_ex(const void* A, int64_t lda, int a_panel, cons
   GemmArgs g{};
   g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.bias = bias;
   g.residual = residual; g.ldr = residual ? ldr : 8; g.out = out; g.ldo = ldo; g.out_f32 = out_f32;
-  g.M = M; g.N = N; g.K = K; g.act = act; g.dbg = g_dbg & 15; g.stagger = g_stagger;
+  g.M = M; g.N = N; g.K = K; g.act = act; g.dbg = g_dbg & 31;
   g.a_panel = a_panel; g.w_panel = w_panel; g.o_panel = o_panel; g.r_panel = residual ? r_panel : 0;
   return launch<0>(g, dtype, (hipStream_t)stream);
+}
+
+// out = LayerNorm(A W^T + bias + residual) * gamma + beta over complete rows: the block owns all N columns
+// (N = 128, 256 or 512), so the normalisation runs on the accumulators (models/network.py:150 ->
+// BertSelfOutput / BertOutput: dense -> dropout(eval: identity) -> LayerNorm(hidden + input))
+extern "C" int mh_gemm_bias_res_ln(const void* A, int64_t lda, int a_panel, const void* W, int64_t ldw, int w_panel,
+                                   const float* bias, const void* residual, int64_t ldr, int r_panel, const float* gamma,
+                                   const float* beta, float eps, void* out, int64_t ldo, int o_panel, int64_t M, int N,
+                                   int K, mh_stream_t stream) {
+  MH_CHECK_ARG(A && W && out && bias && residual && gamma && beta, "gemm_bias_res_ln: null pointer");
+  MH_CHECK_ARG(M > 0 && K > 0 && K % B2K == 0, "gemm_bias_res_ln: bad problem M=%lld K=%d", (long long)M, K);
+  MH_CHECK_ARG(mh_gemm_bias_res_ln_supported(N), "gemm_bias_res_ln: N=%d must be 128, 256 or 512", N);
+  GemmArgs g{};
+  g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.bias = bias;
+  g.residual = residual; g.ldr = ldr; g.out = out; g.ldo = ldo;
+  g.M = M; g.N = N; g.K = K; g.act = MH_ACT_NONE;
+  g.a_panel = a_panel; g.w_panel = w_panel; g.o_panel = o_panel; g.r_panel = r_panel;
+  g.ln_gamma = gamma; g.ln_beta = beta; g.ln_eps = eps;
+  MH_CHECK_ARG((a_panel || lda % 8 == 0) && (w_panel || ldw % 8 == 0) && big_tile_ok(g), "gemm_bias_res_ln: leading dimensions must be multiples of 8");
+  hipStream_t s = (hipStream_t)stream;
+  if (N == 128) return launch_big<CfgStd, 3>(g, s, 1);
+  if (N == 256) return launch_big<CfgWide, 3>(g, s, 1);
+  return launch_big<CfgRow, 3>(g, s, 1);
 }
 
 extern "C" int mh_gemm_batched(const void* A, int64_t lda, int64_t strideA, const void* W, int64_t ldw, int64_t strideW,
@@ -778,7 +1029,7 @@ extern "C" int mh_gemm_qkv_ex(const void* A, int64_t lda, int a_panel, const voi
   MH_CHECK_ARG(L % 8 == 0, "gemm_qkv: seq_len %d must be a multiple of 8", L);
   GemmArgs g{};
   g.A = A; g.lda = lda; g.W = Wqkv; g.ldw = ldw; g.bias = bqkv; g.ldr = 8; g.ldo = 8;
-  g.M = (int64_t)B * L; g.N = 3 * H; g.K = H; g.stagger = g_stagger;
+  g.M = (int64_t)B * L; g.N = 3 * H; g.K = H;
   g.a_panel = a_panel; g.w_panel = w_panel;
   g.q = q; g.k = k; g.vt = vt; g.L = L; g.H = H; g.nh = nh; g.dh = H / nh;
   return launch<1>(g, dtype, (hipStream_t)stream);

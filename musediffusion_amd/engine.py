@@ -149,6 +149,10 @@ class DenoiserEngine:
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
         return self._ws
 
+    def new_workspace(self, B, L):
+        """A private scratch buffer (concurrent forwards on different streams must not share one)."""
+        return torch.empty(int(lib().mh_denoiser_workspace_bytes(C.byref(self._desc), B, L)), dtype=torch.uint8, device=self.device)
+
     def reserve(self, B, L):
         """Allocate scratch up front (call before hipGraph capture: nothing may allocate inside)."""
         self._workspace(B, L)
@@ -164,7 +168,7 @@ class DenoiserEngine:
               "mh_time_embed")
         return out
 
-    def forward(self, x, emb_t, emb_row=None, out=None):
+    def forward(self, x, emb_t, emb_row=None, out=None, ws=None):
         """x [B,L,E] fp32 -> [B,L,E] fp32 (models/network.py:131-158).  emb_t [*,H] fp32,
         emb_row [B] int32 selecting the emb_t row of each batch element (None: row b)."""
         _lib.require_device(x, emb_t, emb_row)
@@ -173,7 +177,7 @@ class DenoiserEngine:
             raise ValueError("latent width %d != model input_dims %d" % (E, self.cfg["E"]))
         x = x.to(torch.float32).contiguous()
         out = torch.empty_like(x) if out is None else out
-        ws = self._workspace(B, L)
+        ws = self._workspace(B, L) if ws is None else ws
         check(lib().mh_denoiser_forward(C.byref(self._desc), ptr(x), ptr(emb_t), ptr(emb_row), ptr(out), B, L, ptr(ws),
                                         ws.numel(), current_stream()), "mh_denoiser_forward")
         return out

@@ -163,6 +163,7 @@ class GaussianDiffusion:
     rng_stream = 0
     noise_fn = None        # optional callable (k, i, x) -> noise tensor (parity tests)
     use_graph = True       # capture the reverse step into a hipGraph when the fused path applies
+    batch_split = 1        # >1: run the denoiser on that many batch slices as concurrent graph branches
 
     def __init__(self, *, betas, predict_xstart, rescale_timesteps=False):
         self.rescale_timesteps = rescale_timesteps
@@ -601,6 +602,13 @@ class _ReverseLoop:
         self.cur_coef = torch.zeros(8, dtype=torch.float32, device=dev)
         self.emb_row = torch.zeros(B, dtype=torch.int32, device=dev)
         self.graphs = {}
+        self.nsplit = max(1, min(int(getattr(diff, "batch_split", 1)), B))
+        if self.nsplit > 1:
+            hb = B // self.nsplit
+            self.split_ws = [eng.new_workspace(B - hb * (self.nsplit - 1) if j == self.nsplit - 1 else hb, L) for j in range(self.nsplit)]
+            self.side_streams = [torch.cuda.Stream() for _ in range(self.nsplit - 1)]
+            self.ev_fork = torch.cuda.Event()
+            self.ev_join = [torch.cuda.Event() for _ in range(self.nsplit - 1)]
 
     # one reverse step as a fixed launch sequence (capturable: no allocation, no sync)
     def _body(self, use_round, in_graph_rng):
@@ -609,7 +617,27 @@ class _ReverseLoop:
         P = _lib.ptr
         _lib.check(L_.mh_step_begin(P(self.state), P(self.steps), P(self.coef_table), P(self.cur_coef), P(self.emb_row),
                                     self.B, st), "mh_step_begin")
-        self.eng.forward(self.x, self.emb_table, self.emb_row, out=self.model_out)
+        nsplit = self.nsplit
+        if nsplit <= 1:
+            self.eng.forward(self.x, self.emb_table, self.emb_row, out=self.model_out)
+        else:
+            # independent sequences -> independent chains: run the halves of the batch as concurrent branches so
+            # that blocks of DIFFERENT kernels (one branch's epilogue, the other's MFMA main loop) share each CU
+            main = torch.cuda.current_stream()
+            self.ev_fork.record(main)
+            hb = self.B // nsplit
+            for j in range(nsplit):
+                sl = slice(j * hb, (j + 1) * hb if j + 1 < nsplit else self.B)
+                if j == 0:
+                    self.eng.forward(self.x[sl], self.emb_table, self.emb_row[sl], out=self.model_out[sl], ws=self.split_ws[0])
+                else:
+                    side = self.side_streams[j - 1]
+                    side.wait_event(self.ev_fork)
+                    with torch.cuda.stream(side):
+                        self.eng.forward(self.x[sl], self.emb_table, self.emb_row[sl], out=self.model_out[sl], ws=self.split_ws[j])
+                        self.ev_join[j - 1].record(side)
+            for j in range(1, nsplit):
+                main.wait_event(self.ev_join[j - 1])
         if use_round:
             _lib.check(L_.mh_round_to_embedding_mfma(P(self.model_out), P(self.table_pad), P(self.table_norm),
                                                      P(self.round_idx), self.B * self.L, self.E, self.table32.shape[0],

@@ -316,6 +316,62 @@ def test_gemm_panel_layouts(case):
     assert_close(outf, q(A, MH_BF16) @ q(W, MH_BF16).T + b, 2e-3, 1e-4, what="gemm panel->f32")
 
 
+@pytest.mark.parametrize("variant", [3, 4, 5])
+def test_gemm_big_tile_variants(variant):
+    """both big-tile configurations (256x128 / 256x256) against the fp32 matmul of the bf16-rounded operands"""
+    lib().mh_gemm_set_variant(variant)
+    try:
+        for (M, N, K, act, use_res) in [(700, 512, 256, "gelu", False), (513, 264, 96, None, True), (40, 1536, 512, None, False)]:
+            A, W = rnd(M, K, seed=171, scale=0.5), rnd(N, K, seed=172, scale=1.0 / math.sqrt(K))
+            b, R = rnd(N, seed=173, scale=0.1), rnd(M, N, seed=174)
+            ref = q(A, MH_BF16) @ q(W, MH_BF16).T + b
+            ref = {None: lambda v: v, "gelu": torch.nn.functional.gelu}[act](ref)
+            if use_res:
+                ref = ref + q(R, MH_BF16)
+            out = ops.gemm_bias_act(A.to(DEV).bfloat16(), W.to(DEV).bfloat16(), b.to(DEV), R.to(DEV).bfloat16() if use_res else None,
+                                    act, MH_BF16)
+            assert_close(out.float(), ref, 2e-3, 2 ** -8, what="big tile variant %d %s" % (variant, (M, N, K)))
+        # QKV scatter through the same tile
+        B, L, H, nh = 3, 40, 256, 4
+        X, Wq, bq = rnd(B * L, H, seed=175), rnd(3 * H, H, seed=176, scale=1.0 / 16), rnd(3 * H, seed=177, scale=0.1)
+        qh, kh, vt = ops.gemm_qkv(X.to(DEV).bfloat16(), Wq.to(DEV).bfloat16(), bq.to(DEV), B, L, nh, MH_BF16)
+        ref = (q(X, MH_BF16) @ q(Wq, MH_BF16).T + bq).view(B, L, 3, nh, H // nh)
+        assert_close(qh.float(), ref[:, :, 0].permute(0, 2, 1, 3), 2e-3, 2 ** -8, what="qkv q variant %d" % variant)
+        assert_close(kh.float(), ref[:, :, 1].permute(0, 2, 1, 3), 2e-3, 2 ** -8, what="qkv k variant %d" % variant)
+        assert_close(vt.float(), ref[:, :, 2].permute(0, 2, 3, 1), 2e-3, 2 ** -8, what="qkv vt variant %d" % variant)
+    finally:
+        lib().mh_gemm_set_variant(2)
+
+
+@pytest.mark.parametrize("N", [128, 256, 512])
+@pytest.mark.parametrize("panel", [0, 1])
+def test_gemm_bias_residual_layernorm(N, panel):
+    """dense + residual + LayerNorm in one kernel == the three separate steps (BertSelfOutput / BertOutput)"""
+    from musediffusion_amd._lib import check, current_stream
+    M, K = 333, 2 * N
+    A, W = rnd(M, K, seed=181, scale=0.5), rnd(N, K, seed=182, scale=1.0 / math.sqrt(K))
+    b, R = rnd(N, seed=183, scale=0.1), rnd(M, N, seed=184)
+    g, bt = 1.0 + rnd(N, seed=185, scale=0.1), rnd(N, seed=186, scale=0.1)
+    pre = q(A, MH_BF16) @ q(W, MH_BF16).T + b + q(R, MH_BF16)
+    ref = torch.nn.functional.layer_norm(pre, (N,), g, bt, 1e-12)
+    assert lib().mh_gemm_bias_res_ln_supported(N) == 1 and lib().mh_gemm_bias_res_ln_supported(768) == 0
+    gd, btd, bd = g.to(DEV), bt.to(DEV), b.to(DEV)
+    if panel:
+        Ad, Wd, Rd = dev_panel(A), dev_panel(W), dev_panel(R)
+        out = torch.zeros(N // 32, M, 32, device=DEV, dtype=torch.bfloat16)
+        check(lib().mh_gemm_bias_res_ln(Ad.data_ptr(), M, 1, Wd.data_ptr(), N, 1, bd.data_ptr(), Rd.data_ptr(), M, 1, gd.data_ptr(),
+                                        btd.data_ptr(), 1e-12, out.data_ptr(), M, 1, M, N, K, current_stream()))
+        got = from_panel(out.float().cpu(), M, N)
+    else:
+        Ad, Wd, Rd = A.to(DEV).bfloat16(), W.to(DEV).bfloat16(), R.to(DEV).bfloat16()
+        out = torch.zeros(M, N, device=DEV, dtype=torch.bfloat16)
+        check(lib().mh_gemm_bias_res_ln(Ad.data_ptr(), K, 0, Wd.data_ptr(), K, 0, bd.data_ptr(), Rd.data_ptr(), N, 0, gd.data_ptr(),
+                                        btd.data_ptr(), 1e-12, out.data_ptr(), N, 0, M, N, K, current_stream()))
+        got = out.float().cpu()
+    # the fused path normalises the fp32 accumulator (the unfused one rounds the sum to bf16 first): tolerance is bf16 output rounding
+    assert_close(got, ref, 1e-3, 2 ** -7, what="gemm+res+ln N=%d panel=%d" % (N, panel))
+
+
 @pytest.mark.parametrize("H", [64, 128, 512, 768])
 def test_layernorm_panel(H):
     from musediffusion_amd._lib import check, current_stream
