@@ -245,6 +245,7 @@ def main():
     ap.add_argument("--split", type=int, default=1, help="batch slices run as concurrent graph branches")
     ap.add_argument("--gemm", type=int, default=None, help="bf16 GEMM kernel variant 0/1/2 (see mh_gemm_set_variant)")
     ap.add_argument("--no-fuse-ln", action="store_true", help="A/B: separate GEMM and LayerNorm kernels")
+    ap.add_argument("--no-stream-attn", action="store_true", help="A/B: LDS-resident attention instead of the streaming kernel")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -270,6 +271,8 @@ def main():
         _lib.lib().mh_gemm_set_variant(args.gemm)
     if args.no_fuse_ln:
         _lib.lib().mh_denoiser_set_fuse_ln(0)
+    if args.no_stream_attn:
+        _lib.lib().mh_attention_set_stream(0)
     c = WORKLOADS[args.workload]
     model, diff = build(c, args.dtype, device, seed=0)
     if world > 1:

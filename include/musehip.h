@@ -126,7 +126,26 @@ int mh_attention_fwd_ex(const void* q, const void* k, const void* vt, void* ctx,
 
 /* A/B switch: 1 (default) lets the bf16 kernel keep K and V^T of a (batch, head) resident in LDS when they
  * fit (<= 128 KiB), 0 forces the tiled double-buffered kernel. */
+/* Streaming attention (bf16): same result as mh_attention_fwd_ex, for seq_len % 256 == 0, seq_len >= 512, head
+ * dim 32 / 64 (mh_attention_stream_supported).  K / V^T are streamed through LDS by LDS-DMA in 256-key stages,
+ * double-buffered across stages and (batch, head) items by persistent 16-wave blocks.  `vt_perm` is V^T
+ * [B, nh, dh, L] with the keys of every group of 16 stored as 0-3, 8-11, 4-7, 12-15 (what mh_gemm_qkv_vtperm
+ * writes): the order in which the S^T accumulators hold the probabilities.  Replaces BertSelfAttention of
+ * the encoder called at models/network.py:151. */
+int mh_attention_stream_fwd(const void* q, const void* k, const void* vt_perm, void* ctx, int64_t ld_ctx, int ctx_panel,
+                            int B, int L, int nh, int dh, float scale, mh_stream_t stream);
+int mh_attention_stream_supported(int L, int dh);
+/* A/B switch read by mh_denoiser_forward's panel path: 1 (default) = use the streaming kernel when supported. */
+int mh_attention_set_stream(int on);
+int mh_attention_stream_enabled(void);
+/* mh_gemm_qkv_ex (bf16) writing V^T in the key order mh_attention_stream_fwd reads (seq_len % 16 == 0). */
+int mh_gemm_qkv_vtperm(const void* A, int64_t lda, int a_panel, const void* Wqkv, int64_t ldw, int w_panel,
+                       const float* bqkv, void* q, void* k, void* vt_perm, int B, int L, int H, int nh,
+                       mh_stream_t stream);
 int mh_attention_set_variant(int resident);
+/* Diagnostic: when non-NULL, the LDS-resident attention kernel writes 100 MHz timestamps per block into
+ * stamps[block * 32 + {0: start, 1: K/V staged, 2 + w: wave w done}] (u64).  NULL (default) disables it. */
+int mh_attention_set_profile(void* stamps);
 
 /* K7/K8 tail  out = LayerNorm(x) * gamma + beta over the last dim (eps 1e-12 in the reference,
  *      network.py:79 and HF BertSelfOutput/BertOutput).  x, out [rows, H] `dtype`. */

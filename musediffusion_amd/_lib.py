@@ -73,7 +73,13 @@ SIGNATURES = {
     "mh_gemm_qkv": (INT, [VP, I64, VP, I64, VP, VP, VP, VP, INT, INT, INT, INT, INT, VP]),
     "mh_gemm_qkv_ex": (INT, [VP, I64, INT, VP, I64, INT, VP, VP, VP, VP, INT, INT, INT, INT, INT, VP]),
     "mh_attention_fwd_ex": (INT, [VP, VP, VP, VP, I64, INT, INT, INT, INT, INT, F32, INT, VP]),
+    "mh_attention_stream_fwd": (INT, [VP, VP, VP, VP, I64, INT, INT, INT, INT, INT, F32, VP]),
+    "mh_attention_stream_supported": (INT, [INT, INT]),
+    "mh_attention_set_stream": (INT, [INT]),
+    "mh_attention_stream_enabled": (INT, []),
+    "mh_gemm_qkv_vtperm": (INT, [VP, I64, INT, VP, I64, INT, VP, VP, VP, VP, INT, INT, INT, INT, VP]),
     "mh_attention_set_variant": (INT, [INT]),
+    "mh_attention_set_profile": (INT, [VP]),
     "mh_attention_fwd": (INT, [VP, VP, VP, VP, I64, INT, INT, INT, INT, F32, INT, VP]),
     "mh_layernorm": (INT, [VP, VP, VP, VP, I64, INT, F32, INT, VP]),
     "mh_layernorm_panel": (INT, [VP, I64, VP, VP, VP, I64, I64, INT, F32, VP]),

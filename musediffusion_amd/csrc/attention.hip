@@ -215,11 +215,13 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const bf16* __restrict__
 // one 8-wave workgroup per (batch, head) loads them ONCE (the tiled kernel re-reads them for every 128-query block
 // and pays a barrier per 64-key tile), then every wave walks its 32-query tiles over all keys with no further
 // synchronisation.  Same fragment layouts / swizzles / online softmax as attn_bf16_kernel.
-template <int DH>
-__global__ __launch_bounds__(512) void attn_res_bf16_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K,
+template <int DH, int NW>
+__global__ __launch_bounds__(64 * NW) void attn_res_bf16_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K,
                                                             const bf16* __restrict__ VT, bf16* __restrict__ ctx,
-                                                            int64_t ld_ctx, int L, int nh, float scale_log2e, int ctx_panel) {
+                                                            int64_t ld_ctx, int L, int nh, float scale_log2e, int ctx_panel,
+                                                            unsigned long long* prof) {
   constexpr int CH = DH / 8, RPB = 128 / DH, KROWB = DH * 2;
+  const unsigned long long pt0 = prof ? __builtin_amdgcn_s_memrealtime() : 0ull;
   constexpr int KT_BYTES = 64 * KROWB, VT_BYTES = DH * 128;
   constexpr int KS = DH / 16, DT = DH / 32;
   extern __shared__ __attribute__((aligned(16))) char smem_dyn[];
@@ -235,55 +237,54 @@ __global__ __launch_bounds__(512) void attn_res_bf16_kernel(const bf16* __restri
   const bf16* Vb = VT + (int64_t)bh * DH * L;
 
   // ---- stage all of K ([keys][DH], swizzled 16-B chunks) and V^T (per 64-key tile [DH][64 keys], key-permuted)
-  // K, then V^T: within each, all of a thread's global loads are issued before its first LDS write (a
-  // load -> store loop would expose one full memory latency per iteration)
+  // all of a thread's global loads (K and V^T) are issued before its first LDS write: one exposed memory
+  // latency per block instead of one per operand
   const int Lp = ntiles * 64;
-  constexpr int MAXIT = (64 * 1024 / 16) / 512;   // 16-B chunks per thread per operand when the operand fills 64 KiB
+  constexpr int NT = 64 * NW;
+  constexpr int MAXIT = (64 * 1024 / 16) / NT;   // 16-B chunks per thread per operand when the operand fills 64 KiB
   const int cpr = Lp / 8;                          // 16-B chunks per V^T row
   {
-    f32x4 reg[MAXIT];
+    f32x4 regk[MAXIT], regv[MAXIT];
 #pragma unroll
     for (int i = 0; i < MAXIT; ++i) {
-      const int qd = tid + 512 * i;
+      const int qd = tid + NT * i;
       if (qd < Lp * CH) {
         const int row = qd / CH, c = qd % CH;
-        reg[i] = *reinterpret_cast<const f32x4*>(Kb + (int64_t)(row < L ? row : L - 1) * DH + c * 8);
+        regk[i] = *reinterpret_cast<const f32x4*>(Kb + (int64_t)(row < L ? row : L - 1) * DH + c * 8);
       }
     }
 #pragma unroll
     for (int i = 0; i < MAXIT; ++i) {
-      const int qd = tid + 512 * i;
-      if (qd < Lp * CH) {
-        const int row = qd / CH, c = qd % CH;
-        *reinterpret_cast<f32x4*>(kbase + row * KROWB + ((c ^ ((row / RPB) & (CH - 1))) << 4)) = reg[i];
-      }
-    }
-  }
-  {
-    f32x4 reg[MAXIT];
-#pragma unroll
-    for (int i = 0; i < MAXIT; ++i) {
-      const int qd = tid + 512 * i;
+      const int qd = tid + NT * i;
       if (qd < DH * cpr) {
         const int d = qd / cpr, key = (qd % cpr) * 8;
-        reg[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (key < L) reg[i] = *reinterpret_cast<const f32x4*>(Vb + (int64_t)d * L + key);
+        regv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (key < L) regv[i] = *reinterpret_cast<const f32x4*>(Vb + (int64_t)d * L + key);
       }
     }
 #pragma unroll
     for (int i = 0; i < MAXIT; ++i) {
-      const int qd = tid + 512 * i;
+      const int qd = tid + NT * i;
+      if (qd < Lp * CH) {
+        const int row = qd / CH, c = qd % CH;
+        *reinterpret_cast<f32x4*>(kbase + row * KROWB + ((c ^ ((row / RPB) & (CH - 1))) << 4)) = regk[i];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < MAXIT; ++i) {
+      const int qd = tid + NT * i;
       if (qd < DH * cpr) {
         const int d = qd / cpr, cg = qd % cpr;
         const int t = cg >> 3, c = cg & 7, sblk = c >> 1, sw = (d >> 1) & 7, half = (c & 1) * 8;
         typedef __attribute__((ext_vector_type(2))) float f32x2;
         char* vb = vbase + t * VT_BYTES + d * 128;
-        *reinterpret_cast<f32x2*>(vb + (((2 * sblk) ^ sw) << 4) + half) = f32x2{reg[i][0], reg[i][1]};
-        *reinterpret_cast<f32x2*>(vb + (((2 * sblk + 1) ^ sw) << 4) + half) = f32x2{reg[i][2], reg[i][3]};
+        *reinterpret_cast<f32x2*>(vb + (((2 * sblk) ^ sw) << 4) + half) = f32x2{regv[i][0], regv[i][1]};
+        *reinterpret_cast<f32x2*>(vb + (((2 * sblk + 1) ^ sw) << 4) + half) = f32x2{regv[i][2], regv[i][3]};
       }
     }
   }
   __syncthreads();
+  if (prof && threadIdx.x == 0) { prof[blockIdx.x * 32] = pt0; prof[blockIdx.x * 32 + 1] = __builtin_amdgcn_s_memrealtime(); }
 
   // One 32-query tile per wave at a time, software-pipelined fragment loads: the eight K fragments of tile t+1
   // are read from LDS while tile t's softmax / P.V run, the eight V^T fragments of tile t while its K.Q^T
@@ -292,7 +293,7 @@ __global__ __launch_bounds__(512) void attn_res_bf16_kernel(const bf16* __restri
   const int nq = (L + 31) / 32;
   const int krow0 = lq, krow1 = 32 + lq;
   const int ksw0 = (krow0 / RPB) & (CH - 1), ksw1 = (krow1 / RPB) & (CH - 1);
-  for (int qt = wave; qt < nq; qt += 8) {
+  for (int qt = wave; qt < nq; qt += NW) {
     const int q0 = qt * 32;
     bf16x8 qf[KS];
     {
@@ -409,6 +410,7 @@ __global__ __launch_bounds__(512) void attn_res_bf16_kernel(const bf16* __restri
       }
     }
   }
+  if (prof && (threadIdx.x & 63) == 0) prof[blockIdx.x * 32 + 2 + (threadIdx.x >> 6)] = __builtin_amdgcn_s_memrealtime();
 }
 
 // ------------------------------------------------------------------------------ f32 / VALU
@@ -540,7 +542,185 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(const float* __restrict__
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Streaming attention (bf16, L a multiple of 256, >= 512 queries per block): persistent blocks of 16 waves, one
+// 32-query tile per wave, K / V^T streamed through LDS in 256-key stages by LDS-DMA, double-buffered - the
+// stage (or the next (batch, head)) after the current one is in flight while the current one is computed, so
+// the HBM traffic is spread over the whole kernel instead of arriving as one burst per block before any MFMA
+// can start (the LDS-resident kernel above spends 10 of its 33 us per block in that burst at L = 512).
+// V^T arrives in the "P-operand" key order (mh_gemm_qkv_vtperm): within every 16 keys the two middle groups of
+// four are swapped, which is the order the S^T accumulator registers hold the probabilities in, so a stage
+// is a straight 16-byte-granular copy (source-side XOR swizzle) and P feeds the P.V MFMA without a shuffle.
+template <int DH>
+__global__ __launch_bounds__(1024) void attn_stream_bf16_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K,
+                                                                const bf16* __restrict__ VT, bf16* __restrict__ ctx,
+                                                                int64_t ld_ctx, int L, int nh, int nbh, float scale_log2e,
+                                                                int ctx_panel) {
+  constexpr int NW = 16, SK = 256;                       // waves, keys per stage
+  constexpr int CH = DH / 8, RPB = 128 / DH, KROWB = DH * 2;
+  constexpr int KS = DH / 16, DT = DH / 32;
+  constexpr int KST = SK * KROWB, VT_BYTES = DH * 128;   // K stage bytes (= V stage bytes), V^T bytes per 64-key tile
+  constexpr int PK = KST / 1024 / NW;                    // 1-KiB DMA pieces per wave per operand per stage
+  constexpr int KRP = 1024 / KROWB;                      // K rows per piece
+  static_assert(PK >= 1, "stage too small for 16 waves");
+  extern __shared__ __attribute__((aligned(16))) char smem_dyn[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = lane >> 5, lq = lane & 31;
+  const int nqb = (L + 511) / 512, nst = L / SK;
+  const int nitems = nbh * nqb;
+  const int my_items = (nitems - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int total = my_items * nst;
+
+  auto issue = [&](int g) {   // DMA stage g (of this block's flattened (item, stage) sequence) into buffer g & 1
+    const int item = blockIdx.x + (g / nst) * gridDim.x, st = g % nst;
+    const int bh = item / nqb;
+    const bf16* Kb = K + ((int64_t)bh * L + (int64_t)st * SK) * DH;
+    const bf16* Vb = VT + (int64_t)bh * DH * L + (int64_t)st * SK;
+    char* kdst = smem_dyn + (g & 1) * (2 * KST);
+    char* vdst = kdst + KST;
+#pragma unroll
+    for (int j = 0; j < PK; ++j) {
+      const int p = wave + NW * j;
+      const int row = p * KRP + lane / CH, pc = lane % CH;             // key within the stage, physical chunk
+      const int lc = pc ^ ((row / RPB) & (CH - 1));
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Kb + (int64_t)row * DH + lc * 8),
+                                       (__attribute__((address_space(3))) void*)(kdst + p * 1024), 16, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < PK; ++j) {
+      const int p = wave + NW * j;
+      const int t = p / (DH / 8), d = (p % (DH / 8)) * 8 + (lane >> 3), pc = lane & 7;
+      const int lc = pc ^ ((d >> 1) & 7);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Vb + (int64_t)d * L + t * 64 + lc * 8),
+                                       (__attribute__((address_space(3))) void*)(vdst + p * 1024), 16, 0, 0);
+    }
+  };
+
+  const int ksw0 = (lq / RPB) & (CH - 1), ksw1 = ((32 + lq) / RPB) & (CH - 1);
+  bf16x8 qf[KS];
+  f32x16 o[DT];
+  float m_run = -INFINITY, l_run = 0.f;
+  int q0 = 0;
+  bool active = false;
+
+  if (total > 0) issue(0);
+  for (int g = 0; g < total; ++g) {
+    const int item = blockIdx.x + (g / nst) * gridDim.x, st = g % nst;
+    const int bh = item / nqb, qb = item % nqb;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // stage g (issued one stage ago) has landed
+    __builtin_amdgcn_s_barrier();                      // ... for every wave; buffer (g+1)&1 was released at the end of stage g-1
+    if (g + 1 < total) issue(g + 1);
+    if (st == 0) {
+      q0 = qb * 512 + wave * 32;
+      active = q0 < L;
+      if (active) {
+        const bf16* Qb = Q + (int64_t)bh * L * DH;
+        int qr = q0 + lq; if (qr >= L) qr = L - 1;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(Qb + (int64_t)qr * DH + 16 * ks + 8 * h);
+      }
+#pragma unroll
+      for (int i = 0; i < DT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
+      m_run = -INFINITY; l_run = 0.f;
+    }
+    if (active) {
+      const char* kbuf = smem_dyn + (g & 1) * (2 * KST);
+      const char* vbuf = kbuf + KST;
+      for (int t = 0; t < SK / 64; ++t) {
+        const char* kb = kbuf + t * (64 * KROWB);
+        const char* vb = vbuf + t * VT_BYTES;
+        f32x16 s[2];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+          bf16x8 kf[KS];
+          const int krow = 32 * kt + lq, ksw = kt ? ksw1 : ksw0;
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) kf[ks] = *reinterpret_cast<const bf16x8*>(kb + krow * KROWB + (((2 * ks + h) ^ ksw) << 4));
+#pragma unroll
+          for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[ks], s[kt], 0, 0, 0);
+        }
+        float mx4[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+          for (int r = 0; r < 16; r += 4)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) mx4[e] = fmaxf(mx4[e], s[kt][r + e]);
+        float mx = fmaxf(fmaxf(mx4[0], mx4[1]), fmaxf(mx4[2], mx4[3]));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        // lazy rescale: the running reference m_run only moves when some row's tile maximum exceeds it by more than
+        // 2^8 in the exponent domain (always on the first tile, where it is -inf); otherwise the probabilities are
+        // taken against the stale reference (p <= 256, harmless in fp32 / bf16) and the 32 accumulator multiplies,
+        // the exp of alpha and the l_run multiply are skipped.  The final o / l is unchanged up to rounding.
+        if (__builtin_amdgcn_ballot_w64((mx - m_run) * scale_log2e > 8.0f) != 0) {
+          const float m_new = fmaxf(m_run, mx);
+          const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * scale_log2e);
+          l_run *= alpha;
+          m_run = m_new;
+#pragma unroll
+          for (int i = 0; i < DT; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+        }
+        const float mb = m_run * scale_log2e;
+        float ps4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float p = __builtin_amdgcn_exp2f(s[kt][r] * scale_log2e - mb);
+            s[kt][r] = p;
+            ps4[r & 3] += p;
+          }
+        l_run += (ps4[0] + ps4[1]) + (ps4[2] + ps4[3]);
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+          for (int s2 = 0; s2 < 2; ++s2) {
+            bf16x8 pf;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pf[j] = (bf16)s[kt][8 * s2 + j];
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+              const int d = dt * 32 + lq;
+              const bf16x8 vf = *reinterpret_cast<const bf16x8*>(vb + d * 128 + (((2 * (2 * kt + s2) + h) ^ ((d >> 1) & 7)) << 4));
+              o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[dt], 0, 0, 0);
+            }
+          }
+      }
+      if (st == nst - 1) {   // last stage of this (batch, head): normalise and write the context rows
+        const float inv = 1.0f / (l_run + __shfl_xor(l_run, 32, 64));
+        const int qr = q0 + lq;
+        if (qr < L) {
+          const int b = bh / nh, head = bh % nh;
+          const int64_t tok = (int64_t)b * L + qr;
+#pragma unroll
+          for (int dt = 0; dt < DT; ++dt) {
+            bf16* dst = ctx_panel ? ctx + (((int64_t)(head * DT + dt)) * ld_ctx + tok) * 32 : ctx + tok * ld_ctx + head * DH + dt * 32;
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+              bf16x4 v;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = (bf16)(o[dt][rg * 4 + e] * inv);
+              *reinterpret_cast<bf16x4*>(dst + 8 * rg + 4 * h) = v;
+            }
+          }
+        }
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                      // every wave is done reading buffer g & 1
+  }
+}
+
 int g_attn_resident = 1;
+unsigned long long* g_attn_prof = nullptr;   // diagnostic stamps (mh_attention_set_profile)
 
 template <int DH>
 int launch_f32(const float* q, const float* k, const float* vt, float* ctx, int64_t ld, int B, int L, int nh,
@@ -565,12 +745,19 @@ int launch_bf16(const bf16* q, const bf16* k, const bf16* vt, bf16* ctx, int64_t
   if (g_attn_resident && DH <= 64 && res_bytes <= 128 * 1024 && L >= 128) {
     static bool attr_set = false;
     if (!attr_set) {
-      MH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_res_bf16_kernel<DH>),
+      MH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_res_bf16_kernel<DH, 8>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+      MH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_res_bf16_kernel<DH, 16>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
       attr_set = true;
     }
-    MH_LAUNCH((attn_res_bf16_kernel<DH>), dim3(B * nh), dim3(512), res_bytes, s, q, k, vt, ctx, ld, L, nh,
-              scale * 1.4426950408889634f, ctx_panel);
+    // 16 waves (four per SIMD) when the sequence has a 32-query tile for each of them
+    if (g_attn_resident == 2 && L >= 512)
+      MH_LAUNCH((attn_res_bf16_kernel<DH, 16>), dim3(B * nh), dim3(1024), res_bytes, s, q, k, vt, ctx, ld, L, nh,
+                scale * 1.4426950408889634f, ctx_panel, g_attn_prof);
+    else
+      MH_LAUNCH((attn_res_bf16_kernel<DH, 8>), dim3(B * nh), dim3(512), res_bytes, s, q, k, vt, ctx, ld, L, nh,
+                scale * 1.4426950408889634f, ctx_panel, g_attn_prof);
     MH_CHECK_LAUNCH();
     return MH_OK;
   }
@@ -583,8 +770,56 @@ int launch_bf16(const bf16* q, const bf16* k, const bf16* vt, bf16* ctx, int64_t
 
 }  // namespace
 
+namespace { int g_attn_stream = 1; }
+extern "C" int mh_attention_set_stream(int on) {
+  g_attn_stream = on != 0;
+  return MH_OK;
+}
+extern "C" int mh_attention_stream_enabled(void) { return g_attn_stream; }
+
+extern "C" int mh_attention_stream_supported(int L, int dh) { return L >= 512 && L % 256 == 0 && (dh == 32 || dh == 64); }
+
+extern "C" int mh_attention_stream_fwd(const void* q, const void* k, const void* vt_perm, void* ctx, int64_t ld_ctx, int ctx_panel,
+                                       int B, int L, int nh, int dh, float scale, mh_stream_t stream) {
+  MH_CHECK_ARG(q && k && vt_perm && ctx, "attention_stream: null pointer");
+  MH_CHECK_ARG(B > 0 && nh > 0 && mh_attention_stream_supported(L, dh),
+               "attention_stream: needs seq_len %% 256 == 0, seq_len >= 512 and head dim 32 or 64 (got L=%d dh=%d)", L, dh);
+  MH_CHECK_ARG(ctx_panel || ld_ctx % 4 == 0, "attention_stream: ld_ctx must be a multiple of 4");
+  hipStream_t s = (hipStream_t)stream;
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+  const int nbh = B * nh, nitems = nbh * ((L + 511) / 512);
+  const dim3 grid((unsigned)(nitems < cus ? nitems : cus)), block(1024);
+  const float sl2 = scale * 1.4426950408889634f;
+  const bf16 *Q = (const bf16*)q, *K = (const bf16*)k, *V = (const bf16*)vt_perm;
+  if (dh == 64) {
+    constexpr int bytes = 4 * 256 * 64 * 2;
+    static bool attr_set = false;
+    if (!attr_set) {
+      MH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_stream_bf16_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+      attr_set = true;
+    }
+    MH_LAUNCH((attn_stream_bf16_kernel<64>), grid, block, bytes, s, Q, K, V, (bf16*)ctx, ld_ctx, L, nh, nbh, sl2, ctx_panel);
+  } else {
+    constexpr int bytes = 4 * 256 * 32 * 2;
+    static bool attr_set = false;
+    if (!attr_set) {
+      MH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_stream_bf16_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+      attr_set = true;
+    }
+    MH_LAUNCH((attn_stream_bf16_kernel<32>), grid, block, bytes, s, Q, K, V, (bf16*)ctx, ld_ctx, L, nh, nbh, sl2, ctx_panel);
+  }
+  MH_CHECK_LAUNCH();
+  return MH_OK;
+}
+
+extern "C" int mh_attention_set_profile(void* stamps) {
+  g_attn_prof = reinterpret_cast<unsigned long long*>(stamps);
+  return MH_OK;
+}
+
 extern "C" int mh_attention_set_variant(int resident) {
-  g_attn_resident = resident ? 1 : 0;
+  g_attn_resident = resident < 0 ? 0 : (resident > 2 ? 2 : resident);
   return MH_OK;
 }
 

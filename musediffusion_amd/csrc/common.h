@@ -94,17 +94,17 @@ __device__ __forceinline__ float wave_max(float v) {
 // exact-erf GELU (HF hidden_act="gelu"), tanh, SiLU in fp32
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float silu(float x) { return x / (1.0f + expf(-x)); }
-// GELU for the bf16 path: erf by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, far below the bf16
-// rounding of the result) = one v_exp, one v_rcp and ~10 FMAs instead of ocml's branchy erff.
+// GELU for the bf16 path: x * Phi(x) with Phi(x) ~ sigmoid(x (a + b x^2 + c x^4)), a minimax fit of the erf form
+// (max |error| 2.5e-5 over all x - two orders below the bf16 rounding of the result; the fp32 parity path
+// uses erff).  One v_exp, one v_rcp, 7 cheap VALU ops; x^2 is clamped at 64 where the quartic is still
+// increasing (sigmoid is 0 / 1 to fp32 precision beyond |x| = 8).
 __device__ __forceinline__ float gelu_erf_fast(float x) {
-  const float z = fabsf(x) * 0.70710678118654752440f;
-  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
-  float p = fmaf(1.061405429f, t, -1.453152027f);
-  p = fmaf(p, t, 1.421413741f);
-  p = fmaf(p, t, -0.284496736f);
-  p = fmaf(p, t, 0.254829592f);
-  const float e = 1.0f - p * t * __builtin_amdgcn_exp2f(-z * z * 1.4426950408889634f);  // erf(|x|/sqrt2)
-  return 0.5f * x * (1.0f + copysignf(e, x));
+  constexpr float kL2E = 1.4426950408889634f;
+  const float u = fminf(x * x, 64.0f);
+  float p = fmaf(0.0007030335771326705f * kL2E, u, -0.07401129204508086f * kL2E);
+  p = fmaf(p, u, -1.5950157685701116f * kL2E);
+  const float e = __builtin_amdgcn_exp2f(x * p);              // exp(-x (a + b u + c u^2))
+  return x * __builtin_amdgcn_rcpf(1.0f + e);
 }
 
 static inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

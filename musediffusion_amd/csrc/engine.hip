@@ -160,6 +160,7 @@ extern "C" int mh_denoiser_forward(const mh_denoiser* m, const float* x, const f
       return mh_gemm_bias_res_ln(A, N, P, W, H, P, bias, res, N, P, gamma, beta, m->ln_eps, o, N, P, N, H, K, stream);
     };
     const bool fuse_ln = g_fuse_ln && mh_gemm_bias_res_ln_supported(H);
+    const bool stream_attn = mh_attention_stream_enabled() && mh_attention_stream_supported(L, dh) && H % 64 == 0;
     if (m->has_proj) {
       if ((rc = mh_pack_panel(x, m->E, w.xin, N, N, m->E, m->E_pad, stream))) return rc;
       if ((rc = gemm(w.xin, m->w_up0, H, m->b_up0, nullptr, w.buf0, 0, N, H, m->E_pad, MH_ACT_TANH))) return rc;
@@ -174,8 +175,13 @@ extern "C" int mh_denoiser_forward(const mh_denoiser* m, const float* x, const f
     }
     for (int l = 0; l < m->nL; ++l) {
       const mh_layer_weights& lw = m->layers[l];
-      if ((rc = mh_gemm_qkv_ex(w.bufX, N, P, lw.w_qkv, 3 * H, P, lw.b_qkv, w.q, w.k, w.vt, B, L, H, m->nh, dt, stream))) return rc;
-      if ((rc = mh_attention_fwd_ex(w.q, w.k, w.vt, w.buf0, N, P, B, L, m->nh, dh, scale, dt, stream))) return rc;
+      if (stream_attn) {   // V^T written in the streaming kernel's key order: its stages are straight LDS-DMA copies
+        if ((rc = mh_gemm_qkv_vtperm(w.bufX, N, P, lw.w_qkv, 3 * H, P, lw.b_qkv, w.q, w.k, w.vt, B, L, H, m->nh, stream))) return rc;
+        if ((rc = mh_attention_stream_fwd(w.q, w.k, w.vt, w.buf0, N, P, B, L, m->nh, dh, scale, stream))) return rc;
+      } else {
+        if ((rc = mh_gemm_qkv_ex(w.bufX, N, P, lw.w_qkv, 3 * H, P, lw.b_qkv, w.q, w.k, w.vt, B, L, H, m->nh, dt, stream))) return rc;
+        if ((rc = mh_attention_fwd_ex(w.q, w.k, w.vt, w.buf0, N, P, B, L, m->nh, dh, scale, dt, stream))) return rc;
+      }
       if (fuse_ln) {   // dense + residual + LayerNorm in one kernel: the block owns complete rows
         if ((rc = gemm_ln(w.buf0, lw.w_ao, lw.b_ao, w.bufX, lw.ln1_g, lw.ln1_b, w.bufX1, H))) return rc;
       } else {

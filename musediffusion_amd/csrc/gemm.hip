@@ -42,6 +42,7 @@ struct GemmArgs {
   // second slot ((blockIdx.x / 8) / cus_per_xcd odd) start `stagger` ticks (100 MHz) late so that one
   // block's epilogue stores run under its neighbour's main loop instead of beside its epilogue
   int ntiles, cus_per_xcd, stagger;
+  int vt_perm;   // QKV scatter: V^T keys in the P-operand order of mh_attention_stream_fwd (middle groups of 4 swapped per 16)
 };
 
 template <typename T> struct Tile;
@@ -647,7 +648,9 @@ __global__ __launch_bounds__(C::THREADS, C::STAGE * C::NST <= 80 * 1024 ? 2 : 1)
       for (int i = 0; i < TI; ++i) {
         const int row = r0 + 16 * i + 4 * fg;
         if (row < M32) {
-          const int b = row / g.L, l = row - b * g.L;
+          const int b = row / g.L;
+          int l = row - b * g.L;
+          if (g.vt_perm) l = (l & ~15) | ((((l >> 3) & 1) | ((l >> 1) & 2)) << 2);   // 4-token group 0,1,2,3 -> 0,2,1,3
           bf16* base = dst + (int64_t)b * g.H * g.L + l;
 #pragma unroll
           for (int j = 0; j < TJ; ++j) {
@@ -1020,9 +1023,26 @@ extern "C" int mh_gemm_qkv(const void* A, int64_t lda, const void* Wqkv, int64_t
   return mh_gemm_qkv_ex(A, lda, 0, Wqkv, ldw, 0, bqkv, q, k, vt, B, L, H, nh, dtype, stream);
 }
 
+namespace { int qkv_impl(const void* A, int64_t lda, int a_panel, const void* Wqkv, int64_t ldw, int w_panel, const float* bqkv,
+                         void* q, void* k, void* vt, int B, int L, int H, int nh, int dtype, int vt_perm, mh_stream_t stream); }
+
 extern "C" int mh_gemm_qkv_ex(const void* A, int64_t lda, int a_panel, const void* Wqkv, int64_t ldw, int w_panel,
                               const float* bqkv, void* q, void* k, void* vt, int B, int L, int H, int nh, int dtype,
                               mh_stream_t stream) {
+  return qkv_impl(A, lda, a_panel, Wqkv, ldw, w_panel, bqkv, q, k, vt, B, L, H, nh, dtype, 0, stream);
+}
+
+extern "C" int mh_gemm_qkv_vtperm(const void* A, int64_t lda, int a_panel, const void* Wqkv, int64_t ldw, int w_panel,
+                                  const float* bqkv, void* q, void* k, void* vt_perm, int B, int L, int H, int nh,
+                                  mh_stream_t stream) {
+  MH_CHECK_ARG(L % 16 == 0, "gemm_qkv_vtperm: seq_len %d must be a multiple of 16", L);
+  MH_CHECK_ARG(g_variant >= 2, "gemm_qkv_vtperm: needs the big-tile bf16 kernel");
+  return qkv_impl(A, lda, a_panel, Wqkv, ldw, w_panel, bqkv, q, k, vt_perm, B, L, H, nh, MH_BF16, 1, stream);
+}
+
+namespace {
+int qkv_impl(const void* A, int64_t lda, int a_panel, const void* Wqkv, int64_t ldw, int w_panel, const float* bqkv,
+             void* q, void* k, void* vt, int B, int L, int H, int nh, int dtype, int vt_perm, mh_stream_t stream) {
   MH_CHECK_ARG(A && Wqkv && bqkv && q && k && vt, "gemm_qkv: null pointer");
   MH_CHECK_ARG(H % 64 == 0, "gemm_qkv: hidden size %d must be a multiple of 64", H);
   MH_CHECK_ARG(nh > 0 && H % nh == 0 && (H / nh) % 8 == 0, "gemm_qkv: head dim must be a multiple of 8");
@@ -1032,8 +1052,11 @@ extern "C" int mh_gemm_qkv_ex(const void* A, int64_t lda, int a_panel, const voi
   g.M = (int64_t)B * L; g.N = 3 * H; g.K = H;
   g.a_panel = a_panel; g.w_panel = w_panel;
   g.q = q; g.k = k; g.vt = vt; g.L = L; g.H = H; g.nh = nh; g.dh = H / nh;
+  g.vt_perm = vt_perm;
+  MH_CHECK_ARG(!vt_perm || (big_tile_ok(g) && H % 64 == 0), "gemm_qkv_vtperm: shape not served by the big-tile kernel");
   return launch<1>(g, dtype, (hipStream_t)stream);
 }
+}  // namespace
 
 
 // ---------------------------------------------------------------- nearest-embedding rounding on the fp32 MFMA

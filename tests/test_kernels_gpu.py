@@ -159,6 +159,50 @@ def test_attention(dtype, dh, L):
     assert_close(out, ref, atol, what="attention dh=%d L=%d" % (dh, L))
 
 
+def _vt_perm(vt):
+    """[..., dh, L] -> keys of every group of 16 stored as 0-3, 8-11, 4-7, 12-15 (mh_gemm_qkv_vtperm's order)."""
+    *lead, L = vt.shape
+    return vt.reshape(*lead, L // 16, 4, 4)[..., [0, 2, 1, 3], :].reshape(*lead, L).contiguous()
+
+
+@pytest.mark.parametrize("dh,L,B,nh", [(64, 512, 3, 5), (32, 512, 2, 3), (64, 1024, 2, 2), (64, 768, 1, 3)])
+def test_attention_stream(dh, L, B, nh):
+    """streaming kernel (LDS-DMA stages, permuted V^T) == softmax(QK^T/sqrt(dh)) V, row-major and panel output"""
+    from musediffusion_amd._lib import check, current_stream
+    qh, kh, vh = (rnd(B, nh, L, dh, seed=230 + i) for i in range(3))
+    kh = kh * 1.5
+    kh[:, :, 300] *= 4.0
+    scale = 1.0 / math.sqrt(dh)
+    ref = _attn_ref(q(qh, MH_BF16), q(kh, MH_BF16), q(vh, MH_BF16), scale).permute(0, 2, 1, 3).reshape(B * L, nh * dh)
+    assert lib().mh_attention_stream_supported(L, dh) == 1 and lib().mh_attention_stream_supported(136, dh) == 0
+    vtp = _vt_perm(vh.transpose(-1, -2).contiguous())
+    vt_dev = torch.zeros(vtp.numel() + 128, device=DEV, dtype=torch.bfloat16)
+    vt_dev[: vtp.numel()] = vtp.to(DEV).bfloat16().flatten()
+    qd, kd = qh.to(DEV).bfloat16().contiguous(), kh.to(DEV).bfloat16().contiguous()
+    out = torch.zeros(B * L, nh * dh, device=DEV, dtype=torch.bfloat16)
+    check(lib().mh_attention_stream_fwd(qd.data_ptr(), kd.data_ptr(), vt_dev.data_ptr(), out.data_ptr(), nh * dh, 0, B, L, nh, dh,
+                                        scale, current_stream()))
+    assert_close(out, ref, 2e-2, what="attention_stream dh=%d L=%d" % (dh, L))
+    outp = torch.zeros(nh * dh // 32, B * L, 32, device=DEV, dtype=torch.bfloat16)
+    check(lib().mh_attention_stream_fwd(qd.data_ptr(), kd.data_ptr(), vt_dev.data_ptr(), outp.data_ptr(), B * L, 1, B, L, nh, dh,
+                                        scale, current_stream()))
+    assert torch.equal(outp.permute(1, 0, 2).reshape(B * L, nh * dh), out)
+
+
+def test_gemm_qkv_vtperm():
+    from musediffusion_amd._lib import check, current_stream
+    B, L, H, nh = 2, 48, 128, 2
+    X, Wq, bq = rnd(B * L, H, seed=240), rnd(3 * H, H, seed=241, scale=1.0 / 11), rnd(3 * H, seed=242, scale=0.1)
+    Xd, Wd, bd = X.to(DEV).bfloat16(), Wq.to(DEV).bfloat16(), bq.to(DEV)
+    q0, k0, vt0 = ops.gemm_qkv(Xd, Wd, bd, B, L, nh, MH_BF16)
+    q1, k1 = torch.empty_like(q0), torch.empty_like(k0)
+    vt1 = torch.zeros(B * H * L + 128, device=DEV, dtype=torch.bfloat16)
+    check(lib().mh_gemm_qkv_vtperm(Xd.data_ptr(), H, 0, Wd.data_ptr(), H, 0, bd.data_ptr(), q1.data_ptr(), k1.data_ptr(),
+                                   vt1.data_ptr(), B, L, H, nh, current_stream()))
+    assert torch.equal(q0, q1) and torch.equal(k0, k1)
+    assert torch.equal(vt1[: B * H * L].view(B, nh, H // nh, L), _vt_perm(vt0))
+
+
 @pytest.mark.parametrize("dtype", [MH_F32, MH_BF16], ids=["f32", "bf16"])
 @pytest.mark.parametrize("H", [64, 512, 768])
 def test_layernorm(H, dtype):

@@ -14,7 +14,7 @@ q = torch.randn(a.B, a.nh, a.L, a.dh, device=dev).to(bf)
 k = torch.randn(a.B, a.nh, a.L, a.dh, device=dev).to(bf)
 vt = torch.randn(a.B * a.nh * a.dh * a.L + 256, device=dev).to(bf)
 flops = 4.0 * a.B * a.nh * a.L * a.L * a.dh
-for res in (0, 1):
+for res in (0, 1, 2):
     _lib.lib().mh_attention_set_variant(res)
     ops.attention(q, k, vt, a.dh ** -0.5, 1)
     torch.cuda.synchronize()
@@ -25,3 +25,33 @@ for res in (0, 1):
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / a.reps
     print("attention resident=%d: %7.1f us  %6.1f TFLOP/s" % (res, ms * 1e3, flops / ms / 1e9))
+
+if _lib.lib().mh_attention_stream_supported(a.L, a.dh):
+    ctx = torch.empty(a.B * a.L, a.nh * a.dh, device=dev, dtype=bf)
+    def run():
+        _lib.check(_lib.lib().mh_attention_stream_fwd(q.data_ptr(), k.data_ptr(), vt.data_ptr(), ctx.data_ptr(), a.nh * a.dh, 0, a.B, a.L,
+                                                      a.nh, a.dh, a.dh ** -0.5, _lib.current_stream()))
+    run(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(a.reps):
+        run()
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / a.reps
+    print("attention stream    : %7.1f us  %6.1f TFLOP/s" % (ms * 1e3, flops / ms / 1e9))
+# per-block timeline of the resident kernel (100 MHz stamps)
+for res in (1, 2):
+    _lib.lib().mh_attention_set_variant(res)
+    st = torch.zeros(a.B * a.nh * 32, dtype=torch.int64, device=dev)
+    _lib.lib().mh_attention_set_profile(st.data_ptr())
+    ops.attention(q, k, vt, a.dh ** -0.5, 1)
+    torch.cuda.synchronize()
+    _lib.lib().mh_attention_set_profile(None)
+    s_ = st.view(-1, 32).cpu().double()
+    nw = 8 if res == 1 else 16
+    t0 = s_[:, 0].min()
+    stage = (s_[:, 1] - s_[:, 0]).mean() / 100
+    ends = s_[:, 2:2 + nw]
+    print("resident=%d: staging %.2f us/block; block duration %.2f us (first wave done after %.2f, last %.2f); blocks start at %s us" % (
+        res, stage, ((ends.max(1).values - s_[:, 0]).mean()) / 100, ((ends.min(1).values - s_[:, 0]).mean()) / 100,
+        ((ends.max(1).values - s_[:, 0]).mean()) / 100, sorted(set(((s_[:, 0] - t0) / 100).round().tolist()))[:6]))
