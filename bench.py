@@ -16,7 +16,7 @@ own batch of 64 (weak scaling; the reference shards whole batches over ranks, ru
 rank 0 builds the weights and ONE RCCL broadcast of the packed arena distributes them.
 
 Prints ONE JSON line (rank 0) with the driver's contract plus `roofline` (dominant kernel: the bf16
-MFMA GEMM, timed live with HIP events on the launch stream) and `cpu_baseline` (the oracle = a
+MFMA GEMM of the FFN intermediate dense, timed live with HIP events on the launch stream) and `cpu_baseline` (the oracle = a
 torch-CPU fp32 port of the reference path, timed on the host cores on a bounded sample).
 """
 import argparse
@@ -51,20 +51,6 @@ def step_flops(c):
     return N * per_tok + 2 * B * (4 * Tt * Tt + 4 * Tt * H)
 
 
-def _unused_gemm_launches(c):
-    """(M, N, K) of every launch of the generic GEMM kernel (gemm_kernel<bf16, EPI=0>) in one step."""
-    N, H, F, E = c["B"] * c["L"], c["H"], c["F"], c["E"]
-    Ep = (E + 63) // 64 * 64
-    out = []
-    if E != H:
-        out += [(N, H, Ep), (N, H, H)]
-    for _ in range(c["nL"]):
-        out += [(N, H, H), (N, F, H), (N, H, F)]
-    if E != H:
-        out += [(N, H, H), (N, E, H)]
-    return out
-
-
 def build(c, dtype, device, seed=0):
     from musediffusion_amd.models.diffusion import SpacedDiffusion, get_named_beta_schedule, space_timesteps
     from musediffusion_amd.models.network import TransformerNetModel
@@ -78,39 +64,29 @@ def build(c, dtype, device, seed=0):
 
 
 def time_dominant_kernel(c, dtype, device, reps):
-    """Average launch duration of the generic GEMM kernel over the launches one step makes, measured with HIP
-    events on the launch stream: back-to-back launches of the real shapes in the layout the engine uses
-    (K32 panels for bf16, row-major for fp32), bias + the step's epilogues included."""
+    """Average launch duration of the step's dominant kernel - the FFN intermediate dense (x W1^T + b1, GELU):
+    N = ffn, K = d_model, one launch per encoder layer, ~30% of the step in profiles/ - measured with HIP events on
+    the launch stream: back-to-back launches of the real shape in the layout the engine uses (K32 panels for
+    bf16, row-major for fp32), bias + GELU epilogue included.  Conservative: inside the step, between the
+    attention and LayerNorm-fused kernels, rocprofv3 shows the same launch ~10% shorter (profiles/) - the chip
+    holds a lower clock under a pure-MFMA load."""
     from musediffusion_amd import _lib, ops
     code = ops.dtype_code(dtype)
     td = ops.TORCH_DTYPE[code]
     panel = 1 if code == _lib.MH_BF16 else 0
-    N_tok, H, F, E = c["B"] * c["L"], c["H"], c["F"], c["E"]
-    Ep = (E + 63) // 64 * 64
-    # (N_out, K, act, residual, fp32 out) of every generic-GEMM launch of one step (engine.hip order)
-    launches = []
-    if E != H:
-        launches += [(H, Ep, 1, False, False), (H, H, 0, False, False)]
-    for _ in range(c["nL"]):
-        launches += [(H, H, 0, True, False), (F, H, 2, False, False), (H, F, 0, True, False)]
-    if E != H:
-        launches += [(H, H, 1, False, False), (E, H, 0, False, True)]
-    Kmax, Nmax = max(k for _, k, _, _, _ in launches), max(n for n, _, _, _, _ in launches)
-    A = torch.randn(N_tok * Kmax, device=device).to(td)
-    W = (torch.randn(Nmax * Kmax, device=device) / 32).to(td)
-    R = torch.randn(N_tok * Nmax, device=device).to(td)
-    O = torch.empty(N_tok * max(Nmax, 1) * 2, device=device, dtype=td)
-    bias = torch.zeros(Nmax, device=device)
+    N_tok, H, F = c["B"] * c["L"], c["H"], c["F"]
+    A = torch.randn(N_tok * H, device=device).to(td)
+    W = (torch.randn(F * H, device=device) / 32).to(td)
+    O = torch.empty(N_tok * F, device=device, dtype=td)
+    bias = torch.zeros(F, device=device)
     lib, st = _lib.lib(), _lib.current_stream
+    nl = c["nL"]
 
     def one_pass():
-        for (n, k, act, res, f32) in launches:
-            lda = N_tok if panel else k
-            ldw = n if panel else k
-            ldo = n if f32 else (N_tok if panel else n)
-            _lib.check(lib.mh_gemm_bias_act_ex(A.data_ptr(), lda, panel, W.data_ptr(), ldw, panel, bias.data_ptr(),
-                                               R.data_ptr() if res else None, N_tok if panel else n, panel, O.data_ptr(), ldo,
-                                               0 if f32 else panel, int(f32), N_tok, n, k, act, code, st()))
+        for _ in range(nl):
+            _lib.check(lib.mh_gemm_bias_act_ex(A.data_ptr(), N_tok if panel else H, panel, W.data_ptr(), F if panel else H, panel,
+                                               bias.data_ptr(), None, 0, 0, O.data_ptr(), N_tok if panel else F, panel, 0,
+                                               N_tok, F, H, 2, code, st()))
     one_pass()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -119,9 +95,19 @@ def time_dominant_kernel(c, dtype, device, reps):
         one_pass()
     e1.record()
     torch.cuda.synchronize()
-    avg_ms = e0.elapsed_time(e1) / (reps * len(launches))
-    flops_per_launch = sum(2.0 * N_tok * n * k for (n, k, _, _, _) in launches) / len(launches)
-    return avg_ms, flops_per_launch, len(launches)
+    avg_ms = e0.elapsed_time(e1) / (reps * nl)
+    return avg_ms, 2.0 * N_tok * F * H, nl
+
+
+def pmc_traffic(workload, dtype):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE doubled as
+    MI355X_MICROARCH.md prescribes for gfx950, + WRITE_SIZE); None when no pass was recorded for this workload."""
+    try:
+        with open(os.path.join(REPO, "profiles", "pmc_traffic.json")) as f:
+            rec = json.load(f).get("%s/%s" % (workload, dtype))
+        return None if rec is None else float(rec["traffic_bytes_per_launch"])
+    except (OSError, ValueError, KeyError):
+        return None
 
 
 def cpu_baseline(c, seconds_budget=25.0):
@@ -340,10 +326,12 @@ def main():
             avg_ms, fpl, nl = time_dominant_kernel(c, args.dtype, device, reps=5)
             ach = fpl / (avg_ms * 1e-3) / 1e12
             peak = MFMA_PEAK_TFLOPS[args.dtype]
-            kname = "gemm_big_kernel<EPI=0> bf16 256x128 tile" if args.dtype == "bf16" else "gemm_kernel<float,EPI=0>"
-            out["roofline"] = {"bound": "mfma", "kernel": "%s (%d launches/step)" % (kname, nl),
+            kname = ("gemm_big_kernel<EPI=0, ACT=gelu> bf16 big tile" if args.dtype == "bf16" else "gemm_kernel<float,EPI=0>")
+            out["roofline"] = {"bound": "mfma", "kernel": "%s: FFN intermediate dense [%d x %d x %d] (%d launches/step)"
+                                                          % (kname, c["B"] * c["L"], c["F"], c["H"], nl),
                                "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                               "traffic": None, "avg_launch_ms": round(avg_ms, 5), "flops_per_launch": fpl}
+                               "traffic": pmc_traffic(args.workload, args.dtype), "avg_launch_ms": round(avg_ms, 5),
+                               "flops_per_launch": fpl}
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(c)
             out["cpu_baseline"]["value"] = round(out["cpu_baseline"]["value"], 5)

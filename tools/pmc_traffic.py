@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Fold two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) over bench.py into per-kernel HBM bytes per launch.
+
+    rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_f -o p -- python3 bench.py ...
+    rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_w -o p -- python3 bench.py ...
+    python tools/pmc_traffic.py gpurun_out/pmc_f gpurun_out/pmc_w c2/bf16 > gpurun_out/pmc_traffic_summary.txt
+
+FETCH_SIZE / WRITE_SIZE are reported in KiB; on gfx950 FETCH_SIZE counts wide streaming reads at half their bytes
+(MI355X_MICROARCH.md, HBM), so it is doubled.  Writes gpurun_out/pmc_traffic.json for bench.py's `roofline.traffic`.
+"""
+import collections
+import csv
+import glob
+import json
+import sys
+
+
+def per_kernel(d, counter):
+    f = glob.glob(d + "/*counter_collection.csv")[0]
+    acc = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] == counter:
+            acc[(r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", ""), r["Grid_Size"])].append(float(r["Counter_Value"]))
+    return {k: (sum(v) / len(v), len(v)) for k, v in acc.items()}
+
+
+fetch, write = per_kernel(sys.argv[1], "FETCH_SIZE"), per_kernel(sys.argv[2], "WRITE_SIZE")
+key = sys.argv[3]
+rows = []
+for k in fetch:
+    fk, n = fetch[k]
+    wk = write.get(k, (0.0, 0))[0]
+    rows.append((n * (2 * fk + wk), k, n, fk, wk))
+rows.sort(reverse=True)
+print("%-78s %8s %6s %12s %12s %14s" % ("kernel", "grid", "n", "FETCH KiB", "WRITE KiB", "HBM MB/launch"))
+for tot, k, n, fk, wk in rows[:14]:
+    print("%-78s %8s %6d %12.1f %12.1f %14.2f" % (k[0][:78], k[1], n, fk, wk, (2 * fk + wk) * 1024 / 1e6))
+dom = [r for r in rows if "gemm_big_kernel" in r[1][0] and ", 0, 2, 0>" in r[1][0]]
+if dom:
+    tot, k, n, fk, wk = dom[0]
+    rec = {key: {"kernel": k[0], "launches_sampled": n, "fetch_kib": fk, "write_kib": wk,
+                 "traffic_bytes_per_launch": (2 * fk + wk) * 1024,
+                 "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; FETCH_SIZE doubled (gfx950)"}}
+    json.dump(rec, open("gpurun_out/pmc_traffic.json", "w"), indent=1)
+    print("dominant (FFN intermediate dense): %.1f MB per launch" % (rec[key]["traffic_bytes_per_launch"] / 1e6))
