@@ -357,6 +357,7 @@ template <int BM_, int BN_, int WM_, int WN_, int NST_, bool PP_ = false>
 struct BigCfg {
   static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, NST = NST_;
   static constexpr bool PP = PP_;   // ping-pong main loop (two wave groups half a K-step apart)
+  static constexpr int PRO = PP_ ? NST_ - 1 : NST_;   // stages a main loop has in flight before its first K-step
   static constexpr int NW = WM * WN, THREADS = NW * 64;
   static constexpr int TI = BM / WM / 16, TJ = BN / WN / 16;
   static constexpr int STAGE = (BM + BN) * 64;
@@ -368,6 +369,23 @@ using CfgWide = BigCfg<256, 256, 2, 4, 4>;
 using CfgRow = BigCfg<128, 512, 2, 4, 3>;
 using CfgWidePP = BigCfg<256, 256, 2, 4, 4, true>;
 constexpr int B2K = 32;
+
+// one DMA stage (K-step kt) of a tile into ring slot kt % NST: PA + PW 1-KiB pieces per wave
+template <class C, int DBG>
+__device__ __forceinline__ void issue_stage(const char* smem, const char* const (&srcA)[C::PA], const char* const (&srcW)[C::PW],
+                                            const int (&ldsA)[C::PA], const int (&ldsW)[C::PW], int kt, int64_t kstepA,
+                                            int64_t kstepW) {
+  if constexpr ((DBG & 1) != 0) return;
+  char* base = const_cast<char*>(smem) + (kt % C::NST) * C::STAGE;
+#pragma unroll
+  for (int j = 0; j < C::PA; ++j)
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcA[j] + kt * kstepA),
+                                     (__attribute__((address_space(3))) void*)(base + ldsA[j]), 16, 0, 0);
+#pragma unroll
+  for (int j = 0; j < C::PW; ++j)
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcW[j] + kt * kstepW),
+                                     (__attribute__((address_space(3))) void*)(base + C::BM * 64 + ldsW[j]), 16, 0, 0);
+}
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 // wait until all but the youngest `stages` DMA stages (PIECES loads each) of this wave have landed
@@ -387,23 +405,12 @@ template <class C, bool SWAP, int DBG>
 __device__ __forceinline__ void big_mainloop(f32x4 (&acc)[C::TI][C::TJ], const char* smem, const char* const (&srcA)[C::PA],
                                              const char* const (&srcW)[C::PW], const int (&ldsA)[C::PA], const int (&ldsW)[C::PW],
                                              int nk, int a_off, const int (&b_offs)[C::TJ], int64_t kstepA, int64_t kstepW,
-                                             unsigned* prof = nullptr) {
+                                             bool pre, unsigned* prof = nullptr) {
   constexpr int TI = C::TI, TJ = C::TJ;
   // DBG bit 4 (tools/gemm_bench.py --dbg 28): per-wave shader-clock totals of the three phases of a K-step
   unsigned long long pt_wait = 0, pt_bar = 0, pt_work = 0, pt0 = 0, pt1 = 0;
   auto tick = [&]() -> unsigned long long { if constexpr ((DBG & 16) != 0) return __builtin_amdgcn_s_memtime(); else return 0ull; };
-  auto issue = [&](int kt) {
-    if constexpr ((DBG & 1) != 0) return;
-    char* base = const_cast<char*>(smem) + (kt % C::NST) * C::STAGE;
-#pragma unroll
-    for (int j = 0; j < C::PA; ++j)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcA[j] + kt * kstepA),
-                                       (__attribute__((address_space(3))) void*)(base + ldsA[j]), 16, 0, 0);
-#pragma unroll
-    for (int j = 0; j < C::PW; ++j)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcW[j] + kt * kstepW),
-                                       (__attribute__((address_space(3))) void*)(base + C::BM * 64 + ldsW[j]), 16, 0, 0);
-  };
+  auto issue = [&](int kt) { issue_stage<C, DBG>(smem, srcA, srcW, ldsA, ldsW, kt, kstepA, kstepW); };
   auto read_frag = [&](const char* p) -> bf16x8 {
     if constexpr ((DBG & 8) != 0) { bf16x8 v; asm volatile("" : "=v"(v)); return v; }   // ablation: no LDS reads
     else return *reinterpret_cast<const bf16x8*>(p);
@@ -411,8 +418,12 @@ __device__ __forceinline__ void big_mainloop(f32x4 (&acc)[C::TI][C::TJ], const c
   unsigned long long pc0 = 0, pr0 = 0;
   if constexpr ((DBG & 16) != 0) { pc0 = __builtin_amdgcn_s_memtime(); pr0 = __builtin_amdgcn_s_memrealtime(); }
   const int npro = nk < C::NST ? nk : C::NST;
-  for (int st = 0; st < npro; ++st) issue(st);
-  wait_stages<C::PIECES>(npro - 1);
+  if (pre) {   // the stages were issued before the previous tile's epilogue, whose stores share the counter: drain all
+    wait_vmcnt<0>();
+  } else {
+    for (int st = 0; st < npro; ++st) issue(st);
+    wait_stages<C::PIECES>(npro - 1);
+  }
   __builtin_amdgcn_s_barrier();
   bf16x8 a[TI], b[TJ], bn[TJ];
 #pragma unroll
@@ -485,28 +496,21 @@ template <class C, bool SWAP, int DBG>
 __device__ __forceinline__ void pp_mainloop(f32x4 (&acc)[C::TI][C::TJ], const char* smem, const char* const (&srcA)[C::PA],
                                             const char* const (&srcW)[C::PW], const int (&ldsA)[C::PA], const int (&ldsW)[C::PW],
                                             int nk, int a_off, const int (&b_offs)[C::TJ], int64_t kstepA, int64_t kstepW,
-                                            int group) {
+                                            int group, bool pre) {
   constexpr int TI = C::TI, TJ = C::TJ, D = C::NST - 1;
   static_assert(C::WM == 2, "ping-pong needs exactly two wave rows");
-  auto issue = [&](int kt) {
-    if constexpr ((DBG & 1) != 0) return;
-    char* base = const_cast<char*>(smem) + (kt % C::NST) * C::STAGE;
-#pragma unroll
-    for (int j = 0; j < C::PA; ++j)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcA[j] + kt * kstepA),
-                                       (__attribute__((address_space(3))) void*)(base + ldsA[j]), 16, 0, 0);
-#pragma unroll
-    for (int j = 0; j < C::PW; ++j)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcW[j] + kt * kstepW),
-                                       (__attribute__((address_space(3))) void*)(base + C::BM * 64 + ldsW[j]), 16, 0, 0);
-  };
+  auto issue = [&](int kt) { issue_stage<C, DBG>(smem, srcA, srcW, ldsA, ldsW, kt, kstepA, kstepW); };
   auto read_frag = [&](const char* p) -> bf16x8 {
     if constexpr ((DBG & 8) != 0) { bf16x8 v; asm volatile("" : "=v"(v)); return v; }
     else return *reinterpret_cast<const bf16x8*>(p);
   };
   const int npro = nk < D ? nk : D;
-  for (int st = 0; st < npro; ++st) issue(st);
-  wait_stages<C::PIECES>(npro - 1);
+  if (pre) {
+    wait_vmcnt<0>();
+  } else {
+    for (int st = 0; st < npro; ++st) issue(st);
+    wait_stages<C::PIECES>(npro - 1);
+  }
   __builtin_amdgcn_s_barrier();
   if (group == 1) __builtin_amdgcn_s_barrier();
   bf16x8 a[TI], b[TJ];
@@ -550,15 +554,17 @@ template <class C, bool SWAP, int DBG>
 __device__ __forceinline__ void run_mainloop(f32x4 (&acc)[C::TI][C::TJ], const char* smem, const char* const (&srcA)[C::PA],
                                              const char* const (&srcW)[C::PW], const int (&ldsA)[C::PA], const int (&ldsW)[C::PW],
                                              int nk, int a_off, const int (&b_offs)[C::TJ], int64_t kstepA, int64_t kstepW,
-                                             int group, unsigned* prof = nullptr) {
-  if constexpr (C::PP) pp_mainloop<C, SWAP, DBG>(acc, smem, srcA, srcW, ldsA, ldsW, nk, a_off, b_offs, kstepA, kstepW, group);
-  else big_mainloop<C, SWAP, DBG>(acc, smem, srcA, srcW, ldsA, ldsW, nk, a_off, b_offs, kstepA, kstepW, prof);
+                                             int group, bool pre, unsigned* prof = nullptr) {
+  if constexpr (C::PP) pp_mainloop<C, SWAP, DBG>(acc, smem, srcA, srcW, ldsA, ldsW, nk, a_off, b_offs, kstepA, kstepW, group, pre);
+  else big_mainloop<C, SWAP, DBG>(acc, smem, srcA, srcW, ldsA, ldsW, nk, a_off, b_offs, kstepA, kstepW, pre, prof);
 }
 
 // EPI: 0 generic (bias / act / residual), 1 QKV head scatter, 3 bias + residual + LayerNorm over complete rows
 template <class C, int EPI, int ACT, int DBG = 0>
 __global__ __launch_bounds__(C::THREADS, C::STAGE * C::NST <= 80 * 1024 ? 2 : 1) void gemm_big_kernel(const GemmArgs g) {
-  __shared__ __attribute__((aligned(16))) char smem[C::NST * C::STAGE];
+  // LDS: the DMA ring, then (EPI 3) the row-statistics exchange - kept apart so that the next tile's first
+  // stages can already be landing in the ring while this tile's epilogue runs
+  __shared__ __attribute__((aligned(16))) char smem[C::NST * C::STAGE + (EPI == 3 ? C::BM * C::WN * 4 : 0)];
   constexpr int TI = C::TI, TJ = C::TJ;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -571,15 +577,6 @@ __global__ __launch_bounds__(C::THREADS, C::STAGE * C::NST <= 80 * 1024 ? 2 : 1)
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)g.stagger) __builtin_amdgcn_s_sleep(16);
   }
-  for (int vt = blockIdx.x; vt < g.ntiles; vt += gridDim.x) {
-  if (vt != (int)blockIdx.x) {   // the ring is reused: every wave must be done reading the previous tile's last stage
-    __builtin_amdgcn_s_waitcnt(0xC07F);
-    __builtin_amdgcn_s_barrier();
-  }
-  const int bid = xcd_remap(vt, g.ntiles);
-  const int64_t m0 = (int64_t)(bid / tiles_n) * C::BM;
-  const int n0 = (bid % tiles_n) * C::BN;
-
   // DMA coordinates: one piece covers 16 rows x 64 B; lane i lands at row i/4, physical chunk i%4.
   // row-major operand: rows ld elements apart, a K-step advances 32 elements; K32-panel operand
   // ([K/32][ld rows][32]): rows 32 elements apart, a K-step advances one whole panel (ld * 32)
@@ -588,24 +585,57 @@ __global__ __launch_bounds__(C::THREADS, C::STAGE * C::NST <= 80 * 1024 ? 2 : 1)
   int ldsA[C::PA], ldsW[C::PW];
   const int64_t a_row = g.a_panel ? 32 : g.lda, w_row = g.w_panel ? 32 : g.ldw;
   const int64_t kstepA = g.a_panel ? g.lda * 64 : 64, kstepW = g.w_panel ? g.ldw * 64 : 64;
-  {
+#pragma unroll
+  for (int j = 0; j < C::PA; ++j) ldsA[j] = (wave * C::PA + j) * 16 * 64;
+#pragma unroll
+  for (int j = 0; j < C::PW; ++j) ldsW[j] = (wave * C::PW + j) * 16 * 64;
+  auto set_sources = [&](int tile) {
+    const int b2 = xcd_remap(tile, g.ntiles);
+    const int64_t tm0 = (int64_t)(b2 / tiles_n) * C::BM;
+    const int tn0 = (b2 % tiles_n) * C::BN;
     const int rl = lane >> 2, pc = lane & 3;
     const int lc = pc ^ GSW[(rl >> 2) & 3];          // logical chunk stored at this physical slot
 #pragma unroll
     for (int j = 0; j < C::PA; ++j) {
-      const int r16 = (wave * C::PA + j) * 16;
-      int64_t ra = m0 + r16 + rl; if (ra >= g.M) ra = g.M - 1;
+      int64_t ra = tm0 + (wave * C::PA + j) * 16 + rl; if (ra >= g.M) ra = g.M - 1;
       srcA[j] = reinterpret_cast<const char*>(g.A) + ((int64_t)blockIdx.y * g.sA + ra * a_row + lc * 8) * 2;
-      ldsA[j] = r16 * 64;
     }
 #pragma unroll
     for (int j = 0; j < C::PW; ++j) {
-      const int r16 = (wave * C::PW + j) * 16;
-      int rw = n0 + r16 + rl; if (rw >= g.N) rw = g.N - 1;
+      int rw = tn0 + (wave * C::PW + j) * 16 + rl; if (rw >= g.N) rw = g.N - 1;
       srcW[j] = reinterpret_cast<const char*>(g.W) + ((int64_t)blockIdx.y * g.sW + (int64_t)rw * w_row + lc * 8) * 2;
-      ldsW[j] = r16 * 64;
     }
+  };
+  bool pre = false;   // this tile's first stages were issued before the previous tile's epilogue
+  // persistent: after a tile's main loop the ring is idle, so the next tile's first stages are put in flight
+  // BEFORE the epilogue: their latency (an HBM miss for the A rows) hides behind the stores
+  auto prefetch_next = [&](int vt) {
+    const int vn = vt + (int)gridDim.x;
+    pre = false;
+    if constexpr (EPI == 3) return;   // the row-statistics epilogue has no registers to spare for the carried pointers
+    if (g.dbg & 32) return;           // A/B: no prefetch across the epilogue
+    if (vn < g.ntiles) {
+      set_sources(vn);
+      if constexpr (!C::PP) {   // (the ping-pong loop ends on a barrier that every fragment read precedes)
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_s_barrier();
+      }
+      const int npro = nk < C::PRO ? nk : C::PRO;
+      for (int st = 0; st < npro; ++st) issue_stage<C, DBG>(smem, srcA, srcW, ldsA, ldsW, st, kstepA, kstepW);
+      pre = true;
+    }
+  };
+  for (int vt = blockIdx.x; vt < g.ntiles; vt += gridDim.x) {
+  if (!pre) {
+    if (vt != (int)blockIdx.x) {   // the ring is reused: every wave must be done reading the previous tile's last stage
+      __builtin_amdgcn_s_waitcnt(0xC07F);
+      __builtin_amdgcn_s_barrier();
+    }
+    set_sources(vt);
   }
+  const int bid = xcd_remap(vt, g.ntiles);
+  const int64_t m0 = (int64_t)(bid / tiles_n) * C::BM;
+  const int n0 = (bid % tiles_n) * C::BN;
   const int frag_off = fr * 64 + ((fg ^ GSW[(fr >> 2) & 3]) << 4);
   const int a_off = wm * (TI * 16 * 64) + frag_off;
   const int wcol0 = n0 + wn * (TJ * 16);
@@ -631,7 +661,8 @@ __global__ __launch_bounds__(C::THREADS, C::STAGE * C::NST <= 80 * 1024 ? 2 : 1)
     const int which = wcol0 / g.H;   // wave-uniform: 0 q, 1 k, 2 v
     const int M32 = (int)g.M, r0 = (int)wrow0;
     if (which == 2) {
-      run_mainloop<C, false, DBG>(acc, smem, srcA, srcW, ldsA, ldsW, nk, a_off, b_offs, kstepA, kstepW, wm);
+      run_mainloop<C, false, DBG>(acc, smem, srcA, srcW, ldsA, ldsW, nk, a_off, b_offs, kstepA, kstepW, wm, pre);
+      prefetch_next(vt);
       // acc[i][j][r] = D[m = 16i + 4fg + r][n = 16j + fr]: 4 consecutive tokens per lane -> V^T rows
       bf16* dst = reinterpret_cast<bf16*>(g.vt);
       float bv[TJ];
@@ -664,7 +695,8 @@ __global__ __launch_bounds__(C::THREADS, C::STAGE * C::NST <= 80 * 1024 ? 2 : 1)
         }
       }
     } else {
-      run_mainloop<C, true, DBG>(acc, smem, srcA, srcW, ldsA, ldsW, nk, a_off, b_offs, kstepA, kstepW, wm);
+      run_mainloop<C, true, DBG>(acc, smem, srcA, srcW, ldsA, ldsW, nk, a_off, b_offs, kstepA, kstepW, wm, pre);
+      prefetch_next(vt);
       bf16* dst = reinterpret_cast<bf16*>(which == 0 ? g.q : g.k);
 #pragma unroll
       for (int qh = 0; qh < TJ / 2; ++qh) {
@@ -689,8 +721,9 @@ __global__ __launch_bounds__(C::THREADS, C::STAGE * C::NST <= 80 * 1024 ? 2 : 1)
       }
     }
   } else {
-    run_mainloop<C, true, DBG>(acc, smem, srcA, srcW, ldsA, ldsW, nk, a_off, b_offs, kstepA, kstepW, wm,
+    run_mainloop<C, true, DBG>(acc, smem, srcA, srcW, ldsA, ldsW, nk, a_off, b_offs, kstepA, kstepW, wm, pre,
                                reinterpret_cast<unsigned*>(g.out) + 64 + ((int64_t)bid * C::NW + wave) * 8);
+    prefetch_next(vt);
     bf16* outT = reinterpret_cast<bf16*>(g.out) + (int64_t)blockIdx.y * g.sO;
     float* outF = reinterpret_cast<float*>(g.out) + (int64_t)blockIdx.y * g.sO;
     const bf16* res = g.residual ? reinterpret_cast<const bf16*>(g.residual) + (int64_t)blockIdx.y * g.sR : nullptr;
@@ -706,8 +739,7 @@ __global__ __launch_bounds__(C::THREADS, C::STAGE * C::NST <= 80 * 1024 ? 2 : 1)
     if constexpr (EPI == 3) {
       // ---- bias + residual, then LayerNorm over the complete row (the block owns all N columns): two-pass
       // statistics, in-lane -> across the 4 lanes of a row (xor 16, 32) -> across the WN waves through LDS
-      float* red = reinterpret_cast<float*>(smem);     // [BM][WN] floats, reused for both passes
-      __builtin_amdgcn_s_barrier();                      // every wave is done with the ring before it is reused
+      float* red = reinterpret_cast<float*>(smem + C::NST * C::STAGE);   // [BM][WN] floats, reused for both passes
       float rs[TI];
 #pragma unroll
       for (int i = 0; i < TI; ++i) rs[i] = 0.f;
@@ -855,7 +887,7 @@ int launch_big(const GemmArgs& g0, hipStream_t s, int batch) {
   } else if constexpr (EPI == 3) {
     MH_LAUNCH((gemm_big_kernel<C, 3, MH_ACT_NONE>), grid, block, 0, s, g);
   } else {
-    if (g.dbg) {   // timing-only ablations (tools/gemm_bench.py): 1 no DMA, 2 no MFMA, 4 no epilogue, 8 no LDS reads
+    if (g.dbg & 31) {   // timing-only ablations (tools/gemm_bench.py): 1 no DMA, 2 no MFMA, 4 no epilogue, 8 no LDS reads
       switch (g.dbg & 31) {
         case 1: MH_LAUNCH((gemm_big_kernel<C, 0, MH_ACT_NONE, 1>), grid, block, 0, s, g); break;
         case 2: MH_LAUNCH((gemm_big_kernel<C, 0, MH_ACT_NONE, 2>), grid, block, 0, s, g); break;
@@ -940,7 +972,7 @@ extern "C" int mh_gemm_set_stagger(int ticks) {
 }
 
 extern "C" int mh_gemm_set_debug(int bits) {
-  g_dbg = bits & 31;
+  g_dbg = bits & 63;
   return MH_OK;
 }
 
@@ -959,7 +991,7 @@ extern "C" int mh_gemm_bias_act(const void* A, int64_t lda, const void* W, int64
   GemmArgs g{};
   g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.bias = bias;
   g.residual = residual; g.ldr = residual ? ldr : 8; g.out = out; g.ldo = ldo; g.out_f32 = out_f32;
-  g.M = M; g.N = N; g.K = K; g.act = act; g.dbg = g_dbg & 31;
+  g.M = M; g.N = N; g.K = K; g.act = act; g.dbg = g_dbg & 63;
   return launch<0>(g, dtype, (hipStream_t)stream);
 }
 
@@ -975,7 +1007,7 @@ extern "C" int mh_gemm_bias_act_ex(const void* A, int64_t lda, int a_panel, cons
   GemmArgs g{};
   g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.bias = bias;
   g.residual = residual; g.ldr = residual ? ldr : 8; g.out = out; g.ldo = ldo; g.out_f32 = out_f32;
-  g.M = M; g.N = N; g.K = K; g.act = act; g.dbg = g_dbg & 31;
+  g.M = M; g.N = N; g.K = K; g.act = act; g.dbg = g_dbg & 63;
   g.a_panel = a_panel; g.w_panel = w_panel; g.o_panel = o_panel; g.r_panel = residual ? r_panel : 0;
   return launch<0>(g, dtype, (hipStream_t)stream);
 }
