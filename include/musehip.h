@@ -278,6 +278,9 @@ int mh_add_inplace(void* dst, const void* src, int64_t n, int dtype, mh_stream_t
 /* table[ids[n], :] += src[n, :]  (word_embedding gradient; fp32 atomics) */
 int mh_scatter_add_rows(const float* src, const int32_t* ids, float* table, int64_t n, int E, int V, mh_stream_t stream);
 /* q_sample backward: dst[b,i] (+)= src[b,i] * (mask[token] == 0 ? 1 : scale[b]) */
+/* out[i] = sum_s in[s * n + i] (fp32, n % 4 == 0): folds the split-K partials of a weight-gradient GEMM
+ * (mh_gemm_batched over K slices), summation order fixed -> reproducible gradients. */
+int mh_sum_slices(const float* in, int slices, int64_t n, float* out, mh_stream_t stream);
 int mh_scale_rows(const float* src, const float* scale, const int32_t* mask, float* dst, int accumulate, int B, int64_t per_batch,
                   int E, mh_stream_t stream);
 

@@ -108,6 +108,7 @@ SIGNATURES = {
     "mh_sqdiff_bwd": (INT, [VP, VP, F32, VP, VP, VP, INT, INT, I64, VP]),
     "mh_add_inplace": (INT, [VP, VP, I64, INT, VP]),
     "mh_scatter_add_rows": (INT, [VP, VP, VP, I64, INT, INT, VP]),
+    "mh_sum_slices": (INT, [VP, INT, I64, VP, VP]),
     "mh_scale_rows": (INT, [VP, VP, VP, VP, INT, INT, I64, INT, VP]),
     "mh_adamw_ema_step": (INT, [VP, VP, INT, C.POINTER(OptHParams), VP]),
     "mh_grad_norm": (INT, [VP, VP, INT, VP, VP, VP]),

@@ -94,9 +94,48 @@ __global__ void colsum_final_kernel(const float* __restrict__ part_all, int P, i
   float* out = out_all + (int64_t)blockIdx.y * cols;
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= cols) return;
-  float s = 0.f;
-  for (int p = 0; p < P; ++p) s += part[(int64_t)p * cols + c];
+  // eight independent partial sums keep eight loads in flight (a single dependent chain pays one memory
+  // latency per partial); the summation order is fixed, so the result is reproducible
+  float s8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  int p = 0;
+  for (; p + 8 <= P; p += 8) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s8[j] += part[(int64_t)(p + j) * cols + c];
+  }
+  for (; p < P; ++p) s8[0] += part[(int64_t)p * cols + c];
+  const float s = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
   out[c] = accumulate ? out[c] + s : s;
+}
+
+// 16-byte loads: a wave covers 8 x 64 = 512 consecutive columns of one row per instruction (cols % 8 == 0, ld % 8 == 0)
+template <typename T>
+__global__ void colsum8_partial_kernel(const T* __restrict__ in_all, int64_t ld, int64_t rows, int cols, float* __restrict__ part_all,
+                                       int64_t s_in) {
+  constexpr int V = 16 / sizeof(T);
+  const T* in = in_all + (int64_t)blockIdx.z * s_in;
+  float* part = part_all + (int64_t)blockIdx.z * gridDim.y * cols;
+  const int lane = threadIdx.x & 63, rl = threadIdx.x >> 6, P = gridDim.y;
+  const int c = (blockIdx.x * 64 + lane) * V;
+  __shared__ float red[4][64 * V];
+  float s[V];
+#pragma unroll
+  for (int j = 0; j < V; ++j) s[j] = 0.f;
+  if (c < cols)
+    for (int64_t r = (int64_t)blockIdx.y * 4 + rl; r < rows; r += (int64_t)P * 4) {
+      float v[V];
+      if constexpr (sizeof(T) == 2) load8(reinterpret_cast<const bf16*>(in) + r * ld + c, v);
+      else { const f32x4 t = *reinterpret_cast<const f32x4*>(in + r * ld + c); v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3]; }
+#pragma unroll
+      for (int j = 0; j < V; ++j) s[j] += v[j];
+    }
+#pragma unroll
+  for (int j = 0; j < V; ++j) red[rl][lane * V + j] = s[j];
+  __syncthreads();
+  if (rl == 0 && c < cols) {
+#pragma unroll
+    for (int j = 0; j < V; ++j)
+      part[(int64_t)blockIdx.y * cols + c + j] = (red[0][lane * V + j] + red[1][lane * V + j]) + (red[2][lane * V + j] + red[3][lane * V + j]);
+  }
 }
 
 // ------------------------------------------------------------------ activations
@@ -419,10 +458,17 @@ extern "C" int mh_col_sum(const void* in, int64_t ld, int64_t rows, int cols, in
                           int n_partial, float* out, int accumulate, int dtype, mh_stream_t stream) {
   MH_CHECK_ARG(in && partial && out && rows > 0 && cols > 0 && n_partial > 0 && n_partial <= 1024 && batch > 0 && batch <= 65535,
                "col_sum: bad arguments");
-  dim3 grid((cols + 63) / 64, n_partial, batch);
   hipStream_t s = (hipStream_t)stream;
-  MH_DTYPE_SWITCH(dtype, MH_LAUNCH((colsum_partial_kernel<bf16>), grid, dim3(256), 0, s, (const bf16*)in, ld, rows, cols, partial, stride_in),
-                  MH_LAUNCH((colsum_partial_kernel<float>), grid, dim3(256), 0, s, (const float*)in, ld, rows, cols, partial, stride_in), "col_sum");
+  const int vec = dtype == MH_BF16 ? 8 : 4;
+  if (cols % vec == 0 && ld % vec == 0 && stride_in % vec == 0) {
+    dim3 grid((cols / vec + 63) / 64, n_partial, batch);
+    MH_DTYPE_SWITCH(dtype, MH_LAUNCH((colsum8_partial_kernel<bf16>), grid, dim3(256), 0, s, (const bf16*)in, ld, rows, cols, partial, stride_in),
+                    MH_LAUNCH((colsum8_partial_kernel<float>), grid, dim3(256), 0, s, (const float*)in, ld, rows, cols, partial, stride_in), "col_sum");
+  } else {
+    dim3 grid((cols + 63) / 64, n_partial, batch);
+    MH_DTYPE_SWITCH(dtype, MH_LAUNCH((colsum_partial_kernel<bf16>), grid, dim3(256), 0, s, (const bf16*)in, ld, rows, cols, partial, stride_in),
+                    MH_LAUNCH((colsum_partial_kernel<float>), grid, dim3(256), 0, s, (const float*)in, ld, rows, cols, partial, stride_in), "col_sum");
+  }
   MH_CHECK_LAUNCH();
   MH_LAUNCH(colsum_final_kernel, dim3((cols + 255) / 256, batch), dim3(256), 0, s, partial, n_partial, cols, out, accumulate);
   MH_CHECK_LAUNCH();
@@ -554,6 +600,25 @@ extern "C" int mh_scale_rows(const float* src, const float* scale, const int32_t
   MH_CHECK_ARG(src && dst && B > 0 && per_batch > 0 && E > 0, "scale_rows: bad arguments");
   MH_LAUNCH(scale_rows_kernel, dim3(tgrid((int64_t)B * per_batch)), dim3(TB), 0, (hipStream_t)stream, src, scale, mask, dst,
             accumulate, B, per_batch, E);
+  MH_CHECK_LAUNCH();
+  return MH_OK;
+}
+
+// out[i] = sum over s of in[s * n + i]   (fp32; the split-K partials of a weight-gradient GEMM), fixed order
+__global__ void sum_slices_kernel(const float* __restrict__ in, int slices, int64_t n, float* __restrict__ out) {
+  for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += (int64_t)gridDim.x * blockDim.x * 4) {
+    f32x4 acc = *reinterpret_cast<const f32x4*>(in + i);
+    for (int s = 1; s < slices; ++s) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(in + (int64_t)s * n + i);
+      acc[0] += v[0]; acc[1] += v[1]; acc[2] += v[2]; acc[3] += v[3];
+    }
+    *reinterpret_cast<f32x4*>(out + i) = acc;
+  }
+}
+
+extern "C" int mh_sum_slices(const float* in, int slices, int64_t n, float* out, mh_stream_t stream) {
+  MH_CHECK_ARG(in && out && slices > 0 && n > 0 && n % 4 == 0, "sum_slices: bad arguments (n must be a multiple of 4)");
+  MH_LAUNCH(sum_slices_kernel, dim3(tgrid(n / 4)), dim3(TB), 0, (hipStream_t)stream, in, slices, n, out);
   MH_CHECK_LAUNCH();
   return MH_OK;
 }

@@ -21,14 +21,17 @@ from torch.autograd import Function
 from . import _lib, ops
 from ._lib import MH_BF16, MH_F32, check, current_stream, lib, ptr
 
-NPART = 64  # rows of the two-stage column-sum scratch
+NPART = 256  # rows of the two-stage column-sum scratch
 
 
 def _td(dt):
     return ops.TORCH_DTYPE[dt]
 
 
-def _zeros(rows, cols, dt, dev):
+def _zeros(rows, cols, dt, dev, valid_cols=None):
+    """[rows, cols] buffer whose padding columns (beyond valid_cols) must read as zero; no fill when there are none."""
+    if valid_cols is not None and valid_cols == cols:
+        return torch.empty(rows, cols, device=dev, dtype=_td(dt))
     return torch.zeros(rows, cols, device=dev, dtype=_td(dt))
 
 
@@ -36,11 +39,31 @@ def _gemm(A, W, bias, dt, N, K, out=None, out_f32=False, residual=None):
     return ops.gemm_bias_act(A, W, bias, residual, None, dt, out_f32=out_f32, N=N, K=K, out=out)
 
 
+def _gemm_dw(dT, xT, N, Kp, Mp, dt):
+    """dW [N, Kp] fp32 = dT [N, Mp] . xT [Kp, Mp]^T: the reduction runs over the Mp tokens while the output is tiny,
+    so the K range is cut into slices that run as the batch of one batched GEMM (enough tiles to fill the chip)
+    and the fp32 partials are summed in a fixed order."""
+    tiles = ((N + 255) // 256) * ((Kp + 127) // 128)
+    S = 1
+    while S < 64 and tiles * S < 512 and Mp % (2 * S * 64) == 0 and Mp // (2 * S) >= 512:
+        S *= 2
+    dW = torch.empty(N, Kp, device=dT.device, dtype=torch.float32)
+    if S == 1:
+        _gemm(dT, xT, None, dt, Kp, Mp, out=dW, out_f32=True)
+        return dW
+    Ks = Mp // S
+    part = torch.empty(S, N, Kp, device=dT.device, dtype=torch.float32)
+    check(lib().mh_gemm_batched(ptr(dT), Mp, Ks, ptr(xT), Mp, Ks, None, ptr(part), Kp, N * Kp, 1, S, N, Kp, Ks, dt, current_stream()),
+          "mh_gemm_batched")
+    check(lib().mh_sum_slices(ptr(part), S, N * Kp, ptr(dW), current_stream()), "mh_sum_slices")
+    return dW
+
+
 def _transpose(x, rows, cols, dt, ld_out=None, batch=1, stride_in=0, stride_out=0, ld_in=None):
     """[batch][rows, cols] (row pitch ld_in, default x.shape[-1]) -> [batch][cols, ld_out] zero-padded."""
     ld_out = ops.pad64(rows) if ld_out is None else ld_out
     ld_in = x.shape[-1] if ld_in is None else ld_in
-    out = torch.zeros(batch * cols, ld_out, device=x.device, dtype=x.dtype)
+    out = (torch.empty if ld_out == rows else torch.zeros)(batch * cols, ld_out, device=x.device, dtype=x.dtype)
     check(lib().mh_transpose(ptr(x), ld_in, stride_in, ptr(out), ld_out, stride_out or cols * ld_out, rows, cols, batch, dt,
                              current_stream()), "mh_transpose")
     return out
@@ -93,7 +116,7 @@ class _Linear(Function):
         N, K = W.shape
         Np = ops.pad64(N)
         Wc = ops.cast_pad(W.detach(), Kp, dt)                         # [N, Kp]
-        pre = _zeros(M, Np, dt, x.device)
+        pre = _zeros(M, Np, dt, x.device, N)
         _gemm(x, Wc, b.detach() if b is not None else None, dt, N, Kp, out=pre, residual=residual if act is None else None)
         if act is None:
             y = pre
@@ -119,14 +142,13 @@ class _Linear(Function):
         db = _col_sum(dpre, M, N, dt) if has_b else None
         # dX = dpre W : reduction over the N outputs
         WT = _transpose(Wc, N, Kp, dt, ld_out=Np)                      # [Kp, Np]
-        dx = _zeros(M, Kp, dt, x.device)
+        dx = _zeros(M, Kp, dt, x.device, Kp)
         _gemm(dpre, WT, None, dt, Kp, Np, out=dx)
         # dW = dpre^T X : reduction over the M rows
         Mp = ops.pad64(M)
         dT = _transpose(dpre, M, N, dt, ld_out=Mp)                      # [N, Mp]
         xT = _transpose(x, M, Kp, dt, ld_out=Mp)                        # [Kp, Mp]
-        dW = torch.empty(N, Kp, device=x.device, dtype=torch.float32)
-        _gemm(dT, xT, None, dt, Kp, Mp, out=dW, out_f32=True)
+        dW = _gemm_dw(dT, xT, N, Kp, Mp, dt)
         return dx, dW[:, :K].contiguous(), db, None, (dy if has_res else None), None
 
 
@@ -219,7 +241,7 @@ class _Attention(Function):
         check(L_.mh_head_permute(ptr(dctx), ptr(tmp), H, B, L, nh, dh, 2, dt, st), "mh_head_permute")
         dOT.view(BH, dh, Lp)[:, :, :L] = tmp.view(BH, dh, L)                                    # pad the reduction dim
         # P = softmax(q k^T * scale)   [BH, L, Lp]
-        P = torch.zeros(BH * L, Lp, device=dev, dtype=td)
+        P = (torch.empty if Lp == L else torch.zeros)(BH * L, Lp, device=dev, dtype=td)
         check(L_.mh_gemm_batched(ptr(q), dh, L * dh, ptr(k), dh, L * dh, None, ptr(P), Lp, L * Lp, 0, BH, L, L, dh, dt, st),
               "mh_gemm_batched")
         check(L_.mh_softmax_rows(ptr(P), BH * L, L, Lp, scale, dt, st), "mh_softmax_rows")
@@ -230,7 +252,7 @@ class _Attention(Function):
               "mh_gemm_batched")
         # dP = dO V^T : W = V [L(keys), dh]
         V = _transpose(vt, dh, L, dt, ld_out=dh, batch=BH, stride_in=dh * L, stride_out=L * dh, ld_in=L)
-        dP = torch.zeros(BH * L, Lp, device=dev, dtype=td)
+        dP = (torch.empty if Lp == L else torch.zeros)(BH * L, Lp, device=dev, dtype=td)
         check(L_.mh_gemm_batched(ptr(dO), dh, L * dh, ptr(V), dh, L * dh, None, ptr(dP), Lp, L * Lp, 0, BH, L, L, dh, dt, st),
               "mh_gemm_batched")
         check(L_.mh_softmax_bwd_rows(ptr(P), ptr(dP), BH * L, L, Lp, scale, dt, st), "mh_softmax_bwd_rows")   # dP := dS

@@ -258,3 +258,26 @@ def test_rng_modes():
         assert torch.equal(e1, e2) and n0.shape == x_gen.shape
     anchored = (mask3 == 0)
     assert torch.equal(a[anchored], x_start[anchored])
+
+
+def test_batch_split_branches_equal_single_stream():
+    """diffusion.batch_split runs the denoiser on batch slices as concurrent graph branches: same samples bit for bit"""
+    tag = "c1"
+    m, diff, model_emb, inp, c = build(tag)
+    B, L, E = c["B"], c["L"], c["E"]
+    x_start, mask3 = inp["x_start"].to(DEV), inp["mask3"].to(DEV)
+    x_gen = osa.start_latent_generation(inp["x_start"], inp["mask3"], inp["gen_noise0"]).to(DEV)
+    fn = partial(denoised_fn_round, model_emb.to(DEV), dist=None)
+    kw = dict(model=m, shape=(B, L, E), noise=x_gen, clip_denoised=True, denoised_fn=fn, model_kwargs={}, top_p=1,
+              clamp_step=0, clamp_first=True, mask=mask3, x_start=x_start, t_enc=6, only_last=True)
+    diff.noise_fn = None
+    diff.rng_mode, diff.rng_seed, diff.rng_stream = "philox", 11, 0
+    outs = {}
+    for split in (1, 2, 4):
+        for ug in (True, False):
+            diff.batch_split, diff.use_graph = split, ug
+            outs[(split, ug)] = diff.p_sample_loop(**kw)[0].clone()
+    diff.batch_split = 1
+    ref = outs[(1, True)]
+    for k, v in outs.items():
+        assert torch.equal(v, ref), "batch_split=%d graph=%s differs" % k
