@@ -134,6 +134,21 @@ int mh_attention_fwd_ex(const void* q, const void* k, const void* vt, void* ctx,
  * the encoder called at models/network.py:151. */
 int mh_attention_stream_fwd(const void* q, const void* k, const void* vt_perm, void* ctx, int64_t ld_ctx, int ctx_panel,
                             int B, int L, int nh, int dh, float scale, mh_stream_t stream);
+/* mh_attention_stream_fwd that also writes lse2 [B, nh, L] fp32 = log2-domain log-sum-exp of the scaled scores
+ * (P[q][k] = exp2(s[q][k] scale log2e - lse2[q])): what mh_attention_stream_bwd re-creates P from. */
+int mh_attention_stream_fwd_lse(const void* q, const void* k, const void* vt_perm, void* ctx, int64_t ld_ctx, int ctx_panel,
+                                int B, int L, int nh, int dh, float scale, float* lse2, mh_stream_t stream);
+/* Fused attention backward (bf16; same shape limits as the streaming forward).  q, k, v, dO: [B, nh, L, dh] rows;
+ * qT_perm, kT_perm, dOT_perm: [B, nh, dh, L] with the positions of every group of 16 permuted (mh_head_permute
+ * mode 3); lse2 from the forward; D[b, h, l] = sum_d dO o O (mh_attention_bwd_rowdot).  dq, dk, dv are written
+ * token-major: element (token, head, d) at ptr[token * ld_d + head * dh + d] - e.g. the three column blocks of a
+ * [B L, 3H] gradient of the fused QKV projection.  Replaces autograd through BertSelfAttention (the encoder that
+ * models/network.py:151 calls) inside training_losses (models/diffusion.py:594-699). */
+int mh_attention_stream_bwd(const void* q, const void* k, const void* v, const void* qT_perm, const void* kT_perm,
+                            const void* dO, const void* dOT_perm, const float* lse2, const float* D, void* dq, void* dk,
+                            void* dv, int64_t ld_d, int B, int L, int nh, int dh, float scale, mh_stream_t stream);
+int mh_attention_bwd_rowdot(const void* dctx, const void* ctx, int64_t ld, float* D, int B, int L, int nh, int dh,
+                            mh_stream_t stream);
 int mh_attention_stream_supported(int L, int dh);
 /* A/B switch read by mh_denoiser_forward's panel path: 1 (default) = use the streaming kernel when supported. */
 int mh_attention_set_stream(int on);
@@ -245,7 +260,8 @@ int mh_trunc_normal(float* out, int64_t n, float bound, uint64_t seed, uint32_t 
 /* out[b][c][r] = in[b][r][c] */
 int mh_transpose(const void* in, int64_t ld_in, int64_t stride_in, void* out, int64_t ld_out, int64_t stride_out, int rows,
                  int cols, int batch, int dtype, mh_stream_t stream);
-/* mode 0: tokens [B*L, ld_tok] -> heads [B,nh,L,dh]; 1: heads -> tokens; 2: tokens -> transposed heads [B,nh,dh,L] */
+/* mode 0: tokens [B*L, ld_tok] -> heads [B,nh,L,dh]; 1: heads -> tokens; 2: tokens -> transposed heads [B,nh,dh,L];
+ * 3: as 2 with the positions of every group of 16 stored as 0-3, 8-11, 4-7, 12-15 (streaming attention operand order) */
 int mh_head_permute(const void* in, void* out, int64_t ld_tok, int B, int L, int nh, int dh, int mode, int dtype,
                     mh_stream_t stream);
 /* out[b, c] (+)= sum_r in[b][r, c]  (bias / LayerNorm-parameter / position / time-embedding gradients);

@@ -555,7 +555,7 @@ template <int DH>
 __global__ __launch_bounds__(1024) void attn_stream_bf16_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K,
                                                                 const bf16* __restrict__ VT, bf16* __restrict__ ctx,
                                                                 int64_t ld_ctx, int L, int nh, int nbh, float scale_log2e,
-                                                                int ctx_panel) {
+                                                                int ctx_panel, float* __restrict__ lse2) {
   constexpr int NW = 16, SK = 256;                       // waves, keys per stage
   constexpr int CH = DH / 8, RPB = 128 / DH, KROWB = DH * 2;
   constexpr int KS = DH / 16, DT = DH / 32;
@@ -695,11 +695,14 @@ __global__ __launch_bounds__(1024) void attn_stream_bf16_kernel(const bf16* __re
           }
       }
       if (st == nst - 1) {   // last stage of this (batch, head): normalise and write the context rows
-        const float inv = 1.0f / (l_run + __shfl_xor(l_run, 32, 64));
+        const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+        const float inv = 1.0f / l_tot;
         const int qr = q0 + lq;
         if (qr < L) {
           const int b = bh / nh, head = bh % nh;
           const int64_t tok = (int64_t)b * L + qr;
+          // log2-domain log-sum-exp of the scaled scores: P[q][k] = exp2(s c - lse2[q]) (what the backward kernels re-create P from)
+          if (lse2 && h == 0) lse2[(int64_t)bh * L + qr] = m_run * scale_log2e + __builtin_amdgcn_logf(l_tot);
 #pragma unroll
           for (int dt = 0; dt < DT; ++dt) {
             bf16* dst = ctx_panel ? ctx + (((int64_t)(head * DT + dt)) * ld_ctx + tok) * 32 : ctx + tok * ld_ctx + head * DH + dt * 32;
@@ -779,8 +782,16 @@ extern "C" int mh_attention_stream_enabled(void) { return g_attn_stream; }
 
 extern "C" int mh_attention_stream_supported(int L, int dh) { return L >= 512 && L % 256 == 0 && (dh == 32 || dh == 64); }
 
+extern "C" int mh_attention_stream_fwd_lse(const void* q, const void* k, const void* vt_perm, void* ctx, int64_t ld_ctx, int ctx_panel,
+                                           int B, int L, int nh, int dh, float scale, float* lse2, mh_stream_t stream);
+
 extern "C" int mh_attention_stream_fwd(const void* q, const void* k, const void* vt_perm, void* ctx, int64_t ld_ctx, int ctx_panel,
                                        int B, int L, int nh, int dh, float scale, mh_stream_t stream) {
+  return mh_attention_stream_fwd_lse(q, k, vt_perm, ctx, ld_ctx, ctx_panel, B, L, nh, dh, scale, nullptr, stream);
+}
+
+extern "C" int mh_attention_stream_fwd_lse(const void* q, const void* k, const void* vt_perm, void* ctx, int64_t ld_ctx, int ctx_panel,
+                                           int B, int L, int nh, int dh, float scale, float* lse2, mh_stream_t stream) {
   MH_CHECK_ARG(q && k && vt_perm && ctx, "attention_stream: null pointer");
   MH_CHECK_ARG(B > 0 && nh > 0 && mh_attention_stream_supported(L, dh),
                "attention_stream: needs seq_len %% 256 == 0, seq_len >= 512 and head dim 32 or 64 (got L=%d dh=%d)", L, dh);
@@ -799,7 +810,7 @@ extern "C" int mh_attention_stream_fwd(const void* q, const void* k, const void*
       MH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_stream_bf16_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
       attr_set = true;
     }
-    MH_LAUNCH((attn_stream_bf16_kernel<64>), grid, block, bytes, s, Q, K, V, (bf16*)ctx, ld_ctx, L, nh, nbh, sl2, ctx_panel);
+    MH_LAUNCH((attn_stream_bf16_kernel<64>), grid, block, bytes, s, Q, K, V, (bf16*)ctx, ld_ctx, L, nh, nbh, sl2, ctx_panel, lse2);
   } else {
     constexpr int bytes = 4 * 256 * 32 * 2;
     static bool attr_set = false;
@@ -807,7 +818,7 @@ extern "C" int mh_attention_stream_fwd(const void* q, const void* k, const void*
       MH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_stream_bf16_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
       attr_set = true;
     }
-    MH_LAUNCH((attn_stream_bf16_kernel<32>), grid, block, bytes, s, Q, K, V, (bf16*)ctx, ld_ctx, L, nh, nbh, sl2, ctx_panel);
+    MH_LAUNCH((attn_stream_bf16_kernel<32>), grid, block, bytes, s, Q, K, V, (bf16*)ctx, ld_ctx, L, nh, nbh, sl2, ctx_panel, lse2);
   }
   MH_CHECK_LAUNCH();
   return MH_OK;

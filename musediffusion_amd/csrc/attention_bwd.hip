@@ -1,0 +1,372 @@
+// Fused attention backward (bf16 MFMA, gfx950) for training_losses (models/diffusion.py:594-699 -> HF
+// BertSelfAttention backward).  Two streaming kernels in the mould of attn_stream_bf16_kernel (attention.hip):
+// persistent 8-wave blocks, operands copied into LDS by LDS-DMA in 128-row stages, double-buffered, the score
+// matrix never leaves registers.  P is re-created from the forward's log-sum-exp: P[q][k] = exp2(s c - lse2[q]).
+//
+//   attn_bwd_dq_kernel   (one 32-query tile per wave, keys streamed):
+//       S^T = K Q^T,  dP^T = V dO^T,  dS^T = P^T o (dP^T - D[q]),  dQ^T += K^T dS^T
+//   attn_bwd_dkv_kernel  (one 32-key tile per wave, queries streamed):
+//       S = Q K^T,  dP = dO V^T,  dS = P o (dP - D[q]),  dV^T += dO^T P,  dK^T += Q^T dS
+//
+// with D[q] = sum_d dO[q][d] O[q][d].  Every product is a v_mfma_f32_32x32x16_bf16 whose B operand is either a
+// register-resident fragment of the wave's own tile or the previous product's accumulator converted to bf16 in
+// place (its register order is the "P-operand" key order, which is why the transposed operands K^T, Q^T, dO^T
+// arrive with the keys of every group of 16 stored as 0-3, 8-11, 4-7, 12-15: mh_head_permute mode 3).
+// Recomputing S in both kernels costs 2 extra products but needs neither atomics nor an [L, L] tensor in HBM.
+#include "common.h"
+
+namespace {
+
+constexpr int SKB = 128;   // rows (keys or queries) per LDS stage
+
+__device__ __forceinline__ void glds16(const void* g, void* l) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+
+// piece p (1 KiB) of a row-layout operand stage: rows [row][DH] bf16, 16-B chunk c of row r stored at c ^ ((r / RPB) & (CH-1))
+template <int DH>
+__device__ __forceinline__ void dma_rows(const bf16* src, char* dst, int p, int lane) {
+  constexpr int CH = DH / 8, RPB = 128 / DH, KROWB = DH * 2, KRP = 1024 / KROWB;
+  const int row = p * KRP + lane / CH, pc = lane % CH;
+  const int lc = pc ^ ((row / RPB) & (CH - 1));
+  glds16(src + (int64_t)row * DH + lc * 8, dst + p * 1024);
+}
+// piece p of a transposed operand stage: global [DH][L] (key order permuted per 16), LDS = 64-column tiles of [DH][128 B],
+// chunk c of row d stored at c ^ ((d >> 1) & 7)
+template <int DH>
+__device__ __forceinline__ void dma_cols(const bf16* src, int64_t L, char* dst, int p, int lane) {
+  const int t = p / (DH / 8), d = (p % (DH / 8)) * 8 + (lane >> 3), pc = lane & 7;
+  const int lc = pc ^ ((d >> 1) & 7);
+  glds16(src + (int64_t)d * L + t * 64 + lc * 8, dst + p * 1024);
+}
+// A-operand fragment (32 rows x 16 k) of a row-layout stage: stage-relative row R, k-step ks, lane half h
+template <int DH>
+__device__ __forceinline__ bf16x8 frag_rows(const char* stage, int R, int ks, int h) {
+  constexpr int CH = DH / 8, RPB = 128 / DH, KROWB = DH * 2;
+  return *reinterpret_cast<const bf16x8*>(stage + R * KROWB + (((2 * ks + h) ^ ((R / RPB) & (CH - 1))) << 4));
+}
+// A-operand fragment (32 d rows x 16 columns) of a transposed stage: 64-column tile t, 16-column slab sl (0..3), row d
+template <int DH>
+__device__ __forceinline__ bf16x8 frag_cols(const char* stage, int t, int sl, int d, int h) {
+  return *reinterpret_cast<const bf16x8*>(stage + t * (DH * 128) + d * 128 + (((2 * sl + h) ^ ((d >> 1) & 7)) << 4));
+}
+
+__device__ __forceinline__ bf16x8 cvt8(const f32x16& v, int off) {
+  bf16x8 r;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) r[j] = (bf16)v[off + j];
+  return r;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+template <int DH>
+__global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K,
+                                                          const bf16* __restrict__ V, const bf16* __restrict__ KT,
+                                                          const bf16* __restrict__ dO, const float* __restrict__ lse2,
+                                                          const float* __restrict__ Dv, bf16* __restrict__ dQ, int64_t ld_dq,
+                                                          int L, int nh, int nbh, float scale, float scale_log2e) {
+  constexpr int NW = 8;
+  constexpr int KS = DH / 16, DT = DH / 32;
+  constexpr int ST = SKB * DH * 2;                 // bytes of one operand stage (row layout and transposed alike)
+  constexpr int PK = ST / 1024 / NW;               // DMA pieces per wave per operand per stage
+  extern __shared__ __attribute__((aligned(16))) char smem_dyn[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = lane >> 5, lq = lane & 31;
+  const int nqb = L / 256, nst = L / SKB;
+  const int nitems = nbh * nqb;
+  const int my_items = (nitems - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int total = my_items * nst;
+
+  auto issue = [&](int g) {
+    const int item = blockIdx.x + (g / nst) * gridDim.x, st = g % nst;
+    const int bh = item / nqb;
+    const bf16* Kb = K + ((int64_t)bh * L + (int64_t)st * SKB) * DH;
+    const bf16* Vb = V + ((int64_t)bh * L + (int64_t)st * SKB) * DH;
+    const bf16* Tb = KT + (int64_t)bh * DH * L + (int64_t)st * SKB;
+    char* base = smem_dyn + (g & 1) * (3 * ST);
+#pragma unroll
+    for (int j = 0; j < PK; ++j) dma_rows<DH>(Kb, base, wave + NW * j, lane);
+#pragma unroll
+    for (int j = 0; j < PK; ++j) dma_rows<DH>(Vb, base + ST, wave + NW * j, lane);
+#pragma unroll
+    for (int j = 0; j < PK; ++j) dma_cols<DH>(Tb, L, base + 2 * ST, wave + NW * j, lane);
+  };
+
+  bf16x8 qf[KS], dof[KS];
+  f32x16 dq[DT];
+  float lse_q = 0.f, D_q = 0.f;
+  int q0 = 0;
+  if (total > 0) issue(0);
+  for (int g = 0; g < total; ++g) {
+    const int item = blockIdx.x + (g / nst) * gridDim.x, st = g % nst;
+    const int bh = item / nqb, qb = item % nqb;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (g + 1 < total) issue(g + 1);
+    if (st == 0) {
+      q0 = qb * 256 + wave * 32;
+      const int64_t qrow = (int64_t)bh * L + q0 + lq;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        qf[ks] = *reinterpret_cast<const bf16x8*>(Q + qrow * DH + 16 * ks + 8 * h);
+        dof[ks] = *reinterpret_cast<const bf16x8*>(dO + qrow * DH + 16 * ks + 8 * h);
+      }
+      lse_q = lse2[qrow];
+      D_q = Dv[qrow];
+#pragma unroll
+      for (int i = 0; i < DT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dq[i][r] = 0.f;
+    }
+    const char* kst = smem_dyn + (g & 1) * (3 * ST);
+    const char* vst = kst + ST;
+    const char* tst = kst + 2 * ST;
+    for (int t = 0; t < SKB / 64; ++t) {
+      f32x16 s[2], dp[2];
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt) {
+        const int R = t * 64 + 32 * kt + lq;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[kt][r] = 0.f; dp[kt][r] = 0.f; }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<DH>(kst, R, ks, h), qf[ks], s[kt], 0, 0, 0);
+          dp[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<DH>(vst, R, ks, h), dof[ks], dp[kt], 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float p = __builtin_amdgcn_exp2f(s[kt][r] * scale_log2e - lse_q);
+          s[kt][r] = p * (dp[kt][r] - D_q);                      // dS^T (the 1/sqrt(dh) factor is applied to dQ at the end)
+        }
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const bf16x8 dsf = cvt8(s[kt], 8 * s2);
+#pragma unroll
+          for (int dt = 0; dt < DT; ++dt)
+            dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols<DH>(tst, t, 2 * kt + s2, dt * 32 + lq, h), dsf, dq[dt], 0, 0, 0);
+        }
+    }
+    if (st == nst - 1) {
+      const int b = bh / nh, head = bh % nh;
+      const int64_t tok = (int64_t)b * L + q0 + lq;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        bf16* dst = dQ + tok * ld_dq + head * DH + dt * 32;
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          bf16x4 v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = (bf16)(dq[dt][rg * 4 + e] * scale);
+          *reinterpret_cast<bf16x4*>(dst + 8 * rg + 4 * h) = v;
+        }
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+template <int DH>
+__global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K,
+                                                           const bf16* __restrict__ V, const bf16* __restrict__ QT,
+                                                           const bf16* __restrict__ dO, const bf16* __restrict__ dOT,
+                                                           const float* __restrict__ lse2, const float* __restrict__ Dv,
+                                                           bf16* __restrict__ dK, bf16* __restrict__ dV, int64_t ld_d, int L,
+                                                           int nh, int nbh, float scale, float scale_log2e) {
+  constexpr int NW = 8;
+  constexpr int KS = DH / 16, DT = DH / 32;
+  constexpr int ST = SKB * DH * 2;
+  constexpr int PK = ST / 1024 / NW;
+  constexpr int BUF = 4 * ST + 1024;                // Q rows, dO rows, Q^T, dO^T, (lse2 | D) of the stage's 128 queries
+  extern __shared__ __attribute__((aligned(16))) char smem_dyn[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = lane >> 5, lq = lane & 31;
+  const int nkb = L / 256, nst = L / SKB;
+  const int nitems = nbh * nkb;
+  const int my_items = (nitems - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int total = my_items * nst;
+
+  auto issue = [&](int g) {
+    const int item = blockIdx.x + (g / nst) * gridDim.x, st = g % nst;
+    const int bh = item / nkb;
+    const int64_t r0 = (int64_t)bh * L + (int64_t)st * SKB;
+    const int64_t c0 = (int64_t)bh * DH * L + (int64_t)st * SKB;
+    char* base = smem_dyn + (g & 1) * BUF;
+#pragma unroll
+    for (int j = 0; j < PK; ++j) dma_rows<DH>(Q + r0 * DH, base, wave + NW * j, lane);
+#pragma unroll
+    for (int j = 0; j < PK; ++j) dma_rows<DH>(dO + r0 * DH, base + ST, wave + NW * j, lane);
+#pragma unroll
+    for (int j = 0; j < PK; ++j) dma_cols<DH>(QT + c0, L, base + 2 * ST, wave + NW * j, lane);
+#pragma unroll
+    for (int j = 0; j < PK; ++j) dma_cols<DH>(dOT + c0, L, base + 3 * ST, wave + NW * j, lane);
+    if (wave == 0)   // lanes 0-31: lse2 of the 128 queries, lanes 32-63: D
+      glds16((lane < 32 ? lse2 + r0 + 4 * lane : Dv + r0 + 4 * (lane - 32)), base + 4 * ST);
+  };
+
+  bf16x8 kf[KS], vf[KS];
+  f32x16 dk[DT], dv[DT];
+  int k0 = 0;
+  if (total > 0) issue(0);
+  for (int g = 0; g < total; ++g) {
+    const int item = blockIdx.x + (g / nst) * gridDim.x, st = g % nst;
+    const int bh = item / nkb, kb = item % nkb;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (g + 1 < total) issue(g + 1);
+    if (st == 0) {
+      k0 = kb * 256 + wave * 32;
+      const int64_t krow = (int64_t)bh * L + k0 + lq;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        kf[ks] = *reinterpret_cast<const bf16x8*>(K + krow * DH + 16 * ks + 8 * h);
+        vf[ks] = *reinterpret_cast<const bf16x8*>(V + krow * DH + 16 * ks + 8 * h);
+      }
+#pragma unroll
+      for (int i = 0; i < DT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dk[i][r] = 0.f; dv[i][r] = 0.f; }
+    }
+    const char* qst = smem_dyn + (g & 1) * BUF;
+    const char* ost = qst + ST;
+    const char* qtst = qst + 2 * ST;
+    const char* otst = qst + 3 * ST;
+    const float* lst = reinterpret_cast<const float*>(qst + 4 * ST);   // [0..127] lse2, [128..255] D
+    for (int t = 0; t < SKB / 64; ++t) {
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt) {
+        const int R = t * 64 + 32 * qt + lq;
+        f32x16 s, dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<DH>(qst, R, ks, h), kf[ks], s, 0, 0, 0);      // S[query][key]
+          dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<DH>(ost, R, ks, h), vf[ks], dp, 0, 0, 0);    // dP[query][key]
+        }
+        // register r <-> query (r & 3) + 8 (r >> 2) + 4 h of this 32-query tile: four runs of four consecutive queries
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          const int qi = t * 64 + 32 * qt + 8 * rg + 4 * h;
+          const f32x4 ls = *reinterpret_cast<const f32x4*>(lst + qi);
+          const f32x4 dd = *reinterpret_cast<const f32x4*>(lst + 128 + qi);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float p = __builtin_amdgcn_exp2f(s[rg * 4 + e] * scale_log2e - ls[e]);
+            s[rg * 4 + e] = p;
+            dp[rg * 4 + e] = p * (dp[rg * 4 + e] - dd[e]);
+          }
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const bf16x8 pf = cvt8(s, 8 * s2), dsf = cvt8(dp, 8 * s2);
+#pragma unroll
+          for (int dt = 0; dt < DT; ++dt) {
+            dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols<DH>(otst, t, 2 * qt + s2, dt * 32 + lq, h), pf, dv[dt], 0, 0, 0);
+            dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols<DH>(qtst, t, 2 * qt + s2, dt * 32 + lq, h), dsf, dk[dt], 0, 0, 0);
+          }
+        }
+      }
+    }
+    if (st == nst - 1) {
+      const int b = bh / nh, head = bh % nh;
+      const int64_t tok = (int64_t)b * L + k0 + lq;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        bf16* dstk = dK + tok * ld_d + head * DH + dt * 32;
+        bf16* dstv = dV + tok * ld_d + head * DH + dt * 32;
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          bf16x4 a, c;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { a[e] = (bf16)(dk[dt][rg * 4 + e] * scale); c[e] = (bf16)dv[dt][rg * 4 + e]; }
+          *reinterpret_cast<bf16x4*>(dstk + 8 * rg + 4 * h) = a;
+          *reinterpret_cast<bf16x4*>(dstv + 8 * rg + 4 * h) = c;
+        }
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+}
+
+// D[b, h, l] = sum_d dctx[tok][h dh + d] * ctx[tok][h dh + d]   (token-major inputs, one wave per 64 / dh ... simple: thread per (tok, head))
+__global__ void attn_bwd_rowdot_kernel(const bf16* __restrict__ dctx, const bf16* __restrict__ ctx, int64_t ld, float* __restrict__ Dv,
+                                       int B, int L, int nh, int dh) {
+  const int64_t total = (int64_t)B * L * nh;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int head = (int)(i % nh);
+    const int64_t tok = i / nh;
+    const int64_t b = tok / L, l = tok % L;
+    const bf16* a = dctx + tok * ld + head * dh;
+    const bf16* c = ctx + tok * ld + head * dh;
+    float s = 0.f;
+    for (int d = 0; d < dh; d += 8) {
+      float x[8], y[8];
+      load8(a + d, x);
+      load8(c + d, y);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s += x[e] * y[e];
+    }
+    Dv[(b * nh + head) * L + l] = s;
+  }
+}
+
+template <int DH>
+int launch_bwd(const bf16* q, const bf16* k, const bf16* v, const bf16* qT, const bf16* kT, const bf16* dO, const bf16* dOT,
+               const float* lse2, const float* Dv, bf16* dq, bf16* dk, bf16* dv, int64_t ld, int B, int L, int nh, float scale,
+               hipStream_t s) {
+  constexpr int ST = SKB * DH * 2;
+  constexpr int bytes_dq = 2 * 3 * ST, bytes_dkv = 2 * (4 * ST + 1024);
+  static bool attr_set = false;
+  if (!attr_set) {
+    MH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_kernel<DH>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes_dq));
+    MH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkv_kernel<DH>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes_dkv));
+    attr_set = true;
+  }
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+  const int nbh = B * nh, nitems = nbh * (L / 256);
+  const dim3 grid((unsigned)(nitems < cus ? nitems : cus)), block(512);
+  const float sl2 = scale * 1.4426950408889634f;
+  MH_LAUNCH((attn_bwd_dq_kernel<DH>), grid, block, bytes_dq, s, q, k, v, kT, dO, lse2, Dv, dq, ld, L, nh, nbh, scale, sl2);
+  MH_CHECK_LAUNCH();
+  MH_LAUNCH((attn_bwd_dkv_kernel<DH>), grid, block, bytes_dkv, s, q, k, v, qT, dO, dOT, lse2, Dv, dk, dv, ld, L, nh, nbh, scale, sl2);
+  MH_CHECK_LAUNCH();
+  return MH_OK;
+}
+
+}  // namespace
+
+extern "C" int mh_attention_bwd_rowdot(const void* dctx, const void* ctx, int64_t ld, float* D, int B, int L, int nh, int dh,
+                                       mh_stream_t stream) {
+  MH_CHECK_ARG(dctx && ctx && D && B > 0 && L > 0 && nh > 0 && dh > 0 && dh % 8 == 0 && ld % 8 == 0, "attention_bwd_rowdot: bad arguments");
+  const int64_t total = (int64_t)B * L * nh;
+  const int grid = (int)((total + 255) / 256 < 65535 ? (total + 255) / 256 : 65535);
+  MH_LAUNCH(attn_bwd_rowdot_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16*)dctx, (const bf16*)ctx, ld, D, B, L, nh, dh);
+  MH_CHECK_LAUNCH();
+  return MH_OK;
+}
+
+extern "C" int mh_attention_stream_bwd(const void* q, const void* k, const void* v, const void* qT_perm, const void* kT_perm,
+                                       const void* dO, const void* dOT_perm, const float* lse2, const float* D, void* dq, void* dk,
+                                       void* dv, int64_t ld_d, int B, int L, int nh, int dh, float scale, mh_stream_t stream) {
+  MH_CHECK_ARG(q && k && v && qT_perm && kT_perm && dO && dOT_perm && lse2 && D && dq && dk && dv, "attention_stream_bwd: null pointer");
+  MH_CHECK_ARG(B > 0 && nh > 0 && L >= 512 && L % 256 == 0 && (dh == 32 || dh == 64),
+               "attention_stream_bwd: needs seq_len %% 256 == 0, seq_len >= 512 and head dim 32 or 64 (got L=%d dh=%d)", L, dh);
+  MH_CHECK_ARG(ld_d % 4 == 0, "attention_stream_bwd: ld_d must be a multiple of 4");
+  hipStream_t s = (hipStream_t)stream;
+  if (dh == 64)
+    return launch_bwd<64>((const bf16*)q, (const bf16*)k, (const bf16*)v, (const bf16*)qT_perm, (const bf16*)kT_perm, (const bf16*)dO,
+                          (const bf16*)dOT_perm, lse2, D, (bf16*)dq, (bf16*)dk, (bf16*)dv, ld_d, B, L, nh, scale, s);
+  return launch_bwd<32>((const bf16*)q, (const bf16*)k, (const bf16*)v, (const bf16*)qT_perm, (const bf16*)kT_perm, (const bf16*)dO,
+                        (const bf16*)dOT_perm, lse2, D, (bf16*)dq, (bf16*)dk, (bf16*)dv, ld_d, B, L, nh, scale, s);
+}

@@ -35,7 +35,8 @@ __global__ void transpose_kernel(const T* __restrict__ in, int64_t ld_in, int64_
 }
 
 // mode 0: tokens [B*L, ld] (head h at cols [h*dh,(h+1)*dh)) -> heads [B, nh, L, dh]
-// mode 1: heads -> tokens;  mode 2: tokens -> heads transposed [B, nh, dh, L]
+// mode 1: heads -> tokens;  mode 2: tokens -> heads transposed [B, nh, dh, L];  mode 3: as mode 2 with the positions of
+// every group of 16 stored as 0-3, 8-11, 4-7, 12-15 (the streaming attention kernels' "P-operand" order)
 template <typename T>
 __global__ void head_permute_kernel(const T* __restrict__ in, T* __restrict__ out, int64_t ld_tok, int B, int L, int nh,
                                     int dh, int mode) {
@@ -53,7 +54,8 @@ __global__ void head_permute_kernel(const T* __restrict__ in, T* __restrict__ ou
       const int64_t b = tok / L, l = tok % L;
       out[tok * ld_tok + c] = in[((b * nh + h) * L + l) * dh + d];
     } else {
-      const int l = (int)(i % L); int64_t r = i / L;
+      int l = (int)(i % L); int64_t r = i / L;
+      if (mode == 3) l = (l & ~15) | ((((l >> 3) & 1) | ((l >> 1) & 2)) << 2) | (l & 3);   // the permutation is an involution
       const int d = (int)(r % dh); r /= dh;
       const int h = (int)(r % nh); const int64_t b = r / nh;
       out[i] = in[(b * L + l) * ld_tok + h * dh + d];
@@ -443,7 +445,7 @@ extern "C" int mh_transpose(const void* in, int64_t ld_in, int64_t stride_in, vo
 
 extern "C" int mh_head_permute(const void* in, void* out, int64_t ld_tok, int B, int L, int nh, int dh, int mode, int dtype,
                                mh_stream_t stream) {
-  MH_CHECK_ARG(in && out && B > 0 && L > 0 && nh > 0 && dh > 0 && mode >= 0 && mode <= 2, "head_permute: bad arguments");
+  MH_CHECK_ARG(in && out && B > 0 && L > 0 && nh > 0 && dh > 0 && mode >= 0 && mode <= 3 && (mode != 3 || L % 16 == 0), "head_permute: bad arguments");
   const int grid = tgrid((int64_t)B * L * nh * dh);
   hipStream_t s = (hipStream_t)stream;
   MH_DTYPE_SWITCH(dtype,

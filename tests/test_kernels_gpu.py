@@ -189,6 +189,55 @@ def test_attention_stream(dh, L, B, nh):
     assert torch.equal(outp.permute(1, 0, 2).reshape(B * L, nh * dh), out)
 
 
+@pytest.mark.parametrize("dh,L,B,nh", [(64, 512, 2, 3), (64, 1024, 1, 2), (32, 512, 2, 2)])
+def test_attention_stream_backward(dh, L, B, nh):
+    """fused backward kernels (dQ; dK, dV) == torch autograd through softmax(QK^T/sqrt(dh)) V on the bf16-rounded inputs"""
+    from musediffusion_amd._lib import check, current_stream
+    H = nh * dh
+    qkv = rnd(B * L, 3 * H, seed=260, scale=0.8)
+    qkv[:, H + 7] *= 3.0
+    dctx = rnd(B * L, H, seed=261, scale=0.5)
+    scale = 1.0 / math.sqrt(dh)
+    qb = q(qkv, MH_BF16).view(B, L, 3, nh, dh).permute(2, 0, 3, 1, 4).contiguous().requires_grad_(True)   # [3, B, nh, L, dh]
+    out_ref = torch.softmax((qb[0] @ qb[1].transpose(-1, -2)) * scale, -1) @ qb[2]
+    dO_ref = q(dctx, MH_BF16).view(B, L, nh, dh).permute(0, 2, 1, 3)
+    out_ref.backward(dO_ref)
+    gref = qb.grad                                                                                          # [3, B, nh, L, dh]
+    qkv_d, dctx_d = qkv.to(DEV).bfloat16().contiguous(), dctx.to(DEV).bfloat16().contiguous()
+    st = current_stream()
+
+    def perm(src, col0, ld, mode):
+        shape = (B, nh, dh, L) if mode >= 2 else (B, nh, L, dh)
+        out = torch.zeros(B * nh * L * dh + 256, device=DEV, dtype=torch.bfloat16)
+        check(lib().mh_head_permute(src.data_ptr() + col0 * 2, out.data_ptr(), ld, B, L, nh, dh, mode, MH_BF16, st))
+        return out
+    qr, kr, vr = (perm(qkv_d, i * H, 3 * H, 0) for i in range(3))
+    qT, kT, vT = (perm(qkv_d, i * H, 3 * H, 3) for i in range(3))
+    assert torch.equal(vT[: B * H * L].view(B, nh, dh, L), _vt_perm(vr[: B * H * L].view(B, nh, L, dh).transpose(-1, -2).contiguous()))
+    ctx = torch.zeros(B * L, H, device=DEV, dtype=torch.bfloat16)
+    lse = torch.zeros(B * nh * L, device=DEV)
+    check(lib().mh_attention_stream_fwd_lse(qr.data_ptr(), kr.data_ptr(), vT.data_ptr(), ctx.data_ptr(), H, 0, B, L, nh, dh, scale,
+                                            lse.data_ptr(), st))
+    s_ref = (qb[0].detach() @ qb[1].detach().transpose(-1, -2)) * scale
+    assert_close(lse.view(B, nh, L).cpu() / math.log2(math.e), torch.logsumexp(s_ref, -1), 2e-3, what="lse")
+    assert_close(ctx, out_ref.detach().permute(0, 2, 1, 3).reshape(B * L, H), 2e-2, what="ctx")
+    dOr, dOT = perm(dctx_d, 0, H, 0), perm(dctx_d, 0, H, 3)
+    D = torch.zeros(B * nh * L, device=DEV)
+    check(lib().mh_attention_bwd_rowdot(dctx_d.data_ptr(), ctx.data_ptr(), H, D.data_ptr(), B, L, nh, dh, st))
+    D_ref = (dO_ref * out_ref.detach()).sum(-1)
+    assert_close(D.view(B, nh, L), D_ref, 2e-2, 2e-2, what="D")
+    dqkv = torch.zeros(B * L, 3 * H, device=DEV, dtype=torch.bfloat16)
+    check(lib().mh_attention_stream_bwd(qr.data_ptr(), kr.data_ptr(), vr.data_ptr(), qT.data_ptr(), kT.data_ptr(), dOr.data_ptr(),
+                                        dOT.data_ptr(), lse.data_ptr(), D.data_ptr(), dqkv.data_ptr(), dqkv.data_ptr() + H * 2,
+                                        dqkv.data_ptr() + 2 * H * 2, 3 * H, B, L, nh, dh, scale, st))
+    got = dqkv.float().cpu().view(B, L, 3, nh, dh).permute(2, 0, 3, 1, 4)
+    for i, nm in enumerate(("dQ", "dK", "dV")):
+        ref = gref[i]
+        err = (got[i] - ref).abs().max().item()
+        tol = 2e-2 * ref.abs().max().item() + 1e-3
+        assert err <= tol, "%s: max err %.4g > %.4g (ref max %.3g)" % (nm, err, tol, ref.abs().max().item())
+
+
 def test_gemm_qkv_vtperm():
     from musediffusion_amd._lib import check, current_stream
     B, L, H, nh = 2, 48, 128, 2
