@@ -147,6 +147,17 @@ int mh_attention_stream_fwd_lse(const void* q, const void* k, const void* vt_per
 int mh_attention_stream_bwd(const void* q, const void* k, const void* v, const void* qT_perm, const void* kT_perm,
                             const void* dO, const void* dOT_perm, const float* lse2, const float* D, void* dq, void* dk,
                             void* dv, int64_t ld_d, int B, int L, int nh, int dh, float scale, mh_stream_t stream);
+/* The same two entry points for row operands that are NOT [B, nh, L, dh] tensors: row r of (batch b, head h) of
+ * q / k (/ v) starts at ptr + b * batch_stride + h * head_stride + r * row_stride elements (all multiples of 8), e.g.
+ * the column blocks of a token-major [B L, 3H] QKV projection: batch_stride L * 3H, head_stride dh, row_stride 3H. */
+int mh_attention_stream_fwd_ex(const void* q, const void* k, const void* vt_perm, void* ctx, int64_t ld_ctx, int ctx_panel,
+                               int B, int L, int nh, int dh, float scale, float* lse2, int64_t qk_batch_stride,
+                               int64_t qk_head_stride, int64_t qk_row_stride, mh_stream_t stream);
+int mh_attention_stream_bwd_ex(const void* q, const void* k, const void* v, const void* qT_perm, const void* kT_perm,
+                               const void* dO, const void* dOT_perm, const float* lse2, const float* D, void* dq, void* dk,
+                               void* dv, int64_t ld_d, int B, int L, int nh, int dh, float scale, int64_t qkv_batch_stride,
+                               int64_t qkv_head_stride, int64_t qkv_row_stride, int64_t do_batch_stride,
+                               int64_t do_head_stride, int64_t do_row_stride, mh_stream_t stream);
 int mh_attention_bwd_rowdot(const void* dctx, const void* ctx, int64_t ld, float* D, int B, int L, int nh, int dh,
                             mh_stream_t stream);
 int mh_attention_stream_supported(int L, int dh);

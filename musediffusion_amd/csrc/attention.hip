@@ -555,7 +555,7 @@ template <int DH>
 __global__ __launch_bounds__(1024) void attn_stream_bf16_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K,
                                                                 const bf16* __restrict__ VT, bf16* __restrict__ ctx,
                                                                 int64_t ld_ctx, int L, int nh, int nbh, float scale_log2e,
-                                                                int ctx_panel, float* __restrict__ lse2) {
+                                                                int ctx_panel, float* __restrict__ lse2, int64_t qsB, int64_t qsH, int64_t qld) {
   constexpr int NW = 16, SK = 256;                       // waves, keys per stage
   constexpr int CH = DH / 8, RPB = 128 / DH, KROWB = DH * 2;
   constexpr int KS = DH / 16, DT = DH / 32;
@@ -576,7 +576,7 @@ __global__ __launch_bounds__(1024) void attn_stream_bf16_kernel(const bf16* __re
   auto issue = [&](int g) {   // DMA stage g (of this block's flattened (item, stage) sequence) into buffer g & 1
     const int item = blockIdx.x + (g / nst) * gridDim.x, st = g % nst;
     const int bh = item / nqb;
-    const bf16* Kb = K + ((int64_t)bh * L + (int64_t)st * SK) * DH;
+    const bf16* Kb = K + (int64_t)(bh / nh) * qsB + (int64_t)(bh % nh) * qsH + (int64_t)st * SK * qld;   // rows qld elements apart
     const bf16* Vb = VT + (int64_t)bh * DH * L + (int64_t)st * SK;
     char* kdst = smem_dyn + (g & 1) * (2 * KST);
     char* vdst = kdst + KST;
@@ -585,7 +585,7 @@ __global__ __launch_bounds__(1024) void attn_stream_bf16_kernel(const bf16* __re
       const int p = wave + NW * j;
       const int row = p * KRP + lane / CH, pc = lane % CH;             // key within the stage, physical chunk
       const int lc = pc ^ ((row / RPB) & (CH - 1));
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Kb + (int64_t)row * DH + lc * 8),
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Kb + (int64_t)row * qld + lc * 8),
                                        (__attribute__((address_space(3))) void*)(kdst + p * 1024), 16, 0, 0);
     }
 #pragma unroll
@@ -616,10 +616,10 @@ __global__ __launch_bounds__(1024) void attn_stream_bf16_kernel(const bf16* __re
       q0 = qb * 512 + wave * 32;
       active = q0 < L;
       if (active) {
-        const bf16* Qb = Q + (int64_t)bh * L * DH;
+        const bf16* Qb = Q + (int64_t)(bh / nh) * qsB + (int64_t)(bh % nh) * qsH;
         int qr = q0 + lq; if (qr >= L) qr = L - 1;
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(Qb + (int64_t)qr * DH + 16 * ks + 8 * h);
+        for (int ks = 0; ks < KS; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(Qb + (int64_t)qr * qld + 16 * ks + 8 * h);
       }
 #pragma unroll
       for (int i = 0; i < DT; ++i)
@@ -784,6 +784,9 @@ extern "C" int mh_attention_stream_supported(int L, int dh) { return L >= 512 &&
 
 extern "C" int mh_attention_stream_fwd_lse(const void* q, const void* k, const void* vt_perm, void* ctx, int64_t ld_ctx, int ctx_panel,
                                            int B, int L, int nh, int dh, float scale, float* lse2, mh_stream_t stream);
+extern "C" int mh_attention_stream_fwd_ex(const void* q, const void* k, const void* vt_perm, void* ctx, int64_t ld_ctx, int ctx_panel,
+                                          int B, int L, int nh, int dh, float scale, float* lse2, int64_t qk_batch_stride,
+                                          int64_t qk_head_stride, int64_t qk_row_stride, mh_stream_t stream);
 
 extern "C" int mh_attention_stream_fwd(const void* q, const void* k, const void* vt_perm, void* ctx, int64_t ld_ctx, int ctx_panel,
                                        int B, int L, int nh, int dh, float scale, mh_stream_t stream) {
@@ -792,6 +795,14 @@ extern "C" int mh_attention_stream_fwd(const void* q, const void* k, const void*
 
 extern "C" int mh_attention_stream_fwd_lse(const void* q, const void* k, const void* vt_perm, void* ctx, int64_t ld_ctx, int ctx_panel,
                                            int B, int L, int nh, int dh, float scale, float* lse2, mh_stream_t stream) {
+  return mh_attention_stream_fwd_ex(q, k, vt_perm, ctx, ld_ctx, ctx_panel, B, L, nh, dh, scale, lse2, (int64_t)nh * L * dh, (int64_t)L * dh, dh,
+                                    stream);
+}
+
+extern "C" int mh_attention_stream_fwd_ex(const void* q, const void* k, const void* vt_perm, void* ctx, int64_t ld_ctx, int ctx_panel,
+                                          int B, int L, int nh, int dh, float scale, float* lse2, int64_t qsB, int64_t qsH,
+                                          int64_t qld, mh_stream_t stream) {
+  MH_CHECK_ARG(qld % 8 == 0 && qsH % 8 == 0 && qsB % 8 == 0 && qld >= dh, "attention_stream: q/k strides must be multiples of 8 elements");
   MH_CHECK_ARG(q && k && vt_perm && ctx, "attention_stream: null pointer");
   MH_CHECK_ARG(B > 0 && nh > 0 && mh_attention_stream_supported(L, dh),
                "attention_stream: needs seq_len %% 256 == 0, seq_len >= 512 and head dim 32 or 64 (got L=%d dh=%d)", L, dh);
@@ -810,7 +821,7 @@ extern "C" int mh_attention_stream_fwd_lse(const void* q, const void* k, const v
       MH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_stream_bf16_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
       attr_set = true;
     }
-    MH_LAUNCH((attn_stream_bf16_kernel<64>), grid, block, bytes, s, Q, K, V, (bf16*)ctx, ld_ctx, L, nh, nbh, sl2, ctx_panel, lse2);
+    MH_LAUNCH((attn_stream_bf16_kernel<64>), grid, block, bytes, s, Q, K, V, (bf16*)ctx, ld_ctx, L, nh, nbh, sl2, ctx_panel, lse2, qsB, qsH, qld);
   } else {
     constexpr int bytes = 4 * 256 * 32 * 2;
     static bool attr_set = false;
@@ -818,7 +829,7 @@ extern "C" int mh_attention_stream_fwd_lse(const void* q, const void* k, const v
       MH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_stream_bf16_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
       attr_set = true;
     }
-    MH_LAUNCH((attn_stream_bf16_kernel<32>), grid, block, bytes, s, Q, K, V, (bf16*)ctx, ld_ctx, L, nh, nbh, sl2, ctx_panel, lse2);
+    MH_LAUNCH((attn_stream_bf16_kernel<32>), grid, block, bytes, s, Q, K, V, (bf16*)ctx, ld_ctx, L, nh, nbh, sl2, ctx_panel, lse2, qsB, qsH, qld);
   }
   MH_CHECK_LAUNCH();
   return MH_OK;

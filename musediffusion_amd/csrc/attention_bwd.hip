@@ -25,12 +25,17 @@ __device__ __forceinline__ void glds16(const void* g, void* l) {
 
 // piece p (1 KiB) of a row-layout operand stage: rows [row][DH] bf16, 16-B chunk c of row r stored at c ^ ((r / RPB) & (CH-1))
 template <int DH>
-__device__ __forceinline__ void dma_rows(const bf16* src, char* dst, int p, int lane) {
+__device__ __forceinline__ void dma_rows(const bf16* src, int64_t ld, char* dst, int p, int lane) {
   constexpr int CH = DH / 8, RPB = 128 / DH, KROWB = DH * 2, KRP = 1024 / KROWB;
   const int row = p * KRP + lane / CH, pc = lane % CH;
   const int lc = pc ^ ((row / RPB) & (CH - 1));
-  glds16(src + (int64_t)row * DH + lc * 8, dst + p * 1024);
+  glds16(src + (int64_t)row * ld + lc * 8, dst + p * 1024);
 }
+// where the [L, dh] rows of one (batch, head) live: [B, nh, L, dh] tensors or column blocks of token-major [B L, ld] ones
+struct RowLayout {
+  int64_t sB, sH, ld;   // batch stride, head stride, row pitch (elements)
+  __device__ __forceinline__ int64_t at(int bh, int nh, int64_t row) const { return (int64_t)(bh / nh) * sB + (int64_t)(bh % nh) * sH + row * ld; }
+};
 // piece p of a transposed operand stage: global [DH][L] (key order permuted per 16), LDS = 64-column tiles of [DH][128 B],
 // chunk c of row d stored at c ^ ((d >> 1) & 7)
 template <int DH>
@@ -64,7 +69,8 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const bf16* __restrict
                                                           const bf16* __restrict__ V, const bf16* __restrict__ KT,
                                                           const bf16* __restrict__ dO, const float* __restrict__ lse2,
                                                           const float* __restrict__ Dv, bf16* __restrict__ dQ, int64_t ld_dq,
-                                                          int L, int nh, int nbh, float scale, float scale_log2e) {
+                                                          int L, int nh, int nbh, float scale, float scale_log2e, RowLayout lq_,
+                                                          RowLayout lo_) {
   constexpr int NW = 8;
   constexpr int KS = DH / 16, DT = DH / 32;
   constexpr int ST = SKB * DH * 2;                 // bytes of one operand stage (row layout and transposed alike)
@@ -81,14 +87,13 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const bf16* __restrict
   auto issue = [&](int g) {
     const int item = blockIdx.x + (g / nst) * gridDim.x, st = g % nst;
     const int bh = item / nqb;
-    const bf16* Kb = K + ((int64_t)bh * L + (int64_t)st * SKB) * DH;
-    const bf16* Vb = V + ((int64_t)bh * L + (int64_t)st * SKB) * DH;
+    const int64_t roff = lq_.at(bh, nh, (int64_t)st * SKB);
     const bf16* Tb = KT + (int64_t)bh * DH * L + (int64_t)st * SKB;
     char* base = smem_dyn + (g & 1) * (3 * ST);
 #pragma unroll
-    for (int j = 0; j < PK; ++j) dma_rows<DH>(Kb, base, wave + NW * j, lane);
+    for (int j = 0; j < PK; ++j) dma_rows<DH>(K + roff, lq_.ld, base, wave + NW * j, lane);
 #pragma unroll
-    for (int j = 0; j < PK; ++j) dma_rows<DH>(Vb, base + ST, wave + NW * j, lane);
+    for (int j = 0; j < PK; ++j) dma_rows<DH>(V + roff, lq_.ld, base + ST, wave + NW * j, lane);
 #pragma unroll
     for (int j = 0; j < PK; ++j) dma_cols<DH>(Tb, L, base + 2 * ST, wave + NW * j, lane);
   };
@@ -109,8 +114,8 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const bf16* __restrict
       const int64_t qrow = (int64_t)bh * L + q0 + lq;
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
-        qf[ks] = *reinterpret_cast<const bf16x8*>(Q + qrow * DH + 16 * ks + 8 * h);
-        dof[ks] = *reinterpret_cast<const bf16x8*>(dO + qrow * DH + 16 * ks + 8 * h);
+        qf[ks] = *reinterpret_cast<const bf16x8*>(Q + lq_.at(bh, nh, q0 + lq) + 16 * ks + 8 * h);
+        dof[ks] = *reinterpret_cast<const bf16x8*>(dO + lo_.at(bh, nh, q0 + lq) + 16 * ks + 8 * h);
       }
       lse_q = lse2[qrow];
       D_q = Dv[qrow];
@@ -179,7 +184,8 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const bf16* __restric
                                                            const bf16* __restrict__ dO, const bf16* __restrict__ dOT,
                                                            const float* __restrict__ lse2, const float* __restrict__ Dv,
                                                            bf16* __restrict__ dK, bf16* __restrict__ dV, int64_t ld_d, int L,
-                                                           int nh, int nbh, float scale, float scale_log2e) {
+                                                           int nh, int nbh, float scale, float scale_log2e, RowLayout lq_,
+                                                           RowLayout lo_) {
   constexpr int NW = 8;
   constexpr int KS = DH / 16, DT = DH / 32;
   constexpr int ST = SKB * DH * 2;
@@ -201,9 +207,9 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const bf16* __restric
     const int64_t c0 = (int64_t)bh * DH * L + (int64_t)st * SKB;
     char* base = smem_dyn + (g & 1) * BUF;
 #pragma unroll
-    for (int j = 0; j < PK; ++j) dma_rows<DH>(Q + r0 * DH, base, wave + NW * j, lane);
+    for (int j = 0; j < PK; ++j) dma_rows<DH>(Q + lq_.at(bh, nh, (int64_t)st * SKB), lq_.ld, base, wave + NW * j, lane);
 #pragma unroll
-    for (int j = 0; j < PK; ++j) dma_rows<DH>(dO + r0 * DH, base + ST, wave + NW * j, lane);
+    for (int j = 0; j < PK; ++j) dma_rows<DH>(dO + lo_.at(bh, nh, (int64_t)st * SKB), lo_.ld, base + ST, wave + NW * j, lane);
 #pragma unroll
     for (int j = 0; j < PK; ++j) dma_cols<DH>(QT + c0, L, base + 2 * ST, wave + NW * j, lane);
 #pragma unroll
@@ -224,11 +230,10 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const bf16* __restric
     if (g + 1 < total) issue(g + 1);
     if (st == 0) {
       k0 = kb * 256 + wave * 32;
-      const int64_t krow = (int64_t)bh * L + k0 + lq;
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
-        kf[ks] = *reinterpret_cast<const bf16x8*>(K + krow * DH + 16 * ks + 8 * h);
-        vf[ks] = *reinterpret_cast<const bf16x8*>(V + krow * DH + 16 * ks + 8 * h);
+        kf[ks] = *reinterpret_cast<const bf16x8*>(K + lq_.at(bh, nh, k0 + lq) + 16 * ks + 8 * h);
+        vf[ks] = *reinterpret_cast<const bf16x8*>(V + lq_.at(bh, nh, k0 + lq) + 16 * ks + 8 * h);
       }
 #pragma unroll
       for (int i = 0; i < DT; ++i)
@@ -323,7 +328,7 @@ __global__ void attn_bwd_rowdot_kernel(const bf16* __restrict__ dctx, const bf16
 template <int DH>
 int launch_bwd(const bf16* q, const bf16* k, const bf16* v, const bf16* qT, const bf16* kT, const bf16* dO, const bf16* dOT,
                const float* lse2, const float* Dv, bf16* dq, bf16* dk, bf16* dv, int64_t ld, int B, int L, int nh, float scale,
-               hipStream_t s) {
+               RowLayout lqkv, RowLayout ldo, hipStream_t s) {
   constexpr int ST = SKB * DH * 2;
   constexpr int bytes_dq = 2 * 3 * ST, bytes_dkv = 2 * (4 * ST + 1024);
   static bool attr_set = false;
@@ -337,9 +342,9 @@ int launch_bwd(const bf16* q, const bf16* k, const bf16* v, const bf16* qT, cons
   const int nbh = B * nh, nitems = nbh * (L / 256);
   const dim3 grid((unsigned)(nitems < cus ? nitems : cus)), block(512);
   const float sl2 = scale * 1.4426950408889634f;
-  MH_LAUNCH((attn_bwd_dq_kernel<DH>), grid, block, bytes_dq, s, q, k, v, kT, dO, lse2, Dv, dq, ld, L, nh, nbh, scale, sl2);
+  MH_LAUNCH((attn_bwd_dq_kernel<DH>), grid, block, bytes_dq, s, q, k, v, kT, dO, lse2, Dv, dq, ld, L, nh, nbh, scale, sl2, lqkv, ldo);
   MH_CHECK_LAUNCH();
-  MH_LAUNCH((attn_bwd_dkv_kernel<DH>), grid, block, bytes_dkv, s, q, k, v, qT, dO, dOT, lse2, Dv, dk, dv, ld, L, nh, nbh, scale, sl2);
+  MH_LAUNCH((attn_bwd_dkv_kernel<DH>), grid, block, bytes_dkv, s, q, k, v, qT, dO, dOT, lse2, Dv, dk, dv, ld, L, nh, nbh, scale, sl2, lqkv, ldo);
   MH_CHECK_LAUNCH();
   return MH_OK;
 }
@@ -356,9 +361,27 @@ extern "C" int mh_attention_bwd_rowdot(const void* dctx, const void* ctx, int64_
   return MH_OK;
 }
 
+extern "C" int mh_attention_stream_bwd_ex(const void* q, const void* k, const void* v, const void* qT_perm, const void* kT_perm,
+                                          const void* dO, const void* dOT_perm, const float* lse2, const float* D, void* dq, void* dk,
+                                          void* dv, int64_t ld_d, int B, int L, int nh, int dh, float scale, int64_t qkv_batch_stride,
+                                          int64_t qkv_head_stride, int64_t qkv_row_stride, int64_t do_batch_stride,
+                                          int64_t do_head_stride, int64_t do_row_stride, mh_stream_t stream);
+
 extern "C" int mh_attention_stream_bwd(const void* q, const void* k, const void* v, const void* qT_perm, const void* kT_perm,
                                        const void* dO, const void* dOT_perm, const float* lse2, const float* D, void* dq, void* dk,
                                        void* dv, int64_t ld_d, int B, int L, int nh, int dh, float scale, mh_stream_t stream) {
+  const int64_t sB = (int64_t)nh * L * dh, sH = (int64_t)L * dh;
+  return mh_attention_stream_bwd_ex(q, k, v, qT_perm, kT_perm, dO, dOT_perm, lse2, D, dq, dk, dv, ld_d, B, L, nh, dh, scale, sB, sH, dh,
+                                    sB, sH, dh, stream);
+}
+
+extern "C" int mh_attention_stream_bwd_ex(const void* q, const void* k, const void* v, const void* qT_perm, const void* kT_perm,
+                                          const void* dO, const void* dOT_perm, const float* lse2, const float* D, void* dq, void* dk,
+                                          void* dv, int64_t ld_d, int B, int L, int nh, int dh, float scale, int64_t qsB, int64_t qsH,
+                                          int64_t qld, int64_t osB, int64_t osH, int64_t old_, mh_stream_t stream) {
+  MH_CHECK_ARG(qsB % 8 == 0 && qsH % 8 == 0 && qld % 8 == 0 && osB % 8 == 0 && osH % 8 == 0 && old_ % 8 == 0 && qld >= dh && old_ >= dh,
+               "attention_stream_bwd: row strides must be multiples of 8 elements");
+  const RowLayout lqkv{qsB, qsH, qld}, ldo{osB, osH, old_};
   MH_CHECK_ARG(q && k && v && qT_perm && kT_perm && dO && dOT_perm && lse2 && D && dq && dk && dv, "attention_stream_bwd: null pointer");
   MH_CHECK_ARG(B > 0 && nh > 0 && L >= 512 && L % 256 == 0 && (dh == 32 || dh == 64),
                "attention_stream_bwd: needs seq_len %% 256 == 0, seq_len >= 512 and head dim 32 or 64 (got L=%d dh=%d)", L, dh);
@@ -366,7 +389,7 @@ extern "C" int mh_attention_stream_bwd(const void* q, const void* k, const void*
   hipStream_t s = (hipStream_t)stream;
   if (dh == 64)
     return launch_bwd<64>((const bf16*)q, (const bf16*)k, (const bf16*)v, (const bf16*)qT_perm, (const bf16*)kT_perm, (const bf16*)dO,
-                          (const bf16*)dOT_perm, lse2, D, (bf16*)dq, (bf16*)dk, (bf16*)dv, ld_d, B, L, nh, scale, s);
+                          (const bf16*)dOT_perm, lse2, D, (bf16*)dq, (bf16*)dk, (bf16*)dv, ld_d, B, L, nh, scale, lqkv, ldo, s);
   return launch_bwd<32>((const bf16*)q, (const bf16*)k, (const bf16*)v, (const bf16*)qT_perm, (const bf16*)kT_perm, (const bf16*)dO,
-                        (const bf16*)dOT_perm, lse2, D, (bf16*)dq, (bf16*)dk, (bf16*)dv, ld_d, B, L, nh, scale, s);
+                        (const bf16*)dOT_perm, lse2, D, (bf16*)dq, (bf16*)dk, (bf16*)dv, ld_d, B, L, nh, scale, lqkv, ldo, s);
 }

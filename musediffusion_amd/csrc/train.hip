@@ -76,6 +76,49 @@ __global__ void add_pos_time_kernel(const T* __restrict__ x, int64_t ldx, const 
   }
 }
 
+// bf16 fast paths of head_permute.  Modes 0 / 1: 16 bytes (8 head-dim elements) per thread.
+__global__ void head_permute8_kernel(const bf16* __restrict__ in, bf16* __restrict__ out, int64_t ld_tok, int B, int L, int nh, int dh8,
+                                     int mode) {
+  const int64_t total = (int64_t)B * L * nh * dh8;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % dh8); int64_t r = i / dh8;
+    if (mode == 0) {        // i enumerates [b][h][l][d/8]
+      const int l = (int)(r % L); r /= L;
+      const int h = (int)(r % nh); const int64_t b = r / nh;
+      *reinterpret_cast<f32x4*>(out + i * 8) = *reinterpret_cast<const f32x4*>(in + (b * L + l) * ld_tok + (h * dh8 + c) * 8);
+    } else {                // i enumerates [tok][h][d/8]
+      const int h = (int)(r % nh); const int64_t tok = r / nh;
+      const int64_t b = tok / L, l = tok % L;
+      *reinterpret_cast<f32x4*>(out + tok * ld_tok + (h * dh8 + c) * 8) = *reinterpret_cast<const f32x4*>(in + (((b * nh + h) * L + l) * dh8 + c) * 8);
+    }
+  }
+}
+// Modes 2 / 3 (tokens -> [B, nh, dh, L], optionally with the P-operand position order): 64-token tiles through LDS,
+// 16-byte loads along the head dim, 16-byte stores along the sequence.  grid (L / 64, B * nh), 256 threads, DH <= 128.
+template <int DH>
+__global__ __launch_bounds__(256) void head_transpose_kernel(const bf16* __restrict__ in, bf16* __restrict__ out, int64_t ld_tok, int L,
+                                                             int nh, int perm) {
+  __shared__ bf16 tile[64][DH + 8];
+  const int bh = blockIdx.y, b = bh / nh, h = bh % nh, l0 = blockIdx.x * 64;
+  constexpr int CPR = DH / 8;
+  for (int i = threadIdx.x; i < 64 * CPR; i += 256) {
+    const int l = i / CPR, c = i % CPR;
+    *reinterpret_cast<f32x4*>(&tile[l][c * 8]) = *reinterpret_cast<const f32x4*>(in + ((int64_t)b * L + l0 + l) * ld_tok + h * DH + c * 8);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < DH * 8; i += 256) {
+    const int d = i >> 3, c = i & 7;          // output chunk c: positions 8c .. 8c+7 of this tile
+    bf16x8 v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      int l = 8 * c + j;
+      if (perm) l = (l & ~15) | ((((l >> 3) & 1) | ((l >> 1) & 2)) << 2) | (l & 3);
+      v[j] = tile[l][d];
+    }
+    *reinterpret_cast<bf16x8*>(out + ((int64_t)bh * DH + d) * L + l0 + 8 * c) = v;
+  }
+}
+
 template <typename T>
 __global__ void colsum_partial_kernel(const T* __restrict__ in_all, int64_t ld, int64_t rows, int cols, float* __restrict__ part_all,
                                       int64_t s_in) {
@@ -446,8 +489,24 @@ extern "C" int mh_transpose(const void* in, int64_t ld_in, int64_t stride_in, vo
 extern "C" int mh_head_permute(const void* in, void* out, int64_t ld_tok, int B, int L, int nh, int dh, int mode, int dtype,
                                mh_stream_t stream) {
   MH_CHECK_ARG(in && out && B > 0 && L > 0 && nh > 0 && dh > 0 && mode >= 0 && mode <= 3 && (mode != 3 || L % 16 == 0), "head_permute: bad arguments");
-  const int grid = tgrid((int64_t)B * L * nh * dh);
   hipStream_t s = (hipStream_t)stream;
+  const bool vec_ok = dtype == MH_BF16 && dh % 8 == 0 && ld_tok % 8 == 0 && (reinterpret_cast<uintptr_t>(in) & 15) == 0 &&
+                      (reinterpret_cast<uintptr_t>(out) & 15) == 0;
+  if (vec_ok && mode <= 1) {
+    MH_LAUNCH(head_permute8_kernel, dim3(tgrid((int64_t)B * L * nh * (dh / 8))), dim3(TB), 0, s, (const bf16*)in, (bf16*)out, ld_tok, B, L,
+              nh, dh / 8, mode);
+    MH_CHECK_LAUNCH();
+    return MH_OK;
+  }
+  if (vec_ok && mode >= 2 && L % 64 == 0 && (dh == 32 || dh == 64 || dh == 128)) {
+    const dim3 grid(L / 64, B * nh);
+    if (dh == 32) MH_LAUNCH((head_transpose_kernel<32>), grid, dim3(256), 0, s, (const bf16*)in, (bf16*)out, ld_tok, L, nh, mode == 3);
+    else if (dh == 64) MH_LAUNCH((head_transpose_kernel<64>), grid, dim3(256), 0, s, (const bf16*)in, (bf16*)out, ld_tok, L, nh, mode == 3);
+    else MH_LAUNCH((head_transpose_kernel<128>), grid, dim3(256), 0, s, (const bf16*)in, (bf16*)out, ld_tok, L, nh, mode == 3);
+    MH_CHECK_LAUNCH();
+    return MH_OK;
+  }
+  const int grid = tgrid((int64_t)B * L * nh * dh);
   MH_DTYPE_SWITCH(dtype,
                   MH_LAUNCH((head_permute_kernel<bf16>), dim3(grid), dim3(TB), 0, s, (const bf16*)in, (bf16*)out, ld_tok, B, L, nh, dh, mode),
                   MH_LAUNCH((head_permute_kernel<float>), dim3(grid), dim3(TB), 0, s, (const float*)in, (float*)out, ld_tok, B, L, nh, dh, mode),

@@ -216,21 +216,22 @@ class _Attention(Function):
         es = qkv.element_size()
         scale = 1.0 / math.sqrt(dh)
         fused = FUSED_ATTENTION and dt == ops.MH_BF16 and bool(L_.mh_attention_stream_supported(L, dh)) and ld == 3 * H
-        q = torch.empty(B, nh, L, dh, device=qkv.device, dtype=td)
-        k = torch.empty_like(q)
         vt = torch.empty(B * nh * dh * L + 256, device=qkv.device, dtype=td)     # slack: 16-B tail over-read of the last row
         vt[-256:].zero_()
-        check(L_.mh_head_permute(qkv.data_ptr(), ptr(q), ld, B, L, nh, dh, 0, dt, st), "mh_head_permute")
-        check(L_.mh_head_permute(qkv.data_ptr() + H * es, ptr(k), ld, B, L, nh, dh, 0, dt, st), "mh_head_permute")
         check(L_.mh_head_permute(qkv.data_ptr() + 2 * H * es, ptr(vt), ld, B, L, nh, dh, 3 if fused else 2, dt, st), "mh_head_permute")
         if fused:
-            # streaming forward; the log-sum-exp lets the backward kernels re-create P tile by tile (no [L, L] tensor in HBM)
+            # streaming forward straight off the token-major projections (rows of one head are dh-wide column blocks, pitch 3H);
+            # the log-sum-exp lets the backward kernels re-create P tile by tile (no [L, L] tensor in HBM)
             out = torch.empty(B * L, H, device=qkv.device, dtype=td)
             lse = torch.empty(B * nh * L, device=qkv.device, dtype=torch.float32)
-            check(L_.mh_attention_stream_fwd_lse(ptr(q), ptr(k), ptr(vt), ptr(out), H, 0, B, L, nh, dh, scale, ptr(lse), st),
-                  "mh_attention_stream_fwd_lse")
-            ctx.save_for_backward(qkv, q, k, out, lse)
+            check(L_.mh_attention_stream_fwd_ex(qkv.data_ptr(), qkv.data_ptr() + H * es, ptr(vt), ptr(out), H, 0, B, L, nh, dh, scale,
+                                                ptr(lse), L * ld, dh, ld, st), "mh_attention_stream_fwd_ex")
+            ctx.save_for_backward(qkv, out, lse)
         else:
+            q = torch.empty(B, nh, L, dh, device=qkv.device, dtype=td)
+            k = torch.empty_like(q)
+            check(L_.mh_head_permute(qkv.data_ptr(), ptr(q), ld, B, L, nh, dh, 0, dt, st), "mh_head_permute")
+            check(L_.mh_head_permute(qkv.data_ptr() + H * es, ptr(k), ld, B, L, nh, dh, 0, dt, st), "mh_head_permute")
             out = ops.attention(q, k, vt, scale, dt)
             ctx.save_for_backward(q, k, vt)
         ctx.meta = (B, L, nh, dh, H, dt, scale, fused)
@@ -238,27 +239,26 @@ class _Attention(Function):
 
     @staticmethod
     def _backward_fused(ctx, dctx):
-        qkv, q, k, out, lse = ctx.saved_tensors
+        qkv, out, lse = ctx.saved_tensors
         B, L, nh, dh, H, dt, scale, _ = ctx.meta
-        dev, td = q.device, q.dtype
-        L_, st, es = lib(), current_stream(), q.element_size()
+        dev, td = qkv.device, qkv.dtype
+        L_, st, es = lib(), current_stream(), qkv.element_size()
         dctx = dctx.contiguous()
         n = B * nh * L * dh
 
-        def permuted(src, col0, ld, mode):
+        def transposed(src, col0, ld):     # [B, nh, dh, L] in the kernels' position order
             t = torch.empty(n + 256, device=dev, dtype=td)
             t[-256:].zero_()
-            check(L_.mh_head_permute(src.data_ptr() + col0 * es, ptr(t), ld, B, L, nh, dh, mode, dt, st), "mh_head_permute")
+            check(L_.mh_head_permute(src.data_ptr() + col0 * es, ptr(t), ld, B, L, nh, dh, 3, dt, st), "mh_head_permute")
             return t
-        v = permuted(qkv, 2 * H, 3 * H, 0)
-        qT, kT = permuted(qkv, 0, 3 * H, 3), permuted(qkv, H, 3 * H, 3)
-        dO, dOT = permuted(dctx, 0, H, 0), permuted(dctx, 0, H, 3)
+        qT, kT, dOT = transposed(qkv, 0, 3 * H), transposed(qkv, H, 3 * H), transposed(dctx, 0, H)
         D = torch.empty(B * nh * L, device=dev, dtype=torch.float32)
         check(L_.mh_attention_bwd_rowdot(ptr(dctx), ptr(out), H, ptr(D), B, L, nh, dh, st), "mh_attention_bwd_rowdot")
         dqkv = torch.empty(B * L, 3 * H, device=dev, dtype=td)
-        check(L_.mh_attention_stream_bwd(ptr(q), ptr(k), ptr(v), ptr(qT), ptr(kT), ptr(dO), ptr(dOT), ptr(lse), ptr(D),
-                                         dqkv.data_ptr(), dqkv.data_ptr() + H * es, dqkv.data_ptr() + 2 * H * es, 3 * H,
-                                         B, L, nh, dh, scale, st), "mh_attention_stream_bwd")
+        check(L_.mh_attention_stream_bwd_ex(qkv.data_ptr(), qkv.data_ptr() + H * es, qkv.data_ptr() + 2 * H * es, ptr(qT), ptr(kT),
+                                            ptr(dctx), ptr(dOT), ptr(lse), ptr(D), dqkv.data_ptr(), dqkv.data_ptr() + H * es,
+                                            dqkv.data_ptr() + 2 * H * es, 3 * H, B, L, nh, dh, scale,
+                                            L * 3 * H, dh, 3 * H, L * H, dh, H, st), "mh_attention_stream_bwd_ex")
         return dqkv, None, None, None, None
 
     @staticmethod
