@@ -34,6 +34,28 @@ __global__ void transpose_kernel(const T* __restrict__ in, int64_t ld_in, int64_
   }
 }
 
+// bf16 fast path: 64 x 64 tiles, 16-byte loads along the input rows and 16-byte stores along the output rows
+// (rows % 64 == 0, cols % 64 == 0, ld_in / ld_out / strides multiples of 8)
+__global__ __launch_bounds__(256) void transpose64_kernel(const bf16* __restrict__ in, int64_t ld_in, int64_t s_in, bf16* __restrict__ out,
+                                                          int64_t ld_out, int64_t s_out) {
+  __shared__ bf16 tile[64][64 + 8];
+  const bf16* src = in + (int64_t)blockIdx.z * s_in;
+  bf16* dst = out + (int64_t)blockIdx.z * s_out;
+  const int c0 = blockIdx.x * 64, r0 = blockIdx.y * 64;
+  for (int i = threadIdx.x; i < 64 * 8; i += 256) {
+    const int r = i >> 3, c = i & 7;
+    *reinterpret_cast<f32x4*>(&tile[r][c * 8]) = *reinterpret_cast<const f32x4*>(src + (int64_t)(r0 + r) * ld_in + c0 + c * 8);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 64 * 8; i += 256) {
+    const int c = i >> 3, rc = i & 7;         // output row c0 + c, output columns r0 + 8 rc .. + 7
+    bf16x8 v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = tile[8 * rc + j][c];
+    *reinterpret_cast<bf16x8*>(dst + (int64_t)(c0 + c) * ld_out + r0 + 8 * rc) = v;
+  }
+}
+
 // mode 0: tokens [B*L, ld] (head h at cols [h*dh,(h+1)*dh)) -> heads [B, nh, L, dh]
 // mode 1: heads -> tokens;  mode 2: tokens -> heads transposed [B, nh, dh, L];  mode 3: as mode 2 with the positions of
 // every group of 16 stored as 0-3, 8-11, 4-7, 12-15 (the streaming attention kernels' "P-operand" order)
@@ -135,21 +157,26 @@ __global__ void colsum_partial_kernel(const T* __restrict__ in_all, int64_t ld, 
   if (rl == 0 && c < cols) part[(int64_t)blockIdx.y * cols + c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 __global__ void colsum_final_kernel(const float* __restrict__ part_all, int P, int cols, float* __restrict__ out_all, int accumulate) {
+  // block = 64 columns x 4 partial-lanes; every lane keeps four loads in flight; fixed summation order -> reproducible
   const float* part = part_all + (int64_t)blockIdx.y * P * cols;
   float* out = out_all + (int64_t)blockIdx.y * cols;
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= cols) return;
-  // eight independent partial sums keep eight loads in flight (a single dependent chain pays one memory
-  // latency per partial); the summation order is fixed, so the result is reproducible
-  float s8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  int p = 0;
-  for (; p + 8 <= P; p += 8) {
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), pl = threadIdx.x >> 6;
+  __shared__ float red[4][64];
+  float s4[4] = {0.f, 0.f, 0.f, 0.f};
+  if (c < cols) {
+    int p = pl;
+    for (; p + 12 < P; p += 16) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) s8[j] += part[(int64_t)(p + j) * cols + c];
+      for (int j = 0; j < 4; ++j) s4[j] += part[(int64_t)(p + 4 * j) * cols + c];
+    }
+    for (; p < P; p += 4) s4[0] += part[(int64_t)p * cols + c];
   }
-  for (; p < P; ++p) s8[0] += part[(int64_t)p * cols + c];
-  const float s = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
-  out[c] = accumulate ? out[c] + s : s;
+  red[pl][threadIdx.x & 63] = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+  __syncthreads();
+  if (pl == 0 && c < cols) {
+    const float s = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    out[c] = accumulate ? out[c] + s : s;
+  }
 }
 
 // 16-byte loads: a wave covers 8 x 64 = 512 consecutive columns of one row per instruction (cols % 8 == 0, ld % 8 == 0)
@@ -476,8 +503,15 @@ __global__ void sum_partials_kernel(const float* __restrict__ partial, int n, fl
 extern "C" int mh_transpose(const void* in, int64_t ld_in, int64_t stride_in, void* out, int64_t ld_out, int64_t stride_out,
                             int rows, int cols, int batch, int dtype, mh_stream_t stream) {
   MH_CHECK_ARG(in && out && rows > 0 && cols > 0 && batch > 0 && batch <= 65535, "transpose: bad arguments");
-  dim3 grid((cols + 31) / 32, (rows + 31) / 32, batch);
   hipStream_t s = (hipStream_t)stream;
+  if (dtype == MH_BF16 && rows % 64 == 0 && cols % 64 == 0 && ld_in % 8 == 0 && ld_out % 8 == 0 && stride_in % 8 == 0 && stride_out % 8 == 0 &&
+      (reinterpret_cast<uintptr_t>(in) & 15) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0) {
+    MH_LAUNCH(transpose64_kernel, dim3(cols / 64, rows / 64, batch), dim3(256), 0, s, (const bf16*)in, ld_in, stride_in, (bf16*)out, ld_out,
+              stride_out);
+    MH_CHECK_LAUNCH();
+    return MH_OK;
+  }
+  dim3 grid((cols + 31) / 32, (rows + 31) / 32, batch);
   MH_DTYPE_SWITCH(dtype,
                   MH_LAUNCH((transpose_kernel<bf16>), grid, dim3(256), 0, s, (const bf16*)in, ld_in, stride_in, (bf16*)out, ld_out, stride_out, rows, cols),
                   MH_LAUNCH((transpose_kernel<float>), grid, dim3(256), 0, s, (const float*)in, ld_in, stride_in, (float*)out, ld_out, stride_out, rows, cols),
@@ -531,7 +565,7 @@ extern "C" int mh_col_sum(const void* in, int64_t ld, int64_t rows, int cols, in
                     MH_LAUNCH((colsum_partial_kernel<float>), grid, dim3(256), 0, s, (const float*)in, ld, rows, cols, partial, stride_in), "col_sum");
   }
   MH_CHECK_LAUNCH();
-  MH_LAUNCH(colsum_final_kernel, dim3((cols + 255) / 256, batch), dim3(256), 0, s, partial, n_partial, cols, out, accumulate);
+  MH_LAUNCH(colsum_final_kernel, dim3((cols + 63) / 64, batch), dim3(256), 0, s, partial, n_partial, cols, out, accumulate);
   MH_CHECK_LAUNCH();
   return MH_OK;
 }
