@@ -140,12 +140,13 @@ int mh_attention_stream_fwd_lse(const void* q, const void* k, const void* vt_per
                                 int B, int L, int nh, int dh, float scale, float* lse2, mh_stream_t stream);
 /* Fused attention backward (bf16; same shape limits as the streaming forward).  q, k, v, dO: [B, nh, L, dh] rows;
  * qT_perm, kT_perm, dOT_perm: [B, nh, dh, L] with the positions of every group of 16 permuted (mh_head_permute
- * mode 3); lse2 from the forward; D[b, h, l] = sum_d dO o O (mh_attention_bwd_rowdot).  dq, dk, dv are written
+ * mode 3); o = the forward output in dO's layout; lse2 from the forward; D = [B, nh, L] fp32 scratch (the dQ kernel
+ * writes D[b, h, l] = sum_d dO o O there, the dK/dV kernel reads it).  dq, dk, dv are written
  * token-major: element (token, head, d) at ptr[token * ld_d + head * dh + d] - e.g. the three column blocks of a
  * [B L, 3H] gradient of the fused QKV projection.  Replaces autograd through BertSelfAttention (the encoder that
  * models/network.py:151 calls) inside training_losses (models/diffusion.py:594-699). */
 int mh_attention_stream_bwd(const void* q, const void* k, const void* v, const void* qT_perm, const void* kT_perm,
-                            const void* dO, const void* dOT_perm, const float* lse2, const float* D, void* dq, void* dk,
+                            const void* dO, const void* dOT_perm, const void* o, const float* lse2, float* D, void* dq, void* dk,
                             void* dv, int64_t ld_d, int B, int L, int nh, int dh, float scale, mh_stream_t stream);
 /* The same two entry points for row operands that are NOT [B, nh, L, dh] tensors: row r of (batch b, head h) of
  * q / k (/ v) starts at ptr + b * batch_stride + h * head_stride + r * row_stride elements (all multiples of 8), e.g.
@@ -154,7 +155,7 @@ int mh_attention_stream_fwd_ex(const void* q, const void* k, const void* vt_perm
                                int B, int L, int nh, int dh, float scale, float* lse2, int64_t qk_batch_stride,
                                int64_t qk_head_stride, int64_t qk_row_stride, mh_stream_t stream);
 int mh_attention_stream_bwd_ex(const void* q, const void* k, const void* v, const void* qT_perm, const void* kT_perm,
-                               const void* dO, const void* dOT_perm, const float* lse2, const float* D, void* dq, void* dk,
+                               const void* dO, const void* dOT_perm, const void* o, const float* lse2, float* D, void* dq, void* dk,
                                void* dv, int64_t ld_d, int B, int L, int nh, int dh, float scale, int64_t qkv_batch_stride,
                                int64_t qkv_head_stride, int64_t qkv_row_stride, int64_t do_batch_stride,
                                int64_t do_head_stride, int64_t do_row_stride, mh_stream_t stream);
@@ -302,8 +303,11 @@ int mh_sqdiff_mean(const float* a, const float* b, float scale_a, float* out, in
 int mh_sqdiff_bwd(const float* a, const float* b, float scale_a, const float* grad, float* da, float* db, int accumulate, int B,
                   int64_t per_batch, mh_stream_t stream);
 int mh_add_inplace(void* dst, const void* src, int64_t n, int dtype, mh_stream_t stream);
-/* table[ids[n], :] += src[n, :]  (word_embedding gradient; fp32 atomics) */
-int mh_scatter_add_rows(const float* src, const int32_t* ids, float* table, int64_t n, int E, int V, mh_stream_t stream);
+/* table[ids[n], :] += src[n, :]  (word_embedding gradient): chunked partial sums + ordered fold, no atomics,
+ * reproducible; workspace of mh_scatter_add_rows_workspace_bytes(E, V) bytes */
+int mh_scatter_add_rows(const float* src, const int32_t* ids, float* table, int64_t n, int E, int V, void* workspace,
+                        size_t workspace_bytes, mh_stream_t stream);
+size_t mh_scatter_add_rows_workspace_bytes(int E, int V);
 /* q_sample backward: dst[b,i] (+)= src[b,i] * (mask[token] == 0 ? 1 : scale[b]) */
 /* out[i] = sum_s in[s * n + i] (fp32, n % 4 == 0): folds the split-K partials of a weight-gradient GEMM
  * (mh_gemm_batched over K slices), summation order fixed -> reproducible gradients. */
@@ -359,6 +363,11 @@ int mh_step_end(mh_loop_state* state, mh_stream_t stream);
  * global_load_lds; 2 (default) = big tile chosen per shape; 3 = always 256x128 (4 waves, 3-stage
  * global_load_lds ring); 4 = always 256x256 (8 waves, 4-stage ring). */
 int mh_gemm_set_variant(int variant);
+/* out = act(A W^T + bias) and pre_out = A W^T + bias in one pass (bf16 row-major; shapes the big-tile kernel
+ * serves: N % 8 == 0, K % 32 == 0, lda / ldw / ldo % 8 == 0; error otherwise).  Forward of dense + GELU / tanh under
+ * autograd: the backward needs the pre-activation (training_losses, models/diffusion.py:594-699). */
+int mh_gemm_bias_act_pre(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, void* pre_out,
+                         void* out, int64_t ldo, int64_t M, int N, int K, int act, mh_stream_t stream);
 /* out = LayerNorm(A W^T + bias + residual) * gamma + beta, bf16, the whole row normalised inside the
  * GEMM epilogue (one block owns all N columns: N must be 128, 256 or 512 - see ..._supported).
  * Replaces BertSelfOutput / BertOutput (dense -> LayerNorm(hidden + input)) of the encoder that

@@ -76,9 +76,9 @@ SIGNATURES = {
     "mh_attention_stream_fwd": (INT, [VP, VP, VP, VP, I64, INT, INT, INT, INT, INT, F32, VP]),
     "mh_attention_stream_supported": (INT, [INT, INT]),
     "mh_attention_stream_fwd_lse": (INT, [VP, VP, VP, VP, I64, INT, INT, INT, INT, INT, F32, VP, VP]),
-    "mh_attention_stream_bwd": (INT, [VP, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP, I64, INT, INT, INT, INT, F32, VP]),
+    "mh_attention_stream_bwd": (INT, [VP, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP, I64, INT, INT, INT, INT, F32, VP]),
     "mh_attention_stream_fwd_ex": (INT, [VP, VP, VP, VP, I64, INT, INT, INT, INT, INT, F32, VP, I64, I64, I64, VP]),
-    "mh_attention_stream_bwd_ex": (INT, [VP, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP, I64, INT, INT, INT, INT, F32, I64, I64, I64, I64, I64, I64, VP]),
+    "mh_attention_stream_bwd_ex": (INT, [VP, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP, I64, INT, INT, INT, INT, F32, I64, I64, I64, I64, I64, I64, VP]),
     "mh_attention_bwd_rowdot": (INT, [VP, VP, I64, VP, INT, INT, INT, INT, VP]),
     "mh_attention_set_stream": (INT, [INT]),
     "mh_attention_stream_enabled": (INT, []),
@@ -112,7 +112,8 @@ SIGNATURES = {
     "mh_sqdiff_mean": (INT, [VP, VP, F32, VP, INT, I64, VP]),
     "mh_sqdiff_bwd": (INT, [VP, VP, F32, VP, VP, VP, INT, INT, I64, VP]),
     "mh_add_inplace": (INT, [VP, VP, I64, INT, VP]),
-    "mh_scatter_add_rows": (INT, [VP, VP, VP, I64, INT, INT, VP]),
+    "mh_scatter_add_rows": (INT, [VP, VP, VP, I64, INT, INT, VP, C.c_size_t, VP]),
+    "mh_scatter_add_rows_workspace_bytes": (C.c_size_t, [INT, INT]),
     "mh_sum_slices": (INT, [VP, INT, I64, VP, VP]),
     "mh_scale_rows": (INT, [VP, VP, VP, VP, INT, INT, I64, INT, VP]),
     "mh_adamw_ema_step": (INT, [VP, VP, INT, C.POINTER(OptHParams), VP]),
@@ -121,6 +122,7 @@ SIGNATURES = {
     "mh_step_end": (INT, [VP, VP]),
     "mh_gemm_set_variant": (INT, [INT]),
     "mh_gemm_set_stagger": (INT, [INT]),
+    "mh_gemm_bias_act_pre": (INT, [VP, I64, VP, I64, VP, VP, VP, I64, I64, INT, INT, INT, VP]),
     "mh_gemm_bias_res_ln": (INT, [VP, I64, INT, VP, I64, INT, VP, VP, I64, INT, VP, VP, F32, VP, I64, INT, I64, INT, INT, VP]),
     "mh_gemm_bias_res_ln_supported": (INT, [INT]),
     "mh_denoiser_set_fuse_ln": (INT, [INT]),

@@ -67,8 +67,9 @@ __device__ __forceinline__ bf16x8 cvt8(const f32x16& v, int off) {
 template <int DH>
 __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K,
                                                           const bf16* __restrict__ V, const bf16* __restrict__ KT,
-                                                          const bf16* __restrict__ dO, const float* __restrict__ lse2,
-                                                          const float* __restrict__ Dv, bf16* __restrict__ dQ, int64_t ld_dq,
+                                                          const bf16* __restrict__ dO, const bf16* __restrict__ O,
+                                                          const float* __restrict__ lse2, float* __restrict__ Dv,
+                                                          bf16* __restrict__ dQ, int64_t ld_dq,
                                                           int L, int nh, int nbh, float scale, float scale_log2e, RowLayout lq_,
                                                           RowLayout lo_) {
   constexpr int NW = 8;
@@ -118,7 +119,16 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const bf16* __restrict
         dof[ks] = *reinterpret_cast<const bf16x8*>(dO + lo_.at(bh, nh, q0 + lq) + 16 * ks + 8 * h);
       }
       lse_q = lse2[qrow];
-      D_q = Dv[qrow];
+      // D[q] = sum_d dO[q][d] O[q][d]: each lane half holds half of the head dim of its query; kept for the dK/dV kernel
+      D_q = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const bf16x8 of = *reinterpret_cast<const bf16x8*>(O + lo_.at(bh, nh, q0 + lq) + 16 * ks + 8 * h);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) D_q += (float)dof[ks][j] * (float)of[j];
+      }
+      D_q += __shfl_xor(D_q, 32, 64);
+      if (h == 0) Dv[qrow] = D_q;
 #pragma unroll
       for (int i = 0; i < DT; ++i)
 #pragma unroll
@@ -326,8 +336,8 @@ __global__ void attn_bwd_rowdot_kernel(const bf16* __restrict__ dctx, const bf16
 }
 
 template <int DH>
-int launch_bwd(const bf16* q, const bf16* k, const bf16* v, const bf16* qT, const bf16* kT, const bf16* dO, const bf16* dOT,
-               const float* lse2, const float* Dv, bf16* dq, bf16* dk, bf16* dv, int64_t ld, int B, int L, int nh, float scale,
+int launch_bwd(const bf16* q, const bf16* k, const bf16* v, const bf16* qT, const bf16* kT, const bf16* dO, const bf16* dOT, const bf16* o,
+               const float* lse2, float* Dv, bf16* dq, bf16* dk, bf16* dv, int64_t ld, int B, int L, int nh, float scale,
                RowLayout lqkv, RowLayout ldo, hipStream_t s) {
   constexpr int ST = SKB * DH * 2;
   constexpr int bytes_dq = 2 * 3 * ST, bytes_dkv = 2 * (4 * ST + 1024);
@@ -342,7 +352,7 @@ int launch_bwd(const bf16* q, const bf16* k, const bf16* v, const bf16* qT, cons
   const int nbh = B * nh, nitems = nbh * (L / 256);
   const dim3 grid((unsigned)(nitems < cus ? nitems : cus)), block(512);
   const float sl2 = scale * 1.4426950408889634f;
-  MH_LAUNCH((attn_bwd_dq_kernel<DH>), grid, block, bytes_dq, s, q, k, v, kT, dO, lse2, Dv, dq, ld, L, nh, nbh, scale, sl2, lqkv, ldo);
+  MH_LAUNCH((attn_bwd_dq_kernel<DH>), grid, block, bytes_dq, s, q, k, v, kT, dO, o, lse2, Dv, dq, ld, L, nh, nbh, scale, sl2, lqkv, ldo);
   MH_CHECK_LAUNCH();
   MH_LAUNCH((attn_bwd_dkv_kernel<DH>), grid, block, bytes_dkv, s, q, k, v, qT, dO, dOT, lse2, Dv, dk, dv, ld, L, nh, nbh, scale, sl2, lqkv, ldo);
   MH_CHECK_LAUNCH();
@@ -362,34 +372,34 @@ extern "C" int mh_attention_bwd_rowdot(const void* dctx, const void* ctx, int64_
 }
 
 extern "C" int mh_attention_stream_bwd_ex(const void* q, const void* k, const void* v, const void* qT_perm, const void* kT_perm,
-                                          const void* dO, const void* dOT_perm, const float* lse2, const float* D, void* dq, void* dk,
+                                          const void* dO, const void* dOT_perm, const void* o, const float* lse2, float* D, void* dq, void* dk,
                                           void* dv, int64_t ld_d, int B, int L, int nh, int dh, float scale, int64_t qkv_batch_stride,
                                           int64_t qkv_head_stride, int64_t qkv_row_stride, int64_t do_batch_stride,
                                           int64_t do_head_stride, int64_t do_row_stride, mh_stream_t stream);
 
 extern "C" int mh_attention_stream_bwd(const void* q, const void* k, const void* v, const void* qT_perm, const void* kT_perm,
-                                       const void* dO, const void* dOT_perm, const float* lse2, const float* D, void* dq, void* dk,
+                                       const void* dO, const void* dOT_perm, const void* o, const float* lse2, float* D, void* dq, void* dk,
                                        void* dv, int64_t ld_d, int B, int L, int nh, int dh, float scale, mh_stream_t stream) {
   const int64_t sB = (int64_t)nh * L * dh, sH = (int64_t)L * dh;
-  return mh_attention_stream_bwd_ex(q, k, v, qT_perm, kT_perm, dO, dOT_perm, lse2, D, dq, dk, dv, ld_d, B, L, nh, dh, scale, sB, sH, dh,
+  return mh_attention_stream_bwd_ex(q, k, v, qT_perm, kT_perm, dO, dOT_perm, o, lse2, D, dq, dk, dv, ld_d, B, L, nh, dh, scale, sB, sH, dh,
                                     sB, sH, dh, stream);
 }
 
 extern "C" int mh_attention_stream_bwd_ex(const void* q, const void* k, const void* v, const void* qT_perm, const void* kT_perm,
-                                          const void* dO, const void* dOT_perm, const float* lse2, const float* D, void* dq, void* dk,
+                                          const void* dO, const void* dOT_perm, const void* o, const float* lse2, float* D, void* dq, void* dk,
                                           void* dv, int64_t ld_d, int B, int L, int nh, int dh, float scale, int64_t qsB, int64_t qsH,
                                           int64_t qld, int64_t osB, int64_t osH, int64_t old_, mh_stream_t stream) {
   MH_CHECK_ARG(qsB % 8 == 0 && qsH % 8 == 0 && qld % 8 == 0 && osB % 8 == 0 && osH % 8 == 0 && old_ % 8 == 0 && qld >= dh && old_ >= dh,
                "attention_stream_bwd: row strides must be multiples of 8 elements");
   const RowLayout lqkv{qsB, qsH, qld}, ldo{osB, osH, old_};
-  MH_CHECK_ARG(q && k && v && qT_perm && kT_perm && dO && dOT_perm && lse2 && D && dq && dk && dv, "attention_stream_bwd: null pointer");
+  MH_CHECK_ARG(q && k && v && qT_perm && kT_perm && dO && dOT_perm && o && lse2 && D && dq && dk && dv, "attention_stream_bwd: null pointer");
   MH_CHECK_ARG(B > 0 && nh > 0 && L >= 512 && L % 256 == 0 && (dh == 32 || dh == 64),
                "attention_stream_bwd: needs seq_len %% 256 == 0, seq_len >= 512 and head dim 32 or 64 (got L=%d dh=%d)", L, dh);
   MH_CHECK_ARG(ld_d % 4 == 0, "attention_stream_bwd: ld_d must be a multiple of 4");
   hipStream_t s = (hipStream_t)stream;
   if (dh == 64)
     return launch_bwd<64>((const bf16*)q, (const bf16*)k, (const bf16*)v, (const bf16*)qT_perm, (const bf16*)kT_perm, (const bf16*)dO,
-                          (const bf16*)dOT_perm, lse2, D, (bf16*)dq, (bf16*)dk, (bf16*)dv, ld_d, B, L, nh, scale, lqkv, ldo, s);
+                          (const bf16*)dOT_perm, (const bf16*)o, lse2, D, (bf16*)dq, (bf16*)dk, (bf16*)dv, ld_d, B, L, nh, scale, lqkv, ldo, s);
   return launch_bwd<32>((const bf16*)q, (const bf16*)k, (const bf16*)v, (const bf16*)qT_perm, (const bf16*)kT_perm, (const bf16*)dO,
-                        (const bf16*)dOT_perm, lse2, D, (bf16*)dq, (bf16*)dk, (bf16*)dv, ld_d, B, L, nh, scale, lqkv, ldo, s);
+                        (const bf16*)dOT_perm, (const bf16*)o, lse2, D, (bf16*)dq, (bf16*)dk, (bf16*)dv, ld_d, B, L, nh, scale, lqkv, ldo, s);
 }

@@ -31,6 +31,7 @@ struct GemmArgs {
   int act;
   // QKV scatter
   void* q; void* k; void* vt;
+  void* pre_out;   // EPI 0 with an activation (big tile): also store the pre-activation (bias added) here, same layout as out
   int L, H, nh, dh;
   // EPI 2 (nearest-embedding scores): aux[col] = |W_col|^2, rown[row] = |x_row|^2, partial best per (row, slot)
   const float* aux; const float* rown; float* pbest; int32_t* pidx; int nslots;
@@ -827,6 +828,10 @@ __global__ __launch_bounds__(C::THREADS, C::STAGE * C::NST <= 80 * 1024 ? 2 : 1)
 #pragma unroll
               for (int e = 0; e < 8; ++e) v[e] = acc[i][2 * qh + (e >> 2)][e & 3] + bv[e];
               if constexpr (ACT != MH_ACT_NONE) {
+                if (g.pre_out) {   // training: the backward needs the pre-activation
+                  const int64_t po = g.o_panel ? ((int64_t)(col >> 5) * g.ldo + row) * 32 + (col & 31) : row * g.ldo + col;
+                  store8(reinterpret_cast<bf16*>(g.pre_out) + (int64_t)blockIdx.y * g.sO + po, v);
+                }
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = apply_act<bf16>(v[e], ACT);
               }
@@ -1033,6 +1038,19 @@ extern "C" int mh_gemm_bias_res_ln(const void* A, int64_t lda, int a_panel, cons
   if (N == 128) return launch_big<CfgStd, 3>(g, s, 1);
   if (N == 256) return launch_big<CfgWide, 3>(g, s, 1);
   return launch_big<CfgRow, 3>(g, s, 1);
+}
+
+// act(A W^T + bias) -> out AND A W^T + bias -> pre_out in one pass (bf16, row-major, big-tile shapes only): the forward of
+// a dense + activation layer under autograd, whose backward needs the pre-activation (training.py:_Linear)
+extern "C" int mh_gemm_bias_act_pre(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, void* pre_out,
+                                    void* out, int64_t ldo, int64_t M, int N, int K, int act, mh_stream_t stream) {
+  MH_CHECK_ARG(A && W && out && pre_out, "gemm_bias_act_pre: null pointer");
+  MH_CHECK_ARG(M > 0 && N > 0 && act > MH_ACT_NONE && act <= MH_ACT_SILU, "gemm_bias_act_pre: bad problem / activation");
+  GemmArgs g{};
+  g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.bias = bias; g.ldr = 8; g.out = out; g.ldo = ldo;
+  g.M = M; g.N = N; g.K = K; g.act = act; g.pre_out = pre_out;
+  MH_CHECK_ARG(g_variant >= 2 && lda % 8 == 0 && ldw % 8 == 0 && big_tile_ok(g), "gemm_bias_act_pre: shape not served by the big-tile kernel");
+  return launch<0>(g, MH_BF16, (hipStream_t)stream);
 }
 
 extern "C" int mh_gemm_batched(const void* A, int64_t lda, int64_t strideA, const void* W, int64_t ldw, int64_t strideW,

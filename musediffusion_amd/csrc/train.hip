@@ -390,19 +390,35 @@ __global__ void ce_bwd_kernel(const float* __restrict__ logits, int64_t ld, cons
 
 // ------------------------------------------------------------------ squared error: per-batch mean and gradient
 // out[b] = mean_i (scale_a * a[b,i] - b[b,i])^2        (b may be NULL = 0)
-__global__ void sqdiff_mean_kernel(const float* __restrict__ a, const float* __restrict__ bb, float scale_a, float* __restrict__ out,
-                                   int64_t per_batch) {
-  __shared__ float red[4];
+__global__ __launch_bounds__(1024) void sqdiff_mean_kernel(const float* __restrict__ a, const float* __restrict__ bb, float scale_a,
+                                                           float* __restrict__ out, int64_t per_batch) {
+  __shared__ float red[16];
   const int b = blockIdx.x;
-  float s = 0.f;
-  for (int64_t i = threadIdx.x; i < per_batch; i += blockDim.x) {
-    const float d = scale_a * a[(int64_t)b * per_batch + i] - (bb ? bb[(int64_t)b * per_batch + i] : 0.f);
-    s += d * d;
+  const float* pa = a + (int64_t)b * per_batch;
+  const float* pb = bb ? bb + (int64_t)b * per_batch : nullptr;
+  float s4[4] = {0.f, 0.f, 0.f, 0.f};
+  if (per_batch % 4 == 0 && (reinterpret_cast<uintptr_t>(pa) & 15) == 0 && (!pb || (reinterpret_cast<uintptr_t>(pb) & 15) == 0)) {
+    for (int64_t i = (int64_t)threadIdx.x * 4; i < per_batch; i += (int64_t)blockDim.x * 4) {
+      const f32x4 x = *reinterpret_cast<const f32x4*>(pa + i);
+      f32x4 y = {0.f, 0.f, 0.f, 0.f};
+      if (pb) y = *reinterpret_cast<const f32x4*>(pb + i);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { const float d = scale_a * x[e] - y[e]; s4[e] += d * d; }
+    }
+  } else {
+    for (int64_t i = threadIdx.x; i < per_batch; i += blockDim.x) {
+      const float d = scale_a * pa[i] - (pb ? pb[i] : 0.f);
+      s4[0] += d * d;
+    }
   }
-  s = wave_sum(s);
+  float s = wave_sum((s4[0] + s4[1]) + (s4[2] + s4[3]));
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x == 0) out[b] = ((red[0] + red[1]) + (red[2] + red[3])) / (float)per_batch;
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += red[w];
+    out[b] = t / (float)per_batch;
+  }
 }
 // da[b,i] (+)= g[b] * 2 * scale_a * (scale_a*a - b) / per_batch ;  db = -da / scale_a (optional)
 __global__ void sqdiff_bwd_kernel(const float* __restrict__ a, const float* __restrict__ bb, float scale_a, const float* __restrict__ g,
@@ -423,13 +439,49 @@ __global__ void add_inplace_kernel(T* __restrict__ dst, const T* __restrict__ sr
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
     dst[i] = from_f32<T>(to_f32(dst[i]) + to_f32(src[i]));
 }
-__global__ void scatter_add_rows_kernel(const float* __restrict__ src, const int32_t* __restrict__ ids, float* __restrict__ table,
-                                        int64_t n, int E, int V) {
-  const int64_t total = n * E;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    int id = ids[i / E];
-    id = id < 0 ? 0 : (id >= V ? V - 1 : id);
-    atomicAdd(table + (int64_t)id * E + (i % E), src[i]);
+// table[v, :] += sum of the rows src[t, :] with ids[t] == v  (embedding-weight gradient), without atomics: block
+// (v, chunk) scans its chunk of the ids 64 at a time (ballot) and adds the matching rows in index order into
+// partial[chunk][v][:]; a second kernel folds the chunks in order.  Frequent tokens (padding is most of a batch) are
+// spread over the chunks, and the summation order does not change from run to run.
+__global__ __launch_bounds__(256) void scatter_rows_partial_kernel(const float* __restrict__ src, const int32_t* __restrict__ ids,
+                                                                   float* __restrict__ partial, int64_t n, int E, int V, int64_t chunk) {
+  extern __shared__ float red[];   // [4][256]
+  const int v = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t tb = (int64_t)blockIdx.y * chunk, te = tb + chunk < n ? tb + chunk : n;
+  float* dst = partial + ((int64_t)blockIdx.y * V + v) * E;
+  for (int e0 = 0; e0 < E; e0 += 256) {        // 4 columns per lane per pass
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int64_t t0 = tb + (int64_t)wave * 64; t0 < te; t0 += 256) {
+      int id = -1;
+      if (t0 + lane < te) { id = ids[t0 + lane]; id = id < 0 ? 0 : (id >= V ? V - 1 : id); }
+      unsigned long long m = __builtin_amdgcn_ballot_w64(id == v);
+      while (m) {
+        const int j = __builtin_ctzll(m);
+        m &= m - 1;
+        const float* row = src + (t0 + j) * E + e0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          if (e0 + lane + 64 * c < E) acc[c] += row[lane + 64 * c];
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) red[wave * 256 + lane + 64 * c] = acc[c];
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int o = lane + 64 * c;
+        if (e0 + o < E) dst[e0 + o] = (red[o] + red[256 + o]) + (red[512 + o] + red[768 + o]);
+      }
+    }
+    __syncthreads();
+  }
+}
+__global__ void scatter_rows_final_kernel(const float* __restrict__ partial, float* __restrict__ table, int nchunks, int64_t VE) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < VE; i += (int64_t)gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (int c = 0; c < nchunks; ++c) s += partial[(int64_t)c * VE + i];
+    table[i] += s;
   }
 }
 // q_sample backward (diffusion.py:245-255): dst[b,i] (+)= src[b,i] * (mask[token] == 0 ? 1 : scale[b])
@@ -661,7 +713,7 @@ extern "C" int mh_cross_entropy_bwd(const float* logits, int64_t ld, const int32
 
 extern "C" int mh_sqdiff_mean(const float* a, const float* b, float scale_a, float* out, int B, int64_t per_batch, mh_stream_t stream) {
   MH_CHECK_ARG(a && out && B > 0 && per_batch > 0, "sqdiff_mean: bad arguments");
-  MH_LAUNCH(sqdiff_mean_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, a, b, scale_a, out, per_batch);
+  MH_LAUNCH(sqdiff_mean_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, a, b, scale_a, out, per_batch);
   MH_CHECK_LAUNCH();
   return MH_OK;
 }
@@ -683,9 +735,18 @@ extern "C" int mh_add_inplace(void* dst, const void* src, int64_t n, int dtype, 
   return MH_OK;
 }
 
-extern "C" int mh_scatter_add_rows(const float* src, const int32_t* ids, float* table, int64_t n, int E, int V, mh_stream_t stream) {
-  MH_CHECK_ARG(src && ids && table && n > 0 && E > 0 && V > 0, "scatter_add_rows: bad arguments");
-  MH_LAUNCH(scatter_add_rows_kernel, dim3(tgrid(n * E)), dim3(TB), 0, (hipStream_t)stream, src, ids, table, n, E, V);
+extern "C" size_t mh_scatter_add_rows_workspace_bytes(int E, int V) { return (size_t)32 * V * E * sizeof(float); }
+
+extern "C" int mh_scatter_add_rows(const float* src, const int32_t* ids, float* table, int64_t n, int E, int V, void* workspace,
+                                   size_t workspace_bytes, mh_stream_t stream) {
+  MH_CHECK_ARG(src && ids && table && workspace && n > 0 && E > 0 && V > 0, "scatter_add_rows: bad arguments");
+  MH_CHECK_ARG(workspace_bytes >= mh_scatter_add_rows_workspace_bytes(E, V), "scatter_add_rows: workspace too small");
+  const int nchunks = n >= 32 * 256 ? 32 : (int)((n + 255) / 256);
+  const int64_t chunk = ((n + nchunks - 1) / nchunks + 63) / 64 * 64;
+  hipStream_t s = (hipStream_t)stream;
+  MH_LAUNCH(scatter_rows_partial_kernel, dim3(V, nchunks), dim3(256), 4 * 256 * sizeof(float), s, src, ids, (float*)workspace, n, E, V, chunk);
+  MH_CHECK_LAUNCH();
+  MH_LAUNCH(scatter_rows_final_kernel, dim3(tgrid((int64_t)V * E)), dim3(TB), 0, s, (const float*)workspace, table, nchunks, (int64_t)V * E);
   MH_CHECK_LAUNCH();
   return MH_OK;
 }

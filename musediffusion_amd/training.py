@@ -118,13 +118,20 @@ class _Linear(Function):
         Np = ops.pad64(N)
         Wc = ops.cast_pad(W.detach(), Kp, dt)                         # [N, Kp]
         pre = _zeros(M, Np, dt, x.device, N)
-        _gemm(x, Wc, b.detach() if b is not None else None, dt, N, Kp, out=pre, residual=residual if act is None else None)
-        if act is None:
-            y = pre
-        else:
-            y = torch.empty_like(pre)
-            check(lib().mh_act_fwd(ptr(pre), ptr(y), pre.numel(), ops.ACT[act], dt, current_stream()), "mh_act_fwd")
+        fused_act = act is not None and dt == ops.MH_BF16 and N == Np and N % 8 == 0 and Kp % 32 == 0
+        if fused_act:      # one kernel writes the pre-activation (kept for the backward) and the activation
             assert residual is None
+            y = torch.empty_like(pre)
+            check(lib().mh_gemm_bias_act_pre(ptr(x), Kp, ptr(Wc), Kp, ptr(b.detach()) if b is not None else None, ptr(pre), ptr(y), Np,
+                                             M, N, Kp, ops.ACT[act], current_stream()), "mh_gemm_bias_act_pre")
+        else:
+            _gemm(x, Wc, b.detach() if b is not None else None, dt, N, Kp, out=pre, residual=residual if act is None else None)
+            if act is None:
+                y = pre
+            else:
+                y = torch.empty_like(pre)
+                check(lib().mh_act_fwd(ptr(pre), ptr(y), pre.numel(), ops.ACT[act], dt, current_stream()), "mh_act_fwd")
+                assert residual is None
         ctx.save_for_backward(x, Wc, pre if act is not None else None)
         ctx.meta = (act, dt, N, K, Kp, Np, residual is not None, b is not None)
         return y
@@ -252,11 +259,10 @@ class _Attention(Function):
             check(L_.mh_head_permute(src.data_ptr() + col0 * es, ptr(t), ld, B, L, nh, dh, 3, dt, st), "mh_head_permute")
             return t
         qT, kT, dOT = transposed(qkv, 0, 3 * H), transposed(qkv, H, 3 * H), transposed(dctx, 0, H)
-        D = torch.empty(B * nh * L, device=dev, dtype=torch.float32)
-        check(L_.mh_attention_bwd_rowdot(ptr(dctx), ptr(out), H, ptr(D), B, L, nh, dh, st), "mh_attention_bwd_rowdot")
+        D = torch.empty(B * nh * L, device=dev, dtype=torch.float32)      # scratch: rowsum(dO o O), produced by the dQ kernel
         dqkv = torch.empty(B * L, 3 * H, device=dev, dtype=td)
         check(L_.mh_attention_stream_bwd_ex(qkv.data_ptr(), qkv.data_ptr() + H * es, qkv.data_ptr() + 2 * H * es, ptr(qT), ptr(kT),
-                                            ptr(dctx), ptr(dOT), ptr(lse), ptr(D), dqkv.data_ptr(), dqkv.data_ptr() + H * es,
+                                            ptr(dctx), ptr(dOT), ptr(out), ptr(lse), ptr(D), dqkv.data_ptr(), dqkv.data_ptr() + H * es,
                                             dqkv.data_ptr() + 2 * H * es, 3 * H, B, L, nh, dh, scale,
                                             L * 3 * H, dh, 3 * H, L * H, dh, H, st), "mh_attention_stream_bwd_ex")
         return dqkv, None, None, None, None
@@ -326,7 +332,9 @@ class _Embed(Function):
         V, E = ctx.shape
         dW = torch.zeros(V, E, device=g.device, dtype=torch.float32)
         g = g.contiguous()
-        check(lib().mh_scatter_add_rows(ptr(g), ptr(ids32), ptr(dW), ids32.numel(), E, V, current_stream()), "mh_scatter_add_rows")
+        ws = torch.empty(int(lib().mh_scatter_add_rows_workspace_bytes(E, V)), device=g.device, dtype=torch.uint8)
+        check(lib().mh_scatter_add_rows(ptr(g), ptr(ids32), ptr(dW), ids32.numel(), E, V, ptr(ws), ws.numel(), current_stream()),
+              "mh_scatter_add_rows")
         return dW, None
 
 

@@ -227,9 +227,12 @@ def test_attention_stream_backward(dh, L, B, nh):
     D_ref = (dO_ref * out_ref.detach()).sum(-1)
     assert_close(D.view(B, nh, L), D_ref, 2e-2, 2e-2, what="D")
     dqkv = torch.zeros(B * L, 3 * H, device=DEV, dtype=torch.bfloat16)
+    ctx_rows = perm(ctx, 0, H, 0)
+    D2 = torch.zeros(B * nh * L, device=DEV)
     check(lib().mh_attention_stream_bwd(qr.data_ptr(), kr.data_ptr(), vr.data_ptr(), qT.data_ptr(), kT.data_ptr(), dOr.data_ptr(),
-                                        dOT.data_ptr(), lse.data_ptr(), D.data_ptr(), dqkv.data_ptr(), dqkv.data_ptr() + H * 2,
-                                        dqkv.data_ptr() + 2 * H * 2, 3 * H, B, L, nh, dh, scale, st))
+                                        dOT.data_ptr(), ctx_rows.data_ptr(), lse.data_ptr(), D2.data_ptr(), dqkv.data_ptr(),
+                                        dqkv.data_ptr() + H * 2, dqkv.data_ptr() + 2 * H * 2, 3 * H, B, L, nh, dh, scale, st))
+    assert_close(D2.view(B, nh, L), D_ref, 2e-2, 2e-2, what="D from the dQ kernel")
     got = dqkv.float().cpu().view(B, L, 3, nh, dh).permute(2, 0, 3, 1, 4)
     for i, nm in enumerate(("dQ", "dK", "dV")):
         ref = gref[i]
