@@ -433,6 +433,34 @@ int mh_denoiser_forward(const mh_denoiser* m, const float* x, const float* emb_t
                         float* out, int B, int L, void* workspace, size_t workspace_bytes,
                         mh_stream_t stream);
 
+/* ---- batch producers and token validators.  Ragged int32 sequences:
+ * `values` = all rows back to back, `offsets[B + 1]` int64; rows of at most mh_batch_max_row() tokens.
+ * The reference draws its randomness from a host random.Random in data-dependent order; here every draw is an input,
+ * indexed the way the reference consumes it (oracle/batch.py), so results are comparable bit for bit. */
+int mh_batch_max_row(void);
+/* data/wrapper.py:90-127 collate_batches, one field: out[b, j] = j < len_b ? values[offsets[b] + j] : pad; length[b] (may be NULL) */
+int mh_ragged_to_padded(const int32_t* values, const int64_t* offsets, int32_t* out, int32_t* length, int B, int L,
+                        int32_t pad, mh_stream_t stream);
+/* utils/decode_util.py:221-230 meta_to_batch: ids[:, :len] = meta (else 0); mask = 0 on [:, :len + 1], 1 elsewhere */
+int mh_meta_to_batch(const int32_t* meta, int len_meta, int32_t* ids, int32_t* mask, int B, int L, mh_stream_t stream);
+/* data/corruption.py:100-114 masking_token: positions 12 .. first EOS - 1 become 0 where u[offsets[b] + (j - 12)] < p */
+int mh_corrupt_masking_token(const int32_t* values, const int64_t* offsets, const float* u, float p, int32_t* out, int B,
+                             mh_stream_t stream);
+/* :117-133 masking_note: the k-th velocity token (131..194, idx + 3 <= len) zeroes [idx-1, idx+3) where u[offsets[b] + k] < p */
+int mh_corrupt_masking_note(const int32_t* values, const int64_t* offsets, const float* u, float p, int32_t* out, int B,
+                            mh_stream_t stream);
+/* :136-162 randomize_note: ... replaces (velocity, pitch, duration) by new_tokens[(offsets[b] + k) * 3 + 0..2] */
+int mh_corrupt_randomize_note(const int32_t* values, const int64_t* offsets, const float* u, const int32_t* new_tokens,
+                              float p, int32_t* out, int B, mh_stream_t stream);
+/* :165-195 random_rotating: `count` swaps of bars pairs[b][s] = (first < second); bar starts / last EOS taken once from the
+ * input row as the reference does.  status[b] (may be NULL): 0 ok, 1 = fewer than two bars / no EOS / bad pair (row copied
+ * up to the failing swap), 2 = row too long. */
+int mh_corrupt_random_rotating(const int32_t* values, const int64_t* offsets, const int32_t* pairs, int count, int32_t* out,
+                               int32_t* status, int B, mh_stream_t stream);
+/* utils/decode_util.py:73-84, :142-183: per row of tokens [B, L] (valid length lens[b], NULL = L): result[b] = (index of the first
+ * EOS or -1, validate_once passes, validate_rigidly passes | -2 where the reference raises IndexError on a truncated note) */
+int mh_validate_tokens(const int32_t* tokens, const int32_t* lens, int32_t* result, int B, int L, mh_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

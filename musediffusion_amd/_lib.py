@@ -115,6 +115,14 @@ SIGNATURES = {
     "mh_scatter_add_rows": (INT, [VP, VP, VP, I64, INT, INT, VP, C.c_size_t, VP]),
     "mh_scatter_add_rows_workspace_bytes": (C.c_size_t, [INT, INT]),
     "mh_sum_slices": (INT, [VP, INT, I64, VP, VP]),
+    "mh_batch_max_row": (INT, []),
+    "mh_ragged_to_padded": (INT, [VP, VP, VP, VP, INT, INT, C.c_int32, VP]),
+    "mh_meta_to_batch": (INT, [VP, INT, VP, VP, INT, INT, VP]),
+    "mh_corrupt_masking_token": (INT, [VP, VP, VP, F32, VP, INT, VP]),
+    "mh_corrupt_masking_note": (INT, [VP, VP, VP, F32, VP, INT, VP]),
+    "mh_corrupt_randomize_note": (INT, [VP, VP, VP, VP, F32, VP, INT, VP]),
+    "mh_corrupt_random_rotating": (INT, [VP, VP, VP, INT, VP, VP, INT, VP]),
+    "mh_validate_tokens": (INT, [VP, VP, VP, INT, INT, VP]),
     "mh_scale_rows": (INT, [VP, VP, VP, VP, INT, INT, I64, INT, VP]),
     "mh_adamw_ema_step": (INT, [VP, VP, INT, C.POINTER(OptHParams), VP]),
     "mh_grad_norm": (INT, [VP, VP, INT, VP, VP, VP]),

@@ -1,0 +1,287 @@
+// Batch producers and token validators on the device: the integer work either side of
+// the hot path.  Reference: MuseDiffusion/data/corruption.py:100-195 (four corruptions), data/wrapper.py:90-127
+// (collate_batches), utils/decode_util.py:221-230 (meta_to_batch), :73-84 / :142-183 (remove_padding, validate_once,
+// validate_rigidly).  Sequences are ragged: `values` = all rows back to back (int32), `offsets[B + 1]` (int64).
+// One 256-thread block per row; rows of up to MH_BATCH_MAX_ROW tokens (the row lives in LDS).  All kernels are
+// HBM / latency bound byte movers - no MFMA shape here on purpose.  Random draws are inputs (the reference's
+// random.Random stream cannot be reproduced on a GPU; see oracle/batch.py), indexed the way the reference consumes them.
+#include "common.h"
+
+namespace {
+
+constexpr int TB = 256;
+constexpr int MAX_ROW = 4096;   // tokens per row the LDS-resident kernels accept (the reference's seq_len tops out at 2096)
+
+// exclusive prefix sum of one flag per thread over the block (256 threads = 4 waves); returns the block total in `total`
+__device__ __forceinline__ int block_excl_scan(int flag, int* wsum, int& total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const unsigned long long m = __builtin_amdgcn_ballot_w64(flag != 0);
+  const int before = __builtin_popcountll(m & ((1ull << lane) - 1ull));
+  if (lane == 0) wsum[wave] = __builtin_popcountll(m);
+  __syncthreads();
+  int base = 0;
+  for (int w = 0; w < wave; ++w) base += wsum[w];
+  total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+  __syncthreads();
+  return base + before;
+}
+
+__global__ void ragged_to_padded_kernel(const int32_t* __restrict__ values, const int64_t* __restrict__ offsets, int32_t* __restrict__ out,
+                                        int32_t* __restrict__ length, int L, int32_t pad) {
+  const int b = blockIdx.x;
+  const int64_t off = offsets[b];
+  const int n = (int)(offsets[b + 1] - off);
+  for (int j = threadIdx.x; j < L; j += TB) out[(int64_t)b * L + j] = j < n ? values[off + j] : pad;
+  if (length && threadIdx.x == 0) length[b] = n;
+}
+
+__global__ void meta_to_batch_kernel(const int32_t* __restrict__ meta, int len_meta, int32_t* __restrict__ ids, int32_t* __restrict__ mask,
+                                     int64_t total, int L) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int j = (int)(i % L);
+    ids[i] = j < len_meta ? meta[j] : 0;
+    mask[i] = j < len_meta + 1 ? 0 : 1;
+  }
+}
+
+// masking_token (corruption.py:100-114)
+__global__ void corrupt_mt_kernel(const int32_t* __restrict__ values, const int64_t* __restrict__ offsets, const float* __restrict__ u,
+                                  float p, int32_t* __restrict__ out) {
+  __shared__ int eos_s;
+  const int b = blockIdx.x;
+  const int64_t off = offsets[b];
+  const int n = (int)(offsets[b + 1] - off);
+  if (threadIdx.x == 0) eos_s = n;
+  __syncthreads();
+  int first = n;
+  for (int j = 12 + threadIdx.x; j < n; j += TB)
+    if (values[off + j] == 1 && j < first) first = j;
+  if (first < n) atomicMin(&eos_s, first);
+  __syncthreads();
+  const int eos = eos_s;
+  for (int j = threadIdx.x; j < n; j += TB) {
+    const int32_t v = values[off + j];
+    out[off + j] = (j >= 12 && j < eos && u[off + j - 12] < p) ? 0 : v;
+  }
+}
+
+// masking_note / randomize_note (corruption.py:117-162).  MODE 0: zero seq[idx-1 : idx+3]; MODE 1: (velocity, pitch, duration) := new[rank]
+template <int MODE>
+__global__ void corrupt_note_kernel(const int32_t* __restrict__ values, const int64_t* __restrict__ offsets, const float* __restrict__ u,
+                                    const int32_t* __restrict__ newv, float p, int32_t* __restrict__ out) {
+  __shared__ int rank_of[MAX_ROW];     // rank of the velocity token at j if it fires, else -1
+  __shared__ int wsum[4];
+  const int b = blockIdx.x;
+  const int64_t off = offsets[b];
+  const int n = (int)(offsets[b + 1] - off);
+  if (n > MAX_ROW) {   // host wrappers reject such rows; never index LDS out of range
+    for (int j = threadIdx.x; j < n; j += TB) out[off + j] = values[off + j];
+    return;
+  }
+  int carry = 0;
+  for (int j0 = 0; j0 < n; j0 += TB) {
+    const int j = j0 + threadIdx.x;
+    int elig = 0;
+    if (j < n) {
+      const int32_t v = values[off + j];
+      elig = (v >= 131 && v <= 194 && j + 3 <= n) ? 1 : 0;
+    }
+    int total;
+    const int r = carry + block_excl_scan(elig, wsum, total);
+    if (j < n) rank_of[j] = (elig && u[off + r] < p) ? r : -1;
+    carry += total;
+  }
+  __syncthreads();
+  for (int j = threadIdx.x; j < n; j += TB) {
+    int32_t v = values[off + j];
+    if constexpr (MODE == 0) {
+      // zeroed when a firing velocity token sits at idx in [j-2, j+1] (it clears idx-1 .. idx+2); idx = 0 clears seq[-1:3] = nothing
+      bool z = false;
+#pragma unroll
+      for (int d = -2; d <= 1; ++d) {
+        const int idx = j + d;
+        if (idx >= 1 && idx < n && rank_of[idx] >= 0) z = true;
+      }
+      if (z) v = 0;
+    } else {
+      // sequential semantics: the firing token with the LARGEST idx <= j wins (it is processed last)
+      if (rank_of[j] >= 0) v = newv[(off + rank_of[j]) * 3 + 0];
+      else if (j >= 1 && rank_of[j - 1] >= 0) v = newv[(off + rank_of[j - 1]) * 3 + 1];
+      else if (j >= 2 && rank_of[j - 2] >= 0) v = newv[(off + rank_of[j - 2]) * 3 + 2];
+    }
+    out[off + j] = v;
+  }
+}
+
+// random_rotating (corruption.py:165-195): `count` bar swaps; bar starts and the last EOS come from the INPUT row once
+__global__ void corrupt_rr_kernel(const int32_t* __restrict__ values, const int64_t* __restrict__ offsets, const int32_t* __restrict__ pairs,
+                                  int count, int32_t* __restrict__ out, int32_t* __restrict__ status) {
+  __shared__ int32_t buf[2][MAX_ROW];
+  __shared__ int bars[MAX_ROW / 2];
+  __shared__ int wsum[4];
+  __shared__ int eos_s, nbar_s;
+  const int b = blockIdx.x;
+  const int64_t off = offsets[b];
+  const int n = (int)(offsets[b + 1] - off);
+  if (n > MAX_ROW) {
+    for (int j = threadIdx.x; j < n; j += TB) out[off + j] = values[off + j];
+    if (status && threadIdx.x == 0) status[b] = 2;
+    return;
+  }
+  if (threadIdx.x == 0) eos_s = -1;
+  __syncthreads();
+  int carry = 0, last_eos = -1;
+  for (int j0 = 0; j0 < n; j0 += TB) {
+    const int j = j0 + threadIdx.x;
+    int isbar = 0;
+    if (j < n) {
+      const int32_t v = values[off + j];
+      buf[0][j] = v;
+      isbar = v == 2;
+      if (v == 1) last_eos = j;
+    }
+    int total;
+    const int r = carry + block_excl_scan(isbar, wsum, total);
+    if (isbar && r < MAX_ROW / 2) bars[r] = j;
+    carry += total;
+  }
+  if (last_eos >= 0) atomicMax(&eos_s, last_eos);
+  if (threadIdx.x == 0) nbar_s = carry;
+  __syncthreads();
+  const int nbar = nbar_s, eos = eos_s;
+  int cur = 0;
+  bool ok = nbar > 1 && eos >= 0;
+  for (int s = 0; s < count && ok; ++s) {
+    const int first = pairs[((int64_t)b * count + s) * 2], second = pairs[((int64_t)b * count + s) * 2 + 1];
+    if (first < 0 || second <= first || second >= nbar) { ok = false; break; }
+    const int b1s = bars[first], b2s = bars[second], b1e = bars[first + 1];
+    const int b2e = second < nbar - 1 ? bars[second + 1] : eos;
+    if (b2e < b2s) { ok = false; break; }
+    const int lenB2 = b2e - b2s, lenM = b2s - b1e;
+    for (int j = threadIdx.x; j < n; j += TB) {
+      int src = j;
+      if (j >= b1s && j < b2e) {
+        const int q = j - b1s;
+        if (q < lenB2) src = b2s + q;
+        else if (q < lenB2 + lenM) src = b1e + (q - lenB2);
+        else src = b1s + (q - lenB2 - lenM);
+      }
+      buf[cur ^ 1][j] = buf[cur][src];
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+  for (int j = threadIdx.x; j < n; j += TB) out[off + j] = buf[cur][j];
+  if (status && threadIdx.x == 0) status[b] = ok ? 0 : 1;
+}
+
+// remove_padding / validate_once / validate_rigidly (decode_util.py:73-84, :142-183) of row b of tokens [B, L]:
+// result[b] = (index of the first EOS or -1, once ok, rigid ok | -2 where the reference indexes past the end)
+__global__ void validate_tokens_kernel(const int32_t* __restrict__ tokens, const int32_t* __restrict__ lens, int32_t* __restrict__ result, int L) {
+  __shared__ int eos_s, once_s;
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const int32_t* seq = tokens + (int64_t)b * L;
+  const int len = lens ? lens[b] : L;
+  if (lane == 0) { eos_s = len; once_s = 0; }
+  __syncthreads();
+  int first = len;
+  for (int j = lane; j < len; j += 64)
+    if (seq[j] == 1 && j < first) first = j;
+  if (first < len) atomicMin(&eos_s, first);
+  __syncthreads();
+  if (eos_s >= len) {
+    if (lane == 0) { result[b * 3 + 0] = -1; result[b * 3 + 1] = 0; result[b * 3 + 2] = 0; }
+    return;
+  }
+  const int n = eos_s + 1;   // the cut sequence: everything up to and including the first EOS
+  // validate_once: some idx <= n - 3 holds a velocity token between a position token and (pitch, duration); seq[-1] wraps
+  bool hit = false;
+  for (int i = lane; i + 2 <= n - 1; i += 64) {
+    const int32_t t = seq[i], prev = seq[i == 0 ? n - 1 : i - 1];
+    if (t >= 131 && t < 195 && prev >= 432 && prev < 560 && seq[i + 1] >= 3 && seq[i + 1] < 131 && seq[i + 2] >= 304 && seq[i + 2] < 432) hit = true;
+  }
+  if (hit) once_s = 1;
+  __syncthreads();
+  if (lane == 0) {
+    int rigid = 0, i = 0;
+    while (true) {
+      if (i >= n) break;
+      const int32_t t = seq[i];
+      if (t == 1) { rigid = 1; break; }
+      if (t == 2) { ++i; continue; }
+      if (!(t >= 432 && t < 560)) break;
+      if (i + 1 >= n) { rigid = -2; break; }
+      const int32_t t1 = seq[i + 1];
+      if (t1 >= 131 && t1 < 195) {
+        if (i + 3 >= n) { rigid = -2; break; }
+        if (seq[i + 2] >= 3 && seq[i + 2] < 131 && seq[i + 3] >= 304 && seq[i + 3] < 432) { i += 4; continue; }
+        break;
+      }
+      if (t1 >= 195 && t1 < 304) { i += 2; continue; }
+      break;
+    }
+    result[b * 3 + 0] = eos_s;
+    result[b * 3 + 1] = once_s;
+    result[b * 3 + 2] = rigid;
+  }
+}
+
+}  // namespace
+
+extern "C" int mh_batch_max_row(void) { return MAX_ROW; }
+
+extern "C" int mh_ragged_to_padded(const int32_t* values, const int64_t* offsets, int32_t* out, int32_t* length, int B, int L,
+                                   int32_t pad, mh_stream_t stream) {
+  MH_CHECK_ARG(values && offsets && out && B > 0 && L > 0, "ragged_to_padded: bad arguments");
+  MH_LAUNCH(ragged_to_padded_kernel, dim3(B), dim3(TB), 0, (hipStream_t)stream, values, offsets, out, length, L, pad);
+  MH_CHECK_LAUNCH();
+  return MH_OK;
+}
+
+extern "C" int mh_meta_to_batch(const int32_t* meta, int len_meta, int32_t* ids, int32_t* mask, int B, int L, mh_stream_t stream) {
+  MH_CHECK_ARG(meta && ids && mask && B > 0 && L > 0 && len_meta >= 0 && len_meta <= L, "meta_to_batch: bad arguments");
+  const int64_t total = (int64_t)B * L;
+  const int grid = (int)((total + TB - 1) / TB < 4096 ? (total + TB - 1) / TB : 4096);
+  MH_LAUNCH(meta_to_batch_kernel, dim3(grid), dim3(TB), 0, (hipStream_t)stream, meta, len_meta, ids, mask, total, L);
+  MH_CHECK_LAUNCH();
+  return MH_OK;
+}
+
+extern "C" int mh_corrupt_masking_token(const int32_t* values, const int64_t* offsets, const float* u, float p, int32_t* out, int B,
+                                        mh_stream_t stream) {
+  MH_CHECK_ARG(values && offsets && u && out && B > 0, "corrupt_masking_token: bad arguments");
+  MH_LAUNCH(corrupt_mt_kernel, dim3(B), dim3(TB), 0, (hipStream_t)stream, values, offsets, u, p, out);
+  MH_CHECK_LAUNCH();
+  return MH_OK;
+}
+
+extern "C" int mh_corrupt_masking_note(const int32_t* values, const int64_t* offsets, const float* u, float p, int32_t* out, int B,
+                                       mh_stream_t stream) {
+  MH_CHECK_ARG(values && offsets && u && out && B > 0, "corrupt_masking_note: bad arguments");
+  MH_LAUNCH((corrupt_note_kernel<0>), dim3(B), dim3(TB), 0, (hipStream_t)stream, values, offsets, u, (const int32_t*)nullptr, p, out);
+  MH_CHECK_LAUNCH();
+  return MH_OK;
+}
+
+extern "C" int mh_corrupt_randomize_note(const int32_t* values, const int64_t* offsets, const float* u, const int32_t* new_tokens,
+                                         float p, int32_t* out, int B, mh_stream_t stream) {
+  MH_CHECK_ARG(values && offsets && u && new_tokens && out && B > 0, "corrupt_randomize_note: bad arguments");
+  MH_LAUNCH((corrupt_note_kernel<1>), dim3(B), dim3(TB), 0, (hipStream_t)stream, values, offsets, u, new_tokens, p, out);
+  MH_CHECK_LAUNCH();
+  return MH_OK;
+}
+
+extern "C" int mh_corrupt_random_rotating(const int32_t* values, const int64_t* offsets, const int32_t* pairs, int count, int32_t* out,
+                                          int32_t* status, int B, mh_stream_t stream) {
+  MH_CHECK_ARG(values && offsets && pairs && out && B > 0 && count >= 0, "corrupt_random_rotating: bad arguments");
+  MH_LAUNCH(corrupt_rr_kernel, dim3(B), dim3(TB), 0, (hipStream_t)stream, values, offsets, pairs, count, out, status);
+  MH_CHECK_LAUNCH();
+  return MH_OK;
+}
+
+extern "C" int mh_validate_tokens(const int32_t* tokens, const int32_t* lens, int32_t* result, int B, int L, mh_stream_t stream) {
+  MH_CHECK_ARG(tokens && result && B > 0 && L > 0, "validate_tokens: bad arguments");
+  MH_LAUNCH(validate_tokens_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, tokens, lens, result, L);
+  MH_CHECK_LAUNCH();
+  return MH_OK;
+}
