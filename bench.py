@@ -63,48 +63,83 @@ def build(c, dtype, device, seed=0):
     return model, diff
 
 
-def time_dominant_kernel(c, dtype, device, reps):
-    """Average launch duration of the step's dominant kernel - the FFN intermediate dense (x W1^T + b1, GELU):
-    N = ffn, K = d_model, one launch per encoder layer, ~30% of the step in profiles/ - measured with HIP events on
-    the launch stream: back-to-back launches of the real shape in the layout the engine uses (K32 panels for
-    bf16, row-major for fp32), bias + GELU epilogue included.  Conservative: inside the step, between the
-    attention and LayerNorm-fused kernels, rocprofv3 shows the same launch ~10% shorter (profiles/) - the chip
-    holds a lower clock under a pure-MFMA load."""
+def time_dominant_kernel(c, dtype, device, reps, branches=1):
+    """Average launch duration of the step's dominant kernel (largest time share in profiles/), measured with HIP events
+    on the launch streams, launched the way the step launches it.
+
+    bf16 with d_model in {128, 256, 512}: the full-row GEMM with the bias + residual + LayerNorm epilogue
+    (gemm_big_kernel<Row tile, EPI=3>), two launches per encoder layer and graph branch: attention-output dense
+    (K = d_model) and FFN output dense (K = ffn), both N = d_model, on a branch's batch slice.  With two graph
+    branches the step runs two of them side by side, so the timing loop does too (one stream per branch):
+    `avg_launch_ms` = wall time of the region / launches (what the chip sustains), `launch_latency_ms` = the span one
+    launch occupies on its own stream while it shares the chip with the other branch's (what rocprofv3 lists per kernel).  Otherwise (fp32 parity mode, d_model 768): the FFN intermediate dense with its GELU epilogue."""
     from musediffusion_amd import _lib, ops
     code = ops.dtype_code(dtype)
     td = ops.TORCH_DTYPE[code]
     panel = 1 if code == _lib.MH_BF16 else 0
-    N_tok, H, F = c["B"] * c["L"], c["H"], c["F"]
-    A = torch.randn(N_tok * H, device=device).to(td)
-    W = (torch.randn(F * H, device=device) / 32).to(td)
-    O = torch.empty(N_tok * F, device=device, dtype=td)
-    bias = torch.zeros(F, device=device)
-    lib, st = _lib.lib(), _lib.current_stream
-    nl = c["nL"]
+    N_tok, H, F = (c["B"] // branches) * c["L"], c["H"], c["F"]
+    lib = _lib.lib()
+    fused = bool(panel and lib.mh_gemm_bias_res_ln_supported(H) and lib.mh_denoiser_get_fuse_ln())
+    streams = [torch.cuda.Stream() for _ in range(branches)]
+    bufs = []
+    for _ in range(branches):
+        bufs.append(dict(X=torch.randn(N_tok * H, device=device).to(td), Y=torch.empty(N_tok * H, device=device, dtype=td),
+                         Fb=torch.randn(N_tok * F, device=device).to(td), Wa=(torch.randn(H * H, device=device) / 32).to(td),
+                         W1=(torch.randn(F * H, device=device) / 32).to(td), W2=(torch.randn(F * H, device=device) / 32).to(td),
+                         bias=torch.zeros(max(F, H), device=device), g=torch.ones(H, device=device)))
 
-    def one_pass():
-        for _ in range(nl):
-            _lib.check(lib.mh_gemm_bias_act_ex(A.data_ptr(), N_tok if panel else H, panel, W.data_ptr(), F if panel else H, panel,
-                                               bias.data_ptr(), None, 0, 0, O.data_ptr(), N_tok if panel else F, panel, 0,
-                                               N_tok, F, H, 2, code, st()))
-    one_pass()
+    def one_pass(bf, st):
+        for _ in range(c["nL"]):
+            if fused:
+                for (A, W, K) in ((bf["X"], bf["Wa"], H), (bf["Fb"], bf["W2"], F)):
+                    _lib.check(lib.mh_gemm_bias_res_ln(A.data_ptr(), N_tok, 1, W.data_ptr(), H, 1, bf["bias"].data_ptr(), bf["X"].data_ptr(),
+                                                       N_tok, 1, bf["g"].data_ptr(), bf["bias"].data_ptr(), 1e-12, bf["Y"].data_ptr(), N_tok, 1,
+                                                       N_tok, H, K, st))
+            else:
+                _lib.check(lib.mh_gemm_bias_act_ex(bf["X"].data_ptr(), N_tok if panel else H, panel, bf["W1"].data_ptr(), F if panel else H,
+                                                   panel, bf["bias"].data_ptr(), None, 0, 0, bf["Fb"].data_ptr(), N_tok if panel else F, panel,
+                                                   0, N_tok, F, H, 2, code, st))
+    for bf, stream in zip(bufs, streams):
+        one_pass(bf, stream.cuda_stream)
     torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps):
-        one_pass()
-    e1.record()
+    # wall time of the whole region (all branches' launches running side by side) and each stream's own span
+    cur = torch.cuda.current_stream()
+    w0, w1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    w0.record(cur)
+    evs = []
+    for bf, stream in zip(bufs, streams):
+        stream.wait_event(w0)
+        with torch.cuda.stream(stream):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            for _ in range(reps):
+                one_pass(bf, stream.cuda_stream)
+            e1.record(stream)
+            evs.append((e0, e1))
+    for _, e1 in evs:
+        cur.wait_event(e1)
+    w1.record(cur)
     torch.cuda.synchronize()
-    avg_ms = e0.elapsed_time(e1) / (reps * nl)
-    return avg_ms, 2.0 * N_tok * F * H, nl
+    per_pass = c["nL"] * (2 if fused else 1)
+    latency_ms = sum(a.elapsed_time(b) for a, b in evs) / len(evs) / (reps * per_pass)   # one launch, as its stream sees it
+    avg_ms = w0.elapsed_time(w1) / (reps * per_pass * branches)                           # wall time per launch
+    if fused:
+        flops = (2.0 * N_tok * H * H + 2.0 * N_tok * H * F) / 2
+        name = ("gemm_big_kernel<128x512 full-row tile, EPI=bias+residual+LayerNorm> bf16: attention-output dense [%d x %d x %d] and FFN "
+                "output dense [%d x %d x %d], %d launches/step on %d concurrent stream(s)" % (N_tok, H, H, N_tok, H, F, per_pass * branches, branches))
+    else:
+        flops = 2.0 * N_tok * F * H
+        name = "%s: FFN intermediate dense + GELU [%d x %d x %d], %d launches/step" % (
+            "gemm_big_kernel<EPI=0, ACT=gelu> bf16" if panel else "gemm_kernel<float, EPI=0>", N_tok, F, H, per_pass * branches)
+    return avg_ms, flops, name, latency_ms
 
 
-def pmc_traffic(workload, dtype):
+def pmc_traffic(workload, dtype, branches):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE doubled as
     MI355X_MICROARCH.md prescribes for gfx950, + WRITE_SIZE); None when no pass was recorded for this workload."""
     try:
         with open(os.path.join(REPO, "profiles", "pmc_traffic.json")) as f:
-            rec = json.load(f).get("%s/%s" % (workload, dtype))
+            rec = json.load(f).get("%s/%s/b%d" % (workload, dtype, branches))
         return None if rec is None else float(rec["traffic_bytes_per_launch"])
     except (OSError, ValueError, KeyError):
         return None
@@ -228,7 +263,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
-    ap.add_argument("--split", type=int, default=1, help="batch slices run as concurrent graph branches")
+    ap.add_argument("--split", type=int, default=None, help="batch slices run as concurrent graph branches (default: the library's choice)")
     ap.add_argument("--gemm", type=int, default=None, help="bf16 GEMM kernel variant 0/1/2 (see mh_gemm_set_variant)")
     ap.add_argument("--no-fuse-ln", action="store_true", help="A/B: separate GEMM and LayerNorm kernels")
     ap.add_argument("--no-stream-attn", action="store_true", help="A/B: LDS-resident attention instead of the streaming kernel")
@@ -265,7 +300,8 @@ def main():
         broadcast_weights(model, src=0)   # ONE RCCL broadcast of the packed arena
     diff.rng_mode, diff.rng_seed, diff.rng_stream = args.rng, 105, rank
     diff.use_graph = not args.no_graph
-    diff.batch_split = args.split
+    if args.split is not None:
+        diff.batch_split = args.split
 
     batch = synthetic.generation_batch(c["B"], c["L"], seed=1 + rank)
     ids, mask = batch["input_ids"].to(device), batch["input_mask"].to(device)
@@ -317,20 +353,19 @@ def main():
                                    "ffn=%d E=%d vocab=%d T=%d, rounding+clamp+top_p=1 every step"
                                    % (args.workload, c["L"], c["B"], c["H"], c["nL"], c["nh"], c["F"], c["E"], c["V"], c["T"]),
                        "global_batch": c["B"] * world, "seq_len": c["L"], "parallelism": "batch-sharded x%d" % world,
-                       "rng": args.rng, "hipgraph": not args.no_graph,
+                       "rng": args.rng, "hipgraph": not args.no_graph, "graph_branches": int(loop.nsplit),
                        "step_tflop": round(flops / 1e12, 4),
                        "step_tflops_achieved": round(flops / (ms_per_step * 1e-3) / 1e12, 2),
                        "sequences_steps_per_s": round(value * c["B"], 1)},
         }
         if not args.no_kernel_timing:
-            avg_ms, fpl, nl = time_dominant_kernel(c, args.dtype, device, reps=5)
+            avg_ms, fpl, kname, lat_ms = time_dominant_kernel(c, args.dtype, device, reps=5, branches=int(loop.nsplit))
             ach = fpl / (avg_ms * 1e-3) / 1e12
             peak = MFMA_PEAK_TFLOPS[args.dtype]
-            kname = ("gemm_big_kernel<EPI=0, ACT=gelu> bf16 big tile" if args.dtype == "bf16" else "gemm_kernel<float,EPI=0>")
-            out["roofline"] = {"bound": "mfma", "kernel": "%s: FFN intermediate dense [%d x %d x %d] (%d launches/step)"
-                                                          % (kname, c["B"] * c["L"], c["F"], c["H"], nl),
+            out["roofline"] = {"bound": "mfma", "kernel": kname,
                                "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                               "traffic": pmc_traffic(args.workload, args.dtype), "avg_launch_ms": round(avg_ms, 5),
+                               "traffic": pmc_traffic(args.workload, args.dtype, int(loop.nsplit)), "avg_launch_ms": round(avg_ms, 5),
+                               "concurrent_streams": int(loop.nsplit), "launch_latency_ms": round(lat_ms, 5),
                                "flops_per_launch": fpl}
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(c)

@@ -380,6 +380,7 @@ int mh_gemm_bias_res_ln_supported(int N);
 /* A/B switch: mh_denoiser_forward's panel path uses mh_gemm_bias_res_ln for the two post-LN dense layers of an
  * encoder block when the hidden size allows it (default 1) or the separate GEMM + LayerNorm kernels (0). */
 int mh_denoiser_set_fuse_ln(int on);
+int mh_denoiser_get_fuse_ln(void);
 /* Timing-only ablation of the big-tile kernel (results are WRONG when non-zero): bit 0 skips the
  * DMA loads, bit 1 the MFMAs, bit 2 the epilogue stores, bit 3 the LDS fragment reads.  Used by tools/gemm_bench.py only. */
 int mh_gemm_set_debug(int bits);

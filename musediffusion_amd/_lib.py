@@ -134,6 +134,7 @@ SIGNATURES = {
     "mh_gemm_bias_res_ln": (INT, [VP, I64, INT, VP, I64, INT, VP, VP, I64, INT, VP, VP, F32, VP, I64, INT, I64, INT, INT, VP]),
     "mh_gemm_bias_res_ln_supported": (INT, [INT]),
     "mh_denoiser_set_fuse_ln": (INT, [INT]),
+    "mh_denoiser_get_fuse_ln": (INT, []),
     "mh_gemm_set_debug": (INT, [INT]),
     "mh_graph_begin_capture": (INT, [VP]),
     "mh_graph_end_capture": (INT, [VP, C.POINTER(VP)]),

@@ -17,6 +17,7 @@ void mh_set_error(const char* fmt, ...) {
 }
 
 namespace { int g_fuse_ln = 1; }
+extern "C" int mh_denoiser_get_fuse_ln(void) { return g_fuse_ln; }
 extern "C" int mh_denoiser_set_fuse_ln(int on) {
   g_fuse_ln = on != 0;
   return MH_OK;

@@ -35,11 +35,12 @@ rows.sort(reverse=True)
 print("%-78s %8s %6s %12s %12s %14s" % ("kernel", "grid", "n", "FETCH KiB", "WRITE KiB", "HBM MB/launch"))
 for tot, k, n, fk, wk in rows[:14]:
     print("%-78s %8s %6d %12.1f %12.1f %14.2f" % (k[0][:78], k[1], n, fk, wk, (2 * fk + wk) * 1024 / 1e6))
-dom = [r for r in rows if "gemm_big_kernel" in r[1][0] and ", 0, 2, 0>" in r[1][0]]
+dom = [r for r in rows if "gemm_big_kernel" in r[1][0] and ", 3, 0, 0>" in r[1][0]] or \
+      [r for r in rows if "gemm_big_kernel" in r[1][0] and ", 0, 2, 0>" in r[1][0]]
 if dom:
     tot, k, n, fk, wk = dom[0]
     rec = {key: {"kernel": k[0], "launches_sampled": n, "fetch_kib": fk, "write_kib": wk,
                  "traffic_bytes_per_launch": (2 * fk + wk) * 1024,
                  "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; FETCH_SIZE doubled (gfx950)"}}
     json.dump(rec, open("gpurun_out/pmc_traffic.json", "w"), indent=1)
-    print("dominant (FFN intermediate dense): %.1f MB per launch" % (rec[key]["traffic_bytes_per_launch"] / 1e6))
+    print("dominant kernel (%s): %.1f MB per launch" % (k[0][:70], rec[key]["traffic_bytes_per_launch"] / 1e6))
