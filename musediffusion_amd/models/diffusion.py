@@ -587,6 +587,8 @@ class _ReverseLoop:
         self.mean = torch.empty_like(self.x) if (progressive and kind == "p") else None
         self.round_idx = torch.zeros(B * L, dtype=torch.int32, device=dev)
         self.mask, self.mask_per_elem = ops._mask_args(mask, self.x) if mask is not None else (None, 0)
+        if self.mask is not None:
+            self.mask = self.mask.reshape(B, -1)       # batch-major: branches take row slices
         self.x_start = None if x_start is None else x_start.detach().to(torch.float32).contiguous()
         self.table32 = None if table is None else table.detach().to(torch.float32).contiguous()
         self.table_norm = None if table is None else ops.row_sqnorm(self.table32)
@@ -613,7 +615,10 @@ class _ReverseLoop:
             self.split_ws = [eng.new_workspace(B - hb * (self.nsplit - 1) if j == self.nsplit - 1 else hb, L) for j in range(self.nsplit)]
             self.side_streams = [torch.cuda.Stream() for _ in range(self.nsplit - 1)]
             self.ev_fork = torch.cuda.Event()
+            self.ev_noise = torch.cuda.Event()
             self.ev_join = [torch.cuda.Event() for _ in range(self.nsplit - 1)]
+            sizes = [B - hb * (self.nsplit - 1) if j == self.nsplit - 1 else hb for j in range(self.nsplit)]
+            self.split_round_ws = [None if table is None else ops.round_workspace(n * L, E, self.table32.shape[0], dev) for n in sizes]
 
     # one reverse step as a fixed launch sequence (capturable: no allocation, no sync)
     def _body(self, use_round, in_graph_rng):
@@ -623,42 +628,63 @@ class _ReverseLoop:
         _lib.check(L_.mh_step_begin(P(self.state), P(self.steps), P(self.coef_table), P(self.cur_coef), P(self.emb_row),
                                     self.B, st), "mh_step_begin")
         nsplit = self.nsplit
+        per_batch = self.L * self.E
+
+        def tail(sl, stream_h, ws):
+            """rounding + posterior / DDIM update of the batch slice `sl` on the given stream"""
+            nb = sl.stop - sl.start
+            tok = slice(sl.start * self.L, sl.stop * self.L)
+            if use_round:
+                _lib.check(L_.mh_round_to_embedding_mfma(P(self.model_out[sl]), P(self.table_pad), P(self.table_norm),
+                                                         P(self.round_idx[tok]), nb * self.L, self.E, self.table32.shape[0],
+                                                         P(ws), ws.numel(), stream_h), "mh_round_to_embedding_mfma")
+            args = [P(self.model_out[sl]), P(self.x[sl]), P(self.noise[sl]), P(self.round_idx[tok]) if use_round else None,
+                    P(self.table32) if use_round else None, P(self.cur_coef), 0, int(self.clip),
+                    P(self.mask[sl]) if self.mask is not None else None, self.mask_per_elem,
+                    P(self.x_start[sl]) if self.x_start is not None else None, P(self.x[sl]), P(self.pred[sl])]
+            if self.kind == "p":
+                _lib.check(L_.mh_p_sample_epilogue(*args, P(self.mean[sl]) if self.mean is not None else None, nb, per_batch, self.E,
+                                                   stream_h), "mh_p_sample_epilogue")
+            else:
+                _lib.check(L_.mh_ddim_epilogue(*args, nb, per_batch, self.E, stream_h), "mh_ddim_epilogue")
+
+        def draw_noise(stream_h):
+            if in_graph_rng:
+                _lib.check(L_.mh_trunc_normal(P(self.noise), self.noise.numel(), float(self.top_p), int(self.diff.rng_seed),
+                                              int(self.diff.rng_stream), P(self.state), stream_h), "mh_trunc_normal")
+
         if nsplit <= 1:
             self.eng.forward(self.x, self.emb_table, self.emb_row, out=self.model_out)
+            draw_noise(st)
+            tail(slice(0, self.B), st, self.round_ws)
         else:
-            # independent sequences -> independent chains: run the halves of the batch as concurrent branches so
-            # that blocks of DIFFERENT kernels (one branch's epilogue, the other's MFMA main loop) share each CU
+            # independent sequences -> independent chains: the slices of the batch run as concurrent graph branches
+            # (forward, rounding, update), so that blocks of DIFFERENT kernels - one branch's epilogue or attention, the
+            # other's MFMA main loop - share the chip, and kernel boundaries of one branch hide under the other's work.
+            # The whole batch's noise is drawn once, at the head of the first side branch (same Philox counters as unsplit).
             main = torch.cuda.current_stream()
             self.ev_fork.record(main)
             hb = self.B // nsplit
-            for j in range(nsplit):
+            for j in range(1, nsplit):
                 sl = slice(j * hb, (j + 1) * hb if j + 1 < nsplit else self.B)
-                if j == 0:
-                    self.eng.forward(self.x[sl], self.emb_table, self.emb_row[sl], out=self.model_out[sl], ws=self.split_ws[0])
-                else:
-                    side = self.side_streams[j - 1]
-                    side.wait_event(self.ev_fork)
-                    with torch.cuda.stream(side):
-                        self.eng.forward(self.x[sl], self.emb_table, self.emb_row[sl], out=self.model_out[sl], ws=self.split_ws[j])
-                        self.ev_join[j - 1].record(side)
+                side = self.side_streams[j - 1]
+                side.wait_event(self.ev_fork)
+                with torch.cuda.stream(side):
+                    sh = side.cuda_stream
+                    if j == 1:
+                        draw_noise(sh)
+                        self.ev_noise.record(side)
+                    self.eng.forward(self.x[sl], self.emb_table, self.emb_row[sl], out=self.model_out[sl], ws=self.split_ws[j])
+                    if j > 1:
+                        side.wait_event(self.ev_noise)
+                    tail(sl, sh, self.split_round_ws[j])
+                    self.ev_join[j - 1].record(side)
+            sl0 = slice(0, hb)
+            self.eng.forward(self.x[sl0], self.emb_table, self.emb_row[sl0], out=self.model_out[sl0], ws=self.split_ws[0])
+            main.wait_event(self.ev_noise)
+            tail(sl0, st, self.split_round_ws[0])
             for j in range(1, nsplit):
                 main.wait_event(self.ev_join[j - 1])
-        if use_round:
-            _lib.check(L_.mh_round_to_embedding_mfma(P(self.model_out), P(self.table_pad), P(self.table_norm),
-                                                     P(self.round_idx), self.B * self.L, self.E, self.table32.shape[0],
-                                                     P(self.round_ws), self.round_ws.numel(), st),
-                       "mh_round_to_embedding_mfma")
-        if in_graph_rng:
-            _lib.check(L_.mh_trunc_normal(P(self.noise), self.noise.numel(), float(self.top_p), int(self.diff.rng_seed),
-                                          int(self.diff.rng_stream), P(self.state), st), "mh_trunc_normal")
-        args = [P(self.model_out), P(self.x), P(self.noise), P(self.round_idx) if use_round else None,
-                P(self.table32) if use_round else None, P(self.cur_coef), 0, int(self.clip), P(self.mask),
-                self.mask_per_elem, P(self.x_start), P(self.x), P(self.pred)]
-        per_batch = self.L * self.E
-        if self.kind == "p":
-            _lib.check(L_.mh_p_sample_epilogue(*args, P(self.mean), self.B, per_batch, self.E, st), "mh_p_sample_epilogue")
-        else:
-            _lib.check(L_.mh_ddim_epilogue(*args, self.B, per_batch, self.E, st), "mh_ddim_epilogue")
         _lib.check(L_.mh_step_end(P(self.state), st), "mh_step_end")
 
     def begin(self):
