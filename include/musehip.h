@@ -384,9 +384,6 @@ int mh_denoiser_get_fuse_ln(void);
 /* Timing-only ablation of the big-tile kernel (results are WRONG when non-zero): bit 0 skips the
  * DMA loads, bit 1 the MFMAs, bit 2 the epilogue stores, bit 3 the LDS fragment reads.  Used by tools/gemm_bench.py only. */
 int mh_gemm_set_debug(int bits);
-/* Start delay (100 MHz ticks) of the blocks in a CU's second slot of the persistent big-tile kernel:
- * 0 = none (default), -1 = derived from K, > 0 = as given.  A/B knob for tools/gemm_bench.py. */
-int mh_gemm_set_stagger(int ticks);
 
 int mh_graph_begin_capture(mh_stream_t stream);
 int mh_graph_end_capture(mh_stream_t stream, void** graph_exec_out);

@@ -45,7 +45,7 @@ extern "C" int mh_graph_end_capture(mh_stream_t stream, void** graph_exec_out) {
   MH_HIP(hipStreamEndCapture((hipStream_t)stream, &graph));
   hipGraphExec_t exec = nullptr;
   hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-  hipGraphDestroy(graph);
+  (void)hipGraphDestroy(graph);   // the executable graph keeps what it needs
   if (e != hipSuccess) {
     mh_set_error("hipGraphInstantiate: %s", hipGetErrorString(e));
     return MH_ERR_HIP;

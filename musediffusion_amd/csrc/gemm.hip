@@ -39,10 +39,7 @@ struct GemmArgs {
   int64_t sA, sW, sO, sR;  // batch strides in elements (grid.y = batch index)
   const float* ln_gamma; const float* ln_beta; float ln_eps;   // EPI 3
   int dbg;  // timing-only ablation bits (mh_gemm_set_debug): 1 no DMA, 2 no MFMA, 4 no stores
-  // persistent big-tile launch: ntiles output tiles walked by gridDim.x blocks; blocks that land in a CU's
-  // second slot ((blockIdx.x / 8) / cus_per_xcd odd) start `stagger` ticks (100 MHz) late so that one
-  // block's epilogue stores run under its neighbour's main loop instead of beside its epilogue
-  int ntiles, cus_per_xcd, stagger;
+  int ntiles;    // persistent big-tile launch: ntiles output tiles walked by gridDim.x blocks
   int vt_perm;   // QKV scatter: V^T keys in the P-operand order of mh_attention_stream_fwd (middle groups of 4 swapped per 16)
 };
 
@@ -574,10 +571,6 @@ __global__ __launch_bounds__(C::THREADS, C::STAGE * C::NST <= 80 * 1024 ? 2 : 1)
   const int nk = g.K / B2K;
   const int fr = lane & 15, fg = lane >> 4;
   constexpr int GSW[4] = {0, 2, 3, 1};
-  if (g.stagger > 0 && (((blockIdx.x >> 3) / g.cus_per_xcd) & 1)) {
-    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-    while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)g.stagger) __builtin_amdgcn_s_sleep(16);
-  }
   // DMA coordinates: one piece covers 16 rows x 64 B; lane i lands at row i/4, physical chunk i%4.
   // row-major operand: rows ld elements apart, a K-step advances 32 elements; K32-panel operand
   // ([K/32][ld rows][32]): rows 32 elements apart, a K-step advances one whole panel (ld * 32)
@@ -860,8 +853,6 @@ __global__ __launch_bounds__(C::THREADS, C::STAGE * C::NST <= 80 * 1024 ? 2 : 1)
 int g_dbg = 0;
 int g_variant = 2;  // bf16 kernel choice: 0 small-tile register-staged, 1 small-tile global_load_lds, 2 big tile (auto), 3 big Std, 4 big Wide
 
-int g_stagger = 0;   // second-slot start delay in 100 MHz ticks: 0 off, -1 derived from K, > 0 as given
-
 int device_cus() {
   static int cus = 0;
   if (!cus) {
@@ -882,10 +873,6 @@ int launch_big(const GemmArgs& g0, hipStream_t s, int batch) {
   const int per_cu = C::STAGE * C::NST <= 80 * 1024 ? 2 : 1;
   const int64_t slots = (int64_t)cus * per_cu;
   g.ntiles = (int)t2;
-  g.cus_per_xcd = cus / 8 > 0 ? cus / 8 : 1;
-  g.stagger = 0;
-  if (per_cu == 2 && t2 >= slots && batch == 1 && g_stagger != 0)
-    g.stagger = g_stagger > 0 ? g_stagger : ((g.K / B2K) * 80 + 500) / 2;
   const dim3 grid((unsigned)(t2 < slots ? t2 : slots), (unsigned)batch), block(C::THREADS);
   if constexpr (EPI == 1) {
     MH_LAUNCH((gemm_big_kernel<C, 1, MH_ACT_NONE>), grid, block, 0, s, g);
@@ -970,11 +957,6 @@ int launch(const GemmArgs& g, int dtype, hipStream_t s, int batch = 1) {
 }  // namespace
 
 extern "C" int mh_gemm_bias_res_ln_supported(int N) { return N == 128 || N == 256 || N == 512; }
-
-extern "C" int mh_gemm_set_stagger(int ticks) {
-  g_stagger = ticks;
-  return MH_OK;
-}
 
 extern "C" int mh_gemm_set_debug(int bits) {
   g_dbg = bits & 63;

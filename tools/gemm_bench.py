@@ -18,7 +18,6 @@ ap.add_argument("--H", type=int, default=512)
 ap.add_argument("--F", type=int, default=2048)
 ap.add_argument("--shapes", default="ao,ffn1,ffn2,qkv")
 ap.add_argument("--dbg", type=int, default=0)
-ap.add_argument("--stagger", type=int, default=0)
 ap.add_argument("--ab", type=str, default="", help="comma list of debug-bit values to alternate between in one process, e.g. 0,32")
 ap.add_argument("--noact", action="store_true")
 ap.add_argument("--panel", type=int, default=0, help="bit0 A, bit1 W, bit2 out, bit3 residual in K32-panel layout (timing only)")
@@ -26,7 +25,6 @@ ap.add_argument("--pad", type=int, default=0, help="extra elements on every lead
 a = ap.parse_args()
 _lib.lib().mh_gemm_set_variant(a.variant)
 _lib.lib().mh_gemm_set_debug(a.dbg)
-_lib.lib().mh_gemm_set_stagger(a.stagger)
 dev = "cuda"
 M, H, F = a.M, a.H, a.F
 bf = torch.bfloat16
