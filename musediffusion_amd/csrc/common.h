@@ -71,6 +71,15 @@ __device__ __forceinline__ void store8(bf16* p, const float (&v)[8]) {
   for (int i = 0; i < 8; ++i) r[i] = (bf16)v[i];
   *reinterpret_cast<bf16x8*>(p) = r;
 }
+// streaming store: bytes that no block of this kernel reads again must not evict the operand panels from L2
+__device__ __forceinline__ void store8_nt(bf16* p, const float (&v)[8]) {
+  bf16x8 r;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) r[i] = (bf16)v[i];
+  f32x4 raw;
+  __builtin_memcpy(&raw, &r, 16);
+  __builtin_nontemporal_store(raw, reinterpret_cast<f32x4*>(p));
+}
 __device__ __forceinline__ void store8(float* p, const float (&v)[8]) {
   f32x4 a, b;
 #pragma unroll

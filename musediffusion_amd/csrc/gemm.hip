@@ -708,7 +708,7 @@ __global__ __launch_bounds__(C::THREADS, C::STAGE * C::NST <= 80 * 1024 ? 2 : 1)
               float v[8];
 #pragma unroll
               for (int e = 0; e < 8; ++e) v[e] = acc[i][2 * qh + (e >> 2)][e & 3] + bv[e];
-              store8(dst + ((int64_t)b * g.nh * g.L + l) * g.dh + coloff, v);
+              store8_nt(dst + ((int64_t)b * g.nh * g.L + l) * g.dh + coloff, v);
             }
           }
         }
@@ -802,7 +802,7 @@ __global__ __launch_bounds__(C::THREADS, C::STAGE * C::NST <= 80 * 1024 ? 2 : 1)
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = (acc[i][2 * qh + (e >> 2)][e & 3] - mean[i]) * rstd[i] * gv[e] + bt[e];
             const int64_t oo = g.o_panel ? ((int64_t)(col >> 5) * g.ldo + row) * 32 + (col & 31) : row * g.ldo + col;
-            store8(outT + oo, v);
+            store8_nt(outT + oo, v);
           }
         }
       }
@@ -823,7 +823,7 @@ __global__ __launch_bounds__(C::THREADS, C::STAGE * C::NST <= 80 * 1024 ? 2 : 1)
               if constexpr (ACT != MH_ACT_NONE) {
                 if (g.pre_out) {   // training: the backward needs the pre-activation
                   const int64_t po = g.o_panel ? ((int64_t)(col >> 5) * g.ldo + row) * 32 + (col & 31) : row * g.ldo + col;
-                  store8(reinterpret_cast<bf16*>(g.pre_out) + (int64_t)blockIdx.y * g.sO + po, v);
+                  store8_nt(reinterpret_cast<bf16*>(g.pre_out) + (int64_t)blockIdx.y * g.sO + po, v);
                 }
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = apply_act<bf16>(v[e], ACT);
@@ -839,7 +839,7 @@ __global__ __launch_bounds__(C::THREADS, C::STAGE * C::NST <= 80 * 1024 ? 2 : 1)
                 store8(outF + row * g.ldo + col, v);
               } else {
                 const int64_t oo = g.o_panel ? ((int64_t)(col >> 5) * g.ldo + row) * 32 + (col & 31) : row * g.ldo + col;
-                store8(outT + oo, v);
+                store8_nt(outT + oo, v);
               }
             }
           }
@@ -959,7 +959,7 @@ int launch(const GemmArgs& g, int dtype, hipStream_t s, int batch = 1) {
 extern "C" int mh_gemm_bias_res_ln_supported(int N) { return N == 128 || N == 256 || N == 512; }
 
 extern "C" int mh_gemm_set_debug(int bits) {
-  g_dbg = bits & 63;
+  g_dbg = bits & 127;
   return MH_OK;
 }
 
@@ -978,7 +978,7 @@ extern "C" int mh_gemm_bias_act(const void* A, int64_t lda, const void* W, int64
   GemmArgs g{};
   g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.bias = bias;
   g.residual = residual; g.ldr = residual ? ldr : 8; g.out = out; g.ldo = ldo; g.out_f32 = out_f32;
-  g.M = M; g.N = N; g.K = K; g.act = act; g.dbg = g_dbg & 63;
+  g.M = M; g.N = N; g.K = K; g.act = act; g.dbg = g_dbg & 127;
   return launch<0>(g, dtype, (hipStream_t)stream);
 }
 
@@ -994,7 +994,7 @@ extern "C" int mh_gemm_bias_act_ex(const void* A, int64_t lda, int a_panel, cons
   GemmArgs g{};
   g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.bias = bias;
   g.residual = residual; g.ldr = residual ? ldr : 8; g.out = out; g.ldo = ldo; g.out_f32 = out_f32;
-  g.M = M; g.N = N; g.K = K; g.act = act; g.dbg = g_dbg & 63;
+  g.M = M; g.N = N; g.K = K; g.act = act; g.dbg = g_dbg & 127;
   g.a_panel = a_panel; g.w_panel = w_panel; g.o_panel = o_panel; g.r_panel = residual ? r_panel : 0;
   return launch<0>(g, dtype, (hipStream_t)stream);
 }
