@@ -459,6 +459,12 @@ int mh_corrupt_random_rotating(const int32_t* values, const int64_t* offsets, co
  * EOS or -1, validate_once passes, validate_rigidly passes | -2 where the reference raises IndexError on a truncated note) */
 int mh_validate_tokens(const int32_t* tokens, const int32_t* lens, int32_t* result, int B, int L, mh_stream_t stream);
 
+/* metric.py:4-71 get_vectors over a batch of note sequences tokens [B, L] (valid length lens[b], NULL = L):
+ * out[b] = [32 rhythm | 12 melody | 12 harmony] fp32, each L2-normalised - the MSIM / 1NNC features.  status[b] (may be
+ * NULL): 0 ok, 1 = no BAR token, 2 = malformed note group / no terminator (the reference raises ValueError / IndexError). */
+int mh_msim_vectors(const int32_t* tokens, const int32_t* lens, float* out, int32_t* status, int B, int L, float note_len,
+                    mh_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -226,6 +226,76 @@ __global__ void validate_tokens_kernel(const int32_t* __restrict__ tokens, const
   }
 }
 
+// MSIM feature vectors (metric.py:4-71 get_vectors): one lane per sequence walks its note tokens - the scan is a data-dependent
+// state machine (steps of 1, 2 or 4 tokens), so sequences, not tokens, are the parallel dimension.
+// out[b] = [32 rhythm | 12 melody | 12 harmony], each L2-normalised; status[b]: 0 ok, 1 no BAR, 2 malformed token / ran off the end
+__global__ void msim_vectors_kernel(const int32_t* __restrict__ tokens, const int32_t* __restrict__ lens, float* __restrict__ out,
+                                    int32_t* __restrict__ status, int B, int L, float note_len) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const int32_t* midi = tokens + (int64_t)b * L;
+  const int n = lens ? lens[b] : L;
+  float rhythm[32], tmp[32], melody[12], harmony[12];
+#pragma unroll
+  for (int k = 0; k < 32; ++k) { rhythm[k] = 1e-8f; tmp[k] = 1e-8f; }
+#pragma unroll
+  for (int k = 0; k < 12; ++k) { melody[k] = 1e-8f; harmony[k] = 0.f; }
+  int st = 0, i = 0;
+  while (i < n && midi[i] != 2) ++i;
+  if (i >= n) st = 1;
+  ++i;
+  int cur_hi = -1, prev_hi = -1, prev_startp = -1, startp = -2;
+  auto norm32 = [](const float* v, int cnt) {
+    float ss = 0.f;
+    for (int k = 0; k < cnt; ++k) ss += v[k] * v[k];
+    return sqrtf(ss);
+  };
+  while (st == 0) {
+    if (i >= n) { st = 2; break; }
+    const int32_t tok = midi[i];
+    if (tok <= 2) {
+      const float nt = norm32(tmp, 32);
+      for (int k = 0; k < 32; ++k) { rhythm[k] += tmp[k] / nt; tmp[k] = 1e-8f; }
+      ++i;
+      if (tok == 2) { prev_startp = -1; continue; }
+      if (prev_startp != startp && prev_hi >= 0) melody[(((cur_hi - prev_hi) % 12) + 12) % 12] += 1.f;
+      break;
+    }
+    if (tok < 432 || tok > 559 || i + 1 >= n) { st = 2; break; }
+    startp = tok - 432;
+    const int32_t t1 = midi[i + 1];
+    if (t1 >= 195 && t1 <= 303) { i += 2; continue; }
+    if (i + 3 >= n || t1 < 131 || t1 > 194 || midi[i + 2] < 3 || midi[i + 2] > 130 || midi[i + 3] < 304 || midi[i + 3] > 431) { st = 2; break; }
+    const int pitch = midi[i + 2];
+    const int endp = startp + midi[i + 3] - 303;
+    harmony[pitch % 12] += 1.f;
+    const double amp0 = 0.00542676376 * (double)(t1 - 130) * 2.0 + 0.310801;
+    const double amp = amp0 * amp0;
+    const int tend = endp < 128 ? endp : 128;
+    for (int t = 0; t < tend; t += 4) {
+      if (t < startp) continue;
+      double w = 1.0 - (double)(t - startp) / (double)note_len;
+      if (w < 0.0) w = 0.0;
+      const double v = amp * w;
+      if (v > (double)tmp[t >> 2]) tmp[t >> 2] = (float)v;
+    }
+    if (cur_hi >= 0 && prev_startp != startp) {
+      if (prev_hi >= 0) melody[(((cur_hi - prev_hi) % 12) + 12) % 12] += 1.f;
+      prev_hi = cur_hi;
+      cur_hi = pitch;
+    }
+    cur_hi = pitch > cur_hi ? pitch : cur_hi;
+    prev_startp = startp;
+    i += 4;
+  }
+  float* o = out + (int64_t)b * 56;
+  const float nr = norm32(rhythm, 32), nm = norm32(melody, 12), nh = norm32(harmony, 12);
+  for (int k = 0; k < 32; ++k) o[k] = rhythm[k] / nr;
+  for (int k = 0; k < 12; ++k) o[32 + k] = melody[k] / nm;
+  for (int k = 0; k < 12; ++k) o[44 + k] = harmony[k] / nh;
+  if (status) status[b] = st;
+}
+
 }  // namespace
 
 extern "C" int mh_batch_max_row(void) { return MAX_ROW; }
@@ -282,6 +352,14 @@ extern "C" int mh_corrupt_random_rotating(const int32_t* values, const int64_t* 
 extern "C" int mh_validate_tokens(const int32_t* tokens, const int32_t* lens, int32_t* result, int B, int L, mh_stream_t stream) {
   MH_CHECK_ARG(tokens && result && B > 0 && L > 0, "validate_tokens: bad arguments");
   MH_LAUNCH(validate_tokens_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, tokens, lens, result, L);
+  MH_CHECK_LAUNCH();
+  return MH_OK;
+}
+
+extern "C" int mh_msim_vectors(const int32_t* tokens, const int32_t* lens, float* out, int32_t* status, int B, int L, float note_len,
+                               mh_stream_t stream) {
+  MH_CHECK_ARG(tokens && out && B > 0 && L > 0 && note_len > 0.f, "msim_vectors: bad arguments");
+  MH_LAUNCH(msim_vectors_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, tokens, lens, out, status, B, L, note_len);
   MH_CHECK_LAUNCH();
   return MH_OK;
 }

@@ -131,3 +131,69 @@ def validate(tokens, length):
             continue
         break
     return int(eos[0]), once, rigid
+
+
+def msim_vectors(midi, note_len=128):
+    """metric.py:4-71 get_vectors: [32 rhythm | 12 melody | 12 harmony] fp32, each L2-normalised.  `midi` = note tokens from
+    anywhere before the first BAR up to the EOS / padding.  The amplitude expression is evaluated in double and rounded to
+    fp32 on store, as Python floats assigned into a float32 tensor are."""
+    f32 = np.float32
+    i = 0
+    while midi[i] != BAR:
+        i += 1
+    i += 1
+    rhythm = np.full(32, 1e-8, f32)
+    tmp = np.full(32, 1e-8, f32)
+    melody = np.full(12, 1e-8, f32)
+    harmony = np.zeros(12, f32)
+    cur_hi, prev_hi, prev_startp, startp = -1, -1, -1, None
+
+    def norm(v):
+        return f32(np.sqrt(np.sum(v.astype(np.float32) ** 2, dtype=np.float32)))
+    while True:
+        if midi[i] <= 2:
+            tmp = tmp / norm(tmp)
+            rhythm = rhythm + tmp
+            tmp = np.full(32, 1e-8, f32)
+            i += 1
+            if midi[i - 1] == BAR:
+                prev_startp = -1
+                continue
+            if prev_startp != startp and prev_hi >= 0:
+                melody[(cur_hi - prev_hi) % 12] += 1
+            break
+        assert POSITION <= midi[i] <= 559
+        startp = int(midi[i]) - POSITION
+        if CHORD <= midi[i + 1] <= 303:
+            i += 2
+            continue
+        assert VELOCITY <= midi[i + 1] <= 194 and PITCH <= midi[i + 2] <= 130 and DURATION <= midi[i + 3] <= 431
+        pitch = int(midi[i + 2])
+        endp = startp + int(midi[i + 3]) - 303
+        harmony[pitch % 12] += 1
+        amp = (0.00542676376 * (int(midi[i + 1]) - 130) * 2 + 0.310801) ** 2
+        for t in range(0, min(128, endp), 4):
+            if t < startp:
+                continue
+            v = amp * max(0, 1 - (t - startp) / note_len)
+            if v > tmp[t // 4]:
+                tmp[t // 4] = f32(v)
+        if cur_hi >= 0 and prev_startp != startp:
+            if prev_hi >= 0:
+                melody[(cur_hi - prev_hi) % 12] += 1
+            prev_hi = cur_hi
+            cur_hi = pitch
+        cur_hi = max(pitch, cur_hi)
+        prev_startp = startp
+        i += 4
+    return np.concatenate([rhythm / norm(rhythm), melody / norm(melody), harmony / norm(harmony)]).astype(f32)
+
+
+def onnc(vectors):
+    """metric.py:86-117: MSIM matrix (diagonal zeroed), most similar index per row, 1NNC over (first half GT, second generated)"""
+    r, m, h = vectors[:, :32], vectors[:, 32:44], vectors[:, 44:]
+    sim = (r @ r.T) * (m @ m.T) * (h @ h.T)
+    np.fill_diagonal(sim, 0)
+    most = sim.argmax(1)
+    half = len(vectors) // 2
+    return ((most[:half] < half).sum() + (most[half:] >= half).sum()) / len(vectors), sim, most

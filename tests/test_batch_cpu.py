@@ -47,3 +47,15 @@ def test_validators_match_reference():
         assert tuple(int(v) for v in g["val_result"][i]) == got, (i, got, g["val_result"][i])
     r = g["val_result"]
     assert (r[:, 0] == -1).any() and (r[:, 1] == 0).any() and (r[:, 2] == 0).any() and (r[:, 2] == 1).any()
+
+
+def test_msim_vectors_and_onnc_match_reference():
+    g = load_golden("batch.npz")
+    seqs = rows(g)
+    vec = np.stack([ob.msim_vectors(s[12:]) for s in seqs])
+    np.testing.assert_allclose(vec, g["msim_vectors"], rtol=2e-6, atol=2e-7)       # torch.norm's fp32 summation order differs
+    val, sim, most = ob.onnc(g["msim_vectors"])
+    assert np.array_equal(most, g["onnc_mostsim"]) and abs(val - float(g["onnc"])) < 1e-7
+    np.testing.assert_allclose(sim, g["onnc_msim"], rtol=1e-5, atol=1e-7)
+    r = g["msim_vectors"]
+    assert abs(float((r[0, :32] @ r[1, :32]) * (r[0, 32:44] @ r[1, 32:44]) * (r[0, 44:] @ r[1, 44:])) - float(g["msim_01"])) < 1e-6

@@ -117,3 +117,47 @@ def test_validators_and_corruptions_at_batch_scale_match_the_oracle():
     lens = (col["length"].cpu().numpy() - 12).clip(0)
     for i in range(0, len(rows), 5):
         assert tuple(res[i]) == ob.validate(toks[i], int(lens[i])), i
+
+
+def test_msim_vectors_and_onnc_match_reference():
+    from musediffusion_amd import metric as mm
+    g = load_golden("batch.npz")
+    off = g["offsets"]
+    L = 256
+    toks = np.zeros((12, L), np.int32)
+    lens = np.zeros(12, np.int32)
+    for i in range(12):
+        s = g["values"][off[i] + 12:off[i + 1]]
+        toks[i, :len(s)], lens[i] = s, len(s)
+    vec, st = mm.get_vectors(dev(toks), dev(lens), return_status=True)
+    assert int(st.abs().sum()) == 0
+    np.testing.assert_allclose(vec.cpu().numpy(), g["msim_vectors"], rtol=2e-6, atol=2e-7)       # fp32 norm summation order
+    onnc, sim, most = mm.ONNC(dev(toks), dev(lens), return_MSIM=True, return_mostsim=True)
+    assert np.array_equal(most.cpu().numpy(), g["onnc_mostsim"]) and abs(float(onnc) - float(g["onnc"])) < 1e-7
+    np.testing.assert_allclose(sim.cpu().numpy(), g["onnc_msim"], rtol=1e-5, atol=1e-7)
+    ms = mm.MSIM(dev(toks[:1]), dev(toks[1:2]), dev(lens[:1]), dev(lens[1:2]))
+    assert abs(float(ms[0]) - float(g["msim_01"])) < 1e-6
+    # malformed rows are flagged, not crashed on: no BAR / a position token followed by garbage
+    bad = np.zeros((2, 16), np.int32)
+    bad[0, :4] = [432, 140, 60, 310]
+    bad[1, :5] = [2, 432, 7, 7, 1]
+    _, st2 = mm.get_vectors(dev(bad), return_status=True)
+    assert st2.cpu().tolist() == [1, 2]
+    # batch scale against the oracle
+    rng = np.random.default_rng(9)
+    rows = []
+    for _ in range(256):
+        seq = []
+        for k in range(int(rng.integers(5, 180))):
+            if k % 5 == 0:
+                seq.append(2)
+            seq += [int(rng.integers(432, 560)), int(rng.integers(131, 195)), int(rng.integers(3, 131)), int(rng.integers(304, 432))]
+        seq.append(1)
+        rows.append(np.array(seq, np.int32))
+    Lb = max(len(r) for r in rows)
+    tb = np.zeros((len(rows), Lb), np.int32)
+    for i, r in enumerate(rows):
+        tb[i, :len(r)] = r
+    got = mm.get_vectors(dev(tb)).cpu().numpy()
+    for i in range(0, len(rows), 9):
+        np.testing.assert_allclose(got[i], ob.msim_vectors(rows[i]), rtol=3e-6, atol=3e-7)

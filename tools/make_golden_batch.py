@@ -46,6 +46,7 @@ for _name in ("logger", "miditoolkit", "parmap", "pretty_midi"):
 from MuseDiffusion.data import corruption as rcorr  # noqa: E402
 from MuseDiffusion.data.wrapper import collate_batches  # noqa: E402
 from MuseDiffusion.utils import decode_util as rdec  # noqa: E402
+from MuseDiffusion import metric as rmetric  # noqa: E402
 
 
 class Recorder:
@@ -195,6 +196,14 @@ def main():
                 except IndexError:                                   # validate_rigidly indexes past the end on truncated notes
                     res[i, j] = -2
     out["val_tokens"], out["val_len"], out["val_result"] = toks, lens_v, res
+
+    # ---- MSIM feature vectors / MSIM / 1NNC (metric.py:4-117) on the note parts of the 12 sequences
+    notes = [np.array(s[12:], dtype=np.int64) for s in seqs]
+    vecs = [torch.cat(rmetric.get_vectors(n)).numpy() for n in notes]              # [32 rhythm | 12 melody | 12 harmony]
+    out["msim_vectors"] = np.stack(vecs).astype(np.float32)
+    out["msim_01"] = np.float32(rmetric.MSIM(notes[0], notes[1]))
+    onnc, sim, most = rmetric.ONNC(notes, return_MSIM=True, return_mostsim=True)
+    out["onnc"], out["onnc_msim"], out["onnc_mostsim"] = np.float32(onnc), sim.numpy().astype(np.float32), most.numpy().astype(np.int64)
 
     path = os.path.join(REPO, "tests", "golden", "batch.npz")
     np.savez_compressed(path, **out)
