@@ -368,6 +368,11 @@ int mh_gemm_set_variant(int variant);
  * autograd: the backward needs the pre-activation (training_losses, models/diffusion.py:594-699). */
 int mh_gemm_bias_act_pre(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, void* pre_out,
                          void* out, int64_t ldo, int64_t M, int N, int K, int act, mh_stream_t stream);
+/* out = (A W^T) o act'(pre)  (act = MH_ACT_TANH or MH_ACT_GELU_ERF; bf16 row-major, big-tile shapes): the input-gradient
+ * GEMM of the layer that FOLLOWS an activation, with the activation's backward in its epilogue - d(pre) of a dense + GELU
+ * block without materialising d(activation) (training_losses backward, models/diffusion.py:594-699). */
+int mh_gemm_act_grad(const void* A, int64_t lda, const void* W, int64_t ldw, const void* pre, int64_t ld_pre, void* out,
+                     int64_t ldo, int64_t M, int N, int K, int act, mh_stream_t stream);
 /* out = LayerNorm(A W^T + bias + residual) * gamma + beta, bf16, the whole row normalised inside the
  * GEMM epilogue (one block owns all N columns: N must be 128, 256 or 512 - see ..._supported).
  * Replaces BertSelfOutput / BertOutput (dense -> LayerNorm(hidden + input)) of the encoder that

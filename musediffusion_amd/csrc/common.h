@@ -116,4 +116,18 @@ __device__ __forceinline__ float gelu_erf_fast(float x) {
   return x * __builtin_amdgcn_rcpf(1.0f + e);
 }
 
+// d/dx of the erf-form GELU, Phi(x) + x phi(x), for the fused backward epilogue: erf by Abramowitz-Stegun 7.1.26
+// (|err| <= 1.5e-7); exp(-x^2/2) is shared between the erf tail and the density
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  const float e = __builtin_amdgcn_exp2f(-z * z * 1.4426950408889634f);   // exp(-x^2 / 2)
+  const float erf_abs = 1.0f - p * t * e;
+  return 0.5f * (1.0f + copysignf(erf_abs, x)) + x * 0.3989422804014327f * e;
+}
+
 static inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

@@ -32,6 +32,7 @@ struct GemmArgs {
   // QKV scatter
   void* q; void* k; void* vt;
   void* pre_out;   // EPI 0 with an activation (big tile): also store the pre-activation (bias added) here, same layout as out
+  int act_grad;    // EPI 0 (big tile): `residual` holds a PRE-activation and the result is multiplied by act'(it) instead of added to
   int L, H, nh, dh;
   // EPI 2 (nearest-embedding scores): aux[col] = |W_col|^2, rown[row] = |x_row|^2, partial best per (row, slot)
   const float* aux; const float* rown; float* pbest; int32_t* pidx; int nslots;
@@ -832,8 +833,16 @@ __global__ __launch_bounds__(C::THREADS, C::STAGE * C::NST <= 80 * 1024 ? 2 : 1)
                 const int64_t ro = g.r_panel ? ((int64_t)(col >> 5) * g.ldr + row) * 32 + (col & 31) : row * g.ldr + col;
                 float rv[8];
                 load8(res + ro, rv);
+                if (g.act_grad == MH_ACT_GELU_ERF) {          // backward of dense + GELU: dpre = (dY W) o gelu'(pre)
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] += rv[e];
+                  for (int e = 0; e < 8; ++e) v[e] *= gelu_erf_grad(rv[e]);
+                } else if (g.act_grad == MH_ACT_TANH) {
+#pragma unroll
+                  for (int e = 0; e < 8; ++e) { const float th = tanhf(rv[e]); v[e] *= 1.0f - th * th; }
+                } else {
+#pragma unroll
+                  for (int e = 0; e < 8; ++e) v[e] += rv[e];
+                }
               }
               if (g.out_f32) {
                 store8(outF + row * g.ldo + col, v);
@@ -1032,6 +1041,19 @@ extern "C" int mh_gemm_bias_act_pre(const void* A, int64_t lda, const void* W, i
   g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.bias = bias; g.ldr = 8; g.out = out; g.ldo = ldo;
   g.M = M; g.N = N; g.K = K; g.act = act; g.pre_out = pre_out;
   MH_CHECK_ARG(g_variant >= 2 && lda % 8 == 0 && ldw % 8 == 0 && big_tile_ok(g), "gemm_bias_act_pre: shape not served by the big-tile kernel");
+  return launch<0>(g, MH_BF16, (hipStream_t)stream);
+}
+
+// out = (A W^T) o act'(pre): the input-gradient GEMM of the layer AFTER an activation with the activation's own backward
+// folded into its epilogue (bf16 row-major, big-tile shapes; act = tanh or erf-GELU)
+extern "C" int mh_gemm_act_grad(const void* A, int64_t lda, const void* W, int64_t ldw, const void* pre, int64_t ld_pre, void* out,
+                                int64_t ldo, int64_t M, int N, int K, int act, mh_stream_t stream) {
+  MH_CHECK_ARG(A && W && pre && out, "gemm_act_grad: null pointer");
+  MH_CHECK_ARG(M > 0 && N > 0 && (act == MH_ACT_TANH || act == MH_ACT_GELU_ERF), "gemm_act_grad: bad problem / activation");
+  GemmArgs g{};
+  g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.residual = pre; g.ldr = ld_pre; g.out = out; g.ldo = ldo;
+  g.M = M; g.N = N; g.K = K; g.act = MH_ACT_NONE; g.act_grad = act;
+  MH_CHECK_ARG(g_variant >= 2 && lda % 8 == 0 && ldw % 8 == 0 && big_tile_ok(g), "gemm_act_grad: shape not served by the big-tile kernel");
   return launch<0>(g, MH_BF16, (hipStream_t)stream);
 }
 

@@ -22,6 +22,7 @@ from . import _lib, ops
 from ._lib import MH_BF16, MH_F32, check, current_stream, lib, ptr
 
 NPART = 256  # rows of the two-stage column-sum scratch
+FUSED_FFN = True        # bf16: FFN as one tape node with the GELU backward fused into a GEMM epilogue (A/B switch for tests)
 FUSED_ATTENTION = True  # bf16: streaming forward + fused backward kernels when the shape allows (A/B switch for tests)
 
 
@@ -158,6 +159,54 @@ class _Linear(Function):
         xT = _transpose(x, M, Kp, dt, ld_out=Mp)                        # [Kp, Mp]
         dW = _gemm_dw(dT, xT, N, Kp, Mp, dt)
         return dx, dW[:, :K].contiguous(), db, None, (dy if has_res else None), None
+
+
+class _FFN(Function):
+    """y = gelu(x W1^T + b1) W2^T + b2 + x  (HF BertIntermediate + BertOutput.dense + residual) as ONE tape node, so the
+    backward can fold the GELU derivative into the input-gradient GEMM of the second dense: d(pre) = (dY W2) o gelu'(pre)
+    comes out of one kernel and d(activation) is never written (bf16, 64-aligned widths; otherwise two _Linear nodes)."""
+
+    @staticmethod
+    def supported(x, W1, W2, dt):
+        F, H = W1.shape
+        return dt == ops.MH_BF16 and x.shape[1] == H and H % 64 == 0 and F % 64 == 0 and tuple(W2.shape) == (H, F)
+
+    @staticmethod
+    def forward(ctx, x, W1, b1, W2, b2, dt):
+        M, H = x.shape
+        F = W1.shape[0]
+        W1c, W2c = ops.cast_pad(W1.detach(), H, dt), ops.cast_pad(W2.detach(), F, dt)
+        pre = torch.empty(M, F, device=x.device, dtype=x.dtype)
+        f = torch.empty_like(pre)
+        check(lib().mh_gemm_bias_act_pre(ptr(x), H, ptr(W1c), H, ptr(b1.detach()), ptr(pre), ptr(f), F, M, F, H, ops.ACT["gelu"],
+                                         current_stream()), "mh_gemm_bias_act_pre")
+        y = torch.empty(M, H, device=x.device, dtype=x.dtype)
+        _gemm(f, W2c, b2.detach(), dt, H, F, out=y, residual=x)
+        ctx.save_for_backward(x, W1c, W2c, pre, f)
+        ctx.dt = dt
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, W1c, W2c, pre, f = ctx.saved_tensors
+        dt = ctx.dt
+        M, H = x.shape
+        F = W1c.shape[0]
+        dy = dy.contiguous()
+        db2 = _col_sum(dy, M, H, dt)
+        dyT = _transpose(dy, M, H, dt, ld_out=M)                          # [H, M]
+        dW2 = _gemm_dw(dyT, _transpose(f, M, F, dt, ld_out=M), H, F, M, dt)
+        # d(pre) = (dy W2) o gelu'(pre): W2 is [H, F]; the GEMM wants the reduction dim contiguous -> W2^T [F, H]
+        dpre = torch.empty(M, F, device=x.device, dtype=x.dtype)
+        W2T = _transpose(W2c, H, F, dt, ld_out=H)
+        check(lib().mh_gemm_act_grad(ptr(dy), H, ptr(W2T), H, ptr(pre), F, ptr(dpre), F, M, F, H, ops.ACT["gelu"], current_stream()),
+              "mh_gemm_act_grad")
+        db1 = _col_sum(dpre, M, F, dt)
+        dW1 = _gemm_dw(_transpose(dpre, M, F, dt, ld_out=M), _transpose(x, M, H, dt, ld_out=M), F, H, M, dt)
+        dx = torch.empty(M, H, device=x.device, dtype=x.dtype)
+        W1T = _transpose(W1c, F, H, dt, ld_out=F)                         # [H, F]
+        _gemm(dpre, W1T, None, dt, H, F, out=dx, residual=dy)             # + dy: the residual branch
+        return dx, dW1, db1, dW2, db2, None
 
 
 class _LayerNorm(Function):
@@ -445,8 +494,12 @@ def denoiser_forward_with_grad(model, x, timesteps):
         y1 = _linear(ctxv, layer.attention.output.dense, None, dt, residual=X)
         X1 = _LayerNorm.apply(y1, layer.attention.output.LayerNorm.weight, layer.attention.output.LayerNorm.bias,
                               layer.attention.output.LayerNorm.eps, dt)
-        f = _linear(X1, layer.intermediate.dense, "gelu", dt)
-        y2 = _linear(f, layer.output.dense, None, dt, residual=X1)
+        d1, d2 = layer.intermediate.dense, layer.output.dense
+        if FUSED_FFN and (B * L) % 64 == 0 and _FFN.supported(X1, d1.weight, d2.weight, dt):
+            y2 = _FFN.apply(X1, d1.weight, d1.bias, d2.weight, d2.bias, dt)
+        else:
+            f = _linear(X1, d1, "gelu", dt)
+            y2 = _linear(f, d2, None, dt, residual=X1)
         X = _LayerNorm.apply(y2, layer.output.LayerNorm.weight, layer.output.LayerNorm.bias, layer.output.LayerNorm.eps, dt)
     if model.output_dims != H:
         h = _linear(X, model.output_down_proj[0], "tanh", dt)

@@ -145,8 +145,8 @@ def test_ddp_wrapped_training_step_single_rank_nccl():
 
 
 def test_fused_attention_training_path_matches_unfused():
-    """seq_len 512 engages the streaming attention forward + fused backward kernels in training_losses (bf16):
-    same loss and gradients as the batched-GEMM / materialised-softmax path, up to bf16 rounding"""
+    """seq_len 512 engages the streaming attention forward + fused backward kernels and the one-node FFN (GELU backward in a
+    GEMM epilogue) in training_losses (bf16): same loss and gradients as the unfused tape, up to bf16 rounding"""
     from musediffusion_amd import synthetic, training
     torch.manual_seed(3)
     E, H, L, B, V = 32, 128, 512, 2, 97
@@ -163,17 +163,19 @@ def test_fused_attention_training_path_matches_unfused():
     t = torch.tensor([400, 1500], device=DEV)
     res = []
     for fused in (True, False):
-        training.FUSED_ATTENTION = fused
+        training.FUSED_ATTENTION = training.FUSED_FFN = fused
         m.zero_grad(set_to_none=True)
         with CpuDraws(11):
             terms = diff.training_losses(m, t, model_kwargs=batch)
         terms["loss"].mean().backward()
         res.append((terms["loss"].detach().float().cpu(),
                     {n: p.grad.detach().float().cpu().clone() for n, p in m.named_parameters() if p.grad is not None}))
-    training.FUSED_ATTENTION = True
+    training.FUSED_ATTENTION = training.FUSED_FFN = True
     assert torch.allclose(res[0][0], res[1][0], rtol=2e-2, atol=2e-2), (res[0][0], res[1][0])
     for name in ("input_transformers.layer.0.attention.self.query.weight", "input_transformers.layer.0.attention.self.key.weight",
-                 "input_transformers.layer.1.attention.self.value.weight", "word_embedding.weight", "time_embed.0.weight"):
+                 "input_transformers.layer.1.attention.self.value.weight", "input_transformers.layer.0.intermediate.dense.weight",
+                 "input_transformers.layer.1.output.dense.weight", "input_transformers.layer.0.intermediate.dense.bias",
+                 "word_embedding.weight", "time_embed.0.weight"):
         a, b = res[0][1][name].flatten(), res[1][1][name].flatten()
         cos = float(torch.nn.functional.cosine_similarity(a, b, dim=0))
         print("%s: cosine %.5f, |fused| %.3e |unfused| %.3e" % (name, cos, float(a.norm()), float(b.norm())))
