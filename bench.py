@@ -367,7 +367,7 @@ def main():
                                "traffic": pmc_traffic(args.workload, args.dtype, int(loop.nsplit)), "avg_launch_ms": round(avg_ms, 5),
                                "concurrent_streams": int(loop.nsplit), "launch_latency_ms": round(lat_ms, 5),
                                "flops_per_launch": fpl}
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:     # the host baseline is a rank-0, N = 1 measurement
             out["cpu_baseline"] = cpu_baseline(c)
             out["cpu_baseline"]["value"] = round(out["cpu_baseline"]["value"], 5)
         print(json.dumps(out), flush=True)
