@@ -15,9 +15,9 @@ T = 2000 sqrt schedule), synthetic ComMU-shaped generation batch, torch-default 
 own batch of 64 (weak scaling; the reference shards whole batches over ranks, run/sample.py:169);
 rank 0 builds the weights and ONE RCCL broadcast of the packed arena distributes them.
 
-Prints ONE JSON line (rank 0) with the driver's contract plus `roofline` (dominant kernel: the bf16
-MFMA GEMM of the FFN intermediate dense, timed live with HIP events on the launch stream) and `cpu_baseline` (the oracle = a
-torch-CPU fp32 port of the reference path, timed on the host cores on a bounded sample).
+Prints ONE JSON line (rank 0) with the driver's contract plus `roofline` (the kernel with the largest time share - the
+bf16 MFMA GEMM with the LayerNorm epilogue - timed live with HIP events on the launch streams) and, at N = 1,
+`cpu_baseline` (the oracle = a torch-CPU fp32 port of the reference path, timed on the host cores on a bounded sample).
 """
 import argparse
 import json
