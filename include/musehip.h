@@ -389,6 +389,10 @@ int mh_denoiser_get_fuse_ln(void);
 /* Timing-only ablation of the big-tile kernel (results are WRONG when non-zero): bit 0 skips the
  * DMA loads, bit 1 the MFMAs, bit 2 the epilogue stores, bit 3 the LDS fragment reads.  Used by tools/gemm_bench.py only. */
 int mh_gemm_set_debug(int bits);
+/* A/B: which big-tile epilogues use ordinary instead of streaming (nt) output stores: bit 0 QKV scatter, bit 1 dense + GELU
+ * (default 0: both streaming - their outputs are large and read once; measured -0.8% step time for dense + GELU, neutral for QKV).
+ * The dense + residual + LayerNorm epilogue always stores normally: its rows are re-read at once (+1.2% with streaming). */
+int mh_gemm_set_plain_stores(int mask);
 
 int mh_graph_begin_capture(mh_stream_t stream);
 int mh_graph_end_capture(mh_stream_t stream, void** graph_exec_out);

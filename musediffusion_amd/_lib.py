@@ -137,6 +137,7 @@ SIGNATURES = {
     "mh_denoiser_set_fuse_ln": (INT, [INT]),
     "mh_denoiser_get_fuse_ln": (INT, []),
     "mh_gemm_set_debug": (INT, [INT]),
+    "mh_gemm_set_plain_stores": (INT, [INT]),
     "mh_graph_begin_capture": (INT, [VP]),
     "mh_graph_end_capture": (INT, [VP, C.POINTER(VP)]),
     "mh_graph_launch": (INT, [VP, VP]),

@@ -709,7 +709,8 @@ __global__ __launch_bounds__(C::THREADS, C::STAGE * C::NST <= 80 * 1024 ? 2 : 1)
               float v[8];
 #pragma unroll
               for (int e = 0; e < 8; ++e) v[e] = acc[i][2 * qh + (e >> 2)][e & 3] + bv[e];
-              store8_nt(dst + ((int64_t)b * g.nh * g.L + l) * g.dh + coloff, v);
+              if constexpr ((DBG & 32) != 0) store8(dst + ((int64_t)b * g.nh * g.L + l) * g.dh + coloff, v);
+              else store8_nt(dst + ((int64_t)b * g.nh * g.L + l) * g.dh + coloff, v);
             }
           }
         }
@@ -803,7 +804,7 @@ __global__ __launch_bounds__(C::THREADS, C::STAGE * C::NST <= 80 * 1024 ? 2 : 1)
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = (acc[i][2 * qh + (e >> 2)][e & 3] - mean[i]) * rstd[i] * gv[e] + bt[e];
             const int64_t oo = g.o_panel ? ((int64_t)(col >> 5) * g.ldo + row) * 32 + (col & 31) : row * g.ldo + col;
-            store8_nt(outT + oo, v);
+            store8(outT + oo, v);   // ordinary store: the next GEMM re-reads these rows (A operand and residual) from L2 / MALL
           }
         }
       }
@@ -848,7 +849,7 @@ __global__ __launch_bounds__(C::THREADS, C::STAGE * C::NST <= 80 * 1024 ? 2 : 1)
                 store8(outF + row * g.ldo + col, v);
               } else {
                 const int64_t oo = g.o_panel ? ((int64_t)(col >> 5) * g.ldo + row) * 32 + (col & 31) : row * g.ldo + col;
-                store8_nt(outT + oo, v);
+                if constexpr ((DBG & 32) != 0) store8(outT + oo, v); else store8_nt(outT + oo, v);
               }
             }
           }
@@ -872,6 +873,8 @@ int device_cus() {
   return cus;
 }
 
+int g_plain_stores = 0;   // A/B: bit 0 QKV, bit 1 dense+GELU epilogues use ordinary instead of streaming stores
+
 template <class C, int EPI>
 int launch_big(const GemmArgs& g0, hipStream_t s, int batch) {
   GemmArgs g = g0;
@@ -884,7 +887,8 @@ int launch_big(const GemmArgs& g0, hipStream_t s, int batch) {
   g.ntiles = (int)t2;
   const dim3 grid((unsigned)(t2 < slots ? t2 : slots), (unsigned)batch), block(C::THREADS);
   if constexpr (EPI == 1) {
-    MH_LAUNCH((gemm_big_kernel<C, 1, MH_ACT_NONE>), grid, block, 0, s, g);
+    if (g_plain_stores & 1) MH_LAUNCH((gemm_big_kernel<C, 1, MH_ACT_NONE, 32>), grid, block, 0, s, g);
+    else MH_LAUNCH((gemm_big_kernel<C, 1, MH_ACT_NONE>), grid, block, 0, s, g);
   } else if constexpr (EPI == 3) {
     MH_LAUNCH((gemm_big_kernel<C, 3, MH_ACT_NONE>), grid, block, 0, s, g);
   } else {
@@ -903,7 +907,10 @@ int launch_big(const GemmArgs& g0, hipStream_t s, int batch) {
       }
     } else switch (g.act) {
       case MH_ACT_TANH: MH_LAUNCH((gemm_big_kernel<C, 0, MH_ACT_TANH>), grid, block, 0, s, g); break;
-      case MH_ACT_GELU_ERF: MH_LAUNCH((gemm_big_kernel<C, 0, MH_ACT_GELU_ERF>), grid, block, 0, s, g); break;
+      case MH_ACT_GELU_ERF:
+        if (g_plain_stores & 2) MH_LAUNCH((gemm_big_kernel<C, 0, MH_ACT_GELU_ERF, 32>), grid, block, 0, s, g);
+        else MH_LAUNCH((gemm_big_kernel<C, 0, MH_ACT_GELU_ERF>), grid, block, 0, s, g);
+        break;
       case MH_ACT_SILU: MH_LAUNCH((gemm_big_kernel<C, 0, MH_ACT_SILU>), grid, block, 0, s, g); break;
       default: MH_LAUNCH((gemm_big_kernel<C, 0, MH_ACT_NONE>), grid, block, 0, s, g); break;
     }
@@ -966,6 +973,11 @@ int launch(const GemmArgs& g, int dtype, hipStream_t s, int batch = 1) {
 }  // namespace
 
 extern "C" int mh_gemm_bias_res_ln_supported(int N) { return N == 128 || N == 256 || N == 512; }
+
+extern "C" int mh_gemm_set_plain_stores(int mask) {
+  g_plain_stores = mask;
+  return MH_OK;
+}
 
 extern "C" int mh_gemm_set_debug(int bits) {
   g_dbg = bits & 127;

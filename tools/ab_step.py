@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""In-process A/B of library switches on the captured reverse step (bench.py workload c2): alternates settings over several
+rounds and prints the median ms/step of each (boxes of the pool differ by several percent; only same-process numbers compare).
+    python tools/ab_step.py plain_stores 0 1 2 4 7"""
+import contextlib
+import io
+import json
+import os
+import statistics
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+knob, values = sys.argv[1], [int(v) for v in sys.argv[2:]]
+sys.argv = ["bench.py", "--steps", "40", "--warmup", "5", "--no-cpu-baseline", "--no-kernel-timing"]
+import bench  # noqa: E402
+from musediffusion_amd import _lib  # noqa: E402
+
+setters = {"plain_stores": lambda v: _lib.lib().mh_gemm_set_plain_stores(v), "fuse_ln": lambda v: _lib.lib().mh_denoiser_set_fuse_ln(v),
+           "stream_attn": lambda v: _lib.lib().mh_attention_set_stream(v), "gemm_variant": lambda v: _lib.lib().mh_gemm_set_variant(v)}
+res = {v: [] for v in values}
+for rnd in range(5):
+    for v in values:
+        setters[knob](v)
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            bench.main()
+        res[v].append(json.loads(buf.getvalue().strip().splitlines()[-1])["ms_per_step"])
+for v in values:
+    print("%s=%d: median %.4f ms/step (min %.4f)" % (knob, v, statistics.median(res[v]), min(res[v])), flush=True)
