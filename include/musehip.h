@@ -360,8 +360,8 @@ int mh_step_end(mh_loop_state* state, mh_stream_t stream);
 /* Thin hipGraph wrappers so the host can capture a sequence of the calls above on `stream` and
  * replay it (hipStreamBeginCapture / EndCapture / GraphInstantiate / GraphLaunch). */
 /* A/B switch between the bf16 GEMM kernels: 0 = 128x128 tile, register-staged; 1 = 128x128 tile,
- * global_load_lds; 2 (default) = big tile chosen per shape; 3 = always 256x128 (4 waves, 3-stage
- * global_load_lds ring); 4 = always 256x256 (8 waves, 4-stage ring). */
+ * global_load_lds; 2 (default) and 3 = 256x128 tile (4 waves, 3-stage global_load_lds ring, two blocks per CU);
+ * 4 = 256x256 (8 waves, 4-stage ring) where N % 256 == 0; 5 = 256x256 with the ping-pong main loop. */
 int mh_gemm_set_variant(int variant);
 /* out = act(A W^T + bias) and pre_out = A W^T + bias in one pass (bf16 row-major; shapes the big-tile kernel
  * serves: N % 8 == 0, K % 32 == 0, lda / ldw / ldo % 8 == 0; error otherwise).  Forward of dense + GELU / tanh under

@@ -861,7 +861,7 @@ __global__ __launch_bounds__(C::THREADS, C::STAGE * C::NST <= 80 * 1024 ? 2 : 1)
 }
 
 int g_dbg = 0;
-int g_variant = 2;  // bf16 kernel choice: 0 small-tile register-staged, 1 small-tile global_load_lds, 2 big tile (auto), 3 big Std, 4 big Wide
+int g_variant = 2;  // bf16 kernel choice: 0 small-tile register-staged, 1 small-tile global_load_lds, 2 / 3 big 256x128, 4 big 256x256, 5 big 256x256 ping-pong
 
 int device_cus() {
   static int cus = 0;
@@ -924,12 +924,12 @@ bool big_tile_ok(const GemmArgs& g) {
          (g.r_panel || g.ldr % 8 == 0);
 }
 
-// the wide tile moves 1.5x fewer operand bytes per flop but holds one block per CU: worth it once the grid
-// still covers the chip (>= 256 blocks) and N fills its 256 columns
+// The wide (256x256, one block per CU) tile moves 1.5x fewer operand bytes per flop, but measured inside the captured step
+// (tools/ab_step.py, two graph branches) the 256x128 tile is 1.2% faster: at two blocks per CU the blocks of two
+// concurrently running kernels share a CU, which is what the branches are for.  Wide / ping-pong stay selectable (4 / 5).
 bool want_wide(const GemmArgs& g, int batch) {
-  if (g_variant == 3) return false;
-  if (g_variant >= 4) return true;
-  return g.N % 256 == 0 && (int64_t)ceil_div(g.M, CfgWide::BM) * (g.N / 256) * batch >= 256;
+  (void)batch;
+  return g_variant >= 4 && g.N % 256 == 0;
 }
 
 template <int EPI>

@@ -16,11 +16,17 @@ import bench  # noqa: E402
 from musediffusion_amd import _lib  # noqa: E402
 
 setters = {"plain_stores": lambda v: _lib.lib().mh_gemm_set_plain_stores(v), "fuse_ln": lambda v: _lib.lib().mh_denoiser_set_fuse_ln(v),
+           "v3_fuse_ln": lambda v: (_lib.lib().mh_gemm_set_variant(3), _lib.lib().mh_denoiser_set_fuse_ln(v)),
+           "v3_split": None,
            "stream_attn": lambda v: _lib.lib().mh_attention_set_stream(v), "gemm_variant": lambda v: _lib.lib().mh_gemm_set_variant(v)}
 res = {v: [] for v in values}
-for rnd in range(5):
+for rnd in range(3):
     for v in values:
-        setters[knob](v)
+        if knob == "v3_split":
+            _lib.lib().mh_gemm_set_variant(3)
+            sys.argv = ["bench.py", "--steps", "40", "--warmup", "5", "--no-cpu-baseline", "--no-kernel-timing", "--split", str(v)]
+        else:
+            setters[knob](v)
         buf = io.StringIO()
         with contextlib.redirect_stdout(buf):
             bench.main()
