@@ -373,6 +373,13 @@ int mh_gemm_bias_act_pre(const void* A, int64_t lda, const void* W, int64_t ldw,
  * block without materialising d(activation) (training_losses backward, models/diffusion.py:594-699). */
 int mh_gemm_act_grad(const void* A, int64_t lda, const void* W, int64_t ldw, const void* pre, int64_t ld_pre, void* out,
                      int64_t ldo, int64_t M, int N, int K, int act, mh_stream_t stream);
+/* Weight gradient dW[M, N] = A^T B with both bf16 operands k-major as the forward left them (A [K, lda] = dY, B [K, ldb] = X,
+ * K = tokens): no transposed copies; MFMA fragments come out of the k-major LDS image through ds_read_b64_tr_b16.  The token
+ * range is cut into `splits` slices (mh_gemm_dw_splits) writing fp32 partials out_partials [splits][M][N]; fold them with
+ * mh_sum_slices.  Replaces autograd's dense-layer weight gradients in training_losses (models/diffusion.py:594-699). */
+int mh_gemm_dw(const void* A, int64_t lda, const void* B, int64_t ldb, float* out_partials, int splits, int64_t K, int M, int N,
+               mh_stream_t stream);
+int mh_gemm_dw_splits(int64_t K, int M, int N);
 /* out = LayerNorm(A W^T + bias + residual) * gamma + beta, bf16, the whole row normalised inside the
  * GEMM epilogue (one block owns all N columns: N must be 128, 256 or 512 - see ..._supported).
  * Replaces BertSelfOutput / BertOutput (dense -> LayerNorm(hidden + input)) of the encoder that

@@ -22,6 +22,7 @@ from . import _lib, ops
 from ._lib import MH_BF16, MH_F32, check, current_stream, lib, ptr
 
 NPART = 256  # rows of the two-stage column-sum scratch
+TN_DW = True            # bf16: weight gradients straight from the k-major activations (mh_gemm_dw), no transposed copies
 FUSED_FFN = True        # bf16: FFN as one tape node with the GELU backward fused into a GEMM epilogue (A/B switch for tests)
 FUSED_ATTENTION = True  # bf16: streaming forward + fused backward kernels when the shape allows (A/B switch for tests)
 
@@ -59,6 +60,22 @@ def _gemm_dw(dT, xT, N, Kp, Mp, dt):
           "mh_gemm_batched")
     check(lib().mh_sum_slices(ptr(part), S, N * Kp, ptr(dW), current_stream()), "mh_sum_slices")
     return dW
+
+
+def _dw(dy, x, N, Kp, M, dt):
+    """dW [N, Kp] fp32 = dy[:, :N]^T x[:, :Kp] over the M token rows.  bf16: one kernel reads both operands as the forward
+    left them (k-major) and transposes inside LDS; otherwise explicit transposes + the split-K GEMM."""
+    if TN_DW and dt == ops.MH_BF16 and N % 8 == 0 and Kp % 8 == 0 and dy.shape[1] % 8 == 0 and x.shape[1] % 8 == 0 and M % 32 == 0:
+        S = int(lib().mh_gemm_dw_splits(M, N, Kp))
+        part = torch.empty(S, N, Kp, device=dy.device, dtype=torch.float32)
+        check(lib().mh_gemm_dw(ptr(dy), dy.shape[1], ptr(x), x.shape[1], ptr(part), S, M, N, Kp, current_stream()), "mh_gemm_dw")
+        if S == 1:
+            return part[0]
+        dW = torch.empty(N, Kp, device=dy.device, dtype=torch.float32)
+        check(lib().mh_sum_slices(ptr(part), S, N * Kp, ptr(dW), current_stream()), "mh_sum_slices")
+        return dW
+    Mp = ops.pad64(M)
+    return _gemm_dw(_transpose(dy, M, N, dt, ld_out=Mp), _transpose(x, M, Kp, dt, ld_out=Mp), N, Kp, Mp, dt)
 
 
 def _transpose(x, rows, cols, dt, ld_out=None, batch=1, stride_in=0, stride_out=0, ld_in=None):
@@ -154,10 +171,7 @@ class _Linear(Function):
         dx = _zeros(M, Kp, dt, x.device, Kp)
         _gemm(dpre, WT, None, dt, Kp, Np, out=dx)
         # dW = dpre^T X : reduction over the M rows
-        Mp = ops.pad64(M)
-        dT = _transpose(dpre, M, N, dt, ld_out=Mp)                      # [N, Mp]
-        xT = _transpose(x, M, Kp, dt, ld_out=Mp)                        # [Kp, Mp]
-        dW = _gemm_dw(dT, xT, N, Kp, Mp, dt)
+        dW = _dw(dpre, x, N, Kp, M, dt)
         return dx, dW[:, :K].contiguous(), db, None, (dy if has_res else None), None
 
 
@@ -194,15 +208,14 @@ class _FFN(Function):
         F = W1c.shape[0]
         dy = dy.contiguous()
         db2 = _col_sum(dy, M, H, dt)
-        dyT = _transpose(dy, M, H, dt, ld_out=M)                          # [H, M]
-        dW2 = _gemm_dw(dyT, _transpose(f, M, F, dt, ld_out=M), H, F, M, dt)
+        dW2 = _dw(dy, f, H, F, M, dt)
         # d(pre) = (dy W2) o gelu'(pre): W2 is [H, F]; the GEMM wants the reduction dim contiguous -> W2^T [F, H]
         dpre = torch.empty(M, F, device=x.device, dtype=x.dtype)
         W2T = _transpose(W2c, H, F, dt, ld_out=H)
         check(lib().mh_gemm_act_grad(ptr(dy), H, ptr(W2T), H, ptr(pre), F, ptr(dpre), F, M, F, H, ops.ACT["gelu"], current_stream()),
               "mh_gemm_act_grad")
         db1 = _col_sum(dpre, M, F, dt)
-        dW1 = _gemm_dw(_transpose(dpre, M, F, dt, ld_out=M), _transpose(x, M, H, dt, ld_out=M), F, H, M, dt)
+        dW1 = _dw(dpre, x, F, H, M, dt)
         dx = torch.empty(M, H, device=x.device, dtype=x.dtype)
         W1T = _transpose(W1c, F, H, dt, ld_out=F)                         # [H, F]
         _gemm(dpre, W1T, None, dt, H, F, out=dx, residual=dy)             # + dy: the residual branch

@@ -241,6 +241,21 @@ def test_attention_stream_backward(dh, L, B, nh):
         assert err <= tol, "%s: max err %.4g > %.4g (ref max %.3g)" % (nm, err, tol, ref.abs().max().item())
 
 
+@pytest.mark.parametrize("K,M,N", [(4096, 512, 512), (2048, 264, 136), (8192, 2048, 512), (1024, 72, 64)])
+def test_gemm_dw_k_major(K, M, N):
+    """dW = dY^T X straight from the k-major operands (transposing LDS reads) == fp32 matmul of the bf16-rounded inputs"""
+    from musediffusion_amd._lib import check, current_stream
+    A, B = rnd(K, M, seed=270, scale=0.5), rnd(K, N, seed=271, scale=0.5)
+    ref = q(A, MH_BF16).T @ q(B, MH_BF16)
+    Ad, Bd = A.to(DEV).bfloat16().contiguous(), B.to(DEV).bfloat16().contiguous()
+    S = int(lib().mh_gemm_dw_splits(K, M, N))
+    part = torch.zeros(S, M, N, device=DEV)
+    check(lib().mh_gemm_dw(Ad.data_ptr(), M, Bd.data_ptr(), N, part.data_ptr(), S, K, M, N, current_stream()))
+    out = torch.empty(M, N, device=DEV)
+    check(lib().mh_sum_slices(part.data_ptr(), S, M * N, out.data_ptr(), current_stream()))
+    assert_close(out, ref, 2e-3 * math.sqrt(K / 1024), 1e-3, what="gemm_dw K=%d M=%d N=%d splits=%d" % (K, M, N, S))
+
+
 def test_gemm_qkv_vtperm():
     from musediffusion_amd._lib import check, current_stream
     B, L, H, nh = 2, 48, 128, 2

@@ -1,19 +1,23 @@
 #!/usr/bin/env python3
-"""In-process A/B of the training tape options (training.FUSED_FFN) on bench.py --workload train: boxes of the pool differ by
-several percent, so alternatives are only comparable inside one process."""
-import sys, time, torch
+"""In-process A/B of a training tape option on bench.py --workload train (boxes of the pool differ by several percent, so
+alternatives are only comparable inside one process):    python tools/ab_train.py TN_DW | FUSED_FFN | FUSED_ATTENTION"""
+import contextlib
+import io
+import json
 import os
+import sys
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+KNOB = sys.argv[1] if len(sys.argv) > 1 else "FUSED_FFN"
 sys.argv = ["bench.py", "--workload", "train", "--steps", "4", "--warmup", "2", "--no-cpu-baseline", "--no-kernel-timing"]
-import bench
-from musediffusion_amd import training
-import io, contextlib
+import bench  # noqa: E402
+from musediffusion_amd import training  # noqa: E402
+
 for rnd in range(3):
-    for fused in (True, False):
-        training.FUSED_FFN = fused
+    for on in (True, False):
+        setattr(training, KNOB, on)
         buf = io.StringIO()
         with contextlib.redirect_stdout(buf):
             bench.main()
-        import json
-        d = json.loads(buf.getvalue().strip().splitlines()[-1])
-        print("FUSED_FFN=%s: %.2f ms" % (fused, d["ms_per_step"]), flush=True)
+        print("%s=%s: %.2f ms" % (KNOB, on, json.loads(buf.getvalue().strip().splitlines()[-1])["ms_per_step"]), flush=True)
+setattr(training, KNOB, True)
