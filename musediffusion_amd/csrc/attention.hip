@@ -551,24 +551,25 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(const float* __restrict__
 // V^T arrives in the "P-operand" key order (mh_gemm_qkv_vtperm): within every 16 keys the two middle groups of
 // four are swapped, which is the order the S^T accumulator registers hold the probabilities in, so a stage
 // is a straight 16-byte-granular copy (source-side XOR swizzle) and P feeds the P.V MFMA without a shuffle.
-template <int DH>
-__global__ __launch_bounds__(1024) void attn_stream_bf16_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K,
+template <int DH, int NW = 16, int SK = 256>
+__global__ __launch_bounds__(64 * NW) void attn_stream_bf16_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K,
                                                                 const bf16* __restrict__ VT, bf16* __restrict__ ctx,
                                                                 int64_t ld_ctx, int L, int nh, int nbh, float scale_log2e,
                                                                 int ctx_panel, float* __restrict__ lse2, int64_t qsB, int64_t qsH, int64_t qld) {
-  constexpr int NW = 16, SK = 256;                       // waves, keys per stage
+  // NW waves (one 32-query tile each), SK keys per stage.  16 x 256 fills a CU (128 KiB LDS, four waves per SIMD); 8 x 128
+  // leaves half of the CU's registers and LDS for a GEMM block of the other graph branch
   constexpr int CH = DH / 8, RPB = 128 / DH, KROWB = DH * 2;
   constexpr int KS = DH / 16, DT = DH / 32;
   constexpr int KST = SK * KROWB, VT_BYTES = DH * 128;   // K stage bytes (= V stage bytes), V^T bytes per 64-key tile
   constexpr int PK = KST / 1024 / NW;                    // 1-KiB DMA pieces per wave per operand per stage
   constexpr int KRP = 1024 / KROWB;                      // K rows per piece
-  static_assert(PK >= 1, "stage too small for 16 waves");
+  static_assert(PK >= 1, "stage too small for the wave count");
   extern __shared__ __attribute__((aligned(16))) char smem_dyn[];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h = lane >> 5, lq = lane & 31;
-  const int nqb = (L + 511) / 512, nst = L / SK;
+  const int nqb = (L + 32 * NW - 1) / (32 * NW), nst = L / SK;
   const int nitems = nbh * nqb;
   const int my_items = (nitems - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
   const int total = my_items * nst;
@@ -613,7 +614,7 @@ __global__ __launch_bounds__(1024) void attn_stream_bf16_kernel(const bf16* __re
     __builtin_amdgcn_s_barrier();                      // ... for every wave; buffer (g+1)&1 was released at the end of stage g-1
     if (g + 1 < total) issue(g + 1);
     if (st == 0) {
-      q0 = qb * 512 + wave * 32;
+      q0 = qb * (32 * NW) + wave * 32;
       active = q0 < L;
       if (active) {
         const bf16* Qb = Q + (int64_t)(bh / nh) * qsB + (int64_t)(bh % nh) * qsH;
@@ -775,7 +776,7 @@ int launch_bf16(const bf16* q, const bf16* k, const bf16* vt, bf16* ctx, int64_t
 
 namespace { int g_attn_stream = 1; }
 extern "C" int mh_attention_set_stream(int on) {
-  g_attn_stream = on != 0;
+  g_attn_stream = on < 0 ? 0 : (on > 2 ? 2 : on);
   return MH_OK;
 }
 extern "C" int mh_attention_stream_enabled(void) { return g_attn_stream; }
@@ -810,27 +811,26 @@ extern "C" int mh_attention_stream_fwd_ex(const void* q, const void* k, const vo
   hipStream_t s = (hipStream_t)stream;
   int dev = 0, cus = 256;
   if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-  const int nbh = B * nh, nitems = nbh * ((L + 511) / 512);
-  const dim3 grid((unsigned)(nitems < cus ? nitems : cus)), block(1024);
+  const int nbh = B * nh;
   const float sl2 = scale * 1.4426950408889634f;
   const bf16 *Q = (const bf16*)q, *K = (const bf16*)k, *V = (const bf16*)vt_perm;
-  if (dh == 64) {
-    constexpr int bytes = 4 * 256 * 64 * 2;
+  const bool small = g_attn_stream == 2;   // 8 waves x 128-key stages: half a CU per block
+  const int qper = small ? 256 : 512, nitems = nbh * ((L + qper - 1) / qper);
+  const int slots = small ? 2 * cus : cus;
+  const dim3 grid((unsigned)(nitems < slots ? nitems : slots)), block(small ? 512 : 1024);
+  auto go = [&](auto kern, int bytes) -> int {
     static bool attr_set = false;
     if (!attr_set) {
-      MH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_stream_bf16_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+      MH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
       attr_set = true;
     }
-    MH_LAUNCH((attn_stream_bf16_kernel<64>), grid, block, bytes, s, Q, K, V, (bf16*)ctx, ld_ctx, L, nh, nbh, sl2, ctx_panel, lse2, qsB, qsH, qld);
-  } else {
-    constexpr int bytes = 4 * 256 * 32 * 2;
-    static bool attr_set = false;
-    if (!attr_set) {
-      MH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_stream_bf16_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-      attr_set = true;
-    }
-    MH_LAUNCH((attn_stream_bf16_kernel<32>), grid, block, bytes, s, Q, K, V, (bf16*)ctx, ld_ctx, L, nh, nbh, sl2, ctx_panel, lse2, qsB, qsH, qld);
-  }
+    MH_LAUNCH(kern, grid, block, bytes, s, Q, K, V, (bf16*)ctx, ld_ctx, L, nh, nbh, sl2, ctx_panel, lse2, qsB, qsH, qld);
+    return MH_OK;
+  };
+  int rc;
+  if (dh == 64) rc = small ? go(&attn_stream_bf16_kernel<64, 8, 128>, 4 * 128 * 64 * 2) : go(&attn_stream_bf16_kernel<64, 16, 256>, 4 * 256 * 64 * 2);
+  else rc = small ? go(&attn_stream_bf16_kernel<32, 8, 256>, 4 * 256 * 32 * 2) : go(&attn_stream_bf16_kernel<32, 16, 256>, 4 * 256 * 32 * 2);
+  if (rc) return rc;
   MH_CHECK_LAUNCH();
   return MH_OK;
 }

@@ -183,6 +183,14 @@ def test_attention_stream(dh, L, B, nh):
     check(lib().mh_attention_stream_fwd(qd.data_ptr(), kd.data_ptr(), vt_dev.data_ptr(), out.data_ptr(), nh * dh, 0, B, L, nh, dh,
                                         scale, current_stream()))
     assert_close(out, ref, 2e-2, what="attention_stream dh=%d L=%d" % (dh, L))
+    lib().mh_attention_set_stream(2)          # 8-wave / 128-key-stage blocks: same arithmetic per query tile, same bits
+    try:
+        out2 = torch.zeros_like(out)
+        check(lib().mh_attention_stream_fwd(qd.data_ptr(), kd.data_ptr(), vt_dev.data_ptr(), out2.data_ptr(), nh * dh, 0, B, L, nh, dh,
+                                            scale, current_stream()))
+        assert torch.equal(out2, out)
+    finally:
+        lib().mh_attention_set_stream(1)
     outp = torch.zeros(nh * dh // 32, B * L, 32, device=DEV, dtype=torch.bfloat16)
     check(lib().mh_attention_stream_fwd(qd.data_ptr(), kd.data_ptr(), vt_dev.data_ptr(), outp.data_ptr(), B * L, 1, B, L, nh, dh,
                                         scale, current_stream()))
