@@ -482,6 +482,12 @@ int mh_validate_tokens(const int32_t* tokens, const int32_t* lens, int32_t* resu
 int mh_msim_vectors(const int32_t* tokens, const int32_t* lens, float* out, int32_t* status, int B, int L, float note_len,
                     mh_stream_t stream);
 
+/* metric.py:120-168 Controllability_Pitch / _Velocity, the per-row part: out[b] = (sum of pitch tokens 3..130, their count,
+ * count of velocity tokens 131..194, count of those outside [metas[b][7] - 524, metas[b][8] - 524] with 130 / 195 = open bound);
+ * tokens [B, L] note sequences (valid length lens[b], NULL = L), metas [B, meta_ld] meta tokens (meta_ld >= 9). */
+int mh_controllability_counts(const int32_t* tokens, const int32_t* lens, const int32_t* metas, int meta_ld, int32_t* out, int B,
+                              int L, mh_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

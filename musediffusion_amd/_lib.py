@@ -122,6 +122,7 @@ SIGNATURES = {
     "mh_corrupt_masking_note": (INT, [VP, VP, VP, F32, VP, INT, VP]),
     "mh_corrupt_randomize_note": (INT, [VP, VP, VP, VP, F32, VP, INT, VP]),
     "mh_corrupt_random_rotating": (INT, [VP, VP, VP, INT, VP, VP, INT, VP]),
+    "mh_controllability_counts": (INT, [VP, VP, VP, INT, VP, INT, INT, VP]),
     "mh_msim_vectors": (INT, [VP, VP, VP, VP, INT, INT, F32, VP]),
     "mh_validate_tokens": (INT, [VP, VP, VP, INT, INT, VP]),
     "mh_scale_rows": (INT, [VP, VP, VP, VP, INT, INT, I64, INT, VP]),

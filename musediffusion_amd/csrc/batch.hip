@@ -296,6 +296,32 @@ __global__ void msim_vectors_kernel(const int32_t* __restrict__ tokens, const in
   if (status) status[b] = st;
 }
 
+// Controllability counters (metric.py:120-168): per row, (sum and count of pitch tokens 3..130) and (count of velocity tokens
+// 131..194, count of those outside the meta's [min, max]).  out[b] = (pitch_sum, pitch_count, vel_total, vel_wrong) int32;
+// meta[b] = the 11 meta tokens.  One wave per row.
+__global__ void controllability_kernel(const int32_t* __restrict__ tokens, const int32_t* __restrict__ lens, const int32_t* __restrict__ metas,
+                                       int32_t* __restrict__ out, int L, int meta_ld) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const int32_t* midi = tokens + (int64_t)b * L;
+  const int n = lens ? lens[b] : L;
+  const int lo_v = metas[(int64_t)b * meta_ld + 7] - 524, hi_v = metas[(int64_t)b * meta_ld + 8] - 524;
+  int psum = 0, pcnt = 0, vtot = 0, vbad = 0;
+  for (int j = lane; j < n; j += 64) {
+    const int32_t t = midi[j];
+    if (t >= 3 && t <= 130) { psum += t; ++pcnt; }
+    if (t >= 131 && t <= 194) {
+      ++vtot;
+      if (!((lo_v == 130 || lo_v <= t) && (hi_v == 195 || t <= hi_v))) ++vbad;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    psum += __shfl_xor(psum, o, 64); pcnt += __shfl_xor(pcnt, o, 64);
+    vtot += __shfl_xor(vtot, o, 64); vbad += __shfl_xor(vbad, o, 64);
+  }
+  if (lane == 0) { out[b * 4 + 0] = psum; out[b * 4 + 1] = pcnt; out[b * 4 + 2] = vtot; out[b * 4 + 3] = vbad; }
+}
+
 }  // namespace
 
 extern "C" int mh_batch_max_row(void) { return MAX_ROW; }
@@ -360,6 +386,14 @@ extern "C" int mh_msim_vectors(const int32_t* tokens, const int32_t* lens, float
                                mh_stream_t stream) {
   MH_CHECK_ARG(tokens && out && B > 0 && L > 0 && note_len > 0.f, "msim_vectors: bad arguments");
   MH_LAUNCH(msim_vectors_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, tokens, lens, out, status, B, L, note_len);
+  MH_CHECK_LAUNCH();
+  return MH_OK;
+}
+
+extern "C" int mh_controllability_counts(const int32_t* tokens, const int32_t* lens, const int32_t* metas, int meta_ld, int32_t* out, int B,
+                                         int L, mh_stream_t stream) {
+  MH_CHECK_ARG(tokens && metas && out && B > 0 && L > 0 && meta_ld >= 9, "controllability_counts: bad arguments");
+  MH_LAUNCH(controllability_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, tokens, lens, metas, out, L, meta_ld);
   MH_CHECK_LAUNCH();
   return MH_OK;
 }

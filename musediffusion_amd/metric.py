@@ -43,3 +43,37 @@ def ONNC(tokens, lengths=None, return_MSIM=False, return_mostsim=False):
     onnc = ((most[:half] < half).sum() + (most[half:] >= half).sum()) / vec.shape[0]
     extra = ([sim] if return_MSIM else []) + ([most] if return_mostsim else [])
     return onnc if not extra else [onnc] + extra
+
+
+PITCH_RANGE = {631: (3, 38), 632: (39, 50), 633: (51, 62), 634: (63, 74), 635: (75, 86), 636: (87, 98), 637: (99, 130)}
+
+
+def _counts(metas, tokens, lengths):
+    require_device(metas, tokens, lengths)
+    tokens = tokens.to(torch.int32).contiguous()
+    metas = metas.to(torch.int32).contiguous()
+    B, L = tokens.shape
+    lengths = None if lengths is None else lengths.to(torch.int32).contiguous()
+    out = torch.empty(B, 4, device=tokens.device, dtype=torch.int32)
+    check(lib().mh_controllability_counts(ptr(tokens), ptr(lengths), ptr(metas), metas.shape[1], ptr(out), B, L, current_stream()),
+          "mh_controllability_counts")
+    return out
+
+
+def Controllability_Pitch(metas, tokens, lengths=None):
+    """metric.py:131-148 on device batches -> (total rows, rows whose mean pitch leaves the range its meta asks for)"""
+    c = _counts(metas, tokens, lengths)
+    rng = metas[:, 3].long()
+    lo = torch.tensor([PITCH_RANGE.get(k, (0, 0))[0] for k in range(631, 638)], device=tokens.device, dtype=torch.float32)
+    hi = torch.tensor([PITCH_RANGE.get(k, (0, 0))[1] for k in range(631, 638)], device=tokens.device, dtype=torch.float32)
+    idx = (rng - 631).clamp(0, 6)
+    mean = c[:, 0].float() / c[:, 1].clamp(min=1).float()
+    wrong = (rng != 630) & ~((lo[idx] <= mean) & (mean <= hi[idx]))
+    return metas.shape[0], int(wrong.sum())
+
+
+def Controllability_Velocity(metas, tokens, lengths=None):
+    """metric.py:151-168 -> (velocity tokens of the rows with a bounded maximum, those outside their meta's [min, max])"""
+    c = _counts(metas, tokens, lengths)
+    use = (metas[:, 8].long() - 524) != 130
+    return int(c[use, 2].sum()), int(c[use, 3].sum())

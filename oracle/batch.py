@@ -197,3 +197,27 @@ def onnc(vectors):
     most = sim.argmax(1)
     half = len(vectors) // 2
     return ((most[:half] < half).sum() + (most[half:] >= half).sum()) / len(vectors), sim, most
+
+
+PITCH_RANGE = {631: (3, 38), 632: (39, 50), 633: (51, 62), 634: (63, 74), 635: (75, 86), 636: (87, 98), 637: (99, 130)}
+
+
+def controllability(metas, midis):
+    """metric.py:120-168: ((total, wrong) of Controllability_Pitch, (total, wrong) of Controllability_Velocity).  Pitch: a row
+    whose meta[3] != 630 is wrong when the mean of its pitch tokens (3..130) leaves the meta's range.  Velocity: rows with
+    meta[8] - 524 != 130 contribute their velocity tokens (131..194); one is wrong outside [meta[7] - 524, meta[8] - 524]
+    (bound 130 / 195 = open)."""
+    p_wrong, v_total, v_wrong = 0, 0, 0
+    for meta, midi in zip(metas, midis):
+        midi = np.asarray(midi)
+        if meta[3] != 630:
+            pitch = midi[(midi >= 3) & (midi <= 130)]
+            lo, hi = PITCH_RANGE[int(meta[3])]
+            if not (lo <= float(pitch.mean()) <= hi):
+                p_wrong += 1
+        lo_v, hi_v = int(meta[7]) - 524, int(meta[8]) - 524
+        if hi_v != 130:
+            vel = midi[(midi >= 131) & (midi <= 194)]
+            v_total += len(vel)
+            v_wrong += int(sum(not ((lo_v == 130 or lo_v <= e) and (hi_v == 195 or e <= hi_v)) for e in vel))
+    return (len(metas), p_wrong), (v_total, v_wrong)

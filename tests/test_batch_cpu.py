@@ -59,3 +59,10 @@ def test_msim_vectors_and_onnc_match_reference():
     np.testing.assert_allclose(sim, g["onnc_msim"], rtol=1e-5, atol=1e-7)
     r = g["msim_vectors"]
     assert abs(float((r[0, :32] @ r[1, :32]) * (r[0, 32:44] @ r[1, 32:44]) * (r[0, 44:] @ r[1, 44:])) - float(g["msim_01"])) < 1e-6
+
+
+def test_controllability_matches_reference():
+    g = load_golden("batch.npz")
+    (pt, pw), (vt, vw) = ob.controllability(g["ctrl_metas"], [s[12:] for s in rows(g)])
+    assert [pt, pw] == g["ctrl_pitch"].tolist() and [vt, vw] == g["ctrl_velocity"].tolist()
+    assert pw > 0 and vw > 0 and vw < vt

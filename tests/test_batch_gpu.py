@@ -161,3 +161,16 @@ def test_msim_vectors_and_onnc_match_reference():
     got = mm.get_vectors(dev(tb)).cpu().numpy()
     for i in range(0, len(rows), 9):
         np.testing.assert_allclose(got[i], ob.msim_vectors(rows[i]), rtol=3e-6, atol=3e-7)
+
+
+def test_controllability_matches_reference():
+    from musediffusion_amd import metric as mm
+    g = load_golden("batch.npz")
+    off = g["offsets"]
+    toks = np.zeros((12, 256), np.int32)
+    lens = np.zeros(12, np.int32)
+    for i in range(12):
+        s = g["values"][off[i] + 12:off[i + 1]]
+        toks[i, :len(s)], lens[i] = s, len(s)
+    assert list(mm.Controllability_Pitch(dev(g["ctrl_metas"]), dev(toks), dev(lens))) == g["ctrl_pitch"].tolist()
+    assert list(mm.Controllability_Velocity(dev(g["ctrl_metas"]), dev(toks), dev(lens))) == g["ctrl_velocity"].tolist()

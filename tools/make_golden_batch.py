@@ -205,6 +205,22 @@ def main():
     onnc, sim, most = rmetric.ONNC(notes, return_MSIM=True, return_mostsim=True)
     out["onnc"], out["onnc_msim"], out["onnc_mostsim"] = np.float32(onnc), sim.numpy().astype(np.float32), most.numpy().astype(np.int64)
 
+    # ---- controllability counters (metric.py:120-168) on (meta, notes) pairs; metas 3 / 7 / 8 edited to hit every branch
+    metas = np.array([s[:11] for s in seqs], dtype=np.int64)
+    metas[0, 3] = 630                                   # pitch range "any": skipped
+    metas[1, 3], metas[2, 3] = 631, 637
+    metas[3, 8] = 130 + 524                             # max velocity "any": skipped
+    metas[4, 7], metas[4, 8] = 130 + 524, 160 + 524     # no lower bound
+    metas[5, 7], metas[5, 8] = 140 + 524, 195 + 524     # no upper bound
+    for i in range(6, 12):
+        metas[i, 7], metas[i, 8] = 135 + 524 + i, 150 + 524 + 2 * i
+    for i in range(3, 12):
+        metas[i, 3] = 631 + (i % 7)
+    note_arrays = [np.array(s[12:], dtype=np.int64) for s in seqs]
+    out["ctrl_metas"] = metas.astype(np.int32)
+    out["ctrl_pitch"] = np.array(rmetric.Controllability_Pitch(metas, note_arrays), dtype=np.int64)
+    out["ctrl_velocity"] = np.array(rmetric.Controllability_Velocity(metas, note_arrays), dtype=np.int64)
+
     path = os.path.join(REPO, "tests", "golden", "batch.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, {k: v.shape for k, v in out.items()})
