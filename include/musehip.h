@@ -399,7 +399,8 @@ int mh_denoiser_get_fuse_ln(void);
 int mh_gemm_set_debug(int bits);
 /* A/B: which big-tile epilogues use ordinary instead of streaming (nt) output stores: bit 0 QKV scatter, bit 1 dense + GELU
  * (default 0: both streaming - their outputs are large and read once; measured -0.8% step time for dense + GELU, neutral for QKV).
- * The dense + residual + LayerNorm epilogue always stores normally: its rows are re-read at once (+1.2% with streaming). */
+ * The dense + residual + LayerNorm epilogue always stores normally: its rows are re-read at once (+1.2% with streaming).
+ * Bit 2: run the full-row (LayerNorm) tile with the plain instead of the ping-pong main loop (4.5% slower step). */
 int mh_gemm_set_plain_stores(int mask);
 
 int mh_graph_begin_capture(mh_stream_t stream);

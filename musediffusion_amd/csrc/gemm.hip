@@ -367,6 +367,7 @@ using CfgStd = BigCfg<256, 128, 2, 2, 3>;
 using CfgWide = BigCfg<256, 256, 2, 4, 4>;
 using CfgRow = BigCfg<128, 512, 2, 4, 3>;
 using CfgWidePP = BigCfg<256, 256, 2, 4, 4, true>;
+using CfgRowPP = BigCfg<128, 512, 2, 4, 3, true>;
 constexpr int B2K = 32;
 
 // one DMA stage (K-step kt) of a tile into ring slot kt % NST: PA + PW 1-KiB pieces per wave
@@ -873,7 +874,7 @@ int device_cus() {
   return cus;
 }
 
-int g_plain_stores = 0;   // A/B: bit 0 QKV, bit 1 dense+GELU epilogues use ordinary instead of streaming stores
+int g_plain_stores = 0;   // A/B: bit 0 QKV, bit 1 dense+GELU epilogues use ordinary instead of streaming stores; bit 2: full-row tile without ping-pong
 
 template <class C, int EPI>
 int launch_big(const GemmArgs& g0, hipStream_t s, int batch) {
@@ -1039,8 +1040,10 @@ extern "C" int mh_gemm_bias_res_ln(const void* A, int64_t lda, int a_panel, cons
   MH_CHECK_ARG((a_panel || lda % 8 == 0) && (w_panel || ldw % 8 == 0) && big_tile_ok(g), "gemm_bias_res_ln: leading dimensions must be multiples of 8");
   hipStream_t s = (hipStream_t)stream;
   if (N == 128) return launch_big<CfgStd, 3>(g, s, 1);
-  if (N == 256) return launch_big<CfgWide, 3>(g, s, 1);
-  return launch_big<CfgRow, 3>(g, s, 1);
+  if (N == 256) return launch_big<CfgWidePP, 3>(g, s, 1);
+  // one block per CU: the ping-pong main loop pays here (-4.5% step time, tools/ab_step.py); bit 2 of the A/B mask = plain loop
+  if (g_plain_stores & 4) return launch_big<CfgRow, 3>(g, s, 1);
+  return launch_big<CfgRowPP, 3>(g, s, 1);
 }
 
 // act(A W^T + bias) -> out AND A W^T + bias -> pre_out in one pass (bf16, row-major, big-tile shapes only): the forward of
