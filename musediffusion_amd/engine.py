@@ -12,7 +12,7 @@ import ctypes as C
 import torch
 
 from . import _lib, ops
-from ._lib import MH_BF16, MH_F32, Denoiser, LayerWeights, check, current_stream, lib, ptr
+from ._lib import MH_BF16, Denoiser, LayerWeights, check, current_stream, lib, ptr
 
 
 def _align(n, a=256):

@@ -16,7 +16,6 @@ The reference hard-codes the Transformer shape to bert-base-uncased (network.py:
 shape is a keyword-only constructor argument defaulting to those values, so the BASELINE configs
 (2-layer d=128, 12-layer d=512) are reachable without monkey-patching.
 """
-import math
 
 import torch
 import torch.nn as nn

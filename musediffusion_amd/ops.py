@@ -7,7 +7,6 @@ import ctypes as C
 
 import torch
 
-from . import _lib
 from ._lib import MH_BF16, MH_F32, check, current_stream, lib, ptr, require_device
 
 TORCH_DTYPE = {MH_F32: torch.float32, MH_BF16: torch.bfloat16}

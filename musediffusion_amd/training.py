@@ -19,7 +19,7 @@ import torch
 from torch.autograd import Function
 
 from . import _lib, ops
-from ._lib import MH_BF16, MH_F32, check, current_stream, lib, ptr
+from ._lib import MH_F32, check, current_stream, lib, ptr
 
 NPART = 256  # rows of the two-stage column-sum scratch
 TN_DW = True            # bf16: weight gradients straight from the k-major activations (mh_gemm_dw), no transposed copies

@@ -7,7 +7,7 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from musediffusion_amd import _lib, ops  # noqa: E402
+from musediffusion_amd import _lib  # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--variant", type=int, default=2)
