@@ -126,8 +126,8 @@ int mh_attention_fwd_ex(const void* q, const void* k, const void* vt, void* ctx,
 
 /* A/B switch: 1 (default) lets the bf16 kernel keep K and V^T of a (batch, head) resident in LDS when they
  * fit (<= 128 KiB), 0 forces the tiled double-buffered kernel. */
-/* Streaming attention (bf16): same result as mh_attention_fwd_ex, for seq_len % 256 == 0, seq_len >= 512, head
- * dim 32 / 64 (mh_attention_stream_supported).  K / V^T are streamed through LDS by LDS-DMA in 256-key stages,
+/* Streaming attention (bf16): same result as mh_attention_fwd_ex, for seq_len % 16 == 0, seq_len >= 512 (the reference's
+ * default 2096 included: the last stage / key tile is masked), head dim 32 / 64 (mh_attention_stream_supported).  K / V^T are streamed through LDS by LDS-DMA in 256-key stages,
  * double-buffered across stages and (batch, head) items by persistent 16-wave blocks.  `vt_perm` is V^T
  * [B, nh, dh, L] with the keys of every group of 16 stored as 0-3, 8-11, 4-7, 12-15 (what mh_gemm_qkv_vtperm
  * writes): the order in which the S^T accumulators hold the probabilities.  Replaces BertSelfAttention of
@@ -159,6 +159,7 @@ int mh_attention_stream_bwd_ex(const void* q, const void* k, const void* v, cons
                                void* dv, int64_t ld_d, int B, int L, int nh, int dh, float scale, int64_t qkv_batch_stride,
                                int64_t qkv_head_stride, int64_t qkv_row_stride, int64_t do_batch_stride,
                                int64_t do_head_stride, int64_t do_row_stride, mh_stream_t stream);
+int mh_attention_stream_bwd_supported(int L, int dh);   /* seq_len % 256 == 0, >= 512, head dim 32 / 64 */
 int mh_attention_bwd_rowdot(const void* dctx, const void* ctx, int64_t ld, float* D, int B, int L, int nh, int dh,
                             mh_stream_t stream);
 int mh_attention_stream_supported(int L, int dh);

@@ -79,6 +79,7 @@ SIGNATURES = {
     "mh_attention_stream_bwd": (INT, [VP, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP, I64, INT, INT, INT, INT, F32, VP]),
     "mh_attention_stream_fwd_ex": (INT, [VP, VP, VP, VP, I64, INT, INT, INT, INT, INT, F32, VP, I64, I64, I64, VP]),
     "mh_attention_stream_bwd_ex": (INT, [VP, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP, I64, INT, INT, INT, INT, F32, I64, I64, I64, I64, I64, I64, VP]),
+    "mh_attention_stream_bwd_supported": (INT, [INT, INT]),
     "mh_attention_bwd_rowdot": (INT, [VP, VP, I64, VP, INT, INT, INT, INT, VP]),
     "mh_attention_set_stream": (INT, [INT]),
     "mh_attention_stream_enabled": (INT, []),

@@ -569,7 +569,7 @@ __global__ __launch_bounds__(64 * NW) void attn_stream_bf16_kernel(const bf16* _
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h = lane >> 5, lq = lane & 31;
-  const int nqb = (L + 32 * NW - 1) / (32 * NW), nst = L / SK;
+  const int nqb = (L + 32 * NW - 1) / (32 * NW), nst = (L + SK - 1) / SK;   // the last stage / tile may be partial (L % 16 == 0)
   const int nitems = nbh * nqb;
   const int my_items = (nitems - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
   const int total = my_items * nst;
@@ -586,7 +586,9 @@ __global__ __launch_bounds__(64 * NW) void attn_stream_bf16_kernel(const bf16* _
       const int p = wave + NW * j;
       const int row = p * KRP + lane / CH, pc = lane % CH;             // key within the stage, physical chunk
       const int lc = pc ^ ((row / RPB) & (CH - 1));
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Kb + (int64_t)row * qld + lc * 8),
+      int rsrc = row;                                                   // keys past the end: any valid row (their scores are masked)
+      if (st * SK + row >= L) rsrc = L - 1 - st * SK;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Kb + (int64_t)rsrc * qld + lc * 8),
                                        (__attribute__((address_space(3))) void*)(kdst + p * 1024), 16, 0, 0);
     }
 #pragma unroll
@@ -594,7 +596,9 @@ __global__ __launch_bounds__(64 * NW) void attn_stream_bf16_kernel(const bf16* _
       const int p = wave + NW * j;
       const int t = p / (DH / 8), d = (p % (DH / 8)) * 8 + (lane >> 3), pc = lane & 7;
       const int lc = pc ^ ((d >> 1) & 7);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Vb + (int64_t)d * L + t * 64 + lc * 8),
+      int kc = t * 64 + lc * 8;                                         // 8 keys past the end: any valid chunk (finite values x P = 0)
+      if (st * SK + kc >= L) kc = L - 8 - st * SK;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Vb + (int64_t)d * L + kc),
                                        (__attribute__((address_space(3))) void*)(vdst + p * 1024), 16, 0, 0);
     }
   };
@@ -631,9 +635,11 @@ __global__ __launch_bounds__(64 * NW) void attn_stream_bf16_kernel(const bf16* _
     if (active) {
       const char* kbuf = smem_dyn + (g & 1) * (2 * KST);
       const char* vbuf = kbuf + KST;
-      for (int t = 0; t < SK / 64; ++t) {
+      const int st_keys = L - st * SK;                                  // valid keys of this stage (>= 16)
+      for (int t = 0; t < SK / 64 && t * 64 < st_keys; ++t) {
         const char* kb = kbuf + t * (64 * KROWB);
         const char* vb = vbuf + t * VT_BYTES;
+        const int tile_keys = st_keys - t * 64;                         // < 64 only in the sequence's last tile
         f32x16 s[2];
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
@@ -645,6 +651,13 @@ __global__ __launch_bounds__(64 * NW) void attn_stream_bf16_kernel(const bf16* _
           for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
 #pragma unroll
           for (int ks = 0; ks < KS; ++ks) s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[ks], s[kt], 0, 0, 0);
+        }
+        if (tile_keys < 64) {   // register r of sub-tile kt holds key 32 kt + (r & 3) + 8 (r >> 2) + 4 h: mask the ones past the end
+#pragma unroll
+          for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+              if (kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h >= tile_keys) s[kt][r] = -INFINITY;
         }
         float mx4[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
 #pragma unroll
@@ -781,7 +794,7 @@ extern "C" int mh_attention_set_stream(int on) {
 }
 extern "C" int mh_attention_stream_enabled(void) { return g_attn_stream; }
 
-extern "C" int mh_attention_stream_supported(int L, int dh) { return L >= 512 && L % 256 == 0 && (dh == 32 || dh == 64); }
+extern "C" int mh_attention_stream_supported(int L, int dh) { return L >= 512 && L % 16 == 0 && (dh == 32 || dh == 64); }
 
 extern "C" int mh_attention_stream_fwd_lse(const void* q, const void* k, const void* vt_perm, void* ctx, int64_t ld_ctx, int ctx_panel,
                                            int B, int L, int nh, int dh, float scale, float* lse2, mh_stream_t stream);
@@ -806,7 +819,7 @@ extern "C" int mh_attention_stream_fwd_ex(const void* q, const void* k, const vo
   MH_CHECK_ARG(qld % 8 == 0 && qsH % 8 == 0 && qsB % 8 == 0 && qld >= dh, "attention_stream: q/k strides must be multiples of 8 elements");
   MH_CHECK_ARG(q && k && vt_perm && ctx, "attention_stream: null pointer");
   MH_CHECK_ARG(B > 0 && nh > 0 && mh_attention_stream_supported(L, dh),
-               "attention_stream: needs seq_len %% 256 == 0, seq_len >= 512 and head dim 32 or 64 (got L=%d dh=%d)", L, dh);
+               "attention_stream: needs seq_len %% 16 == 0, seq_len >= 512 and head dim 32 or 64 (got L=%d dh=%d)", L, dh);
   MH_CHECK_ARG(ctx_panel || ld_ctx % 4 == 0, "attention_stream: ld_ctx must be a multiple of 4");
   hipStream_t s = (hipStream_t)stream;
   int dev = 0, cus = 256;

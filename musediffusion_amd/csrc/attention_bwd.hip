@@ -361,6 +361,8 @@ int launch_bwd(const bf16* q, const bf16* k, const bf16* v, const bf16* qT, cons
 
 }  // namespace
 
+extern "C" int mh_attention_stream_bwd_supported(int L, int dh) { return L >= 512 && L % 256 == 0 && (dh == 32 || dh == 64); }
+
 extern "C" int mh_attention_bwd_rowdot(const void* dctx, const void* ctx, int64_t ld, float* D, int B, int L, int nh, int dh,
                                        mh_stream_t stream) {
   MH_CHECK_ARG(dctx && ctx && D && B > 0 && L > 0 && nh > 0 && dh > 0 && dh % 8 == 0 && ld % 8 == 0, "attention_bwd_rowdot: bad arguments");
@@ -393,7 +395,7 @@ extern "C" int mh_attention_stream_bwd_ex(const void* q, const void* k, const vo
                "attention_stream_bwd: row strides must be multiples of 8 elements");
   const RowLayout lqkv{qsB, qsH, qld}, ldo{osB, osH, old_};
   MH_CHECK_ARG(q && k && v && qT_perm && kT_perm && dO && dOT_perm && o && lse2 && D && dq && dk && dv, "attention_stream_bwd: null pointer");
-  MH_CHECK_ARG(B > 0 && nh > 0 && L >= 512 && L % 256 == 0 && (dh == 32 || dh == 64),
+  MH_CHECK_ARG(B > 0 && nh > 0 && mh_attention_stream_bwd_supported(L, dh),
                "attention_stream_bwd: needs seq_len %% 256 == 0, seq_len >= 512 and head dim 32 or 64 (got L=%d dh=%d)", L, dh);
   MH_CHECK_ARG(ld_d % 4 == 0, "attention_stream_bwd: ld_d must be a multiple of 4");
   hipStream_t s = (hipStream_t)stream;

@@ -284,7 +284,7 @@ class _Attention(Function):
         st = current_stream()
         es = qkv.element_size()
         scale = 1.0 / math.sqrt(dh)
-        fused = FUSED_ATTENTION and dt == ops.MH_BF16 and bool(L_.mh_attention_stream_supported(L, dh)) and ld == 3 * H
+        fused = FUSED_ATTENTION and dt == ops.MH_BF16 and bool(L_.mh_attention_stream_bwd_supported(L, dh)) and ld == 3 * H
         vt = torch.empty(B * nh * dh * L + 256, device=qkv.device, dtype=td)     # slack: 16-B tail over-read of the last row
         vt[-256:].zero_()
         check(L_.mh_head_permute(qkv.data_ptr() + 2 * H * es, ptr(vt), ld, B, L, nh, dh, 3 if fused else 2, dt, st), "mh_head_permute")

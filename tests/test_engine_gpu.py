@@ -74,3 +74,21 @@ def test_forward_is_deterministic_and_rows_independent():
     rows = torch.tensor([4, 3, 2], dtype=torch.int32, device=DEV)
     y4 = eng.forward(x[[4, 3, 2]].contiguous(), emb_t, emb_row=rows)
     assert torch.equal(y4, y1[[4, 3, 2]])
+
+
+@pytest.mark.parametrize("L", [528, 2096])
+def test_forward_bf16_odd_sequence_lengths(L):
+    """seq_len not a multiple of 64 (2096 is the reference's default, config/train.py:52): the panel engine with the streaming
+    attention's masked last tile against the fp32 parity engine on the same weights"""
+    cfg = dict(E=32, H=128, F=256, nh=2, nL=2, Tt=32, L_max=L)
+    sd = odn.random_state_dict(cfg["E"], cfg["H"], cfg["F"], cfg["nL"], 97, L, cfg["Tt"], seed=3)
+    outs = {}
+    torch.manual_seed(1)
+    x = torch.randn(2, L, cfg["E"])
+    t = torch.tensor([10.0, 700.0])
+    for name, dt in (("bf16", MH_BF16), ("fp32", MH_F32)):
+        eng = DenoiserEngine(cfg, dt, DEV)
+        eng.load_state_dict({k: v.to(DEV) for k, v in sd.items()})
+        outs[name] = eng.forward(x.to(DEV), eng.time_embed(t.to(DEV))).cpu()
+    err = report("forward bf16 vs fp32 engine, L=%d" % L, outs["bf16"], outs["fp32"])
+    assert err < 0.15 and float((outs["bf16"] - outs["fp32"]).abs().mean()) < 0.02

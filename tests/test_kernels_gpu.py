@@ -165,13 +165,15 @@ def _vt_perm(vt):
     return vt.reshape(*lead, L // 16, 4, 4)[..., [0, 2, 1, 3], :].reshape(*lead, L).contiguous()
 
 
-@pytest.mark.parametrize("dh,L,B,nh", [(64, 512, 3, 5), (32, 512, 2, 3), (64, 1024, 2, 2), (64, 768, 1, 3)])
+@pytest.mark.parametrize("dh,L,B,nh", [(64, 512, 3, 5), (32, 512, 2, 3), (64, 1024, 2, 2), (64, 768, 1, 3), (64, 2096, 1, 2),
+                                        (64, 528, 2, 3), (32, 1040, 1, 2)])
 def test_attention_stream(dh, L, B, nh):
     """streaming kernel (LDS-DMA stages, permuted V^T) == softmax(QK^T/sqrt(dh)) V, row-major and panel output"""
     from musediffusion_amd._lib import check, current_stream
     qh, kh, vh = (rnd(B, nh, L, dh, seed=230 + i) for i in range(3))
     kh = kh * 1.5
     kh[:, :, 300] *= 4.0
+    kh[:, :, L - 3] *= 3.0          # a strong key inside the (possibly partial) last tile
     scale = 1.0 / math.sqrt(dh)
     ref = _attn_ref(q(qh, MH_BF16), q(kh, MH_BF16), q(vh, MH_BF16), scale).permute(0, 2, 1, 3).reshape(B * L, nh * dh)
     assert lib().mh_attention_stream_supported(L, dh) == 1 and lib().mh_attention_stream_supported(136, dh) == 0
