@@ -138,7 +138,7 @@ int mh_attention_stream_fwd(const void* q, const void* k, const void* vt_perm, v
  * (P[q][k] = exp2(s[q][k] scale log2e - lse2[q])): what mh_attention_stream_bwd re-creates P from. */
 int mh_attention_stream_fwd_lse(const void* q, const void* k, const void* vt_perm, void* ctx, int64_t ld_ctx, int ctx_panel,
                                 int B, int L, int nh, int dh, float scale, float* lse2, mh_stream_t stream);
-/* Fused attention backward (bf16; same shape limits as the streaming forward).  q, k, v, dO: [B, nh, L, dh] rows;
+/* Fused attention backward (bf16; seq_len % 16 == 0, >= 512: partial last tiles are masked, as in the streaming forward).  q, k, v, dO: [B, nh, L, dh] rows;
  * qT_perm, kT_perm, dOT_perm: [B, nh, dh, L] with the positions of every group of 16 permuted (mh_head_permute
  * mode 3); o = the forward output in dO's layout; lse2 from the forward; D = [B, nh, L] fp32 scratch (the dQ kernel
  * writes D[b, h, l] = sum_d dO o O there, the dK/dV kernel reads it).  dq, dk, dv are written
@@ -159,7 +159,7 @@ int mh_attention_stream_bwd_ex(const void* q, const void* k, const void* v, cons
                                void* dv, int64_t ld_d, int B, int L, int nh, int dh, float scale, int64_t qkv_batch_stride,
                                int64_t qkv_head_stride, int64_t qkv_row_stride, int64_t do_batch_stride,
                                int64_t do_head_stride, int64_t do_row_stride, mh_stream_t stream);
-int mh_attention_stream_bwd_supported(int L, int dh);   /* seq_len % 256 == 0, >= 512, head dim 32 / 64 */
+int mh_attention_stream_bwd_supported(int L, int dh);   /* seq_len % 16 == 0, >= 512, head dim 32 / 64 */
 int mh_attention_bwd_rowdot(const void* dctx, const void* ctx, int64_t ld, float* D, int B, int L, int nh, int dh,
                             mh_stream_t stream);
 int mh_attention_stream_supported(int L, int dh);

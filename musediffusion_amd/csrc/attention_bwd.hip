@@ -25,11 +25,12 @@ __device__ __forceinline__ void glds16(const void* g, void* l) {
 
 // piece p (1 KiB) of a row-layout operand stage: rows [row][DH] bf16, 16-B chunk c of row r stored at c ^ ((r / RPB) & (CH-1))
 template <int DH>
-__device__ __forceinline__ void dma_rows(const bf16* src, int64_t ld, char* dst, int p, int lane) {
+__device__ __forceinline__ void dma_rows(const bf16* src, int64_t ld, char* dst, int p, int lane, int valid_rows) {
   constexpr int CH = DH / 8, RPB = 128 / DH, KROWB = DH * 2, KRP = 1024 / KROWB;
   const int row = p * KRP + lane / CH, pc = lane % CH;
   const int lc = pc ^ ((row / RPB) & (CH - 1));
-  glds16(src + (int64_t)row * ld + lc * 8, dst + p * 1024);
+  const int rsrc = row < valid_rows ? row : valid_rows - 1;     // rows past the sequence end: a valid row (their terms are masked)
+  glds16(src + (int64_t)rsrc * ld + lc * 8, dst + p * 1024);
 }
 // where the [L, dh] rows of one (batch, head) live: [B, nh, L, dh] tensors or column blocks of token-major [B L, ld] ones
 struct RowLayout {
@@ -39,10 +40,12 @@ struct RowLayout {
 // piece p of a transposed operand stage: global [DH][L] (key order permuted per 16), LDS = 64-column tiles of [DH][128 B],
 // chunk c of row d stored at c ^ ((d >> 1) & 7)
 template <int DH>
-__device__ __forceinline__ void dma_cols(const bf16* src, int64_t L, char* dst, int p, int lane) {
+__device__ __forceinline__ void dma_cols(const bf16* src, int64_t L, char* dst, int p, int lane, int valid_cols) {
   const int t = p / (DH / 8), d = (p % (DH / 8)) * 8 + (lane >> 3), pc = lane & 7;
   const int lc = pc ^ ((d >> 1) & 7);
-  glds16(src + (int64_t)d * L + t * 64 + lc * 8, dst + p * 1024);
+  int c = t * 64 + lc * 8;
+  if (c >= valid_cols) c = valid_cols - 8;                      // columns past the end: a valid chunk (finite values x 0)
+  glds16(src + (int64_t)d * L + c, dst + p * 1024);
 }
 // A-operand fragment (32 rows x 16 k) of a row-layout stage: stage-relative row R, k-step ks, lane half h
 template <int DH>
@@ -80,7 +83,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const bf16* __restrict
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h = lane >> 5, lq = lane & 31;
-  const int nqb = L / 256, nst = L / SKB;
+  const int nqb = (L + 255) / 256, nst = (L + SKB - 1) / SKB;     // last query block / key stage may be partial (L % 16 == 0)
   const int nitems = nbh * nqb;
   const int my_items = (nitems - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
   const int total = my_items * nst;
@@ -91,18 +94,20 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const bf16* __restrict
     const int64_t roff = lq_.at(bh, nh, (int64_t)st * SKB);
     const bf16* Tb = KT + (int64_t)bh * DH * L + (int64_t)st * SKB;
     char* base = smem_dyn + (g & 1) * (3 * ST);
+    const int valid = L - st * SKB;                       // rows of this stage that exist (the rest: clamped sources, masked scores)
 #pragma unroll
-    for (int j = 0; j < PK; ++j) dma_rows<DH>(K + roff, lq_.ld, base, wave + NW * j, lane);
+    for (int j = 0; j < PK; ++j) dma_rows<DH>(K + roff, lq_.ld, base, wave + NW * j, lane, valid);
 #pragma unroll
-    for (int j = 0; j < PK; ++j) dma_rows<DH>(V + roff, lq_.ld, base + ST, wave + NW * j, lane);
+    for (int j = 0; j < PK; ++j) dma_rows<DH>(V + roff, lq_.ld, base + ST, wave + NW * j, lane, valid);
 #pragma unroll
-    for (int j = 0; j < PK; ++j) dma_cols<DH>(Tb, L, base + 2 * ST, wave + NW * j, lane);
+    for (int j = 0; j < PK; ++j) dma_cols<DH>(Tb, L, base + 2 * ST, wave + NW * j, lane, valid);
   };
 
   bf16x8 qf[KS], dof[KS];
   f32x16 dq[DT];
   float lse_q = 0.f, D_q = 0.f;
   int q0 = 0;
+  bool active = false;
   if (total > 0) issue(0);
   for (int g = 0; g < total; ++g) {
     const int item = blockIdx.x + (g / nst) * gridDim.x, st = g % nst;
@@ -112,23 +117,25 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const bf16* __restrict
     if (g + 1 < total) issue(g + 1);
     if (st == 0) {
       q0 = qb * 256 + wave * 32;
-      const int64_t qrow = (int64_t)bh * L + q0 + lq;
+      active = q0 < L;
+      const int qc = q0 + lq < L ? q0 + lq : L - 1;                 // clamped row of a partial / absent query tile
+      const int64_t qrow = (int64_t)bh * L + qc;
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
-        qf[ks] = *reinterpret_cast<const bf16x8*>(Q + lq_.at(bh, nh, q0 + lq) + 16 * ks + 8 * h);
-        dof[ks] = *reinterpret_cast<const bf16x8*>(dO + lo_.at(bh, nh, q0 + lq) + 16 * ks + 8 * h);
+        qf[ks] = *reinterpret_cast<const bf16x8*>(Q + lq_.at(bh, nh, qc) + 16 * ks + 8 * h);
+        dof[ks] = *reinterpret_cast<const bf16x8*>(dO + lo_.at(bh, nh, qc) + 16 * ks + 8 * h);
       }
       lse_q = lse2[qrow];
       // D[q] = sum_d dO[q][d] O[q][d]: each lane half holds half of the head dim of its query; kept for the dK/dV kernel
       D_q = 0.f;
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
-        const bf16x8 of = *reinterpret_cast<const bf16x8*>(O + lo_.at(bh, nh, q0 + lq) + 16 * ks + 8 * h);
+        const bf16x8 of = *reinterpret_cast<const bf16x8*>(O + lo_.at(bh, nh, qc) + 16 * ks + 8 * h);
 #pragma unroll
         for (int j = 0; j < 8; ++j) D_q += (float)dof[ks][j] * (float)of[j];
       }
       D_q += __shfl_xor(D_q, 32, 64);
-      if (h == 0) Dv[qrow] = D_q;
+      if (h == 0 && q0 + lq < L) Dv[qrow] = D_q;
 #pragma unroll
       for (int i = 0; i < DT; ++i)
 #pragma unroll
@@ -137,7 +144,9 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const bf16* __restrict
     const char* kst = smem_dyn + (g & 1) * (3 * ST);
     const char* vst = kst + ST;
     const char* tst = kst + 2 * ST;
-    for (int t = 0; t < SKB / 64; ++t) {
+    const int st_keys = L - st * SKB;
+    for (int t = 0; active && t < SKB / 64 && t * 64 < st_keys; ++t) {
+      const int tile_keys = st_keys - t * 64;
       f32x16 s[2], dp[2];
 #pragma unroll
       for (int kt = 0; kt < 2; ++kt) {
@@ -154,7 +163,8 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const bf16* __restrict
       for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const float p = __builtin_amdgcn_exp2f(s[kt][r] * scale_log2e - lse_q);
+          float p = __builtin_amdgcn_exp2f(s[kt][r] * scale_log2e - lse_q);
+          if (tile_keys < 64 && kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h >= tile_keys) p = 0.f;   // key past the sequence end
           s[kt][r] = p * (dp[kt][r] - D_q);                      // dS^T (the 1/sqrt(dh) factor is applied to dQ at the end)
         }
 #pragma unroll
@@ -167,7 +177,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const bf16* __restrict
             dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols<DH>(tst, t, 2 * kt + s2, dt * 32 + lq, h), dsf, dq[dt], 0, 0, 0);
         }
     }
-    if (st == nst - 1) {
+    if (st == nst - 1 && q0 + lq < L) {
       const int b = bh / nh, head = bh % nh;
       const int64_t tok = (int64_t)b * L + q0 + lq;
 #pragma unroll
@@ -205,7 +215,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const bf16* __restric
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h = lane >> 5, lq = lane & 31;
-  const int nkb = L / 256, nst = L / SKB;
+  const int nkb = (L + 255) / 256, nst = (L + SKB - 1) / SKB;
   const int nitems = nbh * nkb;
   const int my_items = (nitems - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
   const int total = my_items * nst;
@@ -216,21 +226,26 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const bf16* __restric
     const int64_t r0 = (int64_t)bh * L + (int64_t)st * SKB;
     const int64_t c0 = (int64_t)bh * DH * L + (int64_t)st * SKB;
     char* base = smem_dyn + (g & 1) * BUF;
+    const int valid = L - st * SKB;
 #pragma unroll
-    for (int j = 0; j < PK; ++j) dma_rows<DH>(Q + lq_.at(bh, nh, (int64_t)st * SKB), lq_.ld, base, wave + NW * j, lane);
+    for (int j = 0; j < PK; ++j) dma_rows<DH>(Q + lq_.at(bh, nh, (int64_t)st * SKB), lq_.ld, base, wave + NW * j, lane, valid);
 #pragma unroll
-    for (int j = 0; j < PK; ++j) dma_rows<DH>(dO + lo_.at(bh, nh, (int64_t)st * SKB), lo_.ld, base + ST, wave + NW * j, lane);
+    for (int j = 0; j < PK; ++j) dma_rows<DH>(dO + lo_.at(bh, nh, (int64_t)st * SKB), lo_.ld, base + ST, wave + NW * j, lane, valid);
 #pragma unroll
-    for (int j = 0; j < PK; ++j) dma_cols<DH>(QT + c0, L, base + 2 * ST, wave + NW * j, lane);
+    for (int j = 0; j < PK; ++j) dma_cols<DH>(QT + c0, L, base + 2 * ST, wave + NW * j, lane, valid);
 #pragma unroll
-    for (int j = 0; j < PK; ++j) dma_cols<DH>(dOT + c0, L, base + 3 * ST, wave + NW * j, lane);
-    if (wave == 0)   // lanes 0-31: lse2 of the 128 queries, lanes 32-63: D
-      glds16((lane < 32 ? lse2 + r0 + 4 * lane : Dv + r0 + 4 * (lane - 32)), base + 4 * ST);
+    for (int j = 0; j < PK; ++j) dma_cols<DH>(dOT + c0, L, base + 3 * ST, wave + NW * j, lane, valid);
+    if (wave == 0) {   // lanes 0-31: lse2 of the 128 queries, lanes 32-63: D (groups of 4; past the end: the last valid group)
+      int qo = 4 * (lane & 31);
+      if (qo >= valid) qo = valid - 4;
+      glds16((lane < 32 ? lse2 : Dv) + r0 + qo, base + 4 * ST);
+    }
   };
 
   bf16x8 kf[KS], vf[KS];
   f32x16 dk[DT], dv[DT];
   int k0 = 0;
+  bool active = false;
   if (total > 0) issue(0);
   for (int g = 0; g < total; ++g) {
     const int item = blockIdx.x + (g / nst) * gridDim.x, st = g % nst;
@@ -240,10 +255,12 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const bf16* __restric
     if (g + 1 < total) issue(g + 1);
     if (st == 0) {
       k0 = kb * 256 + wave * 32;
+      active = k0 < L;
+      const int kc = k0 + lq < L ? k0 + lq : L - 1;
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
-        kf[ks] = *reinterpret_cast<const bf16x8*>(K + lq_.at(bh, nh, k0 + lq) + 16 * ks + 8 * h);
-        vf[ks] = *reinterpret_cast<const bf16x8*>(V + lq_.at(bh, nh, k0 + lq) + 16 * ks + 8 * h);
+        kf[ks] = *reinterpret_cast<const bf16x8*>(K + lq_.at(bh, nh, kc) + 16 * ks + 8 * h);
+        vf[ks] = *reinterpret_cast<const bf16x8*>(V + lq_.at(bh, nh, kc) + 16 * ks + 8 * h);
       }
 #pragma unroll
       for (int i = 0; i < DT; ++i)
@@ -255,7 +272,8 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const bf16* __restric
     const char* qtst = qst + 2 * ST;
     const char* otst = qst + 3 * ST;
     const float* lst = reinterpret_cast<const float*>(qst + 4 * ST);   // [0..127] lse2, [128..255] D
-    for (int t = 0; t < SKB / 64; ++t) {
+    const int st_q = L - st * SKB;                                      // queries of this stage that exist
+    for (int t = 0; active && t < SKB / 64 && t * 64 < st_q; ++t) {
 #pragma unroll
       for (int qt = 0; qt < 2; ++qt) {
         const int R = t * 64 + 32 * qt + lq;
@@ -275,7 +293,8 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const bf16* __restric
           const f32x4 dd = *reinterpret_cast<const f32x4*>(lst + 128 + qi);
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            const float p = __builtin_amdgcn_exp2f(s[rg * 4 + e] * scale_log2e - ls[e]);
+            float p = __builtin_amdgcn_exp2f(s[rg * 4 + e] * scale_log2e - ls[e]);
+            if (qi + e >= st_q) p = 0.f;                                  // query past the sequence end
             s[rg * 4 + e] = p;
             dp[rg * 4 + e] = p * (dp[rg * 4 + e] - dd[e]);
           }
@@ -291,7 +310,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const bf16* __restric
         }
       }
     }
-    if (st == nst - 1) {
+    if (st == nst - 1 && k0 + lq < L) {
       const int b = bh / nh, head = bh % nh;
       const int64_t tok = (int64_t)b * L + k0 + lq;
 #pragma unroll
@@ -349,7 +368,7 @@ int launch_bwd(const bf16* q, const bf16* k, const bf16* v, const bf16* qT, cons
   }
   int dev = 0, cus = 256;
   if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-  const int nbh = B * nh, nitems = nbh * (L / 256);
+  const int nbh = B * nh, nitems = nbh * ((L + 255) / 256);
   const dim3 grid((unsigned)(nitems < cus ? nitems : cus)), block(512);
   const float sl2 = scale * 1.4426950408889634f;
   MH_LAUNCH((attn_bwd_dq_kernel<DH>), grid, block, bytes_dq, s, q, k, v, kT, dO, o, lse2, Dv, dq, ld, L, nh, nbh, scale, sl2, lqkv, ldo);
@@ -361,7 +380,7 @@ int launch_bwd(const bf16* q, const bf16* k, const bf16* v, const bf16* qT, cons
 
 }  // namespace
 
-extern "C" int mh_attention_stream_bwd_supported(int L, int dh) { return L >= 512 && L % 256 == 0 && (dh == 32 || dh == 64); }
+extern "C" int mh_attention_stream_bwd_supported(int L, int dh) { return L >= 512 && L % 16 == 0 && (dh == 32 || dh == 64); }
 
 extern "C" int mh_attention_bwd_rowdot(const void* dctx, const void* ctx, int64_t ld, float* D, int B, int L, int nh, int dh,
                                        mh_stream_t stream) {
@@ -396,7 +415,7 @@ extern "C" int mh_attention_stream_bwd_ex(const void* q, const void* k, const vo
   const RowLayout lqkv{qsB, qsH, qld}, ldo{osB, osH, old_};
   MH_CHECK_ARG(q && k && v && qT_perm && kT_perm && dO && dOT_perm && o && lse2 && D && dq && dk && dv, "attention_stream_bwd: null pointer");
   MH_CHECK_ARG(B > 0 && nh > 0 && mh_attention_stream_bwd_supported(L, dh),
-               "attention_stream_bwd: needs seq_len %% 256 == 0, seq_len >= 512 and head dim 32 or 64 (got L=%d dh=%d)", L, dh);
+               "attention_stream_bwd: needs seq_len %% 16 == 0, seq_len >= 512 and head dim 32 or 64 (got L=%d dh=%d)", L, dh);
   MH_CHECK_ARG(ld_d % 4 == 0, "attention_stream_bwd: ld_d must be a multiple of 4");
   hipStream_t s = (hipStream_t)stream;
   if (dh == 64)

@@ -199,7 +199,7 @@ def test_attention_stream(dh, L, B, nh):
     assert torch.equal(outp.permute(1, 0, 2).reshape(B * L, nh * dh), out)
 
 
-@pytest.mark.parametrize("dh,L,B,nh", [(64, 512, 2, 3), (64, 1024, 1, 2), (32, 512, 2, 2)])
+@pytest.mark.parametrize("dh,L,B,nh", [(64, 512, 2, 3), (64, 1024, 1, 2), (32, 512, 2, 2), (64, 528, 1, 2), (64, 2096, 1, 1), (32, 784, 1, 2)])
 def test_attention_stream_backward(dh, L, B, nh):
     """fused backward kernels (dQ; dK, dV) == torch autograd through softmax(QK^T/sqrt(dh)) V on the bf16-rounded inputs"""
     from musediffusion_amd._lib import check, current_stream

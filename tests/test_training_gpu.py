@@ -144,12 +144,13 @@ def test_ddp_wrapped_training_step_single_rank_nccl():
             dist.destroy_process_group()
 
 
-def test_fused_attention_training_path_matches_unfused():
+@pytest.mark.parametrize("L", [512, 528])
+def test_fused_attention_training_path_matches_unfused(L):
     """seq_len 512 engages the streaming attention forward + fused backward kernels and the one-node FFN (GELU backward in a
     GEMM epilogue) in training_losses (bf16): same loss and gradients as the unfused tape, up to bf16 rounding"""
     from musediffusion_amd import synthetic, training
     torch.manual_seed(3)
-    E, H, L, B, V = 32, 128, 512, 2, 97
+    E, H, B, V = 32, 128, 2, 97
     m = TransformerNetModel(E, E, 32, V, L, dropout=0.0, bert_hidden=H, bert_layers=2, bert_heads=2, bert_ffn=256,
                             compute_dtype="bf16")
     m.train().requires_grad_(True).to(DEV)
