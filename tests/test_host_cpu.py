@@ -160,3 +160,20 @@ def test_product_path_refuses_cpu_instead_of_falling_back():
             if f.endswith(".py"):
                 src = open(os.path.join(dp, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), os.path.join(dp, f)
+
+
+def test_batch_and_metric_modules_refuse_cpu_tensors():
+    """the rows next to the path have no CPU fallback either: host tensors raise instead of silently running elsewhere"""
+    from musediffusion_amd import data as mdata, metric as mm
+    from musediffusion_amd._lib import MuseHipError
+    from musediffusion_amd.utils import decode_util as md
+    v, off = torch.zeros(20, dtype=torch.int32), torch.tensor([0, 20])
+    for fn in (lambda: mdata.masking_token(v, off), lambda: mdata.masking_note(v, off), lambda: mdata.randomize_note(v, off),
+               lambda: mdata.random_rotating(v, off), lambda: mdata.collate_batches({"input_ids": v}, off, 32),
+               lambda: mm.get_vectors(torch.zeros(2, 16, dtype=torch.int32)), lambda: md.validate_tokens(torch.zeros(2, 16, dtype=torch.int32))):
+        with pytest.raises(MuseHipError):
+            fn()
+    c = mdata.Corruptions.from_config("mt,mn", 1, 0.5, "{'p': 0.25}")
+    assert c.corr_kwargs == {"p": 0.25} and c.corr_max == 1
+    with pytest.raises(AssertionError):
+        mdata.Corruptions(("zz",), 1, 0.5)
