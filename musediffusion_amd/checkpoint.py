@@ -14,12 +14,13 @@ def parse_resume_step_from_filename(filename):
 
 
 def find_resume_checkpoint(directory):
-    """Newest `model*.pt` in `directory` by modification time, or None (train_util.py:346-351)."""
+    """Last `model*.pt` of `directory` in sorted-name order, or None (train_util.py:346-351: `sorted(...)[-1]`;
+    with the zero-padded step in the name that is the highest step, whatever the files' modification times)."""
     try:
-        cands = [os.path.join(directory, f) for f in os.listdir(directory) if re.match(r"model.*\.pt$", f)]
+        names = sorted(f for f in os.listdir(directory) if f.endswith(".pt") and f.startswith("model"))
     except OSError:
         return None
-    return max(cands, key=os.path.getmtime) if cands else None
+    return os.path.join(directory, names[-1]) if names else None
 
 
 def find_ema_checkpoint(main_checkpoint, step, rate):
@@ -58,8 +59,8 @@ def resume(directory, model, optimizer=None, ema_rates=(), map_location="cpu"):
         names = [n for n, _ in model.named_parameters()]
         for i, rate in enumerate(ema_rates):
             path = find_ema_checkpoint(main, step, rate)
-            if path:
-                sd = torch.load(path, map_location=map_location)
-                for j, n in enumerate(names):
-                    optimizer.ema[i][j].copy_(sd[n])
+            # no EMA file: the reference starts the EMA from a copy of the loaded parameters (train_util.py:139-152)
+            sd = torch.load(path, map_location=map_location) if path else model.state_dict()
+            for j, n in enumerate(names):
+                optimizer.ema[i][j].copy_(sd[n])
     return step

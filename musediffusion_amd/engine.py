@@ -85,7 +85,7 @@ class DenoiserEngine:
         d.dtype = self.dtype
         for k in ("E", "H", "F", "nh", "nL", "Tt", "Tt_pad", "T4_pad", "E_pad", "L_max", "has_proj", "panel"):
             setattr(d, k, int(c[k]))
-        d.ln_eps = 1e-12
+        d.ln_eps = float(c.get("ln_eps", 1e-12))
         for k in ("w_t0", "b_t0", "w_t2", "b_t2", "pos", "ln0_g", "ln0_b"):
             setattr(d, k, self._addr(k))
         for k in ("w_up0", "b_up0", "w_up2", "b_up2", "w_dn0", "b_dn0", "w_dn2", "b_dn2"):

@@ -610,6 +610,9 @@ class _ReverseLoop:
             # config 2, bit-identical samples); small batches would only halve the tile count of every GEMM
             split = 2 if (B % 2 == 0 and B * L >= 32768 and getattr(net, "compute_dtype", "fp32") == "bf16") else 1
         self.nsplit = max(1, min(int(split), B))
+        # the captured graph bakes in raw workspace pointers: the loop owns its scratch (the engine's shared buffer may be
+        # reallocated by any other forward between two replays of a progressive loop)
+        self.own_ws = eng.new_workspace(B, L) if self.nsplit <= 1 else None
         if self.nsplit > 1:
             hb = B // self.nsplit
             self.split_ws = [eng.new_workspace(B - hb * (self.nsplit - 1) if j == self.nsplit - 1 else hb, L) for j in range(self.nsplit)]
@@ -654,7 +657,7 @@ class _ReverseLoop:
                                               int(self.diff.rng_stream), P(self.state), stream_h), "mh_trunc_normal")
 
         if nsplit <= 1:
-            self.eng.forward(self.x, self.emb_table, self.emb_row, out=self.model_out)
+            self.eng.forward(self.x, self.emb_table, self.emb_row, out=self.model_out, ws=self.own_ws)
             draw_noise(st)
             tail(slice(0, self.B), st, self.round_ws)
         else:

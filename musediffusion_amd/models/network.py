@@ -142,7 +142,8 @@ class TransformerNetModel(nn.Module):
         if self._engine is None or self._engine_key != key:
             if self._engine is None or self._engine.device != dev or self._engine.dtype != ops.dtype_code(self.compute_dtype):
                 cfg = dict(E=self.input_dims, H=self.hidden_size, F=self.ffn_size, nh=self.num_heads,
-                           nL=len(self.input_transformers.layer), Tt=self.hidden_t_dim, L_max=self.seq_len)
+                           nL=len(self.input_transformers.layer), Tt=self.hidden_t_dim, L_max=self.seq_len,
+                           ln_eps=self.LayerNorm.eps)
                 self._engine = DenoiserEngine(cfg, self.compute_dtype, dev)
             self._engine.load_state_dict(dict(self.state_dict()))
             self._engine_key = key

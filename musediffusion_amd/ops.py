@@ -245,8 +245,14 @@ class Graph:
         try:
             with torch.cuda.stream(stream):
                 fn()
-        finally:
-            check(lib().mh_graph_end_capture(stream.cuda_stream, C.byref(self.handle)), "mh_graph_end_capture")
+        except BaseException:
+            # leave capture mode, but let fn()'s own exception through (an end-capture error here would mask it)
+            lib().mh_graph_end_capture(stream.cuda_stream, C.byref(self.handle))
+            if self.handle:
+                lib().mh_graph_destroy(self.handle)
+                self.handle = C.c_void_p()
+            raise
+        check(lib().mh_graph_end_capture(stream.cuda_stream, C.byref(self.handle)), "mh_graph_end_capture")
         return self
 
     def launch(self, stream):

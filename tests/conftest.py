@@ -21,3 +21,11 @@ def load_golden(name):
 @pytest.fixture(scope="session")
 def golden():
     return load_golden
+
+
+def free_port():
+    """An unused TCP port on 127.0.0.1 for a torch.distributed rendezvous (no fixed port: parallel test runs collide)."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]

@@ -113,7 +113,8 @@ def test_ddp_wrapped_training_step_single_rank_nccl():
     import torch.distributed as dist
     from torch.nn.parallel import DistributedDataParallel as DDP
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29533")
+    from conftest import free_port
+    os.environ["MASTER_PORT"] = str(free_port())
     created = False
     if not dist.is_initialized():
         dist.init_process_group("nccl", rank=0, world_size=1)
