@@ -37,6 +37,10 @@ WORKLOADS = {
     "c2-bertbase": dict(L=512, B=64, E=128, H=768, nL=12, nh=12, F=3072, V=729, Tt=128, T=2000),
     # BASELINE.json configs[0] shape (plumbing)
     "c1": dict(L=128, B=8, E=128, H=128, nL=2, nh=4, F=512, V=729, Tt=128, T=2000),
+    # BASELINE.json configs[2]: modification (run/sample.py:109-114, :195-197): 200 DDIM steps (gap 10), strength 0.75 -> 150 iterations
+    "c3": dict(L=512, B=64, E=128, H=512, nL=12, nh=8, F=2048, V=729, Tt=128, T=2000, ddim_steps=200, strength=0.75),
+    # BASELINE.json configs[3]: generation, 64 sequences per GPU (512 on 8), through sampling.generate
+    "c4": dict(L=512, B=64, E=128, H=512, nL=12, nh=8, F=2048, V=729, Tt=128, T=2000),
     # BASELINE.json configs[4]: training_losses, seq_len 1024, global batch 256 = 32 per GPU x 8 (DDP, RCCL all-reduce)
     "train": dict(L=1024, B=32, E=128, H=512, nL=12, nh=8, F=2048, V=729, Tt=128, T=2000),
 }
@@ -194,37 +198,105 @@ def cpu_baseline(c, seconds_budget=25.0):
 
 
 def train_main(args, world, rank, local_rank, device):
-    """`--workload train`: one step = training_losses forward + backward over one micro-batch (the reference's
-    _forward_backward_logic, utils/train_util.py:188-232) with DDP gradient all-reduce when N > 1.  Reported
-    separately from the headline sampling metric."""
+    """`--workload train` (BASELINE.json configs[4]): one step = ONE OPTIMIZER STEP of the reference's TrainLoop
+    (utils/train_util.py:170-172): `--accum` micro-batches of 32 sequences x seq_len 1024 per GPU through training_losses
+    forward + backward in train mode (dropout 0.1 at the reference's three sites), DDP gradient all-reduce over RCCL on the
+    last micro-batch only (`no_sync` before it), then the fused AdamW + 3 x EMA step.  Reported separately from the headline
+    sampling metric."""
     import torch.distributed as dist
     from torch.nn.parallel import DistributedDataParallel as DDP
-    from musediffusion_amd import synthetic
+    from musediffusion_amd import sharding, synthetic
+    from musediffusion_amd.train_step import TrainStep
     c = WORKLOADS["train"]
-    model, diff = build(c, args.dtype, device, seed=0)
+    model, diff = build(c, args.dtype, device, seed=rank)
     model.train().requires_grad_(True)
-    net = model
+    ddp = None
     if world > 1:
-        model = DDP(model, device_ids=[local_rank], broadcast_buffers=False, bucket_cap_mb=128, find_unused_parameters=False)
-    batch = {k: v.to(device) for k, v in synthetic.training_batch(c["B"], c["L"], seed=1 + rank).items()}
-    g = torch.Generator().manual_seed(7 + rank)
-
-    def step():
-        t = torch.randint(0, c["T"], (c["B"],), generator=g).to(device)
-        net.zero_grad(set_to_none=True)
-        terms = diff.training_losses(model, t, model_kwargs=batch)
-        terms["loss"].mean().backward()
-        return terms
+        sharding.broadcast_weights(model, src=0)                    # utils/dist_util.py:141-152 as one flat broadcast
+        ddp = DDP(model, device_ids=[local_rank], broadcast_buffers=False, bucket_cap_mb=128, find_unused_parameters=False)
+    loop = TrainStep(model, diff, microbatch=c["B"], lr=1e-4, weight_decay=0.0, ema_rate=(0.5, 0.9, 0.99), learning_steps=320000,
+                     ddp_model=ddp)
+    import numpy as np
+    np.random.seed(7 + rank)                                         # the schedule sampler draws with np.random (step_sample.py:45-63)
+    cond = synthetic.training_batch(c["B"] * args.accum, c["L"], seed=1 + rank)
 
     for _ in range(args.warmup):
-        step()
+        loop.run_step(cond)
+
+    def timed():
+        for _ in range(args.steps):
+            losses, gn = loop.run_step(cond)
+        return losses, gn
+    elapsed, (losses, gn) = timed_region(timed, world, device)
+    assert bool(torch.isfinite(losses["loss"])) and bool(torch.isfinite(gn).all())
+    if rank == 0:
+        N = c["B"] * c["L"] * args.accum
+        fwd = (step_flops(dict(c)) - 2 * c["B"] * c["L"] * c["V"] * c["E"] + 2 * 2 * c["B"] * c["L"] * c["V"] * c["E"]) * args.accum
+        out = {"metric": "training-steps/sec (optimizer steps: %d x training_losses fwd+bwd at seq_len=%d, batch=%d/GPU, + AdamW/EMA)"
+                         % (args.accum, c["L"], c["B"]),
+               "value": round(args.steps / elapsed, 3), "unit": "optimizer steps/s", "n_gpus": world,
+               "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+               "config": {"workload": "TrainLoop.run_step: training_losses_seq2seq_with_corruption fwd+bwd (train mode, dropout %.2f) "
+                                      "x %d micro-batches, DDP all-reduce on the last, fused AdamW + 3 EMA; seq_len=%d microbatch=%d/GPU "
+                                      "d_model=%d layers=%d" % (model.dropout.p, args.accum, c["L"], c["B"], c["H"], c["nL"]),
+                          "global_batch": c["B"] * args.accum * world, "seq_len": c["L"], "parallelism": "ddp x%d" % world,
+                          "rccl_ranks": world, "microbatches_per_step": args.accum,
+                          "ms_per_microbatch": round(elapsed / args.steps / args.accum * 1e3, 3),
+                          "tokens_per_s": round(world * args.steps * N / elapsed, 1),
+                          "approx_tflops": round(3 * fwd / (elapsed / args.steps) / 1e12, 2),
+                          "loss": round(float(losses["loss"]), 4), "grad_norm": round(float(gn), 4)}}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def _free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def self_launch(n, argv):
+    """`python bench.py --gpus N` with no launcher around it: start N fresh ranks (one per GPU) the way the reference's own
+    launcher does (utils/dist_run.py:13-51: `python -m torch.distributed.run`), as a CHILD process of this one, which has
+    not touched the GPU (importing torch does not), and exit with the child's code.  Never an exec of a GPU process."""
+    import subprocess
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // n)))       # dist_run.py:31
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def init_ranks(args):
+    """Rank bookkeeping shared by every workload: WORLD_SIZE must equal --gpus (also when it is 1), one process per GPU, RCCL."""
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit("bench.py: process group has %d ranks, --gpus %d" % (dist.get_world_size(), args.gpus))
+    return world, rank, local_rank, device
+
+
+def timed_region(fn, world, device):
+    """barrier + synchronize on both sides of fn(); returns the MAX elapsed seconds over ranks."""
+    import torch.distributed as dist
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        terms = step()
+    out = fn()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -232,20 +304,67 @@ def train_main(args, world, rank, local_rank, device):
     el = torch.tensor([time.perf_counter() - t0], device=device, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
-    elapsed = float(el.item())
-    assert bool(torch.isfinite(terms["loss"]).all())
+    return float(el.item()), out
+
+
+def assert_same_on_all_ranks(value, what, world, device):
+    """Every rank must hold the same int64 scalar (weight checksum, token checksum)."""
+    import torch.distributed as dist
+    if world == 1:
+        return
+    t = torch.tensor([int(value)], device=device, dtype=torch.int64)
+    parts = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(parts, t)
+    vals = [int(p.item()) for p in parts]
+    if len(set(vals)) != 1:
+        raise SystemExit("bench.py: %s differs across ranks: %s" % (what, vals))
+
+
+def sampling_main(args, world, rank, local_rank, device):
+    """`--workload c3 | c4`: the reference's sampling block (run/sample.py:185-220) end to end through
+    musediffusion_amd.sampling: rank 0 owns the weights -> ONE packed RCCL broadcast -> every rank samples its contiguous
+    shard of the global batch -> ONE token all-gather.  c4 = generation (BASELINE configs[3]: 64 sequences per GPU, p_sample
+    loop), c3 = modification (configs[2]: 200 DDIM steps x strength 0.75 = q_sample to t = 149, then 150 iterations)."""
+    import torch.distributed as dist
+    from musediffusion_amd import sampling, sharding, synthetic
+    c = WORKLOADS[args.workload]
+    model, diff = build(c, args.dtype, device, seed=rank)          # different weights per rank until the broadcast
+    sharding.broadcast_weights(model, src=0, packed=True)
+    assert_same_on_all_ranks(sharding.weights_checksum(model), "weight arena checksum after the broadcast", world, device)
+    diff.rng_mode, diff.rng_seed, diff.rng_stream = args.rng, 105, rank
+    diff.use_graph = not args.no_graph
+    Bg = c["B"] * world
+    torch.manual_seed(105 + rank)
+    if args.workload == "c4":
+        cond = synthetic.generation_batch(Bg, c["L"], seed=1)
+        steps = args.steps
+        run = lambda n: sampling.generate(model, diff, cond, t_enc=n, sharded=True)
+        what = "sampling.generate (p_sample_loop, first %d of T=%d iterations)" % (steps, c["T"])
+    else:
+        tb = synthetic.training_batch(Bg, c["L"], seed=1)
+        cond = {"input_ids": tb["input_ids"], "input_mask": tb["input_mask"]}
+        steps = int(c["ddim_steps"] * c["strength"])
+        run = lambda n: sampling.modify(model, diff, cond, step=c["ddim_steps"], strength=c["strength"], sharded=True)
+        what = "sampling.modify (q_sample to t=%d, %d ddim iterations, gap %d)" % (steps - 1, steps, c["T"] // c["ddim_steps"])
+    if args.warmup > 0:
+        run(min(args.warmup, steps))
+    elapsed, tokens = timed_region(lambda: run(steps), world, device)
+    assert tokens.shape == (Bg, c["L"]) and tokens.dtype == torch.int64
+    assert_same_on_all_ranks(int(tokens.sum().item()) * 1000003 + int((tokens * torch.arange(1, c["L"] + 1, device=tokens.device)).sum().item()),
+                             "gathered token checksum", world, device)
     if rank == 0:
-        N = c["B"] * c["L"]
-        fwd = step_flops(dict(c)) - 2 * N * c["V"] * c["E"] + 2 * 2 * N * c["V"] * c["E"]   # denoiser + two CE heads
-        out = {"metric": "training-steps/sec (training_losses fwd+bwd, seq_len=%d, batch=%d/GPU)" % (c["L"], c["B"]),
-               "value": round(world * args.steps / elapsed, 3), "unit": "micro-batch steps/s", "n_gpus": world,
-               "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+        flops = step_flops(c)
+        ms = elapsed / steps * 1e3
+        out = {"metric": "denoiser-steps/sec (seq_len=%d, batch=%d)" % (c["L"], c["B"]), "value": round(world * steps / elapsed, 3),
+               "unit": "denoiser-steps/s", "n_gpus": world, "steps": steps, "warmup": args.warmup, "ms_per_step": round(ms, 4),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-               "config": {"workload": "training_losses_seq2seq_with_corruption fwd+bwd, seq_len=%d batch=%d/GPU d_model=%d "
-                                      "layers=%d" % (c["L"], c["B"], c["H"], c["nL"]),
-                          "global_batch": c["B"] * world, "seq_len": c["L"], "parallelism": "ddp x%d" % world,
-                          "tokens_per_s": round(world * args.steps * N / elapsed, 1),
-                          "approx_tflops": round(3 * fwd / (elapsed / args.steps) / 1e12, 2)}}
+               "config": {"workload": "%s: %s; seq_len=%d batch=%d/GPU (global %d) d_model=%d layers=%d; timed region = the whole call: "
+                                      "embed + start latent + loop set-up (graph capture) + loop + logits argmax + token all-gather"
+                                      % (args.workload, what, c["L"], c["B"], Bg, c["H"], c["nL"]),
+                          "global_batch": Bg, "seq_len": c["L"], "parallelism": "batch-sharded x%d" % world,
+                          "rccl_ranks": world, "weights": "one packed-arena broadcast from rank 0 (%.1f MB)" % (model.engine().arena_bytes() / 1e6),
+                          "rng": args.rng, "hipgraph": not args.no_graph,
+                          "step_tflops_achieved": round(flops / (ms * 1e-3) / 1e12, 2)}}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
@@ -255,7 +374,7 @@ def train_main(args, world, rank, local_rank, device):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 50; c4: 200; train: 10; c3: fixed by the config)")
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
@@ -263,30 +382,28 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--accum", type=int, default=1, help="train: micro-batches per optimizer step (the reference's batch_size // microbatch)")
     ap.add_argument("--split", type=int, default=None, help="batch slices run as concurrent graph branches (default: the library's choice)")
     ap.add_argument("--gemm", type=int, default=None, help="bf16 GEMM kernel variant 0/1/2 (see mh_gemm_set_variant)")
     ap.add_argument("--no-fuse-ln", action="store_true", help="A/B: separate GEMM and LayerNorm kernels")
     ap.add_argument("--no-stream-attn", action="store_true", help="A/B: LDS-resident attention instead of the streaming kernel")
     args = ap.parse_args()
+    if args.steps is None:
+        args.steps = {"c4": 200, "train": 10}.get(args.workload, 50)
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args.gpus, sys.argv[1:])          # does not return
+    world, rank, local_rank, device = init_ranks(args)
     import torch.distributed as dist
-    if world > 1:
-        dist.init_process_group("nccl", device_id=device)
 
     if args.workload == "train":
         return train_main(args, world, rank, local_rank, device)
+    if args.workload in ("c3", "c4"):
+        return sampling_main(args, world, rank, local_rank, device)
     from functools import partial
-    from musediffusion_amd import _lib, synthetic
+    from musediffusion_amd import _lib, sharding, synthetic
     from musediffusion_amd.models.diffusion import _ReverseLoop
     from musediffusion_amd.models.rounding import denoised_fn_round
-    from musediffusion_amd.sharding import broadcast_weights
 
     if args.gemm is not None:
         _lib.lib().mh_gemm_set_variant(args.gemm)
@@ -295,9 +412,10 @@ def main():
     if args.no_stream_attn:
         _lib.lib().mh_attention_set_stream(0)
     c = WORKLOADS[args.workload]
-    model, diff = build(c, args.dtype, device, seed=0)
+    model, diff = build(c, args.dtype, device, seed=rank)     # different weights per rank until the broadcast
     if world > 1:
-        broadcast_weights(model, src=0)   # ONE RCCL broadcast of the packed arena
+        sharding.broadcast_weights(model, src=0, packed=True)   # ONE RCCL broadcast of the packed arena
+        assert_same_on_all_ranks(sharding.weights_checksum(model), "weight arena checksum after the broadcast", world, device)
     diff.rng_mode, diff.rng_seed, diff.rng_stream = args.rng, 105, rank
     diff.use_graph = not args.no_graph
     if args.split is not None:
@@ -321,24 +439,16 @@ def main():
         loop.begin()
         for k in range(args.warmup):
             loop.advance(k)
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for k in range(args.warmup, total):
-            loop.advance(k)
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        elapsed = time.perf_counter() - t0
-    el = torch.tensor([elapsed], device=device, dtype=torch.float64)
-    if world > 1:
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-    elapsed = float(el.item())
+
+        def timed():
+            for k in range(args.warmup, total):
+                loop.advance(k)
+        elapsed, _ = timed_region(timed, world, device)
     tokens = model.argmax_tokens(loop.x)       # the loop's product: discrete tokens (run/sample.py:219-220)
     assert tokens.shape == (c["B"], c["L"]) and bool(torch.isfinite(loop.x).all())
+    all_tokens = sharding.gather_rows(tokens, c["B"] * world)      # one token all-gather (run/sample.py:288-291)
+    assert all_tokens.shape == (c["B"] * world, c["L"])
+    assert_same_on_all_ranks(int(all_tokens.sum().item()), "gathered token checksum", world, device)
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -353,7 +463,7 @@ def main():
                                    "ffn=%d E=%d vocab=%d T=%d, rounding+clamp+top_p=1 every step"
                                    % (args.workload, c["L"], c["B"], c["H"], c["nL"], c["nh"], c["F"], c["E"], c["V"], c["T"]),
                        "global_batch": c["B"] * world, "seq_len": c["L"], "parallelism": "batch-sharded x%d" % world,
-                       "rng": args.rng, "hipgraph": not args.no_graph, "graph_branches": int(loop.nsplit),
+                       "rccl_ranks": world, "rng": args.rng, "hipgraph": not args.no_graph, "graph_branches": int(loop.nsplit),
                        "step_tflop": round(flops / 1e12, 4),
                        "step_tflops_achieved": round(flops / (ms_per_step * 1e-3) / 1e12, 2),
                        "sequences_steps_per_s": round(value * c["B"], 1)},

@@ -126,8 +126,23 @@ class TransformerNetModel(nn.Module):
         self._engine = None
         self._engine_key = None
         self._table_norm = None
+        self.weights_from_arena = False
 
     # ------------------------------------------------------------------ engine management
+    def pin_engine(self):
+        """The engine's arena was filled from outside (one packed RCCL broadcast): keep it instead of re-packing from
+        this rank's fp32 parameters, which no longer describe the weights."""
+        self._engine_key = self._weights_key()
+        self._table_norm = None
+        self.weights_from_arena = True
+        return self
+
+    def load_state_dict(self, *args, **kwargs):
+        out = super().load_state_dict(*args, **kwargs)
+        self.weights_from_arena = False
+        self._engine_key = None
+        return out
+
     def _weights_key(self):
         ps = list(self.parameters())
         return (self.compute_dtype, str(ps[0].device)) + tuple((p.data_ptr(), p._version) for p in ps)
@@ -139,6 +154,11 @@ class TransformerNetModel(nn.Module):
             raise _lib.MuseHipError("TransformerNetModel runs on the GPU only: call .to('cuda') first "
                                     "(no CPU fallback exists)")
         key = self._weights_key()
+        if self.weights_from_arena:
+            if self._engine_key != key:
+                raise _lib.MuseHipError("this rank's engine holds broadcast weights (sharding.broadcast_weights(packed=True)) "
+                                        "but its fp32 parameters changed: load a state_dict or broadcast flat parameters first")
+            return self._engine
         if self._engine is None or self._engine_key != key:
             if self._engine is None or self._engine.device != dev or self._engine.dtype != ops.dtype_code(self.compute_dtype):
                 cfg = dict(E=self.input_dims, H=self.hidden_size, F=self.ffn_size, nh=self.num_heads,
@@ -205,6 +225,8 @@ class TransformerNetModel(nn.Module):
         :return: an [N x L x C] Tensor of outputs.
         """
         if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            if self.weights_from_arena:
+                raise _lib.MuseHipError("cannot train on a rank whose weights arrived as a packed inference arena")
             from ..training import denoiser_forward_with_grad
             return denoiser_forward_with_grad(self, x, timesteps)
         eng = self.engine()

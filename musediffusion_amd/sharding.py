@@ -19,9 +19,34 @@ def rank():
     return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
 
 
-def broadcast_weights(model, src=0):
-    """Make every rank's parameters equal rank `src`'s with a single broadcast of one flat buffer."""
+def broadcast_weights(model, src=0, packed=False):
+    """Make every rank hold rank `src`'s weights with ONE collective (utils/dist_util.py:141-152 does ~200).
+
+    packed=False: one flat fp32 buffer of all parameters; afterwards `model.parameters()` are equal on every rank
+    (training start-up, DDP).
+    packed=True (sampling ranks, GPU only): the unit is the engine's packed inference arena (compute-dtype
+    matrices + fp32 vectors, 78 MB at config 2 instead of 157 MB of fp32 parameters) followed in the same buffer
+    by the two fp32 tensors the sampling path reads outside the arena (the embedding table for get_embeds /
+    rounding / argmax and lm_head.bias).  Receivers do NOT re-pack: their engine is pinned to the received arena.
+    Their other fp32 `nn.Parameter`s keep their old values, so the model is marked `weights_from_arena` and
+    refuses to train or re-pack until `load_state_dict` / a flat broadcast refreshes it."""
     if world() == 1:
+        return model
+    if packed:
+        eng = model.engine()                       # src: packed from its parameters; others: allocated with the same plan
+        extra = [model.word_embedding.weight.data, model.lm_head.bias.data]
+        tail = torch.cat([t.reshape(-1) for t in extra]).contiguous().view(torch.uint8)
+        flat = torch.cat([eng.arena, tail])
+        dist.broadcast(flat, src=src)
+        if rank() != src:
+            n = eng.arena.numel()
+            eng.arena.copy_(flat[:n])
+            off = n
+            for t in extra:
+                nb = t.numel() * 4
+                t.copy_(flat[off:off + nb].view(torch.float32).view_as(t))
+                off += nb
+            model.pin_engine()
         return model
     params = [p.data for p in model.parameters()]
     flat = torch.cat([p.reshape(-1) for p in params])
@@ -32,6 +57,18 @@ def broadcast_weights(model, src=0):
         p.copy_(flat[off:off + n].view_as(p))
         off += n
     return model
+
+
+def weights_checksum(model):
+    """A scalar every rank can compare after the broadcast: the byte sum of the inference arena when the model runs
+    on the GPU (that is what the sampling kernels read), the fp32 parameter sum otherwise."""
+    if next(model.parameters()).is_cuda:
+        a = model.engine().arena
+        pad = (-a.numel()) % 8
+        if pad:
+            a = torch.cat([a, torch.zeros(pad, dtype=torch.uint8, device=a.device)])
+        return int(a.view(torch.int64).sum().item())
+    return float(sum(p.detach().double().sum() for p in model.parameters()))
 
 
 def shard_bounds(n, r=None, w=None):

@@ -1,0 +1,44 @@
+"""Multi-rank runs of the two sharded paths on the GPU: sampling (packed weight broadcast -> batch shards ->
+token all-gather, against the reference's golden tokens) and training (DDP gradient all-reduce over the kernel-level
+backward, against the reference's golden gradients).  One process per GPU over RCCL when the box has two GPUs; on a one-GPU
+box both ranks share cuda:0 and the collectives run over gloo (tests/dist_worker.py)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from conftest import REPO, free_port  # noqa: E402
+
+
+def run_ranks(case, *extra, world=2, timeout=600):
+    port = free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(REPO, "tests", "dist_worker.py"), case, *extra], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(out)
+    for r, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, "rank %d failed:\n%s" % (r, out[-4000:])
+        assert "rank %d ok" % r in out
+
+
+@pytest.mark.parametrize("tag", ["tiny", "c1"])
+def test_two_rank_sharded_sampling_matches_golden_tokens(tag):
+    run_ranks("generate", tag)
+
+
+def test_two_rank_ddp_gradients_match_golden():
+    run_ranks("ddp")
