@@ -490,6 +490,45 @@ int mh_msim_vectors(const int32_t* tokens, const int32_t* lens, float* out, int3
 int mh_controllability_counts(const int32_t* tokens, const int32_t* lens, const int32_t* metas, int meta_ld, int32_t* out, int B,
                               int L, mh_stream_t stream);
 
+/* ---------------------------------------------------------------- train-mode dropout
+ * Reference: nn.Dropout(dropout) after the embedding LayerNorm (MuseDiffusion/models/network.py:76, :149) and the HF BertEncoder's
+ * hidden dropout (after the attention-output and FFN-output dense layers, before residual + LayerNorm) and attention-probability
+ * dropout, both 0.1 from the bert-base config (network.py:44-46, :74).  Masks are counter-based (Philox4x32-7 keyed by `seed`,
+ * counter = (element group, offset)): the backward re-creates a dense site's mask from the same descriptor; the attention mask
+ * is written once by the forward as a bit tensor (1 bit per probability).  `mask` (test-only, dense sites): explicit keep flags,
+ * one byte per element in row-major order, overriding Philox - how parity tests inject the oracle's masks.  p == 0 (or a null
+ * descriptor): identity. */
+typedef struct mh_dropout {
+  float p;             /* drop probability in [0, 1) */
+  uint64_t seed;       /* Philox key */
+  uint64_t offset;     /* counter words 2..3: one value per (forward call, site) */
+  const uint8_t* mask; /* optional explicit keep flags (device pointer) */
+} mh_dropout;
+
+/* out = x o keep / (1 - p) over [rows, cols] (cols % 8 == 0); element index = row * cols + col.  Forward of the embedding site,
+ * backward of every dense site. */
+int mh_dropout_fwd(const void* x, int64_t ldx, void* out, int64_t ldo, int64_t rows, int cols, int dtype, const mh_dropout* drop,
+                   mh_stream_t stream);
+/* out = dropout(A W^T + bias) + residual: BertSelfOutput / BertOutput dense -> dropout -> (+ input) in one GEMM (row-major). */
+int mh_gemm_bias_dropout_res(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, const void* residual,
+                             int64_t ldr, void* out, int64_t ldo, int64_t M, int N, int K, int dtype, const mh_dropout* drop,
+                             mh_stream_t stream);
+/* attention-probability keep bits: [B nh][ceil(L/32)][32 ceil(L/32)] uint32, word = key, bit = query % 32 */
+size_t mh_dropout_bits_words(int BH, int L);
+int mh_dropout_bits(uint32_t* keep_bits, int BH, int L, const mh_dropout* drop, mh_stream_t stream);
+/* P[bh][q][k] = keep ? P / (1 - p) : 0 over a materialised [B nh, L, ldp] tensor (probabilities forward, their gradient backward) */
+int mh_dropout_bits_apply(void* P, int64_t ldp, const uint32_t* keep_bits, int BH, int L, float p, int dtype, mh_stream_t stream);
+/* streaming attention with probability dropout: keep_bits written (bits_in = 0) or read (bits_in = 1) by the forward, read by the
+ * backward (BertSelfAttention: softmax -> dropout -> . V) */
+int mh_attention_stream_fwd_drop(const void* q, const void* k, const void* vt_perm, void* ctx, int64_t ld_ctx, int ctx_panel, int B,
+                                 int L, int nh, int dh, float scale, float* lse2, int64_t qk_batch_stride, int64_t qk_head_stride,
+                                 int64_t qk_row_stride, const mh_dropout* drop, uint32_t* keep_bits, int bits_in, mh_stream_t stream);
+int mh_attention_stream_bwd_drop(const void* q, const void* k, const void* v, const void* qT_perm, const void* kT_perm, const void* dO,
+                                 const void* dOT_perm, const void* o, const float* lse2, float* D, void* dq, void* dk, void* dv,
+                                 int64_t ld_d, int B, int L, int nh, int dh, float scale, int64_t qkv_batch_stride,
+                                 int64_t qkv_head_stride, int64_t qkv_row_stride, int64_t do_batch_stride, int64_t do_head_stride,
+                                 int64_t do_row_stride, const uint32_t* keep_bits, float drop_p, mh_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

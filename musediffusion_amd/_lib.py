@@ -39,6 +39,11 @@ class OptHParams(C.Structure):
                 ("ema_one_minus", F32 * 4)]
 
 
+class Dropout(C.Structure):
+    """mh_dropout"""
+    _fields_ = [("p", F32), ("seed", C.c_uint64), ("offset", C.c_uint64), ("mask", VP)]
+
+
 class LayerWeights(C.Structure):
     """mh_layer_weights"""
     _fields_ = [(n, VP) for n in ("w_qkv", "b_qkv", "w_ao", "b_ao", "ln1_g", "ln1_b", "w_ff1", "b_ff1",
@@ -146,6 +151,13 @@ SIGNATURES = {
     "mh_graph_end_capture": (INT, [VP, C.POINTER(VP)]),
     "mh_graph_launch": (INT, [VP, VP]),
     "mh_graph_destroy": (INT, [VP]),
+    "mh_dropout_fwd": (INT, [VP, I64, VP, I64, I64, INT, INT, C.POINTER(Dropout), VP]),
+    "mh_gemm_bias_dropout_res": (INT, [VP, I64, VP, I64, VP, VP, I64, VP, I64, I64, INT, INT, INT, C.POINTER(Dropout), VP]),
+    "mh_dropout_bits_words": (C.c_size_t, [INT, INT]),
+    "mh_dropout_bits": (INT, [VP, INT, INT, C.POINTER(Dropout), VP]),
+    "mh_dropout_bits_apply": (INT, [VP, I64, VP, INT, INT, F32, INT, VP]),
+    "mh_attention_stream_fwd_drop": (INT, [VP, VP, VP, VP, I64, INT, INT, INT, INT, INT, F32, VP, I64, I64, I64, C.POINTER(Dropout), VP, INT, VP]),
+    "mh_attention_stream_bwd_drop": (INT, [VP, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP, I64, INT, INT, INT, INT, F32, I64, I64, I64, I64, I64, I64, VP, F32, VP]),
     "mh_denoiser_workspace_bytes": (C.c_size_t, [C.POINTER(Denoiser), INT, INT]),
     "mh_time_embed": (INT, [C.POINTER(Denoiser), VP, VP, INT, VP, C.c_size_t, VP]),
     "mh_denoiser_forward": (INT, [C.POINTER(Denoiser), VP, VP, VP, VP, INT, INT, VP, C.c_size_t, VP]),

@@ -551,11 +551,16 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(const float* __restrict__
 // V^T arrives in the "P-operand" key order (mh_gemm_qkv_vtperm): within every 16 keys the two middle groups of
 // four are swapped, which is the order the S^T accumulator registers hold the probabilities in, so a stage
 // is a straight 16-byte-granular copy (source-side XOR swizzle) and P feeds the P.V MFMA without a shuffle.
-template <int DH, int NW = 16, int SK = 256>
+// DROP (training): attention-probability dropout (HF BertSelfAttention: softmax -> dropout -> . V).  The keep flags of the
+// wave's 32 x 32 S^T sub-tile come from Philox (drop_keep_attn) and are written to `keep_bits` ([B nh][ceil(L/32)][32 ceil(L/32)],
+// word = key, bit = query % 32) for the backward kernels - or, with bits_in, are read from it (mask injection for parity tests).
+// The softmax normaliser runs over the un-dropped probabilities; 1 / (1 - p) is folded into the final 1 / l.
+template <int DH, int NW = 16, int SK = 256, bool DROP = false>
 __global__ __launch_bounds__(64 * NW) void attn_stream_bf16_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K,
                                                                 const bf16* __restrict__ VT, bf16* __restrict__ ctx,
                                                                 int64_t ld_ctx, int L, int nh, int nbh, float scale_log2e,
-                                                                int ctx_panel, float* __restrict__ lse2, int64_t qsB, int64_t qsH, int64_t qld) {
+                                                                int ctx_panel, float* __restrict__ lse2, int64_t qsB, int64_t qsH, int64_t qld,
+                                                                const DropArgs drop, uint32_t* __restrict__ keep_bits, int bits_in) {
   // NW waves (one 32-query tile each), SK keys per stage.  16 x 256 fills a CU (128 KiB LDS, four waves per SIMD); 8 x 128
   // leaves half of the CU's registers and LDS for a GEMM block of the other graph branch
   constexpr int CH = DH / 8, RPB = 128 / DH, KROWB = DH * 2;
@@ -693,6 +698,27 @@ __global__ __launch_bounds__(64 * NW) void attn_stream_bf16_kernel(const bf16* _
             ps4[r & 3] += p;
           }
         l_run += (ps4[0] + ps4[1]) + (ps4[2] + ps4[3]);
+        if constexpr (DROP) {
+          const int nb32 = (L + 31) >> 5;
+#pragma unroll
+          for (int kt = 0; kt < 2; ++kt) {
+            if (32 * kt < tile_keys) {                                     // (wave-uniform)
+              const int kb = (st * SK + t * 64 + 32 * kt) >> 5;
+              uint32_t* words = keep_bits + (((int64_t)bh * nb32 + (q0 >> 5)) * nb32 + kb) * 32;
+              uint32_t km;
+              if (bits_in) {
+                km = drop_load_tile(words, lq, h);
+              } else {
+                const int qc = q0 + lq < L ? q0 + lq : L - 1;
+                km = drop_keep_attn(drop, bh, L, nb32, qc, kb, h);
+                const uint32_t w = drop_pack_tile(km, lane);
+                if (lane < 32) words[lane] = w;
+              }
+#pragma unroll
+              for (int r = 0; r < 16; ++r) s[kt][r] = (km >> r) & 1u ? s[kt][r] : 0.f;
+            }
+          }
+        }
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -710,7 +736,7 @@ __global__ __launch_bounds__(64 * NW) void attn_stream_bf16_kernel(const bf16* _
       }
       if (st == nst - 1) {   // last stage of this (batch, head): normalise and write the context rows
         const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-        const float inv = 1.0f / l_tot;
+        const float inv = (DROP ? drop.rscale : 1.0f) / l_tot;
         const int qr = q0 + lq;
         if (qr < L) {
           const int b = bh / nh, head = bh % nh;
@@ -813,9 +839,27 @@ extern "C" int mh_attention_stream_fwd_lse(const void* q, const void* k, const v
                                     stream);
 }
 
+int mh_drop_args(const mh_dropout* d, DropArgs* out);
+extern "C" int mh_attention_stream_fwd_drop(const void* q, const void* k, const void* vt_perm, void* ctx, int64_t ld_ctx, int ctx_panel,
+                                            int B, int L, int nh, int dh, float scale, float* lse2, int64_t qsB, int64_t qsH,
+                                            int64_t qld, const mh_dropout* drop, uint32_t* keep_bits, int bits_in, mh_stream_t stream);
+
 extern "C" int mh_attention_stream_fwd_ex(const void* q, const void* k, const void* vt_perm, void* ctx, int64_t ld_ctx, int ctx_panel,
                                           int B, int L, int nh, int dh, float scale, float* lse2, int64_t qsB, int64_t qsH,
                                           int64_t qld, mh_stream_t stream) {
+  return mh_attention_stream_fwd_drop(q, k, vt_perm, ctx, ld_ctx, ctx_panel, B, L, nh, dh, scale, lse2, qsB, qsH, qld, nullptr, nullptr, 0, stream);
+}
+
+// The streaming forward with attention-probability dropout: drop->p > 0 needs `keep_bits` (mh_dropout_bits_words(B nh, L) words):
+// written by the kernel (bits_in = 0: Philox, the same bits mh_dropout_bits produces) or read from it (bits_in = 1).
+extern "C" int mh_attention_stream_fwd_drop(const void* q, const void* k, const void* vt_perm, void* ctx, int64_t ld_ctx, int ctx_panel,
+                                            int B, int L, int nh, int dh, float scale, float* lse2, int64_t qsB, int64_t qsH,
+                                            int64_t qld, const mh_dropout* drop, uint32_t* keep_bits, int bits_in, mh_stream_t stream) {
+  DropArgs da;
+  int rcd = mh_drop_args(drop, &da);
+  if (rcd) return rcd;
+  const bool dropping = da.thr != 0;
+  MH_CHECK_ARG(!dropping || keep_bits, "attention_stream: dropout needs the keep_bits tensor");
   MH_CHECK_ARG(qld % 8 == 0 && qsH % 8 == 0 && qsB % 8 == 0 && qld >= dh, "attention_stream: q/k strides must be multiples of 8 elements");
   MH_CHECK_ARG(q && k && vt_perm && ctx, "attention_stream: null pointer");
   MH_CHECK_ARG(B > 0 && nh > 0 && mh_attention_stream_supported(L, dh),
@@ -837,11 +881,12 @@ extern "C" int mh_attention_stream_fwd_ex(const void* q, const void* k, const vo
       MH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
       attr_set = true;
     }
-    MH_LAUNCH(kern, grid, block, bytes, s, Q, K, V, (bf16*)ctx, ld_ctx, L, nh, nbh, sl2, ctx_panel, lse2, qsB, qsH, qld);
+    MH_LAUNCH(kern, grid, block, bytes, s, Q, K, V, (bf16*)ctx, ld_ctx, L, nh, nbh, sl2, ctx_panel, lse2, qsB, qsH, qld, da, keep_bits, bits_in);
     return MH_OK;
   };
   int rc;
-  if (dh == 64) rc = small ? go(&attn_stream_bf16_kernel<64, 8, 128>, 4 * 128 * 64 * 2) : go(&attn_stream_bf16_kernel<64, 16, 256>, 4 * 256 * 64 * 2);
+  if (dropping) rc = dh == 64 ? go(&attn_stream_bf16_kernel<64, 16, 256, true>, 4 * 256 * 64 * 2) : go(&attn_stream_bf16_kernel<32, 16, 256, true>, 4 * 256 * 32 * 2);
+  else if (dh == 64) rc = small ? go(&attn_stream_bf16_kernel<64, 8, 128>, 4 * 128 * 64 * 2) : go(&attn_stream_bf16_kernel<64, 16, 256>, 4 * 256 * 64 * 2);
   else rc = small ? go(&attn_stream_bf16_kernel<32, 8, 256>, 4 * 256 * 32 * 2) : go(&attn_stream_bf16_kernel<32, 16, 256>, 4 * 256 * 32 * 2);
   if (rc) return rc;
   MH_CHECK_LAUNCH();

@@ -67,14 +67,14 @@ __device__ __forceinline__ bf16x8 cvt8(const f32x16& v, int off) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
-template <int DH>
+template <int DH, bool DROP>
 __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K,
                                                           const bf16* __restrict__ V, const bf16* __restrict__ KT,
                                                           const bf16* __restrict__ dO, const bf16* __restrict__ O,
                                                           const float* __restrict__ lse2, float* __restrict__ Dv,
                                                           bf16* __restrict__ dQ, int64_t ld_dq,
                                                           int L, int nh, int nbh, float scale, float scale_log2e, RowLayout lq_,
-                                                          RowLayout lo_) {
+                                                          RowLayout lo_, const uint32_t* __restrict__ keep_bits, float rscale) {
   constexpr int NW = 8;
   constexpr int KS = DH / 16, DT = DH / 32;
   constexpr int ST = SKB * DH * 2;                 // bytes of one operand stage (row layout and transposed alike)
@@ -160,13 +160,23 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const bf16* __restrict
         }
       }
 #pragma unroll
-      for (int kt = 0; kt < 2; ++kt)
+      for (int kt = 0; kt < 2; ++kt) {
+        uint32_t km = 0xffffu;
+        if constexpr (DROP) {   // dP = dP_drop o keep / (1 - p): the forward's keep bits of this S^T sub-tile
+          if (32 * kt < tile_keys) {
+            const int nb32 = (L + 31) >> 5, kb = (st * SKB + t * 64 + 32 * kt) >> 5;
+            km = drop_load_tile(keep_bits + (((int64_t)bh * nb32 + (q0 >> 5)) * nb32 + kb) * 32, lq, h);
+          }
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           float p = __builtin_amdgcn_exp2f(s[kt][r] * scale_log2e - lse_q);
           if (tile_keys < 64 && kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h >= tile_keys) p = 0.f;   // key past the sequence end
-          s[kt][r] = p * (dp[kt][r] - D_q);                      // dS^T (the 1/sqrt(dh) factor is applied to dQ at the end)
+          float dpv = dp[kt][r];
+          if constexpr (DROP) dpv = (km >> r) & 1u ? dpv * rscale : 0.f;
+          s[kt][r] = p * (dpv - D_q);                            // dS^T (the 1/sqrt(dh) factor is applied to dQ at the end)
         }
+      }
 #pragma unroll
       for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -198,14 +208,14 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const bf16* __restrict
 }
 
 // ---------------------------------------------------------------------------------------------------------
-template <int DH>
+template <int DH, bool DROP>
 __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K,
                                                            const bf16* __restrict__ V, const bf16* __restrict__ QT,
                                                            const bf16* __restrict__ dO, const bf16* __restrict__ dOT,
                                                            const float* __restrict__ lse2, const float* __restrict__ Dv,
                                                            bf16* __restrict__ dK, bf16* __restrict__ dV, int64_t ld_d, int L,
                                                            int nh, int nbh, float scale, float scale_log2e, RowLayout lq_,
-                                                           RowLayout lo_) {
+                                                           RowLayout lo_, const uint32_t* __restrict__ keep_bits, float rscale) {
   constexpr int NW = 8;
   constexpr int KS = DH / 16, DT = DH / 32;
   constexpr int ST = SKB * DH * 2;
@@ -278,6 +288,13 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const bf16* __restric
       for (int qt = 0; qt < 2; ++qt) {
         const int R = t * 64 + 32 * qt + lq;
         f32x16 s, dp;
+        uint32_t kw = 0xffffffffu;     // keep bits of this lane's key for the 32 queries of the tile (bit = query % 32)
+        if constexpr (DROP) {
+          const int nb32 = (L + 31) >> 5;
+          int qb = (st * SKB + t * 64 + 32 * qt) >> 5; if (qb >= nb32) qb = nb32 - 1;
+          const int kc = k0 + lq < L ? k0 + lq : L - 1;
+          kw = keep_bits[((int64_t)bh * nb32 + qb) * nb32 * 32 + kc];
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
@@ -295,8 +312,14 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const bf16* __restric
           for (int e = 0; e < 4; ++e) {
             float p = __builtin_amdgcn_exp2f(s[rg * 4 + e] * scale_log2e - ls[e]);
             if (qi + e >= st_q) p = 0.f;                                  // query past the sequence end
-            s[rg * 4 + e] = p;
-            dp[rg * 4 + e] = p * (dp[rg * 4 + e] - dd[e]);
+            float dpv = dp[rg * 4 + e], pd = p;
+            if constexpr (DROP) {                                         // P_drop feeds dV; dP = dP_drop o keep / (1 - p)
+              const bool keep = (kw >> (8 * rg + 4 * h + e)) & 1u;
+              pd = keep ? p * rscale : 0.f;
+              dpv = keep ? dpv * rscale : 0.f;
+            }
+            s[rg * 4 + e] = pd;
+            dp[rg * 4 + e] = p * (dpv - dd[e]);
           }
         }
 #pragma unroll
@@ -354,16 +377,16 @@ __global__ void attn_bwd_rowdot_kernel(const bf16* __restrict__ dctx, const bf16
   }
 }
 
-template <int DH>
+template <int DH, bool DROP>
 int launch_bwd(const bf16* q, const bf16* k, const bf16* v, const bf16* qT, const bf16* kT, const bf16* dO, const bf16* dOT, const bf16* o,
                const float* lse2, float* Dv, bf16* dq, bf16* dk, bf16* dv, int64_t ld, int B, int L, int nh, float scale,
-               RowLayout lqkv, RowLayout ldo, hipStream_t s) {
+               RowLayout lqkv, RowLayout ldo, const uint32_t* keep_bits, float rscale, hipStream_t s) {
   constexpr int ST = SKB * DH * 2;
   constexpr int bytes_dq = 2 * 3 * ST, bytes_dkv = 2 * (4 * ST + 1024);
   static bool attr_set = false;
   if (!attr_set) {
-    MH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_kernel<DH>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes_dq));
-    MH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkv_kernel<DH>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes_dkv));
+    MH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_kernel<DH, DROP>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes_dq));
+    MH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkv_kernel<DH, DROP>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes_dkv));
     attr_set = true;
   }
   int dev = 0, cus = 256;
@@ -371,9 +394,11 @@ int launch_bwd(const bf16* q, const bf16* k, const bf16* v, const bf16* qT, cons
   const int nbh = B * nh, nitems = nbh * ((L + 255) / 256);
   const dim3 grid((unsigned)(nitems < cus ? nitems : cus)), block(512);
   const float sl2 = scale * 1.4426950408889634f;
-  MH_LAUNCH((attn_bwd_dq_kernel<DH>), grid, block, bytes_dq, s, q, k, v, kT, dO, o, lse2, Dv, dq, ld, L, nh, nbh, scale, sl2, lqkv, ldo);
+  MH_LAUNCH((attn_bwd_dq_kernel<DH, DROP>), grid, block, bytes_dq, s, q, k, v, kT, dO, o, lse2, Dv, dq, ld, L, nh, nbh, scale, sl2, lqkv, ldo,
+            keep_bits, rscale);
   MH_CHECK_LAUNCH();
-  MH_LAUNCH((attn_bwd_dkv_kernel<DH>), grid, block, bytes_dkv, s, q, k, v, qT, dO, dOT, lse2, Dv, dk, dv, ld, L, nh, nbh, scale, sl2, lqkv, ldo);
+  MH_LAUNCH((attn_bwd_dkv_kernel<DH, DROP>), grid, block, bytes_dkv, s, q, k, v, qT, dO, dOT, lse2, Dv, dk, dv, ld, L, nh, nbh, scale, sl2, lqkv, ldo,
+            keep_bits, rscale);
   MH_CHECK_LAUNCH();
   return MH_OK;
 }
@@ -406,10 +431,27 @@ extern "C" int mh_attention_stream_bwd(const void* q, const void* k, const void*
                                     sB, sH, dh, stream);
 }
 
+extern "C" int mh_attention_stream_bwd_drop(const void* q, const void* k, const void* v, const void* qT_perm, const void* kT_perm,
+                                            const void* dO, const void* dOT_perm, const void* o, const float* lse2, float* D, void* dq, void* dk,
+                                            void* dv, int64_t ld_d, int B, int L, int nh, int dh, float scale, int64_t qsB, int64_t qsH,
+                                            int64_t qld, int64_t osB, int64_t osH, int64_t old_, const uint32_t* keep_bits, float drop_p,
+                                            mh_stream_t stream);
+
 extern "C" int mh_attention_stream_bwd_ex(const void* q, const void* k, const void* v, const void* qT_perm, const void* kT_perm,
                                           const void* dO, const void* dOT_perm, const void* o, const float* lse2, float* D, void* dq, void* dk,
                                           void* dv, int64_t ld_d, int B, int L, int nh, int dh, float scale, int64_t qsB, int64_t qsH,
                                           int64_t qld, int64_t osB, int64_t osH, int64_t old_, mh_stream_t stream) {
+  return mh_attention_stream_bwd_drop(q, k, v, qT_perm, kT_perm, dO, dOT_perm, o, lse2, D, dq, dk, dv, ld_d, B, L, nh, dh, scale, qsB, qsH, qld,
+                                      osB, osH, old_, nullptr, 0.f, stream);
+}
+
+// Backward of the streaming attention whose forward dropped probabilities with rate drop_p: `keep_bits` is the bit tensor that
+// forward wrote (or was given); null / drop_p == 0: no dropout.
+extern "C" int mh_attention_stream_bwd_drop(const void* q, const void* k, const void* v, const void* qT_perm, const void* kT_perm,
+                                            const void* dO, const void* dOT_perm, const void* o, const float* lse2, float* D, void* dq, void* dk,
+                                            void* dv, int64_t ld_d, int B, int L, int nh, int dh, float scale, int64_t qsB, int64_t qsH,
+                                            int64_t qld, int64_t osB, int64_t osH, int64_t old_, const uint32_t* keep_bits, float drop_p,
+                                            mh_stream_t stream) {
   MH_CHECK_ARG(qsB % 8 == 0 && qsH % 8 == 0 && qld % 8 == 0 && osB % 8 == 0 && osH % 8 == 0 && old_ % 8 == 0 && qld >= dh && old_ >= dh,
                "attention_stream_bwd: row strides must be multiples of 8 elements");
   const RowLayout lqkv{qsB, qsH, qld}, ldo{osB, osH, old_};
@@ -417,10 +459,12 @@ extern "C" int mh_attention_stream_bwd_ex(const void* q, const void* k, const vo
   MH_CHECK_ARG(B > 0 && nh > 0 && mh_attention_stream_bwd_supported(L, dh),
                "attention_stream_bwd: needs seq_len %% 16 == 0, seq_len >= 512 and head dim 32 or 64 (got L=%d dh=%d)", L, dh);
   MH_CHECK_ARG(ld_d % 4 == 0, "attention_stream_bwd: ld_d must be a multiple of 4");
+  MH_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || keep_bits), "attention_stream_bwd: dropout needs keep_bits and p in [0, 1)");
   hipStream_t s = (hipStream_t)stream;
-  if (dh == 64)
-    return launch_bwd<64>((const bf16*)q, (const bf16*)k, (const bf16*)v, (const bf16*)qT_perm, (const bf16*)kT_perm, (const bf16*)dO,
-                          (const bf16*)dOT_perm, (const bf16*)o, lse2, D, (bf16*)dq, (bf16*)dk, (bf16*)dv, ld_d, B, L, nh, scale, lqkv, ldo, s);
-  return launch_bwd<32>((const bf16*)q, (const bf16*)k, (const bf16*)v, (const bf16*)qT_perm, (const bf16*)kT_perm, (const bf16*)dO,
-                        (const bf16*)dOT_perm, (const bf16*)o, lse2, D, (bf16*)dq, (bf16*)dk, (bf16*)dv, ld_d, B, L, nh, scale, lqkv, ldo, s);
+  const float rs = 1.0f / (1.0f - drop_p);
+#define MH_BWD_ARGS (const bf16*)q, (const bf16*)k, (const bf16*)v, (const bf16*)qT_perm, (const bf16*)kT_perm, (const bf16*)dO, \
+                    (const bf16*)dOT_perm, (const bf16*)o, lse2, D, (bf16*)dq, (bf16*)dk, (bf16*)dv, ld_d, B, L, nh, scale, lqkv, ldo, keep_bits, rs, s
+  if (drop_p > 0.f) return dh == 64 ? launch_bwd<64, true>(MH_BWD_ARGS) : launch_bwd<32, true>(MH_BWD_ARGS);
+  return dh == 64 ? launch_bwd<64, false>(MH_BWD_ARGS) : launch_bwd<32, false>(MH_BWD_ARGS);
+#undef MH_BWD_ARGS
 }

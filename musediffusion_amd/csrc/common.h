@@ -130,4 +130,102 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
   return 0.5f * (1.0f + copysignf(erf_abs, x)) + x * 0.3989422804014327f * e;
 }
 
+// ---- Philox4x32 (counter-based RNG): 10 rounds for the sampling noise (mh_trunc_normal), 7 rounds (the fewest that
+// pass BigCrush, Salmon et al. SC'11) for train-mode dropout masks, where one call pays for 8 elements.
+template <int ROUNDS>
+__device__ __forceinline__ void mh_philox(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+  for (int r = 0; r < ROUNDS; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+    c[1] = (uint32_t)p1; c[3] = (uint32_t)p0; c[0] = n0; c[2] = n2;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+}
+
+// Train-mode dropout (models/network.py:149; HF BertSelfOutput / BertOutput / BertSelfAttention dropouts).  A keep
+// decision takes 16 random bits: keep <=> u16 >= thr, thr = round(p * 65536), so the drop rate is p to 2^-17.
+// Device-side view of mh_dropout (include/musehip.h): all by value, usable inside kernel argument structs.
+struct DropArgs {
+  uint32_t thr;            // 0: dropout off
+  float rscale;            // 1 / (1 - p)
+  uint32_t seed_lo, seed_hi, off_lo, off_hi;
+  const uint8_t* mask;     // test-only: explicit keep flags per element (row-major, dense sites), overrides Philox
+};
+__device__ __forceinline__ uint32_t drop_thr(float p) { return (uint32_t)(p * 65536.0f + 0.5f); }
+// dense sites: element e = row * cols + col; one call serves the 8 consecutive elements of group e >> 3 (cols % 8 == 0)
+// returns bit i set <=> element 8 g + i is KEPT
+__device__ __forceinline__ uint32_t drop_keep8(const DropArgs& d, uint64_t group) {
+  uint32_t c[4] = {(uint32_t)group, (uint32_t)(group >> 32), d.off_lo, d.off_hi};
+  mh_philox<7>(c, d.seed_lo, d.seed_hi);
+  uint32_t m = 0;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    m |= ((c[w] & 0xffffu) >= d.thr ? 1u : 0u) << (2 * w);
+    m |= ((c[w] >> 16) >= d.thr ? 1u : 0u) << (2 * w + 1);
+  }
+  return m;
+}
+// same decision for 8 consecutive elements starting at element index e0 (e0 % 8 == 0), from the explicit mask or Philox
+__device__ __forceinline__ uint32_t drop_keep8_at(const DropArgs& d, uint64_t e0) {
+  if (d.mask) {
+    const uint64_t raw = *reinterpret_cast<const uint64_t*>(d.mask + e0);
+    uint32_t m = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) m |= (((raw >> (8 * i)) & 0xff) != 0 ? 1u : 0u) << i;
+    return m;
+  }
+  return drop_keep8(d, e0 >> 3);
+}
+// attention probabilities: the keep flags of one lane of an S^T tile (query q, lane half h) for the 32-key block kb:
+// two calls (a = 0, 1) cover keys 16 a + 8 jj + 4 h + e (jj 0..1, e 0..3) = registers r = 8 a + 4 jj + e of the 32x32x16
+// accumulator.  Returns bit r set <=> P[q][32 kb + key(r)] is KEPT.  nkb = ceil(L / 32).
+__device__ __forceinline__ uint32_t drop_keep_attn(const DropArgs& d, int64_t bh, int L, int nkb, int q, int kb, int h) {
+  const uint64_t base = ((((uint64_t)bh * L + q) * nkb + kb) << 2) | (uint64_t)h;
+  uint32_t m = 0;
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+    const uint64_t idx = base | ((uint64_t)a << 1);
+    uint32_t c[4] = {(uint32_t)idx, (uint32_t)(idx >> 32), d.off_lo, d.off_hi};
+    mh_philox<7>(c, d.seed_lo, d.seed_hi);
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      m |= ((c[w] & 0xffffu) >= d.thr ? 1u : 0u) << (8 * a + 2 * w);
+      m |= ((c[w] >> 16) >= d.thr ? 1u : 0u) << (8 * a + 2 * w + 1);
+    }
+  }
+  return m;
+}
+// Pack a wave's keep flags of one 32-query x 32-key S^T tile into the bit tensor: lane (lq, h) holds flags `m` (bit r <->
+// key (r & 3) + 8 (r >> 2) + 4 h, query lq).  Word layout: bits[key], bit = query (lq).  Returns, in lanes 0..31, the word
+// of key = lane.
+__device__ __forceinline__ uint32_t drop_pack_tile(uint32_t m, int lane) {
+  const int n = lane & 31;                       // the key whose word this lane ends up with
+  const int my_r = ((n >> 3) << 2) | (n & 3), my_hh = (n >> 2) & 1;
+  uint32_t w = 0;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const uint64_t b = __builtin_amdgcn_ballot_w64(((m >> r) & 1u) != 0);
+    if (my_r == r) w = my_hh ? (uint32_t)(b >> 32) : (uint32_t)b;
+  }
+  return w;
+}
+// Read the flags of one lane of an S^T tile back from the bit tensor: words of keys 8 j + 4 h + e at `tile_words` (32 words,
+// 16-byte aligned); bit lq of each.
+__device__ __forceinline__ uint32_t drop_load_tile(const uint32_t* tile_words, int lq, int h) {
+  uint32_t m = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const uint4 v = *reinterpret_cast<const uint4*>(tile_words + 8 * j + 4 * h);
+    m |= ((v.x >> lq) & 1u) << (4 * j);
+    m |= ((v.y >> lq) & 1u) << (4 * j + 1);
+    m |= ((v.z >> lq) & 1u) << (4 * j + 2);
+    m |= ((v.w >> lq) & 1u) << (4 * j + 3);
+  }
+  return m;
+}
+
 static inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

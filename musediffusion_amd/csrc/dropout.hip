@@ -1,0 +1,130 @@
+// Train-mode dropout outside the fused kernels (reference: nn.Dropout at models/network.py:76, :149 and the HF BertEncoder's
+// hidden / attention-probability dropouts, both 0.1 from the bert-base config, network.py:44-46).
+//   mh_dropout_fwd         y = x o keep / (1 - p) over a dense [rows, cols] activation: the embedding-LayerNorm site forward,
+//                          and the BACKWARD of every dense site (the mask is re-created from (seed, offset), never stored)
+//   mh_dropout_bits        the attention-probability keep mask as a bit tensor [B nh][ceil(L/32)][32 ceil(L/32)] (word = key,
+//                          bit = query % 32), exactly the bits the fused forward (attention.hip) writes
+//   mh_dropout_bits_apply  P o keep / (1 - p) on a materialised [B nh, L, ldp] probability / gradient tensor (fp32 parity mode
+//                          and shapes the streaming kernels do not serve)
+// The Philox counter conventions live in common.h (drop_keep8 / drop_keep_attn).
+#include "common.h"
+
+int mh_drop_args(const mh_dropout* d, DropArgs* out) {
+  DropArgs a{};
+  if (d && d->p > 0.f) {
+    MH_CHECK_ARG(d->p < 1.f, "dropout: p=%g must be in [0, 1)", (double)d->p);
+    a.thr = (uint32_t)(d->p * 65536.0f + 0.5f);
+    a.rscale = 1.0f / (1.0f - d->p);
+    a.seed_lo = (uint32_t)d->seed; a.seed_hi = (uint32_t)(d->seed >> 32);
+    a.off_lo = (uint32_t)d->offset; a.off_hi = (uint32_t)(d->offset >> 32);
+    a.mask = d->mask;
+  } else {
+    a.rscale = 1.0f;
+  }
+  *out = a;
+  return MH_OK;
+}
+
+namespace {
+
+template <typename T>
+__global__ void dropout_fwd_kernel(const T* __restrict__ x, int64_t ldx, T* __restrict__ out, int64_t ldo, int64_t rows, int cols,
+                                   const DropArgs d) {
+  const int gpr = cols >> 3;                                  // 8-element groups per row
+  const int64_t total = rows * gpr;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = i / gpr;
+    const int col = (int)(i - row * gpr) << 3;
+    float v[8];
+    load8(x + row * ldx + col, v);
+    const uint32_t m = drop_keep8_at(d, (uint64_t)row * cols + col);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (m >> e) & 1u ? v[e] * d.rscale : 0.f;
+    store8(out + row * ldo + col, v);
+  }
+}
+
+// one wave per (bh, 32-query block, 32-key block): the S^T tile of the fused kernels
+__global__ __launch_bounds__(256) void dropout_bits_kernel(uint32_t* __restrict__ bits, int64_t ntiles, int L, int nqb, int nkb,
+                                                           const DropArgs d) {
+  const int lane = threadIdx.x & 63, lq = lane & 31, h = lane >> 5;
+  const int64_t w0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  for (int64_t tile = w0; tile < ntiles; tile += (int64_t)gridDim.x * 4) {
+    const int kb = (int)(tile % nkb);
+    const int qb = (int)((tile / nkb) % nqb);
+    const int64_t bh = tile / ((int64_t)nkb * nqb);
+    int q = qb * 32 + lq; if (q >= L) q = L - 1;
+    const uint32_t m = drop_keep_attn(d, bh, L, nkb, q, kb, h);
+    const uint32_t w = drop_pack_tile(m, lane);
+    if (lane < 32) bits[((bh * nqb + qb) * nkb + kb) * 32 + lane] = w;
+  }
+}
+
+template <typename T>
+__global__ void dropout_bits_apply_kernel(T* __restrict__ P, int64_t ldp, const uint32_t* __restrict__ bits, int64_t BH, int L, int nqb,
+                                          int nkb, float rscale) {
+  const int64_t total = BH * L * L;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int k = (int)(i % L);
+    const int q = (int)((i / L) % L);
+    const int64_t bh = i / ((int64_t)L * L);
+    const uint32_t w = bits[((bh * nqb + (q >> 5)) * nkb) * 32 + k];
+    T* p = P + (bh * L + q) * ldp + k;
+    *p = (w >> (q & 31)) & 1u ? from_f32<T>(to_f32(*p) * rscale) : from_f32<T>(0.f);
+  }
+}
+
+inline int ew_grid(int64_t n) {
+  int64_t b = (n + 255) / 256;
+  return (int)(b < 1 ? 1 : (b > 65535 * 4 ? 65535 * 4 : b));
+}
+
+}  // namespace
+
+extern "C" size_t mh_dropout_bits_words(int BH, int L) {
+  const size_t nb = (size_t)((L + 31) / 32);
+  return (size_t)BH * nb * nb * 32;
+}
+
+extern "C" int mh_dropout_fwd(const void* x, int64_t ldx, void* out, int64_t ldo, int64_t rows, int cols, int dtype,
+                              const mh_dropout* drop, mh_stream_t stream) {
+  MH_CHECK_ARG(x && out && rows > 0 && cols > 0 && cols % 8 == 0 && ldx >= cols && ldo >= cols && ldx % 8 == 0 && ldo % 8 == 0,
+               "dropout_fwd: bad arguments (cols and leading dimensions must be multiples of 8)");
+  DropArgs d;
+  int rc = mh_drop_args(drop, &d);
+  if (rc) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  const int grid = ew_grid(rows * (cols / 8));
+  if (dtype == MH_BF16) MH_LAUNCH((dropout_fwd_kernel<bf16>), dim3(grid), dim3(256), 0, s, (const bf16*)x, ldx, (bf16*)out, ldo, rows, cols, d);
+  else if (dtype == MH_F32) MH_LAUNCH((dropout_fwd_kernel<float>), dim3(grid), dim3(256), 0, s, (const float*)x, ldx, (float*)out, ldo, rows, cols, d);
+  else { mh_set_error("dropout_fwd: unknown dtype %d", dtype); return MH_ERR_INVALID; }
+  MH_CHECK_LAUNCH();
+  return MH_OK;
+}
+
+extern "C" int mh_dropout_bits(uint32_t* keep_bits, int BH, int L, const mh_dropout* drop, mh_stream_t stream) {
+  MH_CHECK_ARG(keep_bits && BH > 0 && L > 0 && drop && drop->p > 0.f && !drop->mask, "dropout_bits: bad arguments");
+  DropArgs d;
+  int rc = mh_drop_args(drop, &d);
+  if (rc) return rc;
+  const int nb = (L + 31) / 32;
+  const int64_t ntiles = (int64_t)BH * nb * nb;
+  const int grid = (int)((ntiles + 3) / 4 < 262140 ? (ntiles + 3) / 4 : 262140);
+  MH_LAUNCH(dropout_bits_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, keep_bits, ntiles, L, nb, nb, d);
+  MH_CHECK_LAUNCH();
+  return MH_OK;
+}
+
+extern "C" int mh_dropout_bits_apply(void* P, int64_t ldp, const uint32_t* keep_bits, int BH, int L, float p, int dtype,
+                                     mh_stream_t stream) {
+  MH_CHECK_ARG(P && keep_bits && BH > 0 && L > 0 && ldp >= L && p >= 0.f && p < 1.f, "dropout_bits_apply: bad arguments");
+  const int nb = (L + 31) / 32;
+  const float rs = 1.0f / (1.0f - p);
+  hipStream_t s = (hipStream_t)stream;
+  const int grid = ew_grid((int64_t)BH * L * L);
+  if (dtype == MH_BF16) MH_LAUNCH((dropout_bits_apply_kernel<bf16>), dim3(grid), dim3(256), 0, s, (bf16*)P, ldp, keep_bits, (int64_t)BH, L, nb, nb, rs);
+  else if (dtype == MH_F32) MH_LAUNCH((dropout_bits_apply_kernel<float>), dim3(grid), dim3(256), 0, s, (float*)P, ldp, keep_bits, (int64_t)BH, L, nb, nb, rs);
+  else { mh_set_error("dropout_bits_apply: unknown dtype %d", dtype); return MH_ERR_INVALID; }
+  MH_CHECK_LAUNCH();
+  return MH_OK;
+}

@@ -157,23 +157,6 @@ __global__ void step_epilogue_kernel(const float* __restrict__ model_out, const 
 }
 
 // ---------------------------------------------------------------- Philox4x32-10 truncated normal
-__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
-  const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
-  const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
-  const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
-  const uint32_t n1 = (uint32_t)p1;
-  const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
-  const uint32_t n3 = (uint32_t)p0;
-  c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
-}
-__device__ __forceinline__ void philox10(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
-#pragma unroll
-  for (int r = 0; r < 10; ++r) {
-    philox_round(c, k0, k1);
-    k0 += 0x9E3779B9u;
-    k1 += 0xBB67AE85u;
-  }
-}
 __device__ __forceinline__ float u01(uint32_t r) { return ((float)(r >> 8) + 0.5f) * (1.0f / 16777216.0f); }
 
 __global__ void trunc_normal_kernel(float* __restrict__ out, int64_t n, float bound, uint32_t seed_lo,
@@ -184,7 +167,7 @@ __global__ void trunc_normal_kernel(float* __restrict__ out, int64_t n, float bo
     bool done = false;
     for (uint32_t attempt = 0; attempt < 64 && !done; ++attempt) {
       uint32_t c[4] = {(uint32_t)i, (uint32_t)(i >> 32), step, (stream_id << 8) | attempt};
-      philox10(c, seed_lo, seed_hi);
+      mh_philox<10>(c, seed_lo, seed_hi);
       const float r0 = sqrtf(-2.0f * logf(u01(c[0]))), r1 = sqrtf(-2.0f * logf(u01(c[2])));
       const float a0 = 6.283185307179586f * u01(c[1]), a1 = 6.283185307179586f * u01(c[3]);
       const float cand[4] = {r0 * cosf(a0), r0 * sinf(a0), r1 * cosf(a1), r1 * sinf(a1)};

@@ -42,6 +42,7 @@ struct GemmArgs {
   int dbg;  // timing-only ablation bits (mh_gemm_set_debug): 1 no DMA, 2 no MFMA, 4 no stores
   int ntiles;    // persistent big-tile launch: ntiles output tiles walked by gridDim.x blocks
   int vt_perm;   // QKV scatter: V^T keys in the P-operand order of mh_attention_stream_fwd (middle groups of 4 swapped per 16)
+  DropArgs drop; // EPI 0: train-mode dropout of (A W^T + bias) before the residual is added (thr == 0: off)
 };
 
 template <typename T> struct Tile;
@@ -305,6 +306,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
           if (g.act != MH_ACT_NONE) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = apply_act<T>(v[e], g.act);
+          }
+          if (g.drop.thr) {   // HF BertSelfOutput / BertOutput: dense -> dropout -> (+ input) (N % 8 == 0: checked by the entry point)
+            const uint32_t km = drop_keep8_at(g.drop, (uint64_t)row * g.N + col);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (km >> e) & 1u ? v[e] * g.drop.rscale : 0.f;
           }
           if (nv == 8 && vec_ok) {
             if (res) {
@@ -831,6 +837,11 @@ __global__ __launch_bounds__(C::THREADS, C::STAGE * C::NST <= 80 * 1024 ? 2 : 1)
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = apply_act<bf16>(v[e], ACT);
               }
+              if constexpr ((DBG & 64) != 0) {   // train-mode dropout of the dense output, before the residual
+                const uint32_t km = drop_keep8_at(g.drop, (uint64_t)row * g.N + col);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (km >> e) & 1u ? v[e] * g.drop.rscale : 0.f;
+              }
               if (res) {
                 const int64_t ro = g.r_panel ? ((int64_t)(col >> 5) * g.ldr + row) * 32 + (col & 31) : row * g.ldr + col;
                 float rv[8];
@@ -913,7 +924,10 @@ int launch_big(const GemmArgs& g0, hipStream_t s, int batch) {
         else MH_LAUNCH((gemm_big_kernel<C, 0, MH_ACT_GELU_ERF>), grid, block, 0, s, g);
         break;
       case MH_ACT_SILU: MH_LAUNCH((gemm_big_kernel<C, 0, MH_ACT_SILU>), grid, block, 0, s, g); break;
-      default: MH_LAUNCH((gemm_big_kernel<C, 0, MH_ACT_NONE>), grid, block, 0, s, g); break;
+      default:
+        if (g.drop.thr) MH_LAUNCH((gemm_big_kernel<C, 0, MH_ACT_NONE, 64>), grid, block, 0, s, g);
+        else MH_LAUNCH((gemm_big_kernel<C, 0, MH_ACT_NONE>), grid, block, 0, s, g);
+        break;
     }
   }
   MH_CHECK_LAUNCH();
@@ -1044,6 +1058,26 @@ extern "C" int mh_gemm_bias_res_ln(const void* A, int64_t lda, int a_panel, cons
   // one block per CU: the ping-pong main loop pays here (-4.5% step time, tools/ab_step.py); bit 2 of the A/B mask = plain loop
   if (g_plain_stores & 4) return launch_big<CfgRow, 3>(g, s, 1);
   return launch_big<CfgRowPP, 3>(g, s, 1);
+}
+
+// out = dropout(A W^T + bias) + residual: the dense half of HF BertSelfOutput / BertOutput in train mode (the LayerNorm that
+// follows stays a separate kernel on the training path).  Row-major operands; N % 8 == 0.  The keep mask of element (row, col)
+// comes from Philox4x32-7 keyed by drop->seed at counter ((row N + col) / 8, drop->offset) - mh_dropout_fwd with the same
+// descriptor re-creates it for the backward - or from drop->mask (tests).
+int mh_drop_args(const mh_dropout* d, DropArgs* out);
+extern "C" int mh_gemm_bias_dropout_res(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, const void* residual,
+                                        int64_t ldr, void* out, int64_t ldo, int64_t M, int N, int K, int dtype, const mh_dropout* drop,
+                                        mh_stream_t stream) {
+  MH_CHECK_ARG(A && W && out, "gemm_bias_dropout_res: null pointer");
+  MH_CHECK_ARG(M > 0 && N > 0 && N % 8 == 0, "gemm_bias_dropout_res: bad problem M=%lld N=%d (N must be a multiple of 8)", (long long)M, N);
+  GemmArgs g{};
+  g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.bias = bias;
+  g.residual = residual; g.ldr = residual ? ldr : 8; g.out = out; g.ldo = ldo;
+  g.M = M; g.N = N; g.K = K; g.act = MH_ACT_NONE; g.dbg = 0;
+  int rc = mh_drop_args(drop, &g.drop);
+  if (rc) return rc;
+  MH_CHECK_ARG(ldo % 8 == 0 && (!residual || ldr % 8 == 0), "gemm_bias_dropout_res: ldo / ldr must be multiples of 8");
+  return launch<0>(g, dtype, (hipStream_t)stream);
 }
 
 // act(A W^T + bias) -> out AND A W^T + bias -> pre_out in one pass (bf16, row-major, big-tile shapes only): the forward of

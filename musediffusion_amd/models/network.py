@@ -78,15 +78,17 @@ class TransformerNetModel(nn.Module):
     :param hidden_t_dim: dims of time embedding.
     :param vocab_size: the size of vocabulary.
     :param seq_len: maximum sequence length (size of the learned position table).
-    :param dropout: accepted for signature parity; inference runs in eval mode (no dropout).
+    :param dropout: rate of the dropout after the embedding LayerNorm in train mode (network.py:76, :149).
     :param bert_hidden/bert_layers/bert_heads/bert_ffn: Transformer shape (default bert-base-uncased).
+    :param bert_hidden_dropout/bert_attention_dropout: the encoder's own train-mode dropouts; the reference leaves them at
+           bert-base's 0.1 / 0.1 whatever `dropout` is (network.py:44-46).  `model.eval()` turns all three off.
     :param compute_dtype: "fp32" (parity mode: fp32 storage + exact-fp32 MFMA) or "bf16"
                           (throughput mode: bf16 storage, bf16 MFMA, fp32 accumulation).
     """
 
     def __init__(self, input_dims, output_dims, hidden_t_dim, vocab_size, seq_len, dropout=0.1, logits_mode=1, *,
                  bert_hidden=768, bert_layers=12, bert_heads=12, bert_ffn=3072, layer_norm_eps=1e-12,
-                 compute_dtype="fp32"):
+                 bert_hidden_dropout=0.1, bert_attention_dropout=0.1, compute_dtype="fp32"):
         super().__init__()
         if input_dims != output_dims:
             raise ValueError("input_dims and output_dims must match (the reference always passes hidden_dim twice, "
@@ -103,6 +105,12 @@ class TransformerNetModel(nn.Module):
         self.seq_len = seq_len
         self.vocab_size = vocab_size
         self.compute_dtype = compute_dtype
+        # the reference's BertEncoder keeps bert-base's dropouts (0.1 / 0.1) whatever `dropout` is (network.py:44-46, :74)
+        self.bert_hidden_dropout = float(bert_hidden_dropout)
+        self.bert_attention_dropout = float(bert_attention_dropout)
+        self.dropout_masks = None          # tests: explicit keep masks per site (training._DropSites)
+        self._dropout_seed = None
+        self._dropout_calls = 0
 
         # construction order follows network.py:55-86 so that a seeded default init draws alike
         self.word_embedding = nn.Embedding(vocab_size, input_dims)
@@ -169,6 +177,20 @@ class TransformerNetModel(nn.Module):
             self._engine_key = key
             self._table_norm = None
         return self._engine
+
+    def dropout_seed(self):
+        """Philox key of this model's dropout masks: fixed at the first training forward from torch's seed (so `torch.manual_seed`
+        makes runs repeatable) and mixed with the rank, so data-parallel replicas drop different units like the reference's
+        per-process generators do."""
+        if self._dropout_seed is None:
+            import torch.distributed as dist
+            r = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+            self._dropout_seed = (int(torch.initial_seed()) * 0x9E3779B97F4A7C15 + 0xD1B54A32D192ED03 * (r + 1)) & (2 ** 64 - 1)
+        return self._dropout_seed
+
+    def next_dropout_call(self):
+        self._dropout_calls += 1
+        return self._dropout_calls
 
     def set_compute_dtype(self, compute_dtype):
         ops.dtype_code(compute_dtype)

@@ -42,6 +42,46 @@ def _gemm(A, W, bias, dt, N, K, out=None, out_f32=False, residual=None):
     return ops.gemm_bias_act(A, W, bias, residual, None, dt, out_f32=out_f32, N=N, K=K, out=out)
 
 
+class _Drop:
+    """One dropout site of one forward call: rate, Philox key / counter offset (the backward re-creates the mask from them),
+    and - for parity tests only - an explicit keep mask (`mask`: uint8 [rows, cols] for dense sites; `bits`: the int32 keep-bit
+    tensor of an attention site, layout of mh_dropout_bits)."""
+    __slots__ = ("p", "seed", "offset", "mask", "bits")
+
+    def __init__(self, p, seed, offset, mask=None, bits=None):
+        self.p, self.seed, self.offset, self.mask, self.bits = float(p), int(seed), int(offset), mask, bits
+
+    def c(self):
+        d = _lib.Dropout()
+        d.p, d.seed, d.offset = self.p, self.seed & (2 ** 64 - 1), self.offset & (2 ** 64 - 1)
+        d.mask = ptr(self.mask)
+        return d
+
+    def apply(self, x, dt):
+        """x o keep / (1 - p) for a dense [rows, cols] tensor (the same op forward and backward)."""
+        import ctypes as C
+        x = x.contiguous()
+        out = torch.empty_like(x)
+        d = self.c()
+        check(lib().mh_dropout_fwd(ptr(x), x.shape[1], ptr(out), out.shape[1], x.shape[0], x.shape[1], dt, C.byref(d), current_stream()),
+              "mh_dropout_fwd")
+        return out
+
+
+def _active(drop):
+    return drop is not None and drop.p > 0.0
+
+
+def _gemm_drop(A, W, bias, dt, N, K, out, residual, drop):
+    """out = dropout(A W^T + bias) + residual (HF BertSelfOutput / BertOutput in train mode)."""
+    import ctypes as C
+    d = drop.c()
+    check(lib().mh_gemm_bias_dropout_res(ptr(A), A.shape[1], ptr(W), W.shape[1], ptr(bias), ptr(residual),
+                                         residual.shape[1] if residual is not None else 0, ptr(out), out.shape[1], A.shape[0], N, K, dt,
+                                         C.byref(d), current_stream()), "mh_gemm_bias_dropout_res")
+    return out
+
+
 def _gemm_dw(dT, xT, N, Kp, Mp, dt):
     """dW [N, Kp] fp32 = dT [N, Mp] . xT [Kp, Mp]^T: the reduction runs over the Mp tokens while the output is tiny,
     so the K range is cut into slices that run as the batch of one batched GEMM (enough tiles to fill the chip)
@@ -130,14 +170,18 @@ class _Linear(Function):
     Output [M, pad64(N)] with zero padding columns."""
 
     @staticmethod
-    def forward(ctx, x, W, b, act, residual, dt):
+    def forward(ctx, x, W, b, act, residual, dt, drop=None):
         M, Kp = x.shape
         N, K = W.shape
         Np = ops.pad64(N)
         Wc = ops.cast_pad(W.detach(), Kp, dt)                         # [N, Kp]
         pre = _zeros(M, Np, dt, x.device, N)
         fused_act = act is not None and dt == ops.MH_BF16 and N == Np and N % 8 == 0 and Kp % 32 == 0
-        if fused_act:      # one kernel writes the pre-activation (kept for the backward) and the activation
+        ctx.drop = drop if _active(drop) else None
+        if ctx.drop is not None:   # dense -> dropout -> + residual in one kernel; the backward re-creates the mask
+            assert act is None and N == Np
+            y = _gemm_drop(x, Wc, b.detach() if b is not None else None, dt, N, Kp, pre, residual, ctx.drop)
+        elif fused_act:      # one kernel writes the pre-activation (kept for the backward) and the activation
             assert residual is None
             y = torch.empty_like(pre)
             check(lib().mh_gemm_bias_act_pre(ptr(x), Kp, ptr(Wc), Kp, ptr(b.detach()) if b is not None else None, ptr(pre), ptr(y), Np,
@@ -163,6 +207,8 @@ class _Linear(Function):
         if act is not None:
             dpre = torch.empty_like(dy)
             check(lib().mh_act_bwd(ptr(dy), ptr(pre), ptr(dpre), dy.numel(), ops.ACT[act], dt, current_stream()), "mh_act_bwd")
+        elif ctx.drop is not None:
+            dpre = ctx.drop.apply(dy, dt)          # the dense branch sees dY o keep / (1 - p); the residual branch sees dY
         else:
             dpre = dy
         db = _col_sum(dpre, M, N, dt) if has_b else None
@@ -172,7 +218,7 @@ class _Linear(Function):
         _gemm(dpre, WT, None, dt, Kp, Np, out=dx)
         # dW = dpre^T X : reduction over the M rows
         dW = _dw(dpre, x, N, Kp, M, dt)
-        return dx, dW[:, :K].contiguous(), db, None, (dy if has_res else None), None
+        return dx, dW[:, :K].contiguous(), db, None, (dy if has_res else None), None, None
 
 
 class _FFN(Function):
@@ -186,7 +232,7 @@ class _FFN(Function):
         return dt == ops.MH_BF16 and x.shape[1] == H and H % 64 == 0 and F % 64 == 0 and tuple(W2.shape) == (H, F)
 
     @staticmethod
-    def forward(ctx, x, W1, b1, W2, b2, dt):
+    def forward(ctx, x, W1, b1, W2, b2, dt, drop=None):
         M, H = x.shape
         F = W1.shape[0]
         W1c, W2c = ops.cast_pad(W1.detach(), H, dt), ops.cast_pad(W2.detach(), F, dt)
@@ -195,7 +241,11 @@ class _FFN(Function):
         check(lib().mh_gemm_bias_act_pre(ptr(x), H, ptr(W1c), H, ptr(b1.detach()), ptr(pre), ptr(f), F, M, F, H, ops.ACT["gelu"],
                                          current_stream()), "mh_gemm_bias_act_pre")
         y = torch.empty(M, H, device=x.device, dtype=x.dtype)
-        _gemm(f, W2c, b2.detach(), dt, H, F, out=y, residual=x)
+        ctx.drop = drop if _active(drop) else None
+        if ctx.drop is not None:
+            _gemm_drop(f, W2c, b2.detach(), dt, H, F, y, x, ctx.drop)
+        else:
+            _gemm(f, W2c, b2.detach(), dt, H, F, out=y, residual=x)
         ctx.save_for_backward(x, W1c, W2c, pre, f)
         ctx.dt = dt
         return y
@@ -207,19 +257,33 @@ class _FFN(Function):
         M, H = x.shape
         F = W1c.shape[0]
         dy = dy.contiguous()
-        db2 = _col_sum(dy, M, H, dt)
-        dW2 = _dw(dy, f, H, F, M, dt)
+        dym = ctx.drop.apply(dy, dt) if ctx.drop is not None else dy      # gradient of the dropped dense output
+        db2 = _col_sum(dym, M, H, dt)
+        dW2 = _dw(dym, f, H, F, M, dt)
         # d(pre) = (dy W2) o gelu'(pre): W2 is [H, F]; the GEMM wants the reduction dim contiguous -> W2^T [F, H]
         dpre = torch.empty(M, F, device=x.device, dtype=x.dtype)
         W2T = _transpose(W2c, H, F, dt, ld_out=H)
-        check(lib().mh_gemm_act_grad(ptr(dy), H, ptr(W2T), H, ptr(pre), F, ptr(dpre), F, M, F, H, ops.ACT["gelu"], current_stream()),
+        check(lib().mh_gemm_act_grad(ptr(dym), H, ptr(W2T), H, ptr(pre), F, ptr(dpre), F, M, F, H, ops.ACT["gelu"], current_stream()),
               "mh_gemm_act_grad")
         db1 = _col_sum(dpre, M, F, dt)
         dW1 = _dw(dpre, x, F, H, M, dt)
         dx = torch.empty(M, H, device=x.device, dtype=x.dtype)
         W1T = _transpose(W1c, F, H, dt, ld_out=F)                         # [H, F]
         _gemm(dpre, W1T, None, dt, H, F, out=dx, residual=dy)             # + dy: the residual branch
-        return dx, dW1, db1, dW2, db2, None
+        return dx, dW1, db1, dW2, db2, None, None
+
+
+class _Dropout(Function):
+    """y = x o keep / (1 - p) on a dense activation (nn.Dropout after the embedding LayerNorm, network.py:149)."""
+
+    @staticmethod
+    def forward(ctx, x, dt, drop):
+        ctx.drop, ctx.dt = drop, dt
+        return drop.apply(x, dt)
+
+    @staticmethod
+    def backward(ctx, g):
+        return ctx.drop.apply(g, ctx.dt), None, None
 
 
 class _LayerNorm(Function):
@@ -266,7 +330,7 @@ class _AddPosTime(Function):
         dpos_l = _col_sum(g.view(B, L * H), B, L * H, dt).view(L, H)                 # sum over the batch
         dpos = torch.zeros(Lmax, H, device=g.device, dtype=torch.float32)
         dpos[:L] = dpos_l
-        demb = _col_sum(g, L, H, dt, batch=B, stride_in=L * H)                        # sum over positions, per sequence
+        demb = _col_sum(g, L, H, dt, batch=B, stride_in=L * H).reshape(B, H)          # sum over positions, per sequence
         return dx, dpos, demb, None, None, None
 
 
@@ -274,7 +338,31 @@ class _Attention(Function):
     """ctx = softmax(q k^T / sqrt(dh)) v over [M, 3H] = [q | k | v] token-major projections (HF BertSelfAttention)."""
 
     @staticmethod
-    def forward(ctx, qkv, B, L, nh, dt):
+    def _keep_bits(drop, BH, L, dev):
+        """The attention site's keep-bit tensor: injected (tests) or generated by the standalone Philox kernel - bit for bit
+        what the fused forward writes itself."""
+        import ctypes as C
+        if drop.bits is not None:
+            return drop.bits
+        bits = torch.empty(int(lib().mh_dropout_bits_words(BH, L)), device=dev, dtype=torch.int32)
+        d = drop.c()
+        check(lib().mh_dropout_bits(ptr(bits), BH, L, C.byref(d), current_stream()), "mh_dropout_bits")
+        return bits
+
+    @staticmethod
+    def _probs(q, k, BH, L, Lp, dh, scale, dt):
+        """P = softmax(q k^T * scale) materialised as [BH L, Lp] (padding columns zero)."""
+        P = (torch.empty if Lp == L else torch.zeros)(BH * L, Lp, device=q.device, dtype=q.dtype)
+        check(lib().mh_gemm_batched(ptr(q), dh, L * dh, ptr(k), dh, L * dh, None, ptr(P), Lp, L * Lp, 0, BH, L, L, dh, dt, current_stream()),
+              "mh_gemm_batched")
+        check(lib().mh_softmax_rows(ptr(P), BH * L, L, Lp, scale, dt, current_stream()), "mh_softmax_rows")
+        return P
+
+    @staticmethod
+    def forward(ctx, qkv, B, L, nh, dt, drop=None):
+        import ctypes as C
+        drop = drop if _active(drop) else None
+        ctx.drop, ctx.bits = drop, None
         M, ld = qkv.shape
         H = ld // 3 if ld % 3 == 0 else None
         assert H is not None
@@ -293,15 +381,37 @@ class _Attention(Function):
             # the log-sum-exp lets the backward kernels re-create P tile by tile (no [L, L] tensor in HBM)
             out = torch.empty(B * L, H, device=qkv.device, dtype=td)
             lse = torch.empty(B * nh * L, device=qkv.device, dtype=torch.float32)
-            check(L_.mh_attention_stream_fwd_ex(qkv.data_ptr(), qkv.data_ptr() + H * es, ptr(vt), ptr(out), H, 0, B, L, nh, dh, scale,
-                                                ptr(lse), L * ld, dh, ld, st), "mh_attention_stream_fwd_ex")
+            if drop is not None:   # probability dropout inside the kernel; it writes the keep bits the backward kernels read
+                bits_in = int(drop.bits is not None)
+                ctx.bits = drop.bits if bits_in else torch.empty(int(L_.mh_dropout_bits_words(B * nh, L)), device=qkv.device, dtype=torch.int32)
+                d = drop.c()
+                check(L_.mh_attention_stream_fwd_drop(qkv.data_ptr(), qkv.data_ptr() + H * es, ptr(vt), ptr(out), H, 0, B, L, nh, dh, scale,
+                                                      ptr(lse), L * ld, dh, ld, C.byref(d), ptr(ctx.bits), bits_in, st),
+                      "mh_attention_stream_fwd_drop")
+            else:
+                check(L_.mh_attention_stream_fwd_ex(qkv.data_ptr(), qkv.data_ptr() + H * es, ptr(vt), ptr(out), H, 0, B, L, nh, dh, scale,
+                                                    ptr(lse), L * ld, dh, ld, st), "mh_attention_stream_fwd_ex")
             ctx.save_for_backward(qkv, out, lse)
         else:
             q = torch.empty(B, nh, L, dh, device=qkv.device, dtype=td)
             k = torch.empty_like(q)
             check(L_.mh_head_permute(qkv.data_ptr(), ptr(q), ld, B, L, nh, dh, 0, dt, st), "mh_head_permute")
             check(L_.mh_head_permute(qkv.data_ptr() + H * es, ptr(k), ld, B, L, nh, dh, 0, dt, st), "mh_head_permute")
-            out = ops.attention(q, k, vt, scale, dt)
+            if drop is not None:
+                # materialised: P -> P o keep / (1 - p) -> . V as batched GEMMs (fp32 parity mode / shapes without a streaming kernel)
+                BH, Lp = B * nh, ops.pad64(L)
+                ctx.bits = _Attention._keep_bits(drop, BH, L, qkv.device)
+                P = _Attention._probs(q, k, BH, L, Lp, dh, scale, dt)
+                check(L_.mh_dropout_bits_apply(ptr(P), Lp, ptr(ctx.bits), BH, L, drop.p, dt, st), "mh_dropout_bits_apply")
+                vtp = torch.zeros(BH * dh, Lp, device=qkv.device, dtype=td)                       # V^T with the reduction dim padded
+                vtp.view(BH, dh, Lp)[:, :, :L] = vt[: BH * dh * L].view(BH, dh, L)
+                o4 = torch.empty(B, nh, L, dh, device=qkv.device, dtype=td)
+                check(L_.mh_gemm_batched(ptr(P), Lp, L * Lp, ptr(vtp), Lp, dh * Lp, None, ptr(o4), dh, L * dh, 0, BH, L, dh, Lp, dt, st),
+                      "mh_gemm_batched")
+                out = torch.empty(B * L, H, device=qkv.device, dtype=td)
+                check(L_.mh_head_permute(ptr(o4), ptr(out), H, B, L, nh, dh, 1, dt, st), "mh_head_permute")
+            else:
+                out = ops.attention(q, k, vt, scale, dt)
             ctx.save_for_backward(q, k, vt)
         ctx.meta = (B, L, nh, dh, H, dt, scale, fused)
         return out
@@ -323,11 +433,12 @@ class _Attention(Function):
         qT, kT, dOT = transposed(qkv, 0, 3 * H), transposed(qkv, H, 3 * H), transposed(dctx, 0, H)
         D = torch.empty(B * nh * L, device=dev, dtype=torch.float32)      # scratch: rowsum(dO o O), produced by the dQ kernel
         dqkv = torch.empty(B * L, 3 * H, device=dev, dtype=td)
-        check(L_.mh_attention_stream_bwd_ex(qkv.data_ptr(), qkv.data_ptr() + H * es, qkv.data_ptr() + 2 * H * es, ptr(qT), ptr(kT),
-                                            ptr(dctx), ptr(dOT), ptr(out), ptr(lse), ptr(D), dqkv.data_ptr(), dqkv.data_ptr() + H * es,
-                                            dqkv.data_ptr() + 2 * H * es, 3 * H, B, L, nh, dh, scale,
-                                            L * 3 * H, dh, 3 * H, L * H, dh, H, st), "mh_attention_stream_bwd_ex")
-        return dqkv, None, None, None, None
+        check(L_.mh_attention_stream_bwd_drop(qkv.data_ptr(), qkv.data_ptr() + H * es, qkv.data_ptr() + 2 * H * es, ptr(qT), ptr(kT),
+                                              ptr(dctx), ptr(dOT), ptr(out), ptr(lse), ptr(D), dqkv.data_ptr(), dqkv.data_ptr() + H * es,
+                                              dqkv.data_ptr() + 2 * H * es, 3 * H, B, L, nh, dh, scale,
+                                              L * 3 * H, dh, 3 * H, L * H, dh, H, ptr(ctx.bits), ctx.drop.p if ctx.drop is not None else 0.0, st),
+              "mh_attention_stream_bwd_drop")
+        return dqkv, None, None, None, None, None
 
     @staticmethod
     def backward(ctx, dctx):
@@ -347,12 +458,14 @@ class _Attention(Function):
         check(L_.mh_head_permute(ptr(dctx), ptr(tmp), H, B, L, nh, dh, 2, dt, st), "mh_head_permute")
         dOT.view(BH, dh, Lp)[:, :, :L] = tmp.view(BH, dh, L)                                    # pad the reduction dim
         # P = softmax(q k^T * scale)   [BH, L, Lp]
-        P = (torch.empty if Lp == L else torch.zeros)(BH * L, Lp, device=dev, dtype=td)
-        check(L_.mh_gemm_batched(ptr(q), dh, L * dh, ptr(k), dh, L * dh, None, ptr(P), Lp, L * Lp, 0, BH, L, L, dh, dt, st),
-              "mh_gemm_batched")
-        check(L_.mh_softmax_rows(ptr(P), BH * L, L, Lp, scale, dt, st), "mh_softmax_rows")
+        P = _Attention._probs(q, k, BH, L, Lp, dh, scale, dt)
+        drop = ctx.drop
+        Pd = P
+        if drop is not None:   # the forward multiplied V by P o keep / (1 - p)
+            Pd = P.clone()
+            check(L_.mh_dropout_bits_apply(ptr(Pd), Lp, ptr(ctx.bits), BH, L, drop.p, dt, st), "mh_dropout_bits_apply")
         # dV = P^T dO : A = P^T [L(keys), Lp(q)], W = dO^T [dh, Lp(q)]
-        PT = _transpose(P, L, L, dt, ld_out=Lp, batch=BH, stride_in=L * Lp, stride_out=L * Lp)
+        PT = _transpose(Pd, L, L, dt, ld_out=Lp, batch=BH, stride_in=L * Lp, stride_out=L * Lp)
         dV = torch.empty(B, nh, L, dh, device=dev, dtype=td)
         check(L_.mh_gemm_batched(ptr(PT), Lp, L * Lp, ptr(dOT), Lp, dh * Lp, None, ptr(dV), dh, L * dh, 0, BH, L, dh, Lp, dt, st),
               "mh_gemm_batched")
@@ -361,6 +474,8 @@ class _Attention(Function):
         dP = (torch.empty if Lp == L else torch.zeros)(BH * L, Lp, device=dev, dtype=td)
         check(L_.mh_gemm_batched(ptr(dO), dh, L * dh, ptr(V), dh, L * dh, None, ptr(dP), Lp, L * Lp, 0, BH, L, L, dh, dt, st),
               "mh_gemm_batched")
+        if drop is not None:   # gradient w.r.t. the un-dropped probabilities
+            check(L_.mh_dropout_bits_apply(ptr(dP), Lp, ptr(ctx.bits), BH, L, drop.p, dt, st), "mh_dropout_bits_apply")
         check(L_.mh_softmax_bwd_rows(ptr(P), ptr(dP), BH * L, L, Lp, scale, dt, st), "mh_softmax_bwd_rows")   # dP := dS
         # dQ = dS K : W = K^T [dh, Lp(keys)]
         KT = _transpose(k.view(BH * L, dh), L, dh, dt, ld_out=Lp, batch=BH, stride_in=L * dh, stride_out=dh * Lp)
@@ -377,7 +492,7 @@ class _Attention(Function):
         es = dqkv.element_size()
         for i, t in enumerate((dQ, dK, dV)):
             check(L_.mh_head_permute(ptr(t), dqkv.data_ptr() + i * H * es, 3 * H, B, L, nh, dh, 1, dt, st), "mh_head_permute")
-        return dqkv, None, None, None, None
+        return dqkv, None, None, None, None, None
 
 
 class _Embed(Function):
@@ -474,8 +589,34 @@ class _TokenCE(Function):
 
 
 # ---------------------------------------------------------------------------------------------- composites
-def _linear(x, lin, act, dt, residual=None):
-    return _Linear.apply(x, lin.weight, lin.bias, act, residual, dt)
+def _linear(x, lin, act, dt, residual=None, drop=None):
+    return _Linear.apply(x, lin.weight, lin.bias, act, residual, dt, drop)
+
+
+class _DropSites:
+    """The dropout sites of ONE training forward (reference: nn.Dropout at network.py:149; HF BertSelfAttention / BertSelfOutput /
+    BertOutput dropouts inside network.py:151).  Every site gets its own Philox counter offset (call number, site index); rates
+    are zero in eval mode.  `model.dropout_masks` (tests) maps site names ("emb", "l0.attn", "l0.ao", "l0.ffn", ...) to explicit
+    keep masks (uint8 [N, H]; int32 keep-bit tensors for the ".attn" sites)."""
+
+    def __init__(self, model):
+        train = model.training
+        self.p_emb = float(model.dropout.p) if train else 0.0
+        self.p_hid = float(model.bert_hidden_dropout) if train else 0.0
+        self.p_att = float(model.bert_attention_dropout) if train else 0.0
+        self.masks = getattr(model, "dropout_masks", None) or {}
+        self.seed = model.dropout_seed()
+        self.call = model.next_dropout_call() if (self.p_emb or self.p_hid or self.p_att) else 0
+        self.nsite = 0
+
+    def site(self, name, p):
+        self.nsite += 1
+        if p <= 0.0:
+            return None
+        inj = self.masks.get(name)
+        if name.endswith(".attn"):
+            return _Drop(p, self.seed, (self.call << 16) | self.nsite, bits=inj)
+        return _Drop(p, self.seed, (self.call << 16) | self.nsite, mask=None if inj is None else inj.to(torch.uint8).contiguous())
 
 
 def denoiser_forward_with_grad(model, x, timesteps):
@@ -496,23 +637,28 @@ def denoiser_forward_with_grad(model, x, timesteps):
         h = _linear(h, model.input_up_proj[2], None, dt)
     else:
         h = xin
+    sites = _DropSites(model)
     pre = _AddPosTime.apply(h, model.position_embeddings.weight, emb_t, B, L, dt)
     X = _LayerNorm.apply(pre, model.LayerNorm.weight, model.LayerNorm.bias, model.LayerNorm.eps, dt)
-    for layer in model.input_transformers.layer:
+    d_emb = sites.site("emb", sites.p_emb)
+    if d_emb is not None:
+        X = _Dropout.apply(X, dt, d_emb)                                                          # network.py:149
+    for li, layer in enumerate(model.input_transformers.layer):
         sa = getattr(layer.attention, "self")
         Wqkv = torch.cat([sa.query.weight, sa.key.weight, sa.value.weight], dim=0)
         bqkv = torch.cat([sa.query.bias, sa.key.bias, sa.value.bias], dim=0)
         qkv = _Linear.apply(X, Wqkv, bqkv, None, None, dt)                                       # [N, 3H]
-        ctxv = _Attention.apply(qkv, B, L, model.num_heads, dt)
-        y1 = _linear(ctxv, layer.attention.output.dense, None, dt, residual=X)
+        ctxv = _Attention.apply(qkv, B, L, model.num_heads, dt, sites.site("l%d.attn" % li, sites.p_att))
+        y1 = _linear(ctxv, layer.attention.output.dense, None, dt, residual=X, drop=sites.site("l%d.ao" % li, sites.p_hid))
         X1 = _LayerNorm.apply(y1, layer.attention.output.LayerNorm.weight, layer.attention.output.LayerNorm.bias,
                               layer.attention.output.LayerNorm.eps, dt)
         d1, d2 = layer.intermediate.dense, layer.output.dense
+        d_ffn = sites.site("l%d.ffn" % li, sites.p_hid)
         if FUSED_FFN and (B * L) % 64 == 0 and _FFN.supported(X1, d1.weight, d2.weight, dt):
-            y2 = _FFN.apply(X1, d1.weight, d1.bias, d2.weight, d2.bias, dt)
+            y2 = _FFN.apply(X1, d1.weight, d1.bias, d2.weight, d2.bias, dt, d_ffn)
         else:
             f = _linear(X1, d1, "gelu", dt)
-            y2 = _linear(f, d2, None, dt, residual=X1)
+            y2 = _linear(f, d2, None, dt, residual=X1, drop=d_ffn)
         X = _LayerNorm.apply(y2, layer.output.LayerNorm.weight, layer.output.LayerNorm.bias, layer.output.LayerNorm.eps, dt)
     if model.output_dims != H:
         h = _linear(X, model.output_down_proj[0], "tanh", dt)

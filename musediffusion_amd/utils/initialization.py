@@ -24,7 +24,7 @@ def create_model_and_diffusion(args, **model_overrides):
     from ..models.network import TransformerNetModel
 
     extra = {}
-    for k in ("bert_hidden", "bert_layers", "bert_heads", "bert_ffn", "compute_dtype"):
+    for k in ("bert_hidden", "bert_layers", "bert_heads", "bert_ffn", "bert_hidden_dropout", "bert_attention_dropout", "compute_dtype"):
         if k in model_overrides:
             extra[k] = model_overrides[k]
         elif getattr(args, k, None) is not None:

@@ -7,7 +7,10 @@ algorithm: per layer
     a   = softmax(Q K^T / sqrt(dh)) V            (no mask is ever passed, network.py:151)
     x1  = LN(a Wo^T + bo + x)                    (BertSelfOutput, eps 1e-12)
     x2  = LN(gelu_erf(x1 Wi^T + bi) Wd^T + bd + x1)   (BertIntermediate + BertOutput)
-Dropouts are inference no-ops here; `train_dropout` is not modelled (fixtures use p=0).
+Dropouts are inference no-ops; train mode is modelled with EXPLICIT keep masks (`masks`: site name -> bool tensor, `p`: the
+rate whose 1 / (1 - p) rescales the kept units) at the reference's sites: "emb" after the embedding LayerNorm (network.py:149),
+per layer "l{i}.attn" on the attention probabilities, "l{i}.ao" / "l{i}.ffn" after the attention-output / FFN-output dense
+(HF BertSelfAttention / BertSelfOutput / BertOutput).
 """
 import math
 
@@ -37,29 +40,35 @@ def _lin(x, sd, prefix):
     return F.linear(x, sd[prefix + ".weight"], sd[prefix + ".bias"])
 
 
-def encoder_layer(x, sd, i, num_heads, eps=1e-12, collect=None):
+def _drop(x, masks, name, p):
+    if not masks or name not in masks:
+        return x
+    return x * masks[name].to(x.dtype) / (1.0 - p)
+
+
+def encoder_layer(x, sd, i, num_heads, eps=1e-12, collect=None, masks=None, p=0.0):
     """One post-LN BERT layer (HF BertLayer; reached from network.py:151)."""
-    p = "input_transformers.layer.%d." % i
+    pre = "input_transformers.layer.%d." % i
     B, L, H = x.shape
     dh = H // num_heads
 
     def heads(t):
         return t.view(B, L, num_heads, dh).permute(0, 2, 1, 3)
 
-    q = heads(_lin(x, sd, p + "attention.self.query"))
-    k = heads(_lin(x, sd, p + "attention.self.key"))
-    v = heads(_lin(x, sd, p + "attention.self.value"))
+    q = heads(_lin(x, sd, pre + "attention.self.query"))
+    k = heads(_lin(x, sd, pre + "attention.self.key"))
+    v = heads(_lin(x, sd, pre + "attention.self.value"))
     scores = torch.matmul(q, k.transpose(-1, -2)) / math.sqrt(dh)
-    probs = torch.softmax(scores, dim=-1)
+    probs = _drop(torch.softmax(scores, dim=-1), masks, "l%d.attn" % i, p)
     ctx = torch.matmul(probs, v).permute(0, 2, 1, 3).reshape(B, L, H)
     if collect is not None:
         collect.setdefault("ctx", []).append(ctx)
-    x1 = F.layer_norm(_lin(ctx, sd, p + "attention.output.dense") + x, (H,),
-                      sd[p + "attention.output.LayerNorm.weight"],
-                      sd[p + "attention.output.LayerNorm.bias"], eps)
-    inter = F.gelu(_lin(x1, sd, p + "intermediate.dense"))  # exact erf form (hidden_act="gelu")
-    x2 = F.layer_norm(_lin(inter, sd, p + "output.dense") + x1, (H,),
-                      sd[p + "output.LayerNorm.weight"], sd[p + "output.LayerNorm.bias"], eps)
+    x1 = F.layer_norm(_drop(_lin(ctx, sd, pre + "attention.output.dense"), masks, "l%d.ao" % i, p) + x, (H,),
+                      sd[pre + "attention.output.LayerNorm.weight"],
+                      sd[pre + "attention.output.LayerNorm.bias"], eps)
+    inter = F.gelu(_lin(x1, sd, pre + "intermediate.dense"))  # exact erf form (hidden_act="gelu")
+    x2 = F.layer_norm(_drop(_lin(inter, sd, pre + "output.dense"), masks, "l%d.ffn" % i, p) + x1, (H,),
+                      sd[pre + "output.LayerNorm.weight"], sd[pre + "output.LayerNorm.bias"], eps)
     return x2
 
 
@@ -78,17 +87,18 @@ def embed_inputs(sd, x, timesteps, hidden_t_dim):
     return F.layer_norm(h, (H,), sd["LayerNorm.weight"], sd["LayerNorm.bias"], 1e-12), emb_t
 
 
-def forward(sd, x, timesteps, num_heads, hidden_t_dim=None, collect=None):
+def forward(sd, x, timesteps, num_heads, hidden_t_dim=None, collect=None, masks=None, p=0.0):
     """TransformerNetModel.forward (network.py:131-158).  x [B,L,E] fp32, timesteps [B]."""
     if hidden_t_dim is None:
         hidden_t_dim = sd["time_embed.0.weight"].shape[1]
     h, emb_t = embed_inputs(sd, x, timesteps, hidden_t_dim)
+    h = _drop(h, masks, "emb", p)
     if collect is not None:
         collect["emb_t"] = emb_t
         collect["emb_inputs"] = h
         collect["hidden"] = []
     for i in range(count_layers(sd)):
-        h = encoder_layer(h, sd, i, num_heads, collect=collect)
+        h = encoder_layer(h, sd, i, num_heads, collect=collect, masks=masks, p=p)
         if collect is not None:
             collect["hidden"].append(h)
     if "output_down_proj.0.weight" in sd:

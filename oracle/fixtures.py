@@ -14,7 +14,14 @@ CONFIGS = {
     "same": dict(H=64, nL=1, nh=2, F=128, E=64, Tt=16, L=24, B=3, V=97),      # E == H: no up/down proj
     "c1": dict(H=128, nL=2, nh=4, F=512, E=128, Tt=128, L=128, B=8, V=729),   # BASELINE config 1 shape
 }
-SEEDS = {"tiny": 0, "same": 1, "c1": 2}
+CONFIGS.update({
+    # the only shape the reference itself can instantiate (bert-base: H 768, 12 heads of 64, ffn 3072; network.py:44-46), two layers
+    "bb": dict(H=768, nL=2, nh=12, F=3072, E=128, Tt=128, L=64, B=2, V=729),
+    # ... with the released checkpoints' embedding width (README.md:534: "embedding dim 500")
+    "bb500": dict(H=768, nL=2, nh=12, F=3072, E=500, Tt=128, L=32, B=2, V=729),
+})
+SEEDS = {"tiny": 0, "same": 1, "c1": 2, "bb": 3, "bb500": 4}
+DROPOUT_P = 0.1   # the reference's train-mode rate at all three kinds of site (config/train.py:61, bert-base config)
 EMB_STD = 0.5
 NOISING_T = 150
 
@@ -82,3 +89,20 @@ def loop_seed(tag, which):
 
 def loss_seed(tag):
     return 800 + SEEDS[tag]
+
+
+def dropout_sites(tag):
+    """Site names in the order the reference's forward reaches its dropouts (network.py:149, then per BertLayer: attention
+    probabilities, attention-output dense, FFN-output dense) with the shape of the tensor each one masks."""
+    c = CONFIGS[tag]
+    B, L, H, nh = c["B"], c["L"], c["H"], c["nh"]
+    sites = [("emb", (B, L, H))]
+    for i in range(c["nL"]):
+        sites += [("l%d.attn" % i, (B, nh, L, L)), ("l%d.ao" % i, (B, L, H)), ("l%d.ffn" % i, (B, L, H))]
+    return sites
+
+
+def dropout_masks(tag, p=DROPOUT_P, seed_base=900):
+    """Deterministic keep masks (bool) for every dropout site of one forward: Bernoulli(1 - p) from an isolated generator."""
+    g = torch.Generator().manual_seed(seed_base + SEEDS[tag])
+    return {name: torch.rand(shape, generator=g) >= p for name, shape in dropout_sites(tag)}

@@ -34,7 +34,7 @@ def build(tag, dev, rank, compute_dtype, train=False):
     c = fx.CONFIGS[tag]
     torch.manual_seed(1234 + rank)
     m = TransformerNetModel(c["E"], c["E"], c["Tt"], c["V"], c["L"], dropout=0.0, bert_hidden=c["H"], bert_layers=c["nL"],
-                            bert_heads=c["nh"], bert_ffn=c["F"], compute_dtype=compute_dtype)
+                            bert_heads=c["nh"], bert_ffn=c["F"], compute_dtype=compute_dtype, bert_hidden_dropout=0.0, bert_attention_dropout=0.0)
     if rank == 0:
         m.load_state_dict(fx.state_dict(tag))          # only rank 0 holds the fixture weights
     m = (m.train().requires_grad_(True) if train else m.eval().requires_grad_(False)).to(dev)

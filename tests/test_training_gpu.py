@@ -21,7 +21,7 @@ DEV = "cuda"
 def build(tag, compute_dtype="fp32"):
     c = fx.CONFIGS[tag]
     m = TransformerNetModel(c["E"], c["E"], c["Tt"], c["V"], c["L"], dropout=0.0, bert_hidden=c["H"],
-                            bert_layers=c["nL"], bert_heads=c["nh"], bert_ffn=c["F"], compute_dtype=compute_dtype)
+                            bert_layers=c["nL"], bert_heads=c["nh"], bert_ffn=c["F"], compute_dtype=compute_dtype, bert_hidden_dropout=0.0, bert_attention_dropout=0.0)
     m.load_state_dict(fx.state_dict(tag))
     m.train().requires_grad_(True).to(DEV)
     diff = SpacedDiffusion(use_timesteps=space_timesteps(2000, [2000]), betas=get_named_beta_schedule("sqrt", 2000),
@@ -153,7 +153,7 @@ def test_fused_attention_training_path_matches_unfused(L):
     torch.manual_seed(3)
     E, H, B, V = 32, 128, 2, 97
     m = TransformerNetModel(E, E, 32, V, L, dropout=0.0, bert_hidden=H, bert_layers=2, bert_heads=2, bert_ffn=256,
-                            compute_dtype="bf16")
+                            compute_dtype="bf16", bert_hidden_dropout=0.0, bert_attention_dropout=0.0)
     m.train().requires_grad_(True).to(DEV)
     diff = SpacedDiffusion(use_timesteps=space_timesteps(2000, [2000]), betas=get_named_beta_schedule("sqrt", 2000),
                            rescale_timesteps=True, predict_xstart=True)

@@ -239,10 +239,80 @@ def gen_losses(tag):
     print("losses_%s.npz" % tag, len(out), "arrays")
 
 
+class InjectedDropout:
+    """Train-mode dropout of the reference with KNOWN masks: `torch.nn.functional.dropout` (what nn.Dropout.forward and HF's
+    eager attention both call) is replaced, for the duration of one forward, by `x * mask_k / (1 - p)` with the k-th mask of
+    oracle.fixtures.dropout_masks in call order (network.py:149, then per BertLayer: probabilities, attention output, FFN
+    output).  Nothing in the reference or in transformers is modified on disk; the patch is removed on exit."""
+
+    def __init__(self, tag, p):
+        self.order = [name for name, _ in fx.dropout_sites(tag)]
+        self.masks, self.p, self.calls = fx.dropout_masks(tag, p), p, 0
+
+    def __enter__(self):
+        self.orig = torch.nn.functional.dropout
+
+        def fake(x, p=0.5, training=True, inplace=False):
+            if not training or p == 0.0:
+                return x
+            assert abs(p - self.p) < 1e-12, p
+            m = self.masks[self.order[self.calls]]
+            self.calls += 1
+            assert m.shape == x.shape, (self.order[self.calls - 1], m.shape, x.shape)
+            return x * m.to(x.dtype) / (1.0 - p)
+        torch.nn.functional.dropout = fake
+        return self
+
+    def __exit__(self, *a):
+        torch.nn.functional.dropout = self.orig
+
+
+def gen_losses_dropout(tag):
+    """training_losses (both variants) in TRAIN mode with dropout 0.1 at the reference's three kinds of site, masks injected."""
+    cfg = fx.CONFIGS[tag]
+    p = fx.DROPOUT_P
+    model, diffusion = build(cfg, dropout=p)
+    sd = fx.state_dict(tag)
+    model.load_state_dict(sd)
+    model.train().requires_grad_(True)
+    li = fx.loss_inputs(tag)
+    batch, t, w = li["batch"], li["t"], li["w"]
+    out = {"sd_sha256": np.array(sd_digest(sd)), "t": npy(t), "loss_w": npy(w), "p": np.array(p)}
+    for variant in ("plain", "corrupt"):
+        kw = {k: v for k, v in batch.items() if variant == "corrupt" or k != "correct_ids"}
+        model.zero_grad(set_to_none=True)
+        torch.manual_seed(fx.loss_seed(tag))
+        with InjectedDropout(tag, p) as inj:
+            terms = diffusion.training_losses(model, t, model_kwargs=kw)
+        assert inj.calls == len(inj.order), (inj.calls, len(inj.order))
+        (terms["loss"] * w).mean().backward()
+        for k in ("mse", "nll", "loss"):
+            out["%s_%s" % (variant, k)] = npy(terms[k])
+        out["%s_g_word" % variant] = npy(model.word_embedding.weight.grad)
+        out["%s_g_q0" % variant] = npy(model.input_transformers.layer[0].attention.self.query.weight.grad)
+        out["%s_g_v1" % variant] = npy(model.input_transformers.layer[1].attention.self.value.weight.grad)
+        out["%s_g_ff2" % variant] = npy(model.input_transformers.layer[0].output.dense.weight.grad)
+        out["%s_g_te0" % variant] = npy(model.time_embed[0].weight.grad)
+        out["%s_g_lmb" % variant] = npy(model.lm_head.bias.grad)
+    # the forward alone, train mode, same masks
+    inp = fx.case_inputs(tag, model.word_embedding.weight.detach())
+    with torch.no_grad(), InjectedDropout(tag, p):
+        out["fwd_y_train"] = npy(model(inp["fwd_x"], inp["fwd_t"]))
+    np.savez_compressed(os.path.join(OUT, "losses_%s_dropout.npz" % tag), **out)
+    print("losses_%s_dropout.npz" % tag, len(out), "arrays")
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    gen_schedules()
-    gen_model_case("tiny", compact=False)
-    gen_model_case("same", compact=False)
-    gen_model_case("c1", compact=True)
-    gen_losses("tiny")
+    only = sys.argv[1:]
+    if not only or "base" in only:
+        gen_schedules()
+        gen_model_case("tiny", compact=False)
+        gen_model_case("same", compact=False)
+        gen_model_case("c1", compact=True)
+        gen_losses("tiny")
+    if not only or "dropout" in only:
+        gen_losses_dropout("tiny")
+    if not only or "bertbase" in only:
+        gen_model_case("bb", compact=True)       # the reference-true width (H 768, 12 heads of 64, ffn 3072)
+        gen_model_case("bb500", compact=True)    # ... with the released weights' E = 500
