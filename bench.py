@@ -45,6 +45,7 @@ WORKLOADS = {
     "train": dict(L=1024, B=32, E=128, H=512, nL=12, nh=8, F=2048, V=729, Tt=128, T=2000),
 }
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}   # dense peaks, MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0                                 # HBM3E spec (6.3 TB/s achievable with a float4 copy, same guide)
 
 
 def step_flops(c):
@@ -138,13 +139,110 @@ def time_dominant_kernel(c, dtype, device, reps, branches=1):
     return avg_ms, flops, name, latency_ms
 
 
-def pmc_traffic(workload, dtype, branches):
+def classify_launch(kernel, note, c, branches):
+    """kernel symbol + launch note (csrc: mh_prof_note) -> (class name, bound, algorithmic work per launch, unit of work).
+    Work is ALGORITHMIC: 2 M N K flops for the MFMA GEMMs, 4 L dh flops per (query, head) for attention, and for the HBM-bound
+    kernels the bytes they must move at least once."""
+    kv = dict(t.split("=", 1) for t in note.split() if "=" in t)
+    N_tok = (c["B"] // branches) * c["L"]
+    H, F, E, L = c["H"], c["F"], c["E"], c["L"]
+    Ep = (E + 63) // 64 * 64
+    if "gemm_big_kernel" in kernel or "gemm_kernel<bf16" in kernel:
+        M, N, K, epi, act = int(kv["M"]), int(kv["N"]), int(kv["K"]), int(kv["epi"]), int(kv["act"])
+        role = {3: "dense+bias+residual+LayerNorm", 1: "QKV projection + head scatter"}.get(epi) or (
+            "dense+GELU (FFN1)" if act == 2 else "dense+tanh" if act == 1 else "dense")
+        return "gemm_big_kernel<%s, EPI=%d> bf16 %s [%d x %d x %d]" % (kv.get("tile", "?"), epi, role, M, N, K), "mfma", 2.0 * M * N * K, "flop"
+    if "gemm_kernel<float" in kernel:
+        M, N, K = int(kv["M"]), int(kv["N"]), int(kv["K"])
+        return "gemm_kernel<float> exact-fp32 MFMA, rounding scores [%d x %d x %d]" % (M, N, K), "mfma_f32", 2.0 * M * N * K, "flop"
+    if kernel == "kern" or "attn_" in kernel:
+        bh, dh = int(kv.get("B*nh", 0)), int(kv.get("dh", 0))
+        return "attn_stream_bf16_kernel<dh=%d> [B*nh=%d, L=%d]" % (dh, bh, L), "valu+mfma", 4.0 * L * dh * bh * L, "flop"
+    b = None
+    if "ln_panel_kernel" in kernel:
+        b = 2 * N_tok * H * 2 + (N_tok * H * 2 if E != H else 0) * 0                        # read [N,H] bf16, write [N,H] bf16
+    elif "pack_panel" in kernel:
+        b = N_tok * E * 4 + N_tok * Ep * 2
+    elif "unpack_panel" in kernel:
+        b = N_tok * H * 2 + N_tok * E * 4
+    elif "step_epilogue" in kernel:
+        b = N_tok * E * 4 * 5 + N_tok * 4        # model_out (or round idx + rows), x_t, noise, x_start in; sample + pred out; mask
+    elif "trunc_normal" in kernel:
+        b = c["B"] * L * E * 4                   # (drawn once for the whole batch)
+    elif "row_sqnorm_f32" in kernel:
+        b = N_tok * E * 4
+    elif "argbest_reduce" in kernel:
+        b = N_tok * 12 * 8
+    if b is not None:
+        return kernel.strip("()"), "hbm", float(b), "B"
+    return kernel.strip("()"), "latency", 0.0, ""
+
+
+def profile_step(loop, c, first_k, n_steps, ms_per_step):
+    """Per-kernel time INSIDE the step: the step's launch sequence run eagerly on the same streams (same branches) with every
+    launch bracketed by HIP events on its stream (mh_profile_start / _stop).  With two branches sharing the chip a launch's span
+    on its stream is longer than its share of the wall time, so spans are turned into shares: share = sum of the class's spans /
+    sum of all spans, in-step duration per launch = share x ms_per_step / launches per step."""
+    import ctypes
+    from musediffusion_amd import _lib
+    lib = _lib.lib()
+    was = loop.diff.use_graph
+    loop.diff.use_graph = False
+    try:
+        with torch.no_grad():
+            loop.advance(first_k)                                  # eager warm-up
+            torch.cuda.synchronize()
+            _lib.check(lib.mh_profile_start(), "mh_profile_start")
+            for k in range(first_k + 1, first_k + 1 + n_steps):
+                loop.advance(k)
+            buf = ctypes.create_string_buffer(1 << 22)
+            need = lib.mh_profile_stop(buf, len(buf))
+            assert 0 < need <= len(buf), need
+    finally:
+        loop.diff.use_graph = was
+    branches = int(loop.nsplit)
+    classes, total = {}, 0.0
+    for line in buf.value.decode().splitlines():
+        kernel, note, grid, block, stream, ms = line.split("\t")
+        ms = float(ms)
+        if ms < 0:
+            continue
+        name, bound, work, unit = classify_launch(kernel, note, c, branches)
+        e = classes.setdefault(name, dict(bound=bound, unit=unit, work=0.0, span_ms=0.0, launches=0))
+        e["work"] += work
+        e["span_ms"] += ms
+        e["launches"] += 1
+        total += ms
+    rows = []
+    for name, e in classes.items():
+        share = e["span_ms"] / total
+        per_step = e["launches"] / n_steps
+        instep_ms = share * ms_per_step / per_step
+        work = e["work"] / e["launches"]
+        row = {"kernel": name, "bound": e["bound"], "launches_per_step": round(per_step, 2), "share": round(share, 4),
+               "avg_launch_ms": round(instep_ms, 5), "stream_span_ms": round(e["span_ms"] / e["launches"], 5)}
+        if e["unit"] == "flop" and work > 0:
+            tf = work / (instep_ms * 1e-3) / 1e12
+            peak = MFMA_PEAK_TFLOPS["fp32" if e["bound"] == "mfma_f32" else "bf16"]
+            row.update(achieved=round(tf, 1), unit="TFLOP/s", frac=round(tf / peak, 4), work_per_launch=work)
+        elif e["unit"] == "B" and work > 0:
+            gbs = work / (instep_ms * 1e-3) / 1e9
+            row.update(achieved=round(gbs, 1), unit="GB/s", frac=round(gbs / HBM_PEAK_GBS, 4), work_per_launch=work)
+        rows.append(row)
+    rows.sort(key=lambda r: -r["share"])
+    return rows, total / n_steps
+
+
+def pmc_traffic(workload, dtype, branches, variant):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE doubled as
-    MI355X_MICROARCH.md prescribes for gfx950, + WRITE_SIZE); None when no pass was recorded for this workload."""
+    MI355X_MICROARCH.md prescribes for gfx950, + WRITE_SIZE).  Entries are keyed by workload AND kernel variant (the tile /
+    epilogue signature bench.py reports): None when no pass was recorded for the variant that runs now (a stale entry never matches)."""
     try:
         with open(os.path.join(REPO, "profiles", "pmc_traffic.json")) as f:
             rec = json.load(f).get("%s/%s/b%d" % (workload, dtype, branches))
-        return None if rec is None else float(rec["traffic_bytes_per_launch"])
+        if rec is None or rec.get("variant") != variant:
+            return None
+        return float(rec["traffic_bytes_per_launch"])
     except (OSError, ValueError, KeyError):
         return None
 
@@ -431,7 +529,8 @@ def main():
     fn = partial(denoised_fn_round, model_emb, dist=None)
 
     total = args.warmup + args.steps
-    indices = list(range(c["T"]))[::-1][:total]
+    PROF_STEPS = 4
+    indices = list(range(c["T"]))[::-1][:total + PROF_STEPS + 2]
     loop = _ReverseLoop.try_build(diff, "p", model, x_noised, True, fn, 1, mask3, x_start, 0.0, indices,
                                   lambda i: fn, False)
     assert loop is not None, "fused reverse loop unavailable"
@@ -469,14 +568,36 @@ def main():
                        "sequences_steps_per_s": round(value * c["B"], 1)},
         }
         if not args.no_kernel_timing:
-            avg_ms, fpl, kname, lat_ms = time_dominant_kernel(c, args.dtype, device, reps=5, branches=int(loop.nsplit))
+            # the dominant kernel = the kernel SYMBOL with the largest share of the step, measured inside the step (profile_step);
+            # its launches of different shapes are pooled: achieved = their mean algorithmic flops / their mean in-step duration
+            rows, span_sum = profile_step(loop, c, total, PROF_STEPS, ms_per_step)
+            sym = lambda r: r["kernel"].split(" [")[0]
+            pools = {}
+            for r in rows:
+                if r["bound"] == "mfma":
+                    pools.setdefault(sym(r), []).append(r)
+            dom = max(pools.values(), key=lambda rs: sum(r["share"] for r in rs))
+            n_l = sum(r["launches_per_step"] for r in dom)
+            share = sum(r["share"] for r in dom)
+            fpl = sum(r["work_per_launch"] * r["launches_per_step"] for r in dom) / n_l
+            avg_ms = share * ms_per_step / n_l
             ach = fpl / (avg_ms * 1e-3) / 1e12
             peak = MFMA_PEAK_TFLOPS[args.dtype]
-            out["roofline"] = {"bound": "mfma", "kernel": kname,
+            variant = sym(dom[0])
+            out["roofline"] = {"bound": "mfma", "kernel": variant + ": " + "; ".join(r["kernel"].split(" [")[1].rstrip("]") for r in dom),
                                "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                               "traffic": pmc_traffic(args.workload, args.dtype, int(loop.nsplit)), "avg_launch_ms": round(avg_ms, 5),
-                               "concurrent_streams": int(loop.nsplit), "launch_latency_ms": round(lat_ms, 5),
+                               "traffic": pmc_traffic(args.workload, args.dtype, int(loop.nsplit), variant),
+                               "avg_launch_ms": round(avg_ms, 5), "launches_per_step": n_l, "share_of_step": round(share, 4),
+                               "how": "in-step: HIP events around every launch of the eager step on its own stream (%d steps); "
+                                      "share = spans of this kernel / all spans (sum %.3f ms per step on %d concurrent streams vs %.3f ms "
+                                      "wall); avg_launch_ms = share x ms_per_step / launches" % (PROF_STEPS, span_sum, int(loop.nsplit), ms_per_step),
+                               "concurrent_streams": int(loop.nsplit),
+                               "stream_span_ms": round(sum(r["stream_span_ms"] * r["launches_per_step"] for r in dom) / n_l, 5),
                                "flops_per_launch": fpl}
+            iso_ms, iso_f, _, _ = time_dominant_kernel(c, args.dtype, device, reps=5, branches=int(loop.nsplit))
+            out["roofline"]["isolated"] = {"avg_launch_ms": round(iso_ms, 5), "achieved": round(iso_f / (iso_ms * 1e-3) / 1e12, 2),
+                                           "note": "secondary: the full-row GEMM + LayerNorm kernel alone in a loop on fresh operands"}
+            out["kernels"] = [{k: v for k, v in r.items() if k != "work_per_launch"} for r in rows if r["share"] >= 0.002]
         if not args.no_cpu_baseline and world == 1:     # the host baseline is a rank-0, N = 1 measurement
             out["cpu_baseline"] = cpu_baseline(c)
             out["cpu_baseline"]["value"] = round(out["cpu_baseline"]["value"], 5)

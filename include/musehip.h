@@ -529,6 +529,13 @@ int mh_attention_stream_bwd_drop(const void* q, const void* k, const void* v, co
                                  int64_t qkv_head_stride, int64_t qkv_row_stride, int64_t do_batch_stride, int64_t do_head_stride,
                                  int64_t do_row_stride, const uint32_t* keep_bits, float drop_p, mh_stream_t stream);
 
+/* ---------------------------------------------------------------- per-launch timing (measurement)
+ * Between mh_profile_start() and mh_profile_stop() every kernel this library launches is bracketed by two HIP events on its own
+ * stream (not capturable: call outside hipGraph capture).  mh_profile_stop synchronises the device and writes one line per launch,
+ * "kernel\tdetail\tgrid\tblock\tstream\tmilliseconds\n", into `out`; it returns the bytes the whole report needs. */
+int mh_profile_start(void);
+int64_t mh_profile_stop(char* out, size_t cap);
+
 #ifdef __cplusplus
 }
 #endif

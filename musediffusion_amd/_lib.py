@@ -158,6 +158,8 @@ SIGNATURES = {
     "mh_dropout_bits_apply": (INT, [VP, I64, VP, INT, INT, F32, INT, VP]),
     "mh_attention_stream_fwd_drop": (INT, [VP, VP, VP, VP, I64, INT, INT, INT, INT, INT, F32, VP, I64, I64, I64, C.POINTER(Dropout), VP, INT, VP]),
     "mh_attention_stream_bwd_drop": (INT, [VP, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP, I64, INT, INT, INT, INT, F32, I64, I64, I64, I64, I64, I64, VP, F32, VP]),
+    "mh_profile_start": (INT, []),
+    "mh_profile_stop": (I64, [C.c_char_p, C.c_size_t]),
     "mh_denoiser_workspace_bytes": (C.c_size_t, [C.POINTER(Denoiser), INT, INT]),
     "mh_time_embed": (INT, [C.POINTER(Denoiser), VP, VP, INT, VP, C.c_size_t, VP]),
     "mh_denoiser_forward": (INT, [C.POINTER(Denoiser), VP, VP, VP, VP, INT, INT, VP, C.c_size_t, VP]),

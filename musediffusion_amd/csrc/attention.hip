@@ -881,6 +881,7 @@ extern "C" int mh_attention_stream_fwd_drop(const void* q, const void* k, const 
       MH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
       attr_set = true;
     }
+    mh_prof_note("attn_stream B*nh=%d L=%d dh=%d drop=%d", nbh, L, dh, (int)dropping);
     MH_LAUNCH(kern, grid, block, bytes, s, Q, K, V, (bf16*)ctx, ld_ctx, L, nh, nbh, sl2, ctx_panel, lse2, qsB, qsH, qld, da, keep_bits, bits_in);
     return MH_OK;
   };

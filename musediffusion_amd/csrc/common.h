@@ -24,10 +24,19 @@ void mh_set_error(const char* fmt, ...);
   } while (0)
 // A launch site clears any stale (sticky) runtime error first so that the check after it reports
 // only this launch's status.
-#define MH_LAUNCH(...)                      \
-  do {                                      \
-    (void)hipGetLastError();                \
-    hipLaunchKernelGGL(__VA_ARGS__);        \
+// Per-launch timing (mh_profile_start / mh_profile_stop, engine.hip): when switched on - never inside a hipGraph capture - every
+// launch is bracketed by two HIP events on ITS stream, so bench.py can report each kernel's share of a step and its rate against
+// the roofline live, the way rocprofv3 --kernel-trace lists them.  `kernel` is a single macro argument (templates in parentheses).
+extern int g_mh_prof_on;
+void mh_prof_begin(const char* kernel, unsigned grid_x, unsigned block_x, hipStream_t stream);
+void mh_prof_end(hipStream_t stream);
+void mh_prof_note(const char* fmt, ...);     // free-form detail attached to the NEXT launch record (shape, role)
+#define MH_LAUNCH(kernel, grid, block, shmem, stream, ...)                      \
+  do {                                                                          \
+    (void)hipGetLastError();                                                    \
+    if (g_mh_prof_on) mh_prof_begin(#kernel, dim3(grid).x, dim3(block).x, stream); \
+    hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);        \
+    if (g_mh_prof_on) mh_prof_end(stream);                                      \
   } while (0)
 #define MH_CHECK_LAUNCH()                                        \
   do {                                                           \

@@ -16,6 +16,67 @@ void mh_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
+// ---------------------------------------------------------------- per-launch timing
+#include <string>
+#include <vector>
+int g_mh_prof_on = 0;
+namespace {
+struct ProfRec { std::string name, note; unsigned grid, block; hipEvent_t e0, e1; hipStream_t s; };
+std::vector<ProfRec> g_prof;
+std::vector<hipEvent_t> g_prof_pool;
+std::string g_prof_note;
+hipEvent_t prof_event() {
+  if (!g_prof_pool.empty()) { hipEvent_t e = g_prof_pool.back(); g_prof_pool.pop_back(); return e; }
+  hipEvent_t e = nullptr;
+  (void)hipEventCreate(&e);
+  return e;
+}
+}  // namespace
+void mh_prof_note(const char* fmt, ...) {
+  if (!g_mh_prof_on) return;
+  char buf[256];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_prof_note = buf;
+}
+void mh_prof_begin(const char* kernel, unsigned grid_x, unsigned block_x, hipStream_t stream) {
+  ProfRec r{kernel, g_prof_note, grid_x, block_x, prof_event(), prof_event(), stream};
+  g_prof_note.clear();
+  (void)hipEventRecord(r.e0, stream);
+  g_prof.push_back(r);
+}
+void mh_prof_end(hipStream_t stream) {
+  if (!g_prof.empty()) (void)hipEventRecord(g_prof.back().e1, stream);
+}
+extern "C" int mh_profile_start(void) {
+  for (auto& r : g_prof) { g_prof_pool.push_back(r.e0); g_prof_pool.push_back(r.e1); }
+  g_prof.clear();
+  g_mh_prof_on = 1;
+  return MH_OK;
+}
+// Stops recording, waits for the device, and writes one line per launch: "kernel\tnote\tgrid\tblock\tstream\tms\n".
+// Returns the number of bytes the full report needs (call again with a larger buffer if it exceeds `cap`), or a negative status.
+extern "C" int64_t mh_profile_stop(char* out, size_t cap) {
+  g_mh_prof_on = 0;
+  if (hipDeviceSynchronize() != hipSuccess) { mh_set_error("profile_stop: device synchronize failed"); return MH_ERR_HIP; }
+  std::string rep;
+  char line[768];
+  for (auto& r : g_prof) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) ms = -1.f;
+    snprintf(line, sizeof(line), "%s\t%s\t%u\t%u\t%p\t%.6f\n", r.name.c_str(), r.note.c_str(), r.grid, r.block, (void*)r.s, ms);
+    rep += line;
+  }
+  if (out && cap > 0) {
+    const size_t n = rep.size() < cap - 1 ? rep.size() : cap - 1;
+    memcpy(out, rep.data(), n);
+    out[n] = 0;
+  }
+  return (int64_t)rep.size() + 1;
+}
+
 namespace { int g_fuse_ln = 1; }
 extern "C" int mh_denoiser_get_fuse_ln(void) { return g_fuse_ln; }
 extern "C" int mh_denoiser_set_fuse_ln(int on) {
@@ -102,7 +163,7 @@ int check_model(const mh_denoiser* m) {
                    m->T4_pad % 64 == 0 && m->T4_pad >= 4 * m->Tt,
                "denoiser: bad padded sizes");
   MH_CHECK_ARG(m->has_proj == (m->E != m->H), "denoiser: has_proj must equal (E != H)");
-  MH_CHECK_ARG(!m->panel || (m->dtype == MH_BF16 && m->E % 8 == 0 && (m->H / m->nh) % 32 == 0), "denoiser: panel layout needs bf16, E %% 8 == 0 and head dim %% 32 == 0");
+  MH_CHECK_ARG(!m->panel || (m->dtype == MH_BF16 && m->E % 4 == 0 && (m->H / m->nh) % 32 == 0), "denoiser: panel layout needs bf16, E %% 4 == 0 and head dim %% 32 == 0");
   MH_CHECK_ARG(m->layers || m->nL == 0, "denoiser: null layer table");
   return MH_OK;
 }

@@ -819,9 +819,12 @@ __global__ __launch_bounds__(C::THREADS, C::STAGE * C::NST <= 80 * 1024 ? 2 : 1)
 #pragma unroll
       for (int qh = 0; qh < TJ / 2; ++qh) {
         const int col = wcol0 + 32 * qh + 8 * fg;
-        if (col < g.N) {   // N % 8 == 0 (checked by the launcher): a lane's 8 columns are all valid
+        if (col < g.N) {   // N % 8 == 0, or an fp32 output with N % 8 == 4 (big_tile_ok): at least the first 4 columns are valid
           float bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-          if (g.bias) load8(g.bias + col, bv);
+          if (g.bias) {
+            if (col + 8 <= g.N) load8(g.bias + col, bv);
+            else { const f32x4 b4 = *reinterpret_cast<const f32x4*>(g.bias + col); bv[0] = b4[0]; bv[1] = b4[1]; bv[2] = b4[2]; bv[3] = b4[3]; }
+          }
 #pragma unroll
           for (int i = 0; i < TI; ++i) {
             const int64_t row = wrow0 + 16 * i + fr;
@@ -858,7 +861,8 @@ __global__ __launch_bounds__(C::THREADS, C::STAGE * C::NST <= 80 * 1024 ? 2 : 1)
                 }
               }
               if (g.out_f32) {
-                store8(outF + row * g.ldo + col, v);
+                if (col + 8 <= g.N) store8(outF + row * g.ldo + col, v);
+                else *reinterpret_cast<f32x4*>(outF + row * g.ldo + col) = f32x4{v[0], v[1], v[2], v[3]};   // N % 8 == 4 tail
               } else {
                 const int64_t oo = g.o_panel ? ((int64_t)(col >> 5) * g.ldo + row) * 32 + (col & 31) : row * g.ldo + col;
                 if constexpr ((DBG & 32) != 0) store8(outT + oo, v); else store8_nt(outT + oo, v);
@@ -898,6 +902,7 @@ int launch_big(const GemmArgs& g0, hipStream_t s, int batch) {
   const int64_t slots = (int64_t)cus * per_cu;
   g.ntiles = (int)t2;
   const dim3 grid((unsigned)(t2 < slots ? t2 : slots), (unsigned)batch), block(C::THREADS);
+  mh_prof_note("tile=%dx%d%s epi=%d act=%d M=%lld N=%d K=%d batch=%d", C::BM, C::BN, C::PP ? "pp" : "", EPI, g.act, (long long)g.M, g.N, g.K, batch);
   if constexpr (EPI == 1) {
     if (g_plain_stores & 1) MH_LAUNCH((gemm_big_kernel<C, 1, MH_ACT_NONE, 32>), grid, block, 0, s, g);
     else MH_LAUNCH((gemm_big_kernel<C, 1, MH_ACT_NONE>), grid, block, 0, s, g);
@@ -935,7 +940,10 @@ int launch_big(const GemmArgs& g0, hipStream_t s, int batch) {
 }
 
 bool big_tile_ok(const GemmArgs& g) {
-  return g.N % 8 == 0 && g.K % B2K == 0 && (g.o_panel || g.ldo % 8 == 0 || (g.out_f32 && g.ldo % 4 == 0)) &&
+  // N % 8 == 0: a lane's 8 output columns are all valid; an fp32 row-major output may end on a half group (N % 4 == 0, e.g. the
+  // released checkpoints' E = 500 down-projection): the epilogue stores only the first four of the last lane's columns
+  const bool n_ok = g.N % 8 == 0 || (g.out_f32 && g.N % 4 == 0 && g.act_grad == 0 && !g.residual && !g.pre_out && !g.q && !g.ln_gamma && !g.drop.thr);
+  return n_ok && g.K % B2K == 0 && (g.o_panel || g.ldo % 8 == 0 || (g.out_f32 && g.ldo % 4 == 0)) &&
          (g.r_panel || g.ldr % 8 == 0);
 }
 
@@ -953,6 +961,7 @@ int launch(const GemmArgs& g, int dtype, hipStream_t s, int batch = 1) {
   MH_CHECK_ARG(tiles > 0 && tiles < (1ll << 31), "gemm: bad grid (M=%lld N=%d)", (long long)g.M, g.N);
   MH_CHECK_ARG(batch >= 1 && batch <= 65535, "gemm: batch %d out of range", batch);
   dim3 grid((unsigned)tiles, (unsigned)batch), block(256);
+  mh_prof_note("tile=128x128 epi=%d act=%d M=%lld N=%d K=%d batch=%d dtype=%d", EPI, g.act, (long long)g.M, g.N, g.K, batch, dtype);
   if (dtype == MH_BF16) {
     MH_CHECK_ARG((g.a_panel || g.lda % 8 == 0) && (g.w_panel || g.ldw % 8 == 0), "gemm(bf16): lda/ldw must be multiples of 8");
     const bool any_panel = g.a_panel || g.w_panel || g.o_panel || g.r_panel;

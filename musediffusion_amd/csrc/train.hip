@@ -664,9 +664,10 @@ extern "C" int mh_layernorm_bwd(const void* x, const void* dy, const float* gamm
                   MH_LAUNCH((ln_bwd_kernel<float>), dim3(n_partial), dim3(256), 0, s, (const float*)x, (const float*)dy, gamma, (float*)dx, pg, pb, rows, H, eps),
                   "layernorm_bwd");
   MH_CHECK_LAUNCH();
-  MH_LAUNCH(colsum_final_kernel, dim3((H + 255) / 256, 1), dim3(256), 0, s, pg, n_partial, H, dgamma, accumulate);
+  // (a colsum_final block folds 64 columns: 4 partial-lanes x 64)
+  MH_LAUNCH(colsum_final_kernel, dim3((H + 63) / 64, 1), dim3(256), 0, s, pg, n_partial, H, dgamma, accumulate);
   MH_CHECK_LAUNCH();
-  MH_LAUNCH(colsum_final_kernel, dim3((H + 255) / 256, 1), dim3(256), 0, s, pb, n_partial, H, dbeta, accumulate);
+  MH_LAUNCH(colsum_final_kernel, dim3((H + 63) / 64, 1), dim3(256), 0, s, pb, n_partial, H, dbeta, accumulate);
   MH_CHECK_LAUNCH();
   return MH_OK;
 }

@@ -33,7 +33,8 @@ class DenoiserEngine:
         c["has_proj"] = int(c["E"] != c["H"])
         # K32-panel layout for every bf16 weight / activation when the shapes allow it
         dh = c["H"] // c["nh"]
-        c["panel"] = int(self.dtype == MH_BF16 and panel and c["E"] % 8 == 0 and dh % 32 == 0 and
+        # (E % 4: the released checkpoints' E = 500 stays on this path - E is zero-padded to 64 inside the arena / input panels)
+        c["panel"] = int(self.dtype == MH_BF16 and panel and c["E"] % 4 == 0 and dh % 32 == 0 and
                          c["H"] // 32 in (2, 4, 8, 12, 16, 24))
         self._plan = self._make_plan()
         self.arena = torch.zeros(self._plan["total"], dtype=torch.uint8, device=self.device)

@@ -46,7 +46,7 @@ def G(g, name):
 
 def sub(t, tag):
     t = t.detach().float().cpu()
-    return t[:, ::8] if (tag == "c1" and t.dim() == 3) else t
+    return t[:, ::8] if (tag in ("c1", "bb", "bb500") and t.dim() == 3) else t
 
 
 def maxerr(a, b):
@@ -65,12 +65,14 @@ def loop_noises(seed, shape, n, top_p):
     return [osa.truncated_noise(z, top_p) if top_p else torch.randn_like(z) for _ in range(n)]
 
 
-@pytest.mark.parametrize("tag", ["tiny", "same", "c1"])
+# bb / bb500: the only encoder shape the reference itself instantiates (H 768, 12 heads of 64, ffn 3072; network.py:44-46), with
+# E = 128 and with the released checkpoints' E = 500
+@pytest.mark.parametrize("tag", ["tiny", "same", "c1", "bb", "bb500"])
 def test_model_surface(tag):
     m, diff, model_emb, inp, c = build(tag)
     g = load_golden("model_%s.npz" % tag)
     y = m(inp["fwd_x"].to(DEV), inp["fwd_t"].to(DEV), input_ids="ignored", anything_else=1)   # **_ is dropped
-    assert maxerr(sub(y, tag), G(g, "fwd_y")) < 1e-4
+    assert maxerr(sub(y, tag), G(g, "fwd_y")) < (2e-4 if c["H"] >= 768 else 1e-4)   # 768- / 3072-term fp32 sums in another order
     ids = inp["batch"]["correct_ids"]
     assert torch.equal(m.get_embeds(ids.to(DEV)).cpu(), inp["x_start"])
     assert torch.equal(m.get_embeds(ids.int().to(DEV)).cpu(), inp["x_start"])
@@ -163,7 +165,7 @@ def run_loops(tag, m, diff, model_emb, inp, c, use_graph):
 
 
 @pytest.mark.parametrize("use_graph", [False, True], ids=["eager", "hipgraph"])
-@pytest.mark.parametrize("tag", ["tiny", "same", "c1"])
+@pytest.mark.parametrize("tag", ["tiny", "same", "c1", "bb", "bb500"])
 def test_loops_final_tokens_exact_fp32(tag, use_graph):
     m, diff, model_emb, inp, c = build(tag)
     g = load_golden("model_%s.npz" % tag)
@@ -178,9 +180,11 @@ def test_loops_final_tokens_exact_fp32(tag, use_graph):
         assert maxerr(sub(s, tag), G(g, "loop_%s" % key)) < 2e-5, key
 
 
-def test_loops_bf16_token_agreement():
-    tag = "c1"
+@pytest.mark.parametrize("tag", ["c1", "bb", "bb500"])
+def test_loops_bf16_token_agreement(tag):
+    """bf16 throughput mode (panel layout; bb500: E = 500 zero-padded inside the arena) against the reference's fp32 tokens."""
     m, diff, model_emb, inp, c = build(tag, "bf16")
+    assert m.engine().cfg["panel"] == 1
     g = load_golden("model_%s.npz" % tag)
     res = run_loops(tag, m, diff, model_emb, inp, c, True)
     for key in ("ddim50", "p12", "mod"):
@@ -337,3 +341,50 @@ def test_full_size_config2_properties():
     agree = float((idx["bf16"] == idx["fp32"]).float().mean())
     print("config 2 first-step rounding agreement bf16 vs fp32: %.4f" % agree)
     assert agree >= 0.99, agree
+
+
+def test_bf16_config2_shape_against_oracle():
+    """BASELINE config 2's denoiser (seq_len 512, d_model 512, 12 layers, 8 heads, ffn 2048, E 128) in the bf16 throughput mode
+    against the fp32 CPU oracle on 2 sequences: one forward and one p_sample step with the oracle's noise.
+    Stated bf16 tolerance: bf16 storage (8 significant bits) of every activation through 12 post-LN layers, the sigmoid-form GELU
+    fit (|err| <= 2.5e-5, csrc/common.h) and fp32 accumulation leave mean |delta| <= 0.02 and max |delta| <= 0.25 on an O(1)
+    model output; the rounded tokens of the step (nearest embedding row) must agree on >= 99% of the positions."""
+    from oracle import denoiser as odn, schedule as osc
+    B, L, E, H, F, nL, nh, V, Tt = 2, 512, 128, 512, 2048, 12, 8, 729, 128
+    sd = odn.random_state_dict(E, H, F, nL, V, L, Tt, seed=11, emb_std=fx.EMB_STD)
+    m = TransformerNetModel(E, E, Tt, V, L, dropout=0.0, bert_hidden=H, bert_layers=nL, bert_heads=nh, bert_ffn=F, compute_dtype="bf16")
+    m.load_state_dict(sd)
+    m.eval().requires_grad_(False).to(DEV)
+    gen = torch.Generator().manual_seed(12)
+    ids = torch.randint(0, V, (B, L), generator=gen)
+    x_start = sd["word_embedding.weight"][ids]
+    x = x_start + 0.8 * torch.randn(B, L, E, generator=gen)
+    t = torch.tensor([1500, 300])
+    ts = t.float() * (1000.0 / 2000)
+    torch.set_num_threads(max(1, min(16, torch.get_num_threads())))
+    with torch.no_grad():
+        ref = odn.forward(sd, x, ts, nh)
+    got = m(x.to(DEV), ts.to(DEV)).cpu()
+    d = (got - ref).abs()
+    print("bf16 config-2 forward: mean |delta| %.4f  max %.4f  (ref absmax %.3f)" % (float(d.mean()), float(d.max()), float(ref.abs().max())))
+    assert float(d.mean()) <= 0.02 and float(d.max()) <= 0.25
+    # one p_sample step: rounding + posterior with the oracle's noise
+    diff = SpacedDiffusion(use_timesteps=space_timesteps(2000, [2000]), betas=get_named_beta_schedule("sqrt", 2000),
+                           rescale_timesteps=True, predict_xstart=True)
+    emb = torch.nn.Embedding(V, E, _weight=m.word_embedding.weight.clone()).eval().requires_grad_(False)
+    fn = partial(denoised_fn_round, emb, dist=None)
+    noise = step_noise(3, (B, L, E), 1)
+    diff.noise_fn = lambda k, i, xx: noise.to(DEV)
+    dcpu = osc.make_diffusion()
+    with torch.no_grad():
+        ref_step = osa.p_sample(dcpu, lambda xx, tt: ref, x, t, True, sd["word_embedding.weight"], top_p=1, noise=noise)   # (forward reused)
+    out = diff.p_sample(m, x.to(DEV), t.to(DEV), clip_denoised=True, denoised_fn=fn, model_kwargs={}, top_p=1)
+    tok_gpu = get_efficient_knn(emb.weight.to(DEV), out["pred_xstart"].reshape(-1, E))[1][0].cpu()
+    tok_ref = osa.nearest_token(sd["word_embedding.weight"], ref_step["pred_xstart"]).reshape(-1)
+    agree = float((tok_gpu == tok_ref).float().mean())
+    same = tok_gpu.view(B, L) == tok_ref.view(B, L)
+    print("bf16 config-2 rounded-token agreement %.4f" % agree)
+    assert agree >= 0.99
+    # where the token decision agrees the rounded x0 is the same embedding row, so the posterior sample is the oracle's to fp32 rounding
+    ds = (out["sample"].cpu() - ref_step["sample"]).abs()[same]
+    assert float(ds.max()) < 1e-5

@@ -183,3 +183,41 @@ def test_fused_attention_training_path_matches_unfused(L):
         print("%s: cosine %.5f, |fused| %.3e |unfused| %.3e" % (name, cos, float(a.norm()), float(b.norm())))
         assert cos > 0.995, (name, cos)
         assert abs(float(a.norm()) / float(b.norm()) - 1.0) < 0.03, name
+
+
+@pytest.mark.parametrize("tag,variant", [("c1", "corrupt"), ("same", "plain")])
+def test_every_parameter_gradient_matches_oracle(tag, variant):
+    """EVERY parameter's gradient (LayerNorm gains / biases, position table, projections, ... - the golden file holds four) of
+    training_losses at d_model 128 / 64 against the CPU oracle (torch autograd over the restated reference ops, pinned to the
+    reference by tests/test_oracle_golden.py), same draws, fp32 mode: 2e-3 of each gradient's max-abs."""
+    from oracle import denoiser as odn, losses as olo, schedule as osc
+    m, diff, c = build(tag)
+    li = fx.loss_inputs(tag)
+    batch, t, w = li["batch"], li["t"], li["w"]
+    kw = {k: v for k, v in batch.items() if variant == "corrupt" or k != "correct_ids"}
+    with CpuDraws(fx.loss_seed(tag)):
+        terms = diff.training_losses(m, t.to(DEV), model_kwargs=kw)
+    (terms["loss"] * w.to(DEV)).mean().backward()
+    sd = {k: v.clone() for k, v in fx.state_dict(tag).items()}
+    pnames = [n for n, _ in m.named_parameters()]
+    for n in pnames:
+        sd[n].requires_grad_(True)
+    sd["lm_head.weight"] = sd["word_embedding.weight"]
+    torch.manual_seed(fx.loss_seed(tag))
+    ref = olo.training_losses(osc.make_diffusion(), lambda x, ts: odn.forward(sd, x, ts, c["nh"]), lambda ids: odn.get_embeds(sd, ids),
+                              lambda h: odn.get_logits(sd, h), t, batch["input_ids"], batch["input_mask"],
+                              correct_ids=batch["correct_ids"] if variant == "corrupt" else None)
+    (ref["loss"] * w).mean().backward()
+    close("loss", terms["loss"], ref["loss"].detach().numpy(), 5e-4)
+    bad = []
+    for n, p in m.named_parameters():
+        r = sd[n].grad
+        err = float((p.grad.detach().cpu() - r).abs().max())
+        scale = float(r.abs().max())
+        # key biases have a zero true gradient (softmax is invariant to a per-query shift): only rounding noise on both sides
+        if "attention.self.key.bias" in n:
+            assert err < 1e-5, (n, err)
+            continue
+        if err > 2e-3 * scale + 1e-7:
+            bad.append((n, err, scale))
+    assert not bad, bad
