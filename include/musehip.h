@@ -533,6 +533,8 @@ int mh_attention_stream_bwd_drop(const void* q, const void* k, const void* v, co
  * Between mh_profile_start() and mh_profile_stop() every kernel this library launches is bracketed by two HIP events on its own
  * stream (not capturable: call outside hipGraph capture).  mh_profile_stop synchronises the device and writes one line per launch,
  * "kernel\tdetail\tgrid\tblock\tstream\tmilliseconds\n", into `out`; it returns the bytes the whole report needs. */
+/* experiment knob (A/B only): co-resident partner blocks of the big-tile GEMMs start `ticks` x 10 ns late */
+int mh_gemm_set_stagger(int ticks);
 int mh_profile_start(void);
 int64_t mh_profile_stop(char* out, size_t cap);
 

