@@ -418,6 +418,9 @@ typedef struct mh_layer_weights {
   const void* w_ff1;   const float* b_ff1;     /* intermediate.dense [F, H] */
   const void* w_ff2;   const float* b_ff2;     /* output.dense [H, F] */
   const float* ln2_g;  const float* ln2_b;     /* output.LayerNorm */
+  /* deferred LayerNorm (NULL: not packed): weights folded with the gain of the LayerNorm that feeds them, and their c1 / c2 vectors */
+  const void* w_qkv_f; const float* c1_qkv; const float* c2_qkv;   /* gamma = PREVIOUS layer's output.LayerNorm (layer 0: unused) */
+  const void* w_ff1_f; const float* c1_ff1; const float* c2_ff1;   /* gamma = this layer's attention.output.LayerNorm */
 } mh_layer_weights;
 
 typedef struct mh_denoiser {
@@ -528,6 +531,30 @@ int mh_attention_stream_bwd_drop(const void* q, const void* k, const void* v, co
                                  int64_t ld_d, int B, int L, int nh, int dh, float scale, int64_t qkv_batch_stride,
                                  int64_t qkv_head_stride, int64_t qkv_row_stride, int64_t do_batch_stride, int64_t do_head_stride,
                                  int64_t do_row_stride, const uint32_t* keep_bits, float drop_p, mh_stream_t stream);
+
+/* ---------------------------------------------------------------- deferred LayerNorm (bf16 throughput path)
+ * HF BertSelfOutput / BertOutput end in LayerNorm(dense(x) + input).  Instead of normalising in the producing GEMM (which needs
+ * a tile that owns complete rows) the producer stores the RAW sum and one partial (sum, sum of squares) pair per row and
+ * 128-column tile (`o_stats`, [M][o_slots][2] fp32); consumers normalise on the fly:
+ *   A operand raw (`a_stats`):  LN(y) W^T + b = rstd_r ((y W'^T)_rc - mean_r c1_c) + c2_c, W' = gamma o W (rows of the folded
+ *       weight matrix passed as W), c1_c = sum_k W'_ck, and the `bias` argument = c2_c = sum_k beta_k W_ck + b_c;
+ *   residual raw (`r_stats`):   (y - mean_r) rstd_r gamma_c + beta_c.
+ * All operands in the K32-panel layout, 256x128 tile.  Reference: the LayerNorm calls inside network.py:151's BertEncoder. */
+typedef struct mh_ln_defer {
+  const float* a_stats; int a_slots; const float* c1;
+  const float* r_stats; int r_slots; const float* r_gamma; const float* r_beta;
+  float* o_stats; int o_slots;
+  int h_norm;          /* width of the normalised rows (d_model) */
+  float eps;
+} mh_ln_defer;
+int mh_gemm_bias_act_defer(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, const void* residual, int64_t ldr,
+                           void* out, int64_t ldo, int64_t M, int N, int K, int act, const mh_ln_defer* defer, mh_stream_t stream);
+int mh_gemm_qkv_vtperm_defer(const void* A, int64_t lda, const void* Wqkv, int64_t ldw, const float* c2, void* q, void* k, void* vt_perm,
+                             int B, int L, int H, int nh, const mh_ln_defer* defer, mh_stream_t stream);
+/* denoiser forward: 0 = never defer, 1 (default) = defer where the width has no full-row LayerNorm epilogue (d_model 768),
+ * 2 = always (A/B) */
+int mh_denoiser_set_defer_ln(int mode);
+int mh_denoiser_get_defer_ln(void);
 
 /* ---------------------------------------------------------------- per-launch timing (measurement)
  * Between mh_profile_start() and mh_profile_stop() every kernel this library launches is bracketed by two HIP events on its own

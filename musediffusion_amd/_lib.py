@@ -48,7 +48,13 @@ class Dropout(C.Structure):
 class LayerWeights(C.Structure):
     """mh_layer_weights"""
     _fields_ = [(n, VP) for n in ("w_qkv", "b_qkv", "w_ao", "b_ao", "ln1_g", "ln1_b", "w_ff1", "b_ff1",
-                                  "w_ff2", "b_ff2", "ln2_g", "ln2_b")]
+                                  "w_ff2", "b_ff2", "ln2_g", "ln2_b", "w_qkv_f", "c1_qkv", "c2_qkv", "w_ff1_f", "c1_ff1", "c2_ff1")]
+
+
+class LnDefer(C.Structure):
+    """mh_ln_defer"""
+    _fields_ = [("a_stats", VP), ("a_slots", INT), ("c1", VP), ("r_stats", VP), ("r_slots", INT), ("r_gamma", VP), ("r_beta", VP),
+                ("o_stats", VP), ("o_slots", INT), ("h_norm", INT), ("eps", F32)]
 
 
 class Denoiser(C.Structure):
@@ -160,6 +166,10 @@ SIGNATURES = {
     "mh_dropout_bits_apply": (INT, [VP, I64, VP, INT, INT, F32, INT, VP]),
     "mh_attention_stream_fwd_drop": (INT, [VP, VP, VP, VP, I64, INT, INT, INT, INT, INT, F32, VP, I64, I64, I64, C.POINTER(Dropout), VP, INT, VP]),
     "mh_attention_stream_bwd_drop": (INT, [VP, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP, I64, INT, INT, INT, INT, F32, I64, I64, I64, I64, I64, I64, VP, F32, VP]),
+    "mh_gemm_bias_act_defer": (INT, [VP, I64, VP, I64, VP, VP, I64, VP, I64, I64, INT, INT, INT, C.POINTER(LnDefer), VP]),
+    "mh_gemm_qkv_vtperm_defer": (INT, [VP, I64, VP, I64, VP, VP, VP, VP, INT, INT, INT, INT, C.POINTER(LnDefer), VP]),
+    "mh_denoiser_set_defer_ln": (INT, [INT]),
+    "mh_denoiser_get_defer_ln": (INT, []),
     "mh_profile_start": (INT, []),
     "mh_profile_stop": (I64, [C.c_char_p, C.c_size_t]),
     "mh_denoiser_workspace_bytes": (C.c_size_t, [C.POINTER(Denoiser), INT, INT]),

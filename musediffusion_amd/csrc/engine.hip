@@ -77,7 +77,13 @@ extern "C" int64_t mh_profile_stop(char* out, size_t cap) {
   return (int64_t)rep.size() + 1;
 }
 
-namespace { int g_fuse_ln = 1; }
+namespace { int g_fuse_ln = 1; int g_defer_ln = 1; }
+extern "C" int mh_denoiser_get_defer_ln(void) { return g_defer_ln; }
+// 0 = never, 1 (default) = where no full-row LayerNorm epilogue exists for the width (d_model 768), 2 = always (A/B)
+extern "C" int mh_denoiser_set_defer_ln(int mode) {
+  g_defer_ln = mode < 0 ? 0 : (mode > 2 ? 2 : mode);
+  return MH_OK;
+}
 extern "C" int mh_denoiser_get_fuse_ln(void) { return g_fuse_ln; }
 extern "C" int mh_denoiser_set_fuse_ln(int on) {
   g_fuse_ln = on != 0;
@@ -132,6 +138,7 @@ inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct Workspace {
   char *xin, *buf0, *buf1, *bufX, *bufX1, *q, *k, *vt, *ffn;
+  float *stats1, *stats2;   // deferred LayerNorm: partial (sum, sumsq) per row and 128-column tile of the two raw row buffers
   size_t total;
 };
 
@@ -149,6 +156,9 @@ Workspace carve(const mh_denoiser* m, int B, int L, char* base) {
   w.k = take(N * m->H * es);
   w.vt = take(N * m->H * es + 256);  // slack: the last V^T row may be over-read by one 16-B chunk
   w.ffn = take(N * (size_t)m->F * es);
+  const size_t slots = (size_t)(m->H + 127) / 128;
+  w.stats1 = (float*)take(N * slots * 2 * sizeof(float));
+  w.stats2 = (float*)take(N * slots * 2 * sizeof(float));
   w.total = off;
   return w;
 }
@@ -235,7 +245,55 @@ extern "C" int mh_denoiser_forward(const mh_denoiser* m, const float* x, const f
                                                 m->ln_eps, stream)))
         return rc;
     }
-    for (int l = 0; l < m->nL; ++l) {
+    // Deferred LayerNorm (DeferArgs, gemm.hip): the attention-output and FFN-output GEMMs store RAW rows + partial row
+    // statistics and their consumers normalise on the fly, so every GEMM runs on the 256x128 tile (no full-row tile, no
+    // LayerNorm kernel - d_model 768 included).  The last layer's output is normalised by the panel LayerNorm kernel.
+    // Measured (same box, tools: bench.py --defer-ln 0/2): +2% steps/s at d_model 768 (two LayerNorm kernels per layer
+    // saved), -7% at d_model 512, where the full-row tile's LayerNorm epilogue is cheaper than the consumers' statistics staging
+    // (a global round trip + two more barriers per tile, and no DMA prefetch across the epilogue): default = only where there is
+    // no fused epilogue.
+    bool defer = (g_defer_ln == 2 || (g_defer_ln == 1 && !fuse_ln)) && stream_attn && m->nL > 0;
+    for (int l = 0; l < m->nL && defer; ++l) defer = m->layers[l].w_ff1_f && (l == 0 || m->layers[l].w_qkv_f);
+    if (defer) {
+      const int S = (H + 127) / 128;
+      bool prev_raw = false;   // bufX holds raw rows of the previous layer's output (statistics in stats2)
+      for (int l = 0; l < m->nL; ++l) {
+        const mh_layer_weights& lw = m->layers[l];
+        const mh_layer_weights* pl = l ? &m->layers[l - 1] : nullptr;
+        mh_ln_defer d{};
+        d.h_norm = H; d.eps = m->ln_eps;
+        if (prev_raw) {
+          d.a_stats = w.stats2; d.a_slots = S; d.c1 = lw.c1_qkv;
+          if ((rc = mh_gemm_qkv_vtperm_defer(w.bufX, N, lw.w_qkv_f, 3 * H, lw.c2_qkv, w.q, w.k, w.vt, B, L, H, m->nh, &d, stream))) return rc;
+        } else {
+          if ((rc = mh_gemm_qkv_vtperm(w.bufX, N, P, lw.w_qkv, 3 * H, P, lw.b_qkv, w.q, w.k, w.vt, B, L, H, m->nh, stream))) return rc;
+        }
+        if ((rc = mh_attention_stream_fwd(w.q, w.k, w.vt, w.buf0, N, P, B, L, m->nh, dh, scale, stream))) return rc;
+        // y1 = ctx W_ao^T + b_ao + X  (raw) -> bufX1, statistics -> stats1
+        d = mh_ln_defer{};
+        d.h_norm = H; d.eps = m->ln_eps;
+        if (prev_raw) { d.r_stats = w.stats2; d.r_slots = S; d.r_gamma = pl->ln2_g; d.r_beta = pl->ln2_b; }
+        d.o_stats = w.stats1; d.o_slots = S;
+        if ((rc = mh_gemm_bias_act_defer(w.buf0, N, lw.w_ao, H, lw.b_ao, w.bufX, N, w.bufX1, N, N, H, H, MH_ACT_NONE, &d, stream))) return rc;
+        // f = gelu(LN1(y1) W1^T + b1)
+        d = mh_ln_defer{};
+        d.h_norm = H; d.eps = m->ln_eps;
+        d.a_stats = w.stats1; d.a_slots = S; d.c1 = lw.c1_ff1;
+        if ((rc = mh_gemm_bias_act_defer(w.bufX1, N, lw.w_ff1_f, F, lw.c2_ff1, nullptr, 0, w.ffn, N, N, F, H, MH_ACT_GELU_ERF, &d, stream))) return rc;
+        // y2 = f W2^T + b2 + LN1(y1)
+        const bool last = l == m->nL - 1;
+        d = mh_ln_defer{};
+        d.h_norm = H; d.eps = m->ln_eps;
+        d.r_stats = w.stats1; d.r_slots = S; d.r_gamma = lw.ln1_g; d.r_beta = lw.ln1_b;
+        if (!last) { d.o_stats = w.stats2; d.o_slots = S; }
+        if ((rc = mh_gemm_bias_act_defer(w.ffn, N, lw.w_ff2, H, lw.b_ff2, w.bufX1, N, last ? w.buf1 : w.bufX, N, N, H, F, MH_ACT_NONE, &d, stream))) return rc;
+        if (last) {
+          if ((rc = mh_layernorm_panel(w.buf1, N, lw.ln2_g, lw.ln2_b, w.bufX, N, N, H, m->ln_eps, stream))) return rc;
+        }
+        prev_raw = !last;
+      }
+    }
+    for (int l = 0; l < m->nL && !defer; ++l) {
       const mh_layer_weights& lw = m->layers[l];
       if (stream_attn) {   // V^T written in the streaming kernel's key order: its stages are straight LDS-DMA copies
         if ((rc = mh_gemm_qkv_vtperm(w.bufX, N, P, lw.w_qkv, 3 * H, P, lw.b_qkv, w.q, w.k, w.vt, B, L, H, m->nh, stream))) return rc;

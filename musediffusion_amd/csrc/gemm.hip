@@ -22,6 +22,22 @@
 
 namespace {
 
+// Deferred LayerNorm (bf16 throughput path): a dense + residual GEMM writes its RAW pre-LayerNorm rows plus per-row partial
+// statistics (one (sum, sum of squares) pair per 128-column tile), and the consumers apply the normalisation themselves:
+//   * as A operand:  LN(y) W^T + b = rstd_r ((y W'^T)_rc - mean_r c1_c) + c2_c  with W' = gamma o W (folded once, engine arena),
+//     c1_c = sum_k W'_ck, c2_c = sum_k beta_k W_ck + b_c - the row scale / shift runs in the epilogue, on the accumulators;
+//   * as residual:   (y - mean_r) rstd_r gamma_c + beta_c, element by element in the epilogue.
+// No tile then needs to own complete rows: every GEMM of a layer runs on the 256x128 tile at two blocks per CU (d_model 768
+// included, which has no full-row tile), and the LayerNorm kernels / epilogues disappear.
+struct DeferArgs {
+  const float* a_stats; int a_slots;   // A rows are raw: [M][a_slots][2] partial (sum, sumsq); g.bias then holds c2
+  const float* c1;                     // [N] sum_k W'[c][k]
+  const float* r_stats; int r_slots;   // residual rows are raw
+  const float* r_gamma; const float* r_beta;
+  float* o_stats; int o_slots;         // write the output rows' partial statistics, slot = column tile (n0 / BN)
+  float inv_h, eps;                    // 1 / (normalised width), LayerNorm eps
+};
+
 struct GemmArgs {
   const void* A; int64_t lda;
   const void* W; int64_t ldw;
@@ -45,6 +61,7 @@ struct GemmArgs {
   int ntiles;    // persistent big-tile launch: ntiles output tiles walked by gridDim.x blocks
   int vt_perm;   // QKV scatter: V^T keys in the P-operand order of mh_attention_stream_fwd (middle groups of 4 swapped per 16)
   int stagger;   // experiment: blocks of the second half of the grid (the co-resident partners) start this many 10-ns ticks late
+  DeferArgs d;   // DBG bit 128 kernels only
   DropArgs drop; // EPI 0: train-mode dropout of (A W^T + bias) before the residual is added (thr == 0: off)
 };
 
@@ -585,7 +602,11 @@ __global__ __launch_bounds__(C::THREADS, C::STAGE * C::NST <= 80 * 1024 ? 2 : 1)
   // stages can already be landing in the ring while this tile's epilogue runs
   // (EPI 3 also keeps bias / LayerNorm gain / shift of the block's BN = N columns in LDS: read back with ds_read in the epilogue,
   // they cost neither vector registers across the main loop nor vmcnt waits between the stores)
-  __shared__ __attribute__((aligned(16))) char smem[C::NST * C::STAGE + (EPI == 3 ? C::BM * C::WN * 4 + 3 * C::BN * 4 : 0)];
+  // deferred LayerNorm (DeferArgs), one compiled variant per operand combination so that unused vectors cost no registers:
+  // DA = A rows raw, DR = residual rows raw, DO = write the output rows' partial statistics
+  constexpr bool DA = (DBG & 128) != 0, DR = (DBG & 256) != 0, DO = (DBG & 512) != 0, DEFER = DA || DR || DO;
+  __shared__ __attribute__((aligned(16))) char smem[C::NST * C::STAGE + (EPI == 3 ? C::BM * C::WN * 4 + 3 * C::BN * 4 : 0) +
+                                                    (DEFER ? C::BM * 8 * (2 + C::WN) : 0)];
   constexpr int TI = C::TI, TJ = C::TJ;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -644,6 +665,7 @@ __global__ __launch_bounds__(C::THREADS, C::STAGE * C::NST <= 80 * 1024 ? 2 : 1)
     const int vn = vt + (int)gridDim.x;
     pre = 0;
     if constexpr (EPI == 3) return;   // the row-statistics epilogue has no registers to spare for the carried pointers
+    if constexpr (DEFER) return;      // (its epilogue holds the row statistics: no registers to spare either)
     if (g.dbg & 32) return;           // A/B: no prefetch across the epilogue
     if (vn < g.ntiles) {
       set_sources(vn);
@@ -654,6 +676,31 @@ __global__ __launch_bounds__(C::THREADS, C::STAGE * C::NST <= 80 * 1024 ? 2 : 1)
       const int npro = nk < C::PRO ? nk : C::PRO;
       for (int st = 0; st < npro; ++st) issue_stage<C, DBG>(smem, srcA, srcW, ldsA, ldsW, st, kstepA, kstepW);
       pre = (full_tile && nk >= C::NST && !(g.dbg & 64)) ? 2 : 1;   // (dbg bit 64: A/B, always drain)
+    }
+  };
+  // DEFER: (mean, rstd) of the tile's A rows / residual rows from the producers' partial sums, staged in LDS for every wave
+  float2* lds_a = reinterpret_cast<float2*>(smem + C::NST * C::STAGE);
+  float2* lds_r = lds_a + C::BM;
+  float2* lds_o = lds_r + C::BM;      // [BM][WN]
+  auto stage_row_stats = [&](int64_t m0) {
+    if constexpr (DA || DR) {
+      for (int t = tid; t < C::BM; t += C::THREADS) {
+        int64_t row = m0 + t; if (row >= g.M) row = g.M - 1;
+        if constexpr (DA) {
+          float s1 = 0.f, s2 = 0.f;
+          for (int sl = 0; sl < g.d.a_slots; ++sl) { const float2 p = reinterpret_cast<const float2*>(g.d.a_stats)[row * g.d.a_slots + sl]; s1 += p.x; s2 += p.y; }
+          const float mean = s1 * g.d.inv_h, var = fmaxf(s2 * g.d.inv_h - mean * mean, 0.f);
+          lds_a[t] = float2{mean, 1.0f / sqrtf(var + g.d.eps)};
+        }
+        if constexpr (DR) {
+          float s1 = 0.f, s2 = 0.f;
+          for (int sl = 0; sl < g.d.r_slots; ++sl) { const float2 p = reinterpret_cast<const float2*>(g.d.r_stats)[row * g.d.r_slots + sl]; s1 += p.x; s2 += p.y; }
+          const float mean = s1 * g.d.inv_h, var = fmaxf(s2 * g.d.inv_h - mean * mean, 0.f);
+          lds_r[t] = float2{mean, 1.0f / sqrtf(var + g.d.eps)};
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
     }
   };
   for (int vt = blockIdx.x; vt < g.ntiles; vt += gridDim.x) {
@@ -699,16 +746,18 @@ __global__ __launch_bounds__(C::THREADS, C::STAGE * C::NST <= 80 * 1024 ? 2 : 1)
       // FULL (interior tile, wave-uniform): no per-lane guards, so the epilogue is straight-line code.  With divergent guards
       // hipcc cannot prove the bias loads complete on every path and puts `s_waitcnt vmcnt(0)` in front of EVERY store block,
       // which also waits for the previous store: the tile's stores then leave one round trip at a time.
+      stage_row_stats(m0);
       auto epi_v = [&](auto fullc) {
         constexpr bool FULL = decltype(fullc)::value;
         bf16* dst = reinterpret_cast<bf16*>(g.vt);
-        float bv[TJ];
+        float bv[TJ], c1v[TJ];
         int64_t coloff[TJ];
 #pragma unroll
         for (int j = 0; j < TJ; ++j) {
           const int col = wcol0 + 16 * j + fr;
           const int cc = (FULL || col < g.N) ? col : g.N - 1;
           bv[j] = g.bias[cc];
+          if constexpr (DA) c1v[j] = g.d.c1[cc];
           const int c = cc - 2 * g.H, head = c / g.dh, d = c % g.dh;
           coloff[j] = (FULL || col < g.N) ? ((int64_t)head * g.dh + d) * g.L : -1;
         }
@@ -720,12 +769,22 @@ __global__ __launch_bounds__(C::THREADS, C::STAGE * C::NST <= 80 * 1024 ? 2 : 1)
             int l = row - b * g.L;
             if (g.vt_perm) l = (l & ~15) | ((((l >> 3) & 1) | ((l >> 1) & 2)) << 2);   // 4-token group 0,1,2,3 -> 0,2,1,3
             bf16* base = dst + (int64_t)b * g.H * g.L + l;
+            float mu[4] = {0.f, 0.f, 0.f, 0.f}, rsd[4] = {1.f, 1.f, 1.f, 1.f};
+            if constexpr (DA) {   // rows 16 i + 4 fg + r of the tile: four consecutive (mean, rstd) pairs
+              const f32x4* sp = reinterpret_cast<const f32x4*>(lds_a + wm * (TI * 16) + 16 * i + 4 * fg);
+              const f32x4 s01 = sp[0], s23 = sp[1];
+              mu[0] = s01[0]; rsd[0] = s01[1]; mu[1] = s01[2]; rsd[1] = s01[3];
+              mu[2] = s23[0]; rsd[2] = s23[1]; mu[3] = s23[2]; rsd[3] = s23[3];
+            }
 #pragma unroll
             for (int j = 0; j < TJ; ++j) {
               if (FULL || coloff[j] >= 0) {
                 bf16x4 v;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = (bf16)(acc[i][j][r] + bv[j]);
+                for (int r = 0; r < 4; ++r) {
+                  if constexpr (DA) v[r] = (bf16)fmaf(rsd[r], fmaf(-mu[r], c1v[j], acc[i][j][r]), bv[j]);
+                  else v[r] = (bf16)(acc[i][j][r] + bv[j]);
+                }
                 *reinterpret_cast<bf16x4*>(base + coloff[j]) = v;
               }
             }
@@ -736,14 +795,25 @@ __global__ __launch_bounds__(C::THREADS, C::STAGE * C::NST <= 80 * 1024 ? 2 : 1)
     } else {
       run_mainloop<C, true, DBG, TI * (TJ / 2)>(acc, smem, srcA, srcW, ldsA, ldsW, nk, a_off, b_offs, kstepA, kstepW, wm, pre);
       prefetch_next(vt, full_tile);
+      stage_row_stats(m0);
       auto epi_qk = [&](auto fullc) {
         constexpr bool FULL = decltype(fullc)::value;
         bf16* dst = reinterpret_cast<bf16*>(which == 0 ? g.q : g.k);
         float bv[TJ / 2][8];          // every bias load before the first store: a load behind a store would wait for it
+        float c1v[TJ / 2][8];
+        float mu[TI], rsd[TI];
 #pragma unroll
         for (int qh = 0; qh < TJ / 2; ++qh) {
           const int col = wcol0 + 32 * qh + 8 * fg;
           load8(g.bias + ((FULL || col < g.N) ? col : 0), bv[qh]);
+          if constexpr (DA) load8(g.d.c1 + ((FULL || col < g.N) ? col : 0), c1v[qh]);
+        }
+        if constexpr (DA) {
+#pragma unroll
+          for (int i = 0; i < TI; ++i) {
+            const float2 st = lds_a[wm * (TI * 16) + 16 * i + fr];
+            mu[i] = st.x; rsd[i] = st.y;
+          }
         }
 #pragma unroll
         for (int qh = 0; qh < TJ / 2; ++qh) {
@@ -758,7 +828,10 @@ __global__ __launch_bounds__(C::THREADS, C::STAGE * C::NST <= 80 * 1024 ? 2 : 1)
                 const int b = row / g.L, l = row - b * g.L;
                 float v[8];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = acc[i][2 * qh + (e >> 2)][e & 3] + bv[qh][e];
+                for (int e = 0; e < 8; ++e) {
+                  if constexpr (DA) v[e] = fmaf(rsd[i], fmaf(-mu[i], c1v[qh][e], acc[i][2 * qh + (e >> 2)][e & 3]), bv[qh][e]);
+                  else v[e] = acc[i][2 * qh + (e >> 2)][e & 3] + bv[qh][e];
+                }
                 if constexpr ((DBG & 32) != 0) store8(dst + ((int64_t)b * g.nh * g.L + l) * g.dh + coloff, v);
                 else store8_nt(dst + ((int64_t)b * g.nh * g.L + l) * g.dh + coloff, v);
               }
@@ -872,9 +945,15 @@ __global__ __launch_bounds__(C::THREADS, C::STAGE * C::NST <= 80 * 1024 ? 2 : 1)
         }
       }
     } else {
+      stage_row_stats(m0);
       auto epi_gen = [&](auto fullc) {
         constexpr bool FULL = decltype(fullc)::value;
         float bv[TJ / 2][8];          // every bias load before the first store
+        float os1[TI], os2[TI];       // DO: running (sum, sum of squares) of this lane's part of each row
+        if constexpr (DO) {
+#pragma unroll
+          for (int i = 0; i < TI; ++i) { os1[i] = 0.f; os2[i] = 0.f; }
+        }
 #pragma unroll
         for (int qh = 0; qh < TJ / 2; ++qh) {
           const int col = wcol0 + 32 * qh + 8 * fg;
@@ -889,6 +968,9 @@ __global__ __launch_bounds__(C::THREADS, C::STAGE * C::NST <= 80 * 1024 ? 2 : 1)
         for (int qh = 0; qh < TJ / 2; ++qh) {
           const int col = wcol0 + 32 * qh + 8 * fg;
           if (FULL || col < g.N) {   // N % 8 == 0, or an fp32 output with N % 8 == 4 (big_tile_ok): at least the first 4 columns are valid
+            float c1v[8], rgv[8], rbv[8];   // deferred-LayerNorm column vectors of this group (loaded with its residual rows)
+            if constexpr (DA) load8(g.d.c1 + ((FULL || col + 8 <= g.N) ? col : 0), c1v);
+            if constexpr (DR) { load8(g.d.r_gamma + ((FULL || col + 8 <= g.N) ? col : 0), rgv); load8(g.d.r_beta + ((FULL || col + 8 <= g.N) ? col : 0), rbv); }
             bf16x8 rraw[TI];         // the group's residual rows: all loads in flight together, behind the previous group's stores
             if (res) {
 #pragma unroll
@@ -903,8 +985,15 @@ __global__ __launch_bounds__(C::THREADS, C::STAGE * C::NST <= 80 * 1024 ? 2 : 1)
               const int64_t row = wrow0 + 16 * i + fr;
               if (FULL || row < g.M) {
                 float v[8];
+                const int rt = wm * (TI * 16) + 16 * i + fr;     // row of the tile: (mean, rstd) pairs staged in LDS
+                if constexpr (DA) {
+                  const float2 sa = lds_a[rt];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = acc[i][2 * qh + (e >> 2)][e & 3] + bv[qh][e];
+                  for (int e = 0; e < 8; ++e) v[e] = fmaf(sa.y, fmaf(-sa.x, c1v[e], acc[i][2 * qh + (e >> 2)][e & 3]), bv[qh][e]);
+                } else {
+#pragma unroll
+                  for (int e = 0; e < 8; ++e) v[e] = acc[i][2 * qh + (e >> 2)][e & 3] + bv[qh][e];
+                }
                 if constexpr (ACT != MH_ACT_NONE) {
                   if (g.pre_out) {   // training: the backward needs the pre-activation
                     const int64_t po = g.o_panel ? ((int64_t)(col >> 5) * g.ldo + row) * 32 + (col & 31) : row * g.ldo + col;
@@ -925,10 +1014,18 @@ __global__ __launch_bounds__(C::THREADS, C::STAGE * C::NST <= 80 * 1024 ? 2 : 1)
                   } else if (g.act_grad == MH_ACT_TANH) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) { const float th = tanhf((float)rraw[i][e]); v[e] *= 1.0f - th * th; }
+                  } else if constexpr (DR) {
+                    const float2 sr = lds_r[rt];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += fmaf(((float)rraw[i][e] - sr.x) * sr.y, rgv[e], rbv[e]);
                   } else {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] += (float)rraw[i][e];
                   }
+                }
+                if constexpr (DO) {   // statistics of the row as the consumers will read it: from the bf16-rounded values
+#pragma unroll
+                  for (int e = 0; e < 8; ++e) { const float r = (float)(bf16)v[e]; os1[i] += r; os2[i] += r * r; }
                 }
                 if (g.out_f32) {
                   if (FULL || col + 8 <= g.N) store8(outF + row * g.ldo + col, v);
@@ -938,6 +1035,25 @@ __global__ __launch_bounds__(C::THREADS, C::STAGE * C::NST <= 80 * 1024 ? 2 : 1)
                   if constexpr ((DBG & 32) != 0) store8(outT + oo, v); else store8_nt(outT + oo, v);
                 }
               }
+            }
+          }
+        }
+        if constexpr (DO) {
+          {   // fold the lane partials over the 4 lanes of a row, then over the WN column waves (fixed order)
+#pragma unroll
+            for (int i = 0; i < TI; ++i) {
+              float a = os1[i], b = os2[i];
+              a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
+              b += __shfl_xor(b, 16, 64); b += __shfl_xor(b, 32, 64);
+              if (fg == 0) lds_o[(wm * (TI * 16) + 16 * i + fr) * C::WN + wn] = float2{a, b};
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            for (int t = tid; t < C::BM; t += C::THREADS) {
+              float a = 0.f, b = 0.f;
+#pragma unroll
+              for (int w = 0; w < C::WN; ++w) { const float2 p = lds_o[t * C::WN + w]; a += p.x; b += p.y; }
+              if (m0 + t < g.M) reinterpret_cast<float2*>(g.d.o_stats)[(m0 + t) * g.d.o_slots + n0 / C::BN] = float2{a, b};
             }
           }
         }
@@ -977,8 +1093,15 @@ int launch_big(const GemmArgs& g0, hipStream_t s, int batch) {
   g.stagger = g_stagger;
   const dim3 grid((unsigned)(t2 < slots ? t2 : slots), (unsigned)batch), block(C::THREADS);
   mh_prof_note("tile=%dx%d%s epi=%d act=%d M=%lld N=%d K=%d batch=%d", C::BM, C::BN, C::PP ? "pp" : "", EPI, g.act, (long long)g.M, g.N, g.K, batch);
+  const bool defer = g.d.a_stats || g.d.r_stats || g.d.o_stats;
   if constexpr (EPI == 1) {
-    if (g_plain_stores & 1) MH_LAUNCH((gemm_big_kernel<C, 1, MH_ACT_NONE, 32>), grid, block, 0, s, g);
+    if (defer) {
+      if constexpr (C::NW == 4) {
+        MH_CHECK_ARG(g.d.a_stats && !g.d.r_stats && !g.d.o_stats, "gemm_qkv: deferred LayerNorm applies to the A operand only");
+        MH_LAUNCH((gemm_big_kernel<C, 1, MH_ACT_NONE, 128>), grid, block, 0, s, g);
+      } else { mh_set_error("gemm: deferred LayerNorm needs the 256x128 tile"); return MH_ERR_UNSUPPORTED; }
+    }
+    else if (g_plain_stores & 1) MH_LAUNCH((gemm_big_kernel<C, 1, MH_ACT_NONE, 32>), grid, block, 0, s, g);
     else MH_LAUNCH((gemm_big_kernel<C, 1, MH_ACT_NONE>), grid, block, 0, s, g);
   } else if constexpr (EPI == 3) {
     MH_LAUNCH((gemm_big_kernel<C, 3, MH_ACT_NONE>), grid, block, 0, s, g);
@@ -996,6 +1119,16 @@ int launch_big(const GemmArgs& g0, hipStream_t s, int batch) {
         case 28: MH_LAUNCH((gemm_big_kernel<C, 0, MH_ACT_NONE, 28>), grid, block, 0, s, g); break;
         default: MH_LAUNCH((gemm_big_kernel<C, 0, MH_ACT_NONE, 14>), grid, block, 0, s, g); break;
       }
+    } else if (defer) {
+      if constexpr (C::NW == 4) {   // the operand combinations a post-LN encoder layer needs (engine.hip)
+        const int da = g.d.a_stats ? 1 : 0, dr = g.d.r_stats ? 1 : 0, dd = g.d.o_stats ? 1 : 0;
+        if (da && !dr && !dd && g.act == MH_ACT_GELU_ERF) MH_LAUNCH((gemm_big_kernel<C, 0, MH_ACT_GELU_ERF, 128>), grid, block, 0, s, g);   // FFN1
+        else if (da && !dr && !dd && g.act == MH_ACT_TANH) MH_LAUNCH((gemm_big_kernel<C, 0, MH_ACT_TANH, 128>), grid, block, 0, s, g);      // (down-projection)
+        else if (!da && !dr && dd && g.act == MH_ACT_NONE) MH_LAUNCH((gemm_big_kernel<C, 0, MH_ACT_NONE, 512>), grid, block, 0, s, g);      // first attention-output dense
+        else if (!da && dr && dd && g.act == MH_ACT_NONE) MH_LAUNCH((gemm_big_kernel<C, 0, MH_ACT_NONE, 768>), grid, block, 0, s, g);       // dense + raw residual -> raw rows
+        else if (!da && dr && !dd && g.act == MH_ACT_NONE) MH_LAUNCH((gemm_big_kernel<C, 0, MH_ACT_NONE, 256>), grid, block, 0, s, g);      // last FFN output dense
+        else { mh_set_error("gemm: unsupported deferred-LayerNorm operand combination (a=%d r=%d o=%d act=%d)", da, dr, dd, g.act); return MH_ERR_UNSUPPORTED; }
+      } else { mh_set_error("gemm: deferred LayerNorm needs the 256x128 tile"); return MH_ERR_UNSUPPORTED; }
     } else switch (g.act) {
       case MH_ACT_TANH: MH_LAUNCH((gemm_big_kernel<C, 0, MH_ACT_TANH>), grid, block, 0, s, g); break;
       case MH_ACT_GELU_ERF:
@@ -1047,6 +1180,7 @@ int launch(const GemmArgs& g, int dtype, hipStream_t s, int batch = 1) {
       if constexpr (EPI == 2) return MH_OK;
       // QKV scatter: a wave's columns must not straddle the q/k/v boundary (H % 64 == 0 for the wide tile)
       else {
+        if (g.d.a_stats || g.d.r_stats || g.d.o_stats) return launch_big<CfgStd, EPI>(g, s, batch);   // deferred LayerNorm: 256x128 only
         if (want_wide(g, batch) && (EPI != 1 || g.H % 64 == 0))
           return g_variant == 4 ? launch_big<CfgWide, EPI>(g, s, batch) : launch_big<CfgWidePP, EPI>(g, s, batch);
         return launch_big<CfgStd, EPI>(g, s, batch);
@@ -1121,6 +1255,40 @@ extern "C" int mh_gemm_bias_act_ex(const void* A, int64_t lda, int a_panel, cons
   g.M = M; g.N = N; g.K = K; g.act = act; g.dbg = g_dbg & 127;
   g.a_panel = a_panel; g.w_panel = w_panel; g.o_panel = o_panel; g.r_panel = residual ? r_panel : 0;
   return launch<0>(g, dtype, (hipStream_t)stream);
+}
+
+namespace {
+int fill_defer(const mh_ln_defer* d, GemmArgs& g, const char* who) {
+  if (!d) return MH_OK;
+  MH_CHECK_ARG(d->h_norm > 0 && d->eps >= 0.f, "%s: deferred LayerNorm needs the normalised width and eps", who);
+  MH_CHECK_ARG(!d->a_stats || (d->c1 && d->a_slots > 0), "%s: a_stats needs c1 and a_slots", who);
+  MH_CHECK_ARG(!d->r_stats || (d->r_gamma && d->r_beta && d->r_slots > 0 && g.residual), "%s: r_stats needs gamma, beta, r_slots and a residual", who);
+  MH_CHECK_ARG(!d->o_stats || d->o_slots >= ceil_div(g.N, 128), "%s: o_slots must cover the %d column tiles", who, ceil_div(g.N, 128));
+  g.d.a_stats = d->a_stats; g.d.a_slots = d->a_slots; g.d.c1 = d->c1;
+  g.d.r_stats = d->r_stats; g.d.r_slots = d->r_slots; g.d.r_gamma = d->r_gamma; g.d.r_beta = d->r_beta;
+  g.d.o_stats = d->o_stats; g.d.o_slots = d->o_slots;
+  g.d.inv_h = 1.0f / (float)d->h_norm; g.d.eps = d->eps;
+  return MH_OK;
+}
+}  // namespace
+
+// mh_gemm_bias_act_ex in the K32-panel layout (all four operands) with deferred-LayerNorm operands (struct mh_ln_defer):
+//   out = act(LN?(A) W^T + bias) [+ LN?(residual)], optionally writing the output rows' partial statistics.
+extern "C" int mh_gemm_bias_act_defer(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, const void* residual,
+                                      int64_t ldr, void* out, int64_t ldo, int64_t M, int N, int K, int act, const mh_ln_defer* defer,
+                                      mh_stream_t stream) {
+  MH_CHECK_ARG(A && W && out && bias, "gemm_bias_act_defer: null pointer");
+  MH_CHECK_ARG(M > 0 && N > 0 && N % 8 == 0 && K % B2K == 0, "gemm_bias_act_defer: bad problem M=%lld N=%d K=%d", (long long)M, N, K);
+  MH_CHECK_ARG(act == MH_ACT_NONE || act == MH_ACT_TANH || act == MH_ACT_GELU_ERF, "gemm_bias_act_defer: activation %d", act);
+  MH_CHECK_ARG(g_variant >= 2, "gemm_bias_act_defer: needs the big-tile bf16 kernel");
+  GemmArgs g{};
+  g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.bias = bias;
+  g.residual = residual; g.ldr = residual ? ldr : 8; g.out = out; g.ldo = ldo;
+  g.M = M; g.N = N; g.K = K; g.act = act;
+  g.a_panel = 1; g.w_panel = 1; g.o_panel = 1; g.r_panel = residual ? 1 : 0;
+  int rc = fill_defer(defer, g, "gemm_bias_act_defer");
+  if (rc) return rc;
+  return launch<0>(g, MH_BF16, (hipStream_t)stream);
 }
 
 // out = LayerNorm(A W^T + bias + residual) * gamma + beta over complete rows: the block owns all N columns
@@ -1215,7 +1383,16 @@ extern "C" int mh_gemm_qkv(const void* A, int64_t lda, const void* Wqkv, int64_t
 }
 
 namespace { int qkv_impl(const void* A, int64_t lda, int a_panel, const void* Wqkv, int64_t ldw, int w_panel, const float* bqkv,
-                         void* q, void* k, void* vt, int B, int L, int H, int nh, int dtype, int vt_perm, mh_stream_t stream); }
+                         void* q, void* k, void* vt, int B, int L, int H, int nh, int dtype, int vt_perm, mh_stream_t stream,
+                         const mh_ln_defer* defer = nullptr); }
+
+// mh_gemm_qkv_vtperm (panel operands) whose A rows are raw pre-LayerNorm values (defer->a_stats / c1; bqkv = c2)
+extern "C" int mh_gemm_qkv_vtperm_defer(const void* A, int64_t lda, const void* Wqkv, int64_t ldw, const float* c2, void* q, void* k,
+                                        void* vt_perm, int B, int L, int H, int nh, const mh_ln_defer* defer, mh_stream_t stream) {
+  MH_CHECK_ARG(L % 16 == 0, "gemm_qkv_vtperm_defer: seq_len %d must be a multiple of 16", L);
+  MH_CHECK_ARG(g_variant >= 2 && defer && defer->a_stats, "gemm_qkv_vtperm_defer: needs the big-tile bf16 kernel and a_stats");
+  return qkv_impl(A, lda, 1, Wqkv, ldw, 1, c2, q, k, vt_perm, B, L, H, nh, MH_BF16, 1, stream, defer);
+}
 
 extern "C" int mh_gemm_qkv_ex(const void* A, int64_t lda, int a_panel, const void* Wqkv, int64_t ldw, int w_panel,
                               const float* bqkv, void* q, void* k, void* vt, int B, int L, int H, int nh, int dtype,
@@ -1233,7 +1410,8 @@ extern "C" int mh_gemm_qkv_vtperm(const void* A, int64_t lda, int a_panel, const
 
 namespace {
 int qkv_impl(const void* A, int64_t lda, int a_panel, const void* Wqkv, int64_t ldw, int w_panel, const float* bqkv,
-             void* q, void* k, void* vt, int B, int L, int H, int nh, int dtype, int vt_perm, mh_stream_t stream) {
+             void* q, void* k, void* vt, int B, int L, int H, int nh, int dtype, int vt_perm, mh_stream_t stream,
+             const mh_ln_defer* defer) {
   MH_CHECK_ARG(A && Wqkv && bqkv && q && k && vt, "gemm_qkv: null pointer");
   MH_CHECK_ARG(H % 64 == 0, "gemm_qkv: hidden size %d must be a multiple of 64", H);
   MH_CHECK_ARG(nh > 0 && H % nh == 0 && (H / nh) % 8 == 0, "gemm_qkv: head dim must be a multiple of 8");
@@ -1244,6 +1422,8 @@ int qkv_impl(const void* A, int64_t lda, int a_panel, const void* Wqkv, int64_t 
   g.a_panel = a_panel; g.w_panel = w_panel;
   g.q = q; g.k = k; g.vt = vt; g.L = L; g.H = H; g.nh = nh; g.dh = H / nh;
   g.vt_perm = vt_perm;
+  int rcd = fill_defer(defer, g, "gemm_qkv");
+  if (rcd) return rcd;
   MH_CHECK_ARG(!vt_perm || (big_tile_ok(g) && H % 64 == 0), "gemm_qkv_vtperm: shape not served by the big-tile kernel");
   return launch<1>(g, dtype, (hipStream_t)stream);
 }

@@ -75,6 +75,10 @@ class DenoiserEngine:
             mat(p + "w_ff1", F, H); vec(p + "b_ff1", F)
             mat(p + "w_ff2", H, F); vec(p + "b_ff2", H)
             vec(p + "ln2_g", H); vec(p + "ln2_b", H)
+            if c["panel"]:   # deferred LayerNorm (csrc/gemm.hip DeferArgs): weights folded with the gain of the LayerNorm feeding them
+                if l > 0:
+                    mat(p + "w_qkv_f", 3 * H, H); vec(p + "c1_qkv", 3 * H); vec(p + "c2_qkv", 3 * H)
+                mat(p + "w_ff1_f", F, H); vec(p + "c1_ff1", F); vec(p + "c2_ff1", F)
         plan["total"] = off
         return plan
 
@@ -93,7 +97,8 @@ class DenoiserEngine:
             setattr(d, k, self._addr(k) if c["has_proj"] else None)
         for l in range(c["nL"]):
             for k, _ in LayerWeights._fields_:
-                setattr(self._layers[l], k, self._addr("l%d.%s" % (l, k)))
+                name = "l%d.%s" % (l, k)
+                setattr(self._layers[l], k, self._addr(name) if name in self._plan else None)
         d.layers = C.cast(self._layers, C.POINTER(LayerWeights))
 
     # ------------------------------------------------------------------ packing
@@ -141,7 +146,24 @@ class DenoiserEngine:
             self._put_mat(p + "w_ff2", sd[s + "output.dense.weight"]); self._put_vec(p + "b_ff2", sd[s + "output.dense.bias"])
             self._put_vec(p + "ln2_g", sd[s + "output.LayerNorm.weight"])
             self._put_vec(p + "ln2_b", sd[s + "output.LayerNorm.bias"])
+            if c["panel"]:
+                f32 = lambda t: t.detach().to(self.device, torch.float32)
+                if l > 0:
+                    ps = "input_transformers.layer.%d." % (l - 1)
+                    bq = torch.cat([f32(sd[s + "attention.self.%s.bias" % nm]) for nm in ("query", "key", "value")])
+                    self._put_folded(p, "qkv", torch.cat(qkv, dim=0), bq, f32(sd[ps + "output.LayerNorm.weight"]), f32(sd[ps + "output.LayerNorm.bias"]))
+                self._put_folded(p, "ff1", f32(sd[s + "intermediate.dense.weight"]), f32(sd[s + "intermediate.dense.bias"]),
+                                 f32(sd[s + "attention.output.LayerNorm.weight"]), f32(sd[s + "attention.output.LayerNorm.bias"]))
         return self
+
+    def _put_folded(self, p, nm, W, b, gamma, beta):
+        """Deferred LayerNorm operands of a dense layer fed by LN(y) = (y - mean) rstd gamma + beta:  W' = gamma o W (rounded to the
+        compute dtype FIRST, so that c1 = row sums of exactly the matrix the MFMA multiplies), c1 = sum_k W'[:, k],
+        c2 = sum_k beta_k W[:, k] + b.  One-time weight preprocessing, like the casts."""
+        Wf = (W * gamma[None, :]).to(ops.TORCH_DTYPE[self.dtype]).to(torch.float32)
+        self._put_mat(p + "w_%s_f" % nm, Wf)
+        self._put_vec(p + "c1_" + nm, Wf.sum(dim=1))
+        self._put_vec(p + "c2_" + nm, (W * beta[None, :]).sum(dim=1) + b)
 
     # ------------------------------------------------------------------ execution
     def _workspace(self, B, L):
