@@ -871,7 +871,9 @@ extern "C" int mh_attention_stream_fwd_drop(const void* q, const void* k, const 
   const int nbh = B * nh;
   const float sl2 = scale * 1.4426950408889634f;
   const bf16 *Q = (const bf16*)q, *K = (const bf16*)k, *V = (const bf16*)vt_perm;
-  const bool small = g_attn_stream == 2;   // 8 waves x 128-key stages: half a CU per block
+  // 8 waves x 128-key stages: half a CU per block.  The dropout variant always runs there: its mask generation needs ~30
+  // registers more than the 128 a 16-wave block leaves each wave (the 16-wave build spilled 82 dwords per lane: 3.5x slower)
+  const bool small = g_attn_stream == 2 || dropping;
   const int qper = small ? 256 : 512, nitems = nbh * ((L + qper - 1) / qper);
   const int slots = small ? 2 * cus : cus;
   const dim3 grid((unsigned)(nitems < slots ? nitems : slots)), block(small ? 512 : 1024);
@@ -886,7 +888,7 @@ extern "C" int mh_attention_stream_fwd_drop(const void* q, const void* k, const 
     return MH_OK;
   };
   int rc;
-  if (dropping) rc = dh == 64 ? go(&attn_stream_bf16_kernel<64, 16, 256, true>, 4 * 256 * 64 * 2) : go(&attn_stream_bf16_kernel<32, 16, 256, true>, 4 * 256 * 32 * 2);
+  if (dropping) rc = dh == 64 ? go(&attn_stream_bf16_kernel<64, 8, 128, true>, 4 * 128 * 64 * 2) : go(&attn_stream_bf16_kernel<32, 8, 256, true>, 4 * 256 * 32 * 2);
   else if (dh == 64) rc = small ? go(&attn_stream_bf16_kernel<64, 8, 128>, 4 * 128 * 64 * 2) : go(&attn_stream_bf16_kernel<64, 16, 256>, 4 * 256 * 64 * 2);
   else rc = small ? go(&attn_stream_bf16_kernel<32, 8, 256>, 4 * 256 * 32 * 2) : go(&attn_stream_bf16_kernel<32, 16, 256>, 4 * 256 * 32 * 2);
   if (rc) return rc;

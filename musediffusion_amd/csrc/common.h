@@ -159,6 +159,7 @@ __device__ __forceinline__ void mh_philox(uint32_t (&c)[4], uint32_t k0, uint32_
 // decision takes 16 random bits: keep <=> u16 >= thr, thr = round(p * 65536), so the drop rate is p to 2^-17.
 // Device-side view of mh_dropout (include/musehip.h): all by value, usable inside kernel argument structs.
 struct DropArgs {
+  uint32_t thr8, thr_tie;  // attention probabilities: 8-bit threshold floor(256 p) and the 8-bit tie-break threshold (below)
   uint32_t thr;            // 0: dropout off
   float rscale;            // 1 / (1 - p)
   uint32_t seed_lo, seed_hi, off_lo, off_hi;
@@ -189,22 +190,24 @@ __device__ __forceinline__ uint32_t drop_keep8_at(const DropArgs& d, uint64_t e0
   }
   return drop_keep8(d, e0 >> 3);
 }
-// attention probabilities: the keep flags of one lane of an S^T tile (query q, lane half h) for the 32-key block kb:
-// two calls (a = 0, 1) cover keys 16 a + 8 jj + 4 h + e (jj 0..1, e 0..3) = registers r = 8 a + 4 jj + e of the 32x32x16
-// accumulator.  Returns bit r set <=> P[q][32 kb + key(r)] is KEPT.  nkb = ceil(L / 32).
+// attention probabilities: the keep flags of one lane of an S^T tile (query q, lane half h) for the 32-key block kb.  ONE
+// Philox call gives the lane's 16 elements a random BYTE each (register r of the 32x32x16 accumulator <-> byte r of the 128
+// bits <-> key (r & 3) + 8 (r >> 2) + 4 h): the element is dropped when its byte is below thr8 = floor(256 p), kept when above,
+// and on the tie (probability 2^-8) decided by the NEXT byte against thr_tie = round(256 frac(256 p)) - so the drop rate is p to
+// 2^-16, as at the dense sites, at half the generator work (the forward is VALU-bound).  The tie-break byte is another
+// element's primary byte: a dependence that touches 0.4% of the elements.  nkb = ceil(L / 32).
+// Returns bit r set <=> P[q][32 kb + key(r)] is KEPT.
 __device__ __forceinline__ uint32_t drop_keep_attn(const DropArgs& d, int64_t bh, int L, int nkb, int q, int kb, int h) {
-  const uint64_t base = ((((uint64_t)bh * L + q) * nkb + kb) << 2) | (uint64_t)h;
+  const uint64_t idx = ((((uint64_t)bh * L + q) * nkb + kb) << 1) | (uint64_t)h;
+  uint32_t c[4] = {(uint32_t)idx, (uint32_t)(idx >> 32), d.off_lo, d.off_hi};
+  mh_philox<7>(c, d.seed_lo, d.seed_hi);
   uint32_t m = 0;
 #pragma unroll
-  for (int a = 0; a < 2; ++a) {
-    const uint64_t idx = base | ((uint64_t)a << 1);
-    uint32_t c[4] = {(uint32_t)idx, (uint32_t)(idx >> 32), d.off_lo, d.off_hi};
-    mh_philox<7>(c, d.seed_lo, d.seed_hi);
-#pragma unroll
-    for (int w = 0; w < 4; ++w) {
-      m |= ((c[w] & 0xffffu) >= d.thr ? 1u : 0u) << (8 * a + 2 * w);
-      m |= ((c[w] >> 16) >= d.thr ? 1u : 0u) << (8 * a + 2 * w + 1);
-    }
+  for (int r = 0; r < 16; ++r) {
+    const uint32_t b = (c[r >> 2] >> (8 * (r & 3))) & 0xffu;
+    const uint32_t b2 = (c[((r + 1) & 15) >> 2] >> (8 * ((r + 1) & 3))) & 0xffu;
+    const bool keep = b > d.thr8 || (b == d.thr8 && b2 >= d.thr_tie);
+    m |= (keep ? 1u : 0u) << r;
   }
   return m;
 }

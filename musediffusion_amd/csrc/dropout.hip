@@ -14,6 +14,9 @@ int mh_drop_args(const mh_dropout* d, DropArgs* out) {
   if (d && d->p > 0.f) {
     MH_CHECK_ARG(d->p < 1.f, "dropout: p=%g must be in [0, 1)", (double)d->p);
     a.thr = (uint32_t)(d->p * 65536.0f + 0.5f);
+    const float p256 = d->p * 256.0f;
+    a.thr8 = (uint32_t)p256;                                            // floor
+    a.thr_tie = (uint32_t)((p256 - (float)a.thr8) * 256.0f + 0.5f);     // drop on the tie when the next byte is below this
     a.rscale = 1.0f / (1.0f - d->p);
     a.seed_lo = (uint32_t)d->seed; a.seed_hi = (uint32_t)(d->seed >> 32);
     a.off_lo = (uint32_t)d->offset; a.off_hi = (uint32_t)(d->offset >> 32);

@@ -24,8 +24,23 @@ def per_kernel(d, counter):
     return {k: (sum(v) / len(v), len(v)) for k, v in acc.items()}
 
 
+import re
+
+
+def variant_of(kernel_name):
+    """rocprof kernel name -> the variant string bench.py reports for its dominant kernel (tile + epilogue signature)"""
+    m = re.search(r"gemm_big_kernel<BigCfg<(\d+), (\d+), \d+, \d+, \d+, (true|false)>, (\d+), (\d+), (\d+)>", kernel_name)
+    if not m:
+        return kernel_name
+    bm, bn, pp, epi, act, dbg = m.groups()
+    role = {"3": "dense+bias+residual+LayerNorm", "1": "QKV projection + head scatter"}.get(epi) or (
+        "dense+GELU (FFN1)" if act == "2" else "dense+tanh" if act == "1" else "dense")
+    return "gemm_big_kernel<%sx%s%s, EPI=%s> bf16 %s" % (bm, bn, "pp" if pp == "true" else "", epi, role)
+
+
 fetch, write = per_kernel(sys.argv[1], "FETCH_SIZE"), per_kernel(sys.argv[2], "WRITE_SIZE")
 key = sys.argv[3]
+outdir = sys.argv[4] if len(sys.argv) > 4 else "gpurun_out"
 rows = []
 for k in fetch:
     fk, n = fetch[k]
@@ -39,8 +54,8 @@ dom = [r for r in rows if "gemm_big_kernel" in r[1][0] and ", 3, 0, 0>" in r[1][
       [r for r in rows if "gemm_big_kernel" in r[1][0] and ", 0, 2, 0>" in r[1][0]]
 if dom:
     tot, k, n, fk, wk = dom[0]
-    rec = {key: {"kernel": k[0], "launches_sampled": n, "fetch_kib": fk, "write_kib": wk,
+    rec = {key: {"kernel": k[0], "variant": variant_of(k[0]), "launches_sampled": n, "fetch_kib": fk, "write_kib": wk,
                  "traffic_bytes_per_launch": (2 * fk + wk) * 1024,
                  "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; FETCH_SIZE doubled (gfx950)"}}
-    json.dump(rec, open("gpurun_out/pmc_traffic.json", "w"), indent=1)
+    json.dump(rec, open(outdir + "/pmc_traffic.json", "w"), indent=1)
     print("dominant kernel (%s): %.1f MB per launch" % (k[0][:70], rec[key]["traffic_bytes_per_launch"] / 1e6))
