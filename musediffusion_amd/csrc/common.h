@@ -125,6 +125,13 @@ __device__ __forceinline__ float gelu_erf_fast(float x) {
   return x * __builtin_amdgcn_rcpf(1.0f + e);
 }
 
+// tanh for the bf16 path: 1 - 2 / (1 + 2^(2 x log2 e)) with one v_exp and one v_rcp (|error| < 3e-7 relative to fp32 tanh for
+// |x| < 10, exact saturation beyond: two orders below the bf16 rounding of the result); the fp32 parity path uses tanhf
+__device__ __forceinline__ float tanh_fast(float x) {
+  const float e = __builtin_amdgcn_exp2f(fminf(x * 2.885390081777927f, 126.0f));
+  return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + e);
+}
+
 // d/dx of the erf-form GELU, Phi(x) + x phi(x), for the fused backward epilogue: erf by Abramowitz-Stegun 7.1.26
 // (|err| <= 1.5e-7); exp(-x^2/2) is shared between the erf tail and the density
 __device__ __forceinline__ float gelu_erf_grad(float x) {

@@ -74,7 +74,7 @@ constexpr int BM = 128, BN = 128, CS_LD = 68;
 template <typename T>
 __device__ __forceinline__ float apply_act(float v, int act) {
   switch (act) {
-    case MH_ACT_TANH: return tanhf(v);
+    case MH_ACT_TANH: return sizeof(T) == 2 ? tanh_fast(v) : tanhf(v);
     case MH_ACT_GELU_ERF: return sizeof(T) == 2 ? gelu_erf_fast(v) : gelu_erf(v);
     case MH_ACT_SILU: return silu(v);
     default: return v;
