@@ -2,7 +2,7 @@
 
 The reference walks every sequence token by token in Python (`get_vectors`) and then multiplies three small similarity
 matrices; here one kernel launch extracts the [32 rhythm | 12 melody | 12 harmony] features of all sequences and the
-matrix part stays the reference's three matmuls (on the device)."""
+three similarity matrices come from the library's exact-fp32 MFMA GEMM."""
 import torch
 
 from ._lib import check, current_stream, lib, ptr, require_device
@@ -20,10 +20,20 @@ def get_vectors(tokens, lengths=None, note_len=128, return_status=False):
     return (out, status) if return_status else out
 
 
+def _gram(a, b):
+    """a b^T for [Ba, C] x [Bb, C] fp32 on the library's exact-fp32 MFMA GEMM (C zero-padded to the kernel's K granule of 16)."""
+    from . import ops
+    C = a.shape[1]
+    Cp = (C + 15) // 16 * 16
+    pad = lambda t: ops.cast_pad(t.contiguous(), Cp, ops.MH_F32)
+    return ops.gemm_bias_act(pad(a), pad(b), None, None, None, ops.MH_F32, out_f32=True, N=b.shape[0], K=Cp)
+
+
 def _similarity(vec_a, vec_b):
-    r = vec_a[:, :32] @ vec_b[:, :32].T
-    m = vec_a[:, 32:44] @ vec_b[:, 32:44].T
-    h = vec_a[:, 44:] @ vec_b[:, 44:].T
+    """metric.py:96-104: rhythm x melody x harmony similarity matrices, multiplied element-wise"""
+    r = _gram(vec_a[:, :32], vec_b[:, :32])
+    m = _gram(vec_a[:, 32:44], vec_b[:, 32:44])
+    h = _gram(vec_a[:, 44:], vec_b[:, 44:])
     return r * m * h
 
 

@@ -401,3 +401,32 @@ def test_bf16_config2_shape_against_oracle():
     # where the token decision agrees the rounded x0 is the same embedding row, so the posterior sample is the oracle's to fp32 rounding
     ds = (out["sample"].cpu() - ref_step["sample"]).abs()[same]
     assert float(ds.max()) < 1e-5
+
+
+@pytest.mark.parametrize("use_graph", [False, True], ids=["eager", "hipgraph"])
+def test_respaced_loop_with_non_identity_timestep_map(use_graph):
+    """timestep_respacing "ddim25" (reference: space_timesteps + SpacedDiffusion, diffusion.py:920-1017): 25 retained steps whose
+    `timestep_map` is not the identity, so the fused loop must look the model's timestep up through the map and rescale by the
+    ORIGINAL step count (_WrappedModel, :1020-1032).  Final tokens of a p_sample loop over all 25 steps against the oracle."""
+    from oracle import denoiser as odn, schedule as osc
+    tag = "tiny"
+    c = fx.CONFIGS[tag]
+    sd = fx.state_dict(tag)
+    m, _, model_emb, inp, _ = build(tag)
+    diff = SpacedDiffusion(use_timesteps=space_timesteps(2000, "ddim25"), betas=get_named_beta_schedule("sqrt", 2000),
+                           rescale_timesteps=True, predict_xstart=True)
+    assert diff.num_timesteps == 25 and diff.timestep_map != list(range(25))
+    B, L, E = c["B"], c["L"], c["E"]
+    x_start, mask3 = inp["x_start"], inp["mask3"]
+    x_gen = osa.start_latent_generation(x_start, mask3, inp["gen_noise0"])
+    nz = loop_noises(4242, (B, L, E), 25, 1)
+    d = osc.make_diffusion(timestep_respacing="ddim25")
+    ref = osa.p_sample_loop(d, lambda x, ts: odn.forward(sd, x, ts, c["nh"]), (B, L, E), x_gen, True, sd["word_embedding.weight"],
+                            top_p=1, clamp_step=0, clamp_first=True, mask=mask3, x_start=x_start, step_noise=lambda k, i, x: nz[k])
+    diff.use_graph = use_graph
+    diff.noise_fn = lambda k, i, x: nz[k].to(DEV)
+    fn = partial(denoised_fn_round, model_emb.to(DEV), dist=None)
+    got = diff.p_sample_loop(m, (B, L, E), noise=x_gen.to(DEV), clip_denoised=True, denoised_fn=fn, model_kwargs={}, top_p=1,
+                             clamp_step=0, clamp_first=True, mask=mask3.to(DEV), x_start=x_start.to(DEV), only_last=True)[-1]
+    assert torch.equal(m.argmax_tokens(got).cpu(), odn.get_logits(sd, ref).argmax(-1))
+    assert maxerr(got.cpu(), ref) < 2e-5

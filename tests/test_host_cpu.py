@@ -177,3 +177,24 @@ def test_batch_and_metric_modules_refuse_cpu_tensors():
     assert c.corr_kwargs == {"p": 0.25} and c.corr_max == 1
     with pytest.raises(AssertionError):
         mdata.Corruptions(("zz",), 1, 0.5)
+
+
+def test_reference_written_checkpoint_loads_on_cpu():
+    """tests/golden/ref_ckpt/ was written by the REFERENCE's model class and torch.optim.AdamW with the reference's own save calls
+    (tools/make_golden.py gen_reference_checkpoint; utils/train_util.py:294-319).  Its keys / shapes must load strictly."""
+    import os
+    from conftest import GOLDEN
+    from musediffusion_amd import checkpoint
+    from musediffusion_amd.models.network import TransformerNetModel
+    d = os.path.join(GOLDEN, "ref_ckpt")
+    f = np.load(os.path.join(d, "forward.npz"))
+    c = {k[4:]: int(f[k]) for k in f.files if k.startswith("cfg_")}
+    m = TransformerNetModel(c["E"], c["E"], c["Tt"], c["V"], c["L"], bert_hidden=c["H"], bert_layers=c["nL"], bert_heads=c["nh"], bert_ffn=c["F"])
+    main = checkpoint.find_resume_checkpoint(d)
+    assert os.path.basename(main) == "model_000007.pt" and checkpoint.parse_resume_step_from_filename(main) == 7
+    sd = torch.load(main, map_location="cpu")
+    missing, unexpected = m.load_state_dict(sd, strict=True), None
+    assert set(sd) == set(m.state_dict())
+    assert checkpoint.find_ema_checkpoint(main, 7, "0.9999").endswith("ema_0.9999_000007.pt")
+    osd = torch.load(os.path.join(d, "opt_000007.pt"), map_location="cpu")
+    assert len(osd["state"]) == len(list(m.parameters())) and set(osd["state"][0]) >= {"step", "exp_avg", "exp_avg_sq"}

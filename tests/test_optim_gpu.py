@@ -74,3 +74,32 @@ def test_checkpoint_round_trip_reference_format(tmp_path):
         assert torch.equal(a, b)
     assert opt2.step_count == 1 and torch.equal(opt2.exp_avg[5], opt.exp_avg[5]) and torch.equal(opt2.ema[1][3], opt.ema[1][3])
     assert checkpoint.resume(str(tmp_path / "nope"), m2) == 0
+
+
+def test_resume_from_a_checkpoint_the_reference_wrote():
+    """Resume from tests/golden/ref_ckpt/ (written by the reference's own model class + torch.optim.AdamW, tools/make_golden.py):
+    parameters, EMA copy and Adam moments arrive bit for bit, and the forward on the loaded weights equals the reference's recorded
+    forward (fp32 mode, 1e-4)."""
+    import numpy as np
+    from conftest import GOLDEN
+    from musediffusion_amd.models.network import TransformerNetModel
+    d = os.path.join(GOLDEN, "ref_ckpt")
+    f = np.load(os.path.join(d, "forward.npz"))
+    c = {k[4:]: int(f[k]) for k in f.files if k.startswith("cfg_")}
+    m = TransformerNetModel(c["E"], c["E"], c["Tt"], c["V"], c["L"], bert_hidden=c["H"], bert_layers=c["nL"], bert_heads=c["nh"],
+                            bert_ffn=c["F"], compute_dtype="fp32").to(DEV)
+    opt = FusedAdamWEMA(m.parameters(), lr=3e-4, ema_rates=(0.9999,))
+    assert checkpoint.resume(d, m, opt, ema_rates=("0.9999",)) == 7
+    sd = torch.load(os.path.join(d, "model_000007.pt"), map_location="cpu")
+    for n, p in m.named_parameters():
+        assert torch.equal(p.detach().cpu(), sd[n]), n
+    esd = torch.load(os.path.join(d, "ema_0.9999_000007.pt"), map_location="cpu")
+    for j, (n, _) in enumerate(m.named_parameters()):
+        assert torch.equal(opt.ema[0][j].cpu(), esd[n]), n
+    osd = torch.load(os.path.join(d, "opt_000007.pt"), map_location="cpu")
+    assert opt.step_count == 1 and abs(opt.lr - 1e-4) < 1e-12
+    for i in (0, 3, len(opt.params) - 1):
+        assert torch.equal(opt.exp_avg[i].cpu(), osd["state"][i]["exp_avg"]) and torch.equal(opt.exp_avg_sq[i].cpu(), osd["state"][i]["exp_avg_sq"])
+    m.eval().requires_grad_(False)
+    y = m(torch.from_numpy(f["x"]).to(DEV), torch.from_numpy(f["t"]).to(DEV)).cpu().numpy()
+    assert float(np.abs(y - f["y"]).max()) < 1e-4

@@ -221,3 +221,44 @@ def test_every_parameter_gradient_matches_oracle(tag, variant):
         if err > 2e-3 * scale + 1e-7:
             bad.append((n, err, scale))
     assert not bad, bad
+
+
+def test_bf16_fused_training_at_seq_len_1024_against_oracle():
+    """BASELINE config 5's sequence length (1024) through the bf16 training kernels that run there - streaming attention forward,
+    fused dQ / dK-dV backward, one-node FFN, k-major weight-gradient GEMM - against the fp32 CPU oracle (torch autograd over the
+    restated reference ops), same draws, dropout off.  Stated bf16 tolerance: losses 3e-2, every weight-matrix gradient cosine
+    > 0.99 against the oracle's (bf16 activations and bf16 gradient tensors through 2 layers)."""
+    from oracle import denoiser as odn, losses as olo, schedule as osc
+    from musediffusion_amd import synthetic
+    E, H, F, nL, nh, V, L, B, Tt = 32, 128, 256, 2, 2, 97, 1024, 2, 32
+    sd = odn.random_state_dict(E, H, F, nL, V, L, Tt, seed=31, emb_std=fx.EMB_STD)
+    m = TransformerNetModel(E, E, Tt, V, L, dropout=0.0, bert_hidden=H, bert_layers=nL, bert_heads=nh, bert_ffn=F, compute_dtype="bf16",
+                            bert_hidden_dropout=0.0, bert_attention_dropout=0.0)
+    m.load_state_dict(sd)
+    m.train().requires_grad_(True).to(DEV)
+    diff = SpacedDiffusion(use_timesteps=space_timesteps(2000, [2000]), betas=get_named_beta_schedule("sqrt", 2000),
+                           rescale_timesteps=True, predict_xstart=True)
+    tb = synthetic.training_batch(B, L, seed=6)
+    batch = {"input_ids": tb["input_ids"] % V, "correct_ids": tb["correct_ids"] % V, "input_mask": tb["input_mask"]}
+    t = torch.tensor([250, 1700])
+    with CpuDraws(41):
+        terms = diff.training_losses(m, t.to(DEV), model_kwargs=batch)
+    terms["loss"].mean().backward()
+    ref_sd = {k: v.clone() for k, v in sd.items()}
+    names = [n for n, _ in m.named_parameters()]
+    for n in names:
+        ref_sd[n].requires_grad_(True)
+    ref_sd["lm_head.weight"] = ref_sd["word_embedding.weight"]
+    torch.manual_seed(41)
+    ref = olo.training_losses(osc.make_diffusion(), lambda x, ts: odn.forward(ref_sd, x, ts, nh), lambda ids: odn.get_embeds(ref_sd, ids),
+                              lambda h: odn.get_logits(ref_sd, h), t, batch["input_ids"], batch["input_mask"], correct_ids=batch["correct_ids"])
+    ref["loss"].mean().backward()
+    assert torch.allclose(terms["loss"].detach().cpu(), ref["loss"].detach(), rtol=3e-2, atol=3e-2)
+    worst = (1.0, "")
+    for n, p in m.named_parameters():
+        if p.dim() < 2 or "position_embeddings" in n:
+            continue
+        cos = float(torch.nn.functional.cosine_similarity(p.grad.detach().cpu().flatten(), ref_sd[n].grad.flatten(), dim=0))
+        worst = min(worst, (cos, n))
+    print("worst weight-gradient cosine vs the fp32 oracle: %.5f (%s)" % worst)
+    assert worst[0] > 0.99, worst

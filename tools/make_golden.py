@@ -302,9 +302,40 @@ def gen_losses_dropout(tag):
     print("losses_%s_dropout.npz" % tag, len(out), "arrays")
 
 
+def gen_reference_checkpoint():
+    """A checkpoint directory as the REFERENCE writes it (utils/train_util.py:294-319: `th.save(model.state_dict())`,
+    `th.save(opt.state_dict())`, one `ema_{rate}_{step:06d}.pt` per rate) from the reference's own model class and
+    torch.optim.AdamW, at a micro shape so that the files stay a few tens of KB; plus the reference's forward on the saved weights."""
+    cfg = dict(H=64, nL=1, nh=2, F=64, E=16, Tt=16, L=8, B=2, V=60)
+    torch.manual_seed(4321)
+    model, diffusion = build(cfg)
+    model.train()
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=0.0)
+    g = torch.Generator().manual_seed(77)
+    for p_ in model.parameters():
+        p_.grad = torch.randn(p_.shape, generator=g) * 0.01
+    opt.step()
+    ema = {k: v.detach().clone() * 0.999 for k, v in model.state_dict().items()}     # stands for an EMA copy: any tensors under the model's keys
+    d = os.path.join(OUT, "ref_ckpt")
+    os.makedirs(d, exist_ok=True)
+    step = 7
+    torch.save(model.state_dict(), os.path.join(d, "model_%06d.pt" % step))
+    torch.save(ema, os.path.join(d, "ema_0.9999_%06d.pt" % step))
+    torch.save(opt.state_dict(), os.path.join(d, "opt_%06d.pt" % step))
+    model.eval()
+    x = fx.seeded_randn(31, cfg["B"], cfg["L"], cfg["E"])
+    t = torch.tensor([12.5, 700.0])
+    with torch.no_grad():
+        y = model(x, t)
+    np.savez_compressed(os.path.join(d, "forward.npz"), x=npy(x), t=npy(t), y=npy(y), **{"cfg_" + k: np.array(v) for k, v in cfg.items()})
+    print("ref_ckpt:", sorted(os.listdir(d)))
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     only = sys.argv[1:]
+    if not only or "ckpt" in only:
+        gen_reference_checkpoint()
     if not only or "base" in only:
         gen_schedules()
         gen_model_case("tiny", compact=False)
