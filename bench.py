@@ -533,7 +533,8 @@ def main():
 
     total = args.warmup + args.steps
     PROF_STEPS = 4
-    indices = list(range(c["T"]))[::-1][:total + PROF_STEPS + 2]
+    need = total + PROF_STEPS + 2
+    indices = (list(range(c["T"]))[::-1] * (need // c["T"] + 1))[:need]     # (a timed region longer than T steps wraps around)
     loop = _ReverseLoop.try_build(diff, "p", model, x_noised, True, fn, 1, mask3, x_start, 0.0, indices,
                                   lambda i: fn, False)
     assert loop is not None, "fused reverse loop unavailable"
