@@ -562,6 +562,8 @@ int mh_denoiser_get_defer_ln(void);
  * "kernel\tdetail\tgrid\tblock\tstream\tmilliseconds\n", into `out`; it returns the bytes the whole report needs. */
 /* experiment knob (A/B only): co-resident partner blocks of the big-tile GEMMs start `ticks` x 10 ns late */
 int mh_gemm_set_stagger(int ticks);
+/* experiment knob (A/B only): LDS-DMA pieces of the 256x128 kernels issued between the MFMA rows instead of as one burst */
+int mh_gemm_set_spread(int on);
 int mh_profile_start(void);
 int64_t mh_profile_stop(char* out, size_t cap);
 

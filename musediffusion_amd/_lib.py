@@ -154,6 +154,7 @@ SIGNATURES = {
     "mh_denoiser_get_fuse_ln": (INT, []),
     "mh_gemm_set_debug": (INT, [INT]),
     "mh_gemm_set_stagger": (INT, [INT]),
+    "mh_gemm_set_spread": (INT, [INT]),
     "mh_gemm_set_plain_stores": (INT, [INT]),
     "mh_graph_begin_capture": (INT, [VP]),
     "mh_graph_end_capture": (INT, [VP, C.POINTER(VP)]),

@@ -413,6 +413,23 @@ __device__ __forceinline__ void issue_stage(const char* smem, const char* const 
                                      (__attribute__((address_space(3))) void*)(base + C::BM * 64 + ldsW[j]), 16, 0, 0);
 }
 
+// piece p (0 .. PA + PW - 1) of DMA stage kt: the same transfers as issue_stage, one at a time (interleaved issue, DBG bit 1024)
+template <class C>
+__device__ __forceinline__ void issue_piece(const char* smem, const char* const (&srcA)[C::PA], const char* const (&srcW)[C::PW],
+                                            const int (&ldsA)[C::PA], const int (&ldsW)[C::PW], int kt, int64_t kstepA, int64_t kstepW, int p) {
+  char* base = const_cast<char*>(smem) + (kt % C::NST) * C::STAGE;
+#pragma unroll
+  for (int j = 0; j < C::PA; ++j)
+    if (p == j)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcA[j] + kt * kstepA),
+                                       (__attribute__((address_space(3))) void*)(base + ldsA[j]), 16, 0, 0);
+#pragma unroll
+  for (int j = 0; j < C::PW; ++j)
+    if (p == C::PA + j)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcW[j] + kt * kstepW),
+                                       (__attribute__((address_space(3))) void*)(base + C::BM * 64 + ldsW[j]), 16, 0, 0);
+}
+
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 // wait until all but the youngest `stages` DMA stages (PIECES loads each) of this wave have landed; EXTRA = vector-memory
 // operations of another kind (the previous tile's epilogue stores) issued after the awaited stage (vmcnt counts in issue order)
@@ -495,13 +512,16 @@ __device__ __forceinline__ void big_mainloop(f32x4 (&acc)[C::TI][C::TJ], const c
     pt0 = tick();
     pt_bar += pt0 - pt1;
     pt1 = pt0;
-    if (kt + C::NST < nk) issue(kt + C::NST);   // slot kt % NST: every wave has read stage kt out of it
+    constexpr bool SPREAD = (DBG & 1024) != 0 && C::PIECES <= TI;   // one DMA piece behind each MFMA row instead of a burst
+    const bool refill = kt + C::NST < nk;
+    if (!SPREAD && refill) issue(kt + C::NST);   // slot kt % NST: every wave has read stage kt out of it
 #pragma unroll
     for (int j = 0; j < TJ; ++j) bn[j] = read_frag(Ws + b_offs[j]);
 #pragma unroll
     for (int i = 0; i < TI; ++i) {
       mfma_row(i);
       a[i] = read_frag(As + a_off + i * (16 * 64));
+      if constexpr (SPREAD) { if (refill && i < C::PIECES) issue_piece<C>(smem, srcA, srcW, ldsA, ldsW, kt + C::NST, kstepA, kstepW, i); }
       __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
@@ -1065,6 +1085,7 @@ __global__ __launch_bounds__(C::THREADS, C::STAGE * C::NST <= 80 * 1024 ? 2 : 1)
 }
 
 int g_dbg = 0;
+int g_spread = 0;     // A/B: DMA pieces interleaved with the MFMA rows (DBG bit 1024 kernels)
 int g_stagger = 0;
 int g_variant = 2;  // bf16 kernel choice: 0 small-tile register-staged, 1 small-tile global_load_lds, 2 / 3 big 256x128, 4 big 256x256, 5 big 256x256 ping-pong
 
@@ -1101,6 +1122,7 @@ int launch_big(const GemmArgs& g0, hipStream_t s, int batch) {
         MH_LAUNCH((gemm_big_kernel<C, 1, MH_ACT_NONE, 128>), grid, block, 0, s, g);
       } else { mh_set_error("gemm: deferred LayerNorm needs the 256x128 tile"); return MH_ERR_UNSUPPORTED; }
     }
+    else if (g_spread && C::NW == 4) { if constexpr (C::NW == 4) MH_LAUNCH((gemm_big_kernel<C, 1, MH_ACT_NONE, 1024>), grid, block, 0, s, g); }
     else if (g_plain_stores & 1) MH_LAUNCH((gemm_big_kernel<C, 1, MH_ACT_NONE, 32>), grid, block, 0, s, g);
     else MH_LAUNCH((gemm_big_kernel<C, 1, MH_ACT_NONE>), grid, block, 0, s, g);
   } else if constexpr (EPI == 3) {
@@ -1132,12 +1154,14 @@ int launch_big(const GemmArgs& g0, hipStream_t s, int batch) {
     } else switch (g.act) {
       case MH_ACT_TANH: MH_LAUNCH((gemm_big_kernel<C, 0, MH_ACT_TANH>), grid, block, 0, s, g); break;
       case MH_ACT_GELU_ERF:
-        if (g_plain_stores & 2) MH_LAUNCH((gemm_big_kernel<C, 0, MH_ACT_GELU_ERF, 32>), grid, block, 0, s, g);
+        if (g_spread && C::NW == 4) { if constexpr (C::NW == 4) MH_LAUNCH((gemm_big_kernel<C, 0, MH_ACT_GELU_ERF, 1024>), grid, block, 0, s, g); }
+        else if (g_plain_stores & 2) MH_LAUNCH((gemm_big_kernel<C, 0, MH_ACT_GELU_ERF, 32>), grid, block, 0, s, g);
         else MH_LAUNCH((gemm_big_kernel<C, 0, MH_ACT_GELU_ERF>), grid, block, 0, s, g);
         break;
       case MH_ACT_SILU: MH_LAUNCH((gemm_big_kernel<C, 0, MH_ACT_SILU>), grid, block, 0, s, g); break;
       default:
-        if (g.drop.thr) MH_LAUNCH((gemm_big_kernel<C, 0, MH_ACT_NONE, 64>), grid, block, 0, s, g);
+        if (g_spread && C::NW == 4 && !g.drop.thr) { if constexpr (C::NW == 4) MH_LAUNCH((gemm_big_kernel<C, 0, MH_ACT_NONE, 1024>), grid, block, 0, s, g); }
+        else if (g.drop.thr) MH_LAUNCH((gemm_big_kernel<C, 0, MH_ACT_NONE, 64>), grid, block, 0, s, g);
         else MH_LAUNCH((gemm_big_kernel<C, 0, MH_ACT_NONE>), grid, block, 0, s, g);
         break;
     }
@@ -1213,6 +1237,13 @@ extern "C" int mh_gemm_set_plain_stores(int mask) {
 
 extern "C" int mh_gemm_set_stagger(int ticks) {
   g_stagger = ticks;
+  return MH_OK;
+}
+
+// experiment knob (A/B only): 1 = the 256x128 kernels issue one LDS-DMA piece behind each MFMA row of a K-step instead of all six
+// right after the barrier.  Measured (tools/gemm_bench.py --spread): FFN1 -2.6 %, QKV -1 %, FFN2 / attention-output +-0 per launch.
+extern "C" int mh_gemm_set_spread(int on) {
+  g_spread = on != 0;
   return MH_OK;
 }
 
