@@ -484,6 +484,7 @@ def main():
     ap.add_argument("--split", type=int, default=None, help="batch slices run as concurrent graph branches (default: the library's choice)")
     ap.add_argument("--gemm", type=int, default=None, help="bf16 GEMM kernel variant 0/1/2 (see mh_gemm_set_variant)")
     ap.add_argument("--no-fuse-ln", action="store_true", help="A/B: separate GEMM and LayerNorm kernels")
+    ap.add_argument("--spread", type=int, default=None, help="A/B: 1 = LDS-DMA pieces of the 256x128 GEMMs issued between the MFMA rows (mh_gemm_set_spread)")
     ap.add_argument("--defer-ln", type=int, default=None, help="A/B: deferred LayerNorm 0 never / 1 where no fused epilogue exists (default) / 2 always")
     ap.add_argument("--no-stream-attn", action="store_true", help="A/B: LDS-resident attention instead of the streaming kernel")
     args = ap.parse_args()
@@ -508,6 +509,8 @@ def main():
         _lib.lib().mh_gemm_set_variant(args.gemm)
     if args.no_fuse_ln:
         _lib.lib().mh_denoiser_set_fuse_ln(0)
+    if args.spread is not None:
+        _lib.lib().mh_gemm_set_spread(args.spread)
     if args.defer_ln is not None:
         _lib.lib().mh_denoiser_set_defer_ln(args.defer_ln)
     if args.no_stream_attn:
