@@ -377,10 +377,18 @@ def init_ranks(args):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    # MUSE_BENCH_SHARE_GPU=1 (tests/test_multirank_gpu.py on a one-GPU box only): every rank on cuda:0, collectives over gloo -
+    # the launcher, the rank logic and the collectives' call sites are exercised end to end; the numbers mean nothing
+    share = os.environ.get("MUSE_BENCH_SHARE_GPU") == "1"
+    if share:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
         if dist.get_world_size() != args.gpus:
             raise SystemExit("bench.py: process group has %d ranks, --gpus %d" % (dist.get_world_size(), args.gpus))
     return world, rank, local_rank, device

@@ -42,3 +42,26 @@ def test_two_rank_sharded_sampling_matches_golden_tokens(tag):
 
 def test_two_rank_ddp_gradients_match_golden():
     run_ranks("ddp")
+
+
+@pytest.mark.parametrize("workload", ["c2", "c4", "train"])
+def test_bench_gpus_2_self_launches_and_reports_two_ranks(workload):
+    """`python bench.py --gpus 2` with NO launcher around it (what a SCALE run does): the parent starts two ranks through
+    torch.distributed.run, they broadcast rank 0's weights, run the workload, gather, and rank 0 prints one JSON line with
+    n_gpus = rccl_ranks = 2.  Two GPUs: one rank per GPU over RCCL; one GPU: both ranks share it and the collectives run over gloo
+    (MUSE_BENCH_SHARE_GPU) - the code path above the backend is the same."""
+    import json
+    import torch
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    if torch.cuda.device_count() < 2:
+        env["MUSE_BENCH_SHARE_GPU"] = "1"
+    cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--workload", workload, "--steps", "3", "--warmup", "1",
+           "--no-cpu-baseline", "--no-kernel-timing"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-3000:])
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["rccl_ranks"] == 2 and out["value"] > 0
+    assert out["scaling"] == "weak" and out["config"]["global_batch"] == 2 * (32 if workload == "train" else 64)
