@@ -156,26 +156,31 @@ __global__ void colsum_partial_kernel(const T* __restrict__ in_all, int64_t ld, 
   __syncthreads();
   if (rl == 0 && c < cols) part[(int64_t)blockIdx.y * cols + c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
-__global__ void colsum_final_kernel(const float* __restrict__ part_all, int P, int cols, float* __restrict__ out_all, int accumulate) {
-  // block = 64 columns x 4 partial-lanes; every lane keeps four loads in flight; fixed summation order -> reproducible
+__global__ __launch_bounds__(1024) void colsum_final_kernel(const float* __restrict__ part_all, int P, int cols, float* __restrict__ out_all, int accumulate) {
+  // block = 64 columns x 16 partial-lanes: every lane issues all of its loads (P / 16 <= 64) before the first add, so the fold
+  // costs one memory round trip instead of a chain of them (it is pure latency: P x cols floats); fixed summation order ->
+  // reproducible: lane pl adds partials pl, pl + 16, ... in order, lanes are folded 0..15 in order
   const float* part = part_all + (int64_t)blockIdx.y * P * cols;
   float* out = out_all + (int64_t)blockIdx.y * cols;
   const int c = blockIdx.x * 64 + (threadIdx.x & 63), pl = threadIdx.x >> 6;
-  __shared__ float red[4][64];
-  float s4[4] = {0.f, 0.f, 0.f, 0.f};
+  __shared__ float red[16][64];
+  float s = 0.f;
   if (c < cols) {
     int p = pl;
-    for (; p + 12 < P; p += 16) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) s4[j] += part[(int64_t)(p + 4 * j) * cols + c];
+    for (; p + 48 < P; p += 64) {
+      const float a0 = part[(int64_t)p * cols + c], a1 = part[(int64_t)(p + 16) * cols + c];
+      const float a2 = part[(int64_t)(p + 32) * cols + c], a3 = part[(int64_t)(p + 48) * cols + c];
+      s = (((s + a0) + a1) + a2) + a3;
     }
-    for (; p < P; p += 4) s4[0] += part[(int64_t)p * cols + c];
+    for (; p < P; p += 16) s += part[(int64_t)p * cols + c];
   }
-  red[pl][threadIdx.x & 63] = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+  red[pl][threadIdx.x & 63] = s;
   __syncthreads();
   if (pl == 0 && c < cols) {
-    const float s = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
-    out[c] = accumulate ? out[c] + s : s;
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) t += red[w][threadIdx.x];
+    out[c] = accumulate ? out[c] + t : t;
   }
 }
 
@@ -617,7 +622,7 @@ extern "C" int mh_col_sum(const void* in, int64_t ld, int64_t rows, int cols, in
                     MH_LAUNCH((colsum_partial_kernel<float>), grid, dim3(256), 0, s, (const float*)in, ld, rows, cols, partial, stride_in), "col_sum");
   }
   MH_CHECK_LAUNCH();
-  MH_LAUNCH(colsum_final_kernel, dim3((cols + 63) / 64, batch), dim3(256), 0, s, partial, n_partial, cols, out, accumulate);
+  MH_LAUNCH(colsum_final_kernel, dim3((cols + 63) / 64, batch), dim3(1024), 0, s, partial, n_partial, cols, out, accumulate);
   MH_CHECK_LAUNCH();
   return MH_OK;
 }
@@ -665,9 +670,9 @@ extern "C" int mh_layernorm_bwd(const void* x, const void* dy, const float* gamm
                   "layernorm_bwd");
   MH_CHECK_LAUNCH();
   // (a colsum_final block folds 64 columns: 4 partial-lanes x 64)
-  MH_LAUNCH(colsum_final_kernel, dim3((H + 63) / 64, 1), dim3(256), 0, s, pg, n_partial, H, dgamma, accumulate);
+  MH_LAUNCH(colsum_final_kernel, dim3((H + 63) / 64, 1), dim3(1024), 0, s, pg, n_partial, H, dgamma, accumulate);
   MH_CHECK_LAUNCH();
-  MH_LAUNCH(colsum_final_kernel, dim3((H + 63) / 64, 1), dim3(256), 0, s, pb, n_partial, H, dbeta, accumulate);
+  MH_LAUNCH(colsum_final_kernel, dim3((H + 63) / 64, 1), dim3(1024), 0, s, pb, n_partial, H, dbeta, accumulate);
   MH_CHECK_LAUNCH();
   return MH_OK;
 }
