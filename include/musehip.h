@@ -516,7 +516,9 @@ int mh_dropout_fwd(const void* x, int64_t ldx, void* out, int64_t ldo, int64_t r
 int mh_gemm_bias_dropout_res(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, const void* residual,
                              int64_t ldr, void* out, int64_t ldo, int64_t M, int N, int K, int dtype, const mh_dropout* drop,
                              mh_stream_t stream);
-/* attention-probability keep bits: [B nh][ceil(L/32)][32 ceil(L/32)] uint32, word = key, bit = query % 32 */
+/* attention-probability keep bits, 1 bit per probability, lane-native layout (csrc/common.h drop_word_index): uint32
+ * [B nh][nb = ceil(L/32) query blocks][ceil(nb/2) pairs of 32-key blocks][64 lanes]; the word of lane (query % 32) + 32 h holds bit
+ * r (+ 16 for the odd key block) <-> key (r & 3) + 8 (r >> 2) + 4 h of the block */
 size_t mh_dropout_bits_words(int BH, int L);
 int mh_dropout_bits(uint32_t* keep_bits, int BH, int L, const mh_dropout* drop, mh_stream_t stream);
 /* P[bh][q][k] = keep ? P / (1 - p) : 0 over a materialised [B nh, L, ldp] tensor (probabilities forward, their gradient backward) */

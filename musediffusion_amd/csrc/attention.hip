@@ -552,10 +552,12 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(const float* __restrict__
 // four are swapped, which is the order the S^T accumulator registers hold the probabilities in, so a stage
 // is a straight 16-byte-granular copy (source-side XOR swizzle) and P feeds the P.V MFMA without a shuffle.
 // DROP (training): attention-probability dropout (HF BertSelfAttention: softmax -> dropout -> . V).  The keep flags of the
-// wave's 32 x 32 S^T sub-tile come from Philox (drop_keep_attn) and are written to `keep_bits` ([B nh][ceil(L/32)][32 ceil(L/32)],
-// word = key, bit = query % 32) for the backward kernels - or, with bits_in, are read from it (mask injection for parity tests).
+// wave's 32 x 32 S^T sub-tile come from Philox (drop_keep_attn) and are written to `keep_bits` (lane-native words, common.h
+// drop_word_index: one store per lane and 64-key tile) for the backward kernels - or, with bits_in, are read from it (mask injection).
 // The softmax normaliser runs over the un-dropped probabilities; 1 / (1 - p) is folded into the final 1 / l.
-template <int DH, int NW = 16, int SK = 256, bool DROP = false>
+// DROP: 0 = no dropout, 1 = generate the keep flags (Philox) and write the bit tensor, 2 = read the bit tensor (a pre-pass or a test
+// wrote it): the reading variant needs no generator registers and fits the 16-wave geometry
+template <int DH, int NW = 16, int SK = 256, int DROP = 0>
 __global__ __launch_bounds__(64 * NW) void attn_stream_bf16_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K,
                                                                 const bf16* __restrict__ VT, bf16* __restrict__ ctx,
                                                                 int64_t ld_ctx, int L, int nh, int nbh, float scale_log2e,
@@ -698,26 +700,23 @@ __global__ __launch_bounds__(64 * NW) void attn_stream_bf16_kernel(const bf16* _
             ps4[r & 3] += p;
           }
         l_run += (ps4[0] + ps4[1]) + (ps4[2] + ps4[3]);
-        if constexpr (DROP) {
+        if constexpr (DROP != 0) {
           const int nb32 = (L + 31) >> 5;
-#pragma unroll
-          for (int kt = 0; kt < 2; ++kt) {
-            if (32 * kt < tile_keys) {                                     // (wave-uniform)
-              const int kb = (st * SK + t * 64 + 32 * kt) >> 5;
-              uint32_t* words = keep_bits + (((int64_t)bh * nb32 + (q0 >> 5)) * nb32 + kb) * 32;
-              uint32_t km;
-              if (bits_in) {
-                km = drop_load_tile(words, lq, h);
-              } else {
-                const int qc = q0 + lq < L ? q0 + lq : L - 1;
-                km = drop_keep_attn(drop, bh, L, nb32, qc, kb, h);
-                const uint32_t w = drop_pack_tile(km, lane);
-                if (lane < 32) words[lane] = w;
-              }
-#pragma unroll
-              for (int r = 0; r < 16; ++r) s[kt][r] = (km >> r) & 1u ? s[kt][r] : 0.f;
-            }
+          const int64_t wi = drop_word_index(bh, nb32, q0 >> 5, (st * SK + t * 64) >> 6, lane);   // this lane's word of the 64-key tile
+          uint32_t kw;
+          if constexpr (DROP == 2) {
+            kw = keep_bits[wi];
+          } else {
+            const int qc = q0 + lq < L ? q0 + lq : L - 1;
+            const int kb = (st * SK + t * 64) >> 5;
+            kw = drop_keep_attn(drop, bh, L, nb32, qc, kb, h);
+            if (32 < tile_keys) kw |= drop_keep_attn(drop, bh, L, nb32, qc, kb + 1, h) << 16;   // (wave-uniform)
+            keep_bits[wi] = kw;
           }
+#pragma unroll
+          for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[kt][r] = (kw >> (16 * kt + r)) & 1u ? s[kt][r] : 0.f;
         }
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
@@ -736,7 +735,7 @@ __global__ __launch_bounds__(64 * NW) void attn_stream_bf16_kernel(const bf16* _
       }
       if (st == nst - 1) {   // last stage of this (batch, head): normalise and write the context rows
         const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-        const float inv = (DROP ? drop.rscale : 1.0f) / l_tot;
+        const float inv = (DROP != 0 ? drop.rscale : 1.0f) / l_tot;
         const int qr = q0 + lq;
         if (qr < L) {
           const int b = bh / nh, head = bh % nh;
@@ -815,7 +814,7 @@ int launch_bf16(const bf16* q, const bf16* k, const bf16* vt, bf16* ctx, int64_t
 
 namespace { int g_attn_stream = 1; }
 extern "C" int mh_attention_set_stream(int on) {
-  g_attn_stream = on < 0 ? 0 : (on > 2 ? 2 : on);
+  g_attn_stream = on < 0 ? 0 : (on > 3 ? 3 : on);
   return MH_OK;
 }
 extern "C" int mh_attention_stream_enabled(void) { return g_attn_stream; }
@@ -873,7 +872,9 @@ extern "C" int mh_attention_stream_fwd_drop(const void* q, const void* k, const 
   const bf16 *Q = (const bf16*)q, *K = (const bf16*)k, *V = (const bf16*)vt_perm;
   // 8 waves x 128-key stages: half a CU per block.  The dropout variant always runs there: its mask generation needs ~30
   // registers more than the 128 a 16-wave block leaves each wave (the 16-wave build spilled 82 dwords per lane: 3.5x slower)
-  const bool small = g_attn_stream == 2 || dropping;
+  // the in-kernel generator runs on the 8-wave geometry (its Philox state does not fit the 128 registers of a 16-wave block without
+  // spilling 25 dwords per lane; mode 3 = A/B: generator on 16 waves); the bit reader fits 16 waves
+  const bool small = g_attn_stream == 2 || (dropping && !bits_in && g_attn_stream != 3);
   const int qper = small ? 256 : 512, nitems = nbh * ((L + qper - 1) / qper);
   const int slots = small ? 2 * cus : cus;
   const dim3 grid((unsigned)(nitems < slots ? nitems : slots)), block(small ? 512 : 1024);
@@ -888,7 +889,9 @@ extern "C" int mh_attention_stream_fwd_drop(const void* q, const void* k, const 
     return MH_OK;
   };
   int rc;
-  if (dropping) rc = dh == 64 ? go(&attn_stream_bf16_kernel<64, 8, 128, true>, 4 * 128 * 64 * 2) : go(&attn_stream_bf16_kernel<32, 8, 256, true>, 4 * 256 * 32 * 2);
+  if (dropping && bits_in) rc = dh == 64 ? go(&attn_stream_bf16_kernel<64, 16, 256, 2>, 4 * 256 * 64 * 2) : go(&attn_stream_bf16_kernel<32, 16, 256, 2>, 4 * 256 * 32 * 2);
+  else if (dropping && !small) rc = dh == 64 ? go(&attn_stream_bf16_kernel<64, 16, 256, 1>, 4 * 256 * 64 * 2) : go(&attn_stream_bf16_kernel<32, 16, 256, 1>, 4 * 256 * 32 * 2);
+  else if (dropping) rc = dh == 64 ? go(&attn_stream_bf16_kernel<64, 8, 128, 1>, 4 * 128 * 64 * 2) : go(&attn_stream_bf16_kernel<32, 8, 256, 1>, 4 * 256 * 32 * 2);
   else if (dh == 64) rc = small ? go(&attn_stream_bf16_kernel<64, 8, 128>, 4 * 128 * 64 * 2) : go(&attn_stream_bf16_kernel<64, 16, 256>, 4 * 256 * 64 * 2);
   else rc = small ? go(&attn_stream_bf16_kernel<32, 8, 256>, 4 * 256 * 32 * 2) : go(&attn_stream_bf16_kernel<32, 16, 256>, 4 * 256 * 32 * 2);
   if (rc) return rc;

@@ -159,15 +159,14 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const bf16* __restrict
           dp[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<DH>(vst, R, ks, h), dof[ks], dp[kt], 0, 0, 0);
         }
       }
+      uint32_t kw = 0xffffffffu;
+      if constexpr (DROP) {   // dP = dP_drop o keep / (1 - p): this lane's word of the 64-key tile, as the forward stored it
+        const int nb32 = (L + 31) >> 5;
+        kw = keep_bits[drop_word_index(bh, nb32, q0 >> 5, (st * SKB + t * 64) >> 6, lane)];
+      }
 #pragma unroll
       for (int kt = 0; kt < 2; ++kt) {
-        uint32_t km = 0xffffu;
-        if constexpr (DROP) {   // dP = dP_drop o keep / (1 - p): the forward's keep bits of this S^T sub-tile
-          if (32 * kt < tile_keys) {
-            const int nb32 = (L + 31) >> 5, kb = (st * SKB + t * 64 + 32 * kt) >> 5;
-            km = drop_load_tile(keep_bits + (((int64_t)bh * nb32 + (q0 >> 5)) * nb32 + kb) * 32, lq, h);
-          }
-        }
+        const uint32_t km = kw >> (16 * kt);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           float p = __builtin_amdgcn_exp2f(s[kt][r] * scale_log2e - lse_q);
@@ -288,12 +287,18 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const bf16* __restric
       for (int qt = 0; qt < 2; ++qt) {
         const int R = t * 64 + 32 * qt + lq;
         f32x16 s, dp;
-        uint32_t kw = 0xffffffffu;     // keep bits of this lane's key for the 32 queries of the tile (bit = query % 32)
+        // keep flags of this lane's key for its 16 queries of the tile: query 8 rg + 4 h + e lives in the word of forward lane
+        // (query % 32) + 32 hk, at bit rk (+ 16 for an odd key block): four consecutive words per rg
+        uint4 kwv[4];
+        int kshift = 0;
         if constexpr (DROP) {
           const int nb32 = (L + 31) >> 5;
           int qb = (st * SKB + t * 64 + 32 * qt) >> 5; if (qb >= nb32) qb = nb32 - 1;
-          const int kc = k0 + lq < L ? k0 + lq : L - 1;
-          kw = keep_bits[((int64_t)bh * nb32 + qb) * nb32 * 32 + kc];
+          const int kbk = k0 >> 5, hk = (lq >> 2) & 1;
+          kshift = (lq & 3) + 4 * (lq >> 3) + 16 * (kbk & 1);
+          const uint32_t* wp = keep_bits + drop_word_index(bh, nb32, qb, kbk >> 1, 32 * hk + 4 * h);
+#pragma unroll
+          for (int rg = 0; rg < 4; ++rg) kwv[rg] = *reinterpret_cast<const uint4*>(wp + 8 * rg);
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
@@ -314,7 +319,8 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const bf16* __restric
             if (qi + e >= st_q) p = 0.f;                                  // query past the sequence end
             float dpv = dp[rg * 4 + e], pd = p;
             if constexpr (DROP) {                                         // P_drop feeds dV; dP = dP_drop o keep / (1 - p)
-              const bool keep = (kw >> (8 * rg + 4 * h + e)) & 1u;
+              const uint32_t kwe = e == 0 ? kwv[rg].x : e == 1 ? kwv[rg].y : e == 2 ? kwv[rg].z : kwv[rg].w;
+              const bool keep = (kwe >> kshift) & 1u;
               pd = keep ? p * rscale : 0.f;
               dpv = keep ? dpv * rscale : 0.f;
             }

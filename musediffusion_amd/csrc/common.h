@@ -218,33 +218,17 @@ __device__ __forceinline__ uint32_t drop_keep_attn(const DropArgs& d, int64_t bh
   }
   return m;
 }
-// Pack a wave's keep flags of one 32-query x 32-key S^T tile into the bit tensor: lane (lq, h) holds flags `m` (bit r <->
-// key (r & 3) + 8 (r >> 2) + 4 h, query lq).  Word layout: bits[key], bit = query (lq).  Returns, in lanes 0..31, the word
-// of key = lane.
-__device__ __forceinline__ uint32_t drop_pack_tile(uint32_t m, int lane) {
-  const int n = lane & 31;                       // the key whose word this lane ends up with
-  const int my_r = ((n >> 3) << 2) | (n & 3), my_hh = (n >> 2) & 1;
-  uint32_t w = 0;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const uint64_t b = __builtin_amdgcn_ballot_w64(((m >> r) & 1u) != 0);
-    if (my_r == r) w = my_hh ? (uint32_t)(b >> 32) : (uint32_t)b;
-  }
-  return w;
+// The keep-bit tensor is LANE-NATIVE: uint32 [B nh][nb = ceil(L / 32) query blocks][ceil(nb / 2) pairs of 32-key blocks][64 lanes].
+// The word of lane (lq, h) holds that lane's 16 flags of the pair's even key block in its low half and of the odd block in its high
+// half - bit r <-> key (r & 3) + 8 (r >> 2) + 4 h of the block, query lq of the query block: exactly the registers the lane holds
+// of an S^T tile, so the forward stores its flags as they are (no ballots) and the dQ kernel loads one word per 64-key tile.
+__device__ __forceinline__ int64_t drop_word_index(int64_t bh, int nb, int qb, int kp, int lane) {
+  return ((((int64_t)bh * nb + qb) * ((nb + 1) >> 1) + kp) << 6) + lane;
 }
-// Read the flags of one lane of an S^T tile back from the bit tensor: words of keys 8 j + 4 h + e at `tile_words` (32 words,
-// 16-byte aligned); bit lq of each.
-__device__ __forceinline__ uint32_t drop_load_tile(const uint32_t* tile_words, int lq, int h) {
-  uint32_t m = 0;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const uint4 v = *reinterpret_cast<const uint4*>(tile_words + 8 * j + 4 * h);
-    m |= ((v.x >> lq) & 1u) << (4 * j);
-    m |= ((v.y >> lq) & 1u) << (4 * j + 1);
-    m |= ((v.z >> lq) & 1u) << (4 * j + 2);
-    m |= ((v.w >> lq) & 1u) << (4 * j + 3);
-  }
-  return m;
+// flag of probability (q, k) of (batch, head) bh - for the kernels that do not hold S^T tiles (materialised path)
+__device__ __forceinline__ uint32_t drop_flag(const uint32_t* bits, int64_t bh, int nb, int q, int k) {
+  const int kk = k & 31, h = (kk >> 2) & 1, r = (kk & 3) + 4 * (kk >> 3);
+  return (bits[drop_word_index(bh, nb, q >> 5, k >> 6, (q & 31) + 32 * h)] >> (r + 16 * ((k >> 5) & 1))) & 1u;
 }
 
 static inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

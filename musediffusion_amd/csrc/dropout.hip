@@ -2,8 +2,8 @@
 // hidden / attention-probability dropouts, both 0.1 from the bert-base config, network.py:44-46).
 //   mh_dropout_fwd         y = x o keep / (1 - p) over a dense [rows, cols] activation: the embedding-LayerNorm site forward,
 //                          and the BACKWARD of every dense site (the mask is re-created from (seed, offset), never stored)
-//   mh_dropout_bits        the attention-probability keep mask as a bit tensor [B nh][ceil(L/32)][32 ceil(L/32)] (word = key,
-//                          bit = query % 32), exactly the bits the fused forward (attention.hip) writes
+//   mh_dropout_bits        the attention-probability keep mask as a bit tensor (lane-native layout, common.h drop_word_index),
+//                          exactly the words the fused forward (attention.hip) writes
 //   mh_dropout_bits_apply  P o keep / (1 - p) on a materialised [B nh, L, ldp] probability / gradient tensor (fp32 parity mode
 //                          and shapes the streaming kernels do not serve)
 // The Philox counter conventions live in common.h (drop_keep8 / drop_keep_attn).
@@ -47,33 +47,32 @@ __global__ void dropout_fwd_kernel(const T* __restrict__ x, int64_t ldx, T* __re
   }
 }
 
-// one wave per (bh, 32-query block, 32-key block): the S^T tile of the fused kernels
-__global__ __launch_bounds__(256) void dropout_bits_kernel(uint32_t* __restrict__ bits, int64_t ntiles, int L, int nqb, int nkb,
+// one wave per (bh, 32-query block, pair of 32-key blocks): the 64-key S^T tile of the fused kernels, lane-native words
+__global__ __launch_bounds__(256) void dropout_bits_kernel(uint32_t* __restrict__ bits, int64_t ntiles, int L, int nb, int nkp,
                                                            const DropArgs d) {
   const int lane = threadIdx.x & 63, lq = lane & 31, h = lane >> 5;
   const int64_t w0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   for (int64_t tile = w0; tile < ntiles; tile += (int64_t)gridDim.x * 4) {
-    const int kb = (int)(tile % nkb);
-    const int qb = (int)((tile / nkb) % nqb);
-    const int64_t bh = tile / ((int64_t)nkb * nqb);
+    const int kp = (int)(tile % nkp);
+    const int qb = (int)((tile / nkp) % nb);
+    const int64_t bh = tile / ((int64_t)nkp * nb);
     int q = qb * 32 + lq; if (q >= L) q = L - 1;
-    const uint32_t m = drop_keep_attn(d, bh, L, nkb, q, kb, h);
-    const uint32_t w = drop_pack_tile(m, lane);
-    if (lane < 32) bits[((bh * nqb + qb) * nkb + kb) * 32 + lane] = w;
+    uint32_t kw = drop_keep_attn(d, bh, L, nb, q, 2 * kp, h);
+    if (2 * kp + 1 < nb) kw |= drop_keep_attn(d, bh, L, nb, q, 2 * kp + 1, h) << 16;
+    bits[drop_word_index(bh, nb, qb, kp, lane)] = kw;
   }
 }
 
 template <typename T>
-__global__ void dropout_bits_apply_kernel(T* __restrict__ P, int64_t ldp, const uint32_t* __restrict__ bits, int64_t BH, int L, int nqb,
-                                          int nkb, float rscale) {
+__global__ void dropout_bits_apply_kernel(T* __restrict__ P, int64_t ldp, const uint32_t* __restrict__ bits, int64_t BH, int L, int nb,
+                                          float rscale) {
   const int64_t total = BH * L * L;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int k = (int)(i % L);
     const int q = (int)((i / L) % L);
     const int64_t bh = i / ((int64_t)L * L);
-    const uint32_t w = bits[((bh * nqb + (q >> 5)) * nkb) * 32 + k];
     T* p = P + (bh * L + q) * ldp + k;
-    *p = (w >> (q & 31)) & 1u ? from_f32<T>(to_f32(*p) * rscale) : from_f32<T>(0.f);
+    *p = drop_flag(bits, bh, nb, q, k) ? from_f32<T>(to_f32(*p) * rscale) : from_f32<T>(0.f);
   }
 }
 
@@ -86,7 +85,7 @@ inline int ew_grid(int64_t n) {
 
 extern "C" size_t mh_dropout_bits_words(int BH, int L) {
   const size_t nb = (size_t)((L + 31) / 32);
-  return (size_t)BH * nb * nb * 32;
+  return (size_t)BH * nb * ((nb + 1) / 2) * 64;
 }
 
 extern "C" int mh_dropout_fwd(const void* x, int64_t ldx, void* out, int64_t ldo, int64_t rows, int cols, int dtype,
@@ -110,10 +109,10 @@ extern "C" int mh_dropout_bits(uint32_t* keep_bits, int BH, int L, const mh_drop
   DropArgs d;
   int rc = mh_drop_args(drop, &d);
   if (rc) return rc;
-  const int nb = (L + 31) / 32;
-  const int64_t ntiles = (int64_t)BH * nb * nb;
+  const int nb = (L + 31) / 32, nkp = (nb + 1) / 2;
+  const int64_t ntiles = (int64_t)BH * nb * nkp;
   const int grid = (int)((ntiles + 3) / 4 < 262140 ? (ntiles + 3) / 4 : 262140);
-  MH_LAUNCH(dropout_bits_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, keep_bits, ntiles, L, nb, nb, d);
+  MH_LAUNCH(dropout_bits_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, keep_bits, ntiles, L, nb, nkp, d);
   MH_CHECK_LAUNCH();
   return MH_OK;
 }
@@ -125,8 +124,8 @@ extern "C" int mh_dropout_bits_apply(void* P, int64_t ldp, const uint32_t* keep_
   const float rs = 1.0f / (1.0f - p);
   hipStream_t s = (hipStream_t)stream;
   const int grid = ew_grid((int64_t)BH * L * L);
-  if (dtype == MH_BF16) MH_LAUNCH((dropout_bits_apply_kernel<bf16>), dim3(grid), dim3(256), 0, s, (bf16*)P, ldp, keep_bits, (int64_t)BH, L, nb, nb, rs);
-  else if (dtype == MH_F32) MH_LAUNCH((dropout_bits_apply_kernel<float>), dim3(grid), dim3(256), 0, s, (float*)P, ldp, keep_bits, (int64_t)BH, L, nb, nb, rs);
+  if (dtype == MH_BF16) MH_LAUNCH((dropout_bits_apply_kernel<bf16>), dim3(grid), dim3(256), 0, s, (bf16*)P, ldp, keep_bits, (int64_t)BH, L, nb, rs);
+  else if (dtype == MH_F32) MH_LAUNCH((dropout_bits_apply_kernel<float>), dim3(grid), dim3(256), 0, s, (float*)P, ldp, keep_bits, (int64_t)BH, L, nb, rs);
   else { mh_set_error("dropout_bits_apply: unknown dtype %d", dtype); return MH_ERR_INVALID; }
   MH_CHECK_LAUNCH();
   return MH_OK;

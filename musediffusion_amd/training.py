@@ -46,10 +46,11 @@ class _Drop:
     """One dropout site of one forward call: rate, Philox key / counter offset (the backward re-creates the mask from them),
     and - for parity tests only - an explicit keep mask (`mask`: uint8 [rows, cols] for dense sites; `bits`: the int32 keep-bit
     tensor of an attention site, layout of mh_dropout_bits)."""
-    __slots__ = ("p", "seed", "offset", "mask", "bits")
+    __slots__ = ("p", "seed", "offset", "mask", "bits", "ready")
 
-    def __init__(self, p, seed, offset, mask=None, bits=None):
+    def __init__(self, p, seed, offset, mask=None, bits=None, ready=None):
         self.p, self.seed, self.offset, self.mask, self.bits = float(p), int(seed), int(offset), mask, bits
+        self.ready = ready      # event after which `bits` (generated on a side stream) may be read
 
     def c(self):
         d = _lib.Dropout()
@@ -363,6 +364,8 @@ class _Attention(Function):
         import ctypes as C
         drop = drop if _active(drop) else None
         ctx.drop, ctx.bits = drop, None
+        if drop is not None and drop.ready is not None:      # keep bits drawn ahead on a side stream
+            torch.cuda.current_stream().wait_event(drop.ready)
         M, ld = qkv.shape
         H = ld // 3 if ld % 3 == 0 else None
         assert H is not None
@@ -381,7 +384,7 @@ class _Attention(Function):
             # the log-sum-exp lets the backward kernels re-create P tile by tile (no [L, L] tensor in HBM)
             out = torch.empty(B * L, H, device=qkv.device, dtype=td)
             lse = torch.empty(B * nh * L, device=qkv.device, dtype=torch.float32)
-            if drop is not None:   # probability dropout inside the kernel; it writes the keep bits the backward kernels read
+            if drop is not None:   # probability dropout inside the kernel: it reads the keep bits a pre-pass / a test wrote, or draws and writes them
                 bits_in = int(drop.bits is not None)
                 ctx.bits = drop.bits if bits_in else torch.empty(int(L_.mh_dropout_bits_words(B * nh, L)), device=qkv.device, dtype=torch.int32)
                 d = drop.c()
@@ -609,12 +612,46 @@ class _DropSites:
         self.call = model.next_dropout_call() if (self.p_emb or self.p_hid or self.p_att) else 0
         self.nsite = 0
 
+    def pregenerate_attention_bits(self, model, B, L, dt, dev):
+        """The attention masks do not depend on data (counter-based Philox): all layers' keep-bit tensors are drawn at the start of
+        the forward by the standalone generator on a side stream - a VALU-only kernel next to the first GEMMs - and the streaming
+        forward only READS them (the in-kernel generator needs the 8-wave geometry or spills: 260 us per layer against 128 us for
+        the reader at seq_len 1024 x batch 32; tools/attn_drop_bench.py).  Only where the fused attention path will run."""
+        import ctypes as C
+        self.pre = {}
+        nh = model.num_heads
+        dh = model.hidden_size // nh
+        if self.p_att <= 0.0 or not (FUSED_ATTENTION and dt == ops.MH_BF16 and bool(lib().mh_attention_stream_bwd_supported(L, dh))):
+            return
+        side = getattr(model, "_bits_stream", None)
+        if side is None:
+            side = model._bits_stream = torch.cuda.Stream()
+        main = torch.cuda.current_stream()
+        side.wait_stream(main)
+        nwords = int(lib().mh_dropout_bits_words(B * nh, L))
+        for li in range(len(model.input_transformers.layer)):
+            name = "l%d.attn" % li
+            if name in self.masks:
+                continue
+            bits = torch.empty(nwords, device=dev, dtype=torch.int32)
+            bits.record_stream(side)
+            d = _Drop(self.p_att, self.seed, (self.call << 16) | (2 + 3 * li)).c()      # the offset site() gives this site
+            with torch.cuda.stream(side):
+                check(lib().mh_dropout_bits(ptr(bits), B * nh, L, C.byref(d), side.cuda_stream), "mh_dropout_bits")
+                ev = torch.cuda.Event()
+                ev.record(side)
+            self.pre[name] = (bits, ev)
+
     def site(self, name, p):
         self.nsite += 1
         if p <= 0.0:
             return None
         inj = self.masks.get(name)
         if name.endswith(".attn"):
+            if inj is None and name in getattr(self, "pre", {}):
+                bits, ev = self.pre[name]
+                assert (self.call << 16) | self.nsite == (self.call << 16) | (2 + 3 * int(name[1:].split(".")[0]))
+                return _Drop(p, self.seed, (self.call << 16) | self.nsite, bits=bits, ready=ev)
             return _Drop(p, self.seed, (self.call << 16) | self.nsite, bits=inj)
         return _Drop(p, self.seed, (self.call << 16) | self.nsite, mask=None if inj is None else inj.to(torch.uint8).contiguous())
 
@@ -638,6 +675,7 @@ def denoiser_forward_with_grad(model, x, timesteps):
     else:
         h = xin
     sites = _DropSites(model)
+    sites.pregenerate_attention_bits(model, B, L, dt, dev)
     pre = _AddPosTime.apply(h, model.position_embeddings.weight, emb_t, B, L, dt)
     X = _LayerNorm.apply(pre, model.LayerNorm.weight, model.LayerNorm.bias, model.LayerNorm.eps, dt)
     d_emb = sites.site("emb", sites.p_emb)

@@ -38,25 +38,35 @@ def dropout_fwd(x, d, dt):
     return out
 
 
-def bits_to_mask(bits, BH, L):
-    """keep-bit tensor [BH][nb][32 nb] (word = key, bit = query % 32) -> bool [BH, L(q), L(k)]"""
+def _bit_coords(L, device):
+    """(word index within a (batch, head), bit) of every probability (q, k): the lane-native layout of csrc/common.h drop_word_index"""
     nb = (L + 31) // 32
-    w = bits.view(BH, nb, nb * 32).to(torch.int64) & 0xffffffff
-    sh = torch.arange(32, device=bits.device).view(1, 1, 32, 1)
-    m = ((w.unsqueeze(2) >> sh) & 1).bool()                        # [BH, nb, 32, keys]
-    return m.reshape(BH, nb * 32, nb * 32)[:, :L, :L]
+    nkp = (nb + 1) // 2
+    q = torch.arange(L, device=device).view(L, 1)
+    k = torch.arange(L, device=device).view(1, L)
+    kk = k & 31
+    h = (kk >> 2) & 1
+    r = (kk & 3) + 4 * (kk >> 3)
+    word = (((q >> 5) * nkp + (k >> 6)) << 6) + (q & 31) + 32 * h
+    bit = r + 16 * ((k >> 5) & 1)
+    return word.expand(L, L), bit.expand(L, L), nb * nkp * 64
+
+
+def bits_to_mask(bits, BH, L):
+    """keep-bit tensor -> bool [BH, L(q), L(k)]"""
+    word, bit, per_bh = _bit_coords(L, bits.device)
+    w = bits.view(BH, per_bh).to(torch.int64) & 0xffffffff
+    return ((w[:, word.reshape(-1)] >> bit.reshape(-1)) & 1).bool().view(BH, L, L)
 
 
 def mask_to_bits(mask):
     """bool [BH, L, L] -> int32 keep-bit tensor (test helper: how the oracle's attention masks are injected)"""
     BH, L, _ = mask.shape
-    nb = (L + 31) // 32
-    full = torch.zeros(BH, nb * 32, nb * 32, dtype=torch.int64, device=mask.device)
-    full[:, :L, :L] = mask.to(torch.int64)
-    sh = torch.arange(32, device=mask.device, dtype=torch.int64).view(1, 1, 32, 1)
-    w = (full.view(BH, nb, 32, nb * 32) << sh).sum(dim=2)           # [BH, nb, keys]
-    w = torch.where(w >= 2 ** 31, w - 2 ** 32, w)
-    return w.to(torch.int32).reshape(-1).contiguous()
+    word, bit, per_bh = _bit_coords(L, mask.device)
+    out = torch.zeros(BH, per_bh, dtype=torch.int64, device=mask.device)
+    out.scatter_add_(1, word.reshape(1, -1).expand(BH, -1), mask.reshape(BH, -1).to(torch.int64) << bit.reshape(1, -1))
+    out = torch.where(out >= 2 ** 31, out - 2 ** 32, out)
+    return out.to(torch.int32).reshape(-1).contiguous()
 
 
 @pytest.mark.parametrize("dt,td", [(MH_F32, torch.float32), (MH_BF16, torch.bfloat16)])
@@ -143,9 +153,11 @@ def test_streaming_attention_dropout_forward_bits_and_values(L, dh):
     assert abs(rate - p) < 4e-3, rate
     ref = torch_attention(qkv, B, L, nh, dh, keep, p)
     assert float((out.float() - ref).abs().max()) < 3e-2
-    # reading the bits back (injection mode) gives the same output; p = 0 equals the plain kernel
+    # reading the bits back (pre-pass / injection mode) gives the same output up to the summation order of the two block geometries
+    # (the generator runs on 8 waves x 128-key stages, the reader on 16 x 256); p = 0 equals the plain kernel
     out2, _ = stream_fwd(qkv, B, L, nh, dh, d, bits, 1)
-    assert torch.equal(out, out2)
+    assert float((out.float() - out2.float()).abs().max()) < 2e-2
+    assert float((out2.float() - ref).abs().max()) < 3e-2
     out0, _ = stream_fwd(qkv, B, L, nh, dh, None, None, 0)
     assert float((out0.float() - torch_attention(qkv, B, L, nh, dh, None, 0)).abs().max()) < 3e-2
     assert float((out0.float() - out.float()).abs().max()) > 1e-2

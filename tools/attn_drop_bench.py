@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""Streaming attention forward with probability dropout at the training shape: in-kernel Philox (writes the keep bits) against a
+standalone bit pre-pass (mh_dropout_bits) + the bit-reading forward, and the dropout-free forward."""
+import ctypes as C
+import math
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from musediffusion_amd import _lib  # noqa: E402
+from musediffusion_amd._lib import check, current_stream, lib, ptr  # noqa: E402
+
+B, L, nh, dh = 32, 1024, 8, 64
+H = nh * dh
+dev = "cuda"
+qkv = (torch.randn(B * L, 3 * H, device=dev) * 0.7).to(torch.bfloat16)
+vt = torch.zeros(B * nh * dh * L + 256, device=dev, dtype=torch.bfloat16)
+L_ = lib()
+st = current_stream()
+check(L_.mh_head_permute(qkv.data_ptr() + 2 * H * 2, ptr(vt), 3 * H, B, L, nh, dh, 3, 1, st))
+out = torch.empty(B * L, H, device=dev, dtype=torch.bfloat16)
+lse = torch.empty(B * nh * L, device=dev, dtype=torch.float32)
+bits = torch.zeros(int(L_.mh_dropout_bits_words(B * nh, L)), device=dev, dtype=torch.int32)
+d = _lib.Dropout(); d.p, d.seed, d.offset, d.mask = 0.1, 42, 7, None
+
+
+def fwd(drop, bits_in):
+    check(L_.mh_attention_stream_fwd_drop(qkv.data_ptr(), qkv.data_ptr() + H * 2, ptr(vt), ptr(out), H, 0, B, L, nh, dh, 1 / math.sqrt(dh),
+                                          ptr(lse), L * 3 * H, dh, 3 * H, C.byref(d) if drop else None, ptr(bits) if drop else None, bits_in, st))
+
+
+def gen():
+    check(L_.mh_dropout_bits(ptr(bits), B * nh, L, C.byref(d), st))
+
+
+def t(fn, n=20):
+    fn(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n * 1e3
+
+
+print("no dropout            : %7.1f us" % t(lambda: fwd(False, 0)))
+print("in-kernel Philox      : %7.1f us" % t(lambda: fwd(True, 0)))
+L_.mh_attention_set_stream(3)
+print("in-kernel, 16 waves   : %7.1f us" % t(lambda: fwd(True, 0)))
+L_.mh_attention_set_stream(1)
+print("bit pre-pass          : %7.1f us" % t(gen))
+print("bit-reading forward   : %7.1f us" % t(lambda: fwd(True, 1)))
