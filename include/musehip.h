@@ -382,6 +382,12 @@ int mh_gemm_act_grad(const void* A, int64_t lda, const void* W, int64_t ldw, con
 int mh_gemm_dw(const void* A, int64_t lda, const void* B, int64_t ldb, float* out_partials, int splits, int64_t K, int M, int N,
                mh_stream_t stream);
 int mh_gemm_dw_splits(int64_t K, int M, int N);
+int mh_gemm_dw_set_blocks(int blocks);   /* A/B knob: blocks a launch aims for when choosing `splits` (default 512) */
+/* The same with the bias gradient of that linear as a by-product (with_colsum != 0): each split slice is M N + M floats - the
+ * products, then sum_k A[k][m] over the slice's tokens, taken off the matrix pipe (an all-ones operand) by the blocks that already
+ * hold the A panel - so dY is not read a second time for autograd's `grad_bias = dY.sum(0)`; one mh_sum_slices over M N + M folds both. */
+int mh_gemm_dw_bias(const void* A, int64_t lda, const void* B, int64_t ldb, float* out_partials, int splits, int64_t K, int M, int N,
+                    int with_colsum, mh_stream_t stream);
 /* out = LayerNorm(A W^T + bias + residual) * gamma + beta, bf16, the whole row normalised inside the
  * GEMM epilogue (one block owns all N columns: N must be 128, 256 or 512 - see ..._supported).
  * Replaces BertSelfOutput / BertOutput (dense -> LayerNorm(hidden + input)) of the encoder that

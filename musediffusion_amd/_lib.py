@@ -146,6 +146,8 @@ SIGNATURES = {
     "mh_gemm_set_variant": (INT, [INT]),
     "mh_gemm_dw": (INT, [VP, I64, VP, I64, VP, INT, I64, INT, INT, VP]),
     "mh_gemm_dw_splits": (INT, [I64, INT, INT]),
+    "mh_gemm_dw_set_blocks": (INT, [INT]),
+    "mh_gemm_dw_bias": (INT, [VP, I64, VP, I64, VP, INT, I64, INT, INT, INT, VP]),
     "mh_gemm_act_grad": (INT, [VP, I64, VP, I64, VP, I64, VP, I64, I64, INT, INT, INT, VP]),
     "mh_gemm_bias_act_pre": (INT, [VP, I64, VP, I64, VP, VP, VP, I64, I64, INT, INT, INT, VP]),
     "mh_gemm_bias_res_ln": (INT, [VP, I64, INT, VP, I64, INT, VP, VP, I64, INT, VP, VP, F32, VP, I64, INT, I64, INT, INT, VP]),

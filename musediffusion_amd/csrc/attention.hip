@@ -557,7 +557,9 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(const float* __restrict__
 // The softmax normaliser runs over the un-dropped probabilities; 1 / (1 - p) is folded into the final 1 / l.
 // DROP: 0 = no dropout, 1 = generate the keep flags (Philox) and write the bit tensor, 2 = read the bit tensor (a pre-pass or a test
 // wrote it): the reading variant needs no generator registers and fits the 16-wave geometry
-template <int DH, int NW = 16, int SK = 256, int DROP = 0>
+// FULL: seq_len is a multiple of SK, so no stage or tile is partial - the key-bound compares (which hipcc if-converts into a compare
+// + select per score of EVERY tile, a third of the tile's vector instructions) are compiled out
+template <int DH, int NW = 16, int SK = 256, int DROP = 0, bool FULL = false>
 __global__ __launch_bounds__(64 * NW) void attn_stream_bf16_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K,
                                                                 const bf16* __restrict__ VT, bf16* __restrict__ ctx,
                                                                 int64_t ld_ctx, int L, int nh, int nbh, float scale_log2e,
@@ -594,7 +596,7 @@ __global__ __launch_bounds__(64 * NW) void attn_stream_bf16_kernel(const bf16* _
       const int row = p * KRP + lane / CH, pc = lane % CH;             // key within the stage, physical chunk
       const int lc = pc ^ ((row / RPB) & (CH - 1));
       int rsrc = row;                                                   // keys past the end: any valid row (their scores are masked)
-      if (st * SK + row >= L) rsrc = L - 1 - st * SK;
+      if (!FULL && st * SK + row >= L) rsrc = L - 1 - st * SK;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Kb + (int64_t)rsrc * qld + lc * 8),
                                        (__attribute__((address_space(3))) void*)(kdst + p * 1024), 16, 0, 0);
     }
@@ -604,7 +606,7 @@ __global__ __launch_bounds__(64 * NW) void attn_stream_bf16_kernel(const bf16* _
       const int t = p / (DH / 8), d = (p % (DH / 8)) * 8 + (lane >> 3), pc = lane & 7;
       const int lc = pc ^ ((d >> 1) & 7);
       int kc = t * 64 + lc * 8;                                         // 8 keys past the end: any valid chunk (finite values x P = 0)
-      if (st * SK + kc >= L) kc = L - 8 - st * SK;
+      if (!FULL && st * SK + kc >= L) kc = L - 8 - st * SK;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Vb + (int64_t)d * L + kc),
                                        (__attribute__((address_space(3))) void*)(vdst + p * 1024), 16, 0, 0);
     }
@@ -643,10 +645,10 @@ __global__ __launch_bounds__(64 * NW) void attn_stream_bf16_kernel(const bf16* _
       const char* kbuf = smem_dyn + (g & 1) * (2 * KST);
       const char* vbuf = kbuf + KST;
       const int st_keys = L - st * SK;                                  // valid keys of this stage (>= 16)
-      for (int t = 0; t < SK / 64 && t * 64 < st_keys; ++t) {
+      for (int t = 0; t < SK / 64 && (FULL || t * 64 < st_keys); ++t) {
         const char* kb = kbuf + t * (64 * KROWB);
         const char* vb = vbuf + t * VT_BYTES;
-        const int tile_keys = st_keys - t * 64;                         // < 64 only in the sequence's last tile
+        const int tile_keys = FULL ? 64 : st_keys - t * 64;             // < 64 only in the sequence's last tile
         f32x16 s[2];
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
@@ -659,7 +661,7 @@ __global__ __launch_bounds__(64 * NW) void attn_stream_bf16_kernel(const bf16* _
 #pragma unroll
           for (int ks = 0; ks < KS; ++ks) s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[ks], s[kt], 0, 0, 0);
         }
-        if (tile_keys < 64) {   // register r of sub-tile kt holds key 32 kt + (r & 3) + 8 (r >> 2) + 4 h: mask the ones past the end
+        if (!FULL && tile_keys < 64) {   // register r of sub-tile kt holds key 32 kt + (r & 3) + 8 (r >> 2) + 4 h: mask the ones past the end
 #pragma unroll
           for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -710,7 +712,7 @@ __global__ __launch_bounds__(64 * NW) void attn_stream_bf16_kernel(const bf16* _
             const int qc = q0 + lq < L ? q0 + lq : L - 1;
             const int kb = (st * SK + t * 64) >> 5;
             kw = drop_keep_attn(drop, bh, L, nb32, qc, kb, h);
-            if (32 < tile_keys) kw |= drop_keep_attn(drop, bh, L, nb32, qc, kb + 1, h) << 16;   // (wave-uniform)
+            if (FULL || 32 < tile_keys) kw |= drop_keep_attn(drop, bh, L, nb32, qc, kb + 1, h) << 16;   // (wave-uniform)
             keep_bits[wi] = kw;
           }
 #pragma unroll
@@ -814,7 +816,7 @@ int launch_bf16(const bf16* q, const bf16* k, const bf16* vt, bf16* ctx, int64_t
 
 namespace { int g_attn_stream = 1; }
 extern "C" int mh_attention_set_stream(int on) {
-  g_attn_stream = on < 0 ? 0 : (on > 3 ? 3 : on);
+  g_attn_stream = on < 0 ? 0 : (on > 4 ? 4 : on);
   return MH_OK;
 }
 extern "C" int mh_attention_stream_enabled(void) { return g_attn_stream; }
@@ -889,9 +891,13 @@ extern "C" int mh_attention_stream_fwd_drop(const void* q, const void* k, const 
     return MH_OK;
   };
   int rc;
-  if (dropping && bits_in) rc = dh == 64 ? go(&attn_stream_bf16_kernel<64, 16, 256, 2>, 4 * 256 * 64 * 2) : go(&attn_stream_bf16_kernel<32, 16, 256, 2>, 4 * 256 * 32 * 2);
-  else if (dropping && !small) rc = dh == 64 ? go(&attn_stream_bf16_kernel<64, 16, 256, 1>, 4 * 256 * 64 * 2) : go(&attn_stream_bf16_kernel<32, 16, 256, 1>, 4 * 256 * 32 * 2);
+  const bool full = L % 256 == 0 && g_attn_stream != 4;   // (mode 4 = A/B: the key-bound build on every length)
+  if (dropping && bits_in) {   // (the full-tile build of the bit reader spills 14 dwords per lane and measured 5 % slower: key-bound build)
+    rc = dh == 64 ? go(&attn_stream_bf16_kernel<64, 16, 256, 2>, 4 * 256 * 64 * 2) : go(&attn_stream_bf16_kernel<32, 16, 256, 2>, 4 * 256 * 32 * 2);
+  } else if (dropping && !small) rc = dh == 64 ? go(&attn_stream_bf16_kernel<64, 16, 256, 1>, 4 * 256 * 64 * 2) : go(&attn_stream_bf16_kernel<32, 16, 256, 1>, 4 * 256 * 32 * 2);
   else if (dropping) rc = dh == 64 ? go(&attn_stream_bf16_kernel<64, 8, 128, 1>, 4 * 128 * 64 * 2) : go(&attn_stream_bf16_kernel<32, 8, 256, 1>, 4 * 256 * 32 * 2);
+  else if (full && dh == 64) rc = small ? go(&attn_stream_bf16_kernel<64, 8, 128, 0, true>, 4 * 128 * 64 * 2) : go(&attn_stream_bf16_kernel<64, 16, 256, 0, true>, 4 * 256 * 64 * 2);
+  else if (full) rc = small ? go(&attn_stream_bf16_kernel<32, 8, 256, 0, true>, 4 * 256 * 32 * 2) : go(&attn_stream_bf16_kernel<32, 16, 256, 0, true>, 4 * 256 * 32 * 2);
   else if (dh == 64) rc = small ? go(&attn_stream_bf16_kernel<64, 8, 128>, 4 * 128 * 64 * 2) : go(&attn_stream_bf16_kernel<64, 16, 256>, 4 * 256 * 64 * 2);
   else rc = small ? go(&attn_stream_bf16_kernel<32, 8, 256>, 4 * 256 * 32 * 2) : go(&attn_stream_bf16_kernel<32, 16, 256>, 4 * 256 * 32 * 2);
   if (rc) return rc;

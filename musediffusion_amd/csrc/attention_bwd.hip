@@ -67,7 +67,8 @@ __device__ __forceinline__ bf16x8 cvt8(const f32x16& v, int off) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
-template <int DH, bool DROP>
+// FULL (both kernels): seq_len % 256 == 0 - no partial block, stage or tile, the per-score bound compares are compiled out
+template <int DH, bool DROP, bool FULL>
 __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K,
                                                           const bf16* __restrict__ V, const bf16* __restrict__ KT,
                                                           const bf16* __restrict__ dO, const bf16* __restrict__ O,
@@ -145,8 +146,8 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const bf16* __restrict
     const char* vst = kst + ST;
     const char* tst = kst + 2 * ST;
     const int st_keys = L - st * SKB;
-    for (int t = 0; active && t < SKB / 64 && t * 64 < st_keys; ++t) {
-      const int tile_keys = st_keys - t * 64;
+    for (int t = 0; active && t < SKB / 64 && (FULL || t * 64 < st_keys); ++t) {
+      const int tile_keys = FULL ? 64 : st_keys - t * 64;
       f32x16 s[2], dp[2];
 #pragma unroll
       for (int kt = 0; kt < 2; ++kt) {
@@ -170,7 +171,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const bf16* __restrict
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           float p = __builtin_amdgcn_exp2f(s[kt][r] * scale_log2e - lse_q);
-          if (tile_keys < 64 && kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h >= tile_keys) p = 0.f;   // key past the sequence end
+          if (!FULL && tile_keys < 64 && kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h >= tile_keys) p = 0.f;   // key past the sequence end
           float dpv = dp[kt][r];
           if constexpr (DROP) dpv = (km >> r) & 1u ? dpv * rscale : 0.f;
           s[kt][r] = p * (dpv - D_q);                            // dS^T (the 1/sqrt(dh) factor is applied to dQ at the end)
@@ -207,7 +208,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const bf16* __restrict
 }
 
 // ---------------------------------------------------------------------------------------------------------
-template <int DH, bool DROP>
+template <int DH, bool DROP, bool FULL>
 __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K,
                                                            const bf16* __restrict__ V, const bf16* __restrict__ QT,
                                                            const bf16* __restrict__ dO, const bf16* __restrict__ dOT,
@@ -282,7 +283,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const bf16* __restric
     const char* otst = qst + 3 * ST;
     const float* lst = reinterpret_cast<const float*>(qst + 4 * ST);   // [0..127] lse2, [128..255] D
     const int st_q = L - st * SKB;                                      // queries of this stage that exist
-    for (int t = 0; active && t < SKB / 64 && t * 64 < st_q; ++t) {
+    for (int t = 0; active && t < SKB / 64 && (FULL || t * 64 < st_q); ++t) {
 #pragma unroll
       for (int qt = 0; qt < 2; ++qt) {
         const int R = t * 64 + 32 * qt + lq;
@@ -316,7 +317,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const bf16* __restric
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             float p = __builtin_amdgcn_exp2f(s[rg * 4 + e] * scale_log2e - ls[e]);
-            if (qi + e >= st_q) p = 0.f;                                  // query past the sequence end
+            if (!FULL && qi + e >= st_q) p = 0.f;                                  // query past the sequence end
             float dpv = dp[rg * 4 + e], pd = p;
             if constexpr (DROP) {                                         // P_drop feeds dV; dP = dP_drop o keep / (1 - p)
               const uint32_t kwe = e == 0 ? kwv[rg].x : e == 1 ? kwv[rg].y : e == 2 ? kwv[rg].z : kwv[rg].w;
@@ -383,7 +384,7 @@ __global__ void attn_bwd_rowdot_kernel(const bf16* __restrict__ dctx, const bf16
   }
 }
 
-template <int DH, bool DROP>
+template <int DH, bool DROP, bool FULL>
 int launch_bwd(const bf16* q, const bf16* k, const bf16* v, const bf16* qT, const bf16* kT, const bf16* dO, const bf16* dOT, const bf16* o,
                const float* lse2, float* Dv, bf16* dq, bf16* dk, bf16* dv, int64_t ld, int B, int L, int nh, float scale,
                RowLayout lqkv, RowLayout ldo, const uint32_t* keep_bits, float rscale, hipStream_t s) {
@@ -391,8 +392,8 @@ int launch_bwd(const bf16* q, const bf16* k, const bf16* v, const bf16* qT, cons
   constexpr int bytes_dq = 2 * 3 * ST, bytes_dkv = 2 * (4 * ST + 1024);
   static bool attr_set = false;
   if (!attr_set) {
-    MH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_kernel<DH, DROP>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes_dq));
-    MH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkv_kernel<DH, DROP>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes_dkv));
+    MH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_kernel<DH, DROP, FULL>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes_dq));
+    MH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkv_kernel<DH, DROP, FULL>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes_dkv));
     attr_set = true;
   }
   int dev = 0, cus = 256;
@@ -400,10 +401,10 @@ int launch_bwd(const bf16* q, const bf16* k, const bf16* v, const bf16* qT, cons
   const int nbh = B * nh, nitems = nbh * ((L + 255) / 256);
   const dim3 grid((unsigned)(nitems < cus ? nitems : cus)), block(512);
   const float sl2 = scale * 1.4426950408889634f;
-  MH_LAUNCH((attn_bwd_dq_kernel<DH, DROP>), grid, block, bytes_dq, s, q, k, v, kT, dO, o, lse2, Dv, dq, ld, L, nh, nbh, scale, sl2, lqkv, ldo,
+  MH_LAUNCH((attn_bwd_dq_kernel<DH, DROP, FULL>), grid, block, bytes_dq, s, q, k, v, kT, dO, o, lse2, Dv, dq, ld, L, nh, nbh, scale, sl2, lqkv, ldo,
             keep_bits, rscale);
   MH_CHECK_LAUNCH();
-  MH_LAUNCH((attn_bwd_dkv_kernel<DH, DROP>), grid, block, bytes_dkv, s, q, k, v, qT, dO, dOT, lse2, Dv, dk, dv, ld, L, nh, nbh, scale, sl2, lqkv, ldo,
+  MH_LAUNCH((attn_bwd_dkv_kernel<DH, DROP, FULL>), grid, block, bytes_dkv, s, q, k, v, qT, dO, dOT, lse2, Dv, dk, dv, ld, L, nh, nbh, scale, sl2, lqkv, ldo,
             keep_bits, rscale);
   MH_CHECK_LAUNCH();
   return MH_OK;
@@ -470,7 +471,11 @@ extern "C" int mh_attention_stream_bwd_drop(const void* q, const void* k, const 
   const float rs = 1.0f / (1.0f - drop_p);
 #define MH_BWD_ARGS (const bf16*)q, (const bf16*)k, (const bf16*)v, (const bf16*)qT_perm, (const bf16*)kT_perm, (const bf16*)dO, \
                     (const bf16*)dOT_perm, (const bf16*)o, lse2, D, (bf16*)dq, (bf16*)dk, (bf16*)dv, ld_d, B, L, nh, scale, lqkv, ldo, keep_bits, rs, s
-  if (drop_p > 0.f) return dh == 64 ? launch_bwd<64, true>(MH_BWD_ARGS) : launch_bwd<32, true>(MH_BWD_ARGS);
-  return dh == 64 ? launch_bwd<64, false>(MH_BWD_ARGS) : launch_bwd<32, false>(MH_BWD_ARGS);
+  if (L % 256 == 0 && mh_attention_stream_enabled() != 4) {   // (mode 4 = A/B: the bound-checking build on every length)
+    if (drop_p > 0.f) return dh == 64 ? launch_bwd<64, true, true>(MH_BWD_ARGS) : launch_bwd<32, true, true>(MH_BWD_ARGS);
+    return dh == 64 ? launch_bwd<64, false, true>(MH_BWD_ARGS) : launch_bwd<32, false, true>(MH_BWD_ARGS);
+  }
+  if (drop_p > 0.f) return dh == 64 ? launch_bwd<64, true, false>(MH_BWD_ARGS) : launch_bwd<32, true, false>(MH_BWD_ARGS);
+  return dh == 64 ? launch_bwd<64, false, false>(MH_BWD_ARGS) : launch_bwd<32, false, false>(MH_BWD_ARGS);
 #undef MH_BWD_ARGS
 }

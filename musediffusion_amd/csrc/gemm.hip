@@ -1552,15 +1552,21 @@ namespace {
 struct TnArgs {
   const bf16* A; int64_t lda;   // [K, lda], columns = m
   const bf16* B; int64_t ldb;   // [K, ldb], columns = n
-  float* out;                   // [splits][M][N]
+  float* out;                   // [splits][slice]: M x N products, then (CS) the M column sums of A
   int M, N;
   int64_t Kslice;               // tokens per slice (multiple of 32)
+  int64_t slice;                // floats per split slice: M N (+ M)
 };
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 
 __device__ __forceinline__ int tn_f(int row) { return ((row & 3) | (((row >> 3) & 1) << 2)) << 1; }
 
+// CS > 0: the kernel also writes the column sums of A over its token slice (the bias gradient of the same linear: A = dY) behind
+// the M x N products of the slice.  They come out of the matrix pipe - one more MFMA against an all-ones operand gives sum_k A[k][m]
+// in every row of the product - and the work is dealt out over the blocks and waves that share a 256-column panel of A: CS = number
+// of (n-tile, wave column) workers taking part (2, 4 or 8), worker w sums the 16-column tiles i with i % CS == w.
+template <int CS>
 __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnArgs g) {
   constexpr int BMt = 256, BNt = 128, NSTt = 3, ASTAGE = 32 * BMt * 2, BSTAGE = 32 * BNt * 2, STAGEt = ASTAGE + BSTAGE;
   constexpr int TIt = 8, TJt = 4;
@@ -1639,6 +1645,14 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnArgs g) {
   for (int i = 0; i < TIt; ++i)
 #pragma unroll
     for (int j = 0; j < TJt; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  constexpr int NCS = CS > 0 ? TIt / CS : 1;               // column-sum tiles per worker
+  f32x4 accs[NCS];
+#pragma unroll
+  for (int c = 0; c < NCS; ++c) accs[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int worker = (int)(blockIdx.x % tiles_n) * 2 + wn;  // (wave-uniform)
+  bf16x8 ones;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones[e] = (bf16)1.0f;
 
   const int npro = nk < NSTt - 1 ? nk : NSTt - 1;
   for (int st = 0; st < npro; ++st) issue(st);
@@ -1657,10 +1671,30 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnArgs g) {
     for (int i = 0; i < TIt; ++i)
 #pragma unroll
       for (int j = 0; j < TJt; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);   // D'[n][m]
+    if constexpr (CS > 0) {
+      if (worker < CS) {
+#pragma unroll
+        for (int c = 0; c < NCS; ++c) {
+          bf16x8 ac = a[c * CS];
+#pragma unroll
+          for (int w = 1; w < CS; ++w) if (worker == w) ac = a[c * CS + w];
+          accs[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, ac, accs[c], 0, 0, 0);
+        }
+      }
+    }
     __builtin_amdgcn_s_waitcnt(0xC07F);
   }
   // D' tile (rows n, cols m): lane holds m = fr, n = 4 fg + r -> 4 consecutive n of one m: one 16-byte store
-  float* outp = g.out + (int64_t)blockIdx.y * g.M * g.N;
+  float* outp = g.out + (int64_t)blockIdx.y * g.slice;
+  if constexpr (CS > 0) {
+    if (worker < CS && fg == 0) {                           // every row of the ones-product holds the sums: take row 0 (lanes 0..15)
+#pragma unroll
+      for (int c = 0; c < NCS; ++c) {
+        const int m = m0 + wm * 128 + 16 * (c * CS + worker) + fr;
+        if (m < g.M) outp[(int64_t)g.M * g.N + m] = accs[c][0];
+      }
+    }
+  }
 #pragma unroll
   for (int i = 0; i < TIt; ++i) {
     const int m = m0 + wm * 128 + 16 * i + fr;
@@ -1676,23 +1710,45 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnArgs g) {
 
 }  // namespace
 
+namespace { int g_dw_blocks = 512; }
+// blocks a weight-gradient launch aims for when it cuts the token range (A/B knob; 512 = two per CU)
+extern "C" int mh_gemm_dw_set_blocks(int blocks) {
+  g_dw_blocks = blocks < 1 ? 1 : blocks;
+  return MH_OK;
+}
+
 extern "C" int mh_gemm_dw_splits(int64_t K, int M, int N) {
   const int tiles = ceil_div(M, 256) * ceil_div(N, 128);
   int S = 1;
-  while (S < 64 && tiles * S < 512 && K % (2 * S * 32) == 0 && K / (2 * S) >= 512) S *= 2;
+  while (S < 64 && tiles * S < g_dw_blocks && K % (2 * S * 32) == 0 && K / (2 * S) >= 512) S *= 2;
   return S;
 }
 
 // dW = A^T B for k-major bf16 operands: out_partials [splits][M][N] fp32 (splits = mh_gemm_dw_splits(K, M, N); fold with
 // mh_sum_slices).  M, N multiples of 8, lda / ldb multiples of 8, K a multiple of 32 * splits.
+extern "C" int mh_gemm_dw_bias(const void* A, int64_t lda, const void* B, int64_t ldb, float* out_partials, int splits, int64_t K, int M,
+                               int N, int with_colsum, mh_stream_t stream);
+
 extern "C" int mh_gemm_dw(const void* A, int64_t lda, const void* B, int64_t ldb, float* out_partials, int splits, int64_t K, int M,
                           int N, mh_stream_t stream) {
+  return mh_gemm_dw_bias(A, lda, B, ldb, out_partials, splits, K, M, N, 0, stream);
+}
+
+// with_colsum != 0: every split slice is M N + M floats - the products, then the column sums of A over the slice's tokens (A = dY:
+// the bias gradient of the linear whose weight gradient this is); one mh_sum_slices over M N + M elements folds both.
+extern "C" int mh_gemm_dw_bias(const void* A, int64_t lda, const void* B, int64_t ldb, float* out_partials, int splits, int64_t K, int M,
+                               int N, int with_colsum, mh_stream_t stream) {
   MH_CHECK_ARG(A && B && out_partials, "gemm_dw: null pointer");
   MH_CHECK_ARG(M > 0 && N > 0 && M % 8 == 0 && N % 4 == 0 && N % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0, "gemm_dw: M, N, lda, ldb must be multiples of 8");
   MH_CHECK_ARG(splits >= 1 && splits <= 65535 && K > 0 && K % ((int64_t)splits * 32) == 0, "gemm_dw: K=%lld must be a multiple of 32 * splits", (long long)K);
-  TnArgs g{(const bf16*)A, lda, (const bf16*)B, ldb, out_partials, M, N, K / splits};
-  const dim3 grid((unsigned)(ceil_div(M, 256) * ceil_div(N, 128)), (unsigned)splits);
-  MH_LAUNCH(gemm_tn_kernel, grid, dim3(256), 0, (hipStream_t)stream, g);
+  TnArgs g{(const bf16*)A, lda, (const bf16*)B, ldb, out_partials, M, N, K / splits, (int64_t)M * N + (with_colsum ? M : 0)};
+  const int tiles_n = ceil_div(N, 128);
+  const dim3 grid((unsigned)(ceil_div(M, 256) * tiles_n), (unsigned)splits);
+  mh_prof_note("gemm_dw M=%d N=%d K=%lld splits=%d colsum=%d", M, N, (long long)K, splits, with_colsum != 0);
+  if (!with_colsum) MH_LAUNCH(gemm_tn_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, g);
+  else if (tiles_n >= 4) MH_LAUNCH(gemm_tn_kernel<8>, grid, dim3(256), 0, (hipStream_t)stream, g);
+  else if (tiles_n >= 2) MH_LAUNCH(gemm_tn_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, g);
+  else MH_LAUNCH(gemm_tn_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, g);
   MH_CHECK_LAUNCH();
   return MH_OK;
 }

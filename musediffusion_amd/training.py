@@ -103,20 +103,26 @@ def _gemm_dw(dT, xT, N, Kp, Mp, dt):
     return dW
 
 
-def _dw(dy, x, N, Kp, M, dt):
-    """dW [N, Kp] fp32 = dy[:, :N]^T x[:, :Kp] over the M token rows.  bf16: one kernel reads both operands as the forward
-    left them (k-major) and transposes inside LDS; otherwise explicit transposes + the split-K GEMM."""
+def _dw(dy, x, N, Kp, M, dt, bias=False):
+    """dW [N, Kp] fp32 = dy[:, :N]^T x[:, :Kp] over the M token rows (bias: and db [N] = column sums of dy, returned as a pair).
+    bf16: one kernel reads both operands as the forward left them (k-major), transposes inside LDS and takes the column sums off
+    the matrix pipe; otherwise explicit transposes + the split-K GEMM and a column-sum pass."""
     if TN_DW and dt == ops.MH_BF16 and N % 8 == 0 and Kp % 8 == 0 and dy.shape[1] % 8 == 0 and x.shape[1] % 8 == 0 and M % 32 == 0:
         S = int(lib().mh_gemm_dw_splits(M, N, Kp))
-        part = torch.empty(S, N, Kp, device=dy.device, dtype=torch.float32)
-        check(lib().mh_gemm_dw(ptr(dy), dy.shape[1], ptr(x), x.shape[1], ptr(part), S, M, N, Kp, current_stream()), "mh_gemm_dw")
+        n = N * Kp + (N if bias else 0)
+        part = torch.empty(S, n, device=dy.device, dtype=torch.float32)
+        check(lib().mh_gemm_dw_bias(ptr(dy), dy.shape[1], ptr(x), x.shape[1], ptr(part), S, M, N, Kp, int(bias), current_stream()),
+              "mh_gemm_dw_bias")
         if S == 1:
-            return part[0]
-        dW = torch.empty(N, Kp, device=dy.device, dtype=torch.float32)
-        check(lib().mh_sum_slices(ptr(part), S, N * Kp, ptr(dW), current_stream()), "mh_sum_slices")
-        return dW
+            out = part[0]
+        else:
+            out = torch.empty(n, device=dy.device, dtype=torch.float32)
+            check(lib().mh_sum_slices(ptr(part), S, n, ptr(out), current_stream()), "mh_sum_slices")
+        dW = out[:N * Kp].view(N, Kp)
+        return (dW, out[N * Kp:]) if bias else dW
     Mp = ops.pad64(M)
-    return _gemm_dw(_transpose(dy, M, N, dt, ld_out=Mp), _transpose(x, M, Kp, dt, ld_out=Mp), N, Kp, Mp, dt)
+    dW = _gemm_dw(_transpose(dy, M, N, dt, ld_out=Mp), _transpose(x, M, Kp, dt, ld_out=Mp), N, Kp, Mp, dt)
+    return (dW, _col_sum(dy, M, N, dt)) if bias else dW
 
 
 def _transpose(x, rows, cols, dt, ld_out=None, batch=1, stride_in=0, stride_out=0, ld_in=None):
@@ -212,13 +218,12 @@ class _Linear(Function):
             dpre = ctx.drop.apply(dy, dt)          # the dense branch sees dY o keep / (1 - p); the residual branch sees dY
         else:
             dpre = dy
-        db = _col_sum(dpre, M, N, dt) if has_b else None
         # dX = dpre W : reduction over the N outputs
         WT = _transpose(Wc, N, Kp, dt, ld_out=Np)                      # [Kp, Np]
         dx = _zeros(M, Kp, dt, x.device, Kp)
         _gemm(dpre, WT, None, dt, Kp, Np, out=dx)
         # dW = dpre^T X : reduction over the M rows
-        dW = _dw(dpre, x, N, Kp, M, dt)
+        dW, db = _dw(dpre, x, N, Kp, M, dt, bias=True) if has_b else (_dw(dpre, x, N, Kp, M, dt), None)
         return dx, dW[:, :K].contiguous(), db, None, (dy if has_res else None), None, None
 
 
@@ -259,15 +264,13 @@ class _FFN(Function):
         F = W1c.shape[0]
         dy = dy.contiguous()
         dym = ctx.drop.apply(dy, dt) if ctx.drop is not None else dy      # gradient of the dropped dense output
-        db2 = _col_sum(dym, M, H, dt)
-        dW2 = _dw(dym, f, H, F, M, dt)
+        dW2, db2 = _dw(dym, f, H, F, M, dt, bias=True)
         # d(pre) = (dy W2) o gelu'(pre): W2 is [H, F]; the GEMM wants the reduction dim contiguous -> W2^T [F, H]
         dpre = torch.empty(M, F, device=x.device, dtype=x.dtype)
         W2T = _transpose(W2c, H, F, dt, ld_out=H)
         check(lib().mh_gemm_act_grad(ptr(dym), H, ptr(W2T), H, ptr(pre), F, ptr(dpre), F, M, F, H, ops.ACT["gelu"], current_stream()),
               "mh_gemm_act_grad")
-        db1 = _col_sum(dpre, M, F, dt)
-        dW1 = _dw(dpre, x, F, H, M, dt)
+        dW1, db1 = _dw(dpre, x, F, H, M, dt, bias=True)
         dx = torch.empty(M, H, device=x.device, dtype=x.dtype)
         W1T = _transpose(W1c, F, H, dt, ld_out=F)                         # [H, F]
         _gemm(dpre, W1T, None, dt, H, F, out=dx, residual=dy)             # + dy: the residual branch

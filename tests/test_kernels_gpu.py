@@ -266,6 +266,23 @@ def test_gemm_dw_k_major(K, M, N):
     assert_close(out, ref, 2e-3 * math.sqrt(K / 1024), 1e-3, what="gemm_dw K=%d M=%d N=%d splits=%d" % (K, M, N, S))
 
 
+@pytest.mark.parametrize("K,M,N", [(4096, 512, 512), (2048, 264, 136), (8192, 2048, 512), (8192, 512, 2048), (1024, 72, 64), (2048, 128, 384)])
+def test_gemm_dw_with_bias_gradient(K, M, N):
+    """the fused form: each split slice carries dW and, behind it, the column sums of dY (all-ones MFMA); one mh_sum_slices folds both"""
+    from musediffusion_amd._lib import check, current_stream
+    A, B = rnd(K, M, seed=272, scale=0.5), rnd(K, N, seed=273, scale=0.5)
+    ref, ref_b = q(A, MH_BF16).T @ q(B, MH_BF16), q(A, MH_BF16).sum(0)
+    Ad, Bd = A.to(DEV).bfloat16().contiguous(), B.to(DEV).bfloat16().contiguous()
+    S = int(lib().mh_gemm_dw_splits(K, M, N))
+    n = M * N + M
+    part = torch.full((S, n), float("nan"), device=DEV)
+    check(lib().mh_gemm_dw_bias(Ad.data_ptr(), M, Bd.data_ptr(), N, part.data_ptr(), S, K, M, N, 1, current_stream()))
+    out = torch.empty(n, device=DEV)
+    check(lib().mh_sum_slices(part.data_ptr(), S, n, out.data_ptr(), current_stream()))
+    assert_close(out[:M * N].view(M, N), ref, 2e-3 * math.sqrt(K / 1024), 1e-3, what="gemm_dw_bias dW K=%d M=%d N=%d splits=%d" % (K, M, N, S))
+    assert_close(out[M * N:], ref_b, 2e-3 * math.sqrt(K / 1024), 1e-3, what="gemm_dw_bias db K=%d M=%d N=%d" % (K, M, N))
+
+
 def test_gemm_qkv_vtperm():
     from musediffusion_amd._lib import check, current_stream
     B, L, H, nh = 2, 48, 128, 2

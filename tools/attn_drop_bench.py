@@ -52,3 +52,9 @@ print("in-kernel, 16 waves   : %7.1f us" % t(lambda: fwd(True, 0)))
 L_.mh_attention_set_stream(1)
 print("bit pre-pass          : %7.1f us" % t(gen))
 print("bit-reading forward   : %7.1f us" % t(lambda: fwd(True, 1)))
+# key-bound compares compiled out (seq_len % 256 == 0) against the general build (mode 4), alternating
+for rep in range(3):
+    for mode, name in ((1, "full-tile build"), (4, "key-bound build")):
+        L_.mh_attention_set_stream(mode)
+        print("%s: no dropout %7.1f us   bit-reading %7.1f us" % (name, t(lambda: fwd(False, 0)), t(lambda: fwd(True, 1))))
+L_.mh_attention_set_stream(1)

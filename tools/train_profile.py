@@ -16,8 +16,11 @@ from musediffusion_amd import _lib, synthetic  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--dropout", type=float, default=0.1)
 ap.add_argument("--steps", type=int, default=2)
+ap.add_argument("--dw-blocks", type=int, default=0, help="A/B: blocks a weight-gradient launch aims for (mh_gemm_dw_set_blocks)")
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
+if a.dw_blocks:
+    _lib.check(_lib.lib().mh_gemm_dw_set_blocks(a.dw_blocks))
 c = bench.WORKLOADS["train"]
 model, diff = bench.build(c, "bf16", dev, seed=0)
 model.dropout.p = a.dropout
@@ -55,7 +58,7 @@ acc = collections.defaultdict(lambda: [0, 0.0])
 tot = 0.0
 for line in buf.value.decode().splitlines():
     kernel, note, grid, block, stream, ms = line.split("\t")
-    key = kernel.strip("()")[:60] + (" | " + " ".join(x for x in note.split() if x.split("=")[0] in ("tile", "epi", "act", "N", "K", "drop")) if note else "")
+    key = kernel.strip("()")[:60] + (" | " + " ".join(x for x in note.split() if x.split("=")[0] in ("tile", "epi", "act", "M", "N", "K", "drop", "splits")) if note else "")
     acc[key][0] += 1
     acc[key][1] += float(ms)
     tot += float(ms)
