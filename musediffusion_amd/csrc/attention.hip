@@ -558,7 +558,8 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(const float* __restrict__
 // DROP: 0 = no dropout, 1 = generate the keep flags (Philox) and write the bit tensor, 2 = read the bit tensor (a pre-pass or a test
 // wrote it): the reading variant needs no generator registers and fits the 16-wave geometry
 // FULL: seq_len is a multiple of SK, so no stage or tile is partial - the key-bound compares (which hipcc if-converts into a compare
-// + select per score of EVERY tile, a third of the tile's vector instructions) are compiled out
+// + select per score of EVERY tile, a third of the tile's vector instructions) are compiled out.  (The bit reader keeps the
+// key-bound body: its bound-free build spills 60 B per lane and measured 5 % slower, as did staging its keep words in LDS.)
 template <int DH, int NW = 16, int SK = 256, int DROP = 0, bool FULL = false>
 __global__ __launch_bounds__(64 * NW) void attn_stream_bf16_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K,
                                                                 const bf16* __restrict__ VT, bf16* __restrict__ ctx,
@@ -892,7 +893,7 @@ extern "C" int mh_attention_stream_fwd_drop(const void* q, const void* k, const 
   };
   int rc;
   const bool full = L % 256 == 0 && g_attn_stream != 4;   // (mode 4 = A/B: the key-bound build on every length)
-  if (dropping && bits_in) {   // (the full-tile build of the bit reader spills 14 dwords per lane and measured 5 % slower: key-bound build)
+  if (dropping && bits_in) {
     rc = dh == 64 ? go(&attn_stream_bf16_kernel<64, 16, 256, 2>, 4 * 256 * 64 * 2) : go(&attn_stream_bf16_kernel<32, 16, 256, 2>, 4 * 256 * 32 * 2);
   } else if (dropping && !small) rc = dh == 64 ? go(&attn_stream_bf16_kernel<64, 16, 256, 1>, 4 * 256 * 64 * 2) : go(&attn_stream_bf16_kernel<32, 16, 256, 1>, 4 * 256 * 32 * 2);
   else if (dropping) rc = dh == 64 ? go(&attn_stream_bf16_kernel<64, 8, 128, 1>, 4 * 128 * 64 * 2) : go(&attn_stream_bf16_kernel<32, 8, 256, 1>, 4 * 256 * 32 * 2);

@@ -102,6 +102,11 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const bf16* __restrict
     for (int j = 0; j < PK; ++j) dma_rows<DH>(V + roff, lq_.ld, base + ST, wave + NW * j, lane, valid);
 #pragma unroll
     for (int j = 0; j < PK; ++j) dma_cols<DH>(Tb, L, base + 2 * ST, wave + NW * j, lane, valid);
+    if constexpr (DROP && FULL) {   // this wave's keep words of the stage's two 64-key tiles (2 x 64 words, contiguous): 512 B, lanes 0..31
+      const int qbw = (item % nqb) * 8 + wave;
+      if (lane < 32)
+        glds16(keep_bits + drop_word_index(bh, (L + 31) >> 5, qbw, st * (SKB / 64), 0) + 4 * lane, smem_dyn + 2 * 3 * ST + (g & 1) * 4096 + wave * 512);
+    }
   };
 
   bf16x8 qf[KS], dof[KS];
@@ -161,7 +166,9 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const bf16* __restrict
         }
       }
       uint32_t kw = 0xffffffffu;
-      if constexpr (DROP) {   // dP = dP_drop o keep / (1 - p): this lane's word of the 64-key tile, as the forward stored it
+      if constexpr (DROP && FULL) {   // ... staged in LDS with the operands (a global load here would wait for the next stage's DMA)
+        kw = *reinterpret_cast<const uint32_t*>(smem_dyn + 2 * 3 * ST + (g & 1) * 4096 + wave * 512 + t * 256 + lane * 4);
+      } else if constexpr (DROP) {   // dP = dP_drop o keep / (1 - p): this lane's word of the 64-key tile, as the forward stored it
         const int nb32 = (L + 31) >> 5;
         kw = keep_bits[drop_word_index(bh, nb32, q0 >> 5, (st * SKB + t * 64) >> 6, lane)];
       }
@@ -220,7 +227,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const bf16* __restric
   constexpr int KS = DH / 16, DT = DH / 32;
   constexpr int ST = SKB * DH * 2;
   constexpr int PK = ST / 1024 / NW;
-  constexpr int BUF = 4 * ST + 1024;                // Q rows, dO rows, Q^T, dO^T, (lse2 | D) of the stage's 128 queries
+  constexpr int BUF = 4 * ST + 1024 + (DROP && FULL ? 4096 : 0);   // Q rows, dO rows, Q^T, dO^T, (lse2 | D) of the stage's 128 queries, keep words
   extern __shared__ __attribute__((aligned(16))) char smem_dyn[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -249,6 +256,11 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const bf16* __restric
       int qo = 4 * (lane & 31);
       if (qo >= valid) qo = valid - 4;
       glds16((lane < 32 ? lse2 : Dv) + r0 + qo, base + 4 * ST);
+    }
+    if constexpr (DROP && FULL) {   // keep words of (4 query blocks of the stage) x (the block's 4 pairs of key blocks): 1 KiB per query block
+      if (wave >= 4)
+        glds16(keep_bits + drop_word_index(bh, (L + 31) >> 5, st * (SKB / 32) + wave - 4, (item % nkb) * 4, 0) + 4 * lane,
+               base + 4 * ST + 1024 + (wave - 4) * 1024);
     }
   };
 
@@ -297,9 +309,15 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const bf16* __restric
           int qb = (st * SKB + t * 64 + 32 * qt) >> 5; if (qb >= nb32) qb = nb32 - 1;
           const int kbk = k0 >> 5, hk = (lq >> 2) & 1;
           kshift = (lq & 3) + 4 * (lq >> 3) + 16 * (kbk & 1);
-          const uint32_t* wp = keep_bits + drop_word_index(bh, nb32, qb, kbk >> 1, 32 * hk + 4 * h);
+          if constexpr (FULL) {   // staged in LDS with the operands
+            const uint32_t* wl = reinterpret_cast<const uint32_t*>(qst + 4 * ST + 1024) + (2 * t + qt) * 256 + ((wave >> 1) & 3) * 64 + 32 * hk + 4 * h;
 #pragma unroll
-          for (int rg = 0; rg < 4; ++rg) kwv[rg] = *reinterpret_cast<const uint4*>(wp + 8 * rg);
+            for (int rg = 0; rg < 4; ++rg) kwv[rg] = *reinterpret_cast<const uint4*>(wl + 8 * rg);
+          } else {
+            const uint32_t* wp = keep_bits + drop_word_index(bh, nb32, qb, kbk >> 1, 32 * hk + 4 * h);
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) kwv[rg] = *reinterpret_cast<const uint4*>(wp + 8 * rg);
+          }
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
@@ -389,7 +407,7 @@ int launch_bwd(const bf16* q, const bf16* k, const bf16* v, const bf16* qT, cons
                const float* lse2, float* Dv, bf16* dq, bf16* dk, bf16* dv, int64_t ld, int B, int L, int nh, float scale,
                RowLayout lqkv, RowLayout ldo, const uint32_t* keep_bits, float rscale, hipStream_t s) {
   constexpr int ST = SKB * DH * 2;
-  constexpr int bytes_dq = 2 * 3 * ST, bytes_dkv = 2 * (4 * ST + 1024);
+  constexpr int bytes_dq = 2 * 3 * ST + (DROP && FULL ? 2 * 4096 : 0), bytes_dkv = 2 * (4 * ST + 1024 + (DROP && FULL ? 4096 : 0));
   static bool attr_set = false;
   if (!attr_set) {
     MH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_kernel<DH, DROP, FULL>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes_dq));
