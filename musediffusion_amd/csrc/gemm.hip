@@ -386,14 +386,19 @@ struct BigCfg {
   static constexpr int NW = WM * WN, THREADS = NW * 64;
   static constexpr int TI = BM / WM / 16, TJ = BN / WN / 16;
   static constexpr int STAGE = (BM + BN) * 64;
-  static constexpr int PA = BM / 16 / NW, PW = BN / 16 / NW, PIECES = PA + PW;
-  static_assert(PA >= 1 && PW >= 1 && TJ % 4 == 0 && NST >= 3, "unsupported big-tile configuration");
+  // DMA pieces (16 rows x 64 B) per wave and stage.  A tile with fewer A pieces than waves (BM 64 on 8 waves) still gives every
+  // wave one: the upper waves re-load the lower waves' pieces (identical bytes to the same LDS address), so that every wave's
+  // vmcnt arithmetic stays the same
+  static constexpr int APIECES = BM / 16;
+  static constexpr int PA = (APIECES + NW - 1) / NW, PW = BN / 16 / NW, PIECES = PA + PW;
+  static_assert(PA >= 1 && PW >= 1 && TJ % 4 == 0 && NST >= 3 && (APIECES % NW == 0 || NW % APIECES == 0), "unsupported big-tile configuration");
 };
 using CfgStd = BigCfg<256, 128, 2, 2, 3>;
 using CfgWide = BigCfg<256, 256, 2, 4, 4>;
 using CfgRow = BigCfg<128, 512, 2, 4, 3>;
 using CfgWidePP = BigCfg<256, 256, 2, 4, 4, true>;
 using CfgRowPP = BigCfg<128, 512, 2, 4, 3, true>;
+using CfgRow64 = BigCfg<64, 512, 1, 8, 3>;   // full-row tile over 64 rows: twice the blocks of CfgRow (short K: the epilogue dominates)
 constexpr int B2K = 32;
 
 // one DMA stage (K-step kt) of a tile into ring slot kt % NST: PA + PW 1-KiB pieces per wave
@@ -644,7 +649,7 @@ __global__ __launch_bounds__(C::THREADS, C::STAGE * C::NST <= 80 * 1024 ? 2 : 1)
   const int64_t a_row = g.a_panel ? 32 : g.lda, w_row = g.w_panel ? 32 : g.ldw;
   const int64_t kstepA = g.a_panel ? g.lda * 64 : 64, kstepW = g.w_panel ? g.ldw * 64 : 64;
 #pragma unroll
-  for (int j = 0; j < C::PA; ++j) ldsA[j] = (wave * C::PA + j) * 16 * 64;
+  for (int j = 0; j < C::PA; ++j) ldsA[j] = ((wave * C::PA + j) % C::APIECES) * 16 * 64;
 #pragma unroll
   for (int j = 0; j < C::PW; ++j) ldsW[j] = (wave * C::PW + j) * 16 * 64;
   auto set_sources = [&](int tile) {
@@ -655,7 +660,7 @@ __global__ __launch_bounds__(C::THREADS, C::STAGE * C::NST <= 80 * 1024 ? 2 : 1)
     const int lc = pc ^ GSW[(rl >> 2) & 3];          // logical chunk stored at this physical slot
 #pragma unroll
     for (int j = 0; j < C::PA; ++j) {
-      int64_t ra = tm0 + (wave * C::PA + j) * 16 + rl; if (ra >= g.M) ra = g.M - 1;
+      int64_t ra = tm0 + ((wave * C::PA + j) % C::APIECES) * 16 + rl; if (ra >= g.M) ra = g.M - 1;
       srcA[j] = reinterpret_cast<const char*>(g.A) + ((int64_t)blockIdx.y * g.sA + ra * a_row + lc * 8) * 2;
     }
 #pragma unroll
@@ -1344,6 +1349,7 @@ extern "C" int mh_gemm_bias_res_ln(const void* A, int64_t lda, int a_panel, cons
   if (N == 256) return launch_big<CfgWidePP, 3>(g, s, 1);
   // one block per CU: the ping-pong main loop pays here (-4.5% step time, tools/ab_step.py); bit 2 of the A/B mask = plain loop
   if (g_plain_stores & 4) return launch_big<CfgRow, 3>(g, s, 1);
+  if ((g_plain_stores & 16) || ((g_plain_stores & 8) && K <= 512)) return launch_big<CfgRow64, 3>(g, s, 1);   // A/B: 64-row full-row tile
   return launch_big<CfgRowPP, 3>(g, s, 1);
 }
 

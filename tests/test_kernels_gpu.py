@@ -481,10 +481,20 @@ def test_gemm_big_tile_variants(variant):
         lib().mh_gemm_set_variant(2)
 
 
-@pytest.mark.parametrize("N", [128, 256, 512])
+@pytest.mark.parametrize("N,rows64", [(128, 0), (256, 0), (512, 0), (512, 1)])
 @pytest.mark.parametrize("panel", [0, 1])
-def test_gemm_bias_residual_layernorm(N, panel):
-    """dense + residual + LayerNorm in one kernel == the three separate steps (BertSelfOutput / BertOutput)"""
+def test_gemm_bias_residual_layernorm(N, panel, rows64):
+    """dense + residual + LayerNorm in one kernel == the three separate steps (BertSelfOutput / BertOutput); rows64: the 64-row
+    full-row tile (twice the blocks; selectable with mh_gemm_set_plain_stores bit 16)"""
+    from musediffusion_amd._lib import check, current_stream
+    lib().mh_gemm_set_plain_stores(16 if rows64 else 0)
+    try:
+        _gemm_bias_residual_layernorm(N, panel)
+    finally:
+        lib().mh_gemm_set_plain_stores(0)
+
+
+def _gemm_bias_residual_layernorm(N, panel):
     from musediffusion_amd._lib import check, current_stream
     M, K = 333, 2 * N
     A, W = rnd(M, K, seed=181, scale=0.5), rnd(N, K, seed=182, scale=1.0 / math.sqrt(K))
