@@ -243,12 +243,13 @@ __global__ void act_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x
 // ------------------------------------------------------------------ LayerNorm backward
 // one wave per row (H <= 2048); block = 4 waves walking rows blockIdx.x*4 + w, + gridDim.x*4, ...;
 // dgamma / dbeta partials accumulate in registers over the block's rows and are written per block.
-constexpr int LNCH = 4;
-template <typename T>
+// LNCH = 16-byte chunks per lane (ceil(H / 512)): a compile-time bound keeps the per-row and per-column registers of a narrow model
+// at a quarter of the H = 2048 build's, i.e. four times the waves per SIMD to hide the row's dependent reductions behind
+template <typename T, int LNCH>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, const float* __restrict__ gamma,
                                                      T* __restrict__ dx, float* __restrict__ pg, float* __restrict__ pb,
                                                      int64_t rows, int H, float eps) {
-  __shared__ float red[2][4][2048 / 1];  // [dgamma|dbeta][wave][col]  (32 KiB)
+  __shared__ float red[2][4][512 * LNCH];  // [dgamma|dbeta][wave][col]
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int nch = H >> 3;
   float ag[LNCH][8], ab[LNCH][8];
@@ -664,10 +665,11 @@ extern "C" int mh_layernorm_bwd(const void* x, const void* dy, const float* gamm
   hipStream_t s = (hipStream_t)stream;
   float* pg = partial;
   float* pb = partial + (int64_t)n_partial * H;
-  MH_DTYPE_SWITCH(dtype,
-                  MH_LAUNCH((ln_bwd_kernel<bf16>), dim3(n_partial), dim3(256), 0, s, (const bf16*)x, (const bf16*)dy, gamma, (bf16*)dx, pg, pb, rows, H, eps),
-                  MH_LAUNCH((ln_bwd_kernel<float>), dim3(n_partial), dim3(256), 0, s, (const float*)x, (const float*)dy, gamma, (float*)dx, pg, pb, rows, H, eps),
-                  "layernorm_bwd");
+#define MH_LNB(T, N) MH_LAUNCH((ln_bwd_kernel<T, N>), dim3(n_partial), dim3(256), 0, s, (const T*)x, (const T*)dy, gamma, (T*)dx, pg, pb, rows, H, eps)
+  if (H <= 512) { MH_DTYPE_SWITCH(dtype, MH_LNB(bf16, 1), MH_LNB(float, 1), "layernorm_bwd"); }
+  else if (H <= 1024) { MH_DTYPE_SWITCH(dtype, MH_LNB(bf16, 2), MH_LNB(float, 2), "layernorm_bwd"); }
+  else { MH_DTYPE_SWITCH(dtype, MH_LNB(bf16, 4), MH_LNB(float, 4), "layernorm_bwd"); }
+#undef MH_LNB
   MH_CHECK_LAUNCH();
   // (a colsum_final block folds 64 columns: 4 partial-lanes x 64)
   MH_LAUNCH(colsum_final_kernel, dim3((H + 63) / 64, 1), dim3(1024), 0, s, pg, n_partial, H, dgamma, accumulate);

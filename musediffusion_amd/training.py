@@ -305,7 +305,7 @@ class _LayerNorm(Function):
         M, H = x.shape
         dy = dy.contiguous()
         dx = torch.empty_like(x)
-        nb = min(512, (M + 3) // 4)
+        nb = min(1024, (M + 3) // 4)
         part = torch.empty(2 * nb * H, device=x.device, dtype=torch.float32)
         dg = torch.empty(H, device=x.device, dtype=torch.float32)
         db = torch.empty(H, device=x.device, dtype=torch.float32)
