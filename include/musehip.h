@@ -317,6 +317,17 @@ int mh_sum_slices(const float* in, int slices, int64_t n, float* out, mh_stream_
 int mh_scale_rows(const float* src, const float* scale, const int32_t* mask, float* dst, int accumulate, int B, int64_t per_batch,
                   int E, mh_stream_t stream);
 
+/* bf16 working copies of fp32 master weights, all in ONE launch: for every item, dst [rows, ld_dst] = bf16(src [rows, cols]) and
+ * (dst_t != NULL) dst_t [cols, ld_t] = its transpose - the operands of a dense layer's forward / weight-gradient GEMMs and of its
+ * input-gradient GEMM.  Replaces the per-layer fp32 -> compute-dtype casts autocast-style training does on every forward
+ * (the reference trains in fp32, utils/train_util.py:188-232; bf16 compute is this framework's mode).  rows, cols multiples of 64;
+ * `items` is a DEVICE table, tile_start = running sum of (rows / 64) (cols / 64) over the preceding items, total_tiles its end. */
+typedef struct mh_wprep_item {
+  const float* src; void* dst; void* dst_t;
+  int32_t rows, cols; int64_t ld_dst, ld_t; int32_t tile_start, pad_;
+} mh_wprep_item;
+int mh_weight_prep(const mh_wprep_item* items, int n_items, int total_tiles, mh_stream_t stream);
+
 /* ------------------------------------------------------------------ optimizer step
  * Fused multi-tensor AdamW + up to 4 EMA copies (+ gradient L2 norm) over every parameter tensor in one
  * launch each: utils/train_util.py:246-280 (optimize, _log_grad_norm) and :21-31 (update_ema).

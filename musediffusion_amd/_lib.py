@@ -45,6 +45,12 @@ class Dropout(C.Structure):
     _fields_ = [("p", F32), ("seed", C.c_uint64), ("offset", C.c_uint64), ("mask", VP)]
 
 
+class WPrepItem(C.Structure):
+    """mh_wprep_item"""
+    _fields_ = [("src", VP), ("dst", VP), ("dst_t", VP), ("rows", C.c_int32), ("cols", C.c_int32), ("ld_dst", C.c_int64),
+                ("ld_t", C.c_int64), ("tile_start", C.c_int32), ("pad_", C.c_int32)]
+
+
 class LayerWeights(C.Structure):
     """mh_layer_weights"""
     _fields_ = [(n, VP) for n in ("w_qkv", "b_qkv", "w_ao", "b_ao", "ln1_g", "ln1_b", "w_ff1", "b_ff1",
@@ -147,6 +153,7 @@ SIGNATURES = {
     "mh_gemm_dw": (INT, [VP, I64, VP, I64, VP, INT, I64, INT, INT, VP]),
     "mh_gemm_dw_splits": (INT, [I64, INT, INT]),
     "mh_gemm_dw_set_blocks": (INT, [INT]),
+    "mh_weight_prep": (INT, [VP, INT, INT, VP]),
     "mh_gemm_dw_bias": (INT, [VP, I64, VP, I64, VP, INT, I64, INT, INT, INT, VP]),
     "mh_gemm_act_grad": (INT, [VP, I64, VP, I64, VP, I64, VP, I64, I64, INT, INT, INT, VP]),
     "mh_gemm_bias_act_pre": (INT, [VP, I64, VP, I64, VP, VP, VP, I64, I64, INT, INT, INT, VP]),

@@ -787,6 +787,47 @@ extern "C" int mh_sum_slices(const float* in, int slices, int64_t n, float* out,
   return MH_OK;
 }
 
+// ------------------------------------------------------------------ bf16 working copies of the master weights, one launch
+namespace {
+__global__ __launch_bounds__(256) void weight_prep_kernel(const mh_wprep_item* __restrict__ items, int n_items) {
+  __shared__ bf16 tile[64][66];
+  int it = 0;
+  for (int i = 1; i < n_items; ++i) if ((int)blockIdx.x >= items[i].tile_start) it = i;     // (block-uniform; tables are short)
+  const mh_wprep_item w = items[it];
+  const int local = (int)blockIdx.x - w.tile_start, tc = w.cols >> 6;
+  const int r0 = (local / tc) * 64, c0 = (local % tc) * 64;
+  const int t = threadIdx.x, tr = t >> 4, c4 = (t & 15) * 4;
+  bf16* dst = reinterpret_cast<bf16*>(w.dst);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = tr + 16 * r;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(w.src + (int64_t)(r0 + row) * w.cols + c0 + c4);
+    bf16x4 b;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { b[e] = (bf16)v[e]; tile[row][c4 + e] = b[e]; }
+    *reinterpret_cast<bf16x4*>(dst + (int64_t)(r0 + row) * w.ld_dst + c0 + c4) = b;
+  }
+  if (!w.dst_t) return;
+  __syncthreads();
+  bf16* dstT = reinterpret_cast<bf16*>(w.dst_t);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int col = tr + 16 * r;                      // column of the source tile = row of the transposed one
+    bf16x4 b;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) b[e] = tile[c4 + e][col];
+    *reinterpret_cast<bf16x4*>(dstT + (int64_t)(c0 + col) * w.ld_t + r0 + c4) = b;
+  }
+}
+}  // namespace
+
+extern "C" int mh_weight_prep(const mh_wprep_item* items, int n_items, int total_tiles, mh_stream_t stream) {
+  MH_CHECK_ARG(items && n_items > 0 && total_tiles > 0, "weight_prep: empty table");
+  MH_LAUNCH(weight_prep_kernel, dim3((unsigned)total_tiles), dim3(256), 0, (hipStream_t)stream, items, n_items);
+  MH_CHECK_LAUNCH();
+  return MH_OK;
+}
+
 extern "C" int mh_adamw_ema_step(const mh_opt_tensor* tensors, const mh_opt_chunk* chunks, int n_chunks,
                                  const mh_opt_hparams* hp, mh_stream_t stream) {
   MH_CHECK_ARG(tensors && chunks && hp && n_chunks > 0, "adamw_ema_step: bad arguments");

@@ -25,6 +25,7 @@ NPART = 256  # rows of the two-stage column-sum scratch
 TN_DW = True            # bf16: weight gradients straight from the k-major activations (mh_gemm_dw), no transposed copies
 FUSED_FFN = True        # bf16: FFN as one tape node with the GELU backward fused into a GEMM epilogue (A/B switch for tests)
 FUSED_ATTENTION = True  # bf16: streaming forward + fused backward kernels when the shape allows (A/B switch for tests)
+WEIGHT_PREP = True      # bf16: the encoder's weight casts / transposes of a forward + backward in one launch (_WeightPrep)
 
 
 def _td(dt):
@@ -177,11 +178,13 @@ class _Linear(Function):
     Output [M, pad64(N)] with zero padding columns."""
 
     @staticmethod
-    def forward(ctx, x, W, b, act, residual, dt, drop=None):
+    def forward(ctx, x, W, b, act, residual, dt, drop=None, prep=None):
         M, Kp = x.shape
         N, K = W.shape
         Np = ops.pad64(N)
-        Wc = ops.cast_pad(W.detach(), Kp, dt)                         # [N, Kp]
+        # prep: (W in the compute dtype [N, Kp], its transpose [Kp, Np]) made by _WeightPrep in one launch for the whole encoder
+        Wc = prep[0] if prep is not None else ops.cast_pad(W.detach(), Kp, dt)                         # [N, Kp]
+        ctx.WT = prep[1] if prep is not None else None
         pre = _zeros(M, Np, dt, x.device, N)
         fused_act = act is not None and dt == ops.MH_BF16 and N == Np and N % 8 == 0 and Kp % 32 == 0
         ctx.drop = drop if _active(drop) else None
@@ -219,12 +222,12 @@ class _Linear(Function):
         else:
             dpre = dy
         # dX = dpre W : reduction over the N outputs
-        WT = _transpose(Wc, N, Kp, dt, ld_out=Np)                      # [Kp, Np]
+        WT = ctx.WT if ctx.WT is not None else _transpose(Wc, N, Kp, dt, ld_out=Np)                      # [Kp, Np]
         dx = _zeros(M, Kp, dt, x.device, Kp)
         _gemm(dpre, WT, None, dt, Kp, Np, out=dx)
         # dW = dpre^T X : reduction over the M rows
         dW, db = _dw(dpre, x, N, Kp, M, dt, bias=True) if has_b else (_dw(dpre, x, N, Kp, M, dt), None)
-        return dx, dW[:, :K].contiguous(), db, None, (dy if has_res else None), None, None
+        return dx, dW[:, :K].contiguous(), db, None, (dy if has_res else None), None, None, None
 
 
 class _FFN(Function):
@@ -238,10 +241,15 @@ class _FFN(Function):
         return dt == ops.MH_BF16 and x.shape[1] == H and H % 64 == 0 and F % 64 == 0 and tuple(W2.shape) == (H, F)
 
     @staticmethod
-    def forward(ctx, x, W1, b1, W2, b2, dt, drop=None):
+    def forward(ctx, x, W1, b1, W2, b2, dt, drop=None, prep=None):
         M, H = x.shape
         F = W1.shape[0]
-        W1c, W2c = ops.cast_pad(W1.detach(), H, dt), ops.cast_pad(W2.detach(), F, dt)
+        if prep is not None:      # (W1c, W1T, W2c, W2T) from _WeightPrep
+            W1c, W2c = prep[0], prep[2]
+            ctx.WT = (prep[1], prep[3])
+        else:
+            W1c, W2c = ops.cast_pad(W1.detach(), H, dt), ops.cast_pad(W2.detach(), F, dt)
+            ctx.WT = None
         pre = torch.empty(M, F, device=x.device, dtype=x.dtype)
         f = torch.empty_like(pre)
         check(lib().mh_gemm_bias_act_pre(ptr(x), H, ptr(W1c), H, ptr(b1.detach()), ptr(pre), ptr(f), F, M, F, H, ops.ACT["gelu"],
@@ -267,14 +275,14 @@ class _FFN(Function):
         dW2, db2 = _dw(dym, f, H, F, M, dt, bias=True)
         # d(pre) = (dy W2) o gelu'(pre): W2 is [H, F]; the GEMM wants the reduction dim contiguous -> W2^T [F, H]
         dpre = torch.empty(M, F, device=x.device, dtype=x.dtype)
-        W2T = _transpose(W2c, H, F, dt, ld_out=H)
+        W2T = ctx.WT[1] if ctx.WT is not None else _transpose(W2c, H, F, dt, ld_out=H)
         check(lib().mh_gemm_act_grad(ptr(dym), H, ptr(W2T), H, ptr(pre), F, ptr(dpre), F, M, F, H, ops.ACT["gelu"], current_stream()),
               "mh_gemm_act_grad")
         dW1, db1 = _dw(dpre, x, F, H, M, dt, bias=True)
         dx = torch.empty(M, H, device=x.device, dtype=x.dtype)
-        W1T = _transpose(W1c, F, H, dt, ld_out=F)                         # [H, F]
+        W1T = ctx.WT[0] if ctx.WT is not None else _transpose(W1c, F, H, dt, ld_out=F)                         # [H, F]
         _gemm(dpre, W1T, None, dt, H, F, out=dx, residual=dy)             # + dy: the residual branch
-        return dx, dW1, db1, dW2, db2, None, None
+        return dx, dW1, db1, dW2, db2, None, None, None
 
 
 class _Dropout(Function):
@@ -595,8 +603,8 @@ class _TokenCE(Function):
 
 
 # ---------------------------------------------------------------------------------------------- composites
-def _linear(x, lin, act, dt, residual=None, drop=None):
-    return _Linear.apply(x, lin.weight, lin.bias, act, residual, dt, drop)
+def _linear(x, lin, act, dt, residual=None, drop=None, prep=None):
+    return _Linear.apply(x, lin.weight, lin.bias, act, residual, dt, drop, prep)
 
 
 class _DropSites:
@@ -659,6 +667,67 @@ class _DropSites:
         return _Drop(p, self.seed, (self.call << 16) | self.nsite, mask=None if inj is None else inj.to(torch.uint8).contiguous())
 
 
+class _WeightPrep:
+    """bf16 working copies (row-major and transposed) of the encoder's dense weights, refreshed by ONE launch per forward
+    (mh_weight_prep) instead of a cast per dense layer in the forward and a transpose per layer in the backward.  The buffers and
+    the device table live with the model; the table is rebuilt when a parameter moved (model.to(), a fresh state)."""
+
+    def __init__(self, model, dev):
+        H, layers = model.hidden_size, list(model.input_transformers.layer)
+        F = layers[0].intermediate.dense.weight.shape[0]
+        bf = torch.bfloat16
+        self.qkv = [torch.empty(3 * H, H, device=dev, dtype=bf) for _ in layers]
+        self.qkv_t = [torch.empty(H, 3 * H, device=dev, dtype=bf) for _ in layers]
+        self.ao = [torch.empty(H, H, device=dev, dtype=bf) for _ in layers]
+        self.ao_t = [torch.empty(H, H, device=dev, dtype=bf) for _ in layers]
+        self.w1 = [torch.empty(F, H, device=dev, dtype=bf) for _ in layers]
+        self.w1_t = [torch.empty(H, F, device=dev, dtype=bf) for _ in layers]
+        self.w2 = [torch.empty(H, F, device=dev, dtype=bf) for _ in layers]
+        self.w2_t = [torch.empty(F, H, device=dev, dtype=bf) for _ in layers]
+        items, tiles = [], 0
+
+        def add(W, dst, dst_t, ld_dst, ld_t):
+            nonlocal tiles
+            it = _lib.WPrepItem(W.data_ptr(), dst, dst_t, W.shape[0], W.shape[1], ld_dst, ld_t, tiles, 0)
+            tiles += (W.shape[0] // 64) * (W.shape[1] // 64)
+            items.append(it)
+        for li, layer in enumerate(layers):
+            sa = getattr(layer.attention, "self")
+            for j, lin in enumerate((sa.query, sa.key, sa.value)):      # three parameters, one [3H, H] operand
+                add(lin.weight, self.qkv[li].data_ptr() + j * H * H * 2, self.qkv_t[li].data_ptr() + j * H * 2, H, 3 * H)
+            add(layer.attention.output.dense.weight, self.ao[li].data_ptr(), self.ao_t[li].data_ptr(), H, H)
+            add(layer.intermediate.dense.weight, self.w1[li].data_ptr(), self.w1_t[li].data_ptr(), H, F)
+            add(layer.output.dense.weight, self.w2[li].data_ptr(), self.w2_t[li].data_ptr(), F, H)
+        import ctypes as C
+        raw = (_lib.WPrepItem * len(items))(*items)
+        self.table = torch.frombuffer(bytearray(C.string_at(C.addressof(raw), C.sizeof(raw))), dtype=torch.uint8).to(dev)
+        self.n, self.tiles = len(items), tiles
+        self.key = _WeightPrep.key_of(model)
+
+    @staticmethod
+    def key_of(model):
+        return tuple(p.data_ptr() for layer in model.input_transformers.layer for p in layer.parameters())
+
+    @staticmethod
+    def supported(model, dt):
+        layers = list(model.input_transformers.layer)
+        H = model.hidden_size
+        return (dt == ops.MH_BF16 and len(layers) > 0 and H % 64 == 0 and layers[0].intermediate.dense.weight.shape[0] % 64 == 0
+                and all(p.dtype == torch.float32 and p.is_contiguous() for layer in layers for p in layer.parameters()))
+
+    @staticmethod
+    def refresh(model, dt, dev):
+        """-> the model's _WeightPrep with this forward's copies queued on the current stream, or None (shapes / dtype not served)"""
+        if not WEIGHT_PREP or not _WeightPrep.supported(model, dt):
+            return None
+        wp = getattr(model, "_weight_prep", None)
+        if wp is None or wp.key != _WeightPrep.key_of(model) or wp.table.device != dev:
+            wp = _WeightPrep(model, dev)
+            object.__setattr__(model, "_weight_prep", wp)
+        check(lib().mh_weight_prep(ptr(wp.table), wp.n, wp.tiles, current_stream()), "mh_weight_prep")
+        return wp
+
+
 def denoiser_forward_with_grad(model, x, timesteps):
     """TransformerNetModel.forward (network.py:131-158) with a gradient tape made of libmusehip kernels."""
     _lib.require_device(x)
@@ -679,6 +748,7 @@ def denoiser_forward_with_grad(model, x, timesteps):
         h = xin
     sites = _DropSites(model)
     sites.pregenerate_attention_bits(model, B, L, dt, dev)
+    wp = _WeightPrep.refresh(model, dt, dev)
     pre = _AddPosTime.apply(h, model.position_embeddings.weight, emb_t, B, L, dt)
     X = _LayerNorm.apply(pre, model.LayerNorm.weight, model.LayerNorm.bias, model.LayerNorm.eps, dt)
     d_emb = sites.site("emb", sites.p_emb)
@@ -688,18 +758,20 @@ def denoiser_forward_with_grad(model, x, timesteps):
         sa = getattr(layer.attention, "self")
         Wqkv = torch.cat([sa.query.weight, sa.key.weight, sa.value.weight], dim=0)
         bqkv = torch.cat([sa.query.bias, sa.key.bias, sa.value.bias], dim=0)
-        qkv = _Linear.apply(X, Wqkv, bqkv, None, None, dt)                                       # [N, 3H]
+        qkv = _Linear.apply(X, Wqkv, bqkv, None, None, dt, None, None if wp is None else (wp.qkv[li], wp.qkv_t[li]))   # [N, 3H]
         ctxv = _Attention.apply(qkv, B, L, model.num_heads, dt, sites.site("l%d.attn" % li, sites.p_att))
-        y1 = _linear(ctxv, layer.attention.output.dense, None, dt, residual=X, drop=sites.site("l%d.ao" % li, sites.p_hid))
+        y1 = _linear(ctxv, layer.attention.output.dense, None, dt, residual=X, drop=sites.site("l%d.ao" % li, sites.p_hid),
+                     prep=None if wp is None else (wp.ao[li], wp.ao_t[li]))
         X1 = _LayerNorm.apply(y1, layer.attention.output.LayerNorm.weight, layer.attention.output.LayerNorm.bias,
                               layer.attention.output.LayerNorm.eps, dt)
         d1, d2 = layer.intermediate.dense, layer.output.dense
         d_ffn = sites.site("l%d.ffn" % li, sites.p_hid)
         if FUSED_FFN and (B * L) % 64 == 0 and _FFN.supported(X1, d1.weight, d2.weight, dt):
-            y2 = _FFN.apply(X1, d1.weight, d1.bias, d2.weight, d2.bias, dt, d_ffn)
+            y2 = _FFN.apply(X1, d1.weight, d1.bias, d2.weight, d2.bias, dt, d_ffn,
+                            None if wp is None else (wp.w1[li], wp.w1_t[li], wp.w2[li], wp.w2_t[li]))
         else:
-            f = _linear(X1, d1, "gelu", dt)
-            y2 = _linear(f, d2, None, dt, residual=X1, drop=d_ffn)
+            f = _linear(X1, d1, "gelu", dt, prep=None if wp is None else (wp.w1[li], wp.w1_t[li]))
+            y2 = _linear(f, d2, None, dt, residual=X1, drop=d_ffn, prep=None if wp is None else (wp.w2[li], wp.w2_t[li]))
         X = _LayerNorm.apply(y2, layer.output.LayerNorm.weight, layer.output.LayerNorm.bias, layer.output.LayerNorm.eps, dt)
     if model.output_dims != H:
         h = _linear(X, model.output_down_proj[0], "tanh", dt)

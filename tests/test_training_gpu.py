@@ -185,6 +185,46 @@ def test_fused_attention_training_path_matches_unfused(L):
         assert abs(float(a.norm()) / float(b.norm()) - 1.0) < 0.03, name
 
 
+def test_one_launch_weight_copies_give_the_same_tape():
+    """training._WeightPrep (one launch makes the bf16 copies and transposes of every encoder weight) against the per-layer casts
+    and transposes: identical operands, so losses and every gradient are bit-identical; the copies follow an in-place weight update"""
+    from musediffusion_amd import training
+    torch.manual_seed(5)
+    E, H, B, V, L = 32, 128, 2, 97, 64
+    m = TransformerNetModel(E, E, 32, V, L, dropout=0.0, bert_hidden=H, bert_layers=2, bert_heads=2, bert_ffn=256,
+                            compute_dtype="bf16", bert_hidden_dropout=0.0, bert_attention_dropout=0.0)
+    m.train().requires_grad_(True).to(DEV)
+    diff = SpacedDiffusion(use_timesteps=space_timesteps(2000, [2000]), betas=get_named_beta_schedule("sqrt", 2000),
+                           rescale_timesteps=True, predict_xstart=True)
+    gen = torch.Generator().manual_seed(9)
+    ids = torch.randint(3, V, (B, L), generator=gen)
+    batch = {"input_ids": ids, "input_mask": torch.ones(B, L, dtype=torch.long), "correct_ids": ids.clone()}
+    t = torch.tensor([400, 1500], device=DEV)
+
+    def run():
+        m.zero_grad(set_to_none=True)
+        with CpuDraws(11):
+            terms = diff.training_losses(m, t, model_kwargs=batch)
+        terms["loss"].mean().backward()
+        return terms["loss"].detach().clone(), {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None}
+    try:
+        for rnd in range(2):
+            training.WEIGHT_PREP = True
+            l1, g1 = run()
+            assert getattr(m, "_weight_prep", None) is not None
+            training.WEIGHT_PREP = False
+            l0, g0 = run()
+            assert torch.equal(l0, l1)
+            assert g0.keys() == g1.keys()
+            for n in g0:
+                assert torch.equal(g0[n], g1[n]), n
+            with torch.no_grad():      # an optimizer-style in-place update: the next forward's copies must see it
+                for p in m.parameters():
+                    p.add_(0.01 * torch.randn_like(p))
+    finally:
+        training.WEIGHT_PREP = True
+
+
 @pytest.mark.parametrize("tag,variant", [("c1", "corrupt"), ("same", "plain")])
 def test_every_parameter_gradient_matches_oracle(tag, variant):
     """EVERY parameter's gradient (LayerNorm gains / biases, position table, projections, ... - the golden file holds four) of
