@@ -53,6 +53,7 @@ class FusedAdamWEMA:
         self._norm = torch.zeros(1, device=dev, dtype=torch.float32)
         self._table = None
         self._table_key = None
+        self._stage, self._stage_ev, self._stage_k = None, None, 0
 
     def _tensor_table(self):
         grads = [p.grad for p in self.params]
@@ -69,7 +70,20 @@ class FusedAdamWEMA:
                 rows[i, 2], rows[i, 3] = self.exp_avg[i].data_ptr(), self.exp_avg_sq[i].data_ptr()
                 for e in range(len(self.ema_rates)):
                     rows[i, 4 + e] = self.ema[e][i].data_ptr()
-            self._table = torch.from_numpy(rows).to(self.params[0].device)
+            # gradients that were dropped and re-created move: the table follows through a pinned staging buffer and a
+            # stream-ordered copy (no host synchronisation); two staging buffers, each re-used only once its last copy has run
+            if self._stage is None:
+                self._stage = [torch.empty(rows.shape, dtype=torch.int64).pin_memory() for _ in range(2)]
+                self._stage_ev = [None, None]
+                self._table = torch.empty(rows.shape, dtype=torch.int64, device=self.params[0].device)
+            k = self._stage_k = 1 - self._stage_k
+            if self._stage_ev[k] is not None:
+                self._stage_ev[k].synchronize()
+            self._stage[k].copy_(torch.from_numpy(rows))
+            self._table.copy_(self._stage[k], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            self._stage_ev[k] = ev
             self._table_key = key
         return self._table
 

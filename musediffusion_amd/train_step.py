@@ -45,10 +45,11 @@ class TrainStep:
 
     # ------------------------------------------------------------------ train_util.py:188-238
     def zero_grad(self):
+        """train_util.py:240-244 zero-fills every gradient in place; here the tensors are dropped instead, so the first micro-batch's
+        backward stores its gradients rather than adding them to zeros (same values; 187 fills + 187 adds less per step at the
+        reference's model size).  The optimizer's device table follows the new addresses (optim.FusedAdamWEMA._tensor_table)."""
         for p in self.model_params:
-            if p.grad is not None:
-                p.grad.detach_()
-                p.grad.zero_()
+            p.grad = None
 
     def _forward_backward_logic(self, cond, backward):
         self.zero_grad()
