@@ -415,10 +415,11 @@ int mh_denoiser_get_fuse_ln(void);
 /* Timing-only ablation of the big-tile kernel (results are WRONG when non-zero): bit 0 skips the
  * DMA loads, bit 1 the MFMAs, bit 2 the epilogue stores, bit 3 the LDS fragment reads.  Used by tools/gemm_bench.py only. */
 int mh_gemm_set_debug(int bits);
-/* A/B: which big-tile epilogues use ordinary instead of streaming (nt) output stores: bit 0 QKV scatter, bit 1 dense + GELU
- * (default 0: both streaming - their outputs are large and read once; measured -0.8% step time for dense + GELU, neutral for QKV).
- * The dense + residual + LayerNorm epilogue always stores normally: its rows are re-read at once (+1.2% with streaming).
- * Bit 2: run the full-row (LayerNorm) tile with the plain instead of the ping-pong main loop (4.5% slower step). */
+/* A/B mask of the big-tile GEMM epilogues / tiles.  Bit 0: QKV scatter with streaming (nt) q / k stores instead of ordinary ones
+ * (default ordinary: attention reads them back at once; +0.9 % steps/s in round 2).  Bit 1: dense + GELU with ordinary instead of
+ * streaming stores (default streaming: the output is large and read once; ordinary costs 3.8 % of the step).  The dense + residual +
+ * LayerNorm epilogue always stores normally: its rows are re-read at once.  Bit 2: the full-row (LayerNorm) tile with the plain
+ * instead of the ping-pong main loop (4 % slower step).  Bit 3 / 4: the 64-row full-row tile for K <= 512 / always (3 % / 7 % slower). */
 int mh_gemm_set_plain_stores(int mask);
 
 int mh_graph_begin_capture(mh_stream_t stream);

@@ -1104,7 +1104,7 @@ int device_cus() {
   return cus;
 }
 
-int g_plain_stores = 0;   // A/B: bit 0 QKV, bit 1 dense+GELU epilogues use ordinary instead of streaming stores; bit 2: full-row tile without ping-pong
+int g_plain_stores = 0;   // A/B: bit 0 QKV streaming instead of ordinary stores, bit 1 dense+GELU ordinary instead of streaming stores; bit 2: full-row tile without ping-pong; bits 3 / 4: 64-row full-row tile
 
 template <class C, int EPI>
 int launch_big(const GemmArgs& g0, hipStream_t s, int batch) {
@@ -1128,8 +1128,10 @@ int launch_big(const GemmArgs& g0, hipStream_t s, int batch) {
       } else { mh_set_error("gemm: deferred LayerNorm needs the 256x128 tile"); return MH_ERR_UNSUPPORTED; }
     }
     else if (g_spread && C::NW == 4) { if constexpr (C::NW == 4) MH_LAUNCH((gemm_big_kernel<C, 1, MH_ACT_NONE, 1024>), grid, block, 0, s, g); }
-    else if (g_plain_stores & 1) MH_LAUNCH((gemm_big_kernel<C, 1, MH_ACT_NONE, 32>), grid, block, 0, s, g);
-    else MH_LAUNCH((gemm_big_kernel<C, 1, MH_ACT_NONE>), grid, block, 0, s, g);
+    // q / k leave with ordinary stores: the attention kernel reads them back at once (round 2, after the epilogue restructuring:
+    // +0.9 % steps/s over streaming stores, tools/ab_step.py plain_stores 0 1; round 1 had measured the opposite); bit 0 = streaming
+    else if (g_plain_stores & 1) MH_LAUNCH((gemm_big_kernel<C, 1, MH_ACT_NONE>), grid, block, 0, s, g);
+    else MH_LAUNCH((gemm_big_kernel<C, 1, MH_ACT_NONE, 32>), grid, block, 0, s, g);
   } else if constexpr (EPI == 3) {
     MH_LAUNCH((gemm_big_kernel<C, 3, MH_ACT_NONE>), grid, block, 0, s, g);
   } else {
