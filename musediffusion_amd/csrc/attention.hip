@@ -560,7 +560,10 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(const float* __restrict__
 // FULL: seq_len is a multiple of SK, so no stage or tile is partial - the key-bound compares (which hipcc if-converts into a compare
 // + select per score of EVERY tile, a third of the tile's vector instructions) are compiled out.  (The bit reader keeps the
 // key-bound body: its bound-free build spills 60 B per lane and measured 5 % slower, as did staging its keep words in LDS.)
-template <int DH, int NW = 16, int SK = 256, int DROP = 0, bool FULL = false>
+// KVNT: the K / V stage DMA with the nt cache policy (aux 2) - chosen when a (batch, head)'s keys and values are streamed by ONE
+// block and never again (seq_len <= the block's queries): same-box A/B of two builds -1.2 % step time at config 2; with two query
+// blocks per (batch, head) (seq_len 1024) the second reader misses them: +0.4 % on the training step, so the default policy there
+template <int DH, int NW = 16, int SK = 256, int DROP = 0, bool FULL = false, bool KVNT = false>
 __global__ __launch_bounds__(64 * NW) void attn_stream_bf16_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K,
                                                                 const bf16* __restrict__ VT, bf16* __restrict__ ctx,
                                                                 int64_t ld_ctx, int L, int nh, int nbh, float scale_log2e,
@@ -599,7 +602,7 @@ __global__ __launch_bounds__(64 * NW) void attn_stream_bf16_kernel(const bf16* _
       int rsrc = row;                                                   // keys past the end: any valid row (their scores are masked)
       if (!FULL && st * SK + row >= L) rsrc = L - 1 - st * SK;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Kb + (int64_t)rsrc * qld + lc * 8),
-                                       (__attribute__((address_space(3))) void*)(kdst + p * 1024), 16, 0, 0);
+                                       (__attribute__((address_space(3))) void*)(kdst + p * 1024), 16, 0, KVNT ? 2 : 0);
     }
 #pragma unroll
     for (int j = 0; j < PK; ++j) {
@@ -609,7 +612,7 @@ __global__ __launch_bounds__(64 * NW) void attn_stream_bf16_kernel(const bf16* _
       int kc = t * 64 + lc * 8;                                         // 8 keys past the end: any valid chunk (finite values x P = 0)
       if (!FULL && st * SK + kc >= L) kc = L - 8 - st * SK;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Vb + (int64_t)d * L + kc),
-                                       (__attribute__((address_space(3))) void*)(vdst + p * 1024), 16, 0, 0);
+                                       (__attribute__((address_space(3))) void*)(vdst + p * 1024), 16, 0, KVNT ? 2 : 0);
     }
   };
 
@@ -897,6 +900,8 @@ extern "C" int mh_attention_stream_fwd_drop(const void* q, const void* k, const 
     rc = dh == 64 ? go(&attn_stream_bf16_kernel<64, 16, 256, 2>, 4 * 256 * 64 * 2) : go(&attn_stream_bf16_kernel<32, 16, 256, 2>, 4 * 256 * 32 * 2);
   } else if (dropping && !small) rc = dh == 64 ? go(&attn_stream_bf16_kernel<64, 16, 256, 1>, 4 * 256 * 64 * 2) : go(&attn_stream_bf16_kernel<32, 16, 256, 1>, 4 * 256 * 32 * 2);
   else if (dropping) rc = dh == 64 ? go(&attn_stream_bf16_kernel<64, 8, 128, 1>, 4 * 128 * 64 * 2) : go(&attn_stream_bf16_kernel<32, 8, 256, 1>, 4 * 256 * 32 * 2);
+  else if (full && !small && L <= qper)   // one block streams a (batch, head)'s K / V once: nt policy
+    rc = dh == 64 ? go(&attn_stream_bf16_kernel<64, 16, 256, 0, true, true>, 4 * 256 * 64 * 2) : go(&attn_stream_bf16_kernel<32, 16, 256, 0, true, true>, 4 * 256 * 32 * 2);
   else if (full && dh == 64) rc = small ? go(&attn_stream_bf16_kernel<64, 8, 128, 0, true>, 4 * 128 * 64 * 2) : go(&attn_stream_bf16_kernel<64, 16, 256, 0, true>, 4 * 256 * 64 * 2);
   else if (full) rc = small ? go(&attn_stream_bf16_kernel<32, 8, 256, 0, true>, 4 * 256 * 32 * 2) : go(&attn_stream_bf16_kernel<32, 16, 256, 0, true>, 4 * 256 * 32 * 2);
   else if (dh == 64) rc = small ? go(&attn_stream_bf16_kernel<64, 8, 128>, 4 * 128 * 64 * 2) : go(&attn_stream_bf16_kernel<64, 16, 256>, 4 * 256 * 64 * 2);

@@ -402,6 +402,15 @@ using CfgRow64 = BigCfg<64, 512, 1, 8, 3>;   // full-row tile over 64 rows: twic
 constexpr int B2K = 32;
 
 // one DMA stage (K-step kt) of a tile into ring slot kt % NST: PA + PW 1-KiB pieces per wave
+// the LayerNorm epilogue's residual rows are read once, by this block: non-temporal loads (same-box A/B of two builds: -0.6 % step time)
+#ifndef MH_EPI3_RES_NT
+#define MH_EPI3_RES_NT 1
+#endif
+// cache policy of the full-row (ping-pong) tile's A-operand DMA: nt (aux 2) - its rows are read by exactly one block, once, and
+// should not displace the weight matrix every block re-reads from L2 (same-box A/B of two builds: -1.6 % step time; 0 = default policy)
+#ifndef MH_PP_A_AUX
+#define MH_PP_A_AUX 2
+#endif
 template <class C, int DBG>
 __device__ __forceinline__ void issue_stage(const char* smem, const char* const (&srcA)[C::PA], const char* const (&srcW)[C::PW],
                                             const int (&ldsA)[C::PA], const int (&ldsW)[C::PW], int kt, int64_t kstepA,
@@ -409,9 +418,14 @@ __device__ __forceinline__ void issue_stage(const char* smem, const char* const 
   if constexpr ((DBG & 1) != 0) return;
   char* base = const_cast<char*>(smem) + (kt % C::NST) * C::STAGE;
 #pragma unroll
-  for (int j = 0; j < C::PA; ++j)
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcA[j] + kt * kstepA),
-                                     (__attribute__((address_space(3))) void*)(base + ldsA[j]), 16, 0, 0);
+  for (int j = 0; j < C::PA; ++j) {
+    if constexpr (C::PP)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcA[j] + kt * kstepA),
+                                       (__attribute__((address_space(3))) void*)(base + ldsA[j]), 16, 0, MH_PP_A_AUX);
+    else
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcA[j] + kt * kstepA),
+                                       (__attribute__((address_space(3))) void*)(base + ldsA[j]), 16, 0, 0);
+  }
 #pragma unroll
   for (int j = 0; j < C::PW; ++j)
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcW[j] + kt * kstepW),
@@ -906,7 +920,11 @@ __global__ __launch_bounds__(C::THREADS, C::STAGE * C::NST <= 80 * 1024 ? 2 : 1)
           for (int i = 0; i < TI; ++i) {
             int64_t row = wrow0 + 16 * i + fr; if (!FULL && row >= g.M) row = g.M - 1;
             const int64_t ro = g.r_panel ? ((int64_t)(col >> 5) * g.ldr + row) * 32 + (col & 31) : row * g.ldr + col;
+#if MH_EPI3_RES_NT
+            rraw[i] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(res + ro));
+#else
             rraw[i] = *reinterpret_cast<const bf16x8*>(res + ro);
+#endif
           }
 #pragma unroll
           for (int i = 0; i < TI; ++i) {
