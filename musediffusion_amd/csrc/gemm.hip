@@ -1075,7 +1075,9 @@ __global__ __launch_bounds__(C::THREADS, C::STAGE * C::NST <= 80 * 1024 ? 2 : 1)
                   else *reinterpret_cast<f32x4*>(outF + row * g.ldo + col) = f32x4{v[0], v[1], v[2], v[3]};   // N % 8 == 4 tail
                 } else {
                   const int64_t oo = g.o_panel ? ((int64_t)(col >> 5) * g.ldo + row) * 32 + (col & 31) : row * g.ldo + col;
-                  if constexpr ((DBG & 32) != 0) store8(outT + oo, v); else store8_nt(outT + oo, v);
+                  // streaming stores for outputs read once, much later or by a streaming reader; the deferred-LayerNorm producers' raw
+                  // rows are re-read at once as A operand and residual: ordinary stores (c2-bertbase -2.0 % step time, A/B of two builds)
+                  if constexpr ((DBG & 32) != 0 || DO) store8(outT + oo, v); else store8_nt(outT + oo, v);
                 }
               }
             }

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """In-process A/B of library switches on the captured reverse step (bench.py workload c2): alternates settings over several
 rounds and prints the median ms/step of each (boxes of the pool differ by several percent; only same-process numbers compare).
-    python tools/ab_step.py plain_stores 0 1 2 4 7"""
+    python tools/ab_step.py plain_stores 0 1 2 4 7          (AB_WORKLOAD=c2-bertbase selects another bench workload)"""
 import contextlib
 import io
 import json
@@ -11,7 +11,8 @@ import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 knob, values = sys.argv[1], [int(v) for v in sys.argv[2:]]
-sys.argv = ["bench.py", "--steps", "40", "--warmup", "5", "--no-cpu-baseline", "--no-kernel-timing"]
+BASE = ["bench.py", "--steps", "40", "--warmup", "5", "--no-cpu-baseline", "--no-kernel-timing", "--workload", os.environ.get("AB_WORKLOAD", "c2")]
+sys.argv = list(BASE)
 import bench  # noqa: E402
 from musediffusion_amd import _lib  # noqa: E402
 
@@ -24,7 +25,7 @@ for rnd in range(3):
     for v in values:
         if knob == "v3_split":
             _lib.lib().mh_gemm_set_variant(3)
-            sys.argv = ["bench.py", "--steps", "40", "--warmup", "5", "--no-cpu-baseline", "--no-kernel-timing", "--split", str(v)]
+            sys.argv = BASE + ["--split", str(v)]
         else:
             setters[knob](v)
         buf = io.StringIO()
