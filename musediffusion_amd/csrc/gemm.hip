@@ -773,6 +773,16 @@ __global__ __launch_bounds__(C::THREADS, C::STAGE * C::NST <= 80 * 1024 ? 2 : 1)
 #pragma unroll
     for (int j = 0; j < TJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  if constexpr (DA || DR) {
+    // deferred LayerNorm: the tile's first DMA stages go out first and the row statistics (a global round trip + a barrier) are
+    // fetched underneath them, instead of standing between the main loop and the epilogue
+    if (!pre) {
+      const int npro = nk < C::PRO ? nk : C::PRO;
+      for (int st = 0; st < npro; ++st) issue_stage<C, DBG>(smem, srcA, srcW, ldsA, ldsW, st, kstepA, kstepW);
+      pre = 1;
+    }
+    stage_row_stats(m0);
+  }
   // lane's 8 consecutive output columns for (64-column group q, half h): wcol0 + 64q + 32h + 8fg, values
   // acc[i][4q + 2h + (e>>2)][e&3], e = 0..7
   if constexpr (EPI == 1) {
@@ -785,7 +795,6 @@ __global__ __launch_bounds__(C::THREADS, C::STAGE * C::NST <= 80 * 1024 ? 2 : 1)
       // FULL (interior tile, wave-uniform): no per-lane guards, so the epilogue is straight-line code.  With divergent guards
       // hipcc cannot prove the bias loads complete on every path and puts `s_waitcnt vmcnt(0)` in front of EVERY store block,
       // which also waits for the previous store: the tile's stores then leave one round trip at a time.
-      stage_row_stats(m0);
       auto epi_v = [&](auto fullc) {
         constexpr bool FULL = decltype(fullc)::value;
         bf16* dst = reinterpret_cast<bf16*>(g.vt);
@@ -834,7 +843,6 @@ __global__ __launch_bounds__(C::THREADS, C::STAGE * C::NST <= 80 * 1024 ? 2 : 1)
     } else {
       run_mainloop<C, true, DBG, TI * (TJ / 2)>(acc, smem, srcA, srcW, ldsA, ldsW, nk, a_off, b_offs, kstepA, kstepW, wm, pre);
       prefetch_next(vt, full_tile);
-      stage_row_stats(m0);
       auto epi_qk = [&](auto fullc) {
         constexpr bool FULL = decltype(fullc)::value;
         bf16* dst = reinterpret_cast<bf16*>(which == 0 ? g.q : g.k);
@@ -988,7 +996,6 @@ __global__ __launch_bounds__(C::THREADS, C::STAGE * C::NST <= 80 * 1024 ? 2 : 1)
         }
       }
     } else {
-      stage_row_stats(m0);
       auto epi_gen = [&](auto fullc) {
         constexpr bool FULL = decltype(fullc)::value;
         float bv[TJ / 2][8];          // every bias load before the first store
