@@ -644,8 +644,14 @@ __global__ __launch_bounds__(C::THREADS, C::STAGE * C::NST <= 80 * 1024 ? 2 : 1)
   // deferred LayerNorm (DeferArgs), one compiled variant per operand combination so that unused vectors cost no registers:
   // DA = A rows raw, DR = residual rows raw, DO = write the output rows' partial statistics
   constexpr bool DA = (DBG & 128) != 0, DR = (DBG & 256) != 0, DO = (DBG & 512) != 0, DEFER = DA || DR || DO;
+  constexpr int TI_ = C::TI, TJ_ = C::TJ;
+  // (EPI 3 stages the tile's residual rows through LDS after the main loop: each wave's TI x TJ/2 KiB go where the ring was;
+  // a last wave that does not fit - the 128x512 tile: 8 x 16 KiB against a 120 KiB ring - gets its own area at the end)
+  constexpr int RES_W = TI_ * (TJ_ / 2) * 1024, RING = C::NST * C::STAGE;
+  constexpr bool RES_EXTRA = EPI == 3 && C::NW * RES_W > RING;
+  static_assert(EPI != 3 || (C::NW - 1) * RES_W <= RING, "residual staging: at most the last wave may overflow the ring");
   __shared__ __attribute__((aligned(16))) char smem[C::NST * C::STAGE + (EPI == 3 ? C::BM * C::WN * 4 + 3 * C::BN * 4 : 0) +
-                                                    (DEFER ? C::BM * 8 * (2 + C::WN) : 0)];
+                                                    (DEFER ? C::BM * 8 * (2 + C::WN) : 0) + (RES_EXTRA ? RES_W : 0)];
   constexpr int TI = C::TI, TJ = C::TJ;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -915,30 +921,47 @@ __global__ __launch_bounds__(C::THREADS, C::STAGE * C::NST <= 80 * 1024 ? 2 : 1)
         constexpr bool FULL = false;
         float* red = reinterpret_cast<float*>(smem + C::NST * C::STAGE);   // [BM][WN] floats, reused for both passes
         const float* vecs = red + C::BM * C::WN;                            // bias | gamma | beta of the BN columns
+        // The residual rows take ONE memory round trip: every wave DMAs its own TI x TJ/2 pieces (lane-linear: a lane's 16 bytes of
+        // piece (qh, i) are exactly the 8 columns it holds of row 16 i + fr) into the ring the main loop has just left - all waves
+        // are past its last barrier - adds the bias while they fly, and reads them back with ds_read_b128 (no other wave touches them).
+        // (Loading them group by group into registers cost four dependent round trips: there are no registers for more at once.)
+        char* rbase = smem + ((wave + 1) * RES_W <= RING ? wave * RES_W : RING + C::BM * C::WN * 4 + 3 * C::BN * 4);
+        if constexpr (!C::PP) {   // (the ping-pong loop ends on a barrier that every fragment read precedes; the plain loop does not)
+          __builtin_amdgcn_s_waitcnt(0xC07F);
+          __builtin_amdgcn_s_barrier();
+        }
+#pragma unroll
+        for (int qh = 0; qh < TJ / 2; ++qh) {
+          const int col = wcol0 + 32 * qh + 8 * fg;
+#pragma unroll
+          for (int i = 0; i < TI; ++i) {
+            int64_t row = wrow0 + 16 * i + fr; if (!FULL && row >= g.M) row = g.M - 1;
+            const int64_t ro = g.r_panel ? ((int64_t)(col >> 5) * g.ldr + row) * 32 + (col & 31) : row * g.ldr + col;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(res + ro),
+                                             (__attribute__((address_space(3))) void*)(rbase + (qh * TI + i) * 1024), 16, 0, MH_EPI3_RES_NT ? 2 : 0);
+          }
+        }
+#pragma unroll
+        for (int qh = 0; qh < TJ / 2; ++qh) {
+          float bv[8];
+          load8(vecs + wcol0 + 32 * qh + 8 * fg, bv);
+#pragma unroll
+          for (int i = 0; i < TI; ++i)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[i][2 * qh + (e >> 2)][e & 3] += bv[e];
+        }
+        wait_vmcnt<0>();
         float rs[TI];
 #pragma unroll
         for (int i = 0; i < TI; ++i) rs[i] = 0.f;
 #pragma unroll
         for (int qh = 0; qh < TJ / 2; ++qh) {
-          const int col = wcol0 + 32 * qh + 8 * fg;
-          float bv[8];
-          load8(vecs + col, bv);
-          bf16x8 rraw[TI];
 #pragma unroll
           for (int i = 0; i < TI; ++i) {
-            int64_t row = wrow0 + 16 * i + fr; if (!FULL && row >= g.M) row = g.M - 1;
-            const int64_t ro = g.r_panel ? ((int64_t)(col >> 5) * g.ldr + row) * 32 + (col & 31) : row * g.ldr + col;
-#if MH_EPI3_RES_NT
-            rraw[i] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(res + ro));
-#else
-            rraw[i] = *reinterpret_cast<const bf16x8*>(res + ro);
-#endif
-          }
-#pragma unroll
-          for (int i = 0; i < TI; ++i) {
+            const bf16x8 rraw = *reinterpret_cast<const bf16x8*>(rbase + (qh * TI + i) * 1024 + lane * 16);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-              const float v = (acc[i][2 * qh + (e >> 2)][e & 3] + bv[e]) + (float)rraw[i][e];
+              const float v = acc[i][2 * qh + (e >> 2)][e & 3] + (float)rraw[e];
               acc[i][2 * qh + (e >> 2)][e & 3] = v;
               rs[i] += v;
             }
