@@ -1678,23 +1678,25 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnArgs g) {
     offA[half] = row * (BMt * 2) + ((((p >> 1)) ^ f) << 4) + ((p & 1) << 3);
     offB[half] = ASTAGE + row * (BNt * 2) + ((((p >> 1)) ^ f) << 4) + ((p & 1) << 3);
   }
-  auto frag = [&](const char* stage, const int (&off)[2], int tile16, int rowf0, int rowf1) -> bf16x8 {
-    // tile16 = index of the 16-column tile: its two chunks are 2*tile16, 2*tile16 + 1; XOR with f only touches bits 1..3, so
-    // (2*tile16 + c) ^ f = ((2*tile16) ^ f) + c for c in {0, 1}: add the tile's chunk offset after un-XOR-ing bit 0 .. keep simple:
-    (void)rowf0; (void)rowf1;
-    const int t2 = tile16 << 1;
+  // The transposing reads are issued as inline asm: behind the intrinsic form hipcc puts `s_waitcnt vmcnt(0)` in front of the first
+  // read of every K-step (it cannot tell that the read does not alias the LDS-DMA stage it has just queued), which turns the
+  // three-stage ring into a synchronous copy.  The asm form hides the reads from that analysis; their results are only touched
+  // after the explicit lgkmcnt(0) below, which names them as operands so that nothing that uses them can move above it.
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  auto frag_half = [&](unsigned stage_off, const int (&off)[2], int tile16, int half) -> s16x4 {
+    // tile16 = index of the 16-column tile: its two chunks are 2*tile16, 2*tile16 + 1, XOR-ed with the row's swizzle f
+    const int row = 8 * fg + 4 * half + q;
+    const int f = tn_f(row);
+    const int base = off[half] - (((p >> 1) ^ f) << 4);          // row start (+ byte-in-chunk)
+    const unsigned addr = lds0 + stage_off + base + ((((tile16 << 1) + (p >> 1)) ^ f) << 4);
+    s16x4 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr));
+    return v;
+  };
+  auto join = [](const s16x4& lo, const s16x4& hi) -> bf16x8 {
     bf16x8 r;
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-      const int row = 8 * fg + 4 * half + q;
-      const int f = tn_f(row);
-      const int base = off[half] - (((p >> 1) ^ f) << 4);          // row start (+ byte-in-chunk)
-      const int addr = base + (((t2 + (p >> 1)) ^ f) << 4);
-      const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(stage + addr));
-      bf16x4 vb;
-      __builtin_memcpy(&vb, &v, 8);
-      r[4 * half + 0] = vb[0]; r[4 * half + 1] = vb[1]; r[4 * half + 2] = vb[2]; r[4 * half + 3] = vb[3];
-    }
+    __builtin_memcpy(&r, &lo, 8);
+    __builtin_memcpy(reinterpret_cast<char*>(&r) + 8, &hi, 8);
     return r;
   };
 
@@ -1719,12 +1721,22 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnArgs g) {
     wait_stages<6>(younger);
     __builtin_amdgcn_s_barrier();
     if (kt + NSTt - 1 < nk) issue(kt + NSTt - 1);
-    const char* stage = smem + (kt % NSTt) * STAGEt;
+    const unsigned stage = (unsigned)((kt % NSTt) * STAGEt);
+    s16x4 ah[TIt][2], bh[TJt][2];
+#pragma unroll
+    for (int j = 0; j < TJt; ++j) { bh[j][0] = frag_half(stage, offB, wn * 4 + j, 0); bh[j][1] = frag_half(stage, offB, wn * 4 + j, 1); }
+#pragma unroll
+    for (int i = 0; i < TIt; ++i) { ah[i][0] = frag_half(stage, offA, wm * 8 + i, 0); ah[i][1] = frag_half(stage, offA, wm * 8 + i, 1); }
+    static_assert(TIt == 8 && TJt == 4, "the wait below names the 24 fragment halves");
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(ah[0][0]), "+v"(ah[0][1]), "+v"(ah[1][0]), "+v"(ah[1][1]), "+v"(ah[2][0]), "+v"(ah[2][1]), "+v"(ah[3][0]), "+v"(ah[3][1]),
+                   "+v"(ah[4][0]), "+v"(ah[4][1]), "+v"(ah[5][0]), "+v"(ah[5][1]), "+v"(ah[6][0]), "+v"(ah[6][1]), "+v"(ah[7][0]), "+v"(ah[7][1]),
+                   "+v"(bh[0][0]), "+v"(bh[0][1]), "+v"(bh[1][0]), "+v"(bh[1][1]), "+v"(bh[2][0]), "+v"(bh[2][1]), "+v"(bh[3][0]), "+v"(bh[3][1]));
     bf16x8 a[TIt], b[TJt];
 #pragma unroll
-    for (int j = 0; j < TJt; ++j) b[j] = frag(stage, offB, wn * 4 + j, 0, 0);
+    for (int j = 0; j < TJt; ++j) b[j] = join(bh[j][0], bh[j][1]);
 #pragma unroll
-    for (int i = 0; i < TIt; ++i) a[i] = frag(stage, offA, wm * 8 + i, 0, 0);
+    for (int i = 0; i < TIt; ++i) a[i] = join(ah[i][0], ah[i][1]);
 #pragma unroll
     for (int i = 0; i < TIt; ++i)
 #pragma unroll
