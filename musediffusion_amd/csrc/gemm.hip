@@ -1722,39 +1722,25 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnArgs g) {
     __builtin_amdgcn_s_barrier();
     if (kt + NSTt - 1 < nk) issue(kt + NSTt - 1);
     const unsigned stage = (unsigned)((kt % NSTt) * STAGEt);
-    // two phases: the reads of the B fragments and of the first four A row tiles, one wait, then the reads of the last four A tiles
-    // go out in front of the first sixteen MFMAs and land underneath them (the asm statements keep this order)
     s16x4 ah[TIt][2], bh[TJt][2];
 #pragma unroll
     for (int j = 0; j < TJt; ++j) { bh[j][0] = frag_half(stage, offB, wn * 4 + j, 0); bh[j][1] = frag_half(stage, offB, wn * 4 + j, 1); }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { ah[i][0] = frag_half(stage, offA, wm * 8 + i, 0); ah[i][1] = frag_half(stage, offA, wm * 8 + i, 1); }
-    static_assert(TIt == 8 && TJt == 4, "the waits below name the fragment halves");
+    for (int i = 0; i < TIt; ++i) { ah[i][0] = frag_half(stage, offA, wm * 8 + i, 0); ah[i][1] = frag_half(stage, offA, wm * 8 + i, 1); }
+    static_assert(TIt == 8 && TJt == 4, "the wait below names the 24 fragment halves");
     asm volatile("s_waitcnt lgkmcnt(0)"
                  : "+v"(ah[0][0]), "+v"(ah[0][1]), "+v"(ah[1][0]), "+v"(ah[1][1]), "+v"(ah[2][0]), "+v"(ah[2][1]), "+v"(ah[3][0]), "+v"(ah[3][1]),
+                   "+v"(ah[4][0]), "+v"(ah[4][1]), "+v"(ah[5][0]), "+v"(ah[5][1]), "+v"(ah[6][0]), "+v"(ah[6][1]), "+v"(ah[7][0]), "+v"(ah[7][1]),
                    "+v"(bh[0][0]), "+v"(bh[0][1]), "+v"(bh[1][0]), "+v"(bh[1][1]), "+v"(bh[2][0]), "+v"(bh[2][1]), "+v"(bh[3][0]), "+v"(bh[3][1]));
-#pragma unroll
-    for (int i = 4; i < 8; ++i) { ah[i][0] = frag_half(stage, offA, wm * 8 + i, 0); ah[i][1] = frag_half(stage, offA, wm * 8 + i, 1); }
     bf16x8 a[TIt], b[TJt];
 #pragma unroll
     for (int j = 0; j < TJt; ++j) b[j] = join(bh[j][0], bh[j][1]);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) a[i] = join(ah[i][0], ah[i][1]);
+    for (int i = 0; i < TIt; ++i) a[i] = join(ah[i][0], ah[i][1]);
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < TIt; ++i)
 #pragma unroll
       for (int j = 0; j < TJt; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);   // D'[n][m]
-    // (the accumulators of the first phase are named too: the MFMAs that produce them then stay above this wait, under the reads)
-    asm volatile("s_waitcnt lgkmcnt(0)"
-                 : "+v"(ah[4][0]), "+v"(ah[4][1]), "+v"(ah[5][0]), "+v"(ah[5][1]), "+v"(ah[6][0]), "+v"(ah[6][1]), "+v"(ah[7][0]), "+v"(ah[7][1]),
-                   "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[0][2]), "+v"(acc[0][3]), "+v"(acc[1][0]), "+v"(acc[1][1]), "+v"(acc[1][2]), "+v"(acc[1][3]),
-                   "+v"(acc[2][0]), "+v"(acc[2][1]), "+v"(acc[2][2]), "+v"(acc[2][3]), "+v"(acc[3][0]), "+v"(acc[3][1]), "+v"(acc[3][2]), "+v"(acc[3][3]));
-#pragma unroll
-    for (int i = 4; i < 8; ++i) a[i] = join(ah[i][0], ah[i][1]);
-#pragma unroll
-    for (int i = 4; i < 8; ++i)
-#pragma unroll
-      for (int j = 0; j < TJt; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
     if constexpr (CS > 0) {
       if (worker < CS) {
 #pragma unroll
