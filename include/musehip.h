@@ -530,6 +530,13 @@ typedef struct mh_dropout {
  * backward of every dense site. */
 int mh_dropout_fwd(const void* x, int64_t ldx, void* out, int64_t ldo, int64_t rows, int cols, int dtype, const mh_dropout* drop,
                    mh_stream_t stream);
+/* pre_out = dropout(A W^T + bias) + residual (bf16-rounded) AND out = LayerNorm(pre_out) * gamma + beta in ONE kernel: HF
+ * BertSelfOutput / BertOutput in train mode (dense -> dropout -> LayerNorm(hidden + input)) on the full-row tile (N = 512,
+ * row-major bf16).  pre_out is what the LayerNorm backward reads; the statistics are taken from the rounded values, i.e. what a
+ * separate LayerNorm over pre_out computes.  drop may be NULL / p = 0 (eval, or a dropout-free fine-tune). */
+int mh_gemm_bias_dropout_res_ln(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, const void* residual,
+                                int64_t ldr, const float* gamma, const float* beta, float eps, void* pre_out, void* out, int64_t ldo,
+                                int64_t M, int N, int K, const mh_dropout* drop, mh_stream_t stream);
 /* out = dropout(A W^T + bias) + residual: BertSelfOutput / BertOutput dense -> dropout -> (+ input) in one GEMM (row-major). */
 int mh_gemm_bias_dropout_res(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, const void* residual,
                              int64_t ldr, void* out, int64_t ldo, int64_t M, int N, int K, int dtype, const mh_dropout* drop,

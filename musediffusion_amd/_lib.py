@@ -171,6 +171,7 @@ SIGNATURES = {
     "mh_graph_destroy": (INT, [VP]),
     "mh_dropout_fwd": (INT, [VP, I64, VP, I64, I64, INT, INT, C.POINTER(Dropout), VP]),
     "mh_gemm_bias_dropout_res": (INT, [VP, I64, VP, I64, VP, VP, I64, VP, I64, I64, INT, INT, INT, C.POINTER(Dropout), VP]),
+    "mh_gemm_bias_dropout_res_ln": (INT, [VP, I64, VP, I64, VP, VP, I64, VP, VP, F32, VP, VP, I64, I64, INT, INT, C.POINTER(Dropout), VP]),
     "mh_dropout_bits_words": (C.c_size_t, [INT, INT]),
     "mh_dropout_bits": (INT, [VP, INT, INT, C.POINTER(Dropout), VP]),
     "mh_dropout_bits_apply": (INT, [VP, I64, VP, INT, INT, F32, INT, VP]),

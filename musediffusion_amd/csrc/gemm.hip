@@ -950,20 +950,48 @@ __global__ __launch_bounds__(C::THREADS, C::STAGE * C::NST <= 80 * 1024 ? 2 : 1)
 #pragma unroll
             for (int e = 0; e < 8; ++e) acc[i][2 * qh + (e >> 2)][e & 3] += bv[e];
         }
+        if constexpr ((DBG & 64) != 0) {   // train-mode dropout of the dense output, before the residual (same element numbering as EPI 0)
+#pragma unroll
+          for (int qh = 0; qh < TJ / 2; ++qh) {
+            const int col = wcol0 + 32 * qh + 8 * fg;
+#pragma unroll
+            for (int i = 0; i < TI; ++i) {
+              int64_t row = wrow0 + 16 * i + fr; if (row >= g.M) row = g.M - 1;
+              const uint32_t km = drop_keep8_at(g.drop, (uint64_t)row * g.N + col);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) {
+                const float a = acc[i][2 * qh + (e >> 2)][e & 3];
+                acc[i][2 * qh + (e >> 2)][e & 3] = (km >> e) & 1u ? a * g.drop.rscale : 0.f;
+              }
+            }
+          }
+        }
         wait_vmcnt<0>();
         float rs[TI];
 #pragma unroll
         for (int i = 0; i < TI; ++i) rs[i] = 0.f;
+        // pre_out (training): the un-normalised rows are kept for the LayerNorm backward, rounded to bf16, and the statistics are taken
+        // from the ROUNDED values - what a separate LayerNorm kernel reading that tensor would see
+        bf16* preT = reinterpret_cast<bf16*>(g.pre_out);
 #pragma unroll
         for (int qh = 0; qh < TJ / 2; ++qh) {
+          const int col = wcol0 + 32 * qh + 8 * fg;
 #pragma unroll
           for (int i = 0; i < TI; ++i) {
             const bf16x8 rraw = *reinterpret_cast<const bf16x8*>(rbase + (qh * TI + i) * 1024 + lane * 16);
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = acc[i][2 * qh + (e >> 2)][e & 3] + (float)rraw[e];
+            if (preT) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] = (float)(bf16)v[e];
+              const int64_t row = wrow0 + 16 * i + fr;
+              if (row < g.M) store8_nt(preT + row * g.ldo + col, v);
+            }
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-              const float v = acc[i][2 * qh + (e >> 2)][e & 3] + (float)rraw[e];
-              acc[i][2 * qh + (e >> 2)][e & 3] = v;
-              rs[i] += v;
+              acc[i][2 * qh + (e >> 2)][e & 3] = v[e];
+              rs[i] += v[e];
             }
           }
         }
@@ -1183,7 +1211,10 @@ int launch_big(const GemmArgs& g0, hipStream_t s, int batch) {
     else if (g_plain_stores & 1) MH_LAUNCH((gemm_big_kernel<C, 1, MH_ACT_NONE>), grid, block, 0, s, g);
     else MH_LAUNCH((gemm_big_kernel<C, 1, MH_ACT_NONE, 32>), grid, block, 0, s, g);
   } else if constexpr (EPI == 3) {
-    MH_LAUNCH((gemm_big_kernel<C, 3, MH_ACT_NONE>), grid, block, 0, s, g);
+    if (g.drop.thr) {
+      if constexpr (C::BN == 512 && C::PP) MH_LAUNCH((gemm_big_kernel<C, 3, MH_ACT_NONE, 64>), grid, block, 0, s, g);
+      else { mh_set_error("gemm: the dropout + LayerNorm epilogue is built for the 128x512 tile only"); return MH_ERR_UNSUPPORTED; }
+    } else MH_LAUNCH((gemm_big_kernel<C, 3, MH_ACT_NONE>), grid, block, 0, s, g);
   } else {
     if (g.dbg & 31) {   // timing-only ablations (tools/gemm_bench.py): 1 no DMA, 2 no MFMA, 4 no epilogue, 8 no LDS reads
       switch (g.dbg & 31) {
@@ -1423,6 +1454,24 @@ extern "C" int mh_gemm_bias_dropout_res(const void* A, int64_t lda, const void* 
   if (rc) return rc;
   MH_CHECK_ARG(ldo % 8 == 0 && (!residual || ldr % 8 == 0), "gemm_bias_dropout_res: ldo / ldr must be multiples of 8");
   return launch<0>(g, dtype, (hipStream_t)stream);
+}
+
+// out = LayerNorm(pre) with pre = dropout(A W^T + bias) + residual, and pre itself (bf16-rounded, what the LayerNorm backward reads):
+// BertSelfOutput / BertOutput in train mode as ONE kernel (N = 512, row-major bf16; drop may be null or p = 0)
+extern "C" int mh_gemm_bias_dropout_res_ln(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, const void* residual,
+                                           int64_t ldr, const float* gamma, const float* beta, float eps, void* pre_out, void* out,
+                                           int64_t ldo, int64_t M, int N, int K, const mh_dropout* drop, mh_stream_t stream) {
+  MH_CHECK_ARG(A && W && out && pre_out && bias && residual && gamma && beta, "gemm_bias_dropout_res_ln: null pointer");
+  MH_CHECK_ARG(M > 0 && K > 0 && K % B2K == 0 && N == 512, "gemm_bias_dropout_res_ln: needs N = 512 and K %% 32 == 0 (got N=%d K=%d)", N, K);
+  GemmArgs g{};
+  g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.bias = bias;
+  g.residual = residual; g.ldr = ldr; g.out = out; g.ldo = ldo; g.pre_out = pre_out;
+  g.M = M; g.N = N; g.K = K; g.act = MH_ACT_NONE;
+  g.ln_gamma = gamma; g.ln_beta = beta; g.ln_eps = eps;
+  int rc = mh_drop_args(drop, &g.drop);
+  if (rc) return rc;
+  MH_CHECK_ARG(lda % 8 == 0 && ldw % 8 == 0 && ldo % 8 == 0 && ldr % 8 == 0, "gemm_bias_dropout_res_ln: leading dimensions must be multiples of 8");
+  return launch_big<CfgRowPP, 3>(g, (hipStream_t)stream, 1);
 }
 
 // act(A W^T + bias) -> out AND A W^T + bias -> pre_out in one pass (bf16, row-major, big-tile shapes only): the forward of
@@ -1705,7 +1754,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnArgs g) {
   for (int i = 0; i < TIt; ++i)
 #pragma unroll
     for (int j = 0; j < TJt; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  constexpr int NCS = CS > 0 ? TIt / CS : 1;               // column-sum tiles per worker
+  constexpr int NCS = TIt / (CS > 0 ? CS : TIt);            // column-sum tiles per worker
   f32x4 accs[NCS];
 #pragma unroll
   for (int c = 0; c < NCS; ++c) accs[c] = f32x4{0.f, 0.f, 0.f, 0.f};

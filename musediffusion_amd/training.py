@@ -26,6 +26,32 @@ TN_DW = True            # bf16: weight gradients straight from the k-major activ
 FUSED_FFN = True        # bf16: FFN as one tape node with the GELU backward fused into a GEMM epilogue (A/B switch for tests)
 FUSED_ATTENTION = True  # bf16: streaming forward + fused backward kernels when the shape allows (A/B switch for tests)
 WEIGHT_PREP = True      # bf16: the encoder's weight casts / transposes of a forward + backward in one launch (_WeightPrep)
+FUSED_DENSE_LN = True   # bf16, d_model 512: BertSelfOutput / BertOutput dense -> dropout -> + input -> LayerNorm as one kernel
+
+
+class _FusedLN:
+    """Hand-over between a dense node and the LayerNorm node behind it: when the dense node can run the one-kernel form
+    (mh_gemm_bias_dropout_res_ln) it leaves the normalised rows here and the LayerNorm node's forward takes them instead of launching
+    its own kernel.  Both nodes keep their own backward (the dense node returns the UN-normalised rows, which is what the LayerNorm
+    backward reads), so the tape is the same as with two kernels."""
+
+    def __init__(self, ln):
+        self.g, self.b, self.eps, self.y = ln.weight, ln.bias, float(ln.eps), None
+
+    def usable(self, x, N, Kp, residual, dt, act):
+        return (FUSED_DENSE_LN and dt == ops.MH_BF16 and act is None and residual is not None and N == 512 and Kp % 32 == 0
+                and x.shape[1] % 8 == 0 and residual.shape[1] == N and self.g.dtype == torch.float32)
+
+    def run(self, x, Wc, b, residual, pre, drop):
+        import ctypes as C
+        M, Kp = x.shape
+        N = Wc.shape[0]
+        self.y = torch.empty_like(pre)
+        d = drop.c() if drop is not None else None
+        check(lib().mh_gemm_bias_dropout_res_ln(ptr(x), Kp, ptr(Wc), Wc.shape[1], ptr(b), ptr(residual), residual.shape[1],
+                                                ptr(self.g.detach()), ptr(self.b.detach()), self.eps, ptr(pre), ptr(self.y), N, M, N, Kp,
+                                                C.byref(d) if d is not None else None, current_stream()), "mh_gemm_bias_dropout_res_ln")
+        return pre
 
 
 def _td(dt):
@@ -178,7 +204,7 @@ class _Linear(Function):
     Output [M, pad64(N)] with zero padding columns."""
 
     @staticmethod
-    def forward(ctx, x, W, b, act, residual, dt, drop=None, prep=None):
+    def forward(ctx, x, W, b, act, residual, dt, drop=None, prep=None, ln=None):
         M, Kp = x.shape
         N, K = W.shape
         Np = ops.pad64(N)
@@ -188,7 +214,9 @@ class _Linear(Function):
         pre = _zeros(M, Np, dt, x.device, N)
         fused_act = act is not None and dt == ops.MH_BF16 and N == Np and N % 8 == 0 and Kp % 32 == 0
         ctx.drop = drop if _active(drop) else None
-        if ctx.drop is not None:   # dense -> dropout -> + residual in one kernel; the backward re-creates the mask
+        if ln is not None and b is not None and ln.usable(x, N, Kp, residual, dt, act):
+            y = ln.run(x, Wc, b.detach(), residual, pre, ctx.drop)       # ... and the LayerNorm behind it (ln.y) in the same kernel
+        elif ctx.drop is not None:   # dense -> dropout -> + residual in one kernel; the backward re-creates the mask
             assert act is None and N == Np
             y = _gemm_drop(x, Wc, b.detach() if b is not None else None, dt, N, Kp, pre, residual, ctx.drop)
         elif fused_act:      # one kernel writes the pre-activation (kept for the backward) and the activation
@@ -227,7 +255,7 @@ class _Linear(Function):
         _gemm(dpre, WT, None, dt, Kp, Np, out=dx)
         # dW = dpre^T X : reduction over the M rows
         dW, db = _dw(dpre, x, N, Kp, M, dt, bias=True) if has_b else (_dw(dpre, x, N, Kp, M, dt), None)
-        return dx, dW[:, :K].contiguous(), db, None, (dy if has_res else None), None, None, None
+        return dx, dW[:, :K].contiguous(), db, None, (dy if has_res else None), None, None, None, None
 
 
 class _FFN(Function):
@@ -241,7 +269,7 @@ class _FFN(Function):
         return dt == ops.MH_BF16 and x.shape[1] == H and H % 64 == 0 and F % 64 == 0 and tuple(W2.shape) == (H, F)
 
     @staticmethod
-    def forward(ctx, x, W1, b1, W2, b2, dt, drop=None, prep=None):
+    def forward(ctx, x, W1, b1, W2, b2, dt, drop=None, prep=None, ln=None):
         M, H = x.shape
         F = W1.shape[0]
         if prep is not None:      # (W1c, W1T, W2c, W2T) from _WeightPrep
@@ -256,7 +284,9 @@ class _FFN(Function):
                                          current_stream()), "mh_gemm_bias_act_pre")
         y = torch.empty(M, H, device=x.device, dtype=x.dtype)
         ctx.drop = drop if _active(drop) else None
-        if ctx.drop is not None:
+        if ln is not None and ln.usable(f, H, F, x, dt, None):
+            ln.run(f, W2c, b2.detach(), x, y, ctx.drop)
+        elif ctx.drop is not None:
             _gemm_drop(f, W2c, b2.detach(), dt, H, F, y, x, ctx.drop)
         else:
             _gemm(f, W2c, b2.detach(), dt, H, F, out=y, residual=x)
@@ -282,7 +312,7 @@ class _FFN(Function):
         dx = torch.empty(M, H, device=x.device, dtype=x.dtype)
         W1T = ctx.WT[0] if ctx.WT is not None else _transpose(W1c, F, H, dt, ld_out=F)                         # [H, F]
         _gemm(dpre, W1T, None, dt, H, F, out=dx, residual=dy)             # + dy: the residual branch
-        return dx, dW1, db1, dW2, db2, None, None, None
+        return dx, dW1, db1, dW2, db2, None, None, None, None
 
 
 class _Dropout(Function):
@@ -300,8 +330,11 @@ class _Dropout(Function):
 
 class _LayerNorm(Function):
     @staticmethod
-    def forward(ctx, x, g, b, eps, dt):
-        y = ops.layernorm(x, g.detach(), b.detach(), eps, dt)
+    def forward(ctx, x, g, b, eps, dt, fused=None):
+        if fused is not None and fused.y is not None:      # the dense node in front already normalised these rows (_FusedLN)
+            y, fused.y = fused.y, None
+        else:
+            y = ops.layernorm(x, g.detach(), b.detach(), eps, dt)
         ctx.save_for_backward(x, g.detach())
         ctx.meta = (eps, dt)
         return y
@@ -319,7 +352,7 @@ class _LayerNorm(Function):
         db = torch.empty(H, device=x.device, dtype=torch.float32)
         check(lib().mh_layernorm_bwd(ptr(x), ptr(dy), ptr(g), ptr(dx), ptr(part), nb, ptr(dg), ptr(db), 0, M, H, eps, dt,
                                      current_stream()), "mh_layernorm_bwd")
-        return dx, dg, db, None, None
+        return dx, dg, db, None, None, None
 
 
 class _AddPosTime(Function):
@@ -603,8 +636,8 @@ class _TokenCE(Function):
 
 
 # ---------------------------------------------------------------------------------------------- composites
-def _linear(x, lin, act, dt, residual=None, drop=None, prep=None):
-    return _Linear.apply(x, lin.weight, lin.bias, act, residual, dt, drop, prep)
+def _linear(x, lin, act, dt, residual=None, drop=None, prep=None, ln=None):
+    return _Linear.apply(x, lin.weight, lin.bias, act, residual, dt, drop, prep, ln)
 
 
 class _DropSites:
@@ -760,19 +793,21 @@ def denoiser_forward_with_grad(model, x, timesteps):
         bqkv = torch.cat([sa.query.bias, sa.key.bias, sa.value.bias], dim=0)
         qkv = _Linear.apply(X, Wqkv, bqkv, None, None, dt, None, None if wp is None else (wp.qkv[li], wp.qkv_t[li]))   # [N, 3H]
         ctxv = _Attention.apply(qkv, B, L, model.num_heads, dt, sites.site("l%d.attn" % li, sites.p_att))
+        ln1 = _FusedLN(layer.attention.output.LayerNorm)
         y1 = _linear(ctxv, layer.attention.output.dense, None, dt, residual=X, drop=sites.site("l%d.ao" % li, sites.p_hid),
-                     prep=None if wp is None else (wp.ao[li], wp.ao_t[li]))
+                     prep=None if wp is None else (wp.ao[li], wp.ao_t[li]), ln=ln1)
         X1 = _LayerNorm.apply(y1, layer.attention.output.LayerNorm.weight, layer.attention.output.LayerNorm.bias,
-                              layer.attention.output.LayerNorm.eps, dt)
+                              layer.attention.output.LayerNorm.eps, dt, ln1)
         d1, d2 = layer.intermediate.dense, layer.output.dense
         d_ffn = sites.site("l%d.ffn" % li, sites.p_hid)
+        ln2 = _FusedLN(layer.output.LayerNorm)
         if FUSED_FFN and (B * L) % 64 == 0 and _FFN.supported(X1, d1.weight, d2.weight, dt):
             y2 = _FFN.apply(X1, d1.weight, d1.bias, d2.weight, d2.bias, dt, d_ffn,
-                            None if wp is None else (wp.w1[li], wp.w1_t[li], wp.w2[li], wp.w2_t[li]))
+                            None if wp is None else (wp.w1[li], wp.w1_t[li], wp.w2[li], wp.w2_t[li]), ln2)
         else:
             f = _linear(X1, d1, "gelu", dt, prep=None if wp is None else (wp.w1[li], wp.w1_t[li]))
-            y2 = _linear(f, d2, None, dt, residual=X1, drop=d_ffn, prep=None if wp is None else (wp.w2[li], wp.w2_t[li]))
-        X = _LayerNorm.apply(y2, layer.output.LayerNorm.weight, layer.output.LayerNorm.bias, layer.output.LayerNorm.eps, dt)
+            y2 = _linear(f, d2, None, dt, residual=X1, drop=d_ffn, prep=None if wp is None else (wp.w2[li], wp.w2_t[li]), ln=ln2)
+        X = _LayerNorm.apply(y2, layer.output.LayerNorm.weight, layer.output.LayerNorm.bias, layer.output.LayerNorm.eps, dt, ln2)
     if model.output_dims != H:
         h = _linear(X, model.output_down_proj[0], "tanh", dt)
         h = _linear(h, model.output_down_proj[2], None, dt)

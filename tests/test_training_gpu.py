@@ -185,6 +185,50 @@ def test_fused_attention_training_path_matches_unfused(L):
         assert abs(float(a.norm()) / float(b.norm()) - 1.0) < 0.03, name
 
 
+@pytest.mark.parametrize("p", [0.0, 0.1])
+def test_dense_dropout_layernorm_as_one_kernel_matches_two(p):
+    """d_model 512: BertSelfOutput / BertOutput (dense -> dropout -> + input -> LayerNorm) as ONE kernel (mh_gemm_bias_dropout_res_ln)
+    against the dense kernel + the LayerNorm kernel: same Philox masks (same call number), same bf16-rounded pre-LayerNorm rows -
+    the losses agree to bf16 rounding and every gradient points the same way"""
+    from musediffusion_amd import training
+    torch.manual_seed(6)
+    E, H, B, V, L = 32, 512, 2, 97, 128
+    m = TransformerNetModel(E, E, 32, V, L, dropout=p, bert_hidden=H, bert_layers=2, bert_heads=8, bert_ffn=1024,
+                            compute_dtype="bf16", bert_hidden_dropout=p, bert_attention_dropout=0.0)
+    m.train().requires_grad_(True).to(DEV)
+    diff = SpacedDiffusion(use_timesteps=space_timesteps(2000, [2000]), betas=get_named_beta_schedule("sqrt", 2000),
+                           rescale_timesteps=True, predict_xstart=True)
+    gen = torch.Generator().manual_seed(9)
+    ids = torch.randint(3, V, (B, L), generator=gen)
+    batch = {"input_ids": ids, "input_mask": torch.ones(B, L, dtype=torch.long), "correct_ids": ids.clone()}
+    t = torch.tensor([400, 1500], device=DEV)
+    res = []
+    try:
+        for fused in (True, False):
+            training.FUSED_DENSE_LN = fused
+            m._dropout_calls = 0                       # the same Philox counters in both runs
+            m.zero_grad(set_to_none=True)
+            with CpuDraws(11):
+                terms = diff.training_losses(m, t, model_kwargs=batch)
+            terms["loss"].mean().backward()
+            res.append((terms["loss"].detach().float().cpu(),
+                        {n: q.grad.detach().float().cpu().clone() for n, q in m.named_parameters() if q.grad is not None}))
+    finally:
+        training.FUSED_DENSE_LN = True
+    assert torch.allclose(res[0][0], res[1][0], rtol=5e-3, atol=5e-3), (res[0][0], res[1][0])
+    assert res[0][1].keys() == res[1][1].keys()
+    for name in res[0][1]:
+        a, b = res[0][1][name].flatten(), res[1][1][name].flatten()
+        if float(b.norm()) == 0.0:
+            assert float(a.norm()) == 0.0, name
+            continue
+        if name.endswith("attention.self.key.bias"):      # softmax is invariant to a key bias: that gradient is rounding noise
+            continue
+        cos = float(torch.nn.functional.cosine_similarity(a, b, dim=0))
+        assert cos > 0.999, (name, cos)
+        assert abs(float(a.norm()) / float(b.norm()) - 1.0) < 0.02, name
+
+
 def test_one_launch_weight_copies_give_the_same_tape():
     """training._WeightPrep (one launch makes the bf16 copies and transposes of every encoder weight) against the per-layer casts
     and transposes: identical operands, so losses and every gradient are bit-identical; the copies follow an in-place weight update"""
