@@ -951,6 +951,7 @@ __global__ __launch_bounds__(C::THREADS, C::STAGE * C::NST <= 80 * 1024 ? 2 : 1)
             for (int e = 0; e < 8; ++e) acc[i][2 * qh + (e >> 2)][e & 3] += bv[e];
         }
         if constexpr ((DBG & 64) != 0) {   // train-mode dropout of the dense output, before the residual (same element numbering as EPI 0)
+          if (g.drop.thr)                    // (the training build also serves p = 0: it is the one that writes pre_out)
 #pragma unroll
           for (int qh = 0; qh < TJ / 2; ++qh) {
             const int col = wcol0 + 32 * qh + 8 * fg;
@@ -972,7 +973,7 @@ __global__ __launch_bounds__(C::THREADS, C::STAGE * C::NST <= 80 * 1024 ? 2 : 1)
         for (int i = 0; i < TI; ++i) rs[i] = 0.f;
         // pre_out (training): the un-normalised rows are kept for the LayerNorm backward, rounded to bf16, and the statistics are taken
         // from the ROUNDED values - what a separate LayerNorm kernel reading that tensor would see
-        bf16* preT = reinterpret_cast<bf16*>(g.pre_out);
+        bf16* preT = (DBG & 64) != 0 ? reinterpret_cast<bf16*>(g.pre_out) : nullptr;   // (compile-time off in the sampling build)
 #pragma unroll
         for (int qh = 0; qh < TJ / 2; ++qh) {
           const int col = wcol0 + 32 * qh + 8 * fg;
@@ -1211,7 +1212,7 @@ int launch_big(const GemmArgs& g0, hipStream_t s, int batch) {
     else if (g_plain_stores & 1) MH_LAUNCH((gemm_big_kernel<C, 1, MH_ACT_NONE>), grid, block, 0, s, g);
     else MH_LAUNCH((gemm_big_kernel<C, 1, MH_ACT_NONE, 32>), grid, block, 0, s, g);
   } else if constexpr (EPI == 3) {
-    if (g.drop.thr) {
+    if (g.drop.thr || g.pre_out) {   // the training build: dropout (p may be 0) + the un-normalised rows kept for the backward
       if constexpr (C::BN == 512 && C::PP) MH_LAUNCH((gemm_big_kernel<C, 3, MH_ACT_NONE, 64>), grid, block, 0, s, g);
       else { mh_set_error("gemm: the dropout + LayerNorm epilogue is built for the 128x512 tile only"); return MH_ERR_UNSUPPORTED; }
     } else MH_LAUNCH((gemm_big_kernel<C, 3, MH_ACT_NONE>), grid, block, 0, s, g);
