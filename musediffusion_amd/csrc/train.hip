@@ -672,6 +672,11 @@ extern "C" int mh_layernorm_bwd(const void* x, const void* dy, const float* gamm
 #undef MH_LNB
   MH_CHECK_LAUNCH();
   // (a colsum_final block folds 64 columns: 4 partial-lanes x 64)
+  if (dbeta == dgamma + H) {   // the two gradients side by side (as the partials are): one launch folds both
+    MH_LAUNCH(colsum_final_kernel, dim3((H + 63) / 64, 2), dim3(1024), 0, s, pg, n_partial, H, dgamma, accumulate);
+    MH_CHECK_LAUNCH();
+    return MH_OK;
+  }
   MH_LAUNCH(colsum_final_kernel, dim3((H + 63) / 64, 1), dim3(1024), 0, s, pg, n_partial, H, dgamma, accumulate);
   MH_CHECK_LAUNCH();
   MH_LAUNCH(colsum_final_kernel, dim3((H + 63) / 64, 1), dim3(1024), 0, s, pb, n_partial, H, dbeta, accumulate);

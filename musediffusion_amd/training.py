@@ -348,8 +348,8 @@ class _LayerNorm(Function):
         dx = torch.empty_like(x)
         nb = min(1024, (M + 3) // 4)
         part = torch.empty(2 * nb * H, device=x.device, dtype=torch.float32)
-        dg = torch.empty(H, device=x.device, dtype=torch.float32)
-        db = torch.empty(H, device=x.device, dtype=torch.float32)
+        dgb = torch.empty(2, H, device=x.device, dtype=torch.float32)     # side by side: one launch folds both (mh_layernorm_bwd)
+        dg, db = dgb[0], dgb[1]
         check(lib().mh_layernorm_bwd(ptr(x), ptr(dy), ptr(g), ptr(dx), ptr(part), nb, ptr(dg), ptr(db), 0, M, H, eps, dt,
                                      current_stream()), "mh_layernorm_bwd")
         return dx, dg, db, None, None, None
