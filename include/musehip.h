@@ -275,7 +275,9 @@ int mh_trunc_normal(float* out, int64_t n, float bound, uint64_t seed, uint32_t 
 int mh_transpose(const void* in, int64_t ld_in, int64_t stride_in, void* out, int64_t ld_out, int64_t stride_out, int rows,
                  int cols, int batch, int dtype, mh_stream_t stream);
 /* mode 0: tokens [B*L, ld_tok] -> heads [B,nh,L,dh]; 1: heads -> tokens; 2: tokens -> transposed heads [B,nh,dh,L];
- * 3: as 2 with the positions of every group of 16 stored as 0-3, 8-11, 4-7, 12-15 (streaming attention operand order) */
+ * 3: as 2 with the positions of every group of 16 stored as 0-3, 8-11, 4-7, 12-15 (streaming attention operand order);
+ * 4: as 3, and the 256 elements behind the last row are zeroed (the slack the streaming kernels' 16-byte tail reads want: `out`
+ * must hold B nh dh L + 256 elements) - bf16, L % 64 == 0, dh in {32, 64, 128} only */
 int mh_head_permute(const void* in, void* out, int64_t ld_tok, int B, int L, int nh, int dh, int mode, int dtype,
                     mh_stream_t stream);
 /* out[b, c] (+)= sum_r in[b][r, c]  (bias / LayerNorm-parameter / position / time-embedding gradients);

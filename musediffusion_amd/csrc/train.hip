@@ -122,6 +122,9 @@ __global__ __launch_bounds__(256) void head_transpose_kernel(const bf16* __restr
                                                              int nh, int perm) {
   __shared__ bf16 tile[64][DH + 8];
   const int bh = blockIdx.y, b = bh / nh, h = bh % nh, l0 = blockIdx.x * 64;
+  if (perm == 2 && blockIdx.x == 0 && blockIdx.y == 0)      // mode 4: zero the 256-element slack behind the last row
+    out[(int64_t)gridDim.y * DH * L + threadIdx.x] = (bf16)0.0f;
+  perm = perm != 0;
   constexpr int CPR = DH / 8;
   for (int i = threadIdx.x; i < 64 * CPR; i += 256) {
     const int l = i / CPR, c = i % CPR;
@@ -580,7 +583,7 @@ extern "C" int mh_transpose(const void* in, int64_t ld_in, int64_t stride_in, vo
 
 extern "C" int mh_head_permute(const void* in, void* out, int64_t ld_tok, int B, int L, int nh, int dh, int mode, int dtype,
                                mh_stream_t stream) {
-  MH_CHECK_ARG(in && out && B > 0 && L > 0 && nh > 0 && dh > 0 && mode >= 0 && mode <= 3 && (mode != 3 || L % 16 == 0), "head_permute: bad arguments");
+  MH_CHECK_ARG(in && out && B > 0 && L > 0 && nh > 0 && dh > 0 && mode >= 0 && mode <= 4 && (mode < 3 || L % 16 == 0), "head_permute: bad arguments");
   hipStream_t s = (hipStream_t)stream;
   const bool vec_ok = dtype == MH_BF16 && dh % 8 == 0 && ld_tok % 8 == 0 && (reinterpret_cast<uintptr_t>(in) & 15) == 0 &&
                       (reinterpret_cast<uintptr_t>(out) & 15) == 0;
@@ -592,12 +595,14 @@ extern "C" int mh_head_permute(const void* in, void* out, int64_t ld_tok, int B,
   }
   if (vec_ok && mode >= 2 && L % 64 == 0 && (dh == 32 || dh == 64 || dh == 128)) {
     const dim3 grid(L / 64, B * nh);
-    if (dh == 32) MH_LAUNCH((head_transpose_kernel<32>), grid, dim3(256), 0, s, (const bf16*)in, (bf16*)out, ld_tok, L, nh, mode == 3);
-    else if (dh == 64) MH_LAUNCH((head_transpose_kernel<64>), grid, dim3(256), 0, s, (const bf16*)in, (bf16*)out, ld_tok, L, nh, mode == 3);
-    else MH_LAUNCH((head_transpose_kernel<128>), grid, dim3(256), 0, s, (const bf16*)in, (bf16*)out, ld_tok, L, nh, mode == 3);
+    const int perm = mode == 4 ? 2 : (mode == 3 ? 1 : 0);
+    if (dh == 32) MH_LAUNCH((head_transpose_kernel<32>), grid, dim3(256), 0, s, (const bf16*)in, (bf16*)out, ld_tok, L, nh, perm);
+    else if (dh == 64) MH_LAUNCH((head_transpose_kernel<64>), grid, dim3(256), 0, s, (const bf16*)in, (bf16*)out, ld_tok, L, nh, perm);
+    else MH_LAUNCH((head_transpose_kernel<128>), grid, dim3(256), 0, s, (const bf16*)in, (bf16*)out, ld_tok, L, nh, perm);
     MH_CHECK_LAUNCH();
     return MH_OK;
   }
+  MH_CHECK_ARG(mode != 4, "head_permute: mode 4 needs bf16, seq_len %% 64 == 0, head dim 32 / 64 / 128 and 16-byte aligned rows");
   const int grid = tgrid((int64_t)B * L * nh * dh);
   MH_DTYPE_SWITCH(dtype,
                   MH_LAUNCH((head_permute_kernel<bf16>), dim3(grid), dim3(TB), 0, s, (const bf16*)in, (bf16*)out, ld_tok, B, L, nh, dh, mode),

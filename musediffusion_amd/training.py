@@ -421,8 +421,11 @@ class _Attention(Function):
         scale = 1.0 / math.sqrt(dh)
         fused = FUSED_ATTENTION and dt == ops.MH_BF16 and bool(L_.mh_attention_stream_bwd_supported(L, dh)) and ld == 3 * H
         vt = torch.empty(B * nh * dh * L + 256, device=qkv.device, dtype=td)     # slack: 16-B tail over-read of the last row
-        vt[-256:].zero_()
-        check(L_.mh_head_permute(qkv.data_ptr() + 2 * H * es, ptr(vt), ld, B, L, nh, dh, 3 if fused else 2, dt, st), "mh_head_permute")
+        slack_in_kernel = fused and L % 64 == 0 and dh in (32, 64, 128)              # (mode 4 zeroes it in the same launch)
+        if not slack_in_kernel:
+            vt[-256:].zero_()
+        check(L_.mh_head_permute(qkv.data_ptr() + 2 * H * es, ptr(vt), ld, B, L, nh, dh, (4 if slack_in_kernel else 3) if fused else 2, dt, st),
+              "mh_head_permute")
         if fused:
             # streaming forward straight off the token-major projections (rows of one head are dh-wide column blocks, pitch 3H);
             # the log-sum-exp lets the backward kernels re-create P tile by tile (no [L, L] tensor in HBM)
@@ -474,8 +477,10 @@ class _Attention(Function):
 
         def transposed(src, col0, ld):     # [B, nh, dh, L] in the kernels' position order
             t = torch.empty(n + 256, device=dev, dtype=td)
-            t[-256:].zero_()
-            check(L_.mh_head_permute(src.data_ptr() + col0 * es, ptr(t), ld, B, L, nh, dh, 3, dt, st), "mh_head_permute")
+            mode = 4 if (L % 64 == 0 and dh in (32, 64, 128) and ld % 8 == 0) else 3     # 4: the slack is zeroed by the same launch
+            if mode == 3:
+                t[-256:].zero_()
+            check(L_.mh_head_permute(src.data_ptr() + col0 * es, ptr(t), ld, B, L, nh, dh, mode, dt, st), "mh_head_permute")
             return t
         qT, kT, dOT = transposed(qkv, 0, 3 * H), transposed(qkv, H, 3 * H), transposed(dctx, 0, H)
         D = torch.empty(B * nh * L, device=dev, dtype=torch.float32)      # scratch: rowsum(dO o O), produced by the dQ kernel

@@ -223,6 +223,10 @@ def test_attention_stream_backward(dh, L, B, nh):
         return out
     qr, kr, vr = (perm(qkv_d, i * H, 3 * H, 0) for i in range(3))
     qT, kT, vT = (perm(qkv_d, i * H, 3 * H, 3) for i in range(3))
+    if L % 64 == 0:      # mode 4 = mode 3 + the 256-element slack behind the last row zeroed by the same launch
+        dirty = torch.full((B * nh * L * dh + 256,), 7.0, device=DEV, dtype=torch.bfloat16)
+        check(lib().mh_head_permute(qkv_d.data_ptr() + H * 2, dirty.data_ptr(), 3 * H, B, L, nh, dh, 4, MH_BF16, st))
+        assert torch.equal(dirty, kT)
     assert torch.equal(vT[: B * H * L].view(B, nh, dh, L), _vt_perm(vr[: B * H * L].view(B, nh, L, dh).transpose(-1, -2).contiguous()))
     ctx = torch.zeros(B * L, H, device=DEV, dtype=torch.bfloat16)
     lse = torch.zeros(B * nh * L, device=DEV)
