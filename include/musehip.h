@@ -164,7 +164,9 @@ int mh_attention_bwd_rowdot(const void* dctx, const void* ctx, int64_t ld, float
                             mh_stream_t stream);
 int mh_attention_stream_supported(int L, int dh);
 /* A/B switch read by mh_denoiser_forward's panel path: 1 (default) = streaming kernel, 16-wave blocks with 256-key stages;
- * 2 = 8-wave blocks with 128-key stages (half a CU per block, same bits; 3% slower inside the step); 0 = resident / tiled kernels. */
+ * 2 = 8-wave blocks with 128-key stages (half a CU per block, same bits; 3% slower inside the step); 0 = resident / tiled kernels;
+ * 3 = the in-kernel dropout-mask generator on the 16-wave geometry (spills; A/B); 4 = always the bound-checking build (by default
+ * seq_len % 256 == 0 selects builds without the per-score bound compares, forward and backward). */
 int mh_attention_set_stream(int on);
 int mh_attention_stream_enabled(void);
 /* mh_gemm_qkv_ex (bf16) writing V^T in the key order mh_attention_stream_fwd reads (seq_len % 16 == 0). */
