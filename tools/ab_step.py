@@ -16,7 +16,7 @@ sys.argv = list(BASE)
 import bench  # noqa: E402
 from musediffusion_amd import _lib  # noqa: E402
 
-setters = {"plain_stores": lambda v: _lib.lib().mh_gemm_set_plain_stores(v), "fuse_ln": lambda v: _lib.lib().mh_denoiser_set_fuse_ln(v),
+setters = {"gemm_debug": lambda v: _lib.lib().mh_gemm_set_debug(v), "plain_stores": lambda v: _lib.lib().mh_gemm_set_plain_stores(v), "fuse_ln": lambda v: _lib.lib().mh_denoiser_set_fuse_ln(v),
            "v3_fuse_ln": lambda v: (_lib.lib().mh_gemm_set_variant(3), _lib.lib().mh_denoiser_set_fuse_ln(v)),
            "v3_split": None,
            "stream_attn": lambda v: _lib.lib().mh_attention_set_stream(v), "gemm_variant": lambda v: _lib.lib().mh_gemm_set_variant(v)}
