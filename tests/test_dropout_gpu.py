@@ -108,6 +108,31 @@ def test_gemm_dropout_epilogue_matches_standalone_mask(dt, td, M, N, K):
     assert 0.07 < 1 - float(keep.float().mean()) < 0.13
 
 
+@pytest.mark.parametrize("M,K,p", [(1024, 2048, 0.1), (300, 512, 0.1), (640, 256, 0.0)])
+def test_dense_dropout_residual_layernorm_one_kernel(M, K, p):
+    """mh_gemm_bias_dropout_res_ln (HF BertSelfOutput / BertOutput in train mode as one kernel, N = 512): its un-normalised rows are
+    bit-identical with the dense + dropout + residual kernel's (same Philox mask, same arithmetic order), its normalised rows are
+    the LayerNorm of those bf16 rows up to one rounding of the result"""
+    torch.manual_seed(1)
+    N, td = 512, torch.bfloat16
+    A = torch.randn(M, K, device=DEV).to(td)
+    W = (torch.randn(N, K, device=DEV) / math.sqrt(K)).to(td)
+    b = torch.randn(N, device=DEV)
+    R = torch.randn(M, N, device=DEV).to(td)
+    g, bt = 1 + 0.1 * torch.randn(N, device=DEV), 0.1 * torch.randn(N, device=DEV)
+    d = desc(p, seed=77, offset=(3 << 16) | 5)
+    two = torch.empty(M, N, device=DEV, dtype=td)
+    check(lib().mh_gemm_bias_dropout_res(ptr(A), K, ptr(W), K, ptr(b), ptr(R), N, ptr(two), N, M, N, K, MH_BF16, C.byref(d), current_stream()))
+    pre = torch.full((M, N), 7.0, device=DEV, dtype=td)
+    out = torch.full((M, N), 7.0, device=DEV, dtype=td)
+    check(lib().mh_gemm_bias_dropout_res_ln(ptr(A), K, ptr(W), K, ptr(b), ptr(R), N, ptr(g), ptr(bt), 1e-12, ptr(pre), ptr(out), N, M, N, K,
+                                            C.byref(d), current_stream()))
+    assert torch.equal(pre, two)
+    ref = torch.nn.functional.layer_norm(pre.float(), (N,), g, bt, 1e-12)
+    err = (out.float() - ref).abs()
+    assert float((err / (ref.abs() + 1.0)).max()) < 2 ** -7, float(err.max())
+
+
 def stream_inputs(B, L, nh, dh, seed=0):
     torch.manual_seed(seed)
     H = nh * dh
