@@ -287,6 +287,32 @@ def test_gemm_dw_with_bias_gradient(K, M, N):
     assert_close(out[M * N:], ref_b, 2e-3 * math.sqrt(K / 1024), 1e-3, what="gemm_dw_bias db K=%d M=%d N=%d" % (K, M, N))
 
 
+def test_weight_prep_one_launch_copies_and_transposes():
+    """mh_weight_prep: bf16 copies + transposes of several fp32 matrices from one device table, incl. the QKV case (three sources
+    into row / column blocks of one destination): bit-identical with torch's casts"""
+    import ctypes as C
+    from musediffusion_amd import _lib
+    from musediffusion_amd._lib import check, current_stream
+    H, F = 128, 256
+    Ws = [rnd(H, H, seed=300 + i).to(DEV) for i in range(3)] + [rnd(F, H, seed=310).to(DEV), rnd(H, F, seed=311).to(DEV)]
+    qkv = torch.full((3 * H, H), 9.0, device=DEV, dtype=torch.bfloat16)
+    qkv_t = torch.full((H, 3 * H), 9.0, device=DEV, dtype=torch.bfloat16)
+    w1, w1_t = torch.empty(F, H, device=DEV, dtype=torch.bfloat16), torch.empty(H, F, device=DEV, dtype=torch.bfloat16)
+    w2 = torch.empty(H, F, device=DEV, dtype=torch.bfloat16)
+    items, tiles = [], 0
+    for W, dst, dst_t, ld_dst, ld_t in ([(Ws[j], qkv.data_ptr() + j * H * H * 2, qkv_t.data_ptr() + j * H * 2, H, 3 * H) for j in range(3)]
+                                        + [(Ws[3], w1.data_ptr(), w1_t.data_ptr(), H, F), (Ws[4], w2.data_ptr(), None, F, 0)]):
+        items.append(_lib.WPrepItem(W.data_ptr(), dst, dst_t, W.shape[0], W.shape[1], ld_dst, ld_t, tiles, 0))
+        tiles += (W.shape[0] // 64) * (W.shape[1] // 64)
+    raw = (_lib.WPrepItem * len(items))(*items)
+    table = torch.frombuffer(bytearray(C.string_at(C.addressof(raw), C.sizeof(raw))), dtype=torch.uint8).to(DEV)
+    check(lib().mh_weight_prep(table.data_ptr(), len(items), tiles, current_stream()))
+    cat = torch.cat(Ws[:3], 0).bfloat16()
+    assert torch.equal(qkv, cat) and torch.equal(qkv_t, cat.t().contiguous())
+    assert torch.equal(w1, Ws[3].bfloat16()) and torch.equal(w1_t, Ws[3].bfloat16().t().contiguous())
+    assert torch.equal(w2, Ws[4].bfloat16())
+
+
 def test_gemm_qkv_vtperm():
     from musediffusion_amd._lib import check, current_stream
     B, L, H, nh = 2, 48, 128, 2
