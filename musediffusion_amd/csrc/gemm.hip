@@ -67,7 +67,7 @@ struct GemmArgs {
 
 template <typename T> struct Tile;
 template <> struct Tile<bf16> { static constexpr int BK = 64, ROWB = 128, CHUNKS = 8; };
-template <> struct Tile<float> { static constexpr int BK = 16, ROWB = 96, CHUNKS = 4; };
+template <> struct Tile<float> { static constexpr int BK = 16, ROWB = 80, CHUNKS = 4; };
 
 constexpr int BM = 128, BN = 128, CS_LD = 68;
 
