@@ -229,6 +229,57 @@ def test_dense_dropout_layernorm_as_one_kernel_matches_two(p):
         assert abs(float(a.norm()) / float(b.norm()) - 1.0) < 0.02, name
 
 
+def test_micro_batch_accumulation_adds_the_separate_gradients_exactly():
+    """TrainStep.forward_backward (train_util.py:199-226: micro-batches back-propagated one after the other, gradients adding up
+    without a division) at d_model 512 / seq_len 512 in bf16: the accumulated gradient of two micro-batches is bit-for-bit the sum of
+    the gradients of the two run on their own - the kernels are deterministic and nothing else touches the gradients"""
+    from musediffusion_amd.train_step import TrainStep
+
+    class Fixed:                                            # a sampler with a scripted sequence of timesteps, unit weights
+        def __init__(self, ts):
+            self.ts = list(ts)
+
+        def sample(self, n, dev):
+            t = torch.tensor(self.ts[:n], device=dev)
+            self.ts = self.ts[n:]
+            return t, torch.ones(n, device=dev)
+
+    class NoOpt:
+        def grad_norm(self):
+            return torch.zeros(1)
+
+        def step(self, lr=None):
+            pass
+
+    torch.manual_seed(8)
+    E, H, B, V, L = 32, 512, 4, 97, 512
+    m = TransformerNetModel(E, E, 32, V, L, dropout=0.0, bert_hidden=H, bert_layers=2, bert_heads=8, bert_ffn=1024,
+                            compute_dtype="bf16", bert_hidden_dropout=0.0, bert_attention_dropout=0.0)
+    m.train().requires_grad_(True).to(DEV)
+    diff = SpacedDiffusion(use_timesteps=space_timesteps(2000, [2000]), betas=get_named_beta_schedule("sqrt", 2000),
+                           rescale_timesteps=True, predict_xstart=True)
+    gen = torch.Generator().manual_seed(10)
+    ids = torch.randint(3, V, (B, L), generator=gen)
+    cond = {"input_ids": ids, "input_mask": torch.ones(B, L, dtype=torch.long), "correct_ids": ids.clone()}
+    ts = [100, 900, 1500, 30]
+
+    def grads():
+        return {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None}
+    parts = []
+    with CpuDraws(21):                                      # the two halves on their own, drawing in the accumulated run's order
+        for i in (0, 2):
+            step = TrainStep(m, diff, microbatch=2, schedule_sampler=Fixed(ts[i:i + 2]), optimizer=NoOpt())
+            step.forward_backward({k: v[i:i + 2] for k, v in cond.items()})
+            parts.append(grads())
+    with CpuDraws(21):
+        step = TrainStep(m, diff, microbatch=2, schedule_sampler=Fixed(ts), optimizer=NoOpt())
+        step.forward_backward(cond)
+    both = grads()
+    assert both.keys() == parts[0].keys() == parts[1].keys()
+    for n in both:
+        assert torch.equal(both[n], parts[0][n] + parts[1][n]), n
+
+
 def test_one_launch_weight_copies_give_the_same_tape():
     """training._WeightPrep (one launch makes the bf16 copies and transposes of every encoder weight) against the per-layer casts
     and transposes: identical operands, so losses and every gradient are bit-identical; the copies follow an in-place weight update"""
