@@ -229,10 +229,12 @@ def test_dense_dropout_layernorm_as_one_kernel_matches_two(p):
         assert abs(float(a.norm()) / float(b.norm()) - 1.0) < 0.02, name
 
 
-def test_micro_batch_accumulation_adds_the_separate_gradients_exactly():
+@pytest.mark.parametrize("p", [0.0, 0.1])
+def test_micro_batch_accumulation_adds_the_separate_gradients_exactly(p):
     """TrainStep.forward_backward (train_util.py:199-226: micro-batches back-propagated one after the other, gradients adding up
     without a division) at d_model 512 / seq_len 512 in bf16: the accumulated gradient of two micro-batches is bit-for-bit the sum of
-    the gradients of the two run on their own - the kernels are deterministic and nothing else touches the gradients"""
+    the gradients of the two run on their own - the kernels are deterministic (Philox dropout masks included: they are keyed by
+    the forward call number) and nothing else touches the gradients"""
     from musediffusion_amd.train_step import TrainStep
 
     class Fixed:                                            # a sampler with a scripted sequence of timesteps, unit weights
@@ -253,8 +255,8 @@ def test_micro_batch_accumulation_adds_the_separate_gradients_exactly():
 
     torch.manual_seed(8)
     E, H, B, V, L = 32, 512, 4, 97, 512
-    m = TransformerNetModel(E, E, 32, V, L, dropout=0.0, bert_hidden=H, bert_layers=2, bert_heads=8, bert_ffn=1024,
-                            compute_dtype="bf16", bert_hidden_dropout=0.0, bert_attention_dropout=0.0)
+    m = TransformerNetModel(E, E, 32, V, L, dropout=p, bert_hidden=H, bert_layers=2, bert_heads=8, bert_ffn=1024,
+                            compute_dtype="bf16", bert_hidden_dropout=p, bert_attention_dropout=p)
     m.train().requires_grad_(True).to(DEV)
     diff = SpacedDiffusion(use_timesteps=space_timesteps(2000, [2000]), betas=get_named_beta_schedule("sqrt", 2000),
                            rescale_timesteps=True, predict_xstart=True)
@@ -266,11 +268,13 @@ def test_micro_batch_accumulation_adds_the_separate_gradients_exactly():
     def grads():
         return {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None}
     parts = []
+    m._dropout_calls = 0                                    # (dropout masks are keyed by the forward call number: 1, 2 in both runs)
     with CpuDraws(21):                                      # the two halves on their own, drawing in the accumulated run's order
         for i in (0, 2):
             step = TrainStep(m, diff, microbatch=2, schedule_sampler=Fixed(ts[i:i + 2]), optimizer=NoOpt())
             step.forward_backward({k: v[i:i + 2] for k, v in cond.items()})
             parts.append(grads())
+    m._dropout_calls = 0
     with CpuDraws(21):
         step = TrainStep(m, diff, microbatch=2, schedule_sampler=Fixed(ts), optimizer=NoOpt())
         step.forward_backward(cond)
