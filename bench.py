@@ -154,7 +154,8 @@ def classify_launch(kernel, note, c, branches):
         return "gemm_big_kernel<%s, EPI=%d> bf16 %s [%d x %d x %d]" % (kv.get("tile", "?"), epi, role, M, N, K), "mfma", 2.0 * M * N * K, "flop"
     if "gemm_kernel<float" in kernel:
         M, N, K = int(kv["M"]), int(kv["N"]), int(kv["K"])
-        return "gemm_kernel<float> exact-fp32 MFMA, rounding scores [%d x %d x %d]" % (M, N, K), "mfma_f32", 2.0 * M * N * K, "flop"
+        role = "rounding scores" if N == c["V"] else "dense (fp32 parity mode)"
+        return "gemm_kernel<float> exact-fp32 MFMA, %s [%d x %d x %d]" % (role, M, N, K), "mfma_f32", 2.0 * M * N * K, "flop"
     if kernel == "kern" or "attn_" in kernel:
         bh, dh = int(kv.get("B*nh", 0)), int(kv.get("dh", 0))
         return "attn_stream_bf16_kernel<dh=%d> [B*nh=%d, L=%d]" % (dh, bh, L), "valu+mfma", 4.0 * L * dh * bh * L, "flop"
@@ -168,7 +169,7 @@ def classify_launch(kernel, note, c, branches):
     elif "step_epilogue" in kernel:
         b = N_tok * E * 4 * 5 + N_tok * 4        # model_out (or round idx + rows), x_t, noise, x_start in; sample + pred out; mask
     elif "trunc_normal" in kernel:
-        b = c["B"] * L * E * 4                   # (drawn once for the whole batch)
+        b = int(kv.get("n", c["B"] * L * E)) * 4   # (one draw for the whole batch, or one per decoupled batch slice)
     elif "row_sqnorm_f32" in kernel:
         b = N_tok * E * 4
     elif "argbest_reduce" in kernel:
@@ -495,6 +496,8 @@ def main():
     ap.add_argument("--spread", type=int, default=None, help="A/B: 1 = LDS-DMA pieces of the 256x128 GEMMs issued between the MFMA rows (mh_gemm_set_spread)")
     ap.add_argument("--defer-ln", type=int, default=None, help="A/B: deferred LayerNorm 0 never / 1 where no fused epilogue exists (default) / 2 always")
     ap.add_argument("--no-stream-attn", action="store_true", help="A/B: LDS-resident attention instead of the streaming kernel")
+    ap.add_argument("--no-decouple", action="store_true", help="A/B: one graph per step with a fork / join of the batch slices instead of one free-running graph per slice")
+    ap.add_argument("--skew-us", type=int, default=None, help="phase lag between the decoupled batch-slice chains in microseconds (default: half a step)")
     args = ap.parse_args()
     if args.steps is None:
         args.steps = {"train": 10}.get(args.workload, 200)
@@ -532,6 +535,10 @@ def main():
     diff.use_graph = not args.no_graph
     if args.split is not None:
         diff.batch_split = args.split
+    if args.no_decouple:
+        diff.decouple_branches = False
+    if args.skew_us is not None:
+        diff.branch_skew_us = args.skew_us
 
     batch = synthetic.generation_batch(c["B"], c["L"], seed=1 + rank)
     ids, mask = batch["input_ids"].to(device), batch["input_mask"].to(device)
@@ -558,6 +565,7 @@ def main():
             for k in range(args.warmup, total):
                 loop.advance(k)
         elapsed, _ = timed_region(timed, world, device)
+        loop.finish()
     tokens = model.argmax_tokens(loop.x)       # the loop's product: discrete tokens (run/sample.py:219-220)
     assert tokens.shape == (c["B"], c["L"]) and bool(torch.isfinite(loop.x).all())
     all_tokens = sharding.gather_rows(tokens, c["B"] * world)      # one token all-gather (run/sample.py:288-291)
@@ -578,6 +586,7 @@ def main():
                                    % (args.workload, c["L"], c["B"], c["H"], c["nL"], c["nh"], c["F"], c["E"], c["V"], c["T"]),
                        "global_batch": c["B"] * world, "seq_len": c["L"], "parallelism": "batch-sharded x%d" % world,
                        "rccl_ranks": world, "rng": args.rng, "hipgraph": not args.no_graph, "graph_branches": int(loop.nsplit),
+                       "decoupled_branches": bool(loop.decoupled), "branch_skew_us": int(getattr(loop, "skew_us", 0)),
                        "step_tflop": round(flops / 1e12, 4),
                        "step_tflops_achieved": round(flops / (ms_per_step * 1e-3) / 1e12, 2),
                        "sequences_steps_per_s": round(value * c["B"], 1)},
@@ -589,7 +598,7 @@ def main():
             sym = lambda r: r["kernel"].split(" [")[0]
             pools = {}
             for r in rows:
-                if r["bound"] == "mfma":
+                if r["bound"] in ("mfma", "mfma_f32") and r.get("work_per_launch"):
                     pools.setdefault(sym(r), []).append(r)
             dom = max(pools.values(), key=lambda rs: sum(r["share"] for r in rs))
             n_l = sum(r["launches_per_step"] for r in dom)

@@ -267,6 +267,12 @@ int mh_ddim_epilogue(const float* model_out, const float* x_t, const float* nois
  *      step_counter: device uint32 (may be NULL = 0); lets a captured graph advance the stream. */
 int mh_trunc_normal(float* out, int64_t n, float bound, uint64_t seed, uint32_t stream_id,
                     const uint32_t* step_counter, mh_stream_t stream);
+/*      the same for elements first .. first + n - 1 of the call (first % 4 == 0): a batch slice drawn on its own gets the values
+ *      the whole-batch call gives it */
+int mh_trunc_normal_at(float* out, int64_t n, int64_t first, float bound, uint64_t seed, uint32_t stream_id,
+                       const uint32_t* step_counter, mh_stream_t stream);
+/* one idle wave for about `microseconds` on `stream`: a phase lag between concurrently replayed graph branches */
+int mh_stream_delay(unsigned microseconds, mh_stream_t stream);
 
 /* ------------------------------------------------------------------ training path (forward + backward pieces)
  * training_losses (models/diffusion.py:594-699) under utils/train_util.py:188-232.  Every backward matrix
@@ -355,6 +361,10 @@ int mh_adamw_ema_step(const mh_opt_tensor* tensors, const mh_opt_chunk* chunks, 
 /* out[0] = sqrt(sum over all gradient elements of g^2); partial: [n_chunks] fp32 scratch */
 int mh_grad_norm(const mh_opt_tensor* tensors, const mh_opt_chunk* chunks, int n_chunks, float* partial, float* out,
                  mh_stream_t stream);
+/* torch.nn.utils.clip_grad_norm_ on the device (utils/train_util.py:255-264): every gradient *= min(1, max_norm / (norm[0] + 1e-6)),
+ * `norm` = the device scalar mh_grad_norm wrote; no host synchronisation */
+int mh_clip_grads(const mh_opt_tensor* tensors, const mh_opt_chunk* chunks, int n_chunks, const float* norm, float max_norm,
+                  mh_stream_t stream);
 
 /* ------------------------------------------------------------------ captured reverse step support */
 
@@ -585,6 +595,20 @@ int mh_gemm_qkv_vtperm_defer(const void* A, int64_t lda, const void* Wqkv, int64
 /* denoiser forward: 0 = never defer, 1 (default) = defer where the width has no full-row LayerNorm epilogue (d_model 768),
  * 2 = always (A/B) */
 int mh_denoiser_set_defer_ln(int mode);
+/* timing-only A/B knob (tools/ab_step.py skip): leave one kind of launch out of the bf16 panel forward (bit 0 QKV, 1 attention,
+ * 2 attention-output dense + LN, 3 FFN1, 4 FFN2 + LN, 5 up-projection chain, 6 down-projection); outputs are then meaningless */
+int mh_denoiser_set_skip(int mask);
+/* 1: the bf16 panel forward folds softmax scale x log2(e) into the stored queries and runs the pre-scaled attention (A/B; default 0) */
+int mh_denoiser_set_prescale_q(int on);
+/* mh_gemm_qkv_vtperm over K32-panel operands with the queries stored as (x Wq^T + bq) * q_scale (rounded once, from the fp32
+ * accumulator); `defer` (may be NULL) as in mh_gemm_qkv_vtperm_defer.  HF BertSelfAttention's projections (network.py:151) */
+int mh_gemm_qkv_vtperm_qs(const void* A, int64_t lda, const void* Wqkv, int64_t ldw, const float* bqkv, void* q, void* k, void* vt_perm,
+                          int B, int L, int H, int nh, float q_scale, const mh_ln_defer* defer, mh_stream_t stream);
+/* mh_attention_stream_fwd for queries that already carry softmax scale x log2(e) (q_scale above): the running softmax reference lives in
+ * the initial value of the score accumulators, so a probability is exp2(accumulator) - no multiply-subtract per score */
+int mh_attention_stream_prescaled_supported(int L, int dh);   /* mh_attention_stream_supported and seq_len % 256 == 0 */
+int mh_attention_stream_fwd_prescaled(const void* q, const void* k, const void* vt_perm, void* ctx, int64_t ld_ctx, int ctx_panel,
+                                      int B, int L, int nh, int dh, mh_stream_t stream);
 int mh_denoiser_get_defer_ln(void);
 
 /* ---------------------------------------------------------------- per-launch timing (measurement)

@@ -117,6 +117,8 @@ SIGNATURES = {
     "mh_p_sample_epilogue": (INT, [VP, VP, VP, VP, VP, VP, INT, INT, VP, INT, VP, VP, VP, VP, INT, I64, INT, VP]),
     "mh_ddim_epilogue": (INT, [VP, VP, VP, VP, VP, VP, INT, INT, VP, INT, VP, VP, VP, INT, I64, INT, VP]),
     "mh_trunc_normal": (INT, [VP, I64, F32, C.c_uint64, C.c_uint32, VP, VP]),
+    "mh_trunc_normal_at": (INT, [VP, I64, I64, F32, C.c_uint64, C.c_uint32, VP, VP]),
+    "mh_stream_delay": (C.c_int, [C.c_uint, VP]),
     "mh_transpose": (INT, [VP, I64, I64, VP, I64, I64, INT, INT, INT, INT, VP]),
     "mh_head_permute": (INT, [VP, VP, I64, INT, INT, INT, INT, INT, INT, VP]),
     "mh_col_sum": (INT, [VP, I64, I64, INT, INT, I64, VP, INT, VP, INT, INT, VP]),
@@ -147,6 +149,7 @@ SIGNATURES = {
     "mh_scale_rows": (INT, [VP, VP, VP, VP, INT, INT, I64, INT, VP]),
     "mh_adamw_ema_step": (INT, [VP, VP, INT, C.POINTER(OptHParams), VP]),
     "mh_grad_norm": (INT, [VP, VP, INT, VP, VP, VP]),
+    "mh_clip_grads": (INT, [VP, VP, INT, VP, F32, VP]),
     "mh_step_begin": (INT, [VP, VP, VP, VP, VP, INT, VP]),
     "mh_step_end": (INT, [VP, VP]),
     "mh_gemm_set_variant": (INT, [INT]),
@@ -181,6 +184,11 @@ SIGNATURES = {
     "mh_gemm_qkv_vtperm_defer": (INT, [VP, I64, VP, I64, VP, VP, VP, VP, INT, INT, INT, INT, C.POINTER(LnDefer), VP]),
     "mh_denoiser_set_defer_ln": (INT, [INT]),
     "mh_denoiser_get_defer_ln": (INT, []),
+    "mh_denoiser_set_skip": (INT, [INT]),
+    "mh_denoiser_set_prescale_q": (INT, [INT]),
+    "mh_gemm_qkv_vtperm_qs": (INT, [VP, I64, VP, I64, VP, VP, VP, VP, INT, INT, INT, INT, F32, C.POINTER(LnDefer), VP]),
+    "mh_attention_stream_prescaled_supported": (INT, [INT, INT]),
+    "mh_attention_stream_fwd_prescaled": (INT, [VP, VP, VP, VP, I64, INT, INT, INT, INT, INT, VP]),
     "mh_profile_start": (INT, []),
     "mh_profile_stop": (I64, [C.c_char_p, C.c_size_t]),
     "mh_denoiser_workspace_bytes": (C.c_size_t, [C.POINTER(Denoiser), INT, INT]),

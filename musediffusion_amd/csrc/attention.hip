@@ -19,6 +19,8 @@
 // workgroup, exact expf; this is the parity path, kept simple on purpose.
 #include <type_traits>
 
+#include <set>
+
 #include "common.h"
 
 namespace {
@@ -563,7 +565,11 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(const float* __restrict__
 // KVNT: the K / V stage DMA with the nt cache policy (aux 2) - chosen when a (batch, head)'s keys and values are streamed by ONE
 // block and never again (seq_len <= the block's queries): same-box A/B of two builds -1.2 % step time at config 2; with two query
 // blocks per (batch, head) (seq_len 1024) the second reader misses them: +0.4 % on the training step, so the default policy there
-template <int DH, int NW = 16, int SK = 256, int DROP = 0, bool FULL = false, bool KVNT = false>
+// PRE: the queries arrive pre-multiplied by scale x log2(e) (the QKV epilogue folds it in, mh_gemm_qkv_vtperm_qs), so the S^T
+// accumulators are already in the log2 domain, and the running reference lives in their INITIAL value: the first MFMA of every S^T
+// chain takes C = -reference (16 registers that change only when the reference moves), so a probability is exp2(accumulator) with
+// no multiply-subtract per score - 32 of the ~170 vector instructions of a 64-key tile (the kernel is VALU-bound)
+template <int DH, int NW = 16, int SK = 256, int DROP = 0, bool FULL = false, bool KVNT = false, bool PRE = false>
 __global__ __launch_bounds__(64 * NW) void attn_stream_bf16_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K,
                                                                 const bf16* __restrict__ VT, bf16* __restrict__ ctx,
                                                                 int64_t ld_ctx, int L, int nh, int nbh, float scale_log2e,
@@ -620,6 +626,10 @@ __global__ __launch_bounds__(64 * NW) void attn_stream_bf16_kernel(const bf16* _
   bf16x8 qf[KS];
   f32x16 o[DT];
   float m_run = -INFINITY, l_run = 0.f;
+  f32x16 sinit;              // PRE: -reference (log2 domain) in every register
+  bool first_tile = false;   // PRE: no reference yet (wave-uniform)
+#pragma unroll
+  for (int r = 0; r < 16; ++r) sinit[r] = 0.f;
   int q0 = 0;
   bool active = false;
 
@@ -644,11 +654,97 @@ __global__ __launch_bounds__(64 * NW) void attn_stream_bf16_kernel(const bf16* _
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
       m_run = -INFINITY; l_run = 0.f;
+      if constexpr (PRE) {
+        m_run = 0.f; first_tile = true;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sinit[r] = 0.f;
+      }
     }
     if (active) {
       const char* kbuf = smem_dyn + (g & 1) * (2 * KST);
       const char* vbuf = kbuf + KST;
       const int st_keys = L - st * SK;                                  // valid keys of this stage (>= 16)
+      if constexpr (PRE) {
+        // pre-scaled queries: 32-key sub-tiles, one S^T accumulator set live at a time (the 16 registers that freed hold the initial
+        // accumulator = -reference).  The accumulators come out as score - reference in the log2 domain, so p = exp2(accumulator).
+        for (int t2 = 0; t2 < SK / 32 && (FULL || t2 * 32 < st_keys); ++t2) {
+          const int t = t2 >> 1, kt = t2 & 1;
+          const char* kb = kbuf + t * (64 * KROWB);
+          const char* vb = vbuf + t * VT_BYTES;
+          const int sub_keys = FULL ? 32 : st_keys - t2 * 32;             // < 32 only in the sequence's last sub-tile
+          f32x16 sa;
+          {
+            bf16x8 kf[KS];
+            const int krow = 32 * kt + lq, ksw = kt ? ksw1 : ksw0;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) kf[ks] = *reinterpret_cast<const bf16x8*>(kb + krow * KROWB + (((2 * ks + h) ^ ksw) << 4));
+            // the chain's first MFMA reads its C operand from the initial-accumulator registers and writes the accumulator itself
+            // (D != C): as a builtin hipcc copies the 16 registers first, which costs what the multiply-subtract did
+            asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(sa) : "v"(kf[0]), "v"(qf[0]), "v"(sinit));
+#pragma unroll
+            for (int ks = 1; ks < KS; ++ks) sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[ks], sa, 0, 0, 0);
+          }
+          if (!FULL && sub_keys < 32) {   // register r holds key (r & 3) + 8 (r >> 2) + 4 h of the sub-tile: mask the ones past the end
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+              if ((r & 3) + 8 * (r >> 2) + 4 * h >= sub_keys) sa[r] = -INFINITY;
+          }
+          // the row maximum of the 16 scores as ONE asm statement of v_max3 (fmaxf on MFMA outputs makes hipcc canonicalise every
+          // input with a v_max first: 16 more instructions).  hipcc pads no hazard whose consumer sits inside an asm string: the
+          // 12 wait states an 8-pass MFMA result needs before a VALU read open the string (cdna_hip_programming.md 5.7 item 2)
+          float mx, mt1, mt2, mt3, mt4;
+          asm volatile("s_nop 11\n\t"
+                       "v_max3_f32 %0, %5, %6, %7\n\t"
+                       "v_max3_f32 %1, %8, %9, %10\n\t"
+                       "v_max3_f32 %2, %11, %12, %13\n\t"
+                       "v_max3_f32 %3, %14, %15, %16\n\t"
+                       "v_max3_f32 %4, %17, %18, %19\n\t"
+                       "v_max3_f32 %0, %0, %1, %2\n\t"
+                       "v_max3_f32 %1, %3, %4, %20\n\t"
+                       "v_max_f32 %0, %0, %1"
+                       : "=&v"(mx), "=&v"(mt1), "=&v"(mt2), "=&v"(mt3), "=&v"(mt4)
+                       : "v"(sa[0]), "v"(sa[1]), "v"(sa[2]), "v"(sa[3]), "v"(sa[4]), "v"(sa[5]), "v"(sa[6]), "v"(sa[7]), "v"(sa[8]), "v"(sa[9]),
+                         "v"(sa[10]), "v"(sa[11]), "v"(sa[12]), "v"(sa[13]), "v"(sa[14]), "v"(sa[15]));
+          mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+          // the reference moves by `shift` when a row overshoots it by more than 2^8 (or on the item's first sub-tile, where it
+          // becomes the sub-tile maximum): this sub-tile's accumulators, the running sum and the output are re-based
+          if (first_tile || __builtin_amdgcn_ballot_w64(mx > 8.0f) != 0) {
+            const float shift = first_tile ? mx : fmaxf(mx, 0.f);
+            if (!first_tile) {
+              const float alpha = __builtin_amdgcn_exp2f(-shift);
+              l_run *= alpha;
+#pragma unroll
+              for (int i = 0; i < DT; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+            }
+            m_run += shift;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sa[r] -= shift;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sinit[r] = -m_run;
+            first_tile = false;
+          }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) sa[r] = __builtin_amdgcn_exp2f(sa[r]);
+          float ps4[4] = {sa[0], sa[1], sa[2], sa[3]};
+#pragma unroll
+          for (int r = 4; r < 16; ++r) ps4[r & 3] += sa[r];
+          l_run += (ps4[0] + ps4[1]) + (ps4[2] + ps4[3]);
+#pragma unroll
+          for (int s2 = 0; s2 < 2; ++s2) {
+            bf16x8 pf;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pf[j] = (bf16)sa[8 * s2 + j];
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+              const int d = dt * 32 + lq;
+              const bf16x8 vf = *reinterpret_cast<const bf16x8*>(vb + d * 128 + (((2 * (2 * kt + s2) + h) ^ ((d >> 1) & 7)) << 4));
+              o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[dt], 0, 0, 0);
+            }
+          }
+        }
+      } else
       for (int t = 0; t < SK / 64 && (FULL || t * 64 < st_keys); ++t) {
         const char* kb = kbuf + t * (64 * KROWB);
         const char* vb = vbuf + t * VT_BYTES;
@@ -747,7 +843,7 @@ __global__ __launch_bounds__(64 * NW) void attn_stream_bf16_kernel(const bf16* _
           const int b = bh / nh, head = bh % nh;
           const int64_t tok = (int64_t)b * L + qr;
           // log2-domain log-sum-exp of the scaled scores: P[q][k] = exp2(s c - lse2[q]) (what the backward kernels re-create P from)
-          if (lse2 && h == 0) lse2[(int64_t)bh * L + qr] = m_run * scale_log2e + __builtin_amdgcn_logf(l_tot);
+          if (lse2 && h == 0) lse2[(int64_t)bh * L + qr] = (PRE ? m_run : m_run * scale_log2e) + __builtin_amdgcn_logf(l_tot);
 #pragma unroll
           for (int dt = 0; dt < DT; ++dt) {
             bf16* dst = ctx_panel ? ctx + (((int64_t)(head * DT + dt)) * ld_ctx + tok) * 32 : ctx + tok * ld_ctx + head * DH + dt * 32;
@@ -857,14 +953,34 @@ extern "C" int mh_attention_stream_fwd_ex(const void* q, const void* k, const vo
 
 // The streaming forward with attention-probability dropout: drop->p > 0 needs `keep_bits` (mh_dropout_bits_words(B nh, L) words):
 // written by the kernel (bits_in = 0: Philox, the same bits mh_dropout_bits produces) or read from it (bits_in = 1).
+namespace {
+int stream_fwd_impl(const void* q, const void* k, const void* vt_perm, void* ctx, int64_t ld_ctx, int ctx_panel, int B, int L, int nh, int dh,
+                    float scale, float* lse2, int64_t qsB, int64_t qsH, int64_t qld, const mh_dropout* drop, uint32_t* keep_bits, int bits_in,
+                    bool pre, mh_stream_t stream);
+}
+// the pre-scaled form is built for whole 256-key stages only (the key-bound variant of it spills)
+extern "C" int mh_attention_stream_prescaled_supported(int L, int dh) { return mh_attention_stream_supported(L, dh) && L % 256 == 0; }
 extern "C" int mh_attention_stream_fwd_drop(const void* q, const void* k, const void* vt_perm, void* ctx, int64_t ld_ctx, int ctx_panel,
                                             int B, int L, int nh, int dh, float scale, float* lse2, int64_t qsB, int64_t qsH,
                                             int64_t qld, const mh_dropout* drop, uint32_t* keep_bits, int bits_in, mh_stream_t stream) {
+  return stream_fwd_impl(q, k, vt_perm, ctx, ld_ctx, ctx_panel, B, L, nh, dh, scale, lse2, qsB, qsH, qld, drop, keep_bits, bits_in, false, stream);
+}
+// The same forward for queries that carry scale x log2(e) already (mh_gemm_qkv_vtperm_qs): q [B, nh, L, dh]; no dropout
+extern "C" int mh_attention_stream_fwd_prescaled(const void* q, const void* k, const void* vt_perm, void* ctx, int64_t ld_ctx, int ctx_panel,
+                                                 int B, int L, int nh, int dh, mh_stream_t stream) {
+  return stream_fwd_impl(q, k, vt_perm, ctx, ld_ctx, ctx_panel, B, L, nh, dh, 1.0f, nullptr, (int64_t)nh * L * dh, (int64_t)L * dh, dh, nullptr,
+                         nullptr, 0, true, stream);
+}
+namespace {
+int stream_fwd_impl(const void* q, const void* k, const void* vt_perm, void* ctx, int64_t ld_ctx, int ctx_panel, int B, int L, int nh, int dh,
+                    float scale, float* lse2, int64_t qsB, int64_t qsH, int64_t qld, const mh_dropout* drop, uint32_t* keep_bits, int bits_in,
+                    bool pre, mh_stream_t stream) {
   DropArgs da;
   int rcd = mh_drop_args(drop, &da);
   if (rcd) return rcd;
   const bool dropping = da.thr != 0;
   MH_CHECK_ARG(!dropping || keep_bits, "attention_stream: dropout needs the keep_bits tensor");
+  MH_CHECK_ARG(!(pre && dropping), "attention_stream: the pre-scaled form has no dropout variant");
   MH_CHECK_ARG(qld % 8 == 0 && qsH % 8 == 0 && qsB % 8 == 0 && qld >= dh, "attention_stream: q/k strides must be multiples of 8 elements");
   MH_CHECK_ARG(q && k && vt_perm && ctx, "attention_stream: null pointer");
   MH_CHECK_ARG(B > 0 && nh > 0 && mh_attention_stream_supported(L, dh),
@@ -880,16 +996,15 @@ extern "C" int mh_attention_stream_fwd_drop(const void* q, const void* k, const 
   // registers more than the 128 a 16-wave block leaves each wave (the 16-wave build spilled 82 dwords per lane: 3.5x slower)
   // the in-kernel generator runs on the 8-wave geometry (its Philox state does not fit the 128 registers of a 16-wave block without
   // spilling 25 dwords per lane; mode 3 = A/B: generator on 16 waves); the bit reader fits 16 waves
-  const bool small = g_attn_stream == 2 || (dropping && !bits_in && g_attn_stream != 3);
+  const bool small = !pre && (g_attn_stream == 2 || (dropping && !bits_in && g_attn_stream != 3));
   const int qper = small ? 256 : 512, nitems = nbh * ((L + qper - 1) / qper);
   const int slots = small ? 2 * cus : cus;
   const dim3 grid((unsigned)(nitems < slots ? nitems : slots)), block(small ? 512 : 1024);
   auto go = [&](auto kern, int bytes) -> int {
-    static bool attr_set = false;
-    if (!attr_set) {
+    // all instantiations share one function-pointer type, so this lambda body exists once: the attribute is tracked per kernel
+    static std::set<const void*> attr_done;
+    if (attr_done.insert(reinterpret_cast<const void*>(kern)).second)
       MH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-      attr_set = true;
-    }
     mh_prof_note("attn_stream B*nh=%d L=%d dh=%d drop=%d", nbh, L, dh, (int)dropping);
     MH_LAUNCH(kern, grid, block, bytes, s, Q, K, V, (bf16*)ctx, ld_ctx, L, nh, nbh, sl2, ctx_panel, lse2, qsB, qsH, qld, da, keep_bits, bits_in);
     return MH_OK;
@@ -900,6 +1015,12 @@ extern "C" int mh_attention_stream_fwd_drop(const void* q, const void* k, const 
     rc = dh == 64 ? go(&attn_stream_bf16_kernel<64, 16, 256, 2>, 4 * 256 * 64 * 2) : go(&attn_stream_bf16_kernel<32, 16, 256, 2>, 4 * 256 * 32 * 2);
   } else if (dropping && !small) rc = dh == 64 ? go(&attn_stream_bf16_kernel<64, 16, 256, 1>, 4 * 256 * 64 * 2) : go(&attn_stream_bf16_kernel<32, 16, 256, 1>, 4 * 256 * 32 * 2);
   else if (dropping) rc = dh == 64 ? go(&attn_stream_bf16_kernel<64, 8, 128, 1>, 4 * 128 * 64 * 2) : go(&attn_stream_bf16_kernel<32, 8, 256, 1>, 4 * 256 * 32 * 2);
+  else if (pre) {
+    // pre-scaled queries (the sampler's forward): 16 waves, the same FULL / KVNT choices as below
+    MH_CHECK_ARG(mh_attention_stream_prescaled_supported(L, dh), "attention_stream(pre-scaled): seq_len %d must be a multiple of 256", L);
+    if (L <= 512) rc = dh == 64 ? go(&attn_stream_bf16_kernel<64, 16, 256, 0, true, true, true>, 4 * 256 * 64 * 2) : go(&attn_stream_bf16_kernel<32, 16, 256, 0, true, true, true>, 4 * 256 * 32 * 2);
+    else rc = dh == 64 ? go(&attn_stream_bf16_kernel<64, 16, 256, 0, true, false, true>, 4 * 256 * 64 * 2) : go(&attn_stream_bf16_kernel<32, 16, 256, 0, true, false, true>, 4 * 256 * 32 * 2);
+  }
   else if (full && !small && L <= qper)   // one block streams a (batch, head)'s K / V once: nt policy
     rc = dh == 64 ? go(&attn_stream_bf16_kernel<64, 16, 256, 0, true, true>, 4 * 256 * 64 * 2) : go(&attn_stream_bf16_kernel<32, 16, 256, 0, true, true>, 4 * 256 * 32 * 2);
   else if (full && dh == 64) rc = small ? go(&attn_stream_bf16_kernel<64, 8, 128, 0, true>, 4 * 128 * 64 * 2) : go(&attn_stream_bf16_kernel<64, 16, 256, 0, true>, 4 * 256 * 64 * 2);
@@ -910,6 +1031,7 @@ extern "C" int mh_attention_stream_fwd_drop(const void* q, const void* k, const 
   MH_CHECK_LAUNCH();
   return MH_OK;
 }
+}  // namespace
 
 extern "C" int mh_attention_set_profile(void* stamps) {
   g_attn_prof = reinterpret_cast<unsigned long long*>(stamps);

@@ -159,27 +159,40 @@ __global__ void step_epilogue_kernel(const float* __restrict__ model_out, const 
 // ---------------------------------------------------------------- Philox4x32-10 truncated normal
 __device__ __forceinline__ float u01(uint32_t r) { return ((float)(r >> 8) + 0.5f) * (1.0f / 16777216.0f); }
 
-__global__ void trunc_normal_kernel(float* __restrict__ out, int64_t n, float bound, uint32_t seed_lo,
-                                    uint32_t seed_hi, uint32_t stream_id, const uint32_t* __restrict__ step_counter) {
+// One thread owns the 4 consecutive elements of a group; Philox call (group, step, stream, attempt) yields four Box-Muller
+// normals, candidate k going to element k of the group if that element has not accepted one yet (rejection against the bound,
+// resolved in registers: no host sync, diffusion.py:378-388).  Elements are numbered GLOBALLY (first + local index), so a batch
+// slice drawn on its own (the decoupled graph branches of _ReverseLoop) gets exactly the values the whole-batch launch gives it.
+// Hardware transcendentals (v_log / v_sqrt / v_sin / v_cos: sin and cos take revolutions, so 2 pi u needs no range reduction).
+__global__ __launch_bounds__(256) void trunc_normal_kernel(float* __restrict__ out, int64_t n, int64_t first, float bound, uint32_t seed_lo,
+                                                          uint32_t seed_hi, uint32_t stream_id, const uint32_t* __restrict__ step_counter) {
   const uint32_t step = step_counter ? *step_counter : 0u;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    float z = 0.f;
-    bool done = false;
-    for (uint32_t attempt = 0; attempt < 64 && !done; ++attempt) {
-      uint32_t c[4] = {(uint32_t)i, (uint32_t)(i >> 32), step, (stream_id << 8) | attempt};
+  const int64_t ngroups = (n + 3) >> 2;
+  for (int64_t gi = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; gi < ngroups; gi += (int64_t)gridDim.x * blockDim.x) {
+    const uint64_t g = (uint64_t)((first >> 2) + gi);
+    float z[4] = {0.f, 0.f, 0.f, 0.f};
+    uint32_t pending = 0xfu;
+    for (uint32_t attempt = 0; attempt < 64 && pending; ++attempt) {
+      uint32_t c[4] = {(uint32_t)g, (uint32_t)(g >> 32), step, (stream_id << 8) | attempt};
       mh_philox<10>(c, seed_lo, seed_hi);
-      const float r0 = sqrtf(-2.0f * logf(u01(c[0]))), r1 = sqrtf(-2.0f * logf(u01(c[2])));
-      const float a0 = 6.283185307179586f * u01(c[1]), a1 = 6.283185307179586f * u01(c[3]);
-      const float cand[4] = {r0 * cosf(a0), r0 * sinf(a0), r1 * cosf(a1), r1 * sinf(a1)};
+      // sqrt(-2 ln u) = sqrt(-2 ln 2 log2 u)
+      const float r0 = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u01(c[0])));
+      const float r1 = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u01(c[2])));
+      const float a0 = u01(c[1]), a1 = u01(c[3]);
+      const float cand[4] = {r0 * __builtin_amdgcn_cosf(a0), r0 * __builtin_amdgcn_sinf(a0), r1 * __builtin_amdgcn_cosf(a1),
+                             r1 * __builtin_amdgcn_sinf(a1)};
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        if (!done && (bound <= 0.f || fabsf(cand[k]) <= bound)) {
-          z = cand[k];
-          done = true;
+        if (((pending >> k) & 1u) && (bound <= 0.f || fabsf(cand[k]) <= bound)) {
+          z[k] = cand[k];
+          pending &= ~(1u << k);
         }
       }
     }
-    out[i] = z;  // 64 x 4 rejected candidates has probability < 1e-100 for bound >= 0.1
+    // 64 rejected candidates in a row has probability < 1e-30 for bound >= 0.1
+    const int64_t i = gi << 2;
+    if (i + 4 <= n) *reinterpret_cast<f32x4*>(out + i) = f32x4{z[0], z[1], z[2], z[3]};
+    else for (int k = 0; k < 4 && i + k < n; ++k) out[i + k] = z[k];
   }
 }
 
@@ -322,13 +335,34 @@ extern "C" int mh_ddim_epilogue(const float* model_out, const float* x_t, const 
   return MH_OK;
 }
 
-extern "C" int mh_trunc_normal(float* out, int64_t n, float bound, uint64_t seed, uint32_t stream_id,
-                               const uint32_t* step_counter, mh_stream_t stream) {
-  MH_CHECK_ARG(out && n >= 0, "trunc_normal: bad arguments");
+extern "C" int mh_trunc_normal_at(float* out, int64_t n, int64_t first, float bound, uint64_t seed, uint32_t stream_id,
+                                  const uint32_t* step_counter, mh_stream_t stream) {
+  MH_CHECK_ARG(out && n >= 0 && first >= 0 && first % 4 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0,
+               "trunc_normal: bad arguments (the first element index must be a multiple of 4, the output 16-byte aligned)");
   MH_CHECK_ARG(bound <= 0.f || bound >= 0.1f, "trunc_normal: bound %g too tight for rejection sampling", (double)bound);
   if (n == 0) return MH_OK;
-  MH_LAUNCH(trunc_normal_kernel, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, (hipStream_t)stream, out, n, bound,
+  mh_prof_note("n=%lld first=%lld", (long long)n, (long long)first);
+  MH_LAUNCH(trunc_normal_kernel, dim3(ew_grid((n + 3) / 4)), dim3(EW_BLOCK), 0, (hipStream_t)stream, out, n, first, bound,
                      (uint32_t)seed, (uint32_t)(seed >> 32), stream_id, step_counter);
+  MH_CHECK_LAUNCH();
+  return MH_OK;
+}
+extern "C" int mh_trunc_normal(float* out, int64_t n, float bound, uint64_t seed, uint32_t stream_id,
+                               const uint32_t* step_counter, mh_stream_t stream) {
+  return mh_trunc_normal_at(out, n, 0, bound, seed, stream_id, step_counter, stream);
+}
+
+namespace {
+// idles one wave for about `us` microseconds (s_memrealtime ticks at 100 MHz): puts a phase lag between concurrent streams
+__global__ void spin_kernel(unsigned us) {
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime(), d = 100ull * us;
+  while (__builtin_amdgcn_s_memrealtime() - t0 < d) __builtin_amdgcn_s_sleep(32);
+}
+}  // namespace
+extern "C" int mh_stream_delay(unsigned microseconds, mh_stream_t stream) {
+  MH_CHECK_ARG(microseconds <= 100000u, "stream_delay: at most 100 ms");
+  if (microseconds == 0) return MH_OK;
+  MH_LAUNCH(spin_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, microseconds);
   MH_CHECK_LAUNCH();
   return MH_OK;
 }

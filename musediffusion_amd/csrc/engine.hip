@@ -77,7 +77,23 @@ extern "C" int64_t mh_profile_stop(char* out, size_t cap) {
   return (int64_t)rep.size() + 1;
 }
 
-namespace { int g_fuse_ln = 1; int g_defer_ln = 1; }
+namespace { int g_fuse_ln = 1; int g_defer_ln = 1; int g_skip = 0; int g_prescale_q = 0; }
+// 1: the bf16 panel forward stores the queries multiplied by softmax scale x log2(e) (QKV epilogue) and runs the streaming attention
+// on them without a per-score multiply-subtract (mh_attention_stream_fwd_prescaled: a quarter fewer vector instructions per tile).
+// Measured (round 3): 3.782 vs 3.785 ms per step at config 2, 7.329 vs 7.339 at c2-bertbase, 29.3 vs 29.5 us per half-batch launch
+// alone, 18.6 vs 19.4 us for ONE (batch, head) alone on the chip - the kernel is not bound by its vector-instruction count.
+// Default 0 (the queries keep the reference's scaling and one rounding less)
+extern "C" int mh_denoiser_set_prescale_q(int on) {
+  g_prescale_q = on != 0;
+  return MH_OK;
+}
+// timing-only A/B (tools/ab_step.py skip): leave launches of one kind out of the bf16 panel forward to read their marginal cost inside
+// the captured step (outputs are then garbage).  bit 0 QKV, 1 attention, 2 attention-output dense + LN, 3 FFN1, 4 FFN2 + LN,
+// 5 up-projection chain (pack, two GEMMs, embedding LayerNorm), 6 down-projection
+extern "C" int mh_denoiser_set_skip(int mask) {
+  g_skip = mask;
+  return MH_OK;
+}
 extern "C" int mh_denoiser_get_defer_ln(void) { return g_defer_ln; }
 // 0 = never, 1 (default) = where no full-row LayerNorm epilogue exists for the width (d_model 768), 2 = always (A/B)
 extern "C" int mh_denoiser_set_defer_ln(int mode) {
@@ -233,7 +249,14 @@ extern "C" int mh_denoiser_forward(const mh_denoiser* m, const float* x, const f
     };
     const bool fuse_ln = g_fuse_ln && mh_gemm_bias_res_ln_supported(H);
     const bool stream_attn = mh_attention_stream_enabled() && mh_attention_stream_supported(L, dh) && H % 64 == 0;
-    if (m->has_proj) {
+    const bool pre_q = stream_attn && g_prescale_q && mh_attention_stream_prescaled_supported(L, dh);
+    const float q_scale = scale * 1.4426950408889634f;
+    auto attention = [&]() {
+      return pre_q ? mh_attention_stream_fwd_prescaled(w.q, w.k, w.vt, w.buf0, N, P, B, L, m->nh, dh, stream)
+                   : mh_attention_stream_fwd(w.q, w.k, w.vt, w.buf0, N, P, B, L, m->nh, dh, scale, stream);
+    };
+    if (m->has_proj && (g_skip & 32)) {
+    } else if (m->has_proj) {
       if ((rc = mh_pack_panel(x, m->E, w.xin, N, N, m->E, m->E_pad, stream))) return rc;
       if ((rc = gemm(w.xin, m->w_up0, H, m->b_up0, nullptr, w.buf0, 0, N, H, m->E_pad, MH_ACT_TANH))) return rc;
       if ((rc = gemm(w.buf0, m->w_up2, H, m->b_up2, nullptr, w.buf1, 0, N, H, H, MH_ACT_NONE))) return rc;
@@ -264,11 +287,14 @@ extern "C" int mh_denoiser_forward(const mh_denoiser* m, const float* x, const f
         d.h_norm = H; d.eps = m->ln_eps;
         if (prev_raw) {
           d.a_stats = w.stats2; d.a_slots = S; d.c1 = lw.c1_qkv;
-          if ((rc = mh_gemm_qkv_vtperm_defer(w.bufX, N, lw.w_qkv_f, 3 * H, lw.c2_qkv, w.q, w.k, w.vt, B, L, H, m->nh, &d, stream))) return rc;
+          if (pre_q) rc = mh_gemm_qkv_vtperm_qs(w.bufX, N, lw.w_qkv_f, 3 * H, lw.c2_qkv, w.q, w.k, w.vt, B, L, H, m->nh, q_scale, &d, stream);
+          else rc = mh_gemm_qkv_vtperm_defer(w.bufX, N, lw.w_qkv_f, 3 * H, lw.c2_qkv, w.q, w.k, w.vt, B, L, H, m->nh, &d, stream);
         } else {
-          if ((rc = mh_gemm_qkv_vtperm(w.bufX, N, P, lw.w_qkv, 3 * H, P, lw.b_qkv, w.q, w.k, w.vt, B, L, H, m->nh, stream))) return rc;
+          if (pre_q) rc = mh_gemm_qkv_vtperm_qs(w.bufX, N, lw.w_qkv, 3 * H, lw.b_qkv, w.q, w.k, w.vt, B, L, H, m->nh, q_scale, nullptr, stream);
+          else rc = mh_gemm_qkv_vtperm(w.bufX, N, P, lw.w_qkv, 3 * H, P, lw.b_qkv, w.q, w.k, w.vt, B, L, H, m->nh, stream);
         }
-        if ((rc = mh_attention_stream_fwd(w.q, w.k, w.vt, w.buf0, N, P, B, L, m->nh, dh, scale, stream))) return rc;
+        if (rc) return rc;
+        if ((rc = attention())) return rc;
         // y1 = ctx W_ao^T + b_ao + X  (raw) -> bufX1, statistics -> stats1
         d = mh_ln_defer{};
         d.h_norm = H; d.eps = m->ln_eps;
@@ -296,20 +322,26 @@ extern "C" int mh_denoiser_forward(const mh_denoiser* m, const float* x, const f
     for (int l = 0; l < m->nL && !defer; ++l) {
       const mh_layer_weights& lw = m->layers[l];
       if (stream_attn) {   // V^T written in the streaming kernel's key order: its stages are straight LDS-DMA copies
-        if ((rc = mh_gemm_qkv_vtperm(w.bufX, N, P, lw.w_qkv, 3 * H, P, lw.b_qkv, w.q, w.k, w.vt, B, L, H, m->nh, stream))) return rc;
-        if ((rc = mh_attention_stream_fwd(w.q, w.k, w.vt, w.buf0, N, P, B, L, m->nh, dh, scale, stream))) return rc;
+        if (!(g_skip & 1)) {
+          if (pre_q) rc = mh_gemm_qkv_vtperm_qs(w.bufX, N, lw.w_qkv, 3 * H, lw.b_qkv, w.q, w.k, w.vt, B, L, H, m->nh, q_scale, nullptr, stream);
+          else rc = mh_gemm_qkv_vtperm(w.bufX, N, P, lw.w_qkv, 3 * H, P, lw.b_qkv, w.q, w.k, w.vt, B, L, H, m->nh, stream);
+          if (rc) return rc;
+        }
+        if (!(g_skip & 2) && (rc = attention())) return rc;
       } else {
         if ((rc = mh_gemm_qkv_ex(w.bufX, N, P, lw.w_qkv, 3 * H, P, lw.b_qkv, w.q, w.k, w.vt, B, L, H, m->nh, dt, stream))) return rc;
         if ((rc = mh_attention_fwd_ex(w.q, w.k, w.vt, w.buf0, N, P, B, L, m->nh, dh, scale, dt, stream))) return rc;
       }
-      if (fuse_ln) {   // dense + residual + LayerNorm in one kernel: the block owns complete rows
+      if (g_skip & 4) {
+      } else if (fuse_ln) {   // dense + residual + LayerNorm in one kernel: the block owns complete rows
         if ((rc = gemm_ln(w.buf0, lw.w_ao, lw.b_ao, w.bufX, lw.ln1_g, lw.ln1_b, w.bufX1, H))) return rc;
       } else {
         if ((rc = gemm(w.buf0, lw.w_ao, H, lw.b_ao, w.bufX, w.buf1, 0, N, H, H, MH_ACT_NONE))) return rc;
         if ((rc = mh_layernorm_panel(w.buf1, N, lw.ln1_g, lw.ln1_b, w.bufX1, N, N, H, m->ln_eps, stream))) return rc;
       }
-      if ((rc = gemm(w.bufX1, lw.w_ff1, F, lw.b_ff1, nullptr, w.ffn, 0, N, F, H, MH_ACT_GELU_ERF))) return rc;
-      if (fuse_ln) {
+      if (!(g_skip & 8) && (rc = gemm(w.bufX1, lw.w_ff1, F, lw.b_ff1, nullptr, w.ffn, 0, N, F, H, MH_ACT_GELU_ERF))) return rc;
+      if (g_skip & 16) {
+      } else if (fuse_ln) {
         if ((rc = gemm_ln(w.ffn, lw.w_ff2, lw.b_ff2, w.bufX1, lw.ln2_g, lw.ln2_b, w.bufX, F))) return rc;
       } else {
         if ((rc = gemm(w.ffn, lw.w_ff2, H, lw.b_ff2, w.bufX1, w.buf1, 0, N, H, F, MH_ACT_NONE))) return rc;
@@ -317,6 +349,7 @@ extern "C" int mh_denoiser_forward(const mh_denoiser* m, const float* x, const f
       }
     }
     if (m->has_proj) {
+      if (g_skip & 64) return MH_OK;
       if ((rc = gemm(w.bufX, m->w_dn0, H, m->b_dn0, nullptr, w.buf0, 0, N, H, H, MH_ACT_TANH))) return rc;
       return gemm(w.buf0, m->w_dn2, m->E, m->b_dn2, nullptr, out, 1, m->E, m->E, H, MH_ACT_NONE);
     }

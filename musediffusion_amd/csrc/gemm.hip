@@ -60,6 +60,7 @@ struct GemmArgs {
   int dbg;  // timing-only ablation bits (mh_gemm_set_debug): 1 no DMA, 2 no MFMA, 4 no stores
   int ntiles;    // persistent big-tile launch: ntiles output tiles walked by gridDim.x blocks
   int vt_perm;   // QKV scatter: V^T keys in the P-operand order of mh_attention_stream_fwd (middle groups of 4 swapped per 16)
+  float q_scale; // QKV scatter (big tile): the query columns are stored multiplied by this (0 = unscaled): softmax scale x log2(e) for mh_attention_stream_fwd_prescaled
   int stagger;   // experiment: blocks of the second half of the grid (the co-resident partners) start this many 10-ns ticks late
   DeferArgs d;   // DBG bit 128 kernels only
   DropArgs drop; // EPI 0: train-mode dropout of (A W^T + bias) before the residual is added (thr == 0: off)
@@ -855,6 +856,7 @@ __global__ __launch_bounds__(C::THREADS, C::STAGE * C::NST <= 80 * 1024 ? 2 : 1)
         float bv[TJ / 2][8];          // every bias load before the first store: a load behind a store would wait for it
         float c1v[TJ / 2][8];
         float mu[TI], rsd[TI];
+        const bool scale_q = which == 0 && g.q_scale != 0.f;   // (wave-uniform)
 #pragma unroll
         for (int qh = 0; qh < TJ / 2; ++qh) {
           const int col = wcol0 + 32 * qh + 8 * fg;
@@ -884,6 +886,10 @@ __global__ __launch_bounds__(C::THREADS, C::STAGE * C::NST <= 80 * 1024 ? 2 : 1)
                 for (int e = 0; e < 8; ++e) {
                   if constexpr (DA) v[e] = fmaf(rsd[i], fmaf(-mu[i], c1v[qh][e], acc[i][2 * qh + (e >> 2)][e & 3]), bv[qh][e]);
                   else v[e] = acc[i][2 * qh + (e >> 2)][e & 3] + bv[qh][e];
+                }
+                if (scale_q) {
+#pragma unroll
+                  for (int e = 0; e < 8; ++e) v[e] *= g.q_scale;
                 }
                 if constexpr ((DBG & 32) != 0) store8(dst + ((int64_t)b * g.nh * g.L + l) * g.dh + coloff, v);
                 else store8_nt(dst + ((int64_t)b * g.nh * g.L + l) * g.dh + coloff, v);
@@ -1523,7 +1529,7 @@ extern "C" int mh_gemm_qkv(const void* A, int64_t lda, const void* Wqkv, int64_t
 
 namespace { int qkv_impl(const void* A, int64_t lda, int a_panel, const void* Wqkv, int64_t ldw, int w_panel, const float* bqkv,
                          void* q, void* k, void* vt, int B, int L, int H, int nh, int dtype, int vt_perm, mh_stream_t stream,
-                         const mh_ln_defer* defer = nullptr); }
+                         const mh_ln_defer* defer = nullptr, float q_scale = 0.f); }
 
 // mh_gemm_qkv_vtperm (panel operands) whose A rows are raw pre-LayerNorm values (defer->a_stats / c1; bqkv = c2)
 extern "C" int mh_gemm_qkv_vtperm_defer(const void* A, int64_t lda, const void* Wqkv, int64_t ldw, const float* c2, void* q, void* k,
@@ -1546,11 +1552,20 @@ extern "C" int mh_gemm_qkv_vtperm(const void* A, int64_t lda, int a_panel, const
   MH_CHECK_ARG(g_variant >= 2, "gemm_qkv_vtperm: needs the big-tile bf16 kernel");
   return qkv_impl(A, lda, a_panel, Wqkv, ldw, w_panel, bqkv, q, k, vt_perm, B, L, H, nh, MH_BF16, 1, stream);
 }
+// the same with the queries stored as (x Wq^T + bq) * q_scale (one rounding, from the fp32 accumulator): q_scale = softmax scale x log2(e)
+// is what mh_attention_stream_fwd_prescaled expects; defer may be NULL
+extern "C" int mh_gemm_qkv_vtperm_qs(const void* A, int64_t lda, const void* Wqkv, int64_t ldw, const float* bqkv, void* q, void* k,
+                                     void* vt_perm, int B, int L, int H, int nh, float q_scale, const mh_ln_defer* defer, mh_stream_t stream) {
+  MH_CHECK_ARG(L % 16 == 0, "gemm_qkv_vtperm_qs: seq_len %d must be a multiple of 16", L);
+  MH_CHECK_ARG(g_variant >= 2 && q_scale > 0.f, "gemm_qkv_vtperm_qs: needs the big-tile bf16 kernel and a positive scale");
+  MH_CHECK_ARG(!defer || defer->a_stats, "gemm_qkv_vtperm_qs: a deferred LayerNorm descriptor needs a_stats");
+  return qkv_impl(A, lda, 1, Wqkv, ldw, 1, bqkv, q, k, vt_perm, B, L, H, nh, MH_BF16, 1, stream, defer, q_scale);
+}
 
 namespace {
 int qkv_impl(const void* A, int64_t lda, int a_panel, const void* Wqkv, int64_t ldw, int w_panel, const float* bqkv,
              void* q, void* k, void* vt, int B, int L, int H, int nh, int dtype, int vt_perm, mh_stream_t stream,
-             const mh_ln_defer* defer) {
+             const mh_ln_defer* defer, float q_scale) {
   MH_CHECK_ARG(A && Wqkv && bqkv && q && k && vt, "gemm_qkv: null pointer");
   MH_CHECK_ARG(H % 64 == 0, "gemm_qkv: hidden size %d must be a multiple of 64", H);
   MH_CHECK_ARG(nh > 0 && H % nh == 0 && (H / nh) % 8 == 0, "gemm_qkv: head dim must be a multiple of 8");
@@ -1561,6 +1576,7 @@ int qkv_impl(const void* A, int64_t lda, int a_panel, const void* Wqkv, int64_t 
   g.a_panel = a_panel; g.w_panel = w_panel;
   g.q = q; g.k = k; g.vt = vt; g.L = L; g.H = H; g.nh = nh; g.dh = H / nh;
   g.vt_perm = vt_perm;
+  g.q_scale = q_scale;
   int rcd = fill_defer(defer, g, "gemm_qkv");
   if (rcd) return rcd;
   MH_CHECK_ARG(!vt_perm || (big_tile_ok(g) && H % 64 == 0), "gemm_qkv_vtperm: shape not served by the big-tile kernel");

@@ -510,40 +510,96 @@ __global__ void scale_rows_kernel(const float* __restrict__ src, const float* __
 // Replaces the reference's per-tensor foreach: AdamW.step + 3 x update_ema + grad-norm = ~600 launches and
 // ~200 .item() syncs per optimizer step (utils/train_util.py:246-280, :21-31).
 #pragma clang fp contract(off)
-__global__ void adamw_ema_kernel(const mh_opt_tensor* __restrict__ tensors, const mh_opt_chunk* __restrict__ chunks,
-                                 mh_opt_hparams hp) {
-  const mh_opt_chunk ck = chunks[blockIdx.x];
-  const mh_opt_tensor t = tensors[ck.tensor];
-  const int64_t end = ck.offset + ck.count;
-  for (int64_t i = ck.offset + threadIdx.x; i < end; i += blockDim.x) {
-    float p = t.param[i];
-    const float g = t.grad[i];
-    // torch.optim.AdamW (decoupled weight decay), single-tensor order of operations
-    // (every host-side scalar - 1-beta, 1-lr*wd, lr/bias1, 1-rate - is evaluated in double by the host like torch does)
-    p = p * hp.decay_mul;
-    const float m = t.exp_avg[i] * hp.beta1 + g * hp.one_minus_beta1;
-    const float v = t.exp_avg_sq[i] * hp.beta2 + (g * g) * hp.one_minus_beta2;
-    t.exp_avg[i] = m;
-    t.exp_avg_sq[i] = v;
-    const float denom = sqrtf(v) / hp.bias2_sqrt + hp.eps;
-    p = p - hp.step_size * (m / denom);
-    t.param[i] = p;
+// One AdamW + EMA element update (torch.optim.AdamW, decoupled weight decay, single-tensor order of operations; every host-side
+// scalar - 1-beta, 1-lr*wd, lr/bias1, 1-rate - is evaluated in double by the host like torch does)
+__device__ __forceinline__ float adamw_elem(float p, float g, float& m, float& v, const mh_opt_hparams& hp) {
+  p = p * hp.decay_mul;
+  m = m * hp.beta1 + g * hp.one_minus_beta1;
+  v = v * hp.beta2 + (g * g) * hp.one_minus_beta2;
+  const float denom = sqrtf(v) / hp.bias2_sqrt + hp.eps;
+  return p - hp.step_size * (m / denom);
+}
+// 16-byte accesses (a chunk starts on a multiple of 65536 elements of a 256-B aligned tensor); the parameter stream and the EMA
+// copies are read and written exactly once per step: 13 streams of 4 B per parameter, HBM-bound
+template <int NEMA>
+__device__ __forceinline__ void adamw_ema_chunk(const mh_opt_tensor& t, const mh_opt_chunk& ck, const mh_opt_hparams& hp) {
+  const int64_t n4 = ck.count >> 2;
+  f32x4* __restrict__ P = reinterpret_cast<f32x4*>(t.param + ck.offset);
+  const f32x4* __restrict__ G = reinterpret_cast<const f32x4*>(t.grad + ck.offset);
+  f32x4* __restrict__ M = reinterpret_cast<f32x4*>(t.exp_avg + ck.offset);
+  f32x4* __restrict__ V = reinterpret_cast<f32x4*>(t.exp_avg_sq + ck.offset);
+  for (int64_t i = threadIdx.x; i < n4; i += blockDim.x) {
+    f32x4 p = P[i], m = M[i], v = V[i];
+    const f32x4 g = __builtin_nontemporal_load(G + i);
+    f32x4 e[NEMA > 0 ? NEMA : 1];
 #pragma unroll
-    for (int e = 0; e < 4; ++e)
-      if (e < hp.n_ema) t.ema[e][i] = t.ema[e][i] * hp.ema_rate[e] + p * hp.ema_one_minus[e];   // update_ema, train_util.py:21-31
+    for (int k = 0; k < NEMA; ++k) e[k] = reinterpret_cast<const f32x4*>(t.ema[k] + ck.offset)[i];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      float mm = m[c], vv = v[c];
+      p[c] = adamw_elem(p[c], g[c], mm, vv, hp);
+      m[c] = mm; v[c] = vv;
+#pragma unroll
+      for (int k = 0; k < NEMA; ++k) e[k][c] = e[k][c] * hp.ema_rate[k] + p[c] * hp.ema_one_minus[k];   // update_ema, train_util.py:21-31
+    }
+    P[i] = p;
+    __builtin_nontemporal_store(m, M + i);
+    __builtin_nontemporal_store(v, V + i);
+#pragma unroll
+    for (int k = 0; k < NEMA; ++k) __builtin_nontemporal_store(e[k], reinterpret_cast<f32x4*>(t.ema[k] + ck.offset) + i);
+  }
+  for (int64_t i = ck.offset + (n4 << 2) + threadIdx.x; i < ck.offset + ck.count; i += blockDim.x) {   // count % 4 tail
+    float m = t.exp_avg[i], v = t.exp_avg_sq[i];
+    const float p = adamw_elem(t.param[i], t.grad[i], m, v, hp);
+    t.exp_avg[i] = m; t.exp_avg_sq[i] = v; t.param[i] = p;
+#pragma unroll
+    for (int k = 0; k < NEMA; ++k) t.ema[k][i] = t.ema[k][i] * hp.ema_rate[k] + p * hp.ema_one_minus[k];
   }
 }
-__global__ void sumsq_chunks_kernel(const mh_opt_tensor* __restrict__ tensors, const mh_opt_chunk* __restrict__ chunks,
-                                    float* __restrict__ partial) {
+__global__ __launch_bounds__(256) void adamw_ema_kernel(const mh_opt_tensor* __restrict__ tensors, const mh_opt_chunk* __restrict__ chunks,
+                                                       mh_opt_hparams hp) {
+  const mh_opt_chunk ck = chunks[blockIdx.x];
+  const mh_opt_tensor t = tensors[ck.tensor];
+  switch (hp.n_ema) {
+    case 0: adamw_ema_chunk<0>(t, ck, hp); break;
+    case 1: adamw_ema_chunk<1>(t, ck, hp); break;
+    case 2: adamw_ema_chunk<2>(t, ck, hp); break;
+    case 3: adamw_ema_chunk<3>(t, ck, hp); break;
+    default: adamw_ema_chunk<4>(t, ck, hp); break;
+  }
+}
+__global__ __launch_bounds__(256) void sumsq_chunks_kernel(const mh_opt_tensor* __restrict__ tensors, const mh_opt_chunk* __restrict__ chunks,
+                                                          float* __restrict__ partial) {
   __shared__ float red[4];
   const mh_opt_chunk ck = chunks[blockIdx.x];
-  const float* g = tensors[ck.tensor].grad;
+  const float* g = tensors[ck.tensor].grad + ck.offset;
+  // fixed per-thread order: 16-byte pieces strided by the block, then the count % 4 tail
   float s = 0.f;
-  for (int64_t i = ck.offset + threadIdx.x; i < ck.offset + ck.count; i += blockDim.x) s += g[i] * g[i];
+  const int64_t n4 = ck.count >> 2;
+  for (int64_t i = threadIdx.x; i < n4; i += blockDim.x) {
+    const f32x4 v = reinterpret_cast<const f32x4*>(g)[i];
+    s += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+  }
+  for (int64_t i = (n4 << 2) + threadIdx.x; i < ck.count; i += blockDim.x) s += g[i] * g[i];
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
   if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+// torch.nn.utils.clip_grad_norm_: g *= min(1, max_norm / (total_norm + 1e-6)) with the norm read from the device
+__global__ __launch_bounds__(256) void clip_grads_kernel(const mh_opt_tensor* __restrict__ tensors, const mh_opt_chunk* __restrict__ chunks,
+                                                        const float* __restrict__ norm, float max_norm) {
+  const float coef = fminf(max_norm / (norm[0] + 1e-6f), 1.0f);
+  if (coef >= 1.0f) return;
+  const mh_opt_chunk ck = chunks[blockIdx.x];
+  float* g = const_cast<float*>(tensors[ck.tensor].grad) + ck.offset;
+  const int64_t n4 = ck.count >> 2;
+  for (int64_t i = threadIdx.x; i < n4; i += blockDim.x) {
+    f32x4 v = reinterpret_cast<f32x4*>(g)[i];
+    v[0] *= coef; v[1] *= coef; v[2] *= coef; v[3] *= coef;
+    reinterpret_cast<f32x4*>(g)[i] = v;
+  }
+  for (int64_t i = (n4 << 2) + threadIdx.x; i < ck.count; i += blockDim.x) g[i] *= coef;
 }
 __global__ void sum_partials_kernel(const float* __restrict__ partial, int n, float* __restrict__ out) {
   __shared__ float red[4];
@@ -843,6 +899,14 @@ extern "C" int mh_adamw_ema_step(const mh_opt_tensor* tensors, const mh_opt_chun
   MH_CHECK_ARG(tensors && chunks && hp && n_chunks > 0, "adamw_ema_step: bad arguments");
   MH_CHECK_ARG(hp->n_ema >= 0 && hp->n_ema <= 4, "adamw_ema_step: at most 4 EMA copies");
   MH_LAUNCH(adamw_ema_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, tensors, chunks, *hp);
+  MH_CHECK_LAUNCH();
+  return MH_OK;
+}
+
+extern "C" int mh_clip_grads(const mh_opt_tensor* tensors, const mh_opt_chunk* chunks, int n_chunks, const float* norm, float max_norm,
+                             mh_stream_t stream) {
+  MH_CHECK_ARG(tensors && chunks && norm && n_chunks > 0 && max_norm > 0.f, "clip_grads: bad arguments");
+  MH_LAUNCH(clip_grads_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, tensors, chunks, norm, max_norm);
   MH_CHECK_LAUNCH();
   return MH_OK;
 }

@@ -164,6 +164,11 @@ class GaussianDiffusion:
     noise_fn = None        # optional callable (k, i, x) -> noise tensor (parity tests)
     use_graph = True       # capture the reverse step into a hipGraph when the fused path applies
     batch_split = None     # denoiser batch slices run as concurrent graph branches; None = 2 for large bf16 batches, else 1
+    # in-graph RNG, non-progressive loops: every batch slice replays its OWN graph on its own stream, with no per-step join and a phase
+    # lag between the chains.  Measured neutral at config 2 (3.693 vs 3.699 ms / step, any lag: every kernel of the step is a
+    # persistent launch that fills the chip on its own, so the arrangement of two chains does not change the sum): off by default
+    decouple_branches = False
+    branch_skew_us = None      # phase lag of branch j behind branch j-1 at the start of a decoupled loop; None = half a step / branches
 
     def __init__(self, *, betas, predict_xstart, rescale_timesteps=False):
         self.rescale_timesteps = rescale_timesteps
@@ -488,6 +493,53 @@ class GaussianDiffusion:
             return self.training_losses_seq2seq_with_corruption(model, t, model_kwargs, noise)
         return self.training_losses_seq2seq(model, t, model_kwargs, noise)
 
+    @staticmethod
+    def _get_x_start(x_start_mean, std):
+        """x_0 = Emb(w) + std * randn_like (diffusion.py:542-554).  `std` is what the reference passes - the [0] entry of a table
+        expanded to x_start_mean's shape (:610-612) - or anything broadcastable to it; the sum runs in the q_sample kernel with a
+        unit mean coefficient (the same kernel and draw order `training_losses` uses, gradient flows to x_start_mean)."""
+        from ..training import _QSample
+        _lib.require_device(x_start_mean)
+        noise = torch.randn_like(x_start_mean)
+        assert noise.shape == x_start_mean.shape
+        B = x_start_mean.shape[0]
+        std = torch.as_tensor(std, dtype=torch.float32, device=x_start_mean.device)
+        std = std.expand(x_start_mean.shape) if std.dim() <= x_start_mean.dim() else std
+        assert std.shape == x_start_mean.shape, "std must broadcast to x_start_mean"
+        if all(std.stride(d) == 0 or std.shape[d] == 1 for d in range(1, std.dim())):
+            # constant within a batch row (what _extract_into_tensor returns: an expanded view): one coefficient per row
+            lead = std[(slice(None),) + (0,) * (std.dim() - 1)].contiguous()
+            return _QSample.apply(x_start_mean, noise, torch.ones(B, device=noise.device), lead, None)
+        flat = std.reshape(-1).contiguous()                                  # general case: every element its own "row"
+        out = _QSample.apply(x_start_mean.reshape(-1, 1, 1), noise.reshape(-1, 1, 1), torch.ones_like(flat), flat, None)
+        return out.view(x_start_mean.shape)
+
+    @staticmethod
+    def _token_discrete_loss(x_t, get_logits, input_ids, mask=None):
+        """-log p(w | x): per-sequence mean cross-entropy of get_logits(x_t) against input_ids, mask-weighted when a mask is given
+        (diffusion.py:556-575).  With `get_logits` the bound method of a TransformerNetModel the logits GEMM and the cross-entropy
+        are the tape nodes of `training._token_nll`; any other callable's logits go through the same cross-entropy kernel."""
+        from ..training import _TokenCE, _token_nll
+        from .network import TransformerNetModel
+        net = getattr(get_logits, "__self__", None)
+        if isinstance(net, TransformerNetModel) and x_t.is_cuda:
+            return _token_nll(net, x_t, input_ids.to(x_t.device), mask=mask)
+        logits = get_logits(x_t)
+        _lib.require_device(logits)
+        V = logits.size(-1)
+        ids = input_ids.to(logits.device)
+        nll = _TokenCE.apply(logits.reshape(-1, V).float().contiguous(), ids, V).view(ids.shape)
+        if mask is not None:
+            m = mask.to(nll.device, torch.float32)
+            return (nll * m).sum(dim=-1) / m.sum(dim=-1)
+        return nll.mean(dim=-1)
+
+    def _x0_helper(self, model_output, x, t):
+        """{'pred_xprev', 'pred_xstart'} of a model output (diffusion.py:577-592)."""
+        pred_xstart = model_output if self.predict_xstart else self._predict_xstart_from_eps(x_t=x, t=t, eps=model_output)
+        pred_prev, _, _ = self.q_posterior_mean_variance(x_start=pred_xstart, x_t=x, t=t)
+        return {"pred_xprev": pred_prev, "pred_xstart": pred_xstart}
+
     def training_losses_seq2seq(self, model, t, model_kwargs, noise=None):
         """diffusion.py:594-647."""
         from ..training import training_losses
@@ -622,6 +674,33 @@ class _ReverseLoop:
             self.ev_join = [torch.cuda.Event() for _ in range(self.nsplit - 1)]
             sizes = [B - hb * (self.nsplit - 1) if j == self.nsplit - 1 else hb for j in range(self.nsplit)]
             self.split_round_ws = [None if table is None else ops.round_workspace(n * L, E, self.table32.shape[0], dev) for n in sizes]
+            self.slices = [slice(j * hb, j * hb + sizes[j]) for j in range(self.nsplit)]
+            # decoupled branches: the slices are independent chains over the WHOLE loop, so each gets its own loop state and replays
+            # its own graph; nothing joins them until the loop ends
+            self.br_state = [self.state.clone() for _ in range(self.nsplit)]
+            self.br_coef = [torch.zeros(8, dtype=torch.float32, device=dev) for _ in range(self.nsplit)]
+            self.br_graphs = {}
+        self.decoupled = False
+
+    def _tail(self, sl, stream_h, ws, cur_coef, use_round):
+        """rounding + posterior / DDIM update of the batch slice `sl` on the given stream"""
+        L_, P = _lib.lib(), _lib.ptr
+        per_batch = self.L * self.E
+        nb = sl.stop - sl.start
+        tok = slice(sl.start * self.L, sl.stop * self.L)
+        if use_round:
+            _lib.check(L_.mh_round_to_embedding_mfma(P(self.model_out[sl]), P(self.table_pad), P(self.table_norm),
+                                                     P(self.round_idx[tok]), nb * self.L, self.E, self.table32.shape[0],
+                                                     P(ws), ws.numel(), stream_h), "mh_round_to_embedding_mfma")
+        args = [P(self.model_out[sl]), P(self.x[sl]), P(self.noise[sl]), P(self.round_idx[tok]) if use_round else None,
+                P(self.table32) if use_round else None, P(cur_coef), 0, int(self.clip),
+                P(self.mask[sl]) if self.mask is not None else None, self.mask_per_elem,
+                P(self.x_start[sl]) if self.x_start is not None else None, P(self.x[sl]), P(self.pred[sl])]
+        if self.kind == "p":
+            _lib.check(L_.mh_p_sample_epilogue(*args, P(self.mean[sl]) if self.mean is not None else None, nb, per_batch, self.E,
+                                               stream_h), "mh_p_sample_epilogue")
+        else:
+            _lib.check(L_.mh_ddim_epilogue(*args, nb, per_batch, self.E, stream_h), "mh_ddim_epilogue")
 
     # one reverse step as a fixed launch sequence (capturable: no allocation, no sync)
     def _body(self, use_round, in_graph_rng):
@@ -634,22 +713,7 @@ class _ReverseLoop:
         per_batch = self.L * self.E
 
         def tail(sl, stream_h, ws):
-            """rounding + posterior / DDIM update of the batch slice `sl` on the given stream"""
-            nb = sl.stop - sl.start
-            tok = slice(sl.start * self.L, sl.stop * self.L)
-            if use_round:
-                _lib.check(L_.mh_round_to_embedding_mfma(P(self.model_out[sl]), P(self.table_pad), P(self.table_norm),
-                                                         P(self.round_idx[tok]), nb * self.L, self.E, self.table32.shape[0],
-                                                         P(ws), ws.numel(), stream_h), "mh_round_to_embedding_mfma")
-            args = [P(self.model_out[sl]), P(self.x[sl]), P(self.noise[sl]), P(self.round_idx[tok]) if use_round else None,
-                    P(self.table32) if use_round else None, P(self.cur_coef), 0, int(self.clip),
-                    P(self.mask[sl]) if self.mask is not None else None, self.mask_per_elem,
-                    P(self.x_start[sl]) if self.x_start is not None else None, P(self.x[sl]), P(self.pred[sl])]
-            if self.kind == "p":
-                _lib.check(L_.mh_p_sample_epilogue(*args, P(self.mean[sl]) if self.mean is not None else None, nb, per_batch, self.E,
-                                                   stream_h), "mh_p_sample_epilogue")
-            else:
-                _lib.check(L_.mh_ddim_epilogue(*args, nb, per_batch, self.E, stream_h), "mh_ddim_epilogue")
+            self._tail(sl, stream_h, ws, self.cur_coef, use_round)
 
         def draw_noise(stream_h):
             if in_graph_rng:
@@ -690,16 +754,71 @@ class _ReverseLoop:
                 main.wait_event(self.ev_join[j - 1])
         _lib.check(L_.mh_step_end(P(self.state), st), "mh_step_end")
 
+    def _branch_body(self, j, use_round):
+        """One reverse step of batch slice j alone, on the current stream: its own loop state, its slice of the in-graph noise
+        (globally numbered elements: the values of the whole-batch draw), forward, rounding, update.  Same kernels and arithmetic as
+        `_body`; only the launch grouping differs."""
+        L_ = _lib.lib()
+        st = _lib.current_stream()
+        P = _lib.ptr
+        sl = self.slices[j]
+        nb = sl.stop - sl.start
+        state, coef = self.br_state[j], self.br_coef[j]
+        _lib.check(L_.mh_step_begin(P(state), P(self.steps), P(self.coef_table), P(coef), P(self.emb_row[sl]), nb, st), "mh_step_begin")
+        per_batch = self.L * self.E
+        _lib.check(L_.mh_trunc_normal_at(P(self.noise[sl]), nb * per_batch, sl.start * per_batch, float(self.top_p), int(self.diff.rng_seed),
+                                         int(self.diff.rng_stream), P(state), st), "mh_trunc_normal_at")
+        self.eng.forward(self.x[sl], self.emb_table, self.emb_row[sl], out=self.model_out[sl], ws=self.split_ws[j])
+        self._tail(sl, st, self.split_round_ws[j], coef, use_round)
+        _lib.check(L_.mh_step_end(P(state), st), "mh_step_end")
+
     def begin(self):
         """Warm-up launch outside capture (one-time lazy initialisation inside the launchers), state restored."""
         diff = self.diff
         self.in_graph_rng = diff.noise_fn is None and diff.rng_mode == "philox"
         self.stream = torch.cuda.current_stream()
+        self.decoupled = bool(self.nsplit > 1 and self.in_graph_rng and not self.progressive and diff.use_graph and diff.decouple_branches
+                              and (self.L * self.E) % 4 == 0)
         if diff.use_graph:
             snap = (self.x.clone(), self.state.clone())
+            t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            t0.record()
             self._body(self.use_round[0], self.in_graph_rng)
+            t1.record()
             self.x.copy_(snap[0]); self.state.copy_(snap[1])
+            if self.decoupled:
+                # every slice's chain starts behind the inputs; slice j then lags slice j - 1 by a fraction of a step, so that one
+                # slice's small head / tail kernels and kernel boundaries fall under another slice's GEMMs for the whole loop
+                skew = diff.branch_skew_us
+                if skew is None:
+                    t1.synchronize()
+                    skew = int(1e3 * t0.elapsed_time(t1) / self.nsplit)
+                self.skew_us = int(skew)
+                ev = torch.cuda.Event()
+                ev.record(self.stream)
+                for j in range(1, self.nsplit):
+                    side = self.side_streams[j - 1]
+                    side.wait_event(ev)
+                    _lib.check(_lib.lib().mh_stream_delay(min(100000, self.skew_us * j), side.cuda_stream), "mh_stream_delay")
         return self
+
+    def finish(self):
+        """Joins the decoupled branches into the loop's stream (the samples are complete behind it)."""
+        if self.decoupled:
+            for side in self.side_streams:
+                ev = torch.cuda.Event()
+                ev.record(side)
+                self.stream.wait_event(ev)
+
+    def _branch_graph(self, j, ur):
+        g = self.br_graphs.get((j, ur))
+        if g is None:
+            side = torch.cuda.Stream()
+            torch.cuda.synchronize()
+            g = ops.Graph().capture(lambda: self._branch_body(j, ur), side)
+            torch.cuda.synchronize()
+            self.br_graphs[(j, ur)] = g
+        return g
 
     def _graph_for(self, ur):
         g = self.graphs.get(ur)
@@ -722,7 +841,15 @@ class _ReverseLoop:
             else:
                 self.noise.copy_(torch.randn_like(self.x))
         ur = self.use_round[k]
-        if diff.use_graph:
+        if self.decoupled:
+            for j in range(self.nsplit):
+                stream = self.stream if j == 0 else self.side_streams[j - 1]
+                if diff.use_graph:
+                    self._branch_graph(j, ur).launch(stream)
+                else:                       # (per-launch profiling of the same chains, bench.py)
+                    with torch.cuda.stream(stream):
+                        self._branch_body(j, ur)
+        elif diff.use_graph:
             self._graph_for(ur).launch(self.stream)
         else:
             self._body(ur, self.in_graph_rng)
@@ -739,4 +866,5 @@ class _ReverseLoop:
                         out["out"] = {"mean": out["greedy_mean"], "pred_xstart": out["pred_xstart"]}
                     yield out
             if not self.progressive:
+                self.finish()
                 yield {"sample": self.x, "pred_xstart": self.pred}

@@ -94,6 +94,14 @@ class FusedAdamWEMA:
                                  current_stream()), "mh_grad_norm")
         return self._norm
 
+    def clip_grad_norm(self, max_norm):
+        """torch.nn.utils.clip_grad_norm_ (the reference's `grad_clip`, train_util.py:255-264) without a host sync: the norm kernel,
+        then one launch that scales every gradient by min(1, max_norm / (norm + 1e-6)).  Returns the pre-clip norm (device scalar)."""
+        norm = self.grad_norm()
+        check(lib().mh_clip_grads(ptr(self._tensor_table()), ptr(self._chunks), self.n_chunks, ptr(norm), float(max_norm), current_stream()),
+              "mh_clip_grads")
+        return norm
+
     @torch.no_grad()
     def step(self, lr=None):
         """One optimizer step: AdamW on every parameter + all EMA copies, one launch."""

@@ -280,11 +280,15 @@ def test_batch_split_branches_equal_single_stream():
     for split in (1, 2, 4):
         for ug in (True, False):
             diff.batch_split, diff.use_graph = split, ug
-            outs[(split, ug)] = diff.p_sample_loop(**kw)[0].clone()
+            outs[(split, ug, False)] = diff.p_sample_loop(**kw)[0].clone()
+        # decoupled: every slice replays its own graph on its own stream (own loop state, its slice of the globally numbered noise)
+        diff.use_graph, diff.decouple_branches, diff.branch_skew_us = True, True, 50 * split
+        outs[(split, True, True)] = diff.p_sample_loop(**kw)[0].clone()
+        diff.decouple_branches, diff.branch_skew_us = False, None
     diff.batch_split = 1
-    ref = outs[(1, True)]
+    ref = outs[(1, True, False)]
     for k, v in outs.items():
-        assert torch.equal(v, ref), "batch_split=%d graph=%s differs" % k
+        assert torch.equal(v, ref), "batch_split=%d graph=%s decoupled=%s differs" % k
 
 
 def test_full_size_config2_properties():

@@ -199,6 +199,60 @@ def test_attention_stream(dh, L, B, nh):
     assert torch.equal(outp.permute(1, 0, 2).reshape(B * L, nh * dh), out)
 
 
+@pytest.mark.parametrize("dh,L,B,nh", [(64, 512, 3, 5), (32, 512, 2, 3), (64, 1024, 2, 2), (64, 768, 1, 3)])
+def test_attention_stream_prescaled(dh, L, B, nh):
+    """queries that carry scale x log2(e) (the QKV epilogue's form): the reference-in-the-accumulator softmax == softmax(QK^T/sqrt(dh)) V.
+    Forces the re-basing branch: one key row per head beats its predecessors by far more than 2^8, late in the sequence, and one (batch,
+    head) has every score far below zero (the first sub-tile's reference is then a large negative number, not 0)."""
+    from musediffusion_amd._lib import check, current_stream
+    qh, kh, vh = (rnd(B, nh, L, dh, seed=430 + i) for i in range(3))
+    kh = kh * 1.5
+    kh[:, :, 300] *= 6.0
+    kh[:, :, L - 3] = 40.0 * qh[:, :, 17] / qh[:, :, 17].norm(dim=-1, keepdim=True)   # aligned with query 17: its score jumps by > 2^8
+    qh[0, 0] = qh[0, 0].abs() + 2.0                                                       # (batch 0, head 0): all scores << 0
+    kh[0, 0] = -(kh[0, 0].abs() + 2.0)
+    scale = 1.0 / math.sqrt(dh)
+    sl2 = scale * math.log2(math.e)
+    assert lib().mh_attention_stream_prescaled_supported(L, dh) == (1 if L % 256 == 0 else 0)
+    q_pre = (q(qh, MH_BF16) * sl2).bfloat16()                                             # what mh_gemm_qkv_vtperm_qs stores
+    ref = _attn_ref(q_pre.float() / sl2, q(kh, MH_BF16), q(vh, MH_BF16), scale).permute(0, 2, 1, 3).reshape(B * L, nh * dh)
+    vtp = _vt_perm(vh.transpose(-1, -2).contiguous())
+    vt_dev = torch.zeros(vtp.numel() + 128, device=DEV, dtype=torch.bfloat16)
+    vt_dev[: vtp.numel()] = vtp.to(DEV).bfloat16().flatten()
+    qd, kd = q_pre.to(DEV).contiguous(), kh.to(DEV).bfloat16().contiguous()
+    out = torch.zeros(B * L, nh * dh, device=DEV, dtype=torch.bfloat16)
+    check(lib().mh_attention_stream_fwd_prescaled(qd.data_ptr(), kd.data_ptr(), vt_dev.data_ptr(), out.data_ptr(), nh * dh, 0, B, L, nh, dh,
+                                                  current_stream()))
+    assert torch.isfinite(out).all()
+    assert_close(out, ref, 2e-2, what="attention_stream_prescaled dh=%d L=%d" % (dh, L))
+    outp = torch.zeros(nh * dh // 32, B * L, 32, device=DEV, dtype=torch.bfloat16)
+    check(lib().mh_attention_stream_fwd_prescaled(qd.data_ptr(), kd.data_ptr(), vt_dev.data_ptr(), outp.data_ptr(), B * L, 1, B, L, nh, dh,
+                                                  current_stream()))
+    assert torch.equal(outp.permute(1, 0, 2).reshape(B * L, nh * dh), out)
+
+
+def test_gemm_qkv_vtperm_scaled_queries():
+    """mh_gemm_qkv_vtperm_qs: q = (x Wq^T + bq) * q_scale rounded ONCE from the fp32 accumulator; k and V^T as mh_gemm_qkv_vtperm"""
+    from musediffusion_amd._lib import check, current_stream
+    B, L, H, nh = 2, 256, 128, 2
+    X, Wq, bq = rnd(B * L, H, seed=440), rnd(3 * H, H, seed=441, scale=1.0 / 11), rnd(3 * H, seed=442, scale=0.1)
+    Xp, Wp, bd = dev_panel(X), dev_panel(Wq), bq.to(DEV)
+    q0, k0 = (torch.empty(B, nh, L, H // nh, device=DEV, dtype=torch.bfloat16) for _ in range(2))
+    q1, k1 = torch.empty_like(q0), torch.empty_like(k0)
+    vt0, vt1 = (torch.zeros(B * H * L + 128, device=DEV, dtype=torch.bfloat16) for _ in range(2))
+    st = current_stream()
+    check(lib().mh_gemm_qkv_vtperm(Xp.data_ptr(), B * L, 1, Wp.data_ptr(), 3 * H, 1, bd.data_ptr(), q0.data_ptr(), k0.data_ptr(), vt0.data_ptr(),
+                                   B, L, H, nh, st))
+    qs = 0.18033688
+    check(lib().mh_gemm_qkv_vtperm_qs(Xp.data_ptr(), B * L, Wp.data_ptr(), 3 * H, bd.data_ptr(), q1.data_ptr(), k1.data_ptr(), vt1.data_ptr(),
+                                      B, L, H, nh, qs, None, st))
+    assert torch.equal(k0, k1) and torch.equal(vt0, vt1)
+    acc = (q(X, MH_BF16) @ q(Wq[:H], MH_BF16).t() + bq[:H]) * qs                      # fp32 accumulator, then one rounding
+    ref = acc.view(B, L, nh, H // nh).permute(0, 2, 1, 3)
+    assert_close(q1, ref, 1e-3, 2 ** -8, what="scaled queries")
+    assert not torch.equal(q1, q0)
+
+
 @pytest.mark.parametrize("dh,L,B,nh", [(64, 512, 2, 3), (64, 1024, 1, 2), (32, 512, 2, 2), (64, 528, 1, 2), (64, 2096, 1, 1), (32, 784, 1, 2)])
 def test_attention_stream_backward(dh, L, B, nh):
     """fused backward kernels (dQ; dK, dV) == torch autograd through softmax(QK^T/sqrt(dh)) V on the bf16-rounded inputs"""

@@ -18,8 +18,11 @@ from musediffusion_amd import _lib  # noqa: E402
 
 setters = {"gemm_debug": lambda v: _lib.lib().mh_gemm_set_debug(v), "plain_stores": lambda v: _lib.lib().mh_gemm_set_plain_stores(v), "fuse_ln": lambda v: _lib.lib().mh_denoiser_set_fuse_ln(v),
            "v3_fuse_ln": lambda v: (_lib.lib().mh_gemm_set_variant(3), _lib.lib().mh_denoiser_set_fuse_ln(v)),
-           "v3_split": None,
+           "v3_split": None, "skip": lambda v: _lib.lib().mh_denoiser_set_skip(v), "prescale_q": lambda v: _lib.lib().mh_denoiser_set_prescale_q(v),
            "stream_attn": lambda v: _lib.lib().mh_attention_set_stream(v), "gemm_variant": lambda v: _lib.lib().mh_gemm_set_variant(v)}
+from musediffusion_amd.models.diffusion import GaussianDiffusion  # noqa: E402
+setters["decouple"] = lambda v: setattr(GaussianDiffusion, "decouple_branches", bool(v))
+setters["skew"] = lambda v: setattr(GaussianDiffusion, "branch_skew_us", None if v < 0 else v)       # microseconds; -1 = automatic
 res = {v: [] for v in values}
 for rnd in range(3):
     for v in values:

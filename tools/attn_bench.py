@@ -39,6 +39,21 @@ if _lib.lib().mh_attention_stream_supported(a.L, a.dh):
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / a.reps
     print("attention stream    : %7.1f us  %6.1f TFLOP/s" % (ms * 1e3, flops / ms / 1e9))
+if _lib.lib().mh_attention_stream_prescaled_supported(a.L, a.dh):
+    ctx = torch.empty(a.B * a.L, a.nh * a.dh, device=dev, dtype=bf)
+    qp = (q.float() * (a.dh ** -0.5 * 1.4426950408889634)).to(bf)
+    def run_pre():
+        _lib.check(_lib.lib().mh_attention_stream_fwd_prescaled(qp.data_ptr(), k.data_ptr(), vt.data_ptr(), ctx.data_ptr(), a.nh * a.dh, 0, a.B, a.L,
+                                                                a.nh, a.dh, _lib.current_stream()))
+    for name, fn in (("stream", run), ("prescaled", run_pre), ("stream", run), ("prescaled", run_pre)):
+        fn(); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(a.reps * 5):
+            fn()
+        e1.record(); torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / (a.reps * 5)
+        print("attention %-9s: %7.1f us  %6.1f TFLOP/s" % (name, ms * 1e3, flops / ms / 1e9))
 # per-block timeline of the resident kernel (100 MHz stamps)
 for res in (1, 2):
     _lib.lib().mh_attention_set_variant(res)
