@@ -156,6 +156,16 @@ def classify_launch(kernel, note, c, branches):
         M, N, K = int(kv["M"]), int(kv["N"]), int(kv["K"])
         role = "rounding scores" if N == c["V"] else "dense (fp32 parity mode)"
         return "gemm_kernel<float> exact-fp32 MFMA, %s [%d x %d x %d]" % (role, M, N, K), "mfma_f32", 2.0 * M * N * K, "flop"
+    if "gemm_tn_kernel" in kernel:      # weight gradient dW [M x N] = dY^T X over K tokens (note: gemm_dw M N K splits)
+        M, N, K = int(kv["M"]), int(kv["N"]), int(kv["K"])
+        return "gemm_tn_kernel weight gradient [%d x %d over %d tokens, %s slices]" % (M, N, K, kv.get("splits", "?")), "mfma", 2.0 * M * N * K, "flop"
+    if "attn_bwd_dkv" in kernel or "attn_bwd_dq" in kernel:
+        bh, dh = int(kv.get("B*nh", 0)), int(kv.get("dh", 0))
+        nmm = 4 if "dkv" in kernel else 3     # S, dP, dV, dK  /  S, dP, dQ: 2 L^2 dh flops each per (batch, head)
+        return "%s [B*nh=%d, L=%d] (%d products)" % ("attn_bwd_dkv_kernel" if nmm == 4 else "attn_bwd_dq_kernel", bh, L, nmm), "valu+mfma", nmm * 2.0 * L * L * dh * bh, "flop"
+    if "attn_f32_kernel" in kernel:       # fp32 parity mode: tiled attention on the exact-fp32 MFMA / VALU
+        bh, dh = (c["B"] // branches) * c["nh"], H // c["nh"]
+        return "attn_f32_kernel<dh=%d> [B*nh=%d, L=%d]" % (dh, bh, L), "mfma_f32", 4.0 * L * dh * bh * L, "flop"
     if kernel == "kern" or "attn_" in kernel:
         bh, dh = int(kv.get("B*nh", 0)), int(kv.get("dh", 0))
         return "attn_stream_bf16_kernel<dh=%d> [B*nh=%d, L=%d]" % (dh, bh, L), "valu+mfma", 4.0 * L * dh * bh * L, "flop"
@@ -174,40 +184,47 @@ def classify_launch(kernel, note, c, branches):
         b = N_tok * E * 4
     elif "argbest_reduce" in kernel:
         b = N_tok * 12 * 8
+    elif "adamw_ema_kernel" in kernel:
+        b = c.get("n_params", 0) * 4 * (7 + 2 * int(kv.get("n_ema", 0)))       # p, m, v read + written, g read, each EMA copy read + written
+    elif "sumsq_chunks" in kernel:
+        b = c.get("n_params", 0) * 4
+    elif "sum_slices" in kernel:
+        b = (int(kv.get("slices", 0)) + 1) * int(kv.get("n", 0)) * 4
+    elif "ln_bwd_kernel" in kernel:
+        b = 3 * N_tok * H * 2
+    elif "head_transpose" in kernel:
+        b = 2 * N_tok * H * 2
+    elif "dropout_bits_kernel" in kernel:
+        b = (c["B"] // branches) * c["nh"] * L * L // 8
     if b is not None:
         return kernel.strip("()"), "hbm", float(b), "B"
     return kernel.strip("()"), "latency", 0.0, ""
 
 
-def profile_step(loop, c, first_k, n_steps, ms_per_step):
-    """Per-kernel time INSIDE the step: the step's launch sequence run eagerly on the same streams (same branches) with every
-    launch bracketed by HIP events on its stream (mh_profile_start / _stop).  With two branches sharing the chip a launch's span
-    on its stream is longer than its share of the wall time, so spans are turned into shares: share = sum of the class's spans /
-    sum of all spans, in-step duration per launch = share x ms_per_step / launches per step."""
+def collect_launches(run, n_steps):
+    """Runs `run()` n_steps times with the library's per-launch HIP events on -> [(kernel, note, ms)]"""
     import ctypes
     from musediffusion_amd import _lib
     lib = _lib.lib()
-    was = loop.diff.use_graph
-    loop.diff.use_graph = False
-    try:
-        with torch.no_grad():
-            loop.advance(first_k)                                  # eager warm-up
-            torch.cuda.synchronize()
-            _lib.check(lib.mh_profile_start(), "mh_profile_start")
-            for k in range(first_k + 1, first_k + 1 + n_steps):
-                loop.advance(k)
-            buf = ctypes.create_string_buffer(1 << 22)
-            need = lib.mh_profile_stop(buf, len(buf))
-            assert 0 < need <= len(buf), need
-    finally:
-        loop.diff.use_graph = was
-    branches = int(loop.nsplit)
-    classes, total = {}, 0.0
+    torch.cuda.synchronize()
+    _lib.check(lib.mh_profile_start(), "mh_profile_start")
+    for _ in range(n_steps):
+        run()
+    buf = ctypes.create_string_buffer(1 << 24)
+    need = lib.mh_profile_stop(buf, len(buf))
+    assert 0 < need <= len(buf), need
+    recs = []
     for line in buf.value.decode().splitlines():
         kernel, note, grid, block, stream, ms = line.split("\t")
-        ms = float(ms)
-        if ms < 0:
-            continue
+        if float(ms) >= 0:
+            recs.append((kernel, note, float(ms)))
+    return recs
+
+
+def kernel_rows(recs, c, branches, n_steps, ms_per_step):
+    """Per-launch records -> per-class rows with in-step duration, rate and roofline fraction (see profile_step)."""
+    classes, total = {}, 0.0
+    for kernel, note, ms in recs:
         name, bound, work, unit = classify_launch(kernel, note, c, branches)
         e = classes.setdefault(name, dict(bound=bound, unit=unit, work=0.0, span_ms=0.0, launches=0))
         e["work"] += work
@@ -234,6 +251,70 @@ def profile_step(loop, c, first_k, n_steps, ms_per_step):
     return rows, total / n_steps
 
 
+def roofline_from_rows(rows, span_sum, ms_per_step, dtype, workload, branches, n_prof, what="step"):
+    """The dominant kernel = the kernel SYMBOL with the largest share (its launches of different shapes pooled):
+    achieved = mean algorithmic flops per launch / mean in-step duration per launch."""
+    sym = lambda r: r["kernel"].split(" [")[0]
+    pools = {}
+    for r in rows:
+        if r["bound"] in ("mfma", "mfma_f32") and r.get("work_per_launch"):
+            pools.setdefault(sym(r), []).append(r)
+    dom = max(pools.values(), key=lambda rs: sum(r["share"] for r in rs))
+    n_l = sum(r["launches_per_step"] for r in dom)
+    share = sum(r["share"] for r in dom)
+    fpl = sum(r["work_per_launch"] * r["launches_per_step"] for r in dom) / n_l
+    avg_ms = share * ms_per_step / n_l
+    ach = fpl / (avg_ms * 1e-3) / 1e12
+    peak = MFMA_PEAK_TFLOPS["fp32" if dom[0]["bound"] == "mfma_f32" else "bf16"]
+    variant = sym(dom[0])
+    return {"bound": "mfma", "kernel": variant + ": " + "; ".join(r["kernel"].split(" [")[1].rstrip("]") if " [" in r["kernel"] else "" for r in dom),
+            "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+            "traffic": pmc_traffic(workload, dtype, branches, variant),
+            "avg_launch_ms": round(avg_ms, 5), "launches_per_step": n_l, "share_of_step": round(share, 4),
+            "how": "in-%s: HIP events around every launch of the eager %s on its own stream (%d repetitions); share = spans of this kernel / "
+                   "all spans (sum %.3f ms per %s on %d concurrent stream(s) vs %.3f ms wall); avg_launch_ms = share x ms_per_step / launches"
+                   % (what, what, n_prof, span_sum, what, branches, ms_per_step),
+            "concurrent_streams": branches,
+            "stream_span_ms": round(sum(r["stream_span_ms"] * r["launches_per_step"] for r in dom) / n_l, 5),
+            "flops_per_launch": fpl}
+
+
+def profile_step(loop, c, first_k, n_steps, ms_per_step):
+    """Per-kernel time INSIDE the step: the step's launch sequence run eagerly on the same streams (same branches) with every
+    launch bracketed by HIP events on its stream (mh_profile_start / _stop).  With two branches sharing the chip a launch's span
+    on its stream is longer than its share of the wall time, so spans are turned into shares: share = sum of the class's spans /
+    sum of all spans, in-step duration per launch = share x ms_per_step / launches per step."""
+    was = loop.diff.use_graph
+    loop.diff.use_graph = False
+    try:
+        with torch.no_grad():
+            loop.advance(first_k)                                  # eager warm-up
+            k = [first_k]
+
+            def one():
+                k[0] += 1
+                loop.advance(k[0])
+            recs = collect_launches(one, n_steps)
+    finally:
+        loop.diff.use_graph = was
+    return kernel_rows(recs, c, int(loop.nsplit), n_steps, ms_per_step)
+
+
+def dist_evidence(world, device, local_rank):
+    """What proves (or disproves) that RCCL carried `world` ranks on `world` different GPUs: the process group's backend, the rank
+    count as the backend reports it (0 unless it is nccl = RCCL), and every rank's device as the runtime names it."""
+    import torch.distributed as dist
+    backend = dist.get_backend() if (world > 1 and dist.is_initialized()) else "none (single process)"
+    props = torch.cuda.get_device_properties(device)
+    mine = "rank %d: cuda:%d %s uuid=%s" % (int(os.environ.get("RANK", "0")), local_rank, props.name, getattr(props, "uuid", "?"))
+    names = [mine]
+    if world > 1:
+        names = [None] * world
+        dist.all_gather_object(names, mine)
+    return {"backend": backend, "rccl_ranks": dist.get_world_size() if backend == "nccl" else 0, "devices": names,
+            "distinct_devices": len({n.split("uuid=")[-1] for n in names})}
+
+
 def pmc_traffic(workload, dtype, branches, variant):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE doubled as
     MI355X_MICROARCH.md prescribes for gfx950, + WRITE_SIZE).  Entries are keyed by workload AND kernel variant (the tile /
@@ -248,38 +329,70 @@ def pmc_traffic(workload, dtype, branches, variant):
         return None
 
 
-def cpu_baseline(c, seconds_budget=25.0):
-    """The oracle (torch-CPU fp32 port of the reference path) on a bounded sample of the same workload."""
-    from musediffusion_amd import synthetic
-    from oracle import denoiser as odn, sampling as osa, schedule as osc
-    Bs = max(1, min(c["B"], 8))
-    sd = odn.random_state_dict(c["E"], c["H"], c["F"], c["nL"], c["V"], c["L"], c["Tt"], seed=0)
-    # give the CPU its best shot: pick the thread count that runs one denoiser forward fastest
-    # (all hardware threads is far from optimal for torch's CPU GEMMs on many-core hosts)
+def host_description():
+    """CPU model, physical cores and hardware threads of the box (BASELINE.md section 3 asks for them beside the CPU number)."""
+    model, phys = "?", set()
+    try:
+        pid = cid = None
+        for line in open("/proc/cpuinfo"):
+            k, _, v = line.partition(":")
+            k, v = k.strip(), v.strip()
+            if k == "model name":
+                model = v
+            elif k == "physical id":
+                pid = v
+            elif k == "core id":
+                cid = v
+            elif not k and pid is not None:
+                phys.add((pid, cid)); pid = cid = None
+    except OSError:
+        pass
+    return {"cpu_model": model, "physical_cores": len(phys) or None, "hardware_threads": os.cpu_count()}
+
+
+def best_thread_count(fn):
+    """torch's CPU GEMMs are far from optimal on all hardware threads of a many-core host: take the thread count that runs fn() fastest"""
     hw = os.cpu_count() or 1
-    probe_x, probe_t = torch.randn(Bs, c["L"], c["E"]), torch.full((Bs,), 10.0)
     best, cores = None, hw
     for n in sorted({min(hw, k) for k in (8, 16, 32, 64, 128, hw)}):
         torch.set_num_threads(n)
-        with torch.no_grad():
-            odn.forward(sd, probe_x, probe_t, c["nh"])
-            t0 = time.perf_counter()
-            odn.forward(sd, probe_x, probe_t, c["nh"])
-            dt = time.perf_counter() - t0
+        fn()
+        t0 = time.perf_counter()
+        fn()
+        dt = time.perf_counter() - t0
         if best is None or dt < best:
             best, cores = dt, n
     torch.set_num_threads(cores)
+    return cores
+
+
+def cpu_baseline(c, kind="p", seconds_budget=40.0):
+    """The oracle (torch-CPU fp32 port of the reference path) on the same workload: the FULL batch, one warm-up step, then >= 3 timed
+    steps (SURVEY.md 8d / BASELINE.md section 3) unless a step takes so long that the budget ends the loop earlier (never below 2)."""
+    from musediffusion_amd import synthetic
+    from oracle import denoiser as odn, sampling as osa, schedule as osc
+    B = c["B"]
+    sd = odn.random_state_dict(c["E"], c["H"], c["F"], c["nL"], c["V"], c["L"], c["Tt"], seed=0)
+    probe_x, probe_t = torch.randn(min(B, 8), c["L"], c["E"]), torch.full((min(B, 8),), 10.0)
+
+    def probe():
+        with torch.no_grad():
+            odn.forward(sd, probe_x, probe_t, c["nh"])
+    cores = best_thread_count(probe)
     d = osc.make_diffusion(diffusion_steps=c["T"])
-    batch = synthetic.generation_batch(Bs, c["L"], seed=1)
+    batch = synthetic.generation_batch(B, c["L"], seed=1)
     emb_w = sd["word_embedding.weight"]
     x_start = emb_w[batch["input_ids"].long()]
     mask3 = torch.broadcast_to(batch["input_mask"].unsqueeze(-1), x_start.shape)
     torch.manual_seed(105)
     x = osa.start_latent_generation(x_start, mask3)
     fn = lambda xx, ts: odn.forward(sd, xx, ts, c["nh"])
+
     def step(i, x):
-        t = torch.tensor([i] * Bs)
+        t = torch.tensor([i] * B)
         with torch.no_grad():
+            if kind == "ddim":
+                return osa.ddim_sample(d, fn, x, t, True, emb_w, mask=mask3, x_start=x_start)["sample"]
             return osa.p_sample(d, fn, x, t, True, emb_w, top_p=1, mask=mask3, x_start=x_start)["sample"]
     x = step(c["T"] - 1, x)  # warm-up
     n, t0 = 0, time.perf_counter()
@@ -287,13 +400,55 @@ def cpu_baseline(c, seconds_budget=25.0):
         x = step(c["T"] - 2 - n, x)
         n += 1
         el = time.perf_counter() - t0
-        if el > seconds_budget or n >= 20 or (n >= 2 and el > seconds_budget / 2):
+        if n >= 3 and (el > seconds_budget / 2 or n >= 10):
             break
-    sps_sample = n / el
-    return {"value": sps_sample * Bs / c["B"], "unit": "denoiser-steps/s", "cores": cores, "kind": "port",
-            "sample": "oracle p_sample (torch CPU fp32, %d threads) on %d of the %d sequences, %d timed steps in %.1f s "
-                      "after 1 warm-up; value = measured steps/s x %d/%d (cost is linear in batch)"
-                      % (cores, Bs, c["B"], n, el, Bs, c["B"])}
+        if n >= 2 and el > seconds_budget:
+            break
+    out = {"value": n / el, "unit": "denoiser-steps/s", "cores": cores, "kind": "port",
+           "sample": "oracle %s step (torch CPU fp32, %d threads = the fastest of 8 / 16 / 32 / 64 / 128 / all on this host) on the FULL batch of "
+                     "%d sequences x seq_len %d: %d timed steps in %.1f s after 1 warm-up step (%.2f s per step)"
+                     % ("ddim_sample" if kind == "ddim" else "p_sample", cores, B, c["L"], n, el, el / n)}
+    out.update(host_description())
+    return out
+
+
+def cpu_baseline_train(c, n_seq=2, seconds_budget=40.0):
+    """The oracle's training_losses (with-corruption variant) forward + backward over ALL parameters on n_seq of the micro-batch's
+    sequences (fp32, eval-mode arithmetic: the oracle's dropout needs explicit masks), scaled to one micro-batch of c['B'] sequences."""
+    from musediffusion_amd import synthetic
+    from oracle import denoiser as odn, losses as olo, schedule as osc
+    sd = odn.random_state_dict(c["E"], c["H"], c["F"], c["nL"], c["V"], c["L"], c["Tt"], seed=0)
+    for k, v in sd.items():
+        if v.is_floating_point() and k != "lm_head.weight":
+            v.requires_grad_(True)
+    sd["lm_head.weight"] = sd["word_embedding.weight"]
+    d = osc.make_diffusion(diffusion_steps=c["T"])
+    b = synthetic.training_batch(n_seq, c["L"], seed=1)
+    t = torch.tensor([(17 + 613 * i) % c["T"] for i in range(n_seq)])
+
+    def step():
+        for v in sd.values():
+            v.grad = None
+        terms = olo.training_losses(d, lambda x, ts: odn.forward(sd, x, ts, c["nh"]), lambda ids: odn.get_embeds(sd, ids),
+                                    lambda h: odn.get_logits(sd, h), t, b["input_ids"], b["input_mask"], correct_ids=b["correct_ids"])
+        terms["loss"].mean().backward()
+    cores = best_thread_count(step)
+    step()
+    n, t0 = 0, time.perf_counter()
+    while True:
+        step()
+        n += 1
+        el = time.perf_counter() - t0
+        if (n >= 3 and el > seconds_budget / 2) or n >= 10 or (n >= 2 and el > seconds_budget):
+            break
+    per_micro = el / n * c["B"] / n_seq
+    out = {"value": 1.0 / per_micro, "unit": "micro-batches/s (training_losses fwd+bwd, %d x %d tokens)" % (c["B"], c["L"]), "cores": cores,
+           "kind": "port", "sample": "oracle training_losses_seq2seq_with_corruption forward + backward (torch CPU fp32 autograd, %d threads) on %d "
+                                     "of the %d sequences of a micro-batch, seq_len %d: %d timed repetitions in %.1f s after warm-up; value = "
+                                     "measured rate x %d/%d (cost is linear in the batch); the optimizer step is not included"
+                                     % (cores, n_seq, c["B"], c["L"], n, el, n_seq, c["B"])}
+    out.update(host_description())
+    return out
 
 
 def train_main(args, world, rank, local_rank, device):
@@ -328,23 +483,54 @@ def train_main(args, world, rank, local_rank, device):
         return losses, gn
     elapsed, (losses, gn) = timed_region(timed, world, device)
     assert bool(torch.isfinite(losses["loss"])) and bool(torch.isfinite(gn).all())
+    # the gradient all-reduce's EXPOSED time: the same steps with DDP's all-reduce suppressed on every micro-batch (no_sync) - the
+    # difference is what the collective adds to a step after its overlap with the backward (0 by construction at N = 1)
+    nosync_ms = None
+    if world > 1:
+        def timed_nosync():
+            for _ in range(args.steps):
+                with ddp.no_sync():
+                    loop.forward_backward(cond)
+                loop.optimize()
+                loop.step += 1
+        nosync_ms = timed_region(timed_nosync, world, device)[0] / args.steps * 1e3
+    ev = dist_evidence(world, device, local_rank)
+    n_params = sum(p.numel() for p in model.parameters())
+    ms_per_step = elapsed / args.steps * 1e3
+    out = None
     if rank == 0:
         N = c["B"] * c["L"] * args.accum
         fwd = (step_flops(dict(c)) - 2 * c["B"] * c["L"] * c["V"] * c["E"] + 2 * 2 * c["B"] * c["L"] * c["V"] * c["E"]) * args.accum
         out = {"metric": "training-steps/sec (optimizer steps: %d x training_losses fwd+bwd at seq_len=%d, batch=%d/GPU, + AdamW/EMA)"
                          % (args.accum, c["L"], c["B"]),
                "value": round(args.steps / elapsed, 3), "unit": "optimizer steps/s", "n_gpus": world,
-               "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+               "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
                "config": {"workload": "TrainLoop.run_step: training_losses_seq2seq_with_corruption fwd+bwd (train mode, dropout %.2f) "
                                       "x %d micro-batches, DDP all-reduce on the last, fused AdamW + 3 EMA; seq_len=%d microbatch=%d/GPU "
                                       "d_model=%d layers=%d" % (model.dropout.p, args.accum, c["L"], c["B"], c["H"], c["nL"]),
                           "global_batch": c["B"] * args.accum * world, "seq_len": c["L"], "parallelism": "ddp x%d" % world,
-                          "rccl_ranks": world, "microbatches_per_step": args.accum,
+                          "backend": ev["backend"], "rccl_ranks": ev["rccl_ranks"], "devices": ev["devices"],
+                          "distinct_devices": ev["distinct_devices"], "microbatches_per_step": args.accum,
                           "ms_per_microbatch": round(elapsed / args.steps / args.accum * 1e3, 3),
                           "tokens_per_s": round(world * args.steps * N / elapsed, 1),
                           "approx_tflops": round(3 * fwd / (elapsed / args.steps) / 1e12, 2),
+                          "gradient_bytes_all_reduced_per_step": n_params * 4,
+                          "ms_per_step_without_all_reduce": None if nosync_ms is None else round(nosync_ms, 3),
+                          "all_reduce_exposed_ms": None if nosync_ms is None else round(ms_per_step - nosync_ms, 3),
                           "loss": round(float(losses["loss"]), 4), "grad_norm": round(float(gn), 4)}}
+    if not args.no_kernel_timing:
+        # every launch of one optimizer step bracketed by HIP events (all ranks run it: the step holds a collective)
+        recs = collect_launches(lambda: loop.run_step(cond), 2)
+        if rank == 0:
+            cc = dict(c, n_params=n_params)
+            rows, span_sum = kernel_rows(recs, cc, 1, 2, ms_per_step)
+            out["roofline"] = roofline_from_rows(rows, span_sum, ms_per_step, args.dtype, "train", 1, 2, what="optimizer step")
+            out["kernels"] = [{k: v for k, v in r.items() if k != "work_per_launch"} for r in rows if r["share"] >= 0.004]
+    if rank == 0:
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline_train(c)
+            out["cpu_baseline"]["value"] = round(out["cpu_baseline"]["value"], 6)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
@@ -427,6 +613,35 @@ def assert_same_on_all_ranks(value, what, world, device):
         raise SystemExit("bench.py: %s differs across ranks: %s" % (what, vals))
 
 
+def make_loop(model, diff, c, kind, device, rank, need):
+    """The captured reverse step of the workload as a _ReverseLoop over `need` iterations: `kind` "p" = p_sample with rounding, clamp
+    and top_p = 1 (BASELINE configs[1], [3]); "ddim" = ddim_sample with rounding (configs[2])."""
+    from functools import partial
+    from musediffusion_amd import synthetic
+    from musediffusion_amd.models.diffusion import _ReverseLoop
+    from musediffusion_amd.models.rounding import denoised_fn_round
+    batch = synthetic.generation_batch(c["B"], c["L"], seed=1 + rank)
+    ids, mask = batch["input_ids"].to(device), batch["input_mask"].to(device)
+    x_start = model.get_embeds(ids)
+    mask3 = torch.broadcast_to(mask.unsqueeze(-1), x_start.shape)
+    torch.manual_seed(105)
+    x_noised = torch.where(mask3 == 0, x_start, torch.randn_like(x_start))
+    model_emb = torch.nn.Embedding(c["V"], c["E"], _weight=model.word_embedding.weight.clone()).eval().requires_grad_(False)
+    fn = partial(denoised_fn_round, model_emb, dist=None)
+    indices = (list(range(c["T"]))[::-1] * (need // c["T"] + 1))[:need]     # (a timed region longer than T steps wraps around)
+    loop = _ReverseLoop.try_build(diff, kind, model, x_noised, True, fn, 1 if kind == "p" else None, mask3, x_start, 0.0, indices,
+                                  lambda i: fn, False)
+    assert loop is not None, "fused reverse loop unavailable"
+    return loop
+
+
+def step_tables(loop, c, args, ms_per_step, first_k, n_prof=4):
+    """`roofline` + `kernels` of a captured step from its eager, per-launch-timed twin (profile_step)."""
+    rows, span_sum = profile_step(loop, c, first_k, n_prof, ms_per_step)
+    roof = roofline_from_rows(rows, span_sum, ms_per_step, args.dtype, args.workload, int(loop.nsplit), n_prof)
+    return roof, [{k: v for k, v in r.items() if k != "work_per_launch"} for r in rows if r["share"] >= 0.002]
+
+
 def sampling_main(args, world, rank, local_rank, device):
     """`--workload c3 | c4`: the reference's sampling block (run/sample.py:185-220) end to end through
     musediffusion_amd.sampling: rank 0 owns the weights -> ONE packed RCCL broadcast -> every rank samples its contiguous
@@ -437,7 +652,9 @@ def sampling_main(args, world, rank, local_rank, device):
     c = WORKLOADS[args.workload]
     model, diff = build(c, args.dtype, device, seed=rank)          # different weights per rank until the broadcast
     sharding.broadcast_weights(model, src=0, packed=True)
-    assert_same_on_all_ranks(sharding.weights_checksum(model), "weight arena checksum after the broadcast", world, device)
+    arena_sum = sharding.weights_checksum(model)
+    assert_same_on_all_ranks(arena_sum, "weight arena checksum after the broadcast", world, device)
+    ev = dist_evidence(world, device, local_rank)
     diff.rng_mode, diff.rng_seed, diff.rng_stream = args.rng, 105, rank
     diff.use_graph = not args.no_graph
     Bg = c["B"] * world
@@ -469,9 +686,21 @@ def sampling_main(args, world, rank, local_rank, device):
                                       "embed + start latent + loop set-up (graph capture) + loop + logits argmax + token all-gather"
                                       % (args.workload, what, c["L"], c["B"], Bg, c["H"], c["nL"]),
                           "global_batch": Bg, "seq_len": c["L"], "parallelism": "batch-sharded x%d" % world,
-                          "rccl_ranks": world, "weights": "one packed-arena broadcast from rank 0 (%.1f MB)" % (model.engine().arena_bytes() / 1e6),
+                          "backend": ev["backend"], "rccl_ranks": ev["rccl_ranks"], "devices": ev["devices"], "distinct_devices": ev["distinct_devices"],
+                          "weights": "one packed-arena broadcast from rank 0 (%.1f MB)" % (model.engine().arena_bytes() / 1e6),
+                          "arena_checksum_after_broadcast": int(arena_sum),
                           "rng": args.rng, "hipgraph": not args.no_graph,
                           "step_tflops_achieved": round(flops / (ms * 1e-3) / 1e12, 2)}}
+        if not args.no_kernel_timing:
+            # the same captured step as a stand-alone loop (this rank's shard), every launch timed: whole-call ms_per_step is the scale
+            ploop = make_loop(model, diff, c, "p" if args.workload == "c4" else "ddim", device, rank, 16)
+            with torch.no_grad():
+                ploop.begin()
+                ploop.advance(0)
+            out["roofline"], out["kernels"] = step_tables(ploop, c, args, ms, 1)
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(c, kind="p" if args.workload == "c4" else "ddim")
+            out["cpu_baseline"]["value"] = round(out["cpu_baseline"]["value"], 5)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
@@ -528,9 +757,12 @@ def main():
         _lib.lib().mh_attention_set_stream(0)
     c = WORKLOADS[args.workload]
     model, diff = build(c, args.dtype, device, seed=rank)     # different weights per rank until the broadcast
+    arena_sum = None
     if world > 1:
         sharding.broadcast_weights(model, src=0, packed=True)   # ONE RCCL broadcast of the packed arena
-        assert_same_on_all_ranks(sharding.weights_checksum(model), "weight arena checksum after the broadcast", world, device)
+        arena_sum = sharding.weights_checksum(model)
+        assert_same_on_all_ranks(arena_sum, "weight arena checksum after the broadcast", world, device)
+    ev = dist_evidence(world, device, local_rank)
     diff.rng_mode, diff.rng_seed, diff.rng_stream = args.rng, 105, rank
     diff.use_graph = not args.no_graph
     if args.split is not None:
@@ -540,22 +772,9 @@ def main():
     if args.skew_us is not None:
         diff.branch_skew_us = args.skew_us
 
-    batch = synthetic.generation_batch(c["B"], c["L"], seed=1 + rank)
-    ids, mask = batch["input_ids"].to(device), batch["input_mask"].to(device)
-    x_start = model.get_embeds(ids)
-    mask3 = torch.broadcast_to(mask.unsqueeze(-1), x_start.shape)
-    torch.manual_seed(105)
-    x_noised = torch.where(mask3 == 0, x_start, torch.randn_like(x_start))
-    model_emb = torch.nn.Embedding(c["V"], c["E"], _weight=model.word_embedding.weight.clone()).eval().requires_grad_(False)
-    fn = partial(denoised_fn_round, model_emb, dist=None)
-
     total = args.warmup + args.steps
     PROF_STEPS = 4
-    need = total + PROF_STEPS + 2
-    indices = (list(range(c["T"]))[::-1] * (need // c["T"] + 1))[:need]     # (a timed region longer than T steps wraps around)
-    loop = _ReverseLoop.try_build(diff, "p", model, x_noised, True, fn, 1, mask3, x_start, 0.0, indices,
-                                  lambda i: fn, False)
-    assert loop is not None, "fused reverse loop unavailable"
+    loop = make_loop(model, diff, c, "p", device, rank, total + PROF_STEPS + 2)
     with torch.no_grad():
         loop.begin()
         for k in range(args.warmup):
@@ -585,43 +804,19 @@ def main():
                                    "ffn=%d E=%d vocab=%d T=%d, rounding+clamp+top_p=1 every step"
                                    % (args.workload, c["L"], c["B"], c["H"], c["nL"], c["nh"], c["F"], c["E"], c["V"], c["T"]),
                        "global_batch": c["B"] * world, "seq_len": c["L"], "parallelism": "batch-sharded x%d" % world,
-                       "rccl_ranks": world, "rng": args.rng, "hipgraph": not args.no_graph, "graph_branches": int(loop.nsplit),
+                       "backend": ev["backend"], "rccl_ranks": ev["rccl_ranks"], "devices": ev["devices"], "distinct_devices": ev["distinct_devices"],
+                       "arena_checksum_after_broadcast": None if arena_sum is None else int(arena_sum),
+                       "rng": args.rng, "hipgraph": not args.no_graph, "graph_branches": int(loop.nsplit),
                        "decoupled_branches": bool(loop.decoupled), "branch_skew_us": int(getattr(loop, "skew_us", 0)),
                        "step_tflop": round(flops / 1e12, 4),
                        "step_tflops_achieved": round(flops / (ms_per_step * 1e-3) / 1e12, 2),
                        "sequences_steps_per_s": round(value * c["B"], 1)},
         }
         if not args.no_kernel_timing:
-            # the dominant kernel = the kernel SYMBOL with the largest share of the step, measured inside the step (profile_step);
-            # its launches of different shapes are pooled: achieved = their mean algorithmic flops / their mean in-step duration
-            rows, span_sum = profile_step(loop, c, total, PROF_STEPS, ms_per_step)
-            sym = lambda r: r["kernel"].split(" [")[0]
-            pools = {}
-            for r in rows:
-                if r["bound"] in ("mfma", "mfma_f32") and r.get("work_per_launch"):
-                    pools.setdefault(sym(r), []).append(r)
-            dom = max(pools.values(), key=lambda rs: sum(r["share"] for r in rs))
-            n_l = sum(r["launches_per_step"] for r in dom)
-            share = sum(r["share"] for r in dom)
-            fpl = sum(r["work_per_launch"] * r["launches_per_step"] for r in dom) / n_l
-            avg_ms = share * ms_per_step / n_l
-            ach = fpl / (avg_ms * 1e-3) / 1e12
-            peak = MFMA_PEAK_TFLOPS[args.dtype]
-            variant = sym(dom[0])
-            out["roofline"] = {"bound": "mfma", "kernel": variant + ": " + "; ".join(r["kernel"].split(" [")[1].rstrip("]") for r in dom),
-                               "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                               "traffic": pmc_traffic(args.workload, args.dtype, int(loop.nsplit), variant),
-                               "avg_launch_ms": round(avg_ms, 5), "launches_per_step": n_l, "share_of_step": round(share, 4),
-                               "how": "in-step: HIP events around every launch of the eager step on its own stream (%d steps); "
-                                      "share = spans of this kernel / all spans (sum %.3f ms per step on %d concurrent streams vs %.3f ms "
-                                      "wall); avg_launch_ms = share x ms_per_step / launches" % (PROF_STEPS, span_sum, int(loop.nsplit), ms_per_step),
-                               "concurrent_streams": int(loop.nsplit),
-                               "stream_span_ms": round(sum(r["stream_span_ms"] * r["launches_per_step"] for r in dom) / n_l, 5),
-                               "flops_per_launch": fpl}
+            out["roofline"], out["kernels"] = step_tables(loop, c, args, ms_per_step, total, PROF_STEPS)
             iso_ms, iso_f, _, _ = time_dominant_kernel(c, args.dtype, device, reps=5, branches=int(loop.nsplit))
             out["roofline"]["isolated"] = {"avg_launch_ms": round(iso_ms, 5), "achieved": round(iso_f / (iso_ms * 1e-3) / 1e12, 2),
                                            "note": "secondary: the full-row GEMM + LayerNorm kernel alone in a loop on fresh operands"}
-            out["kernels"] = [{k: v for k, v in r.items() if k != "work_per_launch"} for r in rows if r["share"] >= 0.002]
         if not args.no_cpu_baseline and world == 1:     # the host baseline is a rank-0, N = 1 measurement
             out["cpu_baseline"] = cpu_baseline(c)
             out["cpu_baseline"]["value"] = round(out["cpu_baseline"]["value"], 5)

@@ -419,9 +419,11 @@ int launch_bwd(const bf16* q, const bf16* k, const bf16* v, const bf16* qT, cons
   const int nbh = B * nh, nitems = nbh * ((L + 255) / 256);
   const dim3 grid((unsigned)(nitems < cus ? nitems : cus)), block(512);
   const float sl2 = scale * 1.4426950408889634f;
+  mh_prof_note("attn_bwd B*nh=%d L=%d dh=%d", nbh, L, DH);
   MH_LAUNCH((attn_bwd_dq_kernel<DH, DROP, FULL>), grid, block, bytes_dq, s, q, k, v, kT, dO, o, lse2, Dv, dq, ld, L, nh, nbh, scale, sl2, lqkv, ldo,
             keep_bits, rscale);
   MH_CHECK_LAUNCH();
+  mh_prof_note("attn_bwd B*nh=%d L=%d dh=%d", nbh, L, DH);
   MH_LAUNCH((attn_bwd_dkv_kernel<DH, DROP, FULL>), grid, block, bytes_dkv, s, q, k, v, qT, dO, dOT, lse2, Dv, dk, dv, ld, L, nh, nbh, scale, sl2, lqkv, ldo,
             keep_bits, rscale);
   MH_CHECK_LAUNCH();

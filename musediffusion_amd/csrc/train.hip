@@ -848,6 +848,7 @@ __global__ void sum_slices_kernel(const float* __restrict__ in, int slices, int6
 
 extern "C" int mh_sum_slices(const float* in, int slices, int64_t n, float* out, mh_stream_t stream) {
   MH_CHECK_ARG(in && out && slices > 0 && n > 0 && n % 4 == 0, "sum_slices: bad arguments (n must be a multiple of 4)");
+  mh_prof_note("slices=%d n=%lld", slices, (long long)n);
   MH_LAUNCH(sum_slices_kernel, dim3(tgrid(n / 4)), dim3(TB), 0, (hipStream_t)stream, in, slices, n, out);
   MH_CHECK_LAUNCH();
   return MH_OK;
@@ -898,6 +899,7 @@ extern "C" int mh_adamw_ema_step(const mh_opt_tensor* tensors, const mh_opt_chun
                                  const mh_opt_hparams* hp, mh_stream_t stream) {
   MH_CHECK_ARG(tensors && chunks && hp && n_chunks > 0, "adamw_ema_step: bad arguments");
   MH_CHECK_ARG(hp->n_ema >= 0 && hp->n_ema <= 4, "adamw_ema_step: at most 4 EMA copies");
+  mh_prof_note("chunks=%d n_ema=%d", n_chunks, hp->n_ema);
   MH_LAUNCH(adamw_ema_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, tensors, chunks, *hp);
   MH_CHECK_LAUNCH();
   return MH_OK;

@@ -20,7 +20,20 @@ CONFIGS.update({
     # ... with the released checkpoints' embedding width (README.md:534: "embedding dim 500")
     "bb500": dict(H=768, nL=2, nh=12, F=3072, E=500, Tt=128, L=32, B=2, V=729),
 })
-SEEDS = {"tiny": 0, "same": 1, "c1": 2, "bb": 3, "bb500": 4}
+CONFIGS.update({
+    # the BENCHMARKED shapes at two layers / two sequences (round 3): BASELINE config 2's width and seq_len 512 - the streaming
+    # attention, the 128x512 full-row tile and the 256x128 tiles of the bf16 path run under outputs of the reference itself ...
+    "c2s": dict(H=512, nL=2, nh=8, F=2048, E=128, Tt=128, L=512, B=2, V=729),
+    # ... and config 5's seq_len 1024 (training_losses both variants, dropout 0 and injected masks)
+    "c5s": dict(H=512, nL=2, nh=8, F=2048, E=128, Tt=128, L=1024, B=2, V=729),
+})
+SEEDS = {"tiny": 0, "same": 1, "c1": 2, "bb": 3, "bb500": 4, "c2s": 5, "c5s": 6}
+COMPACT = ("c1", "bb", "bb500", "c2s")   # model fixtures that keep every 8th position of [B, L, *] outputs and no inputs
+
+
+def slim(t):
+    """What a 'slim' loss fixture keeps of a gradient: every 4th row and column of a matrix with more than 64 K elements."""
+    return t[::4, ::4] if (t.dim() == 2 and t.numel() > 65536) else t
 DROPOUT_P = 0.1   # the reference's train-mode rate at all three kinds of site (config/train.py:61, bert-base config)
 EMB_STD = 0.5
 NOISING_T = 150

@@ -46,7 +46,7 @@ def G(g, name):
 
 def sub(t, tag):
     t = t.detach().float().cpu()
-    return t[:, ::8] if (tag in ("c1", "bb", "bb500") and t.dim() == 3) else t
+    return t[:, ::8] if (tag in fx.COMPACT and t.dim() == 3) else t
 
 
 def maxerr(a, b):
@@ -66,13 +66,13 @@ def loop_noises(seed, shape, n, top_p):
 
 
 # bb / bb500: the only encoder shape the reference itself instantiates (H 768, 12 heads of 64, ffn 3072; network.py:44-46), with
-# E = 128 and with the released checkpoints' E = 500
-@pytest.mark.parametrize("tag", ["tiny", "same", "c1", "bb", "bb500"])
+# E = 128 and with the released checkpoints' E = 500.  c2s: BASELINE config 2's width and seq_len 512 (the benchmarked shape; 2 layers)
+@pytest.mark.parametrize("tag", ["tiny", "same", "c1", "bb", "bb500", "c2s"])
 def test_model_surface(tag):
     m, diff, model_emb, inp, c = build(tag)
     g = load_golden("model_%s.npz" % tag)
     y = m(inp["fwd_x"].to(DEV), inp["fwd_t"].to(DEV), input_ids="ignored", anything_else=1)   # **_ is dropped
-    assert maxerr(sub(y, tag), G(g, "fwd_y")) < (2e-4 if c["H"] >= 768 else 1e-4)   # 768- / 3072-term fp32 sums in another order
+    assert maxerr(sub(y, tag), G(g, "fwd_y")) < (2e-4 if c["H"] >= 512 else 1e-4)   # 512- ... 3072-term fp32 sums in another order
     ids = inp["batch"]["correct_ids"]
     assert torch.equal(m.get_embeds(ids.to(DEV)).cpu(), inp["x_start"])
     assert torch.equal(m.get_embeds(ids.int().to(DEV)).cpu(), inp["x_start"])
@@ -90,7 +90,7 @@ def test_model_surface(tag):
     assert idx.shape[0] == 1 and torch.equal(idx[0].cpu(), G(g, "round_idx").long())
 
 
-@pytest.mark.parametrize("tag", ["tiny", "same", "c1"])
+@pytest.mark.parametrize("tag", ["tiny", "same", "c1", "c2s"])
 def test_start_latents_and_q_sample_bit_exact(tag):
     m, diff, model_emb, inp, c = build(tag)
     g = load_golden("model_%s.npz" % tag)
@@ -104,7 +104,7 @@ def test_start_latents_and_q_sample_bit_exact(tag):
     assert torch.equal(sub(q, tag), G(g, "q_out"))
 
 
-@pytest.mark.parametrize("tag", ["tiny", "same", "c1"])
+@pytest.mark.parametrize("tag", ["tiny", "same", "c1", "c2s"])
 def test_single_reverse_steps(tag):
     m, diff, model_emb, inp, c = build(tag)
     g = load_golden("model_%s.npz" % tag)
@@ -165,7 +165,7 @@ def run_loops(tag, m, diff, model_emb, inp, c, use_graph):
 
 
 @pytest.mark.parametrize("use_graph", [False, True], ids=["eager", "hipgraph"])
-@pytest.mark.parametrize("tag", ["tiny", "same", "c1", "bb", "bb500"])
+@pytest.mark.parametrize("tag", ["tiny", "same", "c1", "bb", "bb500", "c2s"])
 def test_loops_final_tokens_exact_fp32(tag, use_graph):
     m, diff, model_emb, inp, c = build(tag)
     g = load_golden("model_%s.npz" % tag)
@@ -180,12 +180,19 @@ def test_loops_final_tokens_exact_fp32(tag, use_graph):
         assert maxerr(sub(s, tag), G(g, "loop_%s" % key)) < 2e-5, key
 
 
-@pytest.mark.parametrize("tag", ["c1", "bb", "bb500"])
+@pytest.mark.parametrize("tag", ["c1", "bb", "bb500", "c2s"])
 def test_loops_bf16_token_agreement(tag):
-    """bf16 throughput mode (panel layout; bb500: E = 500 zero-padded inside the arena) against the reference's fp32 tokens."""
+    """bf16 throughput mode (panel layout; bb500: E = 500 zero-padded inside the arena) against the reference's fp32 tokens.
+    c2s (d_model 512, seq_len 512): the kernels of the benchmarked step - streaming attention, 128x512 full-row tile with the LayerNorm
+    epilogue, 256x128 tiles - under the reference's own outputs; its forward is also held to the stated bf16 tolerance."""
     m, diff, model_emb, inp, c = build(tag, "bf16")
     assert m.engine().cfg["panel"] == 1
     g = load_golden("model_%s.npz" % tag)
+    if tag == "c2s":
+        y = m(inp["fwd_x"].to(DEV), inp["fwd_t"].to(DEV))
+        d = (sub(y, tag) - G(g, "fwd_y")).abs()
+        print("bf16 c2s forward vs the reference: mean |d| %.4f max %.4f (ref absmax %.2f)" % (float(d.mean()), float(d.max()), float(G(g, "fwd_y").abs().max())))
+        assert float(d.mean()) < 0.02 and float(d.max()) < 0.25
     res = run_loops(tag, m, diff, model_emb, inp, c, True)
     for key in ("ddim50", "p12", "mod"):
         tokens = m.argmax_tokens(res[key]).cpu()
@@ -289,6 +296,22 @@ def test_batch_split_branches_equal_single_stream():
     ref = outs[(1, True, False)]
     for k, v in outs.items():
         assert torch.equal(v, ref), "batch_split=%d graph=%s decoupled=%s differs" % k
+
+
+@pytest.mark.parametrize("segment", ["first", "last"])
+def test_bf16_drift_over_200_steps_at_full_config2_size(segment):
+    """bf16 (the benchmarked mode) against the fp32 parity mode over 200 clamped p_sample iterations at BASELINE config 2's FULL size,
+    same weights, same Philox noise (tools/drift_c2.py): every step re-rounds to embedding rows, so flipped roundings could compound.
+    Measured (round 3): per-step rounded-token agreement 0.9956 - 0.9985 throughout, final argmax tokens 0.9990 / 0.9966 - no
+    compounding.  Stated tolerance: >= 0.99 at every step and for the final tokens (bit-exactness is the fp32 mode's property)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import drift_c2
+    r = drift_c2.run(steps=200, batch=64, segment=segment)
+    print(r)
+    assert r["agreement_min"] >= 0.99 and r["final_token_agreement"] >= 0.99, r
+    assert r["agreement_last_step"] >= r["agreement_step0"] - 0.005, "token agreement decays along the loop: %s" % r
 
 
 def test_full_size_config2_properties():

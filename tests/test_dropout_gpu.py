@@ -255,6 +255,40 @@ def test_training_losses_with_injected_masks_match_reference(variant):
     close(variant + " grad lm_head.bias", m.lm_head.bias.grad, g[variant + "_g_lmb"], 2e-3)
 
 
+@pytest.mark.parametrize("compute_dtype", ["fp32", "bf16"])
+def test_training_losses_with_injected_masks_at_config5_shape(compute_dtype):
+    """c5s (seq_len 1024, d_model 512): the reference ran in TRAIN mode with the masks of fixtures.dropout_masks; the product fed the
+    same masks - in bf16 through the streaming attention's keep-bit reader, the dropout epilogue of the one-kernel dense + LayerNorm
+    and the fused backward kernels - against the reference's recorded losses and gradients ("corrupt" variant)."""
+    tag, variant = "c5s", "corrupt"
+    g = load_golden("losses_c5s_dropout.npz")
+    m, diff, c = build(tag, compute_dtype)
+    inject(m, tag)
+    li = fx.loss_inputs(tag)
+    batch, t, w = li["batch"], li["t"].to(DEV), li["w"].to(DEV)
+    with CpuDraws(fx.loss_seed(tag)):
+        terms = diff.training_losses(m, t, model_kwargs=dict(batch))
+    (terms["loss"] * w).mean().backward()
+    L0, L1 = m.input_transformers.layer[0], m.input_transformers.layer[1]
+    grads = {"g_word": m.word_embedding.weight.grad, "g_q0": L0.attention.self.query.weight.grad, "g_v1": L1.attention.self.value.weight.grad,
+             "g_ff2": L0.output.dense.weight.grad, "g_te0": m.time_embed[0].weight.grad, "g_lmb": m.lm_head.bias.grad}
+    for k in ("mse", "nll", "loss"):
+        close("%s %s" % (variant, k), terms[k], g["%s_%s" % (variant, k)], 5e-4 if compute_dtype == "fp32" else 3e-2)
+    for key, gr in grads.items():
+        if compute_dtype == "fp32":
+            ref = g["%s_%s" % (variant, key)]
+            if float(np.abs(ref).max()) < 1e-6:     # lm_head.bias: the reference's gradient is rounding noise around 0 (1e-8)
+                assert float((fx.slim(gr).detach().float().cpu() - torch.from_numpy(ref)).abs().max()) < 1e-8, key
+                continue
+            close("%s %s" % (variant, key), fx.slim(gr), ref, 2e-3)
+        else:
+            ref = torch.from_numpy(g["%s_%s" % (variant, key)]).flatten()
+            got = fx.slim(gr).detach().float().cpu().flatten()
+            cos = float(torch.nn.functional.cosine_similarity(got, ref, dim=0))
+            print("bf16 dropout %s: cosine %.5f" % (key, cos))
+            assert cos >= 0.99, (key, cos)
+
+
 def test_train_forward_with_injected_masks_and_eval_identity():
     tag = "tiny"
     g = load_golden("losses_tiny_dropout.npz")

@@ -48,8 +48,9 @@ def test_two_rank_ddp_gradients_match_golden():
 def test_bench_gpus_2_self_launches_and_reports_two_ranks(workload):
     """`python bench.py --gpus 2` with NO launcher around it (what a SCALE run does): the parent starts two ranks through
     torch.distributed.run, they broadcast rank 0's weights, run the workload, gather, and rank 0 prints one JSON line with
-    n_gpus = rccl_ranks = 2.  Two GPUs: one rank per GPU over RCCL; one GPU: both ranks share it and the collectives run over gloo
-    (MUSE_BENCH_SHARE_GPU) - the code path above the backend is the same."""
+    n_gpus = 2.  Two GPUs: one rank per GPU over RCCL (backend nccl, rccl_ranks 2, two distinct device uuids); one GPU: both ranks
+    share it and the collectives run over gloo (MUSE_BENCH_SHARE_GPU) - the code path above the backend is the same, and the line
+    must SAY so: backend gloo, rccl_ranks 0, one distinct device (the fields that make an 8-GPU SCALE line un-fakeable)."""
     import json
     import torch
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
@@ -63,5 +64,13 @@ def test_bench_gpus_2_self_launches_and_reports_two_ranks(workload):
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, p.stdout[-2000:]
     out = json.loads(lines[0])
-    assert out["n_gpus"] == 2 and out["config"]["rccl_ranks"] == 2 and out["value"] > 0
+    assert out["n_gpus"] == 2 and out["value"] > 0 and len(out["config"]["devices"]) == 2
+    if env.get("MUSE_BENCH_SHARE_GPU") == "1":
+        assert out["config"]["backend"] == "gloo" and out["config"]["rccl_ranks"] == 0 and out["config"]["distinct_devices"] == 1
+    else:
+        assert out["config"]["backend"] == "nccl" and out["config"]["rccl_ranks"] == 2 and out["config"]["distinct_devices"] == 2
+    if workload != "train":
+        assert isinstance(out["config"]["arena_checksum_after_broadcast"], int)
+    else:
+        assert out["config"]["all_reduce_exposed_ms"] is not None and out["config"]["gradient_bytes_all_reduced_per_step"] > 0
     assert out["scaling"] == "weak" and out["config"]["global_batch"] == 2 * (32 if workload == "train" else 64)

@@ -1,0 +1,80 @@
+#!/usr/bin/env python3
+"""bf16 against fp32 compute mode over a long clamped loop at BASELINE config 2's full size (seq_len 512, batch 64, d_model 512,
+12 layers): same weights, same start latent, same Philox noise (counter-based: a function of (seed, step, element), so both runs
+draw identical noise whatever their latents are).  Every step snaps pred_xstart to an embedding row, so one flipped rounding changes
+the trajectory: prints, per step, the share of positions whose rounded token agrees, the first step at which any token differs, and
+the agreement of the FINAL argmax tokens (what run/sample.py:219-220 returns).
+
+    python tools/drift_c2.py [--steps 200] [--batch 64]            -> one JSON line
+"""
+import argparse
+import json
+import os
+import sys
+from functools import partial
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def run(steps=200, batch=64, L=512, seed=105, dev="cuda", segment="first"):
+    """segment "first": iterations t = 1999 .. 2000 - steps of the 2000-step loop from the reference's start latent (run/sample.py:185-190,
+    `t_enc=steps`); "last": iterations t = steps - 1 .. 0 - the same process restricted to its last `steps` timesteps (SpacedDiffusion
+    over the contiguous set {0 .. steps - 1}: identical betas), started from q_sample(x_start, steps - 1), where the tokens settle."""
+    from musediffusion_amd import synthetic
+    from musediffusion_amd.models.diffusion import SpacedDiffusion, get_named_beta_schedule, space_timesteps
+    from musediffusion_amd.models.network import TransformerNetModel
+    from musediffusion_amd.models.rounding import denoised_fn_round
+    c = dict(L=L, B=batch, E=128, H=512, nL=12, nh=8, F=2048, V=729, Tt=128)
+    models = {}
+    for cd in ("bf16", "fp32"):
+        torch.manual_seed(0)
+        m = TransformerNetModel(c["E"], c["E"], c["Tt"], c["V"], c["L"], dropout=0.1, bert_hidden=c["H"], bert_layers=c["nL"],
+                                bert_heads=c["nh"], bert_ffn=c["F"], compute_dtype=cd)
+        models[cd] = m.eval().requires_grad_(False).to(dev)
+    models["fp32"].load_state_dict(models["bf16"].state_dict())
+    m = models["bf16"]
+    use = space_timesteps(2000, [2000]) if segment == "first" else set(range(steps))
+    diff = SpacedDiffusion(use_timesteps=use, betas=get_named_beta_schedule("sqrt", 2000), rescale_timesteps=True, predict_xstart=True)
+    b = synthetic.generation_batch(c["B"], c["L"], seed=1)
+    ids, mask = b["input_ids"].to(dev), b["input_mask"].to(dev)
+    x_start = m.get_embeds(ids)
+    mask3 = torch.broadcast_to(mask.unsqueeze(-1), x_start.shape)
+    torch.manual_seed(seed)
+    x_noised = torch.where(mask3 == 0, x_start, torch.randn_like(x_start))
+    if segment == "last":
+        x_noised = diff.q_sample(x_start, torch.full((c["B"],), steps - 1, device=dev), noise=x_noised, mask=mask)
+    emb = torch.nn.Embedding(c["V"], c["E"], _weight=m.word_embedding.weight.clone()).eval().requires_grad_(False).to(dev)
+    fn = partial(denoised_fn_round, emb, dist=None)
+    diff.noise_fn, diff.rng_mode, diff.rng_seed, diff.rng_stream, diff.use_graph = None, "philox", seed, 0, True
+    kw = dict(shape=(c["B"], c["L"], c["E"]), noise=x_noised, clip_denoised=True, denoised_fn=fn, model_kwargs={}, top_p=1, clamp_step=0,
+              clamp_first=True, mask=mask3, x_start=x_start)
+    free = mask3[..., 0] != 0                                    # positions the loop generates (the rest is anchored)
+    traj = {}
+    for cd, mm in models.items():
+        preds = []
+        gen = diff.p_sample_loop_progressive(mm, t_enc=steps, **kw)
+        for out in gen:
+            preds.append(out["pred_xstart"].clone())
+        traj[cd] = (preds, out["sample"].clone())
+    agree = []
+    for a, bb in zip(traj["bf16"][0], traj["fp32"][0]):
+        same = (a == bb).all(dim=-1)                             # rounded rows equal <=> same token decision
+        agree.append(float(same[free].float().mean()))
+    first = next((k for k, v in enumerate(agree) if v < 1.0), None)
+    tok = {cd: models["fp32"].argmax_tokens(traj[cd][1]) for cd in traj}
+    final = float((tok["bf16"] == tok["fp32"])[free].float().mean())
+    return {"segment": segment, "steps": steps, "batch": batch, "seq_len": L, "free_positions": int(free.sum()),
+            "first_step_with_a_differing_token": first, "agreement_step0": agree[0], "agreement_min": min(agree),
+            "agreement_last_step": agree[-1], "final_token_agreement": final,
+            "agreement_every_20_steps": [round(v, 4) for v in agree[::20]]}
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--batch", type=int, default=64)
+    a = ap.parse_args()
+    for seg in ("first", "last"):
+        print(json.dumps(run(a.steps, a.batch, segment=seg)), flush=True)

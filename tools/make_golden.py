@@ -213,8 +213,10 @@ def gen_model_case(tag, compact):
     print("model_%s.npz" % tag, len(out), "arrays")
 
 
-def gen_losses(tag):
-    """training_losses both variants (diffusion.py:594-699), dropout 0, grads of four parameters."""
+def gen_losses(tag, slim=False):
+    """training_losses both variants (diffusion.py:594-699), dropout 0, grads of four parameters (slim: + two more, large
+    matrices kept as every 4th row and column - oracle.fixtures.slim)."""
+    keepg = (lambda t: npy(fx.slim(t))) if slim else npy
     cfg = fx.CONFIGS[tag]
     model, diffusion = build(cfg, dropout=0.0)
     sd = fx.state_dict(tag)
@@ -231,10 +233,13 @@ def gen_losses(tag):
         (terms["loss"] * w).mean().backward()
         for k in ("mse", "nll", "loss"):
             out["%s_%s" % (variant, k)] = npy(terms[k])
-        out["%s_g_word" % variant] = npy(model.word_embedding.weight.grad)
-        out["%s_g_q0" % variant] = npy(model.input_transformers.layer[0].attention.self.query.weight.grad)
-        out["%s_g_te0" % variant] = npy(model.time_embed[0].weight.grad)
-        out["%s_g_lmb" % variant] = npy(model.lm_head.bias.grad)
+        out["%s_g_word" % variant] = keepg(model.word_embedding.weight.grad)
+        out["%s_g_q0" % variant] = keepg(model.input_transformers.layer[0].attention.self.query.weight.grad)
+        out["%s_g_te0" % variant] = keepg(model.time_embed[0].weight.grad)
+        out["%s_g_lmb" % variant] = keepg(model.lm_head.bias.grad)
+        if slim:
+            out["%s_g_v1" % variant] = keepg(model.input_transformers.layer[1].attention.self.value.weight.grad)
+            out["%s_g_ff2" % variant] = keepg(model.input_transformers.layer[0].output.dense.weight.grad)
     np.savez_compressed(os.path.join(OUT, "losses_%s.npz" % tag), **out)
     print("losses_%s.npz" % tag, len(out), "arrays")
 
@@ -267,8 +272,9 @@ class InjectedDropout:
         torch.nn.functional.dropout = self.orig
 
 
-def gen_losses_dropout(tag):
+def gen_losses_dropout(tag, slim=False):
     """training_losses (both variants) in TRAIN mode with dropout 0.1 at the reference's three kinds of site, masks injected."""
+    keepg = (lambda t: npy(fx.slim(t))) if slim else npy
     cfg = fx.CONFIGS[tag]
     p = fx.DROPOUT_P
     model, diffusion = build(cfg, dropout=p)
@@ -288,16 +294,17 @@ def gen_losses_dropout(tag):
         (terms["loss"] * w).mean().backward()
         for k in ("mse", "nll", "loss"):
             out["%s_%s" % (variant, k)] = npy(terms[k])
-        out["%s_g_word" % variant] = npy(model.word_embedding.weight.grad)
-        out["%s_g_q0" % variant] = npy(model.input_transformers.layer[0].attention.self.query.weight.grad)
-        out["%s_g_v1" % variant] = npy(model.input_transformers.layer[1].attention.self.value.weight.grad)
-        out["%s_g_ff2" % variant] = npy(model.input_transformers.layer[0].output.dense.weight.grad)
-        out["%s_g_te0" % variant] = npy(model.time_embed[0].weight.grad)
-        out["%s_g_lmb" % variant] = npy(model.lm_head.bias.grad)
+        out["%s_g_word" % variant] = keepg(model.word_embedding.weight.grad)
+        out["%s_g_q0" % variant] = keepg(model.input_transformers.layer[0].attention.self.query.weight.grad)
+        out["%s_g_v1" % variant] = keepg(model.input_transformers.layer[1].attention.self.value.weight.grad)
+        out["%s_g_ff2" % variant] = keepg(model.input_transformers.layer[0].output.dense.weight.grad)
+        out["%s_g_te0" % variant] = keepg(model.time_embed[0].weight.grad)
+        out["%s_g_lmb" % variant] = keepg(model.lm_head.bias.grad)
     # the forward alone, train mode, same masks
     inp = fx.case_inputs(tag, model.word_embedding.weight.detach())
     with torch.no_grad(), InjectedDropout(tag, p):
-        out["fwd_y_train"] = npy(model(inp["fwd_x"], inp["fwd_t"]))
+        y = model(inp["fwd_x"], inp["fwd_t"])
+        out["fwd_y_train"] = npy(y[:, ::8] if slim else y)
     np.savez_compressed(os.path.join(OUT, "losses_%s_dropout.npz" % tag), **out)
     print("losses_%s_dropout.npz" % tag, len(out), "arrays")
 
@@ -344,6 +351,10 @@ if __name__ == "__main__":
         gen_losses("tiny")
     if not only or "dropout" in only:
         gen_losses_dropout("tiny")
+    if not only or "bench" in only:
+        gen_model_case("c2s", compact=True)      # BASELINE config 2's width and seq_len (2 layers, 2 sequences)
+        gen_losses("c5s", slim=True)             # config 5's seq_len 1024, same width
+        gen_losses_dropout("c5s", slim=True)
     if not only or "bertbase" in only:
         gen_model_case("bb", compact=True)       # the reference-true width (H 768, 12 heads of 64, ffn 3072)
         gen_model_case("bb500", compact=True)    # ... with the released weights' E = 500
