@@ -8,8 +8,11 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# MUSEHIP_LIB: A/B runs of two builds on one GPU box (tools/); the product always loads the in-tree build
-LIB_PATH = os.environ.get("MUSEHIP_LIB") or os.path.join(_HERE, "csrc", "libmusehip.so")
+# The product loads the in-tree build.  Another build is taken ONLY under the explicit A/B switch of tools/ab_lib.sh
+# (MUSEHIP_AB=1 MUSEHIP_LIB=<path>): a stray MUSEHIP_LIB alone changes nothing
+LIB_PATH = os.path.join(_HERE, "csrc", "libmusehip.so")
+if os.environ.get("MUSEHIP_AB") == "1" and os.environ.get("MUSEHIP_LIB"):
+    LIB_PATH = os.environ["MUSEHIP_LIB"]
 
 MH_F32, MH_BF16 = 0, 1
 ACT_NONE, ACT_TANH, ACT_GELU_ERF, ACT_SILU = 0, 1, 2, 3

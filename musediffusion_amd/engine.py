@@ -36,6 +36,10 @@ class DenoiserEngine:
         # (E % 4: the released checkpoints' E = 500 stays on this path - E is zero-padded to 64 inside the arena / input panels)
         c["panel"] = int(self.dtype == MH_BF16 and panel and c["E"] % 4 == 0 and dh % 32 == 0 and
                          c["H"] // 32 in (2, 4, 8, 12, 16, 24))
+        # deferred-LayerNorm operands (folded weights + two vectors per consumer: +58 % matrix bytes at config 2) are planned and packed
+        # only where the forward uses them: widths without a full-row LayerNorm epilogue (d_model 768), or when mode 2 (A/B: deferred
+        # everywhere) is already switched on at construction
+        c["fold_ln"] = int(c["panel"] and (not lib().mh_gemm_bias_res_ln_supported(c["H"]) or lib().mh_denoiser_get_defer_ln() == 2))
         self._plan = self._make_plan()
         self.arena = torch.zeros(self._plan["total"], dtype=torch.uint8, device=self.device)
         self._ws = None
@@ -75,7 +79,7 @@ class DenoiserEngine:
             mat(p + "w_ff1", F, H); vec(p + "b_ff1", F)
             mat(p + "w_ff2", H, F); vec(p + "b_ff2", H)
             vec(p + "ln2_g", H); vec(p + "ln2_b", H)
-            if c["panel"]:   # deferred LayerNorm (csrc/gemm.hip DeferArgs): weights folded with the gain of the LayerNorm feeding them
+            if c["fold_ln"]:   # deferred LayerNorm (csrc/gemm.hip DeferArgs): weights folded with the gain of the LayerNorm feeding them
                 if l > 0:
                     mat(p + "w_qkv_f", 3 * H, H); vec(p + "c1_qkv", 3 * H); vec(p + "c2_qkv", 3 * H)
                 mat(p + "w_ff1_f", F, H); vec(p + "c1_ff1", F); vec(p + "c2_ff1", F)
@@ -146,7 +150,7 @@ class DenoiserEngine:
             self._put_mat(p + "w_ff2", sd[s + "output.dense.weight"]); self._put_vec(p + "b_ff2", sd[s + "output.dense.bias"])
             self._put_vec(p + "ln2_g", sd[s + "output.LayerNorm.weight"])
             self._put_vec(p + "ln2_b", sd[s + "output.LayerNorm.bias"])
-            if c["panel"]:
+            if c["fold_ln"]:
                 f32 = lambda t: t.detach().to(self.device, torch.float32)
                 if l > 0:
                     ps = "input_transformers.layer.%d." % (l - 1)

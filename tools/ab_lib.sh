@@ -2,7 +2,7 @@
 # Same-box A/B of two library builds (how the round's kernel-level changes were judged: boxes of the pool differ by several percent,
 # only alternating runs on ONE box compare).  Builds a second libmusehip.so from another revision and / or with extra compiler
 # flags into tools/ab/ (git-ignored *.so; it travels to the GPU box with the tree), then on the box:
-#     MUSEHIP_LIB=$PWD/tools/ab/libmusehip_<tag>.so python bench.py --steps 100 --no-cpu-baseline --no-kernel-timing
+#     MUSEHIP_AB=1 MUSEHIP_LIB=$PWD/tools/ab/libmusehip_<tag>.so python bench.py --steps 100 --no-cpu-baseline --no-kernel-timing
 # alternated with the plain command, three times each.
 #   bash tools/ab_lib.sh head HEAD                      # the committed sources (against an edited working tree)
 #   bash tools/ab_lib.sh nt0 . -DMH_PP_A_AUX=0          # the working tree with another cache policy for the full-row tile's A operand
