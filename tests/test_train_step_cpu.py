@@ -107,3 +107,38 @@ def test_single_replica_eval_mode_restored_and_lr_anneal():
     for _ in range(3):
         loop.run_step(cond)
     assert loop.opt.lrs == [2.0, 1.5, 1.0]                             # lr * (1 - step / learning_steps), train_util.py:266-272
+
+
+def test_ema_rate_takes_the_reference_config_string():
+    """config/train.py:19 declares `ema_rate: str` and utils/train_util.py:63-67 parses it with split(','): an integrator forwards
+    args.ema_rate as is.  A float, a sequence and None (the reference's empty list) are accepted too."""
+    model = torch.nn.Linear(3, 1)
+    mk = lambda r: TrainStep(model, ToyDiffusion(), ema_rate=r, optimizer=HostOpt(list(model.parameters())))
+    assert mk("0.5,0.9,0.99").ema_rate == [0.5, 0.9, 0.99]
+    assert mk("0.9999").ema_rate == [0.9999]
+    assert mk(0.99).ema_rate == [0.99]
+    assert mk((0.5, 0.9)).ema_rate == [0.5, 0.9]
+    assert mk(None).ema_rate == []
+
+
+def test_optimize_clips_through_the_optimizer_and_returns_a_copy_of_the_norm():
+    """train_util.py:246-264: clip (through `opt.clip_grad_norm` when the optimizer has one), log the norm, step.  The returned norm
+    must not alias the optimizer's buffer (the fused optimizer overwrites it on the next step)."""
+    model = torch.nn.Linear(3, 1)
+
+    class ClipOpt(HostOpt):
+        def __init__(self, params):
+            super().__init__(params)
+            self.buf, self.clipped = torch.zeros(1), []
+
+        def clip_grad_norm(self, max_norm):
+            self.clipped.append(max_norm)
+
+        def grad_norm(self):
+            self.buf.fill_(float(len(self.lrs) + 1))
+            return self.buf
+    opt = ClipOpt(list(model.parameters()))
+    ts = TrainStep(model, ToyDiffusion(), gradient_clipping=0.5, optimizer=opt)
+    g1 = ts.optimize()
+    g2 = ts.optimize()
+    assert opt.clipped == [0.5, 0.5] and float(g1) == 1.0 and float(g2) == 2.0 and g1.data_ptr() != opt.buf.data_ptr()
