@@ -1,0 +1,295 @@
+// Micro-benchmark for the FFN1 question: can the GELU epilogue of tile t hide in the issue slots of tile t+1's MFMAs when a wave
+// has its SIMD to itself (512 registers: two accumulator sets)?  One "tile" = 16 K-steps of a 128x64 wave tile on mfma_16x16x32
+// (32 MFMAs + 12 ds_read_b128 [+ 6 LDS-DMA pieces] per K-step) + 16 epilogue groups (8 x (bias + GELU) + 4 cvt_pk + one 16-byte store).
+//   mode 0: MFMA K-steps only        mode 1: epilogue groups only
+//   mode 2: 16 K-steps, then 16 groups (today's structure)         mode 3: one epilogue group interleaved into every K-step
+// threads 256 = one wave per SIMD, 512 = two (today's two co-resident blocks).  DMA = 1: the K-steps also issue their 6 pieces.
+// Build: hipcc --offload-arch=gfx950 -O3 ffn1_overlap.hip -o ffn1_overlap
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+__device__ __forceinline__ float gelu_fast(float x) {
+  constexpr float kL2E = 1.4426950408889634f;
+  const float u = fminf(x * x, 64.0f);
+  float p = fmaf(0.0007030335771326705f * kL2E, u, -0.07401129204508086f * kL2E);
+  p = fmaf(p, u, -1.5950157685701116f * kL2E);
+  const float e = __builtin_amdgcn_exp2f(x * p);
+  return x * __builtin_amdgcn_rcpf(1.0f + e);
+}
+
+// the same wave tile on mfma_32x32x16 (16 per K-step, 16 ds_read_b64... here: 6 ds_read_b128 halves): does the larger shape leave
+// the issue port to the partner wave's vector instructions?  modes 0 / 1 / 2 / 4 as below
+template <int MODE, int THREADS>
+__global__ __launch_bounds__(THREADS) void k32(const bf16* __restrict__ src, bf16* __restrict__ dst, const float* __restrict__ bias, int tiles,
+                                               unsigned long long* cyc) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  char* mine = lds + (wave & 3) * 24576;
+  for (int i = tid; i < 4 * 24576 / 16; i += blockDim.x) reinterpret_cast<f32x4*>(lds)[i] = reinterpret_cast<const f32x4*>(src)[(i + blockIdx.x * 97) & 65535];
+  __syncthreads();
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.1f * i + 0.01f * r + 0.05f * lane;
+  float bv[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) bv[e] = bias[(lane * 8 + e) & 1023];
+  bf16* gdst = dst + ((size_t)blockIdx.x * blockDim.x + tid) * 8;
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int t = 0; t < tiles; ++t) {
+    auto kstep = [&](int kt) {
+      const char* st = mine + (kt % 3) * 8192;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {     // two k = 16 halves of a 32-deep K-step
+        bf16x8 a[4], b[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) b[j] = *reinterpret_cast<const bf16x8*>(st + ((kk * 2048 + j * 1024 + lane * 16) & 8191));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const bf16x8*>(st + ((4096 + kk * 2048 + i * 512 + lane * 16) & 8191));
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+      }
+    };
+    auto egroup = [&](int g) {
+      const int i = g >> 2, j = (g >> 1) & 1, h = g & 1;
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = gelu_fast(acc[i][j][8 * h + e] + bv[e]);
+      bf16x8 r;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) r[e] = (bf16)v[e];
+      f32x4 raw;
+      __builtin_memcpy(&raw, &r, 16);
+      __builtin_nontemporal_store(raw, reinterpret_cast<f32x4*>(gdst + ((size_t)g + 16 * (size_t)(t & 3)) * 8 * 131072));
+    };
+    auto zero = [&]() {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    };
+    if (MODE == 4 && wave >= 4) {
+#pragma unroll
+      for (int g = 0; g < 16; ++g) egroup(g);
+      zero();
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (MODE == 0 || MODE == 2 || MODE == 4) {
+#pragma unroll
+      for (int kt = 0; kt < 16; ++kt) { kstep(kt); __builtin_amdgcn_sched_barrier(0); }
+    }
+    if (MODE == 1 || MODE == 2 || (MODE == 4 && wave < 4)) {
+#pragma unroll
+      for (int g = 0; g < 16; ++g) egroup(g);
+      if (MODE == 1) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(acc[i][0]), "+v"(acc[i][1]));
+      } else zero();
+    }
+  }
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) s += acc[i][0][0] + acc[i][1][3];
+  if (s == 12345.678f) dst[0] = (bf16)s;
+  if (tid == 0) cyc[blockIdx.x] = (t1 - t0) / tiles;
+}
+
+template <int MODE, int DMA, int THREADS>
+__global__ __launch_bounds__(THREADS) void k(const bf16* __restrict__ src, bf16* __restrict__ dst, const float* __restrict__ bias, int tiles,
+                                         unsigned long long* cyc) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  char* mine = lds + (wave & 3) * 24576 + (wave >> 2) * 3 * 24576 * 0;   // the waves of a SIMD share the staging area (timing only)
+  // fill the staging area once so the fragments are not zeros
+  for (int i = tid; i < 4 * 24576 / 16; i += blockDim.x) reinterpret_cast<f32x4*>(lds)[i] = reinterpret_cast<const f32x4*>(src)[(i + blockIdx.x * 97) & 65535];
+  __syncthreads();
+  constexpr bool TWO = MODE == 3;      // a second accumulator set only where the epilogue of the previous tile rides in the K-loop
+  f32x4 acc[8][4], prev[TWO ? 8 : 1][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { acc[i][j] = f32x4{0.1f * i, 0.2f * j, -0.3f, 0.05f * lane}; if (TWO) prev[i][j] = acc[i][j]; }
+  float bv[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) bv[e] = bias[(lane * 8 + e) & 1023];
+  const bf16* gsrc = src + ((size_t)blockIdx.x * 64 + wave) * 8192 + lane * 8;
+  bf16* gdst = dst + ((size_t)blockIdx.x * blockDim.x + tid) * 8;
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int t = 0; t < tiles; ++t) {
+    auto kstep = [&](int kt) {
+      bf16x8 a[8], b[4];
+      const char* st = mine + (kt % 3) * 8192;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const bf16x8*>(st + ((j * 1024 + lane * 16) & 8191));
+#pragma unroll
+      for (int i = 0; i < 8; ++i) a[i] = *reinterpret_cast<const bf16x8*>(st + ((4096 + i * 512 + lane * 16) & 8191));
+      if (DMA) {
+#pragma unroll
+        for (int p = 0; p < 6; ++p)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc + (size_t)((kt * 6 + p) & 127) * 512),
+                                           (__attribute__((address_space(3))) void*)(mine + 16384 + (p & 7) * 1024), 16, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+      if (DMA) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    };
+    auto egroup = [&](int g) {   // group g = (row tile i = g >> 1, column half qh = g & 1): 8 values of the PREVIOUS tile's accumulators
+      const int i = g >> 1, qh = g & 1;
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = gelu_fast((TWO ? prev[TWO ? i : 0][2 * qh + (e >> 2)][e & 3] : acc[i][2 * qh + (e >> 2)][e & 3]) + bv[e]);
+      bf16x8 r;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) r[e] = (bf16)v[e];
+      f32x4 raw;
+      __builtin_memcpy(&raw, &r, 16);
+      __builtin_nontemporal_store(raw, reinterpret_cast<f32x4*>(gdst + ((size_t)g + 16 * (size_t)(t & 3)) * 8 * 131072));   // (a different row block per tile)
+    };
+    if (MODE == 4 && wave >= 4) {   // the second wave of every SIMD runs half a tile out of phase: its epilogue first
+#pragma unroll
+      for (int g = 0; g < 16; ++g) egroup(g);
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (MODE == 0 || MODE == 2 || MODE == 4) {
+#pragma unroll
+      for (int kt = 0; kt < 16; ++kt) { kstep(kt); __builtin_amdgcn_sched_barrier(0); }
+    }
+    if (MODE == 4 && wave < 4) {
+#pragma unroll
+      for (int g = 0; g < 16; ++g) egroup(g);
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    if (MODE == 1 || MODE == 2) {
+#pragma unroll
+      for (int g = 0; g < 16; ++g) egroup(g);
+      if (MODE == 1) {      // (keep the inputs loop-variant)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(acc[i][0]), "+v"(acc[i][1]), "+v"(acc[i][2]), "+v"(acc[i][3]));
+      }
+    }
+    if (MODE == 3) {
+#pragma unroll
+      for (int kt = 0; kt < 16; ++kt) {
+        kstep(kt);
+        egroup(kt);
+        // spread the group's ~100 vector instructions between the 32 MFMAs: 1 MFMA, then 3 VALU / transcendental slots
+#pragma unroll
+        for (int m = 0; m < 32; ++m) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
+          __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);   // 3 VALU
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    // the finished tile becomes the previous tile (register renaming, no moves in a real kernel: here a cheap dependency)
+    if (TWO) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { prev[i][j] = acc[i][j]; acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    } else if (MODE == 2) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) s += acc[i][j][0] + (TWO ? prev[TWO ? i : 0][j][1] : 0.f);
+  if (s == 12345.678f) dst[0] = (bf16)s;
+  if (tid == 0) cyc[blockIdx.x] = (t1 - t0) / tiles;
+}
+
+template <int MODE, int DMA, int THREADS>
+void run(const char* name, const bf16* src, bf16* dst, const float* bias, unsigned long long* cyc) {
+  const int tiles = 200;
+  const int threads = THREADS;
+  auto kern = k<MODE, DMA, THREADS>;
+  hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 24576);
+  kern<<<256, threads, 4 * 24576>>>(src, dst, bias, tiles, cyc);
+  hipDeviceSynchronize();
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  hipEventRecord(e0);
+  kern<<<256, threads, 4 * 24576>>>(src, dst, bias, tiles, cyc);
+  hipEventRecord(e1); hipEventSynchronize(e1);
+  float ms; hipEventElapsedTime(&ms, e0, e1);
+  unsigned long long c; hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost);
+  const int wps = threads / 256;
+  printf("%-44s dma %d  %d wave(s)/SIMD: %7llu cycles per tile per wave, %7.3f us per tile-round, %7.3f us per tile per SIMD\n", name, DMA, wps, c,
+         ms * 1e3 / tiles, ms * 1e3 / tiles / wps);
+}
+
+template <int MODE, int THREADS>
+void run32(const char* name, const bf16* src, bf16* dst, const float* bias, unsigned long long* cyc) {
+  const int tiles = 200, threads = THREADS;
+  auto kern = k32<MODE, THREADS>;
+  hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 24576);
+  kern<<<256, threads, 4 * 24576>>>(src, dst, bias, tiles, cyc);
+  hipDeviceSynchronize();
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  hipEventRecord(e0);
+  kern<<<256, threads, 4 * 24576>>>(src, dst, bias, tiles, cyc);
+  hipEventRecord(e1); hipEventSynchronize(e1);
+  float ms; hipEventElapsedTime(&ms, e0, e1);
+  const int wps = threads / 256;
+  printf("32x32x16: %-38s %d wave(s)/SIMD: %7.3f us per tile-round, %7.3f us per tile per SIMD\n", name, wps, ms * 1e3 / tiles, ms * 1e3 / tiles / wps);
+}
+
+int main() {
+  bf16 *src, *dst; float* bias; unsigned long long* cyc;
+  hipMalloc(&src, (size_t)256 * 64 * 8192 * 2 + (1 << 20)); hipMalloc(&dst, (size_t)64 * 8 * 131072 * 2 + (1 << 24)); hipMalloc(&bias, 4096); hipMalloc(&cyc, 256 * 8);
+  {  // random-ish operands
+    const size_t n = (size_t)256 * 64 * 8192 + (1 << 19);
+    unsigned short* h = (unsigned short*)malloc(n * 2);
+    unsigned x = 12345;
+    for (size_t i = 0; i < n; ++i) { x = x * 1664525u + 1013904223u; h[i] = (unsigned short)(0x3c00 + ((x >> 16) & 0x3ff) + ((x >> 31) << 15)); }
+    hipMemcpy(src, h, n * 2, hipMemcpyHostToDevice);
+    free(h);
+    float hb[1024]; for (int i = 0; i < 1024; ++i) hb[i] = 0.01f * (i % 37) - 0.2f;
+    hipMemcpy(bias, hb, 4096, hipMemcpyHostToDevice);
+  }
+#define ALL(T) \
+  run<0, 0, T>("K-steps only (32 MFMA + 12 ds_read each)", src, dst, bias, cyc); \
+  run<1, 0, T>("epilogue groups only", src, dst, bias, cyc); \
+  run<2, 0, T>("16 K-steps then 16 groups", src, dst, bias, cyc); \
+  run<3, 0, T>("a group interleaved into every K-step", src, dst, bias, cyc); \
+  run<4, 0, T>("waves 4-7 half a tile out of phase", src, dst, bias, cyc); \
+  run<0, 1, T>("K-steps only", src, dst, bias, cyc); \
+  run<2, 1, T>("16 K-steps then 16 groups", src, dst, bias, cyc); \
+  run<3, 1, T>("a group interleaved into every K-step", src, dst, bias, cyc);
+  ALL(256)
+  ALL(512)
+#define ALL32(T) \
+  run32<0, T>("K-steps only (16 MFMA 32x32x16)", src, dst, bias, cyc); \
+  run32<1, T>("epilogue groups only", src, dst, bias, cyc); \
+  run32<2, T>("16 K-steps then 16 groups", src, dst, bias, cyc); \
+  run32<4, T>("waves 4-7 half a tile out of phase", src, dst, bias, cyc);
+  ALL32(256)
+  ALL32(512)
+  return 0;
+}
