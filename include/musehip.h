@@ -606,6 +606,9 @@ int mh_gemm_qkv_vtperm_qs(const void* A, int64_t lda, const void* Wqkv, int64_t 
                           int B, int L, int H, int nh, float q_scale, const mh_ln_defer* defer, mh_stream_t stream);
 /* mh_attention_stream_fwd for queries that already carry softmax scale x log2(e) (q_scale above): the running softmax reference lives in
  * the initial value of the score accumulators, so a probability is exp2(accumulator) - no multiply-subtract per score */
+/* timing-only ablation of the streaming kernel at head dim 64, seq_len <= 512 (tools/attn_bench.py): 1 no softmax vector work, 2 no S^T
+ * MFMAs, 4 no P.V MFMAs, 8 no LDS fragment reads, 16 no stage DMA (built: 1 2 4 6 7 8 16 24 31); 0 = the real kernel */
+int mh_attention_set_ablation(int bits);
 int mh_attention_stream_prescaled_supported(int L, int dh);   /* mh_attention_stream_supported and seq_len % 256 == 0 */
 int mh_attention_stream_fwd_prescaled(const void* q, const void* k, const void* vt_perm, void* ctx, int64_t ld_ctx, int ctx_panel,
                                       int B, int L, int nh, int dh, mh_stream_t stream);

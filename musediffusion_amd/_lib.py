@@ -190,6 +190,7 @@ SIGNATURES = {
     "mh_denoiser_set_skip": (INT, [INT]),
     "mh_denoiser_set_prescale_q": (INT, [INT]),
     "mh_gemm_qkv_vtperm_qs": (INT, [VP, I64, VP, I64, VP, VP, VP, VP, INT, INT, INT, INT, F32, C.POINTER(LnDefer), VP]),
+    "mh_attention_set_ablation": (INT, [INT]),
     "mh_attention_stream_prescaled_supported": (INT, [INT, INT]),
     "mh_attention_stream_fwd_prescaled": (INT, [VP, VP, VP, VP, I64, INT, INT, INT, INT, INT, VP]),
     "mh_profile_start": (INT, []),

@@ -569,7 +569,9 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(const float* __restrict__
 // accumulators are already in the log2 domain, and the running reference lives in their INITIAL value: the first MFMA of every S^T
 // chain takes C = -reference (16 registers that change only when the reference moves), so a probability is exp2(accumulator) with
 // no multiply-subtract per score - 32 of the ~170 vector instructions of a 64-key tile (the kernel is VALU-bound)
-template <int DH, int NW = 16, int SK = 256, int DROP = 0, bool FULL = false, bool KVNT = false, bool PRE = false>
+// ABL: timing-only ablations (tools/attn_bench.py --ablate; results are garbage): 1 no softmax vector work, 2 no S^T MFMAs, 4 no P.V MFMAs,
+// 8 no LDS fragment reads, 16 no K / V stage DMA
+template <int DH, int NW = 16, int SK = 256, int DROP = 0, bool FULL = false, bool KVNT = false, bool PRE = false, int ABL = 0>
 __global__ __launch_bounds__(64 * NW) void attn_stream_bf16_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K,
                                                                 const bf16* __restrict__ VT, bf16* __restrict__ ctx,
                                                                 int64_t ld_ctx, int L, int nh, int nbh, float scale_log2e,
@@ -594,6 +596,7 @@ __global__ __launch_bounds__(64 * NW) void attn_stream_bf16_kernel(const bf16* _
   const int total = my_items * nst;
 
   auto issue = [&](int g) {   // DMA stage g (of this block's flattened (item, stage) sequence) into buffer g & 1
+    if constexpr ((ABL & 16) != 0) return;
     const int item = blockIdx.x + (g / nst) * gridDim.x, st = g % nst;
     const int bh = item / nqb;
     const bf16* Kb = K + (int64_t)(bh / nh) * qsB + (int64_t)(bh % nh) * qsH + (int64_t)st * SK * qld;   // rows qld elements apart
@@ -647,7 +650,10 @@ __global__ __launch_bounds__(64 * NW) void attn_stream_bf16_kernel(const bf16* _
         const bf16* Qb = Q + (int64_t)(bh / nh) * qsB + (int64_t)(bh % nh) * qsH;
         int qr = q0 + lq; if (qr >= L) qr = L - 1;
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(Qb + (int64_t)qr * qld + 16 * ks + 8 * h);
+        for (int ks = 0; ks < KS; ++ks) {
+          if constexpr ((ABL & 64) != 0) { for (int j = 0; j < 8; ++j) qf[ks][j] = (bf16)(0.01f * (j + ks) + 0.001f * lq); }
+          else qf[ks] = *reinterpret_cast<const bf16x8*>(Qb + (int64_t)qr * qld + 16 * ks + 8 * h);
+        }
       }
 #pragma unroll
       for (int i = 0; i < DT; ++i)
@@ -755,11 +761,16 @@ __global__ __launch_bounds__(64 * NW) void attn_stream_bf16_kernel(const bf16* _
           bf16x8 kf[KS];
           const int krow = 32 * kt + lq, ksw = kt ? ksw1 : ksw0;
 #pragma unroll
-          for (int ks = 0; ks < KS; ++ks) kf[ks] = *reinterpret_cast<const bf16x8*>(kb + krow * KROWB + (((2 * ks + h) ^ ksw) << 4));
+          for (int ks = 0; ks < KS; ++ks) {
+            if constexpr ((ABL & 8) != 0) kf[ks] = qf[(ks + 1) % KS];
+            else kf[ks] = *reinterpret_cast<const bf16x8*>(kb + krow * KROWB + (((2 * ks + h) ^ ksw) << 4));
+          }
 #pragma unroll
-          for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
+          for (int r = 0; r < 16; ++r) s[kt][r] = (ABL & 2) ? 0.01f * r + (float)kf[0][r & 7] : 0.f;
+          if constexpr ((ABL & 2) == 0) {
 #pragma unroll
-          for (int ks = 0; ks < KS; ++ks) s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[ks], s[kt], 0, 0, 0);
+            for (int ks = 0; ks < KS; ++ks) s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[ks], s[kt], 0, 0, 0);
+          }
         }
         if (!FULL && tile_keys < 64) {   // register r of sub-tile kt holds key 32 kt + (r & 3) + 8 (r >> 2) + 4 h: mask the ones past the end
 #pragma unroll
@@ -768,6 +779,7 @@ __global__ __launch_bounds__(64 * NW) void attn_stream_bf16_kernel(const bf16* _
             for (int r = 0; r < 16; ++r)
               if (kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h >= tile_keys) s[kt][r] = -INFINITY;
         }
+        if constexpr ((ABL & 1) == 0) {
         float mx4[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
@@ -802,6 +814,7 @@ __global__ __launch_bounds__(64 * NW) void attn_stream_bf16_kernel(const bf16* _
             ps4[r & 3] += p;
           }
         l_run += (ps4[0] + ps4[1]) + (ps4[2] + ps4[3]);
+        }
         if constexpr (DROP != 0) {
           const int nb32 = (L + 31) >> 5;
           const int64_t wi = drop_word_index(bh, nb32, q0 >> 5, (st * SK + t * 64) >> 6, lane);   // this lane's word of the 64-key tile
@@ -830,8 +843,11 @@ __global__ __launch_bounds__(64 * NW) void attn_stream_bf16_kernel(const bf16* _
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
               const int d = dt * 32 + lq;
-              const bf16x8 vf = *reinterpret_cast<const bf16x8*>(vb + d * 128 + (((2 * (2 * kt + s2) + h) ^ ((d >> 1) & 7)) << 4));
-              o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[dt], 0, 0, 0);
+              bf16x8 vf;
+              if constexpr ((ABL & 8) != 0) vf = qf[(dt + s2) % KS];
+              else vf = *reinterpret_cast<const bf16x8*>(vb + d * 128 + (((2 * (2 * kt + s2) + h) ^ ((d >> 1) & 7)) << 4));
+              if constexpr ((ABL & 4) != 0) asm volatile("" ::"v"(vf), "v"(pf));
+              else o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[dt], 0, 0, 0);
             }
           }
       }
@@ -839,20 +855,39 @@ __global__ __launch_bounds__(64 * NW) void attn_stream_bf16_kernel(const bf16* _
         const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
         const float inv = (DROP != 0 ? drop.rscale : 1.0f) / l_tot;
         const int qr = q0 + lq;
-        if (qr < L) {
+        {
           const int b = bh / nh, head = bh % nh;
-          const int64_t tok = (int64_t)b * L + qr;
+          const int64_t tok = (int64_t)b * L + (qr < L ? qr : L - 1);
           // log2-domain log-sum-exp of the scaled scores: P[q][k] = exp2(s c - lse2[q]) (what the backward kernels re-create P from)
-          if (lse2 && h == 0) lse2[(int64_t)bh * L + qr] = (PRE ? m_run : m_run * scale_log2e) + __builtin_amdgcn_logf(l_tot);
+          if (lse2 && h == 0 && qr < L) lse2[(int64_t)bh * L + qr] = (PRE ? m_run : m_run * scale_log2e) + __builtin_amdgcn_logf(l_tot);
+          // a lane holds 4 consecutive head-dim elements (8 B) of its query's row per group rg, its half-wave partner the next 4: one
+          // v_permlane32_swap per dword and pair of groups gives every lane 16 contiguous bytes, so the row leaves in 2 instead of 4
+          // stores per 32-column block (the store tail is issue-bound: cdna_hip_programming.md T21).  All lanes take part in the
+          // swaps (queries past the end hold finite garbage and do not store); 8-byte stores where the context rows are not 16-B aligned
+          const bool wide = ctx_panel || (ld_ctx % 8 == 0 && (reinterpret_cast<uintptr_t>(ctx) & 15) == 0);   // (wave-uniform)
 #pragma unroll
           for (int dt = 0; dt < DT; ++dt) {
             bf16* dst = ctx_panel ? ctx + (((int64_t)(head * DT + dt)) * ld_ctx + tok) * 32 : ctx + tok * ld_ctx + head * DH + dt * 32;
+            uint2 pk[4];
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) {
               bf16x4 v;
 #pragma unroll
               for (int e = 0; e < 4; ++e) v[e] = (bf16)(o[dt][rg * 4 + e] * inv);
-              *reinterpret_cast<bf16x4*>(dst + 8 * rg + 4 * h) = v;
+              __builtin_memcpy(&pk[rg], &v, 8);
+            }
+            if constexpr ((ABL & 32) != 0) { if (pk[0].x == 0x12345678u) *reinterpret_cast<uint2*>(dst + 4 * h) = pk[0]; }
+            else if (wide) {
+#pragma unroll
+              for (int k = 0; k < 4; k += 2) {
+                uint2 a = pk[k], b = pk[k + 1];
+                auto rx = __builtin_amdgcn_permlane32_swap(a.x, b.x, false, false);
+                auto ry = __builtin_amdgcn_permlane32_swap(a.y, b.y, false, false);
+                if (qr < L) *reinterpret_cast<uint4*>(dst + 8 * k + 8 * h) = uint4{rx[0], ry[0], rx[1], ry[1]};
+              }
+            } else if (qr < L) {
+#pragma unroll
+              for (int rg = 0; rg < 4; ++rg) *reinterpret_cast<uint2*>(dst + 8 * rg + 4 * h) = pk[rg];
             }
           }
         }
@@ -863,6 +898,7 @@ __global__ __launch_bounds__(64 * NW) void attn_stream_bf16_kernel(const bf16* _
   }
 }
 
+int g_attn_abl = 0;        // timing-only ablation of the streaming kernel (mh_attention_set_ablation)
 int g_attn_resident = 1;
 unsigned long long* g_attn_prof = nullptr;   // diagnostic stamps (mh_attention_set_profile)
 
@@ -1021,6 +1057,24 @@ int stream_fwd_impl(const void* q, const void* k, const void* vt_perm, void* ctx
     if (L <= 512) rc = dh == 64 ? go(&attn_stream_bf16_kernel<64, 16, 256, 0, true, true, true>, 4 * 256 * 64 * 2) : go(&attn_stream_bf16_kernel<32, 16, 256, 0, true, true, true>, 4 * 256 * 32 * 2);
     else rc = dh == 64 ? go(&attn_stream_bf16_kernel<64, 16, 256, 0, true, false, true>, 4 * 256 * 64 * 2) : go(&attn_stream_bf16_kernel<32, 16, 256, 0, true, false, true>, 4 * 256 * 32 * 2);
   }
+  else if (g_attn_abl && full && !small && L <= qper && dh == 64) {
+    switch (g_attn_abl) {
+      case 1: rc = go(&attn_stream_bf16_kernel<64, 16, 256, 0, true, true, false, 1>, 4 * 256 * 64 * 2); break;
+      case 2: rc = go(&attn_stream_bf16_kernel<64, 16, 256, 0, true, true, false, 2>, 4 * 256 * 64 * 2); break;
+      case 4: rc = go(&attn_stream_bf16_kernel<64, 16, 256, 0, true, true, false, 4>, 4 * 256 * 64 * 2); break;
+      case 6: rc = go(&attn_stream_bf16_kernel<64, 16, 256, 0, true, true, false, 6>, 4 * 256 * 64 * 2); break;
+      case 7: rc = go(&attn_stream_bf16_kernel<64, 16, 256, 0, true, true, false, 7>, 4 * 256 * 64 * 2); break;
+      case 8: rc = go(&attn_stream_bf16_kernel<64, 16, 256, 0, true, true, false, 8>, 4 * 256 * 64 * 2); break;
+      case 16: rc = go(&attn_stream_bf16_kernel<64, 16, 256, 0, true, true, false, 16>, 4 * 256 * 64 * 2); break;
+      case 24: rc = go(&attn_stream_bf16_kernel<64, 16, 256, 0, true, true, false, 24>, 4 * 256 * 64 * 2); break;
+      case 31: rc = go(&attn_stream_bf16_kernel<64, 16, 256, 0, true, true, false, 31>, 4 * 256 * 64 * 2); break;
+      case 63: rc = go(&attn_stream_bf16_kernel<64, 16, 256, 0, true, true, false, 63>, 4 * 256 * 64 * 2); break;
+      case 95: rc = go(&attn_stream_bf16_kernel<64, 16, 256, 0, true, true, false, 95>, 4 * 256 * 64 * 2); break;
+      case 127: rc = go(&attn_stream_bf16_kernel<64, 16, 256, 0, true, true, false, 127>, 4 * 256 * 64 * 2); break;
+      case 32: rc = go(&attn_stream_bf16_kernel<64, 16, 256, 0, true, true, false, 32>, 4 * 256 * 64 * 2); break;
+      default: mh_set_error("attention_stream: ablation %d not built (1 2 4 6 7 8 16 24 31)", g_attn_abl); return MH_ERR_UNSUPPORTED;
+    }
+  }
   else if (full && !small && L <= qper)   // one block streams a (batch, head)'s K / V once: nt policy
     rc = dh == 64 ? go(&attn_stream_bf16_kernel<64, 16, 256, 0, true, true>, 4 * 256 * 64 * 2) : go(&attn_stream_bf16_kernel<32, 16, 256, 0, true, true>, 4 * 256 * 32 * 2);
   else if (full && dh == 64) rc = small ? go(&attn_stream_bf16_kernel<64, 8, 128, 0, true>, 4 * 128 * 64 * 2) : go(&attn_stream_bf16_kernel<64, 16, 256, 0, true>, 4 * 256 * 64 * 2);
@@ -1032,6 +1086,11 @@ int stream_fwd_impl(const void* q, const void* k, const void* vt_perm, void* ctx
   return MH_OK;
 }
 }  // namespace
+
+extern "C" int mh_attention_set_ablation(int bits) {
+  g_attn_abl = bits;
+  return MH_OK;
+}
 
 extern "C" int mh_attention_set_profile(void* stamps) {
   g_attn_prof = reinterpret_cast<unsigned long long*>(stamps);

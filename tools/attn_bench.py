@@ -54,6 +54,21 @@ if _lib.lib().mh_attention_stream_prescaled_supported(a.L, a.dh):
         e1.record(); torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / (a.reps * 5)
         print("attention %-9s: %7.1f us  %6.1f TFLOP/s" % (name, ms * 1e3, flops / ms / 1e9))
+if a.L <= 512 and a.dh == 64:
+    names = {0: "everything", 1: "no softmax VALU", 2: "no S MFMAs", 4: "no PV MFMAs", 6: "no MFMAs", 7: "no MFMAs, no softmax", 8: "no LDS reads",
+             16: "no DMA", 24: "no DMA, no LDS reads", 31: "nothing (Q load, loop skeleton, stores)", 32: "everything but the context stores",
+             63: "skeleton without the stores", 95: "skeleton without the Q loads", 127: "skeleton without Q loads and stores"}
+    for rnd in range(2):
+        for abl in (0, 1, 2, 4, 6, 7, 8, 16, 24, 31, 32, 63, 95, 127):
+            _lib.lib().mh_attention_set_ablation(abl)
+            run(); torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(a.reps * 5):
+                run()
+            e1.record(); torch.cuda.synchronize()
+            print("ablation %2d %-42s: %7.1f us per launch" % (abl, names[abl], e0.elapsed_time(e1) / (a.reps * 5) * 1e3))
+    _lib.lib().mh_attention_set_ablation(0)
 # per-block timeline of the resident kernel (100 MHz stamps)
 for res in (1, 2):
     _lib.lib().mh_attention_set_variant(res)
