@@ -598,6 +598,8 @@ int mh_denoiser_set_defer_ln(int mode);
 /* timing-only A/B knob (tools/ab_step.py skip): leave one kind of launch out of the bf16 panel forward (bit 0 QKV, 1 attention,
  * 2 attention-output dense + LN, 3 FFN1, 4 FFN2 + LN, 5 up-projection chain, 6 down-projection); outputs are then meaningless */
 int mh_denoiser_set_skip(int mask);
+/* panel LayerNorm kernels: 1 (default) = 4 rows per wave (four times the waves of the 16-row form), 0 = 16 rows per wave (A/B) */
+int mh_layernorm_set_rows4(int on);
 /* 1: the bf16 panel forward folds softmax scale x log2(e) into the stored queries and runs the pre-scaled attention (A/B; default 0) */
 int mh_denoiser_set_prescale_q(int on);
 /* mh_gemm_qkv_vtperm over K32-panel operands with the queries stored as (x Wq^T + bq) * q_scale (rounded once, from the fp32

@@ -188,6 +188,7 @@ SIGNATURES = {
     "mh_denoiser_set_defer_ln": (INT, [INT]),
     "mh_denoiser_get_defer_ln": (INT, []),
     "mh_denoiser_set_skip": (INT, [INT]),
+    "mh_layernorm_set_rows4": (INT, [INT]),
     "mh_denoiser_set_prescale_q": (INT, [INT]),
     "mh_gemm_qkv_vtperm_qs": (INT, [VP, I64, VP, I64, VP, VP, VP, VP, INT, INT, INT, INT, F32, C.POINTER(LnDefer), VP]),
     "mh_attention_set_ablation": (INT, [INT]),
