@@ -600,6 +600,18 @@ int mh_denoiser_set_defer_ln(int mode);
 int mh_denoiser_set_skip(int mask);
 /* panel LayerNorm kernels: 1 (default) = 4 rows per wave (four times the waves of the 16-row form), 0 = 16 rows per wave (A/B) */
 int mh_layernorm_set_rows4(int on);
+/* The forward in three phases over K32-panel activation buffers the caller owns (bf16 [H / 32][ld rows][32]; bf16 panel models with
+ * up / down projections: mh_denoiser_phases_supported): head = latent -> up-projection -> + position / time -> LayerNorm
+ * (network.py:141-149), layers = the encoder (network.py:151), tail = down-projection (network.py:153-157).  A batch slice passes a row
+ * window of a full-batch buffer (pointer + first_row * 32 elements, ld = the full batch's rows), so head and tail can run once for the
+ * whole batch while the encoder layers run per slice on concurrent streams.  Workspace: mh_denoiser_workspace_bytes(m, B, L) of the call. */
+int mh_denoiser_phases_supported(const mh_denoiser* m);
+int mh_denoiser_head(const mh_denoiser* m, const float* x, const float* emb_t, const int32_t* emb_row, void* x_out, int64_t ld_out, int B, int L,
+                     void* workspace, size_t workspace_bytes, mh_stream_t stream);
+int mh_denoiser_layers(const mh_denoiser* m, const void* x_in, int64_t ld_in, void* x_out, int64_t ld_out, int B, int L, void* workspace,
+                       size_t workspace_bytes, mh_stream_t stream);
+int mh_denoiser_tail(const mh_denoiser* m, const void* x_in, int64_t ld_in, float* out, int B, int L, void* workspace, size_t workspace_bytes,
+                     mh_stream_t stream);
 /* 1: the bf16 panel forward folds softmax scale x log2(e) into the stored queries and runs the pre-scaled attention (A/B; default 0) */
 int mh_denoiser_set_prescale_q(int on);
 /* mh_gemm_qkv_vtperm over K32-panel operands with the queries stored as (x Wq^T + bq) * q_scale (rounded once, from the fp32

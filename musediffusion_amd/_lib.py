@@ -199,6 +199,10 @@ SIGNATURES = {
     "mh_denoiser_workspace_bytes": (C.c_size_t, [C.POINTER(Denoiser), INT, INT]),
     "mh_time_embed": (INT, [C.POINTER(Denoiser), VP, VP, INT, VP, C.c_size_t, VP]),
     "mh_denoiser_forward": (INT, [C.POINTER(Denoiser), VP, VP, VP, VP, INT, INT, VP, C.c_size_t, VP]),
+    "mh_denoiser_phases_supported": (INT, [C.POINTER(Denoiser)]),
+    "mh_denoiser_head": (INT, [C.POINTER(Denoiser), VP, VP, VP, VP, I64, INT, INT, VP, C.c_size_t, VP]),
+    "mh_denoiser_layers": (INT, [C.POINTER(Denoiser), VP, I64, VP, I64, INT, INT, VP, C.c_size_t, VP]),
+    "mh_denoiser_tail": (INT, [C.POINTER(Denoiser), VP, I64, VP, INT, INT, VP, C.c_size_t, VP]),
 }
 
 _lib = None

@@ -222,12 +222,50 @@ extern "C" int mh_time_embed(const mh_denoiser* m, const float* t, float* emb_t_
                           m->T4_pad, MH_ACT_NONE, m->dtype, stream);
 }
 
+namespace {
+// The forward in three phases over K32-panel activation buffers the CALLER may own (bf16 panel path only): phase 1 "head" (latent ->
+// up-projection -> + position / time -> LayerNorm) writes its rows to xh (ld = ldh rows per panel), phase 2 "layers" reads layer 0's
+// input from xi (ldi) and writes the last layer's output to xo (ldo), phase 4 "tail" (down-projection) reads xt (ldt).  A null pointer
+// means the workspace's own buffer.  With row windows of ONE full-batch buffer (pointer + first_row * 32 elements, ld = the full
+// batch's rows) the sampler runs head and tail once for the whole batch and only the encoder layers per batch slice: the head / tail
+// launches are latency-bound at a half batch (16 K-steps, a quarter to a half of the chip's block slots), so two half-size launches
+// cost twice one full-size launch.
+struct Phases { int mask; void* xh; int64_t ldh; const void* xi; int64_t ldi; void* xo; int64_t ldo; const void* xt; int64_t ldt; };
+int denoiser_run(const mh_denoiser* m, const float* x, const float* emb_t, const int32_t* emb_row, float* out, int B, int L,
+                 void* workspace, size_t workspace_bytes, mh_stream_t stream, const Phases& ph);
+}  // namespace
+
 extern "C" int mh_denoiser_forward(const mh_denoiser* m, const float* x, const float* emb_t, const int32_t* emb_row,
                                    float* out, int B, int L, void* workspace, size_t workspace_bytes,
                                    mh_stream_t stream) {
+  MH_CHECK_ARG(x && emb_t && out, "denoiser_forward: null pointer");
+  return denoiser_run(m, x, emb_t, emb_row, out, B, L, workspace, workspace_bytes, stream, Phases{7, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, 0});
+}
+
+// Phased entry points (bf16 K32-panel models with up / down projections only; see Phases).  X buffers: bf16 [H / 32][ld rows][32].
+extern "C" int mh_denoiser_phases_supported(const mh_denoiser* m) { return m && m->panel && m->has_proj && m->nL > 0; }
+extern "C" int mh_denoiser_head(const mh_denoiser* m, const float* x, const float* emb_t, const int32_t* emb_row, void* x_out, int64_t ld_out,
+                                int B, int L, void* workspace, size_t workspace_bytes, mh_stream_t stream) {
+  MH_CHECK_ARG(mh_denoiser_phases_supported(m) && x && emb_t && x_out && ld_out >= (int64_t)B * L, "denoiser_head: bad arguments");
+  return denoiser_run(m, x, emb_t, emb_row, nullptr, B, L, workspace, workspace_bytes, stream, Phases{1, x_out, ld_out, nullptr, 0, nullptr, 0, nullptr, 0});
+}
+extern "C" int mh_denoiser_layers(const mh_denoiser* m, const void* x_in, int64_t ld_in, void* x_out, int64_t ld_out, int B, int L,
+                                  void* workspace, size_t workspace_bytes, mh_stream_t stream) {
+  MH_CHECK_ARG(mh_denoiser_phases_supported(m) && x_in && x_out && ld_in >= (int64_t)B * L && ld_out >= (int64_t)B * L, "denoiser_layers: bad arguments");
+  return denoiser_run(m, nullptr, nullptr, nullptr, nullptr, B, L, workspace, workspace_bytes, stream, Phases{2, nullptr, 0, x_in, ld_in, x_out, ld_out, nullptr, 0});
+}
+extern "C" int mh_denoiser_tail(const mh_denoiser* m, const void* x_in, int64_t ld_in, float* out, int B, int L, void* workspace,
+                                size_t workspace_bytes, mh_stream_t stream) {
+  MH_CHECK_ARG(mh_denoiser_phases_supported(m) && x_in && out && ld_in >= (int64_t)B * L, "denoiser_tail: bad arguments");
+  return denoiser_run(m, nullptr, nullptr, nullptr, out, B, L, workspace, workspace_bytes, stream, Phases{4, nullptr, 0, nullptr, 0, nullptr, 0, x_in, ld_in});
+}
+
+namespace {
+int denoiser_run(const mh_denoiser* m, const float* x, const float* emb_t, const int32_t* emb_row, float* out, int B, int L,
+                 void* workspace, size_t workspace_bytes, mh_stream_t stream, const Phases& ph) {
   int rc = check_model(m);
   if (rc) return rc;
-  MH_CHECK_ARG(x && emb_t && out && workspace, "denoiser_forward: null pointer");
+  MH_CHECK_ARG(workspace, "denoiser_forward: null workspace");
   MH_CHECK_ARG(B > 0 && L > 0 && L <= m->L_max, "denoiser_forward: seq_len %d exceeds position table %d", L, m->L_max);
   MH_CHECK_ARG(L % 8 == 0, "denoiser_forward: seq_len %d must be a multiple of 8", L);
   const Workspace w = carve(m, B, L, (char*)workspace);
@@ -239,13 +277,18 @@ extern "C" int mh_denoiser_forward(const mh_denoiser* m, const float* x, const f
   if (m->panel) {
     // ---- bf16 throughput path: every activation and weight in the K32-panel layout (ld = rows per panel)
     const int P = 1;
-    auto gemm = [&](const void* A, const void* W, int64_t w_rows, const float* bias, const void* res, void* o, int of32,
-                    int64_t ldo, int Nout, int K, int act) {
-      return mh_gemm_bias_act_ex(A, N, P, W, w_rows, P, bias, res, N, P, o, ldo, of32 ? 0 : P, of32, N, Nout, K, act, dt, stream);
+    // where the phases hand their rows over (caller-owned row windows or the workspace's own bufX)
+    void* const XH = ph.xh ? ph.xh : (void*)w.bufX;            const int64_t ldH = ph.xh ? ph.ldh : N;
+    const void* const XI = ph.xi ? ph.xi : (const void*)w.bufX; const int64_t ldI = ph.xi ? ph.ldi : N;
+    void* const XO = ph.xo ? ph.xo : (void*)w.bufX;            const int64_t ldO = ph.xo ? ph.ldo : N;
+    const void* const XT = ph.xt ? ph.xt : (const void*)w.bufX; const int64_t ldT = ph.xt ? ph.ldt : N;
+    auto gemm = [&](const void* A, int64_t lda, const void* W, int64_t w_rows, const float* bias, const void* res, int64_t ldr, void* o,
+                    int of32, int64_t ldo, int Nout, int K, int act) {
+      return mh_gemm_bias_act_ex(A, lda, P, W, w_rows, P, bias, res, ldr, P, o, ldo, of32 ? 0 : P, of32, N, Nout, K, act, dt, stream);
     };
-    auto gemm_ln = [&](const void* A, const void* W, const float* bias, const void* res, const float* gamma, const float* beta,
-                       void* o, int K) {
-      return mh_gemm_bias_res_ln(A, N, P, W, H, P, bias, res, N, P, gamma, beta, m->ln_eps, o, N, P, N, H, K, stream);
+    auto gemm_ln = [&](const void* A, const void* W, const float* bias, const void* res, int64_t ldr, const float* gamma, const float* beta,
+                       void* o, int64_t ldo, int K) {
+      return mh_gemm_bias_res_ln(A, N, P, W, H, P, bias, res, ldr, P, gamma, beta, m->ln_eps, o, ldo, P, N, H, K, stream);
     };
     const bool fuse_ln = g_fuse_ln && mh_gemm_bias_res_ln_supported(H);
     const bool stream_attn = mh_attention_stream_enabled() && mh_attention_stream_supported(L, dh) && H % 64 == 0;
@@ -255,19 +298,20 @@ extern "C" int mh_denoiser_forward(const mh_denoiser* m, const float* x, const f
       return pre_q ? mh_attention_stream_fwd_prescaled(w.q, w.k, w.vt, w.buf0, N, P, B, L, m->nh, dh, stream)
                    : mh_attention_stream_fwd(w.q, w.k, w.vt, w.buf0, N, P, B, L, m->nh, dh, scale, stream);
     };
-    if (m->has_proj && (g_skip & 32)) {
+    if (!(ph.mask & 1) || (m->has_proj && (g_skip & 32))) {
     } else if (m->has_proj) {
       if ((rc = mh_pack_panel(x, m->E, w.xin, N, N, m->E, m->E_pad, stream))) return rc;
-      if ((rc = gemm(w.xin, m->w_up0, H, m->b_up0, nullptr, w.buf0, 0, N, H, m->E_pad, MH_ACT_TANH))) return rc;
-      if ((rc = gemm(w.buf0, m->w_up2, H, m->b_up2, nullptr, w.buf1, 0, N, H, H, MH_ACT_NONE))) return rc;
-      if ((rc = mh_add_pos_time_layernorm_panel(w.buf1, N, 0, m->pos, emb_t, emb_row, m->ln0_g, m->ln0_b, w.bufX, N, B, L, H,
+      if ((rc = gemm(w.xin, N, m->w_up0, H, m->b_up0, nullptr, 0, w.buf0, 0, N, H, m->E_pad, MH_ACT_TANH))) return rc;
+      if ((rc = gemm(w.buf0, N, m->w_up2, H, m->b_up2, nullptr, 0, w.buf1, 0, N, H, H, MH_ACT_NONE))) return rc;
+      if ((rc = mh_add_pos_time_layernorm_panel(w.buf1, N, 0, m->pos, emb_t, emb_row, m->ln0_g, m->ln0_b, XH, ldH, B, L, H,
                                                 m->ln_eps, stream)))
         return rc;
     } else {
-      if ((rc = mh_add_pos_time_layernorm_panel(x, H, 1, m->pos, emb_t, emb_row, m->ln0_g, m->ln0_b, w.bufX, N, B, L, H,
+      if ((rc = mh_add_pos_time_layernorm_panel(x, H, 1, m->pos, emb_t, emb_row, m->ln0_g, m->ln0_b, XH, ldH, B, L, H,
                                                 m->ln_eps, stream)))
         return rc;
     }
+    const int nLrun = (ph.mask & 2) ? m->nL : 0;     // (the layer loops below run only in phase 2)
     // Deferred LayerNorm (DeferArgs, gemm.hip): the attention-output and FFN-output GEMMs store RAW rows + partial row
     // statistics and their consumers normalise on the fly, so every GEMM runs on the 256x128 tile (no full-row tile, no
     // LayerNorm kernel - d_model 768 included).  The last layer's output is normalised by the panel LayerNorm kernel.
@@ -280,18 +324,20 @@ extern "C" int mh_denoiser_forward(const mh_denoiser* m, const float* x, const f
     if (defer) {
       const int S = (H + 127) / 128;
       bool prev_raw = false;   // bufX holds raw rows of the previous layer's output (statistics in stats2)
-      for (int l = 0; l < m->nL; ++l) {
+      for (int l = 0; l < nLrun; ++l) {
         const mh_layer_weights& lw = m->layers[l];
         const mh_layer_weights* pl = l ? &m->layers[l - 1] : nullptr;
+        const void* Xin = l == 0 ? XI : (const void*)w.bufX;      // this layer's input rows (layer 0: the head's)
+        const int64_t ldin = l == 0 ? ldI : N;
         mh_ln_defer d{};
         d.h_norm = H; d.eps = m->ln_eps;
         if (prev_raw) {
           d.a_stats = w.stats2; d.a_slots = S; d.c1 = lw.c1_qkv;
-          if (pre_q) rc = mh_gemm_qkv_vtperm_qs(w.bufX, N, lw.w_qkv_f, 3 * H, lw.c2_qkv, w.q, w.k, w.vt, B, L, H, m->nh, q_scale, &d, stream);
-          else rc = mh_gemm_qkv_vtperm_defer(w.bufX, N, lw.w_qkv_f, 3 * H, lw.c2_qkv, w.q, w.k, w.vt, B, L, H, m->nh, &d, stream);
+          if (pre_q) rc = mh_gemm_qkv_vtperm_qs(Xin, ldin, lw.w_qkv_f, 3 * H, lw.c2_qkv, w.q, w.k, w.vt, B, L, H, m->nh, q_scale, &d, stream);
+          else rc = mh_gemm_qkv_vtperm_defer(Xin, ldin, lw.w_qkv_f, 3 * H, lw.c2_qkv, w.q, w.k, w.vt, B, L, H, m->nh, &d, stream);
         } else {
-          if (pre_q) rc = mh_gemm_qkv_vtperm_qs(w.bufX, N, lw.w_qkv, 3 * H, lw.b_qkv, w.q, w.k, w.vt, B, L, H, m->nh, q_scale, nullptr, stream);
-          else rc = mh_gemm_qkv_vtperm(w.bufX, N, P, lw.w_qkv, 3 * H, P, lw.b_qkv, w.q, w.k, w.vt, B, L, H, m->nh, stream);
+          if (pre_q) rc = mh_gemm_qkv_vtperm_qs(Xin, ldin, lw.w_qkv, 3 * H, lw.b_qkv, w.q, w.k, w.vt, B, L, H, m->nh, q_scale, nullptr, stream);
+          else rc = mh_gemm_qkv_vtperm(Xin, ldin, P, lw.w_qkv, 3 * H, P, lw.b_qkv, w.q, w.k, w.vt, B, L, H, m->nh, stream);
         }
         if (rc) return rc;
         if ((rc = attention())) return rc;
@@ -300,7 +346,7 @@ extern "C" int mh_denoiser_forward(const mh_denoiser* m, const float* x, const f
         d.h_norm = H; d.eps = m->ln_eps;
         if (prev_raw) { d.r_stats = w.stats2; d.r_slots = S; d.r_gamma = pl->ln2_g; d.r_beta = pl->ln2_b; }
         d.o_stats = w.stats1; d.o_slots = S;
-        if ((rc = mh_gemm_bias_act_defer(w.buf0, N, lw.w_ao, H, lw.b_ao, w.bufX, N, w.bufX1, N, N, H, H, MH_ACT_NONE, &d, stream))) return rc;
+        if ((rc = mh_gemm_bias_act_defer(w.buf0, N, lw.w_ao, H, lw.b_ao, Xin, ldin, w.bufX1, N, N, H, H, MH_ACT_NONE, &d, stream))) return rc;
         // f = gelu(LN1(y1) W1^T + b1)
         d = mh_ln_defer{};
         d.h_norm = H; d.eps = m->ln_eps;
@@ -314,47 +360,53 @@ extern "C" int mh_denoiser_forward(const mh_denoiser* m, const float* x, const f
         if (!last) { d.o_stats = w.stats2; d.o_slots = S; }
         if ((rc = mh_gemm_bias_act_defer(w.ffn, N, lw.w_ff2, H, lw.b_ff2, w.bufX1, N, last ? w.buf1 : w.bufX, N, N, H, F, MH_ACT_NONE, &d, stream))) return rc;
         if (last) {
-          if ((rc = mh_layernorm_panel(w.buf1, N, lw.ln2_g, lw.ln2_b, w.bufX, N, N, H, m->ln_eps, stream))) return rc;
+          if ((rc = mh_layernorm_panel(w.buf1, N, lw.ln2_g, lw.ln2_b, XO, ldO, N, H, m->ln_eps, stream))) return rc;
         }
         prev_raw = !last;
       }
     }
-    for (int l = 0; l < m->nL && !defer; ++l) {
+    for (int l = 0; l < nLrun && !defer; ++l) {
       const mh_layer_weights& lw = m->layers[l];
+      const void* Xin = l == 0 ? XI : (const void*)w.bufX;      // this layer's input rows (layer 0: the head's) ...
+      const int64_t ldin = l == 0 ? ldI : N;
+      void* Xout = l == m->nL - 1 ? XO : (void*)w.bufX;         // ... and where its output rows go (last layer: the tail's input)
+      const int64_t ldout = l == m->nL - 1 ? ldO : N;
       if (stream_attn) {   // V^T written in the streaming kernel's key order: its stages are straight LDS-DMA copies
         if (!(g_skip & 1)) {
-          if (pre_q) rc = mh_gemm_qkv_vtperm_qs(w.bufX, N, lw.w_qkv, 3 * H, lw.b_qkv, w.q, w.k, w.vt, B, L, H, m->nh, q_scale, nullptr, stream);
-          else rc = mh_gemm_qkv_vtperm(w.bufX, N, P, lw.w_qkv, 3 * H, P, lw.b_qkv, w.q, w.k, w.vt, B, L, H, m->nh, stream);
+          if (pre_q) rc = mh_gemm_qkv_vtperm_qs(Xin, ldin, lw.w_qkv, 3 * H, lw.b_qkv, w.q, w.k, w.vt, B, L, H, m->nh, q_scale, nullptr, stream);
+          else rc = mh_gemm_qkv_vtperm(Xin, ldin, P, lw.w_qkv, 3 * H, P, lw.b_qkv, w.q, w.k, w.vt, B, L, H, m->nh, stream);
           if (rc) return rc;
         }
         if (!(g_skip & 2) && (rc = attention())) return rc;
       } else {
-        if ((rc = mh_gemm_qkv_ex(w.bufX, N, P, lw.w_qkv, 3 * H, P, lw.b_qkv, w.q, w.k, w.vt, B, L, H, m->nh, dt, stream))) return rc;
+        if ((rc = mh_gemm_qkv_ex(Xin, ldin, P, lw.w_qkv, 3 * H, P, lw.b_qkv, w.q, w.k, w.vt, B, L, H, m->nh, dt, stream))) return rc;
         if ((rc = mh_attention_fwd_ex(w.q, w.k, w.vt, w.buf0, N, P, B, L, m->nh, dh, scale, dt, stream))) return rc;
       }
       if (g_skip & 4) {
       } else if (fuse_ln) {   // dense + residual + LayerNorm in one kernel: the block owns complete rows
-        if ((rc = gemm_ln(w.buf0, lw.w_ao, lw.b_ao, w.bufX, lw.ln1_g, lw.ln1_b, w.bufX1, H))) return rc;
+        if ((rc = gemm_ln(w.buf0, lw.w_ao, lw.b_ao, Xin, ldin, lw.ln1_g, lw.ln1_b, w.bufX1, N, H))) return rc;
       } else {
-        if ((rc = gemm(w.buf0, lw.w_ao, H, lw.b_ao, w.bufX, w.buf1, 0, N, H, H, MH_ACT_NONE))) return rc;
+        if ((rc = gemm(w.buf0, N, lw.w_ao, H, lw.b_ao, Xin, ldin, w.buf1, 0, N, H, H, MH_ACT_NONE))) return rc;
         if ((rc = mh_layernorm_panel(w.buf1, N, lw.ln1_g, lw.ln1_b, w.bufX1, N, N, H, m->ln_eps, stream))) return rc;
       }
-      if (!(g_skip & 8) && (rc = gemm(w.bufX1, lw.w_ff1, F, lw.b_ff1, nullptr, w.ffn, 0, N, F, H, MH_ACT_GELU_ERF))) return rc;
+      if (!(g_skip & 8) && (rc = gemm(w.bufX1, N, lw.w_ff1, F, lw.b_ff1, nullptr, 0, w.ffn, 0, N, F, H, MH_ACT_GELU_ERF))) return rc;
       if (g_skip & 16) {
       } else if (fuse_ln) {
-        if ((rc = gemm_ln(w.ffn, lw.w_ff2, lw.b_ff2, w.bufX1, lw.ln2_g, lw.ln2_b, w.bufX, F))) return rc;
+        if ((rc = gemm_ln(w.ffn, lw.w_ff2, lw.b_ff2, w.bufX1, N, lw.ln2_g, lw.ln2_b, Xout, ldout, F))) return rc;
       } else {
-        if ((rc = gemm(w.ffn, lw.w_ff2, H, lw.b_ff2, w.bufX1, w.buf1, 0, N, H, F, MH_ACT_NONE))) return rc;
-        if ((rc = mh_layernorm_panel(w.buf1, N, lw.ln2_g, lw.ln2_b, w.bufX, N, N, H, m->ln_eps, stream))) return rc;
+        if ((rc = gemm(w.ffn, N, lw.w_ff2, H, lw.b_ff2, w.bufX1, N, w.buf1, 0, N, H, F, MH_ACT_NONE))) return rc;
+        if ((rc = mh_layernorm_panel(w.buf1, N, lw.ln2_g, lw.ln2_b, Xout, ldout, N, H, m->ln_eps, stream))) return rc;
       }
     }
+    if (!(ph.mask & 4)) return MH_OK;
     if (m->has_proj) {
       if (g_skip & 64) return MH_OK;
-      if ((rc = gemm(w.bufX, m->w_dn0, H, m->b_dn0, nullptr, w.buf0, 0, N, H, H, MH_ACT_TANH))) return rc;
-      return gemm(w.buf0, m->w_dn2, m->E, m->b_dn2, nullptr, out, 1, m->E, m->E, H, MH_ACT_NONE);
+      if ((rc = gemm(XT, ldT, m->w_dn0, H, m->b_dn0, nullptr, 0, w.buf0, 0, N, H, H, MH_ACT_TANH))) return rc;
+      return gemm(w.buf0, N, m->w_dn2, m->E, m->b_dn2, nullptr, 0, out, 1, m->E, m->E, H, MH_ACT_NONE);
     }
-    return mh_unpack_panel_f32(w.bufX, N, out, m->E, N, m->E, stream);
+    return mh_unpack_panel_f32(XT, ldT, out, m->E, N, m->E, stream);
   }
+  MH_CHECK_ARG(ph.mask == 7, "denoiser: the phased entry points serve the bf16 panel path only");
   // ---- embeddings: (up-projection) + position + time, LayerNorm          network.py:141-149
   if (m->has_proj) {
     if ((rc = mh_cast_pad(x, m->E, w.xin, m->E_pad, N, m->E, N, dt, stream))) return rc;
@@ -395,3 +447,4 @@ extern "C" int mh_denoiser_forward(const mh_denoiser* m, const float* x, const f
   }
   return mh_cast_to_f32(w.bufX, H, out, m->E, N, m->E, dt, stream);
 }
+}  // namespace

@@ -195,6 +195,38 @@ class DenoiserEngine:
               "mh_time_embed")
         return out
 
+    # ------------------------------------------------------------------ the forward in phases (bf16 panel models with projections)
+    def phases_supported(self):
+        return bool(lib().mh_denoiser_phases_supported(C.byref(self._desc)))
+
+    def new_rows(self, n_rows):
+        """A K32-panel activation buffer [H / 32][n_rows][32] bf16 for head / layers / tail to hand rows over in."""
+        return torch.empty(self.cfg["H"] // 32, n_rows, 32, dtype=torch.bfloat16, device=self.device)
+
+    @staticmethod
+    def _window(rows, first):
+        """(pointer, ld) of the row window of a panel buffer that starts at row `first`"""
+        return rows.data_ptr() + first * 32 * rows.element_size(), rows.shape[1]
+
+    def head(self, x, emb_t, emb_row, rows, first, ws):
+        """network.py:141-149 for the batch x [B, L, E]: its B L normalised hidden rows -> rows[:, first : first + B L, :]"""
+        B, L, _ = x.shape
+        p, ld = self._window(rows, first)
+        check(lib().mh_denoiser_head(C.byref(self._desc), ptr(x), ptr(emb_t), ptr(emb_row), p, ld, B, L, ptr(ws), ws.numel(), current_stream()),
+              "mh_denoiser_head")
+
+    def layers(self, rows_in, first_in, rows_out, first_out, B, L, ws):
+        """network.py:151 (the encoder) on the B L rows starting at first_in of rows_in -> rows_out from first_out"""
+        pi, ldi = self._window(rows_in, first_in)
+        po, ldo = self._window(rows_out, first_out)
+        check(lib().mh_denoiser_layers(C.byref(self._desc), pi, ldi, po, ldo, B, L, ptr(ws), ws.numel(), current_stream()), "mh_denoiser_layers")
+
+    def tail(self, rows, first, out, ws):
+        """network.py:153-157: down-projection of the B L rows from `first` -> out [B, L, E] fp32"""
+        B, L, _ = out.shape
+        p, ld = self._window(rows, first)
+        check(lib().mh_denoiser_tail(C.byref(self._desc), p, ld, ptr(out), B, L, ptr(ws), ws.numel(), current_stream()), "mh_denoiser_tail")
+
     def forward(self, x, emb_t, emb_row=None, out=None, ws=None):
         """x [B,L,E] fp32 -> [B,L,E] fp32 (models/network.py:131-158).  emb_t [*,H] fp32,
         emb_row [B] int32 selecting the emb_t row of each batch element (None: row b)."""

@@ -169,6 +169,11 @@ class GaussianDiffusion:
     # persistent launch that fills the chip on its own, so the arrangement of two chains does not change the sum): off by default
     decouple_branches = False
     branch_skew_us = None      # phase lag of branch j behind branch j-1 at the start of a decoupled loop; None = half a step / branches
+    # batch-sliced graph branches: the step's head (up-projection ... embedding LayerNorm) and tail (down-projection, rounding,
+    # posterior update) run ONCE for the whole batch and only the encoder layers per slice (engine.head / layers / tail).  Measured
+    # neutral (3.658 vs 3.660 ms / step at config 2, +0.7 % at c2-bertbase): the head / tail launches are NOT latency-bound - a
+    # full-batch launch of them takes twice a half-batch launch - so off by default
+    shared_head_tail = False
 
     def __init__(self, *, betas, predict_xstart, rescale_timesteps=False):
         self.rescale_timesteps = rescale_timesteps
@@ -680,6 +685,11 @@ class _ReverseLoop:
             self.br_state = [self.state.clone() for _ in range(self.nsplit)]
             self.br_coef = [torch.zeros(8, dtype=torch.float32, device=dev) for _ in range(self.nsplit)]
             self.br_graphs = {}
+            # shared head / tail: full-batch hand-over buffers (the slices read / write row windows of them) and a full-batch workspace
+            self.shared = bool(getattr(diff, "shared_head_tail", False) and eng.phases_supported())
+            if self.shared:
+                self.rows_in, self.rows_out = eng.new_rows(B * L), eng.new_rows(B * L)
+                self.full_ws = eng.new_workspace(B, L)
         self.decoupled = False
 
     def _tail(self, sl, stream_h, ws, cur_coef, use_round):
@@ -723,6 +733,26 @@ class _ReverseLoop:
         if nsplit <= 1:
             self.eng.forward(self.x, self.emb_table, self.emb_row, out=self.model_out, ws=self.own_ws)
             draw_noise(st)
+            tail(slice(0, self.B), st, self.round_ws)
+        elif getattr(self, "shared", False):
+            # head once for the whole batch -> the slices' encoder layers as concurrent branches (the noise is drawn at the head of the
+            # first side branch) -> join -> down-projection, rounding and update once for the whole batch
+            main = torch.cuda.current_stream()
+            self.eng.head(self.x, self.emb_table, self.emb_row, self.rows_in, 0, self.full_ws)
+            self.ev_fork.record(main)
+            for j in range(1, nsplit):
+                sl, side = self.slices[j], self.side_streams[j - 1]
+                side.wait_event(self.ev_fork)
+                with torch.cuda.stream(side):
+                    if j == 1:
+                        draw_noise(side.cuda_stream)
+                    self.eng.layers(self.rows_in, sl.start * self.L, self.rows_out, sl.start * self.L, sl.stop - sl.start, self.L, self.split_ws[j])
+                    self.ev_join[j - 1].record(side)
+            sl0 = self.slices[0]
+            self.eng.layers(self.rows_in, 0, self.rows_out, 0, sl0.stop - sl0.start, self.L, self.split_ws[0])
+            for j in range(1, nsplit):
+                main.wait_event(self.ev_join[j - 1])
+            self.eng.tail(self.rows_out, 0, self.model_out, self.full_ws)
             tail(slice(0, self.B), st, self.round_ws)
         else:
             # independent sequences -> independent chains: the slices of the batch run as concurrent graph branches

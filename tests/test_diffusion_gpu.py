@@ -292,10 +292,52 @@ def test_batch_split_branches_equal_single_stream():
         diff.use_graph, diff.decouple_branches, diff.branch_skew_us = True, True, 50 * split
         outs[(split, True, True)] = diff.p_sample_loop(**kw)[0].clone()
         diff.decouple_branches, diff.branch_skew_us = False, None
+        # head and tail of the step once for the whole batch, the encoder layers per slice (bf16 panel engines only; here: same path)
+        diff.shared_head_tail = True
+        outs[(split, True, "shared")] = diff.p_sample_loop(**kw)[0].clone()
+        diff.shared_head_tail = False
     diff.batch_split = 1
     ref = outs[(1, True, False)]
     for k, v in outs.items():
         assert torch.equal(v, ref), "batch_split=%d graph=%s decoupled=%s differs" % k
+
+
+def test_phased_forward_and_shared_head_tail_bf16():
+    """engine.head / layers / tail over row windows of a full-batch panel buffer == the monolithic forward, bit for bit; and the loop
+    that runs head + tail once for the whole batch and the encoder layers per slice gives the samples of the per-slice loop."""
+    tag = "c2s"          # up / down projections (E != d_model) and the bf16 panel layout: what the phased entry points serve
+    m, diff, model_emb, inp, c = build(tag, "bf16")
+    B, L, E = c["B"], c["L"], c["E"]
+    eng = m.engine()
+    assert eng.phases_supported()
+    x = inp["fwd_x"].to(DEV)
+    emb_t = eng.time_embed(inp["fwd_t"].to(DEV))
+    ref = eng.forward(x, emb_t).clone()
+    rows_in, rows_out = eng.new_rows(B * L), eng.new_rows(B * L)
+    ws_full, ws_a, ws_b = eng.new_workspace(B, L), eng.new_workspace(B // 2, L), eng.new_workspace(B - B // 2, L)
+    row = torch.arange(B, dtype=torch.int32, device=DEV)
+    eng.head(x, emb_t, row, rows_in, 0, ws_full)
+    hb = B // 2
+    eng.layers(rows_in, 0, rows_out, 0, hb, L, ws_a)
+    eng.layers(rows_in, hb * L, rows_out, hb * L, B - hb, L, ws_b)
+    out = torch.empty_like(x)
+    eng.tail(rows_out, 0, out, ws_full)
+    assert torch.equal(out, ref)
+    x_start, mask3 = inp["x_start"].to(DEV), inp["mask3"].to(DEV)
+    x_gen = osa.start_latent_generation(inp["x_start"], inp["mask3"], inp["gen_noise0"]).to(DEV)
+    fn = partial(denoised_fn_round, model_emb.to(DEV), dist=None)
+    kw = dict(model=m, shape=(B, L, E), noise=x_gen, clip_denoised=True, denoised_fn=fn, model_kwargs={}, top_p=1,
+              clamp_step=0, clamp_first=True, mask=mask3, x_start=x_start, t_enc=4, only_last=True)
+    diff.noise_fn = None
+    diff.rng_mode, diff.rng_seed, diff.rng_stream, diff.batch_split = "philox", 11, 0, 2
+    outs = {}
+    for shared in (False, True):
+        for ug in (True, False):
+            diff.shared_head_tail, diff.use_graph = shared, ug
+            outs[(shared, ug)] = diff.p_sample_loop(**kw)[0].clone()
+    diff.shared_head_tail, diff.batch_split = False, None
+    for k, v in outs.items():
+        assert torch.equal(v, outs[(False, True)]), "shared=%s graph=%s differs" % k
 
 
 @pytest.mark.parametrize("segment", ["first", "last"])
