@@ -331,7 +331,9 @@ int denoiser_run(const mh_denoiser* m, const float* x, const float* emb_t, const
         const int64_t ldin = l == 0 ? ldI : N;
         mh_ln_defer d{};
         d.h_norm = H; d.eps = m->ln_eps;
-        if (prev_raw) {
+        if (g_skip & 1) {
+          rc = MH_OK;
+        } else if (prev_raw) {
           d.a_stats = w.stats2; d.a_slots = S; d.c1 = lw.c1_qkv;
           if (pre_q) rc = mh_gemm_qkv_vtperm_qs(Xin, ldin, lw.w_qkv_f, 3 * H, lw.c2_qkv, w.q, w.k, w.vt, B, L, H, m->nh, q_scale, &d, stream);
           else rc = mh_gemm_qkv_vtperm_defer(Xin, ldin, lw.w_qkv_f, 3 * H, lw.c2_qkv, w.q, w.k, w.vt, B, L, H, m->nh, &d, stream);
@@ -340,25 +342,25 @@ int denoiser_run(const mh_denoiser* m, const float* x, const float* emb_t, const
           else rc = mh_gemm_qkv_vtperm(Xin, ldin, P, lw.w_qkv, 3 * H, P, lw.b_qkv, w.q, w.k, w.vt, B, L, H, m->nh, stream);
         }
         if (rc) return rc;
-        if ((rc = attention())) return rc;
+        if (!(g_skip & 2) && (rc = attention())) return rc;
         // y1 = ctx W_ao^T + b_ao + X  (raw) -> bufX1, statistics -> stats1
         d = mh_ln_defer{};
         d.h_norm = H; d.eps = m->ln_eps;
         if (prev_raw) { d.r_stats = w.stats2; d.r_slots = S; d.r_gamma = pl->ln2_g; d.r_beta = pl->ln2_b; }
         d.o_stats = w.stats1; d.o_slots = S;
-        if ((rc = mh_gemm_bias_act_defer(w.buf0, N, lw.w_ao, H, lw.b_ao, Xin, ldin, w.bufX1, N, N, H, H, MH_ACT_NONE, &d, stream))) return rc;
+        if (!(g_skip & 4) && (rc = mh_gemm_bias_act_defer(w.buf0, N, lw.w_ao, H, lw.b_ao, Xin, ldin, w.bufX1, N, N, H, H, MH_ACT_NONE, &d, stream))) return rc;
         // f = gelu(LN1(y1) W1^T + b1)
         d = mh_ln_defer{};
         d.h_norm = H; d.eps = m->ln_eps;
         d.a_stats = w.stats1; d.a_slots = S; d.c1 = lw.c1_ff1;
-        if ((rc = mh_gemm_bias_act_defer(w.bufX1, N, lw.w_ff1_f, F, lw.c2_ff1, nullptr, 0, w.ffn, N, N, F, H, MH_ACT_GELU_ERF, &d, stream))) return rc;
+        if (!(g_skip & 8) && (rc = mh_gemm_bias_act_defer(w.bufX1, N, lw.w_ff1_f, F, lw.c2_ff1, nullptr, 0, w.ffn, N, N, F, H, MH_ACT_GELU_ERF, &d, stream))) return rc;
         // y2 = f W2^T + b2 + LN1(y1)
         const bool last = l == m->nL - 1;
         d = mh_ln_defer{};
         d.h_norm = H; d.eps = m->ln_eps;
         d.r_stats = w.stats1; d.r_slots = S; d.r_gamma = lw.ln1_g; d.r_beta = lw.ln1_b;
         if (!last) { d.o_stats = w.stats2; d.o_slots = S; }
-        if ((rc = mh_gemm_bias_act_defer(w.ffn, N, lw.w_ff2, H, lw.b_ff2, w.bufX1, N, last ? w.buf1 : w.bufX, N, N, H, F, MH_ACT_NONE, &d, stream))) return rc;
+        if (!(g_skip & 16) && (rc = mh_gemm_bias_act_defer(w.ffn, N, lw.w_ff2, H, lw.b_ff2, w.bufX1, N, last ? w.buf1 : w.bufX, N, N, H, F, MH_ACT_NONE, &d, stream))) return rc;
         if (last) {
           if ((rc = mh_layernorm_panel(w.buf1, N, lw.ln2_g, lw.ln2_b, XO, ldO, N, H, m->ln_eps, stream))) return rc;
         }
