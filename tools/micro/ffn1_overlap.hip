@@ -106,6 +106,43 @@ __global__ __launch_bounds__(THREADS) void k32(const bf16* __restrict__ src, bf1
   if (tid == 0) cyc[blockIdx.x] = (t1 - t0) / tiles;
 }
 
+// K-steps only on a 128x128 wave tile (64 mfma_16x16x32 + 16 ds_read_b128 per K-step, 256 accumulator registers: one wave per SIMD
+// with the 512-register budget): does the larger tile keep the matrix pipe as busy as two waves of 128x64 do, with 2/3 of the LDS bytes?
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void kbig(const bf16* __restrict__ src, bf16* __restrict__ dst, int tiles) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  char* mine = lds + (wave & 3) * 24576;
+  for (int i = tid; i < 4 * 24576 / 16; i += blockDim.x) reinterpret_cast<f32x4*>(lds)[i] = reinterpret_cast<const f32x4*>(src)[(i + blockIdx.x * 97) & 65535];
+  __syncthreads();
+  f32x4 acc[8][8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.1f * i, 0.2f * j, -0.3f, 0.05f * lane};
+  for (int t = 0; t < tiles; ++t) {
+#pragma unroll 4
+    for (int kt = 0; kt < 16; ++kt) {
+      bf16x8 a[8], b[8];
+      const char* st = mine + (kt % 3) * 8192;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) b[j] = *reinterpret_cast<const bf16x8*>(st + ((j * 512 + lane * 16) & 8191));
+#pragma unroll
+      for (int i = 0; i < 8; ++i) a[i] = *reinterpret_cast<const bf16x8*>(st + ((4096 + i * 512 + lane * 16) & 8191));
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+    }
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += acc[i][j][0] + acc[i][j][3];
+  if (s == 12345.678f) dst[0] = (bf16)s;
+}
+
 template <int MODE, int DMA, int THREADS>
 __global__ __launch_bounds__(THREADS) void k(const bf16* __restrict__ src, bf16* __restrict__ dst, const float* __restrict__ bias, int tiles,
                                          unsigned long long* cyc) {
@@ -291,5 +328,18 @@ int main() {
   run32<4, T>("waves 4-7 half a tile out of phase", src, dst, bias, cyc);
   ALL32(256)
   ALL32(512)
+  {
+    const int tiles = 200;
+    auto kern = kbig<256>;
+    hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 24576);
+    kern<<<256, 256, 4 * 24576>>>(src, dst, tiles);
+    hipDeviceSynchronize();
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipEventRecord(e0);
+    kern<<<256, 256, 4 * 24576>>>(src, dst, tiles);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    printf("128x128 wave tile, K-steps only, 1 wave/SIMD: %7.3f us per (double-size) tile = %7.3f us per 512 MFMAs per SIMD\n", ms * 1e3 / tiles, ms * 1e3 / tiles / 2);
+  }
   return 0;
 }
