@@ -8,6 +8,7 @@
 typedef __bf16 bf16;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
@@ -125,6 +126,30 @@ __device__ __forceinline__ float gelu_erf_fast(float x) {
   return x * __builtin_amdgcn_rcpf(1.0f + e);
 }
 
+// the same function on 8 values as 4 register pairs: v_pk_mul / v_pk_fma / v_pk_add (two fp32 lanes per instruction) - 5 full-rate +
+// 2 transcendental instructions per value instead of 7 + 2; the operations and their order are gelu_erf_fast's (bit-identical)
+__device__ __forceinline__ void gelu_erf_fast8(float (&v)[8]) {
+  constexpr float kL2E = 1.4426950408889634f;
+  const f32x2 c2 = {0.0007030335771326705f * kL2E, 0.0007030335771326705f * kL2E};
+  const f32x2 c1 = {-0.07401129204508086f * kL2E, -0.07401129204508086f * kL2E};
+  const f32x2 c0 = {-1.5950157685701116f * kL2E, -1.5950157685701116f * kL2E};
+  const f32x2 one = {1.0f, 1.0f};
+#pragma unroll
+  for (int e = 0; e < 8; e += 2) {
+    f32x2 x = {v[e], v[e + 1]};
+    f32x2 u = x * x;
+    u.x = fminf(u.x, 64.0f); u.y = fminf(u.y, 64.0f);
+    f32x2 p = __builtin_elementwise_fma(c2, u, c1);
+    p = __builtin_elementwise_fma(p, u, c0);
+    const f32x2 t = x * p;
+    const f32x2 ex = {__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
+    const f32x2 d = one + ex;
+    const f32x2 r = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+    x = x * r;
+    v[e] = x.x; v[e + 1] = x.y;
+  }
+}
+
 // tanh for the bf16 path: 1 - 2 / (1 + 2^(2 x log2 e)) with one v_exp and one v_rcp (|error| < 3e-7 relative to fp32 tanh for
 // |x| < 10, exact saturation beyond: two orders below the bf16 rounding of the result); the fp32 parity path uses tanhf
 __device__ __forceinline__ float tanh_fast(float x) {
@@ -204,19 +229,29 @@ __device__ __forceinline__ uint32_t drop_keep8_at(const DropArgs& d, uint64_t e0
 // 2^-16, as at the dense sites, at half the generator work (the forward is VALU-bound).  The tie-break byte is another
 // element's primary byte: a dependence that touches 0.4% of the elements.  nkb = ceil(L / 32).
 // Returns bit r set <=> P[q][32 kb + key(r)] is KEPT.
+// (Instruction form: byte r over byte r + 1 is ONE 16-bit number, and the rule above is `number >= 256 thr8 + thr_tie`.  A v_perm
+// puts two neighbours' numbers into the halves of a dword, a subtraction leaves "dropped" in the sign bit and v_alignbit shifts it
+// into the mask: 2.5 instructions per element instead of the 9 of three byte compares - on gfx950 compares, selects, shifts and
+// byte extracts all issue at half the rate of and / add / xor, tools/micro/valu_rate.hip.)
+__device__ __forceinline__ uint32_t drop_keep_attn_from(const uint32_t (&c)[4], uint32_t thr16) {
+  uint32_t m = 0;   // bit r <=> element r is DROPPED; elements enter from the top one down
+#pragma unroll
+  for (int w = 3; w >= 0; --w) {
+    // bytes (B[r + 1], B[r], B[r + 2], B[r + 1]), low to high, for r = 4 w + 2 and r = 4 w
+    const uint32_t d23 = __builtin_amdgcn_perm(c[(w + 1) & 3], c[w], 0x03040203u);
+    const uint32_t d01 = __builtin_amdgcn_perm(c[(w + 1) & 3], c[w], 0x01020001u);
+    m = __builtin_amdgcn_alignbit(m, (d23 >> 16) - thr16, 31);
+    m = __builtin_amdgcn_alignbit(m, (d23 & 0xffffu) - thr16, 31);
+    m = __builtin_amdgcn_alignbit(m, (d01 >> 16) - thr16, 31);
+    m = __builtin_amdgcn_alignbit(m, (d01 & 0xffffu) - thr16, 31);
+  }
+  return ~m & 0xffffu;
+}
 __device__ __forceinline__ uint32_t drop_keep_attn(const DropArgs& d, int64_t bh, int L, int nkb, int q, int kb, int h) {
   const uint64_t idx = ((((uint64_t)bh * L + q) * nkb + kb) << 1) | (uint64_t)h;
   uint32_t c[4] = {(uint32_t)idx, (uint32_t)(idx >> 32), d.off_lo, d.off_hi};
   mh_philox<7>(c, d.seed_lo, d.seed_hi);
-  uint32_t m = 0;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const uint32_t b = (c[r >> 2] >> (8 * (r & 3))) & 0xffu;
-    const uint32_t b2 = (c[((r + 1) & 15) >> 2] >> (8 * ((r + 1) & 3))) & 0xffu;
-    const bool keep = b > d.thr8 || (b == d.thr8 && b2 >= d.thr_tie);
-    m |= (keep ? 1u : 0u) << r;
-  }
-  return m;
+  return drop_keep_attn_from(c, (d.thr8 << 8) + d.thr_tie);
 }
 // The keep-bit tensor is LANE-NATIVE: uint32 [B nh][nb = ceil(L / 32) query blocks][ceil(nb / 2) pairs of 32-key blocks][64 lanes].
 // The word of lane (lq, h) holds that lane's 16 flags of the pair's even key block in its low half and of the odd block in its high

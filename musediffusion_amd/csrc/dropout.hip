@@ -47,19 +47,32 @@ __global__ void dropout_fwd_kernel(const T* __restrict__ x, int64_t ldx, T* __re
   }
 }
 
-// one wave per (bh, 32-query block, pair of 32-key blocks): the 64-key S^T tile of the fused kernels, lane-native words
-__global__ __launch_bounds__(256) void dropout_bits_kernel(uint32_t* __restrict__ bits, int64_t ntiles, int L, int nb, int nkp,
+// one wave per (bh, 32-query block, run of `kchunk` pairs of 32-key blocks - the 64-key S^T tiles of the fused kernels), lane-native
+// words.  No division in the inner loop, and the counter advances by additions.
+__global__ __launch_bounds__(256) void dropout_bits_kernel(uint32_t* __restrict__ bits, int nitems, int nchunks, int kchunk, int L, int nb, int nkp,
                                                            const DropArgs d) {
   const int lane = threadIdx.x & 63, lq = lane & 31, h = lane >> 5;
-  const int64_t w0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  for (int64_t tile = w0; tile < ntiles; tile += (int64_t)gridDim.x * 4) {
-    const int kp = (int)(tile % nkp);
-    const int qb = (int)((tile / nkp) % nb);
-    const int64_t bh = tile / ((int64_t)nkp * nb);
+  const uint32_t thr16 = (d.thr8 << 8) + d.thr_tie;
+  for (int item = blockIdx.x * 4 + (threadIdx.x >> 6); item < nitems; item += gridDim.x * 4) {
+    const int rowblk = item / nchunks, kp0 = (item - rowblk * nchunks) * kchunk;
+    const int bh = rowblk / nb, qb = rowblk - bh * nb;
+    const int kp1 = kp0 + kchunk < nkp ? kp0 + kchunk : nkp;
     int q = qb * 32 + lq; if (q >= L) q = L - 1;
-    uint32_t kw = drop_keep_attn(d, bh, L, nb, q, 2 * kp, h);
-    if (2 * kp + 1 < nb) kw |= drop_keep_attn(d, bh, L, nb, q, 2 * kp + 1, h) << 16;
-    bits[drop_word_index(bh, nb, qb, kp, lane)] = kw;
+    const uint64_t idx0 = ((((uint64_t)bh * L + q) * nb) << 1) | (uint64_t)h;     // drop_keep_attn's counter for key block 0
+    uint32_t* dst = bits + drop_word_index(bh, nb, qb, 0, lane);
+    for (int kp = kp0; kp < kp1; ++kp) {
+      const uint64_t i0 = idx0 + 4 * (uint64_t)kp;
+      uint32_t c0[4] = {(uint32_t)i0, (uint32_t)(i0 >> 32), d.off_lo, d.off_hi};
+      mh_philox<7>(c0, d.seed_lo, d.seed_hi);
+      uint32_t kw = drop_keep_attn_from(c0, thr16);
+      if (2 * kp + 1 < nb) {
+        const uint64_t i1 = i0 + 2;
+        uint32_t c1[4] = {(uint32_t)i1, (uint32_t)(i1 >> 32), d.off_lo, d.off_hi};
+        mh_philox<7>(c1, d.seed_lo, d.seed_hi);
+        kw |= drop_keep_attn_from(c1, thr16) << 16;
+      }
+      dst[(int64_t)kp << 6] = kw;
+    }
   }
 }
 
@@ -110,9 +123,15 @@ extern "C" int mh_dropout_bits(uint32_t* keep_bits, int BH, int L, const mh_drop
   int rc = mh_drop_args(drop, &d);
   if (rc) return rc;
   const int nb = (L + 31) / 32, nkp = (nb + 1) / 2;
-  const int64_t ntiles = (int64_t)BH * nb * nkp;
-  const int grid = (int)((ntiles + 3) / 4 < 262140 ? (ntiles + 3) / 4 : 262140);
-  MH_LAUNCH(dropout_bits_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, keep_bits, ntiles, L, nb, nkp, d);
+  const int64_t nrows = (int64_t)BH * nb;
+  // a wave walks a run of key-block pairs of one row block: whole rows when there are enough of them to fill the chip, shorter runs otherwise
+  int kchunk = nkp;
+  while (kchunk > 1 && nrows * ((nkp + kchunk - 1) / kchunk) < 8192) kchunk = (kchunk + 1) / 2;
+  const int nchunks = (nkp + kchunk - 1) / kchunk;
+  const int64_t nitems = nrows * nchunks;
+  MH_CHECK_ARG(nitems < (1ll << 31), "dropout_bits: %lld work items do not fit 31 bits", (long long)nitems);
+  const int grid = (int)((nitems + 3) / 4 < 262140 ? (nitems + 3) / 4 : 262140);
+  MH_LAUNCH(dropout_bits_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, keep_bits, (int)nitems, nchunks, kchunk, L, nb, nkp, d);
   MH_CHECK_LAUNCH();
   return MH_OK;
 }

@@ -1057,6 +1057,10 @@ __global__ __launch_bounds__(C::THREADS, C::STAGE * C::NST <= 80 * 1024 ? 2 : 1)
       auto epi_gen = [&](auto fullc) {
         constexpr bool FULL = decltype(fullc)::value;
         float bv[TJ / 2][8];          // every bias load before the first store
+        // element offsets as (column part) + (row part), the row part advanced by additions: a 64-bit multiply per store is three
+        // quarter-rate instructions, and the epilogue is vector-bound
+        const int64_t o_rs = g.o_panel ? 32 : g.ldo, r_rs = g.r_panel ? 32 : g.ldr;     // elements between consecutive rows
+        const int64_t o_row0 = (wrow0 + fr) * o_rs, r_row0 = (wrow0 + fr) * r_rs;
         float os1[TI], os2[TI];       // DO: running (sum, sum of squares) of this lane's part of each row
         if constexpr (DO) {
 #pragma unroll
@@ -1081,16 +1085,21 @@ __global__ __launch_bounds__(C::THREADS, C::STAGE * C::NST <= 80 * 1024 ? 2 : 1)
             if constexpr (DR) { load8(g.d.r_gamma + ((FULL || col + 8 <= g.N) ? col : 0), rgv); load8(g.d.r_beta + ((FULL || col + 8 <= g.N) ? col : 0), rbv); }
             bf16x8 rraw[TI];         // the group's residual rows: all loads in flight together, behind the previous group's stores
             if (res) {
+              const int64_t r_col = g.r_panel ? (int64_t)(col >> 5) * g.ldr * 32 + (col & 31) : col;
+              int64_t ro = r_col + r_row0;
 #pragma unroll
               for (int i = 0; i < TI; ++i) {
-                int64_t row = wrow0 + 16 * i + fr; if (!FULL && row >= g.M) row = g.M - 1;
-                const int64_t ro = g.r_panel ? ((int64_t)(col >> 5) * g.ldr + row) * 32 + (col & 31) : row * g.ldr + col;
-                rraw[i] = *reinterpret_cast<const bf16x8*>(res + ro);
+                if (FULL || wrow0 + 16 * i + fr < g.M) rraw[i] = *reinterpret_cast<const bf16x8*>(res + ro);
+                else rraw[i] = *reinterpret_cast<const bf16x8*>(res + r_col + (g.M - 1) * r_rs);
+                ro += 16 * r_rs;
               }
             }
+            const int64_t o_col = g.o_panel ? (int64_t)(col >> 5) * g.ldo * 32 + (col & 31) : col;
+            int64_t oo = o_col + o_row0 - 16 * o_rs;
 #pragma unroll
             for (int i = 0; i < TI; ++i) {
               const int64_t row = wrow0 + 16 * i + fr;
+              oo += 16 * o_rs;
               if (FULL || row < g.M) {
                 float v[8];
                 const int rt = wm * (TI * 16) + 16 * i + fr;     // row of the tile: (mean, rstd) pairs staged in LDS
@@ -1104,11 +1113,13 @@ __global__ __launch_bounds__(C::THREADS, C::STAGE * C::NST <= 80 * 1024 ? 2 : 1)
                 }
                 if constexpr (ACT != MH_ACT_NONE) {
                   if (g.pre_out) {   // training: the backward needs the pre-activation
-                    const int64_t po = g.o_panel ? ((int64_t)(col >> 5) * g.ldo + row) * 32 + (col & 31) : row * g.ldo + col;
-                    store8_nt(reinterpret_cast<bf16*>(g.pre_out) + (int64_t)blockIdx.y * g.sO + po, v);
+                    store8_nt(reinterpret_cast<bf16*>(g.pre_out) + (int64_t)blockIdx.y * g.sO + oo, v);
                   }
+                  if constexpr (ACT == MH_ACT_GELU_ERF) gelu_erf_fast8(v);
+                  else {
 #pragma unroll
-                  for (int e = 0; e < 8; ++e) v[e] = apply_act<bf16>(v[e], ACT);
+                    for (int e = 0; e < 8; ++e) v[e] = apply_act<bf16>(v[e], ACT);
+                  }
                 }
                 if constexpr ((DBG & 64) != 0) {   // train-mode dropout of the dense output, before the residual
                   const uint32_t km = drop_keep8_at(g.drop, (uint64_t)row * g.N + col);
@@ -1136,10 +1147,9 @@ __global__ __launch_bounds__(C::THREADS, C::STAGE * C::NST <= 80 * 1024 ? 2 : 1)
                   for (int e = 0; e < 8; ++e) { const float r = (float)(bf16)v[e]; os1[i] += r; os2[i] += r * r; }
                 }
                 if (g.out_f32) {
-                  if (FULL || col + 8 <= g.N) store8(outF + row * g.ldo + col, v);
-                  else *reinterpret_cast<f32x4*>(outF + row * g.ldo + col) = f32x4{v[0], v[1], v[2], v[3]};   // N % 8 == 4 tail
+                  if (FULL || col + 8 <= g.N) store8(outF + oo, v);
+                  else *reinterpret_cast<f32x4*>(outF + oo) = f32x4{v[0], v[1], v[2], v[3]};   // N % 8 == 4 tail
                 } else {
-                  const int64_t oo = g.o_panel ? ((int64_t)(col >> 5) * g.ldo + row) * 32 + (col & 31) : row * g.ldo + col;
                   // streaming stores for outputs read once, much later or by a streaming reader; the deferred-LayerNorm producers' raw
                   // rows are re-read at once as A operand and residual: ordinary stores (c2-bertbase -2.0 % step time, A/B of two builds)
                   if constexpr ((DBG & 32) != 0 || DO) store8(outT + oo, v); else store8_nt(outT + oo, v);
