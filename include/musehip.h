@@ -139,9 +139,10 @@ int mh_attention_stream_fwd(const void* q, const void* k, const void* vt_perm, v
 int mh_attention_stream_fwd_lse(const void* q, const void* k, const void* vt_perm, void* ctx, int64_t ld_ctx, int ctx_panel,
                                 int B, int L, int nh, int dh, float scale, float* lse2, mh_stream_t stream);
 /* Fused attention backward (bf16; seq_len % 16 == 0, >= 512: partial last tiles are masked, as in the streaming forward).  q, k, v, dO: [B, nh, L, dh] rows;
- * qT_perm, kT_perm, dOT_perm: [B, nh, dh, L] with the positions of every group of 16 permuted (mh_head_permute
- * mode 3); o = the forward output in dO's layout; lse2 from the forward; D = [B, nh, L] fp32 scratch (the dQ kernel
- * writes D[b, h, l] = sum_d dO o O there, the dK/dV kernel reads it).  dq, dk, dv are written
+ * qT_perm, kT_perm, dOT_perm: UNUSED since round 3 (may be null) - the kernels read K^T, Q^T and dO^T out of the row-layout LDS
+ * stages with the transposing ds_read_b64_tr_b16, so the [B, nh, dh, L] copies of round 2 are no longer made; the parameters stay
+ * for binary compatibility.  o = the forward output in dO's layout; lse2 from the forward; D = [B, nh, L] fp32 scratch (the dQ kernel
+ * writes D[b, h, l] = sum_d dO o O there - times (1 - p) in the dropout variant - and the dK/dV kernel reads it).  dq, dk, dv are written
  * token-major: element (token, head, d) at ptr[token * ld_d + head * dh + d] - e.g. the three column blocks of a
  * [B L, 3H] gradient of the fused QKV projection.  Replaces autograd through BertSelfAttention (the encoder that
  * models/network.py:151 calls) inside training_losses (models/diffusion.py:594-699). */

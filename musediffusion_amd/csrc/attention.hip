@@ -831,7 +831,7 @@ __global__ __launch_bounds__(64 * NW) void attn_stream_bf16_kernel(const bf16* _
 #pragma unroll
           for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) s[kt][r] = (kw >> (16 * kt + r)) & 1u ? s[kt][r] : 0.f;
+            for (int r = 0; r < 16; ++r) s[kt][r] = and_bits(s[kt][r], keep_mask(kw, 16 * kt + r));
         }
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)

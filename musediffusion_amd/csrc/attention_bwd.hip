@@ -10,8 +10,12 @@
 //
 // with D[q] = sum_d dO[q][d] O[q][d].  Every product is a v_mfma_f32_32x32x16_bf16 whose B operand is either a
 // register-resident fragment of the wave's own tile or the previous product's accumulator converted to bf16 in
-// place (its register order is the "P-operand" key order, which is why the transposed operands K^T, Q^T, dO^T
-// arrive with the keys of every group of 16 stored as 0-3, 8-11, 4-7, 12-15: mh_head_permute mode 3).
+// place; its register order is the "P-operand" row order (element j of lane half h <-> row 8 (j >> 2) + 4 h + (j & 3) of
+// a 16-row slab).  The transposed operands K^T, Q^T, dO^T are NOT separate tensors: the row-layout LDS stages that feed
+// S and dP are read a second time with the transposing ds_read_b64_tr_b16 (cdna_hip_programming.md T10), whose four
+// rows per 16-lane group are addressed in exactly that order - no transposed copies in HBM, half the LDS-DMA traffic.
+// One swizzle serves both kinds of read (row_swz).  The fragments of a 32-row sub-tile are read ahead of the MFMAs that
+// use them: the next sub-tile's row fragments and this one's transposed fragments land under the exp / dS vector work.
 // Recomputing S in both kernels costs 2 extra products but needs neither atomics nor an [L, L] tensor in HBM.
 #include "common.h"
 
@@ -23,12 +27,22 @@ __device__ __forceinline__ void glds16(const void* g, void* l) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
 
-// piece p (1 KiB) of a row-layout operand stage: rows [row][DH] bf16, 16-B chunk c of row r stored at c ^ ((r / RPB) & (CH-1))
+// 16-byte chunk c of row r of a row-layout stage ([row][DH] bf16) is stored at chunk c ^ row_swz(r).
+// dh 64 (128-byte rows, two per 256 bytes of banks): a rotation of (r >> 1) & 7 - any bijection of those three bits keeps the
+// ds_read_b128 row reads conflict-free (the 16 rows of a lane group then fall on 16 different 16-byte bank slots); the transposing
+// read of a 32-lane half takes 4 consecutive rows x 4 chunks, rows r and r + 2 share their 32 banks, so row bit 1 must move the
+// chunk by 4: bit 0 of (r >> 1) goes to bit 2.  dh 32 (64-byte rows, four per 256 bytes): 4 rows x 4 chunks are 16 slots anyway.
+template <int DH>
+__device__ __forceinline__ int row_swz(int row) {
+  if constexpr (DH == 64) { const int v = (row >> 1) & 7; return ((v & 1) << 2) | (v >> 1); }
+  else return (row / (128 / DH)) & (DH / 8 - 1);
+}
+// piece p (1 KiB) of a row-layout operand stage
 template <int DH>
 __device__ __forceinline__ void dma_rows(const bf16* src, int64_t ld, char* dst, int p, int lane, int valid_rows) {
-  constexpr int CH = DH / 8, RPB = 128 / DH, KROWB = DH * 2, KRP = 1024 / KROWB;
+  constexpr int CH = DH / 8, KROWB = DH * 2, KRP = 1024 / KROWB;
   const int row = p * KRP + lane / CH, pc = lane % CH;
-  const int lc = pc ^ ((row / RPB) & (CH - 1));
+  const int lc = pc ^ row_swz<DH>(row);
   const int rsrc = row < valid_rows ? row : valid_rows - 1;     // rows past the sequence end: a valid row (their terms are masked)
   glds16(src + (int64_t)rsrc * ld + lc * 8, dst + p * 1024);
 }
@@ -37,26 +51,41 @@ struct RowLayout {
   int64_t sB, sH, ld;   // batch stride, head stride, row pitch (elements)
   __device__ __forceinline__ int64_t at(int bh, int nh, int64_t row) const { return (int64_t)(bh / nh) * sB + (int64_t)(bh % nh) * sH + row * ld; }
 };
-// piece p of a transposed operand stage: global [DH][L] (key order permuted per 16), LDS = 64-column tiles of [DH][128 B],
-// chunk c of row d stored at c ^ ((d >> 1) & 7)
-template <int DH>
-__device__ __forceinline__ void dma_cols(const bf16* src, int64_t L, char* dst, int p, int lane, int valid_cols) {
-  const int t = p / (DH / 8), d = (p % (DH / 8)) * 8 + (lane >> 3), pc = lane & 7;
-  const int lc = pc ^ ((d >> 1) & 7);
-  int c = t * 64 + lc * 8;
-  if (c >= valid_cols) c = valid_cols - 8;                      // columns past the end: a valid chunk (finite values x 0)
-  glds16(src + (int64_t)d * L + c, dst + p * 1024);
-}
 // A-operand fragment (32 rows x 16 k) of a row-layout stage: stage-relative row R, k-step ks, lane half h
 template <int DH>
 __device__ __forceinline__ bf16x8 frag_rows(const char* stage, int R, int ks, int h) {
-  constexpr int CH = DH / 8, RPB = 128 / DH, KROWB = DH * 2;
-  return *reinterpret_cast<const bf16x8*>(stage + R * KROWB + (((2 * ks + h) ^ ((R / RPB) & (CH - 1))) << 4));
+  return *reinterpret_cast<const bf16x8*>(stage + R * (DH * 2) + (((2 * ks + h) ^ row_swz<DH>(R)) << 4));
 }
-// A-operand fragment (32 d rows x 16 columns) of a transposed stage: 64-column tile t, 16-column slab sl (0..3), row d
+// A-operand fragment (32 d x 16 k) of the TRANSPOSE of a row-layout stage: k = the 16 rows from Rb (a multiple of 16) in P-operand
+// order, d = 32 dt + lane % 32.  Two transposing reads; lane 4 q + p of a 16-lane group (group = lane half h x column half c16)
+// supplies the address of row 4 h + q (+ 8 for the second read), columns 32 dt + 16 c16 + 4 p ... + 3, and receives column
+// 32 dt + 16 c16 + (its index in the group) of the group's four rows.  The per-lane offsets do not depend on Rb (row_swz has the
+// period 16): tr_offsets computes them once per kernel.
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+template <int DH> struct TrOff { int o[DH / 32][2]; };
 template <int DH>
-__device__ __forceinline__ bf16x8 frag_cols(const char* stage, int t, int sl, int d, int h) {
-  return *reinterpret_cast<const bf16x8*>(stage + t * (DH * 128) + d * 128 + (((2 * sl + h) ^ ((d >> 1) & 7)) << 4));
+__device__ __forceinline__ TrOff<DH> tr_offsets(int lane) {
+  TrOff<DH> t;
+  const int i = lane & 15, q = i >> 2, p = i & 3, c16 = (lane >> 4) & 1, h = lane >> 5;
+#pragma unroll
+  for (int dt = 0; dt < DH / 32; ++dt)
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const int r = 4 * h + q + 8 * half, chunk = 4 * dt + 2 * c16 + (p >> 1);
+      t.o[dt][half] = r * (DH * 2) + ((chunk ^ row_swz<DH>(r)) << 4) + 8 * (p & 1);
+    }
+  return t;
+}
+template <int DH>
+__device__ __forceinline__ bf16x8 frag_tr(const char* stage, int Rb, const TrOff<DH>& to, int dt) {
+  typedef __attribute__((address_space(3))) s16x4* lds_p;
+  const char* b = stage + Rb * (DH * 2);
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(b + to.o[dt][0]));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(b + to.o[dt][1]));
+  bf16x8 r;
+  __builtin_memcpy(&r, &lo, 8);
+  __builtin_memcpy(reinterpret_cast<char*>(&r) + 8, &hi, 8);
+  return r;
 }
 
 __device__ __forceinline__ bf16x8 cvt8(const f32x16& v, int off) {
@@ -70,7 +99,7 @@ __device__ __forceinline__ bf16x8 cvt8(const f32x16& v, int off) {
 // FULL (both kernels): seq_len % 256 == 0 - no partial block, stage or tile, the per-score bound compares are compiled out
 template <int DH, bool DROP, bool FULL>
 __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K,
-                                                          const bf16* __restrict__ V, const bf16* __restrict__ KT,
+                                                          const bf16* __restrict__ V,
                                                           const bf16* __restrict__ dO, const bf16* __restrict__ O,
                                                           const float* __restrict__ lse2, float* __restrict__ Dv,
                                                           bf16* __restrict__ dQ, int64_t ld_dq,
@@ -78,8 +107,9 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const bf16* __restrict
                                                           RowLayout lo_, const uint32_t* __restrict__ keep_bits, float rscale) {
   constexpr int NW = 8;
   constexpr int KS = DH / 16, DT = DH / 32;
-  constexpr int ST = SKB * DH * 2;                 // bytes of one operand stage (row layout and transposed alike)
+  constexpr int ST = SKB * DH * 2;                 // bytes of one operand stage
   constexpr int PK = ST / 1024 / NW;               // DMA pieces per wave per operand per stage
+  constexpr int NSUB = SKB / 32;                   // 32-key sub-tiles per stage
   extern __shared__ __attribute__((aligned(16))) char smem_dyn[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -88,24 +118,22 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const bf16* __restrict
   const int nitems = nbh * nqb;
   const int my_items = (nitems - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
   const int total = my_items * nst;
+  const TrOff<DH> tro = tr_offsets<DH>(lane);
 
   auto issue = [&](int g) {
     const int item = blockIdx.x + (g / nst) * gridDim.x, st = g % nst;
     const int bh = item / nqb;
     const int64_t roff = lq_.at(bh, nh, (int64_t)st * SKB);
-    const bf16* Tb = KT + (int64_t)bh * DH * L + (int64_t)st * SKB;
-    char* base = smem_dyn + (g & 1) * (3 * ST);
+    char* base = smem_dyn + (g & 1) * (2 * ST);
     const int valid = L - st * SKB;                       // rows of this stage that exist (the rest: clamped sources, masked scores)
 #pragma unroll
     for (int j = 0; j < PK; ++j) dma_rows<DH>(K + roff, lq_.ld, base, wave + NW * j, lane, valid);
 #pragma unroll
     for (int j = 0; j < PK; ++j) dma_rows<DH>(V + roff, lq_.ld, base + ST, wave + NW * j, lane, valid);
-#pragma unroll
-    for (int j = 0; j < PK; ++j) dma_cols<DH>(Tb, L, base + 2 * ST, wave + NW * j, lane, valid);
     if constexpr (DROP && FULL) {   // this wave's keep words of the stage's two 64-key tiles (2 x 64 words, contiguous): 512 B, lanes 0..31
       const int qbw = (item % nqb) * 8 + wave;
       if (lane < 32)
-        glds16(keep_bits + drop_word_index(bh, (L + 31) >> 5, qbw, st * (SKB / 64), 0) + 4 * lane, smem_dyn + 2 * 3 * ST + (g & 1) * 4096 + wave * 512);
+        glds16(keep_bits + drop_word_index(bh, (L + 31) >> 5, qbw, st * (SKB / 64), 0) + 4 * lane, smem_dyn + 2 * 2 * ST + (g & 1) * 4096 + wave * 512);
     }
   };
 
@@ -141,58 +169,72 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const bf16* __restrict
         for (int j = 0; j < 8; ++j) D_q += (float)dof[ks][j] * (float)of[j];
       }
       D_q += __shfl_xor(D_q, 32, 64);
+      if constexpr (DROP) {   // dS = p (dP keep / (1 - p_drop) - D) = [p / (1 - p_drop)] (dP keep - D (1 - p_drop)): the factor goes into the exponent,
+        lse_q -= __builtin_amdgcn_logf(rscale);   // D is kept pre-multiplied (for the dK/dV kernel too) - nothing per element
+        D_q *= 1.0f / rscale;
+      }
       if (h == 0 && q0 + lq < L) Dv[qrow] = D_q;
 #pragma unroll
       for (int i = 0; i < DT; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) dq[i][r] = 0.f;
     }
-    const char* kst = smem_dyn + (g & 1) * (3 * ST);
+    const char* kst = smem_dyn + (g & 1) * (2 * ST);
     const char* vst = kst + ST;
-    const char* tst = kst + 2 * ST;
     const int st_keys = L - st * SKB;
-    for (int t = 0; active && t < SKB / 64 && (FULL || t * 64 < st_keys); ++t) {
-      const int tile_keys = FULL ? 64 : st_keys - t * 64;
-      f32x16 s[2], dp[2];
+    if (active) {
+      bf16x8 fk[KS], fv[KS];
 #pragma unroll
-      for (int kt = 0; kt < 2; ++kt) {
-        const int R = t * 64 + 32 * kt + lq;
+      for (int ks = 0; ks < KS; ++ks) { fk[ks] = frag_rows<DH>(kst, lq, ks, h); fv[ks] = frag_rows<DH>(vst, lq, ks, h); }
+      uint32_t kw = 0xffffffffu;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { s[kt][r] = 0.f; dp[kt][r] = 0.f; }
+      for (int i = 0; i < NSUB; ++i) {
+        if (!FULL && i * 32 >= st_keys) break;                     // (wave-uniform)
+        const int sub_keys = FULL ? 32 : st_keys - i * 32;
+        f32x16 s, dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-          s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<DH>(kst, R, ks, h), qf[ks], s[kt], 0, 0, 0);
-          dp[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<DH>(vst, R, ks, h), dof[ks], dp[kt], 0, 0, 0);
+          s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fk[ks], qf[ks], s, 0, 0, 0);       // S^T[key][query]
+          dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fv[ks], dof[ks], dp, 0, 0, 0);    // dP^T[key][query]
         }
-      }
-      uint32_t kw = 0xffffffffu;
-      if constexpr (DROP && FULL) {   // ... staged in LDS with the operands (a global load here would wait for the next stage's DMA)
-        kw = *reinterpret_cast<const uint32_t*>(smem_dyn + 2 * 3 * ST + (g & 1) * 4096 + wave * 512 + t * 256 + lane * 4);
-      } else if constexpr (DROP) {   // dP = dP_drop o keep / (1 - p): this lane's word of the 64-key tile, as the forward stored it
-        const int nb32 = (L + 31) >> 5;
-        kw = keep_bits[drop_word_index(bh, nb32, q0 >> 5, (st * SKB + t * 64) >> 6, lane)];
-      }
+        __builtin_amdgcn_sched_barrier(0);
+        // K^T fragments of this sub-tile (for dQ^T += K^T dS^T), then the next sub-tile's row fragments: both land under the exp / dS work
+        bf16x8 ft[2][DT];
 #pragma unroll
-      for (int kt = 0; kt < 2; ++kt) {
-        const uint32_t km = kw >> (16 * kt);
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+          for (int dt = 0; dt < DT; ++dt) ft[s2][dt] = frag_tr<DH>(kst, 32 * i + 16 * s2, tro, dt);
+        if (i + 1 < NSUB && (FULL || (i + 1) * 32 < st_keys)) {
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) { fk[ks] = frag_rows<DH>(kst, 32 * (i + 1) + lq, ks, h); fv[ks] = frag_rows<DH>(vst, 32 * (i + 1) + lq, ks, h); }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if ((i & 1) == 0) {
+          if constexpr (DROP && FULL) {   // ... staged in LDS with the operands (a global load here would wait for the next stage's DMA)
+            kw = *reinterpret_cast<const uint32_t*>(smem_dyn + 2 * 2 * ST + (g & 1) * 4096 + wave * 512 + (i >> 1) * 256 + lane * 4);
+          } else if constexpr (DROP) {   // dP = dP_drop o keep / (1 - p): this lane's word of the 64-key tile, as the forward stored it
+            const int nb32 = (L + 31) >> 5;
+            kw = keep_bits[drop_word_index(bh, nb32, q0 >> 5, (st * SKB + i * 32) >> 6, lane)];
+          }
+        }
+        const uint32_t km = kw >> (16 * (i & 1));
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          float p = __builtin_amdgcn_exp2f(s[kt][r] * scale_log2e - lse_q);
-          if (!FULL && tile_keys < 64 && kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h >= tile_keys) p = 0.f;   // key past the sequence end
-          float dpv = dp[kt][r];
-          if constexpr (DROP) dpv = (km >> r) & 1u ? dpv * rscale : 0.f;
-          s[kt][r] = p * (dpv - D_q);                            // dS^T (the 1/sqrt(dh) factor is applied to dQ at the end)
+          float p = __builtin_amdgcn_exp2f(s[r] * scale_log2e - lse_q);
+          if (!FULL && sub_keys < 32 && (r & 3) + 8 * (r >> 2) + 4 * h >= sub_keys) p = 0.f;   // key past the sequence end
+          float dpv = dp[r];
+          if constexpr (DROP) dpv = and_bits(dpv, keep_mask(km, r));
+          s[r] = p * (dpv - D_q);                                  // dS^T (the 1/sqrt(dh) factor is applied to dQ at the end)
         }
-      }
-#pragma unroll
-      for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
-          const bf16x8 dsf = cvt8(s[kt], 8 * s2);
+          const bf16x8 dsf = cvt8(s, 8 * s2);
 #pragma unroll
-          for (int dt = 0; dt < DT; ++dt)
-            dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols<DH>(tst, t, 2 * kt + s2, dt * 32 + lq, h), dsf, dq[dt], 0, 0, 0);
+          for (int dt = 0; dt < DT; ++dt) dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ft[s2][dt], dsf, dq[dt], 0, 0, 0);
         }
+      }
     }
     if (st == nst - 1 && q0 + lq < L) {
       const int b = bh / nh, head = bh % nh;
@@ -217,8 +259,8 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const bf16* __restrict
 // ---------------------------------------------------------------------------------------------------------
 template <int DH, bool DROP, bool FULL>
 __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K,
-                                                           const bf16* __restrict__ V, const bf16* __restrict__ QT,
-                                                           const bf16* __restrict__ dO, const bf16* __restrict__ dOT,
+                                                           const bf16* __restrict__ V,
+                                                           const bf16* __restrict__ dO,
                                                            const float* __restrict__ lse2, const float* __restrict__ Dv,
                                                            bf16* __restrict__ dK, bf16* __restrict__ dV, int64_t ld_d, int L,
                                                            int nh, int nbh, float scale, float scale_log2e, RowLayout lq_,
@@ -227,7 +269,8 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const bf16* __restric
   constexpr int KS = DH / 16, DT = DH / 32;
   constexpr int ST = SKB * DH * 2;
   constexpr int PK = ST / 1024 / NW;
-  constexpr int BUF = 4 * ST + 1024 + (DROP && FULL ? 4096 : 0);   // Q rows, dO rows, Q^T, dO^T, (lse2 | D) of the stage's 128 queries, keep words
+  constexpr int NSUB = SKB / 32;                   // 32-query sub-tiles per stage
+  constexpr int BUF = 2 * ST + 1024 + (DROP && FULL ? 4096 : 0);   // Q rows, dO rows, (lse2 | D) of the stage's 128 queries, keep words
   extern __shared__ __attribute__((aligned(16))) char smem_dyn[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -236,31 +279,29 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const bf16* __restric
   const int nitems = nbh * nkb;
   const int my_items = (nitems - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
   const int total = my_items * nst;
+  // DROP: the S accumulators start at log2(1 / (1 - p_drop)) / (scale log2 e), so that exp2(s scale log2 e - lse2) is P / (1 - p_drop)
+  const float s_init = DROP ? __builtin_amdgcn_logf(rscale) / scale_log2e : 0.f;
+  const TrOff<DH> tro = tr_offsets<DH>(lane);
 
   auto issue = [&](int g) {
     const int item = blockIdx.x + (g / nst) * gridDim.x, st = g % nst;
     const int bh = item / nkb;
     const int64_t r0 = (int64_t)bh * L + (int64_t)st * SKB;
-    const int64_t c0 = (int64_t)bh * DH * L + (int64_t)st * SKB;
     char* base = smem_dyn + (g & 1) * BUF;
     const int valid = L - st * SKB;
 #pragma unroll
     for (int j = 0; j < PK; ++j) dma_rows<DH>(Q + lq_.at(bh, nh, (int64_t)st * SKB), lq_.ld, base, wave + NW * j, lane, valid);
 #pragma unroll
     for (int j = 0; j < PK; ++j) dma_rows<DH>(dO + lo_.at(bh, nh, (int64_t)st * SKB), lo_.ld, base + ST, wave + NW * j, lane, valid);
-#pragma unroll
-    for (int j = 0; j < PK; ++j) dma_cols<DH>(QT + c0, L, base + 2 * ST, wave + NW * j, lane, valid);
-#pragma unroll
-    for (int j = 0; j < PK; ++j) dma_cols<DH>(dOT + c0, L, base + 3 * ST, wave + NW * j, lane, valid);
     if (wave == 0) {   // lanes 0-31: lse2 of the 128 queries, lanes 32-63: D (groups of 4; past the end: the last valid group)
       int qo = 4 * (lane & 31);
       if (qo >= valid) qo = valid - 4;
-      glds16((lane < 32 ? lse2 : Dv) + r0 + qo, base + 4 * ST);
+      glds16((lane < 32 ? lse2 : Dv) + r0 + qo, base + 2 * ST);
     }
     if constexpr (DROP && FULL) {   // keep words of (4 query blocks of the stage) x (the block's 4 pairs of key blocks): 1 KiB per query block
       if (wave >= 4)
         glds16(keep_bits + drop_word_index(bh, (L + 31) >> 5, st * (SKB / 32) + wave - 4, (item % nkb) * 4, 0) + 4 * lane,
-               base + 4 * ST + 1024 + (wave - 4) * 1024);
+               base + 2 * ST + 1024 + (wave - 4) * 1024);
     }
   };
 
@@ -291,71 +332,96 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const bf16* __restric
     }
     const char* qst = smem_dyn + (g & 1) * BUF;
     const char* ost = qst + ST;
-    const char* qtst = qst + 2 * ST;
-    const char* otst = qst + 3 * ST;
-    const float* lst = reinterpret_cast<const float*>(qst + 4 * ST);   // [0..127] lse2, [128..255] D
+    const float* lst = reinterpret_cast<const float*>(qst + 2 * ST);   // [0..127] lse2, [128..255] D
     const int st_q = L - st * SKB;                                      // queries of this stage that exist
-    for (int t = 0; active && t < SKB / 64 && (FULL || t * 64 < st_q); ++t) {
+    if (active) {
+      // (the bound-checking builds read a sub-tile's row fragments when they need them: the read-ahead does not fit their registers)
+      bf16x8 fq[KS], fo[KS];
+      if constexpr (FULL) {
 #pragma unroll
-      for (int qt = 0; qt < 2; ++qt) {
-        const int R = t * 64 + 32 * qt + lq;
+        for (int ks = 0; ks < KS; ++ks) { fq[ks] = frag_rows<DH>(qst, lq, ks, h); fo[ks] = frag_rows<DH>(ost, lq, ks, h); }
+      }
+#pragma unroll
+      for (int i = 0; i < NSUB; ++i) {
+        if (!FULL && i * 32 >= st_q) break;                          // (wave-uniform)
+        if constexpr (!FULL) {
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) { fq[ks] = frag_rows<DH>(qst, 32 * i + lq, ks, h); fo[ks] = frag_rows<DH>(ost, 32 * i + lq, ks, h); }
+        }
         f32x16 s, dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[r] = s_init; dp[r] = 0.f; }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fq[ks], kf[ks], s, 0, 0, 0);      // S[query][key]
+          dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fo[ks], vf[ks], dp, 0, 0, 0);    // dP[query][key]
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // dO^T and Q^T fragments of this sub-tile (transposing reads of the same stages): they land under the exp / dS work
+        bf16x8 fot[2][DT], fqt[2][DT];
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+          for (int dt = 0; dt < DT; ++dt) {
+            fot[s2][dt] = frag_tr<DH>(ost, 32 * i + 16 * s2, tro, dt);
+            fqt[s2][dt] = frag_tr<DH>(qst, 32 * i + 16 * s2, tro, dt);
+          }
         // keep flags of this lane's key for its 16 queries of the tile: query 8 rg + 4 h + e lives in the word of forward lane
-        // (query % 32) + 32 hk, at bit rk (+ 16 for an odd key block): four consecutive words per rg
-        uint4 kwv[4];
+        // (query % 32) + 32 hk, at bit rk (+ 16 for an odd key block): four consecutive words per rg (fetched per rg: 16 live words
+        // on top of the prefetched fragments do not fit 256 registers)
+        const uint32_t* kwp = nullptr;
         int kshift = 0;
         if constexpr (DROP) {
           const int nb32 = (L + 31) >> 5;
-          int qb = (st * SKB + t * 64 + 32 * qt) >> 5; if (qb >= nb32) qb = nb32 - 1;
+          int qb = (st * SKB + 32 * i) >> 5; if (qb >= nb32) qb = nb32 - 1;
           const int kbk = k0 >> 5, hk = (lq >> 2) & 1;
           kshift = (lq & 3) + 4 * (lq >> 3) + 16 * (kbk & 1);
-          if constexpr (FULL) {   // staged in LDS with the operands
-            const uint32_t* wl = reinterpret_cast<const uint32_t*>(qst + 4 * ST + 1024) + (2 * t + qt) * 256 + ((wave >> 1) & 3) * 64 + 32 * hk + 4 * h;
-#pragma unroll
-            for (int rg = 0; rg < 4; ++rg) kwv[rg] = *reinterpret_cast<const uint4*>(wl + 8 * rg);
-          } else {
-            const uint32_t* wp = keep_bits + drop_word_index(bh, nb32, qb, kbk >> 1, 32 * hk + 4 * h);
-#pragma unroll
-            for (int rg = 0; rg < 4; ++rg) kwv[rg] = *reinterpret_cast<const uint4*>(wp + 8 * rg);
-          }
+          if constexpr (FULL) kwp = reinterpret_cast<const uint32_t*>(qst + 2 * ST + 1024) + i * 256 + ((wave >> 1) & 3) * 64 + 32 * hk + 4 * h;   // staged in LDS
+          else kwp = keep_bits + drop_word_index(bh, nb32, qb, kbk >> 1, 32 * hk + 4 * h);
         }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-          s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<DH>(qst, R, ks, h), kf[ks], s, 0, 0, 0);      // S[query][key]
-          dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<DH>(ost, R, ks, h), vf[ks], dp, 0, 0, 0);    // dP[query][key]
-        }
+        __builtin_amdgcn_sched_barrier(0);
         // register r <-> query (r & 3) + 8 (r >> 2) + 4 h of this 32-query tile: four runs of four consecutive queries
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) {
-          const int qi = t * 64 + 32 * qt + 8 * rg + 4 * h;
+          const int qi = 32 * i + 8 * rg + 4 * h;
           const f32x4 ls = *reinterpret_cast<const f32x4*>(lst + qi);
           const f32x4 dd = *reinterpret_cast<const f32x4*>(lst + 128 + qi);
+          uint4 kwv = {0u, 0u, 0u, 0u};
+          if constexpr (DROP) kwv = *reinterpret_cast<const uint4*>(kwp + 8 * rg);
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             float p = __builtin_amdgcn_exp2f(s[rg * 4 + e] * scale_log2e - ls[e]);
             if (!FULL && qi + e >= st_q) p = 0.f;                                  // query past the sequence end
             float dpv = dp[rg * 4 + e], pd = p;
-            if constexpr (DROP) {                                         // P_drop feeds dV; dP = dP_drop o keep / (1 - p)
-              const uint32_t kwe = e == 0 ? kwv[rg].x : e == 1 ? kwv[rg].y : e == 2 ? kwv[rg].z : kwv[rg].w;
-              const bool keep = (kwe >> kshift) & 1u;
-              pd = keep ? p * rscale : 0.f;
-              dpv = keep ? dpv * rscale : 0.f;
+            if constexpr (DROP) {                                         // P_drop feeds dV; dP = dP_drop o keep / (1 - p_drop)
+              // p here is P / (1 - p_drop) (s_init) and D arrives multiplied by (1 - p_drop) (the dQ kernel): the factor costs nothing
+              const uint32_t kwe = e == 0 ? kwv.x : e == 1 ? kwv.y : e == 2 ? kwv.z : kwv.w;
+              const uint32_t km = keep_mask(kwe, kshift);
+              pd = and_bits(p, km);
+              dpv = and_bits(dpv, km);
             }
             s[rg * 4 + e] = pd;
             dp[rg * 4 + e] = p * (dpv - dd[e]);
           }
         }
+        bf16x8 pf[2], dsf[2];
 #pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-          const bf16x8 pf = cvt8(s, 8 * s2), dsf = cvt8(dp, 8 * s2);
+        for (int s2 = 0; s2 < 2; ++s2) { pf[s2] = cvt8(s, 8 * s2); dsf[s2] = cvt8(dp, 8 * s2); }
+        __builtin_amdgcn_sched_barrier(0);
+        // the next sub-tile's row fragments take the registers S and dP have just left; they land under the eight products below
+        if constexpr (FULL) {
+          if (i + 1 < NSUB) {
 #pragma unroll
-          for (int dt = 0; dt < DT; ++dt) {
-            dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols<DH>(otst, t, 2 * qt + s2, dt * 32 + lq, h), pf, dv[dt], 0, 0, 0);
-            dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols<DH>(qtst, t, 2 * qt + s2, dt * 32 + lq, h), dsf, dk[dt], 0, 0, 0);
+            for (int ks = 0; ks < KS; ++ks) { fq[ks] = frag_rows<DH>(qst, 32 * (i + 1) + lq, ks, h); fo[ks] = frag_rows<DH>(ost, 32 * (i + 1) + lq, ks, h); }
           }
         }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+          for (int dt = 0; dt < DT; ++dt) {
+            dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fot[s2][dt], pf[s2], dv[dt], 0, 0, 0);
+            dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fqt[s2][dt], dsf[s2], dk[dt], 0, 0, 0);
+          }
       }
     }
     if (st == nst - 1 && k0 + lq < L) {
@@ -407,7 +473,8 @@ int launch_bwd(const bf16* q, const bf16* k, const bf16* v, const bf16* qT, cons
                const float* lse2, float* Dv, bf16* dq, bf16* dk, bf16* dv, int64_t ld, int B, int L, int nh, float scale,
                RowLayout lqkv, RowLayout ldo, const uint32_t* keep_bits, float rscale, hipStream_t s) {
   constexpr int ST = SKB * DH * 2;
-  constexpr int bytes_dq = 2 * 3 * ST + (DROP && FULL ? 2 * 4096 : 0), bytes_dkv = 2 * (4 * ST + 1024 + (DROP && FULL ? 4096 : 0));
+  constexpr int bytes_dq = 2 * 2 * ST + (DROP && FULL ? 2 * 4096 : 0), bytes_dkv = 2 * (2 * ST + 1024 + (DROP && FULL ? 4096 : 0));
+  (void)qT; (void)kT; (void)dOT;   // (the transposed copies of the round-2 interface: no longer read)
   static bool attr_set = false;
   if (!attr_set) {
     MH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_kernel<DH, DROP, FULL>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes_dq));
@@ -420,11 +487,11 @@ int launch_bwd(const bf16* q, const bf16* k, const bf16* v, const bf16* qT, cons
   const dim3 grid((unsigned)(nitems < cus ? nitems : cus)), block(512);
   const float sl2 = scale * 1.4426950408889634f;
   mh_prof_note("attn_bwd B*nh=%d L=%d dh=%d", nbh, L, DH);
-  MH_LAUNCH((attn_bwd_dq_kernel<DH, DROP, FULL>), grid, block, bytes_dq, s, q, k, v, kT, dO, o, lse2, Dv, dq, ld, L, nh, nbh, scale, sl2, lqkv, ldo,
+  MH_LAUNCH((attn_bwd_dq_kernel<DH, DROP, FULL>), grid, block, bytes_dq, s, q, k, v, dO, o, lse2, Dv, dq, ld, L, nh, nbh, scale, sl2, lqkv, ldo,
             keep_bits, rscale);
   MH_CHECK_LAUNCH();
   mh_prof_note("attn_bwd B*nh=%d L=%d dh=%d", nbh, L, DH);
-  MH_LAUNCH((attn_bwd_dkv_kernel<DH, DROP, FULL>), grid, block, bytes_dkv, s, q, k, v, qT, dO, dOT, lse2, Dv, dk, dv, ld, L, nh, nbh, scale, sl2, lqkv, ldo,
+  MH_LAUNCH((attn_bwd_dkv_kernel<DH, DROP, FULL>), grid, block, bytes_dkv, s, q, k, v, dO, lse2, Dv, dk, dv, ld, L, nh, nbh, scale, sl2, lqkv, ldo,
             keep_bits, rscale);
   MH_CHECK_LAUNCH();
   return MH_OK;
@@ -482,7 +549,7 @@ extern "C" int mh_attention_stream_bwd_drop(const void* q, const void* k, const 
   MH_CHECK_ARG(qsB % 8 == 0 && qsH % 8 == 0 && qld % 8 == 0 && osB % 8 == 0 && osH % 8 == 0 && old_ % 8 == 0 && qld >= dh && old_ >= dh,
                "attention_stream_bwd: row strides must be multiples of 8 elements");
   const RowLayout lqkv{qsB, qsH, qld}, ldo{osB, osH, old_};
-  MH_CHECK_ARG(q && k && v && qT_perm && kT_perm && dO && dOT_perm && o && lse2 && D && dq && dk && dv, "attention_stream_bwd: null pointer");
+  MH_CHECK_ARG(q && k && v && dO && o && lse2 && D && dq && dk && dv, "attention_stream_bwd: null pointer");   // (qT_perm, kT_perm, dOT_perm: unused, may be null)
   MH_CHECK_ARG(B > 0 && nh > 0 && mh_attention_stream_bwd_supported(L, dh),
                "attention_stream_bwd: needs seq_len %% 16 == 0, seq_len >= 512 and head dim 32 or 64 (got L=%d dh=%d)", L, dh);
   MH_CHECK_ARG(ld_d % 4 == 0, "attention_stream_bwd: ld_d must be a multiple of 4");

@@ -253,6 +253,10 @@ __device__ __forceinline__ uint32_t drop_keep_attn(const DropArgs& d, int64_t bh
   mh_philox<7>(c, d.seed_lo, d.seed_hi);
   return drop_keep_attn_from(c, (d.thr8 << 8) + d.thr_tie);
 }
+// Applying a keep flag without a compare + select pair (half-rate on gfx950): v_bfe_i32 turns bit `bit` of the word into 0 / ~0 and
+// a v_and clears the dropped value (+0.0f).
+__device__ __forceinline__ uint32_t keep_mask(uint32_t word, uint32_t bit) { return (uint32_t)__builtin_amdgcn_sbfe((int)word, bit, 1u); }
+__device__ __forceinline__ float and_bits(float x, uint32_t m) { return __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, x) & m); }
 // The keep-bit tensor is LANE-NATIVE: uint32 [B nh][nb = ceil(L / 32) query blocks][ceil(nb / 2) pairs of 32-key blocks][64 lanes].
 // The word of lane (lq, h) holds that lane's 16 flags of the pair's even key block in its low half and of the odd block in its high
 // half - bit r <-> key (r & 3) + 8 (r >> 2) + 4 h of the block, query lq of the query block: exactly the registers the lane holds

@@ -473,20 +473,11 @@ class _Attention(Function):
         dev, td = qkv.device, qkv.dtype
         L_, st, es = lib(), current_stream(), qkv.element_size()
         dctx = dctx.contiguous()
-        n = B * nh * L * dh
-
-        def transposed(src, col0, ld):     # [B, nh, dh, L] in the kernels' position order
-            t = torch.empty(n + 256, device=dev, dtype=td)
-            mode = 4 if (L % 64 == 0 and dh in (32, 64, 128) and ld % 8 == 0) else 3     # 4: the slack is zeroed by the same launch
-            if mode == 3:
-                t[-256:].zero_()
-            check(L_.mh_head_permute(src.data_ptr() + col0 * es, ptr(t), ld, B, L, nh, dh, mode, dt, st), "mh_head_permute")
-            return t
-        qT, kT, dOT = transposed(qkv, 0, 3 * H), transposed(qkv, H, 3 * H), transposed(dctx, 0, H)
-        D = torch.empty(B * nh * L, device=dev, dtype=torch.float32)      # scratch: rowsum(dO o O), produced by the dQ kernel
+        # (no transposed copies of q / k / dO: the kernels read K^T, Q^T, dO^T out of the row-layout LDS stages with transposing reads)
+        D = torch.empty(B * nh * L, device=dev, dtype=torch.float32)      # scratch: rowsum(dO o O) (x (1 - p) under dropout), produced by the dQ kernel
         dqkv = torch.empty(B * L, 3 * H, device=dev, dtype=td)
-        check(L_.mh_attention_stream_bwd_drop(qkv.data_ptr(), qkv.data_ptr() + H * es, qkv.data_ptr() + 2 * H * es, ptr(qT), ptr(kT),
-                                              ptr(dctx), ptr(dOT), ptr(out), ptr(lse), ptr(D), dqkv.data_ptr(), dqkv.data_ptr() + H * es,
+        check(L_.mh_attention_stream_bwd_drop(qkv.data_ptr(), qkv.data_ptr() + H * es, qkv.data_ptr() + 2 * H * es, None, None,
+                                              ptr(dctx), None, ptr(out), ptr(lse), ptr(D), dqkv.data_ptr(), dqkv.data_ptr() + H * es,
                                               dqkv.data_ptr() + 2 * H * es, 3 * H, B, L, nh, dh, scale,
                                               L * 3 * H, dh, 3 * H, L * H, dh, H, ptr(ctx.bits), ctx.drop.p if ctx.drop is not None else 0.0, st),
               "mh_attention_stream_bwd_drop")
