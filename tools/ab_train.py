@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""In-process A/B of a training tape option on bench.py --workload train (boxes of the pool differ by several percent, so
+"""In-process A/B of a training tape option (or of the GEMM start stagger) on bench.py --workload train (boxes of the pool differ by several percent, so
 alternatives are only comparable inside one process):    python tools/ab_train.py TN_DW | FUSED_FFN | FUSED_ATTENTION"""
 import contextlib
 import io
@@ -9,10 +9,23 @@ import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 KNOB = sys.argv[1] if len(sys.argv) > 1 else "FUSED_FFN"
+VALS = [int(v) for v in sys.argv[2:]]
 sys.argv = ["bench.py", "--workload", "train", "--steps", "4", "--warmup", "2", "--no-cpu-baseline", "--no-kernel-timing"]
 import bench  # noqa: E402
 from musediffusion_amd import training  # noqa: E402
 
+if KNOB == "stagger":      # library knob: python tools/ab_train.py stagger 0 -500 -1500 1500
+    from musediffusion_amd import _lib
+    vals = VALS
+    for rnd in range(3):
+        for v in vals:
+            _lib.lib().mh_gemm_set_stagger(v)
+            buf = io.StringIO()
+            with contextlib.redirect_stdout(buf):
+                bench.main()
+            print("stagger=%d: %.2f ms" % (v, json.loads(buf.getvalue().strip().splitlines()[-1])["ms_per_step"]), flush=True)
+    _lib.lib().mh_gemm_set_stagger(0)
+    raise SystemExit(0)
 for rnd in range(3):
     for on in (True, False):
         setattr(training, KNOB, on)

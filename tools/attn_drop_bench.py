@@ -58,3 +58,23 @@ for rep in range(3):
         L_.mh_attention_set_stream(mode)
         print("%s: no dropout %7.1f us   bit-reading %7.1f us" % (name, t(lambda: fwd(False, 0)), t(lambda: fwd(True, 1))))
 L_.mh_attention_set_stream(1)
+
+L_.mh_attention_set_stream(2)
+print("bit-reading forward, 8 waves x 128-key stages: %7.1f us" % t(lambda: fwd(True, 1)))
+L_.mh_attention_set_stream(1)
+
+# ---- backward (dQ kernel + dK/dV kernel in one call), with and without dropout
+dctx = (torch.randn(B * L, H, device=dev) * 0.1).to(torch.bfloat16)
+dqkv = torch.empty(B * L, 3 * H, device=dev, dtype=torch.bfloat16)
+Dv = torch.empty(B * nh * L, device=dev, dtype=torch.float32)
+fwd(True, 1)
+
+
+def bwd(p):
+    check(L_.mh_attention_stream_bwd_drop(qkv.data_ptr(), qkv.data_ptr() + H * 2, qkv.data_ptr() + 2 * H * 2, None, None, ptr(dctx), None, ptr(out),
+                                          ptr(lse), ptr(Dv), dqkv.data_ptr(), dqkv.data_ptr() + H * 2, dqkv.data_ptr() + 2 * H * 2, 3 * H, B, L, nh, dh,
+                                          1 / math.sqrt(dh), L * 3 * H, dh, 3 * H, L * H, dh, H, ptr(bits) if p else None, p, st))
+
+
+for rep in range(2):
+    print("backward (dQ + dK/dV kernels): dropout 0.1 %7.1f us   no dropout %7.1f us" % (t(lambda: bwd(0.1)), t(lambda: bwd(0.0))))

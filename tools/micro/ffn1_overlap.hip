@@ -297,6 +297,28 @@ void run32(const char* name, const bf16* src, bf16* dst, const float* bias, unsi
   printf("32x32x16: %-38s %d wave(s)/SIMD: %7.3f us per tile-round, %7.3f us per tile per SIMD\n", name, wps, ms * 1e3 / tiles, ms * 1e3 / tiles / wps);
 }
 
+
+// Power / clock test: the same kernel on a fraction of the chip.  If a wave's time per tile falls and its clock (shader cycles per
+// microsecond) rises when fewer CUs are busy, the full-chip rate is set by the power budget, not by a pipe.
+template <int MODE, int THREADS>
+void run_grid(const char* name, const bf16* src, bf16* dst, const float* bias, unsigned long long* cyc) {
+  const int tiles = 400;
+  auto kern = k<MODE, 0, THREADS>;
+  hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 24576);
+  for (int grid = 256; grid >= 16; grid /= 2) {
+    kern<<<grid, THREADS, 4 * 24576>>>(src, dst, bias, tiles, cyc);
+    hipDeviceSynchronize();
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipEventRecord(e0);
+    kern<<<grid, THREADS, 4 * 24576>>>(src, dst, bias, tiles, cyc);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    unsigned long long c; hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost);
+    printf("%-28s %3d blocks of %d waves/SIMD: %7.3f us per tile-round, %6llu shader cycles -> %.2f GHz\n", name, grid, THREADS / 256, ms * 1e3 / tiles, c,
+           (double)c / (ms * 1e3 / tiles) * 1e-3);
+  }
+}
+
 int main() {
   bf16 *src, *dst; float* bias; unsigned long long* cyc;
   hipMalloc(&src, (size_t)256 * 64 * 8192 * 2 + (1 << 20)); hipMalloc(&dst, (size_t)64 * 8 * 131072 * 2 + (1 << 24)); hipMalloc(&bias, 4096); hipMalloc(&cyc, 256 * 8);
@@ -341,5 +363,8 @@ int main() {
     float ms; hipEventElapsedTime(&ms, e0, e1);
     printf("128x128 wave tile, K-steps only, 1 wave/SIMD: %7.3f us per (double-size) tile = %7.3f us per 512 MFMAs per SIMD\n", ms * 1e3 / tiles, ms * 1e3 / tiles / 2);
   }
+  run_grid<0, 512>("K-steps only", src, dst, bias, cyc);
+  run_grid<1, 512>("epilogue groups only", src, dst, bias, cyc);
+  run_grid<2, 512>("K-steps then groups", src, dst, bias, cyc);
   return 0;
 }
