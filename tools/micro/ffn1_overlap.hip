@@ -209,6 +209,21 @@ __global__ __launch_bounds__(THREADS) void k(const bf16* __restrict__ src, bf16*
 #pragma unroll
       for (int kt = 0; kt < 16; ++kt) { kstep(kt); __builtin_amdgcn_sched_barrier(0); }
     }
+    if (MODE == 5) {   // the same 512 MFMAs with the fragments of ONE K-step kept in registers: what the LDS reads cost (time and clock)
+      bf16x8 a[8], b[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const bf16x8*>(mine + ((j * 1024 + lane * 16) & 8191));
+#pragma unroll
+      for (int i = 0; i < 8; ++i) a[i] = *reinterpret_cast<const bf16x8*>(mine + ((4096 + i * 512 + lane * 16) & 8191));
+#pragma unroll
+      for (int kt = 0; kt < 16; ++kt) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
     if (MODE == 4 && wave < 4) {
 #pragma unroll
       for (int g = 0; g < 16; ++g) egroup(g);
@@ -364,6 +379,9 @@ int main() {
     printf("128x128 wave tile, K-steps only, 1 wave/SIMD: %7.3f us per (double-size) tile = %7.3f us per 512 MFMAs per SIMD\n", ms * 1e3 / tiles, ms * 1e3 / tiles / 2);
   }
   run_grid<0, 512>("K-steps only", src, dst, bias, cyc);
+  run_grid<5, 512>("K-steps, no LDS reads", src, dst, bias, cyc);
+  run_grid<5, 256>("K-steps, no LDS reads", src, dst, bias, cyc);
+  run_grid<0, 256>("K-steps only", src, dst, bias, cyc);
   run_grid<1, 512>("epilogue groups only", src, dst, bias, cyc);
   run_grid<2, 512>("K-steps then groups", src, dst, bias, cyc);
   return 0;
