@@ -170,7 +170,7 @@ def classify_launch(kernel, note, c, branches):
         bh, dh = int(kv.get("B*nh", 0)), int(kv.get("dh", 0))
         return "attn_stream_bf16_kernel<dh=%d> [B*nh=%d, L=%d]" % (dh, bh, L), "valu+mfma", 4.0 * L * dh * bh * L, "flop"
     b = None
-    if "ln_panel_kernel" in kernel:
+    if "ln_panel_kernel" in kernel or "ln_panel4_kernel" in kernel:
         b = 2 * N_tok * H * 2 + (N_tok * H * 2 if E != H else 0) * 0                        # read [N,H] bf16, write [N,H] bf16
     elif "pack_panel" in kernel:
         b = N_tok * E * 4 + N_tok * Ep * 2
