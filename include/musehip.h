@@ -409,6 +409,9 @@ int mh_gemm_dw(const void* A, int64_t lda, const void* B, int64_t ldb, float* ou
                mh_stream_t stream);
 int mh_gemm_dw_splits(int64_t K, int M, int N);
 int mh_gemm_dw_set_blocks(int blocks);   /* A/B knob: blocks a launch aims for when choosing `splits` (default 512) */
+/* A/B: 0 = the weight-gradient GEMM always on the 256 x 128 tile (4 waves, two blocks per CU: round 2), 1 (default) = a 256 x 256 tile on
+ * 8 waves where N % 256 == 0: half the blocks, half the fp32 partials to write and fold.  mh_gemm_dw_splits follows the setting. */
+int mh_gemm_dw_set_wide(int on);
 /* The same with the bias gradient of that linear as a by-product (with_colsum != 0): each split slice is M N + M floats - the
  * products, then sum_k A[k][m] over the slice's tokens, taken off the matrix pipe (an all-ones operand) by the blocks that already
  * hold the A panel - so dY is not read a second time for autograd's `grad_bias = dY.sum(0)`; one mh_sum_slices over M N + M folds both. */

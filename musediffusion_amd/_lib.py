@@ -159,6 +159,7 @@ SIGNATURES = {
     "mh_gemm_dw": (INT, [VP, I64, VP, I64, VP, INT, I64, INT, INT, VP]),
     "mh_gemm_dw_splits": (INT, [I64, INT, INT]),
     "mh_gemm_dw_set_blocks": (INT, [INT]),
+    "mh_gemm_dw_set_wide": (INT, [INT]),
     "mh_weight_prep": (INT, [VP, INT, INT, VP]),
     "mh_gemm_dw_bias": (INT, [VP, I64, VP, I64, VP, INT, I64, INT, INT, INT, VP]),
     "mh_gemm_act_grad": (INT, [VP, I64, VP, I64, VP, I64, VP, I64, I64, INT, INT, INT, VP]),

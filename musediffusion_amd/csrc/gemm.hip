@@ -1700,33 +1700,39 @@ __device__ __forceinline__ int tn_f(int row) { return ((row & 3) | (((row >> 3) 
 // the M x N products of the slice.  They come out of the matrix pipe - one more MFMA against an all-ones operand gives sum_k A[k][m]
 // in every row of the product - and the work is dealt out over the blocks and waves that share a 256-column panel of A: CS = number
 // of (n-tile, wave column) workers taking part (2, 4 or 8), worker w sums the 16-column tiles i with i % CS == w.
-template <int CS>
-__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnArgs g) {
-  constexpr int BMt = 256, BNt = 128, NSTt = 3, ASTAGE = 32 * BMt * 2, BSTAGE = 32 * BNt * 2, STAGEt = ASTAGE + BSTAGE;
+// WN = wave columns of 64 output columns each: 2 -> the 256 x 128 tile on 4 waves, two blocks per CU; 4 -> a 256 x 256 tile on 8 waves,
+// one block per CU - the same waves per SIMD and the same wave tile, but HALF the blocks for the same chip occupancy: the fp32
+// partials of a launch (one tile per block: blocks x 128 KiB, whatever the shape) and their fold by mh_sum_slices halve, and both
+// operand panels are read once per 256 x 256 outputs.
+template <int CS, int WN = 2>
+__global__ __launch_bounds__(128 * WN, WN == 2 ? 2 : 1) void gemm_tn_kernel(const TnArgs g) {
+  constexpr int BMt = 256, BNt = 64 * WN, NWt = 2 * WN, NSTt = 3, ASTAGE = 32 * BMt * 2, BSTAGE = 32 * BNt * 2, STAGEt = ASTAGE + BSTAGE;
   constexpr int TIt = 8, TJt = 4;
+  constexpr int PAt = 16 / NWt, PBt = (BSTAGE / 1024) / NWt;     // 1-KiB DMA pieces per wave and stage: A 4 / 2, B 2
+  constexpr int CPRB = BNt / 8, RPPB = 64 / CPRB;                // B: 16-byte chunks per k-row, k-rows per piece
   __shared__ __attribute__((aligned(16))) char smem[NSTt * STAGEt];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WN, wn = wave % WN;
   const int tiles_n = (g.N + BNt - 1) / BNt;
   const int m0 = (blockIdx.x / tiles_n) * BMt, n0 = (blockIdx.x % tiles_n) * BNt;
   const int64_t k_begin = (int64_t)blockIdx.y * g.Kslice;
   const int nk = (int)(g.Kslice / 32);
   const int fr = lane & 15, fg = lane >> 4;
 
-  // DMA: A stage = 16 pieces of (2 k-rows x 512 B), 4 per wave; B stage = 8 pieces of (4 k-rows x 256 B), 2 per wave
-  const bf16* srcA[4];
-  const bf16* srcB[2];
+  // DMA: A stage = 16 pieces of (2 k-rows x 512 B); B stage = pieces of (RPPB k-rows x BNt * 2 B)
+  const bf16* srcA[PAt];
+  const bf16* srcB[PBt];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int piece = wave * 4 + j, row = piece * 2 + (lane >> 5), pc = lane & 31;
+  for (int j = 0; j < PAt; ++j) {
+    const int piece = wave * PAt + j, row = piece * 2 + (lane >> 5), pc = lane & 31;
     int col = m0 + ((pc ^ tn_f(row)) << 3);
     if (col > g.M - 8) col = g.M - 8;                       // M % 8 == 0: clamp whole chunks (results beyond M are not stored)
     srcA[j] = g.A + (k_begin + row) * g.lda + col;
   }
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int piece = wave * 2 + j, row = piece * 4 + (lane >> 4), pc = lane & 15;
+  for (int j = 0; j < PBt; ++j) {
+    const int piece = wave * PBt + j, row = piece * RPPB + lane / CPRB, pc = lane % CPRB;
     int col = n0 + ((pc ^ tn_f(row)) << 3);
     if (col > g.N - 8) col = g.N - 8;
     srcB[j] = g.B + (k_begin + row) * g.ldb + col;
@@ -1734,13 +1740,13 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnArgs g) {
   auto issue = [&](int kt) {
     char* base = smem + (kt % NSTt) * STAGEt;
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < PAt; ++j)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcA[j] + (int64_t)kt * 32 * g.lda),
-                                       (__attribute__((address_space(3))) void*)(base + (wave * 4 + j) * 1024), 16, 0, 0);
+                                       (__attribute__((address_space(3))) void*)(base + (wave * PAt + j) * 1024), 16, 0, 0);
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < PBt; ++j)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcB[j] + (int64_t)kt * 32 * g.ldb),
-                                       (__attribute__((address_space(3))) void*)(base + ASTAGE + (wave * 2 + j) * 1024), 16, 0, 0);
+                                       (__attribute__((address_space(3))) void*)(base + ASTAGE + (wave * PBt + j) * 1024), 16, 0, 0);
   };
   // transposing reads: lane 4q + p of a 16-lane group addresses row q, columns 4p .. 4p+3 of a (4 k) x (16 columns) block and
   // receives column (lane & 15) of the 4 rows.  Group = k-group fg: rows 8 fg + 4 half + q.
@@ -1785,7 +1791,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnArgs g) {
   f32x4 accs[NCS];
 #pragma unroll
   for (int c = 0; c < NCS; ++c) accs[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const int worker = (int)(blockIdx.x % tiles_n) * 2 + wn;  // (wave-uniform)
+  const int worker = (int)(blockIdx.x % tiles_n) * WN + wn;  // (wave-uniform)
   bf16x8 ones;
 #pragma unroll
   for (int e = 0; e < 8; ++e) ones[e] = (bf16)1.0f;
@@ -1794,7 +1800,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnArgs g) {
   for (int st = 0; st < npro; ++st) issue(st);
   for (int kt = 0; kt < nk; ++kt) {
     const int younger = nk - 1 - kt < NSTt - 2 ? nk - 1 - kt : NSTt - 2;
-    wait_stages<6>(younger);
+    wait_stages<PAt + PBt>(younger);
     __builtin_amdgcn_s_barrier();
     if (kt + NSTt - 1 < nk) issue(kt + NSTt - 1);
     const unsigned stage = (unsigned)((kt % NSTt) * STAGEt);
@@ -1856,17 +1862,26 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnArgs g) {
 
 }  // namespace
 
-namespace { int g_dw_blocks = 512; }
-// blocks a weight-gradient launch aims for when it cuts the token range (A/B knob; 512 = two per CU)
+namespace { int g_dw_blocks = 512; int g_dw_wide = 1; }
+// blocks a weight-gradient launch aims for when it cuts the token range (A/B knob; 512 = two 4-wave blocks per CU; the 256 x 256
+// tile's 8-wave blocks count double)
 extern "C" int mh_gemm_dw_set_blocks(int blocks) {
   g_dw_blocks = blocks < 1 ? 1 : blocks;
   return MH_OK;
 }
+// A/B: 0 = always the 256 x 128 tile (round 2), 1 = the 256 x 256 tile where N is a multiple of 256
+extern "C" int mh_gemm_dw_set_wide(int on) {
+  g_dw_wide = on ? 1 : 0;
+  return MH_OK;
+}
+namespace { bool dw_wide(int N) { return g_dw_wide && N % 256 == 0; } }
 
 extern "C" int mh_gemm_dw_splits(int64_t K, int M, int N) {
-  const int tiles = ceil_div(M, 256) * ceil_div(N, 128);
+  const bool wide = dw_wide(N);
+  const int tiles = ceil_div(M, 256) * ceil_div(N, wide ? 256 : 128);
+  const int target = wide ? (g_dw_blocks + 1) / 2 : g_dw_blocks;
   int S = 1;
-  while (S < 64 && tiles * S < g_dw_blocks && K % (2 * S * 32) == 0 && K / (2 * S) >= 512) S *= 2;
+  while (S < 64 && tiles * S < target && K % (2 * S * 32) == 0 && K / (2 * S) >= 512) S *= 2;
   return S;
 }
 
@@ -1888,13 +1903,20 @@ extern "C" int mh_gemm_dw_bias(const void* A, int64_t lda, const void* B, int64_
   MH_CHECK_ARG(M > 0 && N > 0 && M % 8 == 0 && N % 4 == 0 && N % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0, "gemm_dw: M, N, lda, ldb must be multiples of 8");
   MH_CHECK_ARG(splits >= 1 && splits <= 65535 && K > 0 && K % ((int64_t)splits * 32) == 0, "gemm_dw: K=%lld must be a multiple of 32 * splits", (long long)K);
   TnArgs g{(const bf16*)A, lda, (const bf16*)B, ldb, out_partials, M, N, K / splits, (int64_t)M * N + (with_colsum ? M : 0)};
-  const int tiles_n = ceil_div(N, 128);
+  const bool wide = dw_wide(N);
+  const int tiles_n = ceil_div(N, wide ? 256 : 128);
   const dim3 grid((unsigned)(ceil_div(M, 256) * tiles_n), (unsigned)splits);
-  mh_prof_note("gemm_dw M=%d N=%d K=%lld splits=%d colsum=%d", M, N, (long long)K, splits, with_colsum != 0);
-  if (!with_colsum) MH_LAUNCH(gemm_tn_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, g);
-  else if (tiles_n >= 4) MH_LAUNCH(gemm_tn_kernel<8>, grid, dim3(256), 0, (hipStream_t)stream, g);
-  else if (tiles_n >= 2) MH_LAUNCH(gemm_tn_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, g);
-  else MH_LAUNCH(gemm_tn_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, g);
+  mh_prof_note("gemm_dw M=%d N=%d K=%lld splits=%d colsum=%d tile=256x%d", M, N, (long long)K, splits, with_colsum != 0, wide ? 256 : 128);
+  hipStream_t st = (hipStream_t)stream;
+  if (wide) {   // column-sum workers = n-tiles x 4 wave columns
+    if (!with_colsum) MH_LAUNCH((gemm_tn_kernel<0, 4>), grid, dim3(512), 0, st, g);
+    else if (tiles_n >= 2) MH_LAUNCH((gemm_tn_kernel<8, 4>), grid, dim3(512), 0, st, g);
+    else MH_LAUNCH((gemm_tn_kernel<4, 4>), grid, dim3(512), 0, st, g);
+  }
+  else if (!with_colsum) MH_LAUNCH(gemm_tn_kernel<0>, grid, dim3(256), 0, st, g);
+  else if (tiles_n >= 4) MH_LAUNCH(gemm_tn_kernel<8>, grid, dim3(256), 0, st, g);
+  else if (tiles_n >= 2) MH_LAUNCH(gemm_tn_kernel<4>, grid, dim3(256), 0, st, g);
+  else MH_LAUNCH(gemm_tn_kernel<2>, grid, dim3(256), 0, st, g);
   MH_CHECK_LAUNCH();
   return MH_OK;
 }

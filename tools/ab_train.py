@@ -14,17 +14,18 @@ sys.argv = ["bench.py", "--workload", "train", "--steps", "4", "--warmup", "2", 
 import bench  # noqa: E402
 from musediffusion_amd import training  # noqa: E402
 
-if KNOB == "stagger":      # library knob: python tools/ab_train.py stagger 0 -500 -1500 1500
+if KNOB in ("stagger", "dw_wide"):      # library knobs: python tools/ab_train.py stagger 0 -500 -1500 1500 | dw_wide 0 1
     from musediffusion_amd import _lib
     vals = VALS
     for rnd in range(3):
         for v in vals:
-            _lib.lib().mh_gemm_set_stagger(v)
+            (_lib.lib().mh_gemm_set_stagger if KNOB == "stagger" else _lib.lib().mh_gemm_dw_set_wide)(v)
             buf = io.StringIO()
             with contextlib.redirect_stdout(buf):
                 bench.main()
-            print("stagger=%d: %.2f ms" % (v, json.loads(buf.getvalue().strip().splitlines()[-1])["ms_per_step"]), flush=True)
+            print("%s=%d: %.2f ms" % (KNOB, v, json.loads(buf.getvalue().strip().splitlines()[-1])["ms_per_step"]), flush=True)
     _lib.lib().mh_gemm_set_stagger(0)
+    _lib.lib().mh_gemm_dw_set_wide(1)
     raise SystemExit(0)
 for rnd in range(3):
     for on in (True, False):
