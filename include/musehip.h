@@ -391,6 +391,9 @@ int mh_step_end(mh_loop_state* state, mh_stream_t stream);
  * global_load_lds; 2 (default) and 3 = 256x128 tile (4 waves, 3-stage global_load_lds ring, two blocks per CU);
  * 4 = 256x256 (8 waves, 4-stage ring) where N % 256 == 0; 5 = 256x256 with the ping-pong main loop. */
 int mh_gemm_set_variant(int variant);
+/* 1 (default): with the default variant, launches whose operands are all row-major (the training tape, direct callers) take the
+ * 256 x 256 tile when N % 256 == 0 and it still gives every CU a block; K32-panel launches (the engine) never do.  0: round-2 rule. */
+int mh_gemm_set_auto_wide(int on);
 /* out = act(A W^T + bias) and pre_out = A W^T + bias in one pass (bf16 row-major; shapes the big-tile kernel
  * serves: N % 8 == 0, K % 32 == 0, lda / ldw / ldo % 8 == 0; error otherwise).  Forward of dense + GELU / tanh under
  * autograd: the backward needs the pre-activation (training_losses, models/diffusion.py:594-699). */

@@ -156,6 +156,7 @@ SIGNATURES = {
     "mh_step_begin": (INT, [VP, VP, VP, VP, VP, INT, VP]),
     "mh_step_end": (INT, [VP, VP]),
     "mh_gemm_set_variant": (INT, [INT]),
+    "mh_gemm_set_auto_wide": (INT, [INT]),
     "mh_gemm_dw": (INT, [VP, I64, VP, I64, VP, INT, I64, INT, INT, VP]),
     "mh_gemm_dw_splits": (INT, [I64, INT, INT]),
     "mh_gemm_dw_set_blocks": (INT, [INT]),

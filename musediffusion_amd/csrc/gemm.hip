@@ -1286,9 +1286,16 @@ bool big_tile_ok(const GemmArgs& g) {
 // The wide (256x256, one block per CU) tile moves 1.5x fewer operand bytes per flop, but measured inside the captured step
 // (tools/ab_step.py, two graph branches) the 256x128 tile is 1.2% faster: at two blocks per CU the blocks of two
 // concurrently running kernels share a CU, which is what the branches are for.  Wide / ping-pong stay selectable (4 / 5).
+// Round 3: launches with ROW-MAJOR operands (the training tape, direct callers: one GEMM on the chip at a time) take the wide tile
+// when it still gives every CU a block - bench.py --workload train -2.1 % (tools/ab_train.py gemm_variant 2 4); the engine's
+// K32-panel launches (two concurrent branches) keep the 256x128 tile.  mh_gemm_set_auto_wide(0) switches the rule off.
+int g_auto_wide = 1;
 bool want_wide(const GemmArgs& g, int batch) {
-  (void)batch;
-  return g_variant >= 4 && g.N % 256 == 0;
+  if (g.N % 256 != 0) return false;
+  if (g_variant >= 4) return true;
+  if (g_variant != 2 || !g_auto_wide || batch != 1) return false;
+  if (g.a_panel || g.w_panel || g.o_panel || g.r_panel || g.q) return false;
+  return (int64_t)ceil_div(g.M, 256) * (g.N / 256) >= device_cus();
 }
 
 template <int EPI>
@@ -1311,7 +1318,7 @@ int launch(const GemmArgs& g, int dtype, hipStream_t s, int batch = 1) {
       else {
         if (g.d.a_stats || g.d.r_stats || g.d.o_stats) return launch_big<CfgStd, EPI>(g, s, batch);   // deferred LayerNorm: 256x128 only
         if (want_wide(g, batch) && (EPI != 1 || g.H % 64 == 0))
-          return g_variant == 4 ? launch_big<CfgWide, EPI>(g, s, batch) : launch_big<CfgWidePP, EPI>(g, s, batch);
+          return g_variant == 5 ? launch_big<CfgWidePP, EPI>(g, s, batch) : launch_big<CfgWide, EPI>(g, s, batch);
         return launch_big<CfgStd, EPI>(g, s, batch);
       }
     } else if (g_variant == 1) {
@@ -1354,6 +1361,11 @@ extern "C" int mh_gemm_set_spread(int on) {
 
 extern "C" int mh_gemm_set_debug(int bits) {
   g_dbg = bits & 127;
+  return MH_OK;
+}
+
+extern "C" int mh_gemm_set_auto_wide(int on) {
+  g_auto_wide = on ? 1 : 0;
   return MH_OK;
 }
 

@@ -14,18 +14,20 @@ sys.argv = ["bench.py", "--workload", "train", "--steps", "4", "--warmup", "2", 
 import bench  # noqa: E402
 from musediffusion_amd import training  # noqa: E402
 
-if KNOB in ("stagger", "dw_wide"):      # library knobs: python tools/ab_train.py stagger 0 -500 -1500 1500 | dw_wide 0 1
+if KNOB in ("stagger", "dw_wide", "gemm_variant", "auto_wide"):      # library knobs: python tools/ab_train.py stagger 0 -500 -1500 1500 | dw_wide 0 1
     from musediffusion_amd import _lib
     vals = VALS
     for rnd in range(3):
         for v in vals:
-            (_lib.lib().mh_gemm_set_stagger if KNOB == "stagger" else _lib.lib().mh_gemm_dw_set_wide)(v)
+            {"stagger": _lib.lib().mh_gemm_set_stagger, "dw_wide": _lib.lib().mh_gemm_dw_set_wide, "gemm_variant": _lib.lib().mh_gemm_set_variant, "auto_wide": _lib.lib().mh_gemm_set_auto_wide}[KNOB](v)
             buf = io.StringIO()
             with contextlib.redirect_stdout(buf):
                 bench.main()
             print("%s=%d: %.2f ms" % (KNOB, v, json.loads(buf.getvalue().strip().splitlines()[-1])["ms_per_step"]), flush=True)
     _lib.lib().mh_gemm_set_stagger(0)
     _lib.lib().mh_gemm_dw_set_wide(1)
+    _lib.lib().mh_gemm_set_variant(2)
+    _lib.lib().mh_gemm_set_auto_wide(1)
     raise SystemExit(0)
 for rnd in range(3):
     for on in (True, False):
