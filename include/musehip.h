@@ -34,7 +34,8 @@ typedef void* mh_stream_t; /* hipStream_t */
 
 enum mh_status { MH_OK = 0, MH_ERR_INVALID = -1, MH_ERR_HIP = -2, MH_ERR_UNSUPPORTED = -3 };
 enum mh_dtype { MH_F32 = 0, MH_BF16 = 1 };
-enum mh_act { MH_ACT_NONE = 0, MH_ACT_TANH = 1, MH_ACT_GELU_ERF = 2, MH_ACT_SILU = 3 };
+enum mh_act { MH_ACT_NONE = 0, MH_ACT_TANH = 1, MH_ACT_GELU_ERF = 2, MH_ACT_SILU = 3,
+              MH_ACT_DERIV = 4 /* mh_gemm_act_grad only: `pre` holds act'(pre) already (mh_gemm_bias_act_dact) */ };
 
 const char* mh_last_error(void);
 int mh_abi_version(void);
@@ -399,6 +400,12 @@ int mh_gemm_set_auto_wide(int on);
  * autograd: the backward needs the pre-activation (training_losses, models/diffusion.py:594-699). */
 int mh_gemm_bias_act_pre(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, void* pre_out,
                          void* out, int64_t ldo, int64_t M, int N, int K, int act, mh_stream_t stream);
+/* mh_gemm_bias_act_pre for GELU with the DERIVATIVE stored in place of the pre-activation: dact_out = gelu'(A W^T + bias), out =
+ * gelu(A W^T + bias), both bf16, the derivative from the same exp / rcp pair as the activation (round 3: the backward of
+ * BertIntermediate -> BertOutput then multiplies by it - mh_gemm_act_grad with act = MH_ACT_DERIV - instead of evaluating gelu' from
+ * the pre-activation: -22 ns of vector work per element in the backward for +6 in the forward). */
+int mh_gemm_bias_act_dact(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, void* dact_out, void* out,
+                          int64_t ldo, int64_t M, int N, int K, int act, mh_stream_t stream);
 /* out = (A W^T) o act'(pre)  (act = MH_ACT_TANH or MH_ACT_GELU_ERF; bf16 row-major, big-tile shapes): the input-gradient
  * GEMM of the layer that FOLLOWS an activation, with the activation's backward in its epilogue - d(pre) of a dense + GELU
  * block without materialising d(activation) (training_losses backward, models/diffusion.py:594-699). */

@@ -165,6 +165,7 @@ SIGNATURES = {
     "mh_gemm_dw_bias": (INT, [VP, I64, VP, I64, VP, INT, I64, INT, INT, INT, VP]),
     "mh_gemm_act_grad": (INT, [VP, I64, VP, I64, VP, I64, VP, I64, I64, INT, INT, INT, VP]),
     "mh_gemm_bias_act_pre": (INT, [VP, I64, VP, I64, VP, VP, VP, I64, I64, INT, INT, INT, VP]),
+    "mh_gemm_bias_act_dact": (INT, [VP, I64, VP, I64, VP, VP, VP, I64, I64, INT, INT, INT, VP]),
     "mh_gemm_bias_res_ln": (INT, [VP, I64, INT, VP, I64, INT, VP, VP, I64, INT, VP, VP, F32, VP, I64, INT, I64, INT, INT, VP]),
     "mh_gemm_bias_res_ln_supported": (INT, [INT]),
     "mh_denoiser_set_fuse_ln": (INT, [INT]),

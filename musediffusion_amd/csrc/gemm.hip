@@ -60,6 +60,7 @@ struct GemmArgs {
   int dbg;  // timing-only ablation bits (mh_gemm_set_debug): 1 no DMA, 2 no MFMA, 4 no stores
   int ntiles;    // persistent big-tile launch: ntiles output tiles walked by gridDim.x blocks
   int vt_perm;   // QKV scatter: V^T keys in the P-operand order of mh_attention_stream_fwd (middle groups of 4 swapped per 16)
+  int pre_kind;  // what pre_out receives: 0 the pre-activation, 1 act'(pre) (GELU: gelu_erf_fast8_dgelu)
   float q_scale; // QKV scatter (big tile): the query columns are stored multiplied by this (0 = unscaled): softmax scale x log2(e) for mh_attention_stream_fwd_prescaled
   int stagger;   // experiment: blocks of the second half of the grid (the co-resident partners) start this many 10-ns ticks late
   DeferArgs d;   // DBG bit 128 kernels only
@@ -1112,13 +1113,24 @@ __global__ __launch_bounds__(C::THREADS, C::STAGE * C::NST <= 80 * 1024 ? 2 : 1)
                   for (int e = 0; e < 8; ++e) v[e] = acc[i][2 * qh + (e >> 2)][e & 3] + bv[qh][e];
                 }
                 if constexpr (ACT != MH_ACT_NONE) {
-                  if (g.pre_out) {   // training: the backward needs the pre-activation
-                    store8_nt(reinterpret_cast<bf16*>(g.pre_out) + (int64_t)blockIdx.y * g.sO + oo, v);
+                  bool done = false;
+                  if constexpr (ACT == MH_ACT_GELU_ERF) {
+                    if (g.pre_out && g.pre_kind == 1) {   // training: the backward gets gelu'(pre), from the same exp / rcp as gelu(pre)
+                      float gp[8];
+                      gelu_erf_fast8_dgelu(v, gp);
+                      store8_nt(reinterpret_cast<bf16*>(g.pre_out) + (int64_t)blockIdx.y * g.sO + oo, gp);
+                      done = true;
+                    }
                   }
-                  if constexpr (ACT == MH_ACT_GELU_ERF) gelu_erf_fast8(v);
-                  else {
+                  if (!done) {
+                    if (g.pre_out) {   // training: the backward needs the pre-activation
+                      store8_nt(reinterpret_cast<bf16*>(g.pre_out) + (int64_t)blockIdx.y * g.sO + oo, v);
+                    }
+                    if constexpr (ACT == MH_ACT_GELU_ERF) gelu_erf_fast8(v);
+                    else {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = apply_act<bf16>(v[e], ACT);
+                      for (int e = 0; e < 8; ++e) v[e] = apply_act<bf16>(v[e], ACT);
+                    }
                   }
                 }
                 if constexpr ((DBG & 64) != 0) {   // train-mode dropout of the dense output, before the residual
@@ -1130,6 +1142,9 @@ __global__ __launch_bounds__(C::THREADS, C::STAGE * C::NST <= 80 * 1024 ? 2 : 1)
                   if (g.act_grad == MH_ACT_GELU_ERF) {          // backward of dense + GELU: dpre = (dY W) o gelu'(pre)
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] *= gelu_erf_grad((float)rraw[i][e]);
+                  } else if (g.act_grad == MH_ACT_DERIV) {        // the tensor holds act'(pre) already (mh_gemm_bias_act_dact)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] *= (float)rraw[i][e];
                   } else if (g.act_grad == MH_ACT_TANH) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) { const float th = tanhf((float)rraw[i][e]); v[e] *= 1.0f - th * th; }
@@ -1516,12 +1531,25 @@ extern "C" int mh_gemm_bias_act_pre(const void* A, int64_t lda, const void* W, i
   return launch<0>(g, MH_BF16, (hipStream_t)stream);
 }
 
+// mh_gemm_bias_act_pre for GELU with the DERIVATIVE in place of the pre-activation: dact_out = gelu'(A W^T + bias) (bf16), out = gelu(...).
+// The backward multiplies by it (mh_gemm_act_grad with act = MH_ACT_DERIV) instead of evaluating gelu' again from the pre-activation.
+extern "C" int mh_gemm_bias_act_dact(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, void* dact_out,
+                                     void* out, int64_t ldo, int64_t M, int N, int K, int act, mh_stream_t stream) {
+  MH_CHECK_ARG(A && W && out && dact_out, "gemm_bias_act_dact: null pointer");
+  MH_CHECK_ARG(M > 0 && N > 0 && act == MH_ACT_GELU_ERF, "gemm_bias_act_dact: bad problem / activation (GELU only)");
+  GemmArgs g{};
+  g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.bias = bias; g.ldr = 8; g.out = out; g.ldo = ldo;
+  g.M = M; g.N = N; g.K = K; g.act = act; g.pre_out = dact_out; g.pre_kind = 1;
+  MH_CHECK_ARG(g_variant >= 2 && lda % 8 == 0 && ldw % 8 == 0 && big_tile_ok(g), "gemm_bias_act_dact: shape not served by the big-tile kernel");
+  return launch<0>(g, MH_BF16, (hipStream_t)stream);
+}
+
 // out = (A W^T) o act'(pre): the input-gradient GEMM of the layer AFTER an activation with the activation's own backward
 // folded into its epilogue (bf16 row-major, big-tile shapes; act = tanh or erf-GELU)
 extern "C" int mh_gemm_act_grad(const void* A, int64_t lda, const void* W, int64_t ldw, const void* pre, int64_t ld_pre, void* out,
                                 int64_t ldo, int64_t M, int N, int K, int act, mh_stream_t stream) {
   MH_CHECK_ARG(A && W && pre && out, "gemm_act_grad: null pointer");
-  MH_CHECK_ARG(M > 0 && N > 0 && (act == MH_ACT_TANH || act == MH_ACT_GELU_ERF), "gemm_act_grad: bad problem / activation");
+  MH_CHECK_ARG(M > 0 && N > 0 && (act == MH_ACT_TANH || act == MH_ACT_GELU_ERF || act == MH_ACT_DERIV), "gemm_act_grad: bad problem / activation");
   GemmArgs g{};
   g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.residual = pre; g.ldr = ld_pre; g.out = out; g.ldo = ldo;
   g.M = M; g.N = N; g.K = K; g.act = MH_ACT_NONE; g.act_grad = act;

@@ -25,6 +25,8 @@ NPART = 256  # rows of the two-stage column-sum scratch
 TN_DW = True            # bf16: weight gradients straight from the k-major activations (mh_gemm_dw), no transposed copies
 FUSED_FFN = True        # bf16: FFN as one tape node with the GELU backward fused into a GEMM epilogue (A/B switch for tests)
 FUSED_ATTENTION = True  # bf16: streaming forward + fused backward kernels when the shape allows (A/B switch for tests)
+GELU_DERIV_FWD = True        # the FFN node keeps gelu'(pre) instead of pre (mh_gemm_bias_act_dact; A/B: tools/ab_train.py GELU_DERIV_FWD)
+ACT_DERIV = 4                # MH_ACT_DERIV
 WEIGHT_PREP = True      # bf16: the encoder's weight casts / transposes of a forward + backward in one launch (_WeightPrep)
 FUSED_DENSE_LN = True   # bf16, d_model 512: BertSelfOutput / BertOutput dense -> dropout -> + input -> LayerNorm as one kernel
 
@@ -280,8 +282,11 @@ class _FFN(Function):
             ctx.WT = None
         pre = torch.empty(M, F, device=x.device, dtype=x.dtype)
         f = torch.empty_like(pre)
-        check(lib().mh_gemm_bias_act_pre(ptr(x), H, ptr(W1c), H, ptr(b1.detach()), ptr(pre), ptr(f), F, M, F, H, ops.ACT["gelu"],
-                                         current_stream()), "mh_gemm_bias_act_pre")
+        # GELU_DERIV_FWD: `pre` receives gelu'(pre) - from the exp / rcp pair that gelu(pre) needs anyway - and the backward multiplies
+        ctx.deriv = bool(GELU_DERIV_FWD)
+        fwd = lib().mh_gemm_bias_act_dact if ctx.deriv else lib().mh_gemm_bias_act_pre
+        check(fwd(ptr(x), H, ptr(W1c), H, ptr(b1.detach()), ptr(pre), ptr(f), F, M, F, H, ops.ACT["gelu"], current_stream()),
+              "mh_gemm_bias_act_dact" if ctx.deriv else "mh_gemm_bias_act_pre")
         y = torch.empty(M, H, device=x.device, dtype=x.dtype)
         ctx.drop = drop if _active(drop) else None
         if ln is not None and ln.usable(f, H, F, x, dt, None):
@@ -306,8 +311,8 @@ class _FFN(Function):
         # d(pre) = (dy W2) o gelu'(pre): W2 is [H, F]; the GEMM wants the reduction dim contiguous -> W2^T [F, H]
         dpre = torch.empty(M, F, device=x.device, dtype=x.dtype)
         W2T = ctx.WT[1] if ctx.WT is not None else _transpose(W2c, H, F, dt, ld_out=H)
-        check(lib().mh_gemm_act_grad(ptr(dym), H, ptr(W2T), H, ptr(pre), F, ptr(dpre), F, M, F, H, ops.ACT["gelu"], current_stream()),
-              "mh_gemm_act_grad")
+        check(lib().mh_gemm_act_grad(ptr(dym), H, ptr(W2T), H, ptr(pre), F, ptr(dpre), F, M, F, H, ACT_DERIV if ctx.deriv else ops.ACT["gelu"],
+                                     current_stream()), "mh_gemm_act_grad")
         dW1, db1 = _dw(dpre, x, F, H, M, dt, bias=True)
         dx = torch.empty(M, H, device=x.device, dtype=x.dtype)
         W1T = ctx.WT[0] if ctx.WT is not None else _transpose(W1c, F, H, dt, ld_out=F)                         # [H, F]

@@ -18,7 +18,7 @@ from musediffusion_amd import _lib  # noqa: E402
 
 setters = {"gemm_debug": lambda v: _lib.lib().mh_gemm_set_debug(v), "plain_stores": lambda v: _lib.lib().mh_gemm_set_plain_stores(v), "fuse_ln": lambda v: _lib.lib().mh_denoiser_set_fuse_ln(v),
            "v3_fuse_ln": lambda v: (_lib.lib().mh_gemm_set_variant(3), _lib.lib().mh_denoiser_set_fuse_ln(v)),
-           "v3_split": None, "skip": lambda v: _lib.lib().mh_denoiser_set_skip(v), "ln_rows4": lambda v: _lib.lib().mh_layernorm_set_rows4(v), "prescale_q": lambda v: _lib.lib().mh_denoiser_set_prescale_q(v),
+           "v3_split": None, "v4_split": None, "skip": lambda v: _lib.lib().mh_denoiser_set_skip(v), "ln_rows4": lambda v: _lib.lib().mh_layernorm_set_rows4(v), "prescale_q": lambda v: _lib.lib().mh_denoiser_set_prescale_q(v),
            "stream_attn": lambda v: _lib.lib().mh_attention_set_stream(v), "gemm_variant": lambda v: _lib.lib().mh_gemm_set_variant(v)}
 from musediffusion_amd.models.diffusion import GaussianDiffusion  # noqa: E402
 setters["decouple"] = lambda v: setattr(GaussianDiffusion, "decouple_branches", bool(v))
@@ -30,6 +30,9 @@ for rnd in range(3):
         if knob == "v3_split":
             _lib.lib().mh_gemm_set_variant(3)
             sys.argv = BASE + ["--split", str(v)]
+        elif knob == "v4_split":      # value = 10 * variant + branches: 21 = default tiles, one branch; 41 = 256x256 tile, one branch; 42 ...
+            _lib.lib().mh_gemm_set_variant(v // 10)
+            sys.argv = BASE + ["--split", str(v % 10)]
         else:
             setters[knob](v)
         buf = io.StringIO()
