@@ -574,6 +574,13 @@ int mh_gemm_bias_dropout_res(const void* A, int64_t lda, const void* W, int64_t 
  * r (+ 16 for the odd key block) <-> key (r & 3) + 8 (r >> 2) + 4 h of the block */
 size_t mh_dropout_bits_words(int BH, int L);
 int mh_dropout_bits(uint32_t* keep_bits, int BH, int L, const mh_dropout* drop, mh_stream_t stream);
+/* mh_layernorm_bwd that also writes dx_dropped = dx o keep / (1 - p) for the dropout site of the dense layer IN FRONT of the LayerNorm
+ * (BertSelfOutput / BertOutput: dense -> dropout -> + input -> LayerNorm): the dense branch of that node's backward reads dx_dropped,
+ * the residual branch dx.  Element index of the mask = row * H + col (the dense sites' convention); identical to mh_dropout_fwd
+ * applied to the stored dx.  drop == NULL or p == 0: mh_layernorm_bwd. */
+int mh_layernorm_bwd_drop(const void* x, const void* dy, const float* gamma, void* dx, void* dx_dropped, const mh_dropout* drop,
+                          float* partial, int n_partial, float* dgamma, float* dbeta, int accumulate, int64_t rows, int H, float eps,
+                          int dtype, mh_stream_t stream);
 /* P[bh][q][k] = keep ? P / (1 - p) : 0 over a materialised [B nh, L, ldp] tensor (probabilities forward, their gradient backward) */
 int mh_dropout_bits_apply(void* P, int64_t ldp, const uint32_t* keep_bits, int BH, int L, float p, int dtype, mh_stream_t stream);
 /* streaming attention with probability dropout: keep_bits written (bits_in = 0) or read (bits_in = 1) by the forward, read by the

@@ -129,6 +129,7 @@ SIGNATURES = {
     "mh_act_fwd": (INT, [VP, VP, I64, INT, INT, VP]),
     "mh_act_bwd": (INT, [VP, VP, VP, I64, INT, INT, VP]),
     "mh_layernorm_bwd": (INT, [VP, VP, VP, VP, VP, INT, VP, VP, INT, I64, INT, F32, INT, VP]),
+    "mh_layernorm_bwd_drop": (INT, [VP, VP, VP, VP, VP, VP, VP, INT, VP, VP, INT, I64, INT, F32, INT, VP]),
     "mh_softmax_rows": (INT, [VP, I64, INT, I64, F32, INT, VP]),
     "mh_softmax_bwd_rows": (INT, [VP, VP, I64, INT, I64, F32, INT, VP]),
     "mh_cross_entropy_fwd": (INT, [VP, I64, VP, VP, VP, I64, INT, VP]),

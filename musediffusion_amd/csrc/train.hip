@@ -248,10 +248,13 @@ __global__ void act_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x
 // dgamma / dbeta partials accumulate in registers over the block's rows and are written per block.
 // LNCH = 16-byte chunks per lane (ceil(H / 512)): a compile-time bound keeps the per-row and per-column registers of a narrow model
 // at a quarter of the H = 2048 build's, i.e. four times the waves per SIMD to hide the row's dependent reductions behind
-template <typename T, int LNCH>
+// DROPM: also writes dxm = dx o keep / (1 - p) for the dropout site of the dense layer in FRONT of this LayerNorm (the dense branch of
+// its backward reads dxm, the residual branch dx) - the mask re-created from the site's descriptor exactly as mh_dropout_fwd does on
+// the stored bf16 dx, so the separate re-application pass (a read and a write of the tensor, one launch) disappears.
+template <typename T, int LNCH, bool DROPM = false>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, const float* __restrict__ gamma,
                                                      T* __restrict__ dx, float* __restrict__ pg, float* __restrict__ pb,
-                                                     int64_t rows, int H, float eps) {
+                                                     int64_t rows, int H, float eps, T* __restrict__ dxm = nullptr, const DropArgs drop = DropArgs{}) {
   __shared__ float red[2][4][512 * LNCH];  // [dgamma|dbeta][wave][col]
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int nch = H >> 3;
@@ -310,6 +313,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ x, co
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = rstd * (gv[i][e] - s1 - xv[i][e] * s2);
         store8(dx + row * H + c * 8, o);
+        if constexpr (DROPM) {
+          const uint32_t km = drop_keep8_at(drop, (uint64_t)row * H + c * 8);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = (km >> e) & 1u ? to_f32(from_f32<T>(o[e])) * drop.rscale : 0.f;   // (of the ROUNDED dx, as the separate pass did)
+          store8(dxm + row * H + c * 8, o);
+        }
       }
     }
   }
@@ -718,19 +727,42 @@ extern "C" int mh_act_bwd(const void* dy, const void* x, void* dx, int64_t n, in
   return MH_OK;
 }
 
+int mh_drop_args(const mh_dropout* d, DropArgs* out);
+extern "C" int mh_layernorm_bwd_drop(const void* x, const void* dy, const float* gamma, void* dx, void* dx_dropped, const mh_dropout* drop,
+                                     float* partial, int n_partial, float* dgamma, float* dbeta, int accumulate, int64_t rows, int H,
+                                     float eps, int dtype, mh_stream_t stream);
 extern "C" int mh_layernorm_bwd(const void* x, const void* dy, const float* gamma, void* dx, float* partial, int n_partial,
                                 float* dgamma, float* dbeta, int accumulate, int64_t rows, int H, float eps, int dtype,
                                 mh_stream_t stream) {
+  return mh_layernorm_bwd_drop(x, dy, gamma, dx, nullptr, nullptr, partial, n_partial, dgamma, dbeta, accumulate, rows, H, eps, dtype, stream);
+}
+// mh_layernorm_bwd that also writes dx_dropped = dx o keep / (1 - p) for the dropout site `drop` (element index = row * H + col, the
+// dense sites' convention): what mh_dropout_fwd would make of dx in a second pass.  drop == null or p == 0: plain mh_layernorm_bwd.
+extern "C" int mh_layernorm_bwd_drop(const void* x, const void* dy, const float* gamma, void* dx, void* dx_dropped, const mh_dropout* drop,
+                                     float* partial, int n_partial, float* dgamma, float* dbeta, int accumulate, int64_t rows, int H,
+                                     float eps, int dtype, mh_stream_t stream) {
   MH_CHECK_ARG(x && dy && gamma && dx && partial && dgamma && dbeta, "layernorm_bwd: null pointer");
   MH_CHECK_ARG(rows > 0 && H % 8 == 0 && H <= 2048 && n_partial > 0 && n_partial <= 1024, "layernorm_bwd: bad shape");
   hipStream_t s = (hipStream_t)stream;
   float* pg = partial;
   float* pb = partial + (int64_t)n_partial * H;
+  DropArgs da;
+  int rcd = mh_drop_args(drop, &da);
+  if (rcd) return rcd;
+  if (da.thr != 0 || da.mask) {
+    MH_CHECK_ARG(dx_dropped, "layernorm_bwd_drop: dropout needs the second output");
+#define MH_LNBD(T, N) MH_LAUNCH((ln_bwd_kernel<T, N, true>), dim3(n_partial), dim3(256), 0, s, (const T*)x, (const T*)dy, gamma, (T*)dx, pg, pb, rows, H, eps, (T*)dx_dropped, da)
+    if (H <= 512) { MH_DTYPE_SWITCH(dtype, MH_LNBD(bf16, 1), MH_LNBD(float, 1), "layernorm_bwd_drop"); }
+    else if (H <= 1024) { MH_DTYPE_SWITCH(dtype, MH_LNBD(bf16, 2), MH_LNBD(float, 2), "layernorm_bwd_drop"); }
+    else { MH_DTYPE_SWITCH(dtype, MH_LNBD(bf16, 4), MH_LNBD(float, 4), "layernorm_bwd_drop"); }
+#undef MH_LNBD
+  } else {
 #define MH_LNB(T, N) MH_LAUNCH((ln_bwd_kernel<T, N>), dim3(n_partial), dim3(256), 0, s, (const T*)x, (const T*)dy, gamma, (T*)dx, pg, pb, rows, H, eps)
-  if (H <= 512) { MH_DTYPE_SWITCH(dtype, MH_LNB(bf16, 1), MH_LNB(float, 1), "layernorm_bwd"); }
-  else if (H <= 1024) { MH_DTYPE_SWITCH(dtype, MH_LNB(bf16, 2), MH_LNB(float, 2), "layernorm_bwd"); }
-  else { MH_DTYPE_SWITCH(dtype, MH_LNB(bf16, 4), MH_LNB(float, 4), "layernorm_bwd"); }
+    if (H <= 512) { MH_DTYPE_SWITCH(dtype, MH_LNB(bf16, 1), MH_LNB(float, 1), "layernorm_bwd"); }
+    else if (H <= 1024) { MH_DTYPE_SWITCH(dtype, MH_LNB(bf16, 2), MH_LNB(float, 2), "layernorm_bwd"); }
+    else { MH_DTYPE_SWITCH(dtype, MH_LNB(bf16, 4), MH_LNB(float, 4), "layernorm_bwd"); }
 #undef MH_LNB
+  }
   MH_CHECK_LAUNCH();
   // (a colsum_final block folds 64 columns: 4 partial-lanes x 64)
   if (dbeta == dgamma + H) {   // the two gradients side by side (as the partials are): one launch folds both

@@ -25,6 +25,7 @@ NPART = 256  # rows of the two-stage column-sum scratch
 TN_DW = True            # bf16: weight gradients straight from the k-major activations (mh_gemm_dw), no transposed copies
 FUSED_FFN = True        # bf16: FFN as one tape node with the GELU backward fused into a GEMM epilogue (A/B switch for tests)
 FUSED_ATTENTION = True  # bf16: streaming forward + fused backward kernels when the shape allows (A/B switch for tests)
+LN_BWD_DROP = True           # the LayerNorm backward also writes its input gradient x the dense node's dropout mask (mh_layernorm_bwd_drop)
 GELU_DERIV_FWD = True        # the FFN node keeps gelu'(pre) instead of pre (mh_gemm_bias_act_dact; A/B: tools/ab_train.py GELU_DERIV_FWD)
 ACT_DERIV = 4                # MH_ACT_DERIV
 WEIGHT_PREP = True      # bf16: the encoder's weight casts / transposes of a forward + backward in one launch (_WeightPrep)
@@ -39,6 +40,8 @@ class _FusedLN:
 
     def __init__(self, ln):
         self.g, self.b, self.eps, self.y = ln.weight, ln.bias, float(ln.eps), None
+        self.drop = None     # the dense node's dropout site when it ran the one-kernel form: the LayerNorm backward then also writes ...
+        self.dym = None      # ... dx o keep / (1 - p), which the dense node's backward takes instead of a separate mh_dropout_fwd pass
 
     def usable(self, x, N, Kp, residual, dt, act):
         return (FUSED_DENSE_LN and dt == ops.MH_BF16 and act is None and residual is not None and N == 512 and Kp % 32 == 0
@@ -50,6 +53,7 @@ class _FusedLN:
         N = Wc.shape[0]
         self.y = torch.empty_like(pre)
         d = drop.c() if drop is not None else None
+        self.drop = drop if (LN_BWD_DROP and drop is not None) else None
         check(lib().mh_gemm_bias_dropout_res_ln(ptr(x), Kp, ptr(Wc), Wc.shape[1], ptr(b), ptr(residual), residual.shape[1],
                                                 ptr(self.g.detach()), ptr(self.b.detach()), self.eps, ptr(pre), ptr(self.y), N, M, N, Kp,
                                                 C.byref(d) if d is not None else None, current_stream()), "mh_gemm_bias_dropout_res_ln")
@@ -96,6 +100,17 @@ class _Drop:
         check(lib().mh_dropout_fwd(ptr(x), x.shape[1], ptr(out), out.shape[1], x.shape[0], x.shape[1], dt, C.byref(d), current_stream()),
               "mh_dropout_fwd")
         return out
+
+
+def _dropped_grad(ctx_ln, drop, dy, dt):
+    """dY o keep / (1 - p) for a dense node's backward: taken from the LayerNorm backward when it wrote it next to this very dY
+    (_FusedLN.dym), else one mh_dropout_fwd pass."""
+    if ctx_ln is not None and ctx_ln.dym is not None:
+        src, dym = ctx_ln.dym
+        ctx_ln.dym = None
+        if src.data_ptr() == dy.data_ptr():
+            return dym
+    return drop.apply(dy, dt)
 
 
 def _active(drop):
@@ -235,6 +250,7 @@ class _Linear(Function):
                 check(lib().mh_act_fwd(ptr(pre), ptr(y), pre.numel(), ops.ACT[act], dt, current_stream()), "mh_act_fwd")
                 assert residual is None
         ctx.save_for_backward(x, Wc, pre if act is not None else None)
+        ctx.ln = ln
         ctx.meta = (act, dt, N, K, Kp, Np, residual is not None, b is not None)
         return y
 
@@ -248,7 +264,7 @@ class _Linear(Function):
             dpre = torch.empty_like(dy)
             check(lib().mh_act_bwd(ptr(dy), ptr(pre), ptr(dpre), dy.numel(), ops.ACT[act], dt, current_stream()), "mh_act_bwd")
         elif ctx.drop is not None:
-            dpre = ctx.drop.apply(dy, dt)          # the dense branch sees dY o keep / (1 - p); the residual branch sees dY
+            dpre = _dropped_grad(ctx.ln, ctx.drop, dy, dt)   # the dense branch sees dY o keep / (1 - p); the residual branch sees dY
         else:
             dpre = dy
         # dX = dpre W : reduction over the N outputs
@@ -296,6 +312,7 @@ class _FFN(Function):
         else:
             _gemm(f, W2c, b2.detach(), dt, H, F, out=y, residual=x)
         ctx.save_for_backward(x, W1c, W2c, pre, f)
+        ctx.ln = ln
         ctx.dt = dt
         return y
 
@@ -306,7 +323,7 @@ class _FFN(Function):
         M, H = x.shape
         F = W1c.shape[0]
         dy = dy.contiguous()
-        dym = ctx.drop.apply(dy, dt) if ctx.drop is not None else dy      # gradient of the dropped dense output
+        dym = _dropped_grad(ctx.ln, ctx.drop, dy, dt) if ctx.drop is not None else dy      # gradient of the dropped dense output
         dW2, db2 = _dw(dym, f, H, F, M, dt, bias=True)
         # d(pre) = (dy W2) o gelu'(pre): W2 is [H, F]; the GEMM wants the reduction dim contiguous -> W2^T [F, H]
         dpre = torch.empty(M, F, device=x.device, dtype=x.dtype)
@@ -342,6 +359,7 @@ class _LayerNorm(Function):
             y = ops.layernorm(x, g.detach(), b.detach(), eps, dt)
         ctx.save_for_backward(x, g.detach())
         ctx.meta = (eps, dt)
+        ctx.fused = fused if (fused is not None and fused.drop is not None) else None
         return y
 
     @staticmethod
@@ -355,8 +373,16 @@ class _LayerNorm(Function):
         part = torch.empty(2 * nb * H, device=x.device, dtype=torch.float32)
         dgb = torch.empty(2, H, device=x.device, dtype=torch.float32)     # side by side: one launch folds both (mh_layernorm_bwd)
         dg, db = dgb[0], dgb[1]
-        check(lib().mh_layernorm_bwd(ptr(x), ptr(dy), ptr(g), ptr(dx), ptr(part), nb, ptr(dg), ptr(db), 0, M, H, eps, dt,
-                                     current_stream()), "mh_layernorm_bwd")
+        if ctx.fused is not None:      # ... and dx o keep / (1 - p) of the dense node in front, handed over through the _FusedLN
+            import ctypes as C
+            dxm = torch.empty_like(x)
+            d = ctx.fused.drop.c()
+            check(lib().mh_layernorm_bwd_drop(ptr(x), ptr(dy), ptr(g), ptr(dx), ptr(dxm), C.byref(d), ptr(part), nb, ptr(dg), ptr(db), 0, M, H,
+                                              eps, dt, current_stream()), "mh_layernorm_bwd_drop")
+            ctx.fused.dym = (dx, dxm)
+        else:
+            check(lib().mh_layernorm_bwd(ptr(x), ptr(dy), ptr(g), ptr(dx), ptr(part), nb, ptr(dg), ptr(db), 0, M, H, eps, dt,
+                                         current_stream()), "mh_layernorm_bwd")
         return dx, dg, db, None, None, None
 
 
