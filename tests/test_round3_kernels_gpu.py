@@ -1,0 +1,124 @@
+"""Kernel-level tests of the round-3 training changes (GPU): each new form against the form it replaces - bit for bit where the
+arithmetic is the same, within the stated tolerance where it is not.
+
+* weight-gradient GEMM on the 256 x 256 tile == on the 256 x 128 tile (same slices, same summation order per output element);
+* row-major GEMM launches on the automatically chosen 256 x 256 tile == the 256 x 128 tile;
+* mh_layernorm_bwd_drop == mh_layernorm_bwd followed by mh_dropout_fwd on its dx (HF BertSelfOutput / BertOutput backward);
+* mh_gemm_bias_act_dact: the activation is mh_gemm_bias_act_pre's, the stored derivative is gelu'(pre) to 1.1e-4 + bf16 rounding,
+  and mh_gemm_act_grad(MH_ACT_DERIV) multiplies by it (HF BertIntermediate backward, reached from models/diffusion.py:594-699)."""
+import ctypes as C
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from musediffusion_amd import _lib, ops  # noqa: E402
+from musediffusion_amd._lib import MH_BF16, check, current_stream, lib  # noqa: E402
+
+DEV = "cuda"
+MH_ACT_GELU, MH_ACT_DERIV = 2, 4
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * scale
+
+
+@pytest.mark.parametrize("K,M,N,colsum", [(8192, 2048, 512, 1), (8192, 512, 2048, 1), (4096, 1536, 512, 0), (4096, 512, 256, 1)])
+def test_gemm_dw_wide_and_narrow_tiles_agree(K, M, N, colsum):
+    A = rnd(K, M, seed=901, scale=0.5).to(DEV).bfloat16().contiguous()
+    B = rnd(K, N, seed=902, scale=0.5).to(DEV).bfloat16().contiguous()
+    outs = []
+    try:
+        for wide in (0, 1):
+            check(lib().mh_gemm_dw_set_wide(wide))
+            S = int(lib().mh_gemm_dw_splits(K, M, N))
+            n = M * N + (M if colsum else 0)
+            part = torch.full((S, n), float("nan"), device=DEV)
+            check(lib().mh_gemm_dw_bias(A.data_ptr(), M, B.data_ptr(), N, part.data_ptr(), S, K, M, N, colsum, current_stream()))
+            out = torch.empty(n, device=DEV)
+            check(lib().mh_sum_slices(part.data_ptr(), S, n, out.data_ptr(), current_stream()))
+            outs.append((S, out.cpu()))
+    finally:
+        lib().mh_gemm_dw_set_wide(1)
+    assert not torch.isnan(outs[1][1]).any()
+    ref = A.float().T @ B.float()
+    assert float((outs[1][1][: M * N].view(M, N).to(DEV) - ref).abs().max()) < 2e-3 * math.sqrt(K / 1024) + 1e-3 * float(ref.abs().max())
+    if outs[0][0] == outs[1][0]:      # same token slices: every output element adds the same products in the same order
+        assert torch.equal(outs[0][1][: M * N], outs[1][1][: M * N]), "dW differs between the tiles"
+    assert torch.allclose(outs[0][1], outs[1][1], rtol=1e-5, atol=1e-4)
+
+
+def test_row_major_gemm_takes_the_wide_tile_with_the_same_result():
+    M, N, K = 16384, 1024, 256            # 64 x 4 = 256 wide tiles: one per CU, so the automatic rule switches
+    A = rnd(M, K, seed=903, scale=0.5).to(DEV).bfloat16()
+    W = (rnd(N, K, seed=904) / math.sqrt(K)).to(DEV).bfloat16()
+    b = rnd(N, seed=905, scale=0.1).to(DEV)
+    outs = []
+    try:
+        for auto in (0, 1):
+            check(lib().mh_gemm_set_auto_wide(auto))
+            outs.append(ops.gemm_bias_act(A, W, b, None, "gelu", MH_BF16))
+    finally:
+        lib().mh_gemm_set_auto_wide(1)
+    assert torch.equal(outs[0], outs[1])
+    ref = torch.nn.functional.gelu(A.float() @ W.float().T + b)
+    assert float((outs[1].float() - ref).abs().max()) < 0.03
+
+
+@pytest.mark.parametrize("H,rows", [(512, 4096), (768, 1000), (128, 264)])
+def test_layernorm_backward_with_dropped_copy_matches_two_passes(H, rows):
+    x = rnd(rows, H, seed=906).to(DEV).bfloat16()
+    dy = rnd(rows, H, seed=907, scale=0.1).to(DEV).bfloat16()
+    g = (1 + 0.1 * rnd(H, seed=908)).to(DEV)
+    d = _lib.Dropout()
+    d.p, d.seed, d.offset, d.mask = 0.1, 0x1234ABCD5678, (3 << 16) | 5, None
+    nb = min(1024, (rows + 3) // 4)
+
+    def run(fused):
+        dx, dxm = torch.empty_like(x), torch.empty_like(x)
+        part = torch.empty(2 * nb * H, device=DEV)
+        dgb = torch.empty(2, H, device=DEV)
+        if fused:
+            check(lib().mh_layernorm_bwd_drop(x.data_ptr(), dy.data_ptr(), g.data_ptr(), dx.data_ptr(), dxm.data_ptr(), C.byref(d), part.data_ptr(), nb,
+                                              dgb[0].data_ptr(), dgb[1].data_ptr(), 0, rows, H, 1e-12, MH_BF16, current_stream()))
+        else:
+            check(lib().mh_layernorm_bwd(x.data_ptr(), dy.data_ptr(), g.data_ptr(), dx.data_ptr(), part.data_ptr(), nb, dgb[0].data_ptr(),
+                                         dgb[1].data_ptr(), 0, rows, H, 1e-12, MH_BF16, current_stream()))
+            check(lib().mh_dropout_fwd(dx.data_ptr(), H, dxm.data_ptr(), H, rows, H, MH_BF16, C.byref(d), current_stream()))
+        return dx, dxm, dgb
+
+    a, b = run(True), run(False)
+    for name, u, v in zip(("dx", "dx o keep / (1 - p)", "dgamma | dbeta"), a, b):
+        assert torch.equal(u, v), name
+    kept = float((a[1] != 0).float().mean())
+    assert abs(kept - 0.9) < 0.01
+
+
+def test_gelu_derivative_stored_by_the_forward():
+    M, H, F = 2048, 512, 2048
+    x = rnd(M, H, seed=910, scale=0.7).to(DEV).bfloat16()
+    W1 = (rnd(F, H, seed=911) / math.sqrt(H) * 2.0).to(DEV).bfloat16()
+    b1 = rnd(F, seed=912, scale=0.3).to(DEV)
+    st = current_stream()
+    pre, f0 = torch.empty(M, F, device=DEV, dtype=torch.bfloat16), torch.empty(M, F, device=DEV, dtype=torch.bfloat16)
+    dact, f1 = torch.empty_like(pre), torch.empty_like(pre)
+    check(lib().mh_gemm_bias_act_pre(x.data_ptr(), H, W1.data_ptr(), H, b1.data_ptr(), pre.data_ptr(), f0.data_ptr(), F, M, F, H, MH_ACT_GELU, st))
+    check(lib().mh_gemm_bias_act_dact(x.data_ptr(), H, W1.data_ptr(), H, b1.data_ptr(), dact.data_ptr(), f1.data_ptr(), F, M, F, H, MH_ACT_GELU, st))
+    assert torch.equal(f0, f1), "the activation must not depend on what is stored beside it"
+    z = (x.float() @ W1.float().T + b1).double()
+    ref = 0.5 * (1 + torch.erf(z / math.sqrt(2))) + z * torch.exp(-z * z / 2) / math.sqrt(2 * math.pi)
+    err = (dact.double() - ref).abs()
+    tol = 2e-4 + 2.0 ** -8 * ref.abs() + 1e-3 * (z.abs() < 1e-2)     # 1.1e-4 of the approximation + bf16 rounding of the stored value
+    assert bool((err <= tol).all()), "gelu'(pre): max err %.3e" % float(err.max())
+    assert float(z.abs().max()) > 4.0                                  # both tails are covered
+    # the backward: (dY W2) o dact == what the pre-activation form gives, to the derivative's tolerance
+    dy = rnd(M, H, seed=913, scale=0.1).to(DEV).bfloat16()
+    W2T = (rnd(F, H, seed=914) / math.sqrt(F)).to(DEV).bfloat16()       # [F, H]: dpre = dY W2, the reduction over H
+    d0, d1 = torch.empty_like(pre), torch.empty_like(pre)
+    check(lib().mh_gemm_act_grad(dy.data_ptr(), H, W2T.data_ptr(), H, pre.data_ptr(), F, d0.data_ptr(), F, M, F, H, MH_ACT_GELU, st))
+    check(lib().mh_gemm_act_grad(dy.data_ptr(), H, W2T.data_ptr(), H, dact.data_ptr(), F, d1.data_ptr(), F, M, F, H, MH_ACT_DERIV, st))
+    exact = (dy.float() @ W2T.float().T) * dact.float()
+    assert float((d1.float() - exact).abs().max()) <= 2.0 ** -8 * float(exact.abs().max()) + 1e-6
+    assert float((d1.float() - d0.float()).abs().max()) <= 0.02 * float(d0.float().abs().max())
