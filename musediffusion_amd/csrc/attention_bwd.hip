@@ -21,7 +21,11 @@
 
 namespace {
 
-constexpr int SKB = 128;   // rows (keys or queries) per LDS stage
+#ifndef MH_BWD_SKB
+#define MH_BWD_SKB 128
+#endif
+constexpr int SKB = MH_BWD_SKB;   // rows (keys or queries) per LDS stage: 128 or 256 (build-time A/B: -DMH_BWD_SKB=256)
+static_assert(SKB == 128 || SKB == 256, "stage of 128 or 256 rows");
 
 __device__ __forceinline__ void glds16(const void* g, void* l) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
@@ -110,6 +114,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const bf16* __restrict
   constexpr int ST = SKB * DH * 2;                 // bytes of one operand stage
   constexpr int PK = ST / 1024 / NW;               // DMA pieces per wave per operand per stage
   constexpr int NSUB = SKB / 32;                   // 32-key sub-tiles per stage
+  constexpr int KWW = (SKB / 64) * 256, KWB = NW * KWW;   // keep words: bytes per wave and stage (one 256-byte row of words per 64-key tile), per buffer
   extern __shared__ __attribute__((aligned(16))) char smem_dyn[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -132,8 +137,8 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const bf16* __restrict
     for (int j = 0; j < PK; ++j) dma_rows<DH>(V + roff, lq_.ld, base + ST, wave + NW * j, lane, valid);
     if constexpr (DROP && FULL) {   // this wave's keep words of the stage's two 64-key tiles (2 x 64 words, contiguous): 512 B, lanes 0..31
       const int qbw = (item % nqb) * 8 + wave;
-      if (lane < 32)
-        glds16(keep_bits + drop_word_index(bh, (L + 31) >> 5, qbw, st * (SKB / 64), 0) + 4 * lane, smem_dyn + 2 * 2 * ST + (g & 1) * 4096 + wave * 512);
+      if (lane < KWW / 16)
+        glds16(keep_bits + drop_word_index(bh, (L + 31) >> 5, qbw, st * (SKB / 64), 0) + 4 * lane, smem_dyn + 2 * 2 * ST + (g & 1) * KWB + wave * KWW);
     }
   };
 
@@ -213,7 +218,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const bf16* __restrict
         __builtin_amdgcn_sched_barrier(0);
         if ((i & 1) == 0) {
           if constexpr (DROP && FULL) {   // ... staged in LDS with the operands (a global load here would wait for the next stage's DMA)
-            kw = *reinterpret_cast<const uint32_t*>(smem_dyn + 2 * 2 * ST + (g & 1) * 4096 + wave * 512 + (i >> 1) * 256 + lane * 4);
+            kw = *reinterpret_cast<const uint32_t*>(smem_dyn + 2 * 2 * ST + (g & 1) * KWB + wave * KWW + (i >> 1) * 256 + lane * 4);
           } else if constexpr (DROP) {   // dP = dP_drop o keep / (1 - p): this lane's word of the 64-key tile, as the forward stored it
             const int nb32 = (L + 31) >> 5;
             kw = keep_bits[drop_word_index(bh, nb32, q0 >> 5, (st * SKB + i * 32) >> 6, lane)];
@@ -270,7 +275,8 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const bf16* __restric
   constexpr int ST = SKB * DH * 2;
   constexpr int PK = ST / 1024 / NW;
   constexpr int NSUB = SKB / 32;                   // 32-query sub-tiles per stage
-  constexpr int BUF = 2 * ST + 1024 + (DROP && FULL ? 4096 : 0);   // Q rows, dO rows, (lse2 | D) of the stage's 128 queries, keep words
+  constexpr int LSTB = 2 * SKB * 4, KWQ = SKB / 32;                  // (lse2 | D) bytes per stage; 32-query blocks (1 KiB of keep words each) per stage
+  constexpr int BUF = 2 * ST + LSTB + (DROP && FULL ? KWQ * 1024 : 0);   // Q rows, dO rows, (lse2 | D) of the stage's queries, keep words
   extern __shared__ __attribute__((aligned(16))) char smem_dyn[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -293,15 +299,23 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const bf16* __restric
     for (int j = 0; j < PK; ++j) dma_rows<DH>(Q + lq_.at(bh, nh, (int64_t)st * SKB), lq_.ld, base, wave + NW * j, lane, valid);
 #pragma unroll
     for (int j = 0; j < PK; ++j) dma_rows<DH>(dO + lo_.at(bh, nh, (int64_t)st * SKB), lo_.ld, base + ST, wave + NW * j, lane, valid);
-    if (wave == 0) {   // lanes 0-31: lse2 of the 128 queries, lanes 32-63: D (groups of 4; past the end: the last valid group)
-      int qo = 4 * (lane & 31);
-      if (qo >= valid) qo = valid - 4;
-      glds16((lane < 32 ? lse2 : Dv) + r0 + qo, base + 2 * ST);
+    if constexpr (SKB == 128) {
+      if (wave == 0) {   // lanes 0-31: lse2 of the 128 queries, lanes 32-63: D (groups of 4; past the end: the last valid group)
+        int qo = 4 * (lane & 31);
+        if (qo >= valid) qo = valid - 4;
+        glds16((lane < 32 ? lse2 : Dv) + r0 + qo, base + 2 * ST);
+      }
+    } else {
+      if (wave < 2) {    // wave 0: lse2 of the 256 queries, wave 1: D
+        int qo = 4 * lane;
+        if (qo >= valid) qo = valid - 4;
+        glds16((wave == 0 ? lse2 : Dv) + r0 + qo, base + 2 * ST + wave * 1024);
+      }
     }
-    if constexpr (DROP && FULL) {   // keep words of (4 query blocks of the stage) x (the block's 4 pairs of key blocks): 1 KiB per query block
-      if (wave >= 4)
-        glds16(keep_bits + drop_word_index(bh, (L + 31) >> 5, st * (SKB / 32) + wave - 4, (item % nkb) * 4, 0) + 4 * lane,
-               base + 2 * ST + 1024 + (wave - 4) * 1024);
+    if constexpr (DROP && FULL) {   // keep words of (the stage's 32-query blocks) x (the block's 4 pairs of key blocks): 1 KiB per query block
+      if (wave >= NW - KWQ)
+        glds16(keep_bits + drop_word_index(bh, (L + 31) >> 5, st * KWQ + wave - (NW - KWQ), (item % nkb) * 4, 0) + 4 * lane,
+               base + 2 * ST + LSTB + (wave - (NW - KWQ)) * 1024);
     }
   };
 
@@ -332,7 +346,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const bf16* __restric
     }
     const char* qst = smem_dyn + (g & 1) * BUF;
     const char* ost = qst + ST;
-    const float* lst = reinterpret_cast<const float*>(qst + 2 * ST);   // [0..127] lse2, [128..255] D
+    const float* lst = reinterpret_cast<const float*>(qst + 2 * ST);   // [0..SKB) lse2, [SKB..2 SKB) D
     const int st_q = L - st * SKB;                                      // queries of this stage that exist
     if (active) {
       // (the bound-checking builds read a sub-tile's row fragments when they need them: the read-ahead does not fit their registers)
@@ -376,7 +390,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const bf16* __restric
           int qb = (st * SKB + 32 * i) >> 5; if (qb >= nb32) qb = nb32 - 1;
           const int kbk = k0 >> 5, hk = (lq >> 2) & 1;
           kshift = (lq & 3) + 4 * (lq >> 3) + 16 * (kbk & 1);
-          if constexpr (FULL) kwp = reinterpret_cast<const uint32_t*>(qst + 2 * ST + 1024) + i * 256 + ((wave >> 1) & 3) * 64 + 32 * hk + 4 * h;   // staged in LDS
+          if constexpr (FULL) kwp = reinterpret_cast<const uint32_t*>(qst + 2 * ST + LSTB) + i * 256 + ((wave >> 1) & 3) * 64 + 32 * hk + 4 * h;   // staged in LDS
           else kwp = keep_bits + drop_word_index(bh, nb32, qb, kbk >> 1, 32 * hk + 4 * h);
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -385,7 +399,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const bf16* __restric
         for (int rg = 0; rg < 4; ++rg) {
           const int qi = 32 * i + 8 * rg + 4 * h;
           const f32x4 ls = *reinterpret_cast<const f32x4*>(lst + qi);
-          const f32x4 dd = *reinterpret_cast<const f32x4*>(lst + 128 + qi);
+          const f32x4 dd = *reinterpret_cast<const f32x4*>(lst + SKB + qi);
           uint4 kwv = {0u, 0u, 0u, 0u};
           if constexpr (DROP) kwv = *reinterpret_cast<const uint4*>(kwp + 8 * rg);
 #pragma unroll
@@ -473,7 +487,7 @@ int launch_bwd(const bf16* q, const bf16* k, const bf16* v, const bf16* qT, cons
                const float* lse2, float* Dv, bf16* dq, bf16* dk, bf16* dv, int64_t ld, int B, int L, int nh, float scale,
                RowLayout lqkv, RowLayout ldo, const uint32_t* keep_bits, float rscale, hipStream_t s) {
   constexpr int ST = SKB * DH * 2;
-  constexpr int bytes_dq = 2 * 2 * ST + (DROP && FULL ? 2 * 4096 : 0), bytes_dkv = 2 * (2 * ST + 1024 + (DROP && FULL ? 4096 : 0));
+  constexpr int bytes_dq = 2 * 2 * ST + (DROP && FULL ? 2 * 8 * (SKB / 64) * 256 : 0), bytes_dkv = 2 * (2 * ST + 2 * SKB * 4 + (DROP && FULL ? (SKB / 32) * 1024 : 0));
   (void)qT; (void)kT; (void)dOT;   // (the transposed copies of the round-2 interface: no longer read)
   static bool attr_set = false;
   if (!attr_set) {
