@@ -636,12 +636,17 @@ __global__ __launch_bounds__(64 * NW) void attn_stream_bf16_kernel(const bf16* _
   int q0 = 0;
   bool active = false;
 
+  unsigned long long prof_acc[4] = {0, 0, 0, 0};
   if (total > 0) issue(0);
   for (int g = 0; g < total; ++g) {
     const int item = blockIdx.x + (g / nst) * gridDim.x, st = g % nst;
     const int bh = item / nqb, qb = item % nqb;
+    unsigned long long tp0 = 0, tp1 = 0, tp2 = 0;      // ABL bit 128: where a wave's time goes (clock stamps per stage, summed per wave)
+    if constexpr ((ABL & 128) != 0) tp0 = __builtin_amdgcn_s_memtime();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // stage g (issued one stage ago) has landed
+    if constexpr ((ABL & 128) != 0) tp1 = __builtin_amdgcn_s_memtime();
     __builtin_amdgcn_s_barrier();                      // ... for every wave; buffer (g+1)&1 was released at the end of stage g-1
+    if constexpr ((ABL & 128) != 0) tp2 = __builtin_amdgcn_s_memtime();
     if (g + 1 < total) issue(g + 1);
     if (st == 0) {
       q0 = qb * (32 * NW) + wave * 32;
@@ -894,6 +899,16 @@ __global__ __launch_bounds__(64 * NW) void attn_stream_bf16_kernel(const bf16* _
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if constexpr ((ABL & 128) != 0) {
+      const unsigned long long tp3 = __builtin_amdgcn_s_memtime();
+      __builtin_amdgcn_s_barrier();
+      const unsigned long long tp4 = __builtin_amdgcn_s_memtime();
+      prof_acc[0] += tp1 - tp0; prof_acc[1] += tp2 - tp1; prof_acc[2] += tp3 - tp2; prof_acc[3] += tp4 - tp3;
+      if (g == total - 1 && lane == 0) {   // per (block, wave): DMA wait, top barrier, stage work, bottom barrier (shader clocks)
+        unsigned long long* dstp = reinterpret_cast<unsigned long long*>(keep_bits) + ((size_t)blockIdx.x * NW + wave) * 4;
+        dstp[0] = prof_acc[0]; dstp[1] = prof_acc[1]; dstp[2] = prof_acc[2]; dstp[3] = prof_acc[3];
+      }
+    } else
     __builtin_amdgcn_s_barrier();                      // every wave is done reading buffer g & 1
   }
 }
@@ -1074,6 +1089,7 @@ int stream_fwd_impl(const void* q, const void* k, const void* vt_perm, void* ctx
       case 95: rc = go(&attn_stream_bf16_kernel<64, 16, 256, 0, true, true, false, 95>, 4 * 256 * 64 * 2); break;
       case 127: rc = go(&attn_stream_bf16_kernel<64, 16, 256, 0, true, true, false, 127>, 4 * 256 * 64 * 2); break;
       case 32: rc = go(&attn_stream_bf16_kernel<64, 16, 256, 0, true, true, false, 32>, 4 * 256 * 64 * 2); break;
+      case 128: rc = go(&attn_stream_bf16_kernel<64, 16, 256, 0, true, true, false, 128>, 4 * 256 * 64 * 2); break;   // phase profile into keep_bits (tools/attn_bench.py --prof)
       default: mh_set_error("attention_stream: ablation %d not built (1 2 4 6 7 8 16 24 31)", g_attn_abl); return MH_ERR_UNSUPPORTED;
     }
   }

@@ -8,12 +8,39 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--B", type=int, default=64); ap.add_argument("--L", type=int, default=512)
 ap.add_argument("--nh", type=int, default=8); ap.add_argument("--dh", type=int, default=64)
 ap.add_argument("--reps", type=int, default=20)
+ap.add_argument("--prof", action="store_true", help="only the in-kernel phase profile of the streaming forward (ablation 128)")
 a = ap.parse_args()
 dev, bf = "cuda", torch.bfloat16
 q = torch.randn(a.B, a.nh, a.L, a.dh, device=dev).to(bf)
 k = torch.randn(a.B, a.nh, a.L, a.dh, device=dev).to(bf)
 vt = torch.randn(a.B * a.nh * a.dh * a.L + 256, device=dev).to(bf)
 flops = 4.0 * a.B * a.nh * a.L * a.L * a.dh
+if a.prof:
+    # ablation 128: every wave sums, over its stages, the clocks it spends waiting for the stage's DMA, at the barrier behind it, in the
+    # stage's work and at the end-of-stage barrier, and leaves the four sums in the (otherwise unused) keep_bits buffer
+    ctx = torch.empty(a.B * a.L, a.nh * a.dh, device=dev, dtype=bf)
+    nblk = min(a.B * a.nh * ((a.L + 511) // 512), 256)
+    buf = torch.zeros(nblk * 16 * 4, device=dev, dtype=torch.int64)
+    sB, sH = a.nh * a.L * a.dh, a.L * a.dh
+    _lib.lib().mh_attention_set_ablation(128)
+    for rep in range(3):
+        buf.zero_()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _lib.check(_lib.lib().mh_attention_stream_fwd_drop(q.data_ptr(), k.data_ptr(), vt.data_ptr(), ctx.data_ptr(), a.nh * a.dh, 0, a.B, a.L, a.nh, a.dh,
+                                                           a.dh ** -0.5, None, sB, sH, a.dh, None, buf.data_ptr(), 0, _lib.current_stream()))
+        e1.record(); torch.cuda.synchronize()
+        t = buf.view(nblk, 16, 4).double().cpu()
+        tot = t.sum(-1)
+        print("launch %.1f us; per wave (shader clocks, mean over %d blocks): DMA wait %.0f  top barrier %.0f  stage work %.0f  end barrier %.0f  (sum %.0f)"
+              % (e0.elapsed_time(e1) * 1e3, nblk, *[float(t[:, :, i].mean()) for i in range(4)], float(tot.mean())))
+        print("  by wave index: work " + " ".join("%5.0f" % float(t[:, w, 2].mean()) for w in range(16)))
+        print("  by wave index: barriers " + " ".join("%5.0f" % float((t[:, w, 1] + t[:, w, 3]).mean()) for w in range(16)))
+        print("  blocks: work min %.0f max %.0f; barrier wait min %.0f max %.0f" % (float(t[:, :, 2].min()), float(t[:, :, 2].max()),
+              float((t[:, :, 1] + t[:, :, 3]).min()), float((t[:, :, 1] + t[:, :, 3]).max())))
+    _lib.lib().mh_attention_set_ablation(0)
+    raise SystemExit(0)
 for res in (0, 1, 2):
     _lib.lib().mh_attention_set_variant(res)
     ops.attention(q, k, vt, a.dh ** -0.5, 1)
