@@ -142,6 +142,9 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const bf16* __restrict
     }
   };
 
+#ifdef MH_BWD_PROF
+  unsigned long long prof_acc[4] = {0, 0, 0, 0};
+#endif
   bf16x8 qf[KS], dof[KS];
   f32x16 dq[DT];
   float lse_q = 0.f, D_q = 0.f;
@@ -151,8 +154,17 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const bf16* __restrict
   for (int g = 0; g < total; ++g) {
     const int item = blockIdx.x + (g / nst) * gridDim.x, st = g % nst;
     const int bh = item / nqb, qb = item % nqb;
+#ifdef MH_BWD_PROF
+    const unsigned long long tp0 = __builtin_amdgcn_s_memtime();
+#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef MH_BWD_PROF
+    const unsigned long long tp1 = __builtin_amdgcn_s_memtime();
+#endif
     __builtin_amdgcn_s_barrier();
+#ifdef MH_BWD_PROF
+    const unsigned long long tp2 = __builtin_amdgcn_s_memtime();
+#endif
     if (g + 1 < total) issue(g + 1);
     if (st == 0) {
       q0 = qb * 256 + wave * 32;
@@ -257,7 +269,20 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const bf16* __restrict
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#ifdef MH_BWD_PROF
+    {   // debug build (tools/debug/bwd_prof.py): per (block, wave) clocks spent waiting for the DMA, at the top barrier, in the stage, at the end barrier
+      const unsigned long long tp3 = __builtin_amdgcn_s_memtime();
+      __builtin_amdgcn_s_barrier();
+      const unsigned long long tp4 = __builtin_amdgcn_s_memtime();
+      prof_acc[0] += tp1 - tp0; prof_acc[1] += tp2 - tp1; prof_acc[2] += tp3 - tp2; prof_acc[3] += tp4 - tp3;
+      if (g == total - 1 && lane == 0 && keep_bits) {
+        unsigned long long* dstp = reinterpret_cast<unsigned long long*>(const_cast<uint32_t*>(keep_bits)) + ((size_t)blockIdx.x * NW + wave) * 4;
+        dstp[0] = prof_acc[0]; dstp[1] = prof_acc[1]; dstp[2] = prof_acc[2]; dstp[3] = prof_acc[3];
+      }
+    }
+#else
     __builtin_amdgcn_s_barrier();
+#endif
   }
 }
 
@@ -567,7 +592,7 @@ extern "C" int mh_attention_stream_bwd_drop(const void* q, const void* k, const 
   MH_CHECK_ARG(B > 0 && nh > 0 && mh_attention_stream_bwd_supported(L, dh),
                "attention_stream_bwd: needs seq_len %% 16 == 0, seq_len >= 512 and head dim 32 or 64 (got L=%d dh=%d)", L, dh);
   MH_CHECK_ARG(ld_d % 4 == 0, "attention_stream_bwd: ld_d must be a multiple of 4");
-  MH_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || keep_bits), "attention_stream_bwd: dropout needs keep_bits and p in [0, 1)");
+  MH_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || keep_bits), "attention_stream_bwd: dropout needs keep_bits and p in [0, 1)");   // (p == 0 with keep_bits: the MH_BWD_PROF debug build's output buffer)
   hipStream_t s = (hipStream_t)stream;
   const float rs = 1.0f / (1.0f - drop_p);
 #define MH_BWD_ARGS (const bf16*)q, (const bf16*)k, (const bf16*)v, (const bf16*)qT_perm, (const bf16*)kT_perm, (const bf16*)dO, \
