@@ -31,13 +31,14 @@ __global__ __launch_bounds__(THREADS) void k32(const bf16* __restrict__ src, bf1
   char* mine = lds + (wave & 3) * 24576;
   for (int i = tid; i < 4 * 24576 / 16; i += blockDim.x) reinterpret_cast<f32x4*>(lds)[i] = reinterpret_cast<const f32x4*>(src)[(i + blockIdx.x * 97) & 65535];
   __syncthreads();
-  f32x16 acc[4][2];
+  constexpr bool TWO = MODE == 3;      // a second accumulator set: the previous tile's epilogue rides in this tile's K-loop
+  f32x16 acc[4][2], prev[TWO ? 4 : 1][2];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.1f * i + 0.01f * r + 0.05f * lane;
+      for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.1f * i + 0.01f * r + 0.05f * lane; if (TWO) prev[TWO ? i : 0][j][r] = acc[i][j][r]; }
   float bv[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) bv[e] = bias[(lane * 8 + e) & 1023];
@@ -63,7 +64,7 @@ __global__ __launch_bounds__(THREADS) void k32(const bf16* __restrict__ src, bf1
       const int i = g >> 2, j = (g >> 1) & 1, h = g & 1;
       float v[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = gelu_fast(acc[i][j][8 * h + e] + bv[e]);
+      for (int e = 0; e < 8; ++e) v[e] = gelu_fast((TWO ? prev[TWO ? i : 0][j][8 * h + e] : acc[i][j][8 * h + e]) + bv[e]);
       bf16x8 r;
 #pragma unroll
       for (int e = 0; e < 8; ++e) r[e] = (bf16)v[e];
@@ -97,11 +98,31 @@ __global__ __launch_bounds__(THREADS) void k32(const bf16* __restrict__ src, bf1
         for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(acc[i][0]), "+v"(acc[i][1]));
       } else zero();
     }
+    if (MODE == 3) {
+#pragma unroll
+      for (int kt = 0; kt < 16; ++kt) {
+        kstep(kt);
+        egroup(kt);
+        // one epilogue group (~90 vector instructions, 16 of them transcendental) spread over the K-step's 16 MFMAs: the 24 issue cycles
+        // a 32x32x16 leaves free take 5 - 6 of them
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
+          __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);   // 6 VALU
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { prev[TWO ? i : 0][j] = acc[i][j]; }
+      zero();
+    }
   }
   const unsigned long long t1 = __builtin_amdgcn_s_memtime();
   float s = 0.f;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) s += acc[i][0][0] + acc[i][1][3];
+  for (int i = 0; i < 4; ++i) s += acc[i][0][0] + acc[i][1][3] + (TWO ? prev[TWO ? i : 0][0][5] : 0.f);
   if (s == 12345.678f) dst[0] = (bf16)s;
   if (tid == 0) cyc[blockIdx.x] = (t1 - t0) / tiles;
 }
@@ -362,6 +383,7 @@ int main() {
   run32<0, T>("K-steps only (16 MFMA 32x32x16)", src, dst, bias, cyc); \
   run32<1, T>("epilogue groups only", src, dst, bias, cyc); \
   run32<2, T>("16 K-steps then 16 groups", src, dst, bias, cyc); \
+  run32<3, T>("a group interleaved into every K-step", src, dst, bias, cyc); \
   run32<4, T>("waves 4-7 half a tile out of phase", src, dst, bias, cyc);
   ALL32(256)
   ALL32(512)
