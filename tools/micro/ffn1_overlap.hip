@@ -31,7 +31,7 @@ __global__ __launch_bounds__(THREADS) void k32(const bf16* __restrict__ src, bf1
   char* mine = lds + (wave & 3) * 24576;
   for (int i = tid; i < 4 * 24576 / 16; i += blockDim.x) reinterpret_cast<f32x4*>(lds)[i] = reinterpret_cast<const f32x4*>(src)[(i + blockIdx.x * 97) & 65535];
   __syncthreads();
-  constexpr bool TWO = MODE == 3;      // a second accumulator set: the previous tile's epilogue rides in this tile's K-loop
+  constexpr bool TWO = MODE == 3 || MODE == 5;      // a second accumulator set: the previous tile's epilogue rides in this tile's K-loop (5: without its stores)
   f32x16 acc[4][2], prev[TWO ? 4 : 1][2];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -70,7 +70,8 @@ __global__ __launch_bounds__(THREADS) void k32(const bf16* __restrict__ src, bf1
       for (int e = 0; e < 8; ++e) r[e] = (bf16)v[e];
       f32x4 raw;
       __builtin_memcpy(&raw, &r, 16);
-      __builtin_nontemporal_store(raw, reinterpret_cast<f32x4*>(gdst + ((size_t)g + 16 * (size_t)(t & 3)) * 8 * 131072));
+      if (MODE == 5) { asm volatile("" :: "v"(raw)); if (raw[0] == 12345.678f) __builtin_nontemporal_store(raw, reinterpret_cast<f32x4*>(gdst)); }
+      else __builtin_nontemporal_store(raw, reinterpret_cast<f32x4*>(gdst + ((size_t)g + 16 * (size_t)(t & 3)) * 8 * 131072));
     };
     auto zero = [&]() {
 #pragma unroll
@@ -98,7 +99,7 @@ __global__ __launch_bounds__(THREADS) void k32(const bf16* __restrict__ src, bf1
         for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(acc[i][0]), "+v"(acc[i][1]));
       } else zero();
     }
-    if (MODE == 3) {
+    if (MODE == 3 || MODE == 5) {
 #pragma unroll
       for (int kt = 0; kt < 16; ++kt) {
         kstep(kt);
@@ -384,6 +385,7 @@ int main() {
   run32<1, T>("epilogue groups only", src, dst, bias, cyc); \
   run32<2, T>("16 K-steps then 16 groups", src, dst, bias, cyc); \
   run32<3, T>("a group interleaved into every K-step", src, dst, bias, cyc); \
+  run32<5, T>("... the same without the stores", src, dst, bias, cyc); \
   run32<4, T>("waves 4-7 half a tile out of phase", src, dst, bias, cyc);
   ALL32(256)
   ALL32(512)
