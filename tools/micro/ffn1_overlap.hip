@@ -335,6 +335,88 @@ void run32(const char* name, const bf16* src, bf16* dst, const float* bias, unsi
 }
 
 
+
+// The structure DESIGN section 5 names as the next step, compiler-scheduled as far as hipcc can be led: one wave per SIMD, 128x64 wave
+// tile on mfma_32x32x16, the finished tile COPIED to a second register set, every K-step's fragments read one K-step ahead (no read is
+// waited for right before its MFMA), and one epilogue group of the previous tile behind the K-step's 16 MFMAs.
+template <int THREADS, bool STORES>
+__global__ __launch_bounds__(THREADS) void kpipe(const bf16* __restrict__ src, bf16* __restrict__ dst, const float* __restrict__ bias, int tiles) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  char* mine = lds + (wave & 3) * 24576;
+  for (int i = tid; i < 4 * 24576 / 16; i += blockDim.x) reinterpret_cast<f32x4*>(lds)[i] = reinterpret_cast<const f32x4*>(src)[(i + blockIdx.x * 97) & 65535];
+  __syncthreads();
+  f32x16 acc[4][2], prev[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; prev[i][j][r] = 0.1f * i + 0.01f * r + 0.05f * lane; }
+  float bv[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) bv[e] = bias[(lane * 8 + e) & 1023];
+  bf16* gdst = dst + ((size_t)blockIdx.x * blockDim.x + tid) * 8;
+  bf16x8 fa[2][2][4], fb[2][2][2];     // [buffer][k half][tile]
+  auto load = [&](int buf, int kt) {
+    const char* st = mine + (kt % 3) * 8192;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) fb[buf][kk][j] = *reinterpret_cast<const bf16x8*>(st + ((kk * 2048 + j * 1024 + lane * 16) & 8191));
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fa[buf][kk][i] = *reinterpret_cast<const bf16x8*>(st + ((4096 + kk * 2048 + i * 512 + lane * 16) & 8191));
+    }
+  };
+  load(0, 0);
+  for (int t = 0; t < tiles; ++t) {
+#pragma unroll
+    for (int kt = 0; kt < 16; ++kt) {
+      const int cur = kt & 1;
+      load(cur ^ 1, kt + 1);                       // next K-step's fragments (the last one reads ahead into the next tile's first stage)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[cur][kk][j], fa[cur][kk][i], acc[i][j], 0, 0, 0);
+      {   // epilogue group kt of the previous tile
+        const int i = kt >> 2, j = (kt >> 1) & 1, h = kt & 1;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = gelu_fast(prev[i][j][8 * h + e] + bv[e]);
+        bf16x8 r;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) r[e] = (bf16)v[e];
+        f32x4 raw;
+        __builtin_memcpy(&raw, &r, 16);
+        if (STORES) __builtin_nontemporal_store(raw, reinterpret_cast<f32x4*>(gdst + ((size_t)kt + 16 * (size_t)(t & 3)) * 8 * 131072));
+        else { asm volatile("" :: "v"(raw)); }
+      }
+#pragma unroll
+      for (int m = 0; m < 16; ++m) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read (12 per K-step)
+        __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);   // 6 VALU
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // the finished tile moves to the second register set (128 register moves: 0.25 us), the accumulators restart
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { prev[i][j][r] = acc[i][j][r]; acc[i][j][r] = 0.f; }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(prev[i][0]), "+v"(prev[i][1]));     // (in vector registers, not accumulation registers)
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) s += acc[i][0][0] + acc[i][1][3] + prev[i][0][5] + prev[i][1][7];
+  if (s == 12345.678f) dst[0] = (bf16)s;
+}
+
 // Power / clock test: the same kernel on a fraction of the chip.  If a wave's time per tile falls and its clock (shader cycles per
 // microsecond) rises when fewer CUs are busy, the full-chip rate is set by the power budget, not by a pipe.
 template <int MODE, int THREADS>
@@ -401,6 +483,23 @@ int main() {
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     printf("128x128 wave tile, K-steps only, 1 wave/SIMD: %7.3f us per (double-size) tile = %7.3f us per 512 MFMAs per SIMD\n", ms * 1e3 / tiles, ms * 1e3 / tiles / 2);
+  }
+  {
+    const int tiles = 200;
+    auto k1 = kpipe<256, true>; auto k0 = kpipe<256, false>;
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k1), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 24576);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k0), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 24576);
+    for (int st = 1; st >= 0; --st) {
+      if (st) k1<<<256, 256, 4 * 24576>>>(src, dst, bias, tiles); else k0<<<256, 256, 4 * 24576>>>(src, dst, bias, tiles);
+      hipDeviceSynchronize();
+      hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+      hipEventRecord(e0);
+      if (st) k1<<<256, 256, 4 * 24576>>>(src, dst, bias, tiles); else k0<<<256, 256, 4 * 24576>>>(src, dst, bias, tiles);
+      hipEventRecord(e1); hipEventSynchronize(e1);
+      float ms; hipEventElapsedTime(&ms, e0, e1);
+      printf("32x32x16 pipelined (fragments one K-step ahead, previous tile's group behind every K-step%s), 1 wave/SIMD: %7.3f us per tile per SIMD\n",
+             st ? "" : ", no stores", ms * 1e3 / tiles);
+    }
   }
   run_grid<0, 512>("K-steps only", src, dst, bias, cyc);
   run_grid<5, 512>("K-steps, no LDS reads", src, dst, bias, cyc);
