@@ -122,3 +122,82 @@ def test_gelu_derivative_stored_by_the_forward():
     exact = (dy.float() @ W2T.float().T) * dact.float()
     assert float((d1.float() - exact).abs().max()) <= 2.0 ** -8 * float(exact.abs().max()) + 1e-6
     assert float((d1.float() - d0.float()).abs().max()) <= 0.02 * float(d0.float().abs().max())
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# The keep-flag DEFINITION, restated on the host (numpy): Philox4x32-7 + the byte / tie-break rule + the lane-native word layout of
+# csrc/common.h (drop_keep_attn, drop_word_index) and the dense sites' 16-bit rule (drop_keep8).  Pins the masks themselves, so that a
+# re-expression of the decision code (round 3: one 16-bit compare per element instead of three byte compares) can be checked without an
+# old build of the library.
+
+def _philox7(c, k0, k1):
+    import numpy as np
+    c = [x.astype(np.uint64) for x in c]
+    k0, k1 = np.uint64(k0), np.uint64(k1)
+    M0, M1, W0, W1, MASK = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57), np.uint64(0x9E3779B9), np.uint64(0xBB67AE85), np.uint64(0xFFFFFFFF)
+    for _ in range(7):
+        p0, p1 = M0 * c[0], M1 * c[2]
+        n0 = (p1 >> np.uint64(32)) ^ c[1] ^ k0
+        n2 = (p0 >> np.uint64(32)) ^ c[3] ^ k1
+        c = [n0 & MASK, p1 & MASK, n2 & MASK, p0 & MASK]
+        k0, k1 = (k0 + W0) & MASK, (k1 + W1) & MASK
+    return c
+
+
+@pytest.mark.parametrize("BH,L,p", [(3, 96, 0.1), (2, 528, 0.37), (1, 64, 0.0039)])
+def test_attention_keep_bits_follow_the_documented_rule(BH, L, p):
+    import numpy as np
+    seed, offset = 0x1234567887654321, (7 << 16) | 3
+    d = _lib.Dropout()
+    d.p, d.seed, d.offset, d.mask = p, seed, offset, None
+    n = int(lib().mh_dropout_bits_words(BH, L))
+    bits = torch.zeros(n, dtype=torch.int32, device=DEV)
+    check(lib().mh_dropout_bits(bits.data_ptr(), BH, L, C.byref(d), current_stream()))
+    got = bits.cpu().numpy().view(np.uint32)
+    nb = (L + 31) // 32
+    nkp = (nb + 1) // 2
+    p256 = np.float32(p) * np.float32(256.0)
+    thr8 = int(p256)
+    thr16 = thr8 * 256 + int((p256 - np.float32(thr8)) * np.float32(256.0) + np.float32(0.5))
+    lane = np.arange(64)
+    lq, h = lane & 31, lane >> 5
+    for bh in range(BH):
+        for qb in range(nb):
+            q = np.minimum(qb * 32 + lq, L - 1)
+            for kp in range(nkp):
+                word = np.zeros(64, dtype=np.uint64)
+                for half in range(2):
+                    kb = 2 * kp + half
+                    if kb >= nb:
+                        continue
+                    idx = ((((np.uint64(bh) * np.uint64(L) + q.astype(np.uint64)) * np.uint64(nb) + np.uint64(kb)) << np.uint64(1)) | h.astype(np.uint64))
+                    c = _philox7([idx & np.uint64(0xFFFFFFFF), idx >> np.uint64(32), np.full(64, offset & 0xFFFFFFFF, np.uint64),
+                                  np.full(64, offset >> 32, np.uint64)], seed & 0xFFFFFFFF, seed >> 32)
+                    byte = lambda r: (c[r >> 2] >> np.uint64(8 * (r & 3))) & np.uint64(0xFF)   # noqa: E731
+                    for r in range(16):
+                        keep = (byte(r) * np.uint64(256) + byte((r + 1) & 15)) >= np.uint64(thr16)
+                        word |= keep.astype(np.uint64) << np.uint64(r + 16 * half)
+                base = (((bh * nb + qb) * nkp + kp) << 6)
+                assert np.array_equal(got[base:base + 64], word.astype(np.uint32)), (bh, qb, kp)
+
+
+def test_dense_site_keep_flags_follow_the_documented_rule():
+    import numpy as np
+    rows, cols, p = 37, 128, 0.1
+    seed, offset = 0xABCDEF0123456789, (5 << 16) | 2
+    d = _lib.Dropout()
+    d.p, d.seed, d.offset, d.mask = p, seed, offset, None
+    x = torch.ones(rows, cols, device=DEV)
+    out = torch.empty_like(x)
+    check(lib().mh_dropout_fwd(x.data_ptr(), cols, out.data_ptr(), cols, rows, cols, 0, C.byref(d), current_stream()))     # dtype 0 = fp32
+    got = (out.cpu().numpy() != 0).reshape(-1)
+    assert np.allclose(out.cpu().numpy()[out.cpu().numpy() != 0], 1.0 / (1.0 - p), rtol=1e-6)
+    thr = int(np.float32(p) * np.float32(65536.0) + np.float32(0.5))
+    g = np.arange(rows * cols // 8, dtype=np.uint64)
+    c = _philox7([g & np.uint64(0xFFFFFFFF), g >> np.uint64(32), np.full(g.shape, offset & 0xFFFFFFFF, np.uint64), np.full(g.shape, offset >> 32, np.uint64)],
+                 seed & 0xFFFFFFFF, seed >> 32)
+    keep = np.zeros((g.size, 8), dtype=bool)
+    for w in range(4):
+        keep[:, 2 * w] = (c[w] & np.uint64(0xFFFF)) >= np.uint64(thr)
+        keep[:, 2 * w + 1] = (c[w] >> np.uint64(16)) >= np.uint64(thr)
+    assert np.array_equal(got, keep.reshape(-1))
