@@ -81,17 +81,19 @@ __global__ __launch_bounds__(THREADS) void k32(const bf16* __restrict__ src, bf1
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     };
-    if (MODE == 4 && wave >= 4) {
+    if ((MODE == 4 || MODE == 7) && wave >= 4) {
 #pragma unroll
       for (int g = 0; g < 16; ++g) egroup(g);
       zero();
       __builtin_amdgcn_sched_barrier(0);
     }
-    if (MODE == 0 || MODE == 2 || MODE == 4) {
+    if (MODE == 7) __builtin_amdgcn_s_setprio(2);      // the matrix phase outranks the partner's vector phase: its MFMAs issue on time, the partner fills the gaps
+    if (MODE == 0 || MODE == 2 || MODE == 4 || MODE == 7) {
 #pragma unroll
       for (int kt = 0; kt < 16; ++kt) { kstep(kt); __builtin_amdgcn_sched_barrier(0); }
     }
-    if (MODE == 1 || MODE == 2 || (MODE == 4 && wave < 4)) {
+    if (MODE == 7) __builtin_amdgcn_s_setprio(0);
+    if (MODE == 1 || MODE == 2 || ((MODE == 4 || MODE == 7) && wave < 4)) {
 #pragma unroll
       for (int g = 0; g < 16; ++g) egroup(g);
       if (MODE == 1) {
@@ -468,7 +470,8 @@ int main() {
   run32<2, T>("16 K-steps then 16 groups", src, dst, bias, cyc); \
   run32<3, T>("a group interleaved into every K-step", src, dst, bias, cyc); \
   run32<5, T>("... the same without the stores", src, dst, bias, cyc); \
-  run32<4, T>("waves 4-7 half a tile out of phase", src, dst, bias, cyc);
+  run32<4, T>("waves 4-7 half a tile out of phase", src, dst, bias, cyc); \
+  run32<7, T>("... with the matrix phase at s_setprio 2", src, dst, bias, cyc);
   ALL32(256)
   ALL32(512)
   {
