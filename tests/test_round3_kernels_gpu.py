@@ -201,3 +201,37 @@ def test_dense_site_keep_flags_follow_the_documented_rule():
         keep[:, 2 * w] = (c[w] & np.uint64(0xFFFF)) >= np.uint64(thr)
         keep[:, 2 * w + 1] = (c[w] >> np.uint64(16)) >= np.uint64(thr)
     assert np.array_equal(got, keep.reshape(-1))
+
+
+def test_training_epilogues_on_the_wide_tile_match_the_narrow_tile():
+    """The tape's full-batch launches take the 256 x 256 tile (auto rule: row-major operands, every CU gets a tile); its epilogue
+    variants - stored GELU derivative, multiply-by-derivative, dropout + residual - must give what the 256 x 128 tile gives, bit for bit
+    (same K order per output element, same Philox element numbering)."""
+    M, H, F = 32768, 512, 2048
+    st = current_stream()
+    x = rnd(M, H, seed=920, scale=0.7).to(DEV).bfloat16()
+    W1 = (rnd(F, H, seed=921) / math.sqrt(H) * 2.0).to(DEV).bfloat16()
+    b1 = rnd(F, seed=922, scale=0.3).to(DEV)
+    dy = rnd(M, H, seed=923, scale=0.1).to(DEV).bfloat16()
+    W2T = (rnd(F, H, seed=924) / math.sqrt(F)).to(DEV).bfloat16()
+    W2 = (rnd(H, F, seed=925) / math.sqrt(F)).to(DEV).bfloat16()
+    b2 = rnd(H, seed=926, scale=0.1).to(DEV)
+    d = _lib.Dropout()
+    d.p, d.seed, d.offset, d.mask = 0.1, 0x5555AAAA1234, (9 << 16) | 4, None
+    res = {}
+    try:
+        for auto in (0, 1):
+            check(lib().mh_gemm_set_auto_wide(auto))
+            dact, f = torch.empty(M, F, device=DEV, dtype=torch.bfloat16), torch.empty(M, F, device=DEV, dtype=torch.bfloat16)
+            check(lib().mh_gemm_bias_act_dact(x.data_ptr(), H, W1.data_ptr(), H, b1.data_ptr(), dact.data_ptr(), f.data_ptr(), F, M, F, H, MH_ACT_GELU, st))
+            dpre = torch.empty_like(f)
+            check(lib().mh_gemm_act_grad(dy.data_ptr(), H, W2T.data_ptr(), H, dact.data_ptr(), F, dpre.data_ptr(), F, M, F, H, MH_ACT_DERIV, st))
+            y = torch.empty(M, H, device=DEV, dtype=torch.bfloat16)
+            check(lib().mh_gemm_bias_dropout_res(f.data_ptr(), F, W2.data_ptr(), F, b2.data_ptr(), x.data_ptr(), H, y.data_ptr(), H, M, H, F, MH_BF16, C.byref(d), st))
+            res[auto] = (dact, f, dpre, y)
+    finally:
+        lib().mh_gemm_set_auto_wide(1)
+    for name, u, v in zip(("gelu'(pre)", "gelu(pre)", "(dY W2) o gelu'", "dropout(f W2 + b) + x"), res[0], res[1]):
+        assert torch.equal(u, v), name
+    kept = float(((res[1][3].float() - x.float()).abs() > 0).float().mean())
+    assert 0.88 < kept < 0.92
