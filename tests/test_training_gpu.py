@@ -485,3 +485,42 @@ def test_bf16_fused_training_at_seq_len_1024_against_oracle():
         worst = min(worst, (cos, n))
     print("worst weight-gradient cosine vs the fp32 oracle: %.5f (%s)" % worst)
     assert worst[0] > 0.99, worst
+
+
+def test_full_size_training_step_is_invariant_to_the_tile_choice():
+    """The benchmarked training shape (BASELINE config 5 per GPU: 32 sequences x seq_len 1024, d_model 512, 12 layers, bf16, dropout 0.1)
+    is the only place where the tape's GEMMs take the 256 x 256 tile and the weight-gradient GEMM its 8-wave variant.  Every such form is
+    bit-identical with the 256 x 128 form per kernel (tests/test_round3_kernels_gpu.py), so the WHOLE step must be: the same losses and
+    the same gradient of every parameter, bit for bit, with the round-3 tile rules on and off (same timesteps, same noise, same Philox
+    dropout counters).  Also pins the full-size step's determinism."""
+    from musediffusion_amd import _lib, synthetic
+    torch.manual_seed(12)
+    B, L, E, H, nL = 32, 1024, 128, 512, 12
+    m = TransformerNetModel(E, E, 128, synthetic.VOCAB_SIZE, L, dropout=0.1, bert_hidden=H, bert_layers=nL, bert_heads=8, bert_ffn=2048,
+                            compute_dtype="bf16")
+    m.train().requires_grad_(True).to(DEV)
+    diff = SpacedDiffusion(use_timesteps=space_timesteps(2000, [2000]), betas=get_named_beta_schedule("sqrt", 2000),
+                           rescale_timesteps=True, predict_xstart=True)
+    batch = {k: v.to(DEV) for k, v in synthetic.training_batch(B, L, seed=5).items()}
+    t = torch.arange(B, device=DEV) * 61 % 2000
+    L_ = _lib.lib()
+    res = []
+    try:
+        for wide in (1, 0, 1):
+            L_.mh_gemm_set_auto_wide(wide)
+            L_.mh_gemm_dw_set_wide(wide)
+            m._dropout_calls = 0                       # the same Philox counters in every run
+            m.zero_grad(set_to_none=True)
+            with CpuDraws(21):
+                terms = diff.training_losses(m, t, model_kwargs=batch)
+            terms["loss"].mean().backward()
+            res.append((terms["loss"].detach().clone(), {n: q.grad.detach().clone() for n, q in m.named_parameters() if q.grad is not None}))
+    finally:
+        L_.mh_gemm_set_auto_wide(1)
+        L_.mh_gemm_dw_set_wide(1)
+    assert bool(torch.isfinite(res[0][0]).all()) and float(res[0][0].mean()) > 0
+    for other in (1, 2):
+        assert torch.equal(res[0][0], res[other][0]), "losses differ (run %d)" % other
+        assert res[0][1].keys() == res[other][1].keys()
+        for name in res[0][1]:
+            assert torch.equal(res[0][1][name], res[other][1][name]), (name, other)
