@@ -156,6 +156,65 @@ __global__ void step_epilogue_kernel(const float* __restrict__ model_out, const 
   }
 }
 
+// The same arithmetic on 4 consecutive elements per thread (16-byte loads / stores, 32-bit index math, one coefficient / index / mask
+// lookup per group): E % 4 == 0 and 16-byte aligned tensors - the shapes of the sampling loops.  The per-element statements are the
+// scalar kernel's, so the results are bit-identical.
+template <bool DDIM>
+__global__ __launch_bounds__(256) void step_epilogue4_kernel(const float* __restrict__ model_out, const float* __restrict__ x_t,
+                                                             const float* __restrict__ noise, const int32_t* __restrict__ round_idx,
+                                                             const float* __restrict__ table, const mh_step_coef* __restrict__ coef,
+                                                             int coef_per_batch, int clip, const int32_t* __restrict__ mask, int mask_per_elem,
+                                                             const float* __restrict__ x_start, float* __restrict__ out,
+                                                             float* __restrict__ pred_xstart, float* __restrict__ mean_out, int64_t ngroups,
+                                                             uint32_t groups_per_batch, uint32_t groups_per_row, int E) {
+  for (int64_t gi = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; gi < ngroups; gi += (int64_t)gridDim.x * blockDim.x) {
+    const uint32_t g = (uint32_t)gi;                      // (ngroups < 2^32: checked by the launcher)
+    const uint32_t b = g / groups_per_batch, row = g / groups_per_row, cg = g - row * groups_per_row;
+    const mh_step_coef c = coef[coef_per_batch ? b : 0];
+    const int64_t i = (int64_t)g * 4;
+    f32x4 x0;
+    if (round_idx) x0 = *reinterpret_cast<const f32x4*>(table + (int64_t)round_idx[row] * E + cg * 4);
+    else x0 = *reinterpret_cast<const f32x4*>(model_out + i);
+    const f32x4 xt = *reinterpret_cast<const f32x4*>(x_t + i);
+    f32x4 nz = {0.f, 0.f, 0.f, 0.f};
+    if (noise) nz = *reinterpret_cast<const f32x4*>(noise + i);
+    f32x4 mean, sample;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float v = x0[e];
+      if (clip) v = fminf(fmaxf(v, -1.0f), 1.0f);
+      x0[e] = v;
+      if constexpr (DDIM) {
+        const float eps = (c.recip * xt[e] - v) / c.recipm1;
+        mean[e] = v * c.sqrt_abp + c.dir * eps;
+        sample[e] = mean[e] + c.sigma * nz[e];
+      } else {
+        mean[e] = c.coef1 * v + c.coef2 * xt[e];
+        sample[e] = mean[e] + c.sigma * nz[e];
+      }
+    }
+    if (mask) {
+      if (mask_per_elem) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) if (mask[i + e] == 0) sample[e] = x_start[i + e];
+      } else if (mask[row] == 0) sample = *reinterpret_cast<const f32x4*>(x_start + i);
+    }
+    if (pred_xstart) *reinterpret_cast<f32x4*>(pred_xstart + i) = x0;
+    if (mean_out) *reinterpret_cast<f32x4*>(mean_out + i) = mean;
+    *reinterpret_cast<f32x4*>(out + i) = sample;
+  }
+}
+
+namespace {
+// the 4-wide kernel's preconditions: whole groups per row, 16-byte aligned tensors, 32-bit group numbers
+inline bool step_epilogue_vec_ok(const float* model_out, const float* x_t, const float* noise, const float* table, const float* x_start,
+                                 const float* out, const float* pred, const float* mean, int B, int64_t per_batch, int E) {
+  auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  return E % 4 == 0 && per_batch % E == 0 && (int64_t)B * per_batch / 4 < (1ll << 32) && al(model_out) && al(x_t) && al(noise) && al(table) &&
+         al(x_start) && al(out) && al(pred) && al(mean);
+}
+}  // namespace
+
 // ---------------------------------------------------------------- Philox4x32-10 truncated normal
 __device__ __forceinline__ float u01(uint32_t r) { return ((float)(r >> 8) + 0.5f) * (1.0f / 16777216.0f); }
 
@@ -312,6 +371,11 @@ extern "C" int mh_p_sample_epilogue(const float* model_out, const float* x_t, co
   MH_CHECK_ARG(!round_idx || table, "p_sample_epilogue: round_idx needs the embedding table");
   MH_CHECK_ARG(!mask || x_start, "p_sample_epilogue: mask needs x_start");
   MH_CHECK_ARG(B > 0 && per_batch > 0 && E > 0 && per_batch % E == 0, "p_sample_epilogue: bad shape");
+  if (step_epilogue_vec_ok(model_out, x_t, noise, table, x_start, out, pred_xstart, mean_out, B, per_batch, E)) {
+    const int64_t ng = (int64_t)B * per_batch / 4;
+    MH_LAUNCH((step_epilogue4_kernel<false>), dim3(ew_grid(ng)), dim3(EW_BLOCK), 0, (hipStream_t)stream, model_out, x_t, noise, round_idx, table, coef,
+              coef_per_batch, clip, mask, mask_per_elem, x_start, out, pred_xstart, mean_out, ng, (uint32_t)(per_batch / 4), (uint32_t)(E / 4), E);
+  } else
   MH_LAUNCH((step_epilogue_kernel<false>), dim3(ew_grid((int64_t)B * per_batch)), dim3(EW_BLOCK), 0,
                      (hipStream_t)stream, model_out, x_t, noise, round_idx, table, coef, coef_per_batch, clip, mask,
                      mask_per_elem, x_start, out, pred_xstart, mean_out, B, per_batch, E);
@@ -328,6 +392,11 @@ extern "C" int mh_ddim_epilogue(const float* model_out, const float* x_t, const 
   MH_CHECK_ARG(!round_idx || table, "ddim_epilogue: round_idx needs the embedding table");
   MH_CHECK_ARG(!mask || x_start, "ddim_epilogue: mask needs x_start");
   MH_CHECK_ARG(B > 0 && per_batch > 0 && E > 0 && per_batch % E == 0, "ddim_epilogue: bad shape");
+  if (step_epilogue_vec_ok(model_out, x_t, noise, table, x_start, out, pred_xstart, nullptr, B, per_batch, E)) {
+    const int64_t ng = (int64_t)B * per_batch / 4;
+    MH_LAUNCH((step_epilogue4_kernel<true>), dim3(ew_grid(ng)), dim3(EW_BLOCK), 0, (hipStream_t)stream, model_out, x_t, noise, round_idx, table, coef,
+              coef_per_batch, clip, mask, mask_per_elem, x_start, out, pred_xstart, (float*)nullptr, ng, (uint32_t)(per_batch / 4), (uint32_t)(E / 4), E);
+  } else
   MH_LAUNCH((step_epilogue_kernel<true>), dim3(ew_grid((int64_t)B * per_batch)), dim3(EW_BLOCK), 0,
                      (hipStream_t)stream, model_out, x_t, noise, round_idx, table, coef, coef_per_batch, clip, mask,
                      mask_per_elem, x_start, out, pred_xstart, (float*)nullptr, B, per_batch, E);
