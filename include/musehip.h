@@ -165,20 +165,11 @@ int mh_attention_stream_bwd_supported(int L, int dh);   /* seq_len % 16 == 0, >=
 int mh_attention_bwd_rowdot(const void* dctx, const void* ctx, int64_t ld, float* D, int B, int L, int nh, int dh,
                             mh_stream_t stream);
 int mh_attention_stream_supported(int L, int dh);
-/* A/B switch read by mh_denoiser_forward's panel path: 1 (default) = streaming kernel, 16-wave blocks with 256-key stages;
- * 2 = 8-wave blocks with 128-key stages (half a CU per block, same bits; 3% slower inside the step); 0 = resident / tiled kernels;
- * 3 = the in-kernel dropout-mask generator on the 16-wave geometry (spills; A/B); 4 = always the bound-checking build (by default
- * seq_len % 256 == 0 selects builds without the per-score bound compares, forward and backward). */
-int mh_attention_set_stream(int on);
 int mh_attention_stream_enabled(void);
 /* mh_gemm_qkv_ex (bf16) writing V^T in the key order mh_attention_stream_fwd reads (seq_len % 16 == 0). */
 int mh_gemm_qkv_vtperm(const void* A, int64_t lda, int a_panel, const void* Wqkv, int64_t ldw, int w_panel,
                        const float* bqkv, void* q, void* k, void* vt_perm, int B, int L, int H, int nh,
                        mh_stream_t stream);
-int mh_attention_set_variant(int resident);
-/* Diagnostic: when non-NULL, the LDS-resident attention kernel writes 100 MHz timestamps per block into
- * stamps[block * 32 + {0: start, 1: K/V staged, 2 + w: wave w done}] (u64).  NULL (default) disables it. */
-int mh_attention_set_profile(void* stamps);
 
 /* K7/K8 tail  out = LayerNorm(x) * gamma + beta over the last dim (eps 1e-12 in the reference,
  *      network.py:79 and HF BertSelfOutput/BertOutput).  x, out [rows, H] `dtype`. */
@@ -343,7 +334,11 @@ int mh_weight_prep(const mh_wprep_item* items, int n_items, int total_tiles, mh_
 /* ------------------------------------------------------------------ optimizer step
  * Fused multi-tensor AdamW + up to 4 EMA copies (+ gradient L2 norm) over every parameter tensor in one
  * launch each: utils/train_util.py:246-280 (optimize, _log_grad_norm) and :21-31 (update_ema).
- * `tensors` / `chunks` are DEVICE tables built once by the host. */
+ * `tensors` / `chunks` are DEVICE tables built once by the host.  A tensor whose `grad` is NULL (a frozen parameter, e.g. the
+ * reference's --freeze_embedding, config/train.py:67-68, or one autograd never reached) is skipped by the AdamW arithmetic exactly
+ * as torch.optim.AdamW skips `p.grad is None` (train_util.py:95), adds nothing to the norm (:277) and is left alone by the clip,
+ * while its EMA copies still take update_ema's step (:21-31 walks every master parameter).  param / grad / moments / EMA
+ * pointers must be 16-byte aligned (the host checks). */
 typedef struct mh_opt_tensor {
   float* param; const float* grad; float* exp_avg; float* exp_avg_sq; float* ema[4];
 } mh_opt_tensor;
@@ -388,13 +383,6 @@ int mh_step_end(mh_loop_state* state, mh_stream_t stream);
 
 /* Thin hipGraph wrappers so the host can capture a sequence of the calls above on `stream` and
  * replay it (hipStreamBeginCapture / EndCapture / GraphInstantiate / GraphLaunch). */
-/* A/B switch between the bf16 GEMM kernels: 0 = 128x128 tile, register-staged; 1 = 128x128 tile,
- * global_load_lds; 2 (default) and 3 = 256x128 tile (4 waves, 3-stage global_load_lds ring, two blocks per CU);
- * 4 = 256x256 (8 waves, 4-stage ring) where N % 256 == 0; 5 = 256x256 with the ping-pong main loop. */
-int mh_gemm_set_variant(int variant);
-/* 1 (default): with the default variant, launches whose operands are all row-major (the training tape, direct callers) take the
- * 256 x 256 tile when N % 256 == 0 and it still gives every CU a block; K32-panel launches (the engine) never do.  0: round-2 rule. */
-int mh_gemm_set_auto_wide(int on);
 /* out = act(A W^T + bias) and pre_out = A W^T + bias in one pass (bf16 row-major; shapes the big-tile kernel
  * serves: N % 8 == 0, K % 32 == 0, lda / ldw / ldo % 8 == 0; error otherwise).  Forward of dense + GELU / tanh under
  * autograd: the backward needs the pre-activation (training_losses, models/diffusion.py:594-699). */
@@ -418,10 +406,6 @@ int mh_gemm_act_grad(const void* A, int64_t lda, const void* W, int64_t ldw, con
 int mh_gemm_dw(const void* A, int64_t lda, const void* B, int64_t ldb, float* out_partials, int splits, int64_t K, int M, int N,
                mh_stream_t stream);
 int mh_gemm_dw_splits(int64_t K, int M, int N);
-int mh_gemm_dw_set_blocks(int blocks);   /* A/B knob: blocks a launch aims for when choosing `splits` (default 512) */
-/* A/B: 0 = the weight-gradient GEMM always on the 256 x 128 tile (4 waves, two blocks per CU: round 2), 1 (default) = a 256 x 256 tile on
- * 8 waves where N % 256 == 0: half the blocks, half the fp32 partials to write and fold.  mh_gemm_dw_splits follows the setting. */
-int mh_gemm_dw_set_wide(int on);
 /* The same with the bias gradient of that linear as a by-product (with_colsum != 0): each split slice is M N + M floats - the
  * products, then sum_k A[k][m] over the slice's tokens, taken off the matrix pipe (an all-ones operand) by the blocks that already
  * hold the A panel - so dY is not read a second time for autograd's `grad_bias = dY.sum(0)`; one mh_sum_slices over M N + M folds both. */
@@ -436,19 +420,7 @@ int mh_gemm_bias_res_ln(const void* A, int64_t lda, int a_panel, const void* W, 
                         const float* beta, float eps, void* out, int64_t ldo, int o_panel, int64_t M, int N,
                         int K, mh_stream_t stream);
 int mh_gemm_bias_res_ln_supported(int N);
-/* A/B switch: mh_denoiser_forward's panel path uses mh_gemm_bias_res_ln for the two post-LN dense layers of an
- * encoder block when the hidden size allows it (default 1) or the separate GEMM + LayerNorm kernels (0). */
-int mh_denoiser_set_fuse_ln(int on);
 int mh_denoiser_get_fuse_ln(void);
-/* Timing-only ablation of the big-tile kernel (results are WRONG when non-zero): bit 0 skips the
- * DMA loads, bit 1 the MFMAs, bit 2 the epilogue stores, bit 3 the LDS fragment reads.  Used by tools/gemm_bench.py only. */
-int mh_gemm_set_debug(int bits);
-/* A/B mask of the big-tile GEMM epilogues / tiles.  Bit 0: QKV scatter with streaming (nt) q / k stores instead of ordinary ones
- * (default ordinary: attention reads them back at once; +0.9 % steps/s in round 2).  Bit 1: dense + GELU with ordinary instead of
- * streaming stores (default streaming: the output is large and read once; ordinary costs 3.8 % of the step).  The dense + residual +
- * LayerNorm epilogue always stores normally: its rows are re-read at once.  Bit 2: the full-row (LayerNorm) tile with the plain
- * instead of the ping-pong main loop (4 % slower step).  Bit 3 / 4: the 64-row full-row tile for K <= 512 / always (3 % / 7 % slower). */
-int mh_gemm_set_plain_stores(int mask);
 
 int mh_graph_begin_capture(mh_stream_t stream);
 int mh_graph_end_capture(mh_stream_t stream, void** graph_exec_out);
@@ -613,14 +585,6 @@ int mh_gemm_bias_act_defer(const void* A, int64_t lda, const void* W, int64_t ld
                            void* out, int64_t ldo, int64_t M, int N, int K, int act, const mh_ln_defer* defer, mh_stream_t stream);
 int mh_gemm_qkv_vtperm_defer(const void* A, int64_t lda, const void* Wqkv, int64_t ldw, const float* c2, void* q, void* k, void* vt_perm,
                              int B, int L, int H, int nh, const mh_ln_defer* defer, mh_stream_t stream);
-/* denoiser forward: 0 = never defer, 1 (default) = defer where the width has no full-row LayerNorm epilogue (d_model 768),
- * 2 = always (A/B) */
-int mh_denoiser_set_defer_ln(int mode);
-/* timing-only A/B knob (tools/ab_step.py skip): leave one kind of launch out of the bf16 panel forward (bit 0 QKV, 1 attention,
- * 2 attention-output dense + LN, 3 FFN1, 4 FFN2 + LN, 5 up-projection chain, 6 down-projection); outputs are then meaningless */
-int mh_denoiser_set_skip(int mask);
-/* panel LayerNorm kernels: 1 (default) = 4 rows per wave (four times the waves of the 16-row form), 0 = 16 rows per wave (A/B) */
-int mh_layernorm_set_rows4(int on);
 /* The forward in three phases over K32-panel activation buffers the caller owns (bf16 [H / 32][ld rows][32]; bf16 panel models with
  * up / down projections: mh_denoiser_phases_supported): head = latent -> up-projection -> + position / time -> LayerNorm
  * (network.py:141-149), layers = the encoder (network.py:151), tail = down-projection (network.py:153-157).  A batch slice passes a row
@@ -633,17 +597,12 @@ int mh_denoiser_layers(const mh_denoiser* m, const void* x_in, int64_t ld_in, vo
                        size_t workspace_bytes, mh_stream_t stream);
 int mh_denoiser_tail(const mh_denoiser* m, const void* x_in, int64_t ld_in, float* out, int B, int L, void* workspace, size_t workspace_bytes,
                      mh_stream_t stream);
-/* 1: the bf16 panel forward folds softmax scale x log2(e) into the stored queries and runs the pre-scaled attention (A/B; default 0) */
-int mh_denoiser_set_prescale_q(int on);
 /* mh_gemm_qkv_vtperm over K32-panel operands with the queries stored as (x Wq^T + bq) * q_scale (rounded once, from the fp32
  * accumulator); `defer` (may be NULL) as in mh_gemm_qkv_vtperm_defer.  HF BertSelfAttention's projections (network.py:151) */
 int mh_gemm_qkv_vtperm_qs(const void* A, int64_t lda, const void* Wqkv, int64_t ldw, const float* bqkv, void* q, void* k, void* vt_perm,
                           int B, int L, int H, int nh, float q_scale, const mh_ln_defer* defer, mh_stream_t stream);
 /* mh_attention_stream_fwd for queries that already carry softmax scale x log2(e) (q_scale above): the running softmax reference lives in
  * the initial value of the score accumulators, so a probability is exp2(accumulator) - no multiply-subtract per score */
-/* timing-only ablation of the streaming kernel at head dim 64, seq_len <= 512 (tools/attn_bench.py): 1 no softmax vector work, 2 no S^T
- * MFMAs, 4 no P.V MFMAs, 8 no LDS fragment reads, 16 no stage DMA (built: 1 2 4 6 7 8 16 24 31); 0 = the real kernel */
-int mh_attention_set_ablation(int bits);
 int mh_attention_stream_prescaled_supported(int L, int dh);   /* mh_attention_stream_supported and seq_len % 256 == 0 */
 int mh_attention_stream_fwd_prescaled(const void* q, const void* k, const void* vt_perm, void* ctx, int64_t ld_ctx, int ctx_panel,
                                       int B, int L, int nh, int dh, mh_stream_t stream);
@@ -653,10 +612,6 @@ int mh_denoiser_get_defer_ln(void);
  * Between mh_profile_start() and mh_profile_stop() every kernel this library launches is bracketed by two HIP events on its own
  * stream (not capturable: call outside hipGraph capture).  mh_profile_stop synchronises the device and writes one line per launch,
  * "kernel\tdetail\tgrid\tblock\tstream\tmilliseconds\n", into `out`; it returns the bytes the whole report needs. */
-/* experiment knob (A/B only): co-resident partner blocks of the big-tile GEMMs start `ticks` x 10 ns late */
-int mh_gemm_set_stagger(int ticks);
-/* experiment knob (A/B only): LDS-DMA pieces of the 256x128 kernels issued between the MFMA rows instead of as one burst */
-int mh_gemm_set_spread(int on);
 int mh_profile_start(void);
 int64_t mh_profile_stop(char* out, size_t cap);
 

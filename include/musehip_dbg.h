@@ -1,0 +1,82 @@
+/* libmusehip_dbg.so ONLY (built with -DMH_ABLATE by `make dbg`): process-global A/B switches, ablation knobs and diagnostics of the
+ * kernels.  None of these exists in the production library (libmusehip.so has no mutable global configuration: every default named
+ * below is a compile-time constant there, tests/test_host_cpu.py checks the export lists of both builds).  They serve
+ * tools/ (ab_step.py, ab_train.py, gemm_bench.py, attn_bench.py ...), `bench.py`'s A/B flags and the tests that compare an alternative
+ * kernel form with the default one; several of them make outputs meaningless by design (timing-only ablations). */
+#ifndef MUSEHIP_DBG_H
+#define MUSEHIP_DBG_H
+#include "musehip.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* A/B switch read by mh_denoiser_forward's panel path: 1 (default) = streaming kernel, 16-wave blocks with 256-key stages;
+ * 2 = 8-wave blocks with 128-key stages (half a CU per block, same bits; 3% slower inside the step); 0 = resident / tiled kernels;
+ * 3 = the in-kernel dropout-mask generator on the 16-wave geometry (spills; A/B); 4 = always the bound-checking build (by default
+ * seq_len % 256 == 0 selects builds without the per-score bound compares, forward and backward). */
+int mh_attention_set_stream(int on);
+
+int mh_attention_set_variant(int resident);
+
+/* Diagnostic: when non-NULL, the LDS-resident attention kernel writes 100 MHz timestamps per block into
+ * stamps[block * 32 + {0: start, 1: K/V staged, 2 + w: wave w done}] (u64).  NULL (default) disables it. */
+int mh_attention_set_profile(void* stamps);
+
+/* A/B switch between the bf16 GEMM kernels: 0 = 128x128 tile, register-staged; 1 = 128x128 tile,
+ * global_load_lds; 2 (default) and 3 = 256x128 tile (4 waves, 3-stage global_load_lds ring, two blocks per CU);
+ * 4 = 256x256 (8 waves, 4-stage ring) where N % 256 == 0; 5 = 256x256 with the ping-pong main loop. */
+int mh_gemm_set_variant(int variant);
+
+/* 1 (default): with the default variant, launches whose operands are all row-major (the training tape, direct callers) take the
+ * 256 x 256 tile when N % 256 == 0 and it still gives every CU a block; K32-panel launches (the engine) never do.  0: round-2 rule. */
+int mh_gemm_set_auto_wide(int on);
+
+int mh_gemm_dw_set_blocks(int blocks);   /* A/B knob: blocks a launch aims for when choosing `splits` (default 512) */
+
+/* A/B: 0 = the weight-gradient GEMM always on the 256 x 128 tile (4 waves, two blocks per CU: round 2), 1 (default) = a 256 x 256 tile on
+ * 8 waves where N % 256 == 0: half the blocks, half the fp32 partials to write and fold.  mh_gemm_dw_splits follows the setting. */
+int mh_gemm_dw_set_wide(int on);
+
+/* A/B switch: mh_denoiser_forward's panel path uses mh_gemm_bias_res_ln for the two post-LN dense layers of an
+ * encoder block when the hidden size allows it (default 1) or the separate GEMM + LayerNorm kernels (0). */
+int mh_denoiser_set_fuse_ln(int on);
+
+/* Timing-only ablation of the big-tile kernel (results are WRONG when non-zero): bit 0 skips the
+ * DMA loads, bit 1 the MFMAs, bit 2 the epilogue stores, bit 3 the LDS fragment reads.  Used by tools/gemm_bench.py only. */
+int mh_gemm_set_debug(int bits);
+
+/* A/B mask of the big-tile GEMM epilogues / tiles.  Bit 0: QKV scatter with streaming (nt) q / k stores instead of ordinary ones
+ * (default ordinary: attention reads them back at once; +0.9 % steps/s in round 2).  Bit 1: dense + GELU with ordinary instead of
+ * streaming stores (default streaming: the output is large and read once; ordinary costs 3.8 % of the step).  The dense + residual +
+ * LayerNorm epilogue always stores normally: its rows are re-read at once.  Bit 2: the full-row (LayerNorm) tile with the plain
+ * instead of the ping-pong main loop (4 % slower step).  Bit 3 / 4: the 64-row full-row tile for K <= 512 / always (3 % / 7 % slower). */
+int mh_gemm_set_plain_stores(int mask);
+
+/* denoiser forward: 0 = never defer, 1 (default) = defer where the width has no full-row LayerNorm epilogue (d_model 768),
+ * 2 = always (A/B) */
+int mh_denoiser_set_defer_ln(int mode);
+
+/* timing-only A/B knob (tools/ab_step.py skip): leave one kind of launch out of the bf16 panel forward (bit 0 QKV, 1 attention,
+ * 2 attention-output dense + LN, 3 FFN1, 4 FFN2 + LN, 5 up-projection chain, 6 down-projection); outputs are then meaningless */
+int mh_denoiser_set_skip(int mask);
+
+/* panel LayerNorm kernels: 1 (default) = 4 rows per wave (four times the waves of the 16-row form), 0 = 16 rows per wave (A/B) */
+int mh_layernorm_set_rows4(int on);
+
+/* 1: the bf16 panel forward folds softmax scale x log2(e) into the stored queries and runs the pre-scaled attention (A/B; default 0) */
+int mh_denoiser_set_prescale_q(int on);
+
+/* timing-only ablation of the streaming kernel at head dim 64, seq_len <= 512 (tools/attn_bench.py): 1 no softmax vector work, 2 no S^T
+ * MFMAs, 4 no P.V MFMAs, 8 no LDS fragment reads, 16 no stage DMA (built: 1 2 4 6 7 8 16 24 31); 0 = the real kernel */
+int mh_attention_set_ablation(int bits);
+
+/* experiment knob (A/B only): co-resident partner blocks of the big-tile GEMMs start `ticks` x 10 ns late */
+int mh_gemm_set_stagger(int ticks);
+
+/* experiment knob (A/B only): LDS-DMA pieces of the 256x128 kernels issued between the MFMA rows instead of as one burst */
+int mh_gemm_set_spread(int on);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -102,11 +102,8 @@ SIGNATURES = {
     "mh_attention_stream_bwd_ex": (INT, [VP, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP, I64, INT, INT, INT, INT, F32, I64, I64, I64, I64, I64, I64, VP]),
     "mh_attention_stream_bwd_supported": (INT, [INT, INT]),
     "mh_attention_bwd_rowdot": (INT, [VP, VP, I64, VP, INT, INT, INT, INT, VP]),
-    "mh_attention_set_stream": (INT, [INT]),
     "mh_attention_stream_enabled": (INT, []),
     "mh_gemm_qkv_vtperm": (INT, [VP, I64, INT, VP, I64, INT, VP, VP, VP, VP, INT, INT, INT, INT, VP]),
-    "mh_attention_set_variant": (INT, [INT]),
-    "mh_attention_set_profile": (INT, [VP]),
     "mh_attention_fwd": (INT, [VP, VP, VP, VP, I64, INT, INT, INT, INT, F32, INT, VP]),
     "mh_layernorm": (INT, [VP, VP, VP, VP, I64, INT, F32, INT, VP]),
     "mh_layernorm_panel": (INT, [VP, I64, VP, VP, VP, I64, I64, INT, F32, VP]),
@@ -156,12 +153,8 @@ SIGNATURES = {
     "mh_clip_grads": (INT, [VP, VP, INT, VP, F32, VP]),
     "mh_step_begin": (INT, [VP, VP, VP, VP, VP, INT, VP]),
     "mh_step_end": (INT, [VP, VP]),
-    "mh_gemm_set_variant": (INT, [INT]),
-    "mh_gemm_set_auto_wide": (INT, [INT]),
     "mh_gemm_dw": (INT, [VP, I64, VP, I64, VP, INT, I64, INT, INT, VP]),
     "mh_gemm_dw_splits": (INT, [I64, INT, INT]),
-    "mh_gemm_dw_set_blocks": (INT, [INT]),
-    "mh_gemm_dw_set_wide": (INT, [INT]),
     "mh_weight_prep": (INT, [VP, INT, INT, VP]),
     "mh_gemm_dw_bias": (INT, [VP, I64, VP, I64, VP, INT, I64, INT, INT, INT, VP]),
     "mh_gemm_act_grad": (INT, [VP, I64, VP, I64, VP, I64, VP, I64, I64, INT, INT, INT, VP]),
@@ -169,12 +162,7 @@ SIGNATURES = {
     "mh_gemm_bias_act_dact": (INT, [VP, I64, VP, I64, VP, VP, VP, I64, I64, INT, INT, INT, VP]),
     "mh_gemm_bias_res_ln": (INT, [VP, I64, INT, VP, I64, INT, VP, VP, I64, INT, VP, VP, F32, VP, I64, INT, I64, INT, INT, VP]),
     "mh_gemm_bias_res_ln_supported": (INT, [INT]),
-    "mh_denoiser_set_fuse_ln": (INT, [INT]),
     "mh_denoiser_get_fuse_ln": (INT, []),
-    "mh_gemm_set_debug": (INT, [INT]),
-    "mh_gemm_set_stagger": (INT, [INT]),
-    "mh_gemm_set_spread": (INT, [INT]),
-    "mh_gemm_set_plain_stores": (INT, [INT]),
     "mh_graph_begin_capture": (INT, [VP]),
     "mh_graph_end_capture": (INT, [VP, C.POINTER(VP)]),
     "mh_graph_launch": (INT, [VP, VP]),
@@ -189,13 +177,8 @@ SIGNATURES = {
     "mh_attention_stream_bwd_drop": (INT, [VP, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP, I64, INT, INT, INT, INT, F32, I64, I64, I64, I64, I64, I64, VP, F32, VP]),
     "mh_gemm_bias_act_defer": (INT, [VP, I64, VP, I64, VP, VP, I64, VP, I64, I64, INT, INT, INT, C.POINTER(LnDefer), VP]),
     "mh_gemm_qkv_vtperm_defer": (INT, [VP, I64, VP, I64, VP, VP, VP, VP, INT, INT, INT, INT, C.POINTER(LnDefer), VP]),
-    "mh_denoiser_set_defer_ln": (INT, [INT]),
     "mh_denoiser_get_defer_ln": (INT, []),
-    "mh_denoiser_set_skip": (INT, [INT]),
-    "mh_layernorm_set_rows4": (INT, [INT]),
-    "mh_denoiser_set_prescale_q": (INT, [INT]),
     "mh_gemm_qkv_vtperm_qs": (INT, [VP, I64, VP, I64, VP, VP, VP, VP, INT, INT, INT, INT, F32, C.POINTER(LnDefer), VP]),
-    "mh_attention_set_ablation": (INT, [INT]),
     "mh_attention_stream_prescaled_supported": (INT, [INT, INT]),
     "mh_attention_stream_fwd_prescaled": (INT, [VP, VP, VP, VP, I64, INT, INT, INT, INT, INT, VP]),
     "mh_profile_start": (INT, []),
@@ -209,35 +192,90 @@ SIGNATURES = {
     "mh_denoiser_tail": (INT, [C.POINTER(Denoiser), VP, I64, VP, INT, INT, VP, C.c_size_t, VP]),
 }
 
+# include/musehip_dbg.h: exported by libmusehip_dbg.so only (A/B switches, ablation knobs, diagnostics)
+DBG_SIGNATURES = {
+    "mh_attention_set_stream": (INT, [INT]),
+    "mh_attention_set_variant": (INT, [INT]),
+    "mh_attention_set_profile": (INT, [VP]),
+    "mh_gemm_set_variant": (INT, [INT]),
+    "mh_gemm_set_auto_wide": (INT, [INT]),
+    "mh_gemm_dw_set_blocks": (INT, [INT]),
+    "mh_gemm_dw_set_wide": (INT, [INT]),
+    "mh_denoiser_set_fuse_ln": (INT, [INT]),
+    "mh_gemm_set_debug": (INT, [INT]),
+    "mh_gemm_set_plain_stores": (INT, [INT]),
+    "mh_denoiser_set_defer_ln": (INT, [INT]),
+    "mh_denoiser_set_skip": (INT, [INT]),
+    "mh_layernorm_set_rows4": (INT, [INT]),
+    "mh_denoiser_set_prescale_q": (INT, [INT]),
+    "mh_attention_set_ablation": (INT, [INT]),
+    "mh_gemm_set_stagger": (INT, [INT]),
+    "mh_gemm_set_spread": (INT, [INT]),
+}
+
 _lib = None
+_handles = {}
 
 
 class MuseHipError(RuntimeError):
     pass
 
 
+DBG_LIB_PATH = os.path.join(_HERE, "csrc", "libmusehip_dbg.so")
+
+
+def _load(path, signatures, what):
+    if path in _handles:
+        return _handles[path]
+    if not os.path.exists(path):
+        raise MuseHipError(
+            "%s not found at %s: the HIP kernels are the only compute path "
+            "(build with `make -C musediffusion_amd/csrc` or __graft_entry__.build())" % (what, path))
+    # PyTorch-ROCm wheels bundle their own libamdhip64 (same SONAME as /opt/rocm's).  Import torch
+    # FIRST so the library's DT_NEEDED entry resolves to that already-loaded runtime: two HIP
+    # runtimes in one process do not share devices, streams or allocations.
+    import torch  # noqa: F401
+    handle = C.CDLL(path)
+    for name, (res, args) in signatures.items():
+        try:
+            fn = getattr(handle, name)
+        except AttributeError:
+            raise MuseHipError("%s does not export %s (stale build?)" % (what, name))
+        fn.restype = res
+        fn.argtypes = args
+    _handles[path] = handle
+    return handle
+
+
 def lib():
-    """The loaded library (cached).  Raises MuseHipError when it cannot be loaded."""
+    """The loaded library (cached).  Raises MuseHipError when it cannot be loaded.  This is the production build unless the caller
+    switched to the debug build (use_debug_library / debug_library)."""
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise MuseHipError(
-                "libmusehip.so not found at %s: the HIP kernels are the only compute path "
-                "(build with `make -C musediffusion_amd/csrc` or __graft_entry__.build())" % LIB_PATH)
-        # PyTorch-ROCm wheels bundle their own libamdhip64 (same SONAME as /opt/rocm's).  Import torch
-        # FIRST so the library's DT_NEEDED entry resolves to that already-loaded runtime: two HIP
-        # runtimes in one process do not share devices, streams or allocations.
-        import torch  # noqa: F401
-        handle = C.CDLL(LIB_PATH)
-        for name, (res, args) in SIGNATURES.items():
-            try:
-                fn = getattr(handle, name)
-            except AttributeError:
-                raise MuseHipError("libmusehip.so does not export %s (stale build?)" % name)
-            fn.restype = res
-            fn.argtypes = args
-        _lib = handle
+        _lib = _load(LIB_PATH, SIGNATURES, "libmusehip.so")
     return _lib
+
+
+def use_debug_library(on=True):
+    """Route every later call of this process through libmusehip_dbg.so (-DMH_ABLATE: the same kernels plus the switches of
+    include/musehip_dbg.h) or back to the production library.  For tools/, bench.py's A/B flags and tests that compare kernel forms;
+    the product never calls this.  Each library has its own switch state; objects made under one (captured graphs, engines' arenas)
+    are plain HIP objects and stay valid under the other."""
+    global _lib
+    _lib = _load(DBG_LIB_PATH, {**SIGNATURES, **DBG_SIGNATURES}, "libmusehip_dbg.so") if on else _load(LIB_PATH, SIGNATURES, "libmusehip.so")
+    return _lib
+
+
+class debug_library:
+    """`with _lib.debug_library(): ...` - the debug build for the duration of the block."""
+
+    def __enter__(self):
+        self.prev = _lib
+        return use_debug_library(True)
+
+    def __exit__(self, *a):
+        global _lib
+        _lib = self.prev
 
 
 def check(rc, what=""):

@@ -913,19 +913,20 @@ __global__ __launch_bounds__(64 * NW) void attn_stream_bf16_kernel(const bf16* _
   }
 }
 
-int g_attn_abl = 0;        // timing-only ablation of the streaming kernel (mh_attention_set_ablation)
-int g_attn_resident = 1;
-unsigned long long* g_attn_prof = nullptr;   // diagnostic stamps (mh_attention_set_profile)
+MH_KNOB(int, g_attn_abl, 0);        // timing-only ablation of the streaming kernel (mh_attention_set_ablation)
+MH_KNOB(int, g_attn_resident, 1);
+MH_KNOB(unsigned long long*, g_attn_prof, nullptr);   // diagnostic stamps (mh_attention_set_profile)
 
 template <int DH>
 int launch_f32(const float* q, const float* k, const float* vt, float* ctx, int64_t ld, int B, int L, int nh,
                float scale, hipStream_t s) {
   constexpr size_t bytes = (size_t)(2 * 64 * (DH + 4) + DH * 68 + 64 * 68) * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static bool attr_set[MH_MAX_DEVICES] = {};   // hipFuncSetAttribute acts on the current device's copy of the kernel
+  const int dev = mh_current_device();
+  if (!attr_set[dev]) {
     MH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_f32_kernel<DH>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-    attr_set = true;
+    attr_set[dev] = true;
   }
   dim3 grid(ceil_div(L, 64), B * nh), block(256);
   MH_LAUNCH((attn_f32_kernel<DH>), grid, block, bytes, s, q, k, vt, ctx, ld, L, nh, scale);
@@ -938,13 +939,14 @@ int launch_bf16(const bf16* q, const bf16* k, const bf16* vt, bf16* ctx, int64_t
                 float scale, int ctx_panel, hipStream_t s) {
   const size_t res_bytes = (size_t)ceil_div(L, 64) * 64 * DH * 4;   // K + V^T of one (batch, head)
   if (g_attn_resident && DH <= 64 && res_bytes <= 128 * 1024 && L >= 128) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static bool attr_set[MH_MAX_DEVICES] = {};
+    const int dev = mh_current_device();
+    if (!attr_set[dev]) {
       MH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_res_bf16_kernel<DH, 8>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
       MH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_res_bf16_kernel<DH, 16>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-      attr_set = true;
+      attr_set[dev] = true;
     }
     // 16 waves (four per SIMD) when the sequence has a 32-query tile for each of them
     if (g_attn_resident == 2 && L >= 512)
@@ -965,11 +967,13 @@ int launch_bf16(const bf16* q, const bf16* k, const bf16* vt, bf16* ctx, int64_t
 
 }  // namespace
 
-namespace { int g_attn_stream = 1; }
+namespace { MH_KNOB(int, g_attn_stream, 1); }
+#ifdef MH_ABLATE
 extern "C" int mh_attention_set_stream(int on) {
   g_attn_stream = on < 0 ? 0 : (on > 4 ? 4 : on);
   return MH_OK;
 }
+#endif
 extern "C" int mh_attention_stream_enabled(void) { return g_attn_stream; }
 
 extern "C" int mh_attention_stream_supported(int L, int dh) { return L >= 512 && L % 16 == 0 && (dh == 32 || dh == 64); }
@@ -1053,8 +1057,8 @@ int stream_fwd_impl(const void* q, const void* k, const void* vt_perm, void* ctx
   const dim3 grid((unsigned)(nitems < slots ? nitems : slots)), block(small ? 512 : 1024);
   auto go = [&](auto kern, int bytes) -> int {
     // all instantiations share one function-pointer type, so this lambda body exists once: the attribute is tracked per kernel
-    static std::set<const void*> attr_done;
-    if (attr_done.insert(reinterpret_cast<const void*>(kern)).second)
+    static std::set<std::pair<int, const void*>> attr_done;   // (device, kernel)
+    if (attr_done.insert({mh_current_device(), reinterpret_cast<const void*>(kern)}).second)
       MH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     mh_prof_note("attn_stream B*nh=%d L=%d dh=%d drop=%d", nbh, L, dh, (int)dropping);
     MH_LAUNCH(kern, grid, block, bytes, s, Q, K, V, (bf16*)ctx, ld_ctx, L, nh, nbh, sl2, ctx_panel, lse2, qsB, qsH, qld, da, keep_bits, bits_in);
@@ -1105,20 +1109,26 @@ int stream_fwd_impl(const void* q, const void* k, const void* vt_perm, void* ctx
 }
 }  // namespace
 
+#ifdef MH_ABLATE
 extern "C" int mh_attention_set_ablation(int bits) {
   g_attn_abl = bits;
   return MH_OK;
 }
+#endif
 
+#ifdef MH_ABLATE
 extern "C" int mh_attention_set_profile(void* stamps) {
   g_attn_prof = reinterpret_cast<unsigned long long*>(stamps);
   return MH_OK;
 }
+#endif
 
+#ifdef MH_ABLATE
 extern "C" int mh_attention_set_variant(int resident) {
   g_attn_resident = resident < 0 ? 0 : (resident > 2 ? 2 : resident);
   return MH_OK;
 }
+#endif
 
 extern "C" int mh_attention_fwd_ex(const void* q, const void* k, const void* vt, void* ctx, int64_t ld_ctx,
                                    int ctx_panel, int B, int L, int nh, int dh, float scale, int dtype, mh_stream_t stream);

@@ -514,11 +514,12 @@ int launch_bwd(const bf16* q, const bf16* k, const bf16* v, const bf16* qT, cons
   constexpr int ST = SKB * DH * 2;
   constexpr int bytes_dq = 2 * 2 * ST + (DROP && FULL ? 2 * 8 * (SKB / 64) * 256 : 0), bytes_dkv = 2 * (2 * ST + 2 * SKB * 4 + (DROP && FULL ? (SKB / 32) * 1024 : 0));
   (void)qT; (void)kT; (void)dOT;   // (the transposed copies of the round-2 interface: no longer read)
-  static bool attr_set = false;
-  if (!attr_set) {
+  static bool attr_set[MH_MAX_DEVICES] = {};   // per device: hipFuncSetAttribute acts on the current device's copy of the kernel
+  const int adev = mh_current_device();
+  if (!attr_set[adev]) {
     MH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_kernel<DH, DROP, FULL>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes_dq));
     MH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkv_kernel<DH, DROP, FULL>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes_dkv));
-    attr_set = true;
+    attr_set[adev] = true;
   }
   int dev = 0, cus = 256;
   if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;

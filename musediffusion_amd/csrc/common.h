@@ -5,6 +5,23 @@
 
 #include "../../include/musehip.h"
 
+// A/B switches, ablation knobs and diagnostics (include/musehip_dbg.h) exist only in the debug library (-DMH_ABLATE ->
+// libmusehip_dbg.so).  The production library has no process-global mutable configuration: there every MH_KNOB is a compile-time
+// constant holding the default, the setters are not compiled, and the kernel variants only a knob can reach are dead code.
+// per-device bookkeeping of hipFuncSetAttribute (it acts on the CURRENT device's copy of a kernel): the library may serve several
+// devices from one process
+constexpr int MH_MAX_DEVICES = 64;
+static inline int mh_current_device() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MH_MAX_DEVICES) dev = 0;
+  return dev;
+}
+#ifdef MH_ABLATE
+#define MH_KNOB(type, name, value) type name = value
+#else
+#define MH_KNOB(type, name, value) constexpr type name = value
+#endif
+
 typedef __bf16 bf16;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;

@@ -231,8 +231,10 @@ __global__ __launch_bounds__(256) void trunc_normal_kernel(float* __restrict__ o
     const uint64_t g = (uint64_t)((first >> 2) + gi);
     float z[4] = {0.f, 0.f, 0.f, 0.f};
     uint32_t pending = 0xfu;
-    for (uint32_t attempt = 0; attempt < 64 && pending; ++attempt) {
-      uint32_t c[4] = {(uint32_t)g, (uint32_t)(g >> 32), step, (stream_id << 8) | attempt};
+    // up to 1024 calls per group (the loop ends with the group's last acceptance: the usual cost is 1 - 2 calls); attempts beyond
+    // 255 continue in the top byte of the second counter word, so every value an earlier build drew is unchanged
+    for (uint32_t attempt = 0; attempt < 1024 && pending; ++attempt) {
+      uint32_t c[4] = {(uint32_t)g, (uint32_t)(g >> 32) | ((attempt >> 8) << 24), step, (stream_id << 8) | (attempt & 0xffu)};
       mh_philox<10>(c, seed_lo, seed_hi);
       // sqrt(-2 ln u) = sqrt(-2 ln 2 log2 u)
       const float r0 = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u01(c[0])));
@@ -248,7 +250,9 @@ __global__ __launch_bounds__(256) void trunc_normal_kernel(float* __restrict__ o
         }
       }
     }
-    // 64 rejected candidates in a row has probability < 1e-30 for bound >= 0.1
+    // an element keeps z = 0 only after 1024 rejected candidates in a row: (1 - 0.0797)^1024 = 1e-37 at the tightest bound the entry
+    // point accepts (0.1: acceptance probability 0.0797), 3e-172 at bound 0.2; the reference loops until every element is accepted
+    // (diffusion.py:378-388)
     const int64_t i = gi << 2;
     if (i + 4 <= n) *reinterpret_cast<f32x4*>(out + i) = f32x4{z[0], z[1], z[2], z[3]};
     else for (int k = 0; k < 4 && i + k < n; ++k) out[i + k] = z[k];

@@ -77,34 +77,42 @@ extern "C" int64_t mh_profile_stop(char* out, size_t cap) {
   return (int64_t)rep.size() + 1;
 }
 
-namespace { int g_fuse_ln = 1; int g_defer_ln = 1; int g_skip = 0; int g_prescale_q = 0; }
+namespace { MH_KNOB(int, g_fuse_ln, 1); MH_KNOB(int, g_defer_ln, 1); MH_KNOB(int, g_skip, 0); MH_KNOB(int, g_prescale_q, 0); }
 // 1: the bf16 panel forward stores the queries multiplied by softmax scale x log2(e) (QKV epilogue) and runs the streaming attention
 // on them without a per-score multiply-subtract (mh_attention_stream_fwd_prescaled: a quarter fewer vector instructions per tile).
 // Measured (round 3): 3.782 vs 3.785 ms per step at config 2, 7.329 vs 7.339 at c2-bertbase, 29.3 vs 29.5 us per half-batch launch
 // alone, 18.6 vs 19.4 us for ONE (batch, head) alone on the chip - the kernel is not bound by its vector-instruction count.
 // Default 0 (the queries keep the reference's scaling and one rounding less)
+#ifdef MH_ABLATE
 extern "C" int mh_denoiser_set_prescale_q(int on) {
   g_prescale_q = on != 0;
   return MH_OK;
 }
+#endif
 // timing-only A/B (tools/ab_step.py skip): leave launches of one kind out of the bf16 panel forward to read their marginal cost inside
 // the captured step (outputs are then garbage).  bit 0 QKV, 1 attention, 2 attention-output dense + LN, 3 FFN1, 4 FFN2 + LN,
 // 5 up-projection chain (pack, two GEMMs, embedding LayerNorm), 6 down-projection
+#ifdef MH_ABLATE
 extern "C" int mh_denoiser_set_skip(int mask) {
   g_skip = mask;
   return MH_OK;
 }
+#endif
 extern "C" int mh_denoiser_get_defer_ln(void) { return g_defer_ln; }
 // 0 = never, 1 (default) = where no full-row LayerNorm epilogue exists for the width (d_model 768), 2 = always (A/B)
+#ifdef MH_ABLATE
 extern "C" int mh_denoiser_set_defer_ln(int mode) {
   g_defer_ln = mode < 0 ? 0 : (mode > 2 ? 2 : mode);
   return MH_OK;
 }
+#endif
 extern "C" int mh_denoiser_get_fuse_ln(void) { return g_fuse_ln; }
+#ifdef MH_ABLATE
 extern "C" int mh_denoiser_set_fuse_ln(int on) {
   g_fuse_ln = on != 0;
   return MH_OK;
 }
+#endif
 
 extern "C" const char* mh_last_error(void) { return g_err; }
 extern "C" int mh_abi_version(void) { return 1; }

@@ -1199,10 +1199,10 @@ __global__ __launch_bounds__(C::THREADS, C::STAGE * C::NST <= 80 * 1024 ? 2 : 1)
   }   // persistent tile loop
 }
 
-int g_dbg = 0;
-int g_spread = 0;     // A/B: DMA pieces interleaved with the MFMA rows (DBG bit 1024 kernels)
-int g_stagger = 0;
-int g_variant = 2;  // bf16 kernel choice: 0 small-tile register-staged, 1 small-tile global_load_lds, 2 / 3 big 256x128, 4 big 256x256, 5 big 256x256 ping-pong
+MH_KNOB(int, g_dbg, 0);
+MH_KNOB(int, g_spread, 0);     // A/B: DMA pieces interleaved with the MFMA rows (DBG bit 1024 kernels)
+MH_KNOB(int, g_stagger, 0);
+MH_KNOB(int, g_variant, 2);  // bf16 kernel choice: 0 small-tile register-staged, 1 small-tile global_load_lds, 2 / 3 big 256x128, 4 big 256x256, 5 big 256x256 ping-pong
 
 int device_cus() {
   static int cus = 0;
@@ -1214,7 +1214,7 @@ int device_cus() {
   return cus;
 }
 
-int g_plain_stores = 0;   // A/B: bit 0 QKV streaming instead of ordinary stores, bit 1 dense+GELU ordinary instead of streaming stores; bit 2: full-row tile without ping-pong; bits 3 / 4: 64-row full-row tile
+MH_KNOB(int, g_plain_stores, 0);   // A/B: bit 0 QKV streaming instead of ordinary stores, bit 1 dense+GELU ordinary instead of streaming stores; bit 2: full-row tile without ping-pong; bits 3 / 4: 64-row full-row tile
 
 template <class C, int EPI>
 int launch_big(const GemmArgs& g0, hipStream_t s, int batch) {
@@ -1304,7 +1304,7 @@ bool big_tile_ok(const GemmArgs& g) {
 // Round 3: launches with ROW-MAJOR operands (the training tape, direct callers: one GEMM on the chip at a time) take the wide tile
 // when it still gives every CU a block - bench.py --workload train -2.1 % (tools/ab_train.py gemm_variant 2 4); the engine's
 // K32-panel launches (two concurrent branches) keep the 256x128 tile.  mh_gemm_set_auto_wide(0) switches the rule off.
-int g_auto_wide = 1;
+MH_KNOB(int, g_auto_wide, 1);
 bool want_wide(const GemmArgs& g, int batch) {
   if (g.N % 256 != 0) return false;
   if (g_variant >= 4) return true;
@@ -1357,38 +1357,50 @@ int launch(const GemmArgs& g, int dtype, hipStream_t s, int batch = 1) {
 
 extern "C" int mh_gemm_bias_res_ln_supported(int N) { return N == 128 || N == 256 || N == 512; }
 
+#ifdef MH_ABLATE
 extern "C" int mh_gemm_set_plain_stores(int mask) {
   g_plain_stores = mask;
   return MH_OK;
 }
+#endif
 
+#ifdef MH_ABLATE
 extern "C" int mh_gemm_set_stagger(int ticks) {
   g_stagger = ticks;
   return MH_OK;
 }
+#endif
 
 // experiment knob (A/B only): 1 = the 256x128 kernels issue one LDS-DMA piece behind each MFMA row of a K-step instead of all six
 // right after the barrier.  Measured (tools/gemm_bench.py --spread): FFN1 -2.6 %, QKV -1 %, FFN2 / attention-output +-0 per launch.
+#ifdef MH_ABLATE
 extern "C" int mh_gemm_set_spread(int on) {
   g_spread = on != 0;
   return MH_OK;
 }
+#endif
 
+#ifdef MH_ABLATE
 extern "C" int mh_gemm_set_debug(int bits) {
   g_dbg = bits & 127;
   return MH_OK;
 }
+#endif
 
+#ifdef MH_ABLATE
 extern "C" int mh_gemm_set_auto_wide(int on) {
   g_auto_wide = on ? 1 : 0;
   return MH_OK;
 }
+#endif
 
+#ifdef MH_ABLATE
 extern "C" int mh_gemm_set_variant(int variant) {
   MH_CHECK_ARG(variant >= 0 && variant <= 5, "gemm_set_variant: variant must be 0..5");
   g_variant = variant;
   return MH_OK;
 }
+#endif
 
 extern "C" int mh_gemm_bias_act(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
                                 const void* residual, int64_t ldr, void* out, int64_t ldo, int out_f32,
@@ -1902,18 +1914,22 @@ __global__ __launch_bounds__(128 * WN, WN == 2 ? 2 : 1) void gemm_tn_kernel(cons
 
 }  // namespace
 
-namespace { int g_dw_blocks = 512; int g_dw_wide = 1; }
+namespace { MH_KNOB(int, g_dw_blocks, 512); MH_KNOB(int, g_dw_wide, 1); }
 // blocks a weight-gradient launch aims for when it cuts the token range (A/B knob; 512 = two 4-wave blocks per CU; the 256 x 256
 // tile's 8-wave blocks count double)
+#ifdef MH_ABLATE
 extern "C" int mh_gemm_dw_set_blocks(int blocks) {
   g_dw_blocks = blocks < 1 ? 1 : blocks;
   return MH_OK;
 }
+#endif
 // A/B: 0 = always the 256 x 128 tile (round 2), 1 = the 256 x 256 tile where N is a multiple of 256
+#ifdef MH_ABLATE
 extern "C" int mh_gemm_dw_set_wide(int on) {
   g_dw_wide = on ? 1 : 0;
   return MH_OK;
 }
+#endif
 namespace { bool dw_wide(int N) { return g_dw_wide && N % 256 == 0; } }
 
 extern "C" int mh_gemm_dw_splits(int64_t K, int M, int N) {

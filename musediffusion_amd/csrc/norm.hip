@@ -7,7 +7,7 @@
 namespace {
 
 constexpr int MAXCH = 4;  // 8-element chunks per lane: H <= 64*8*4 = 2048
-int g_ln_rows4 = 1;       // panel LayerNorm: 4 rows per wave (default) or 16 (A/B: mh_layernorm_set_rows4)
+MH_KNOB(int, g_ln_rows4, 1);       // panel LayerNorm: 4 rows per wave (default) or 16 (A/B: mh_layernorm_set_rows4)
 
 template <typename T, bool ADD>
 __global__ __launch_bounds__(256) void ln_kernel(const T* __restrict__ x, int64_t ldx, const float* __restrict__ xf32,
@@ -269,10 +269,12 @@ int launch_ln_panel(const void* x, int64_t ldx, const float* xf32, const float* 
 
 }  // namespace
 
+#ifdef MH_ABLATE
 extern "C" int mh_layernorm_set_rows4(int on) {
   g_ln_rows4 = on != 0;
   return MH_OK;
 }
+#endif
 
 extern "C" int mh_layernorm_panel(const void* x, int64_t ldx, const float* gamma, const float* beta, void* out,
                                   int64_t ldo, int64_t rows, int H, float eps, mh_stream_t stream) {

@@ -533,6 +533,16 @@ __device__ __forceinline__ float adamw_elem(float p, float g, float& m, float& v
 template <int NEMA>
 __device__ __forceinline__ void adamw_ema_chunk(const mh_opt_tensor& t, const mh_opt_chunk& ck, const mh_opt_hparams& hp) {
   const int64_t n4 = ck.count >> 2;
+  if (!t.grad) {   // no gradient (frozen / unused parameter): torch.optim.AdamW skips it, update_ema (train_util.py:21-31) does not
+    if constexpr (NEMA > 0) {
+      for (int64_t i = ck.offset + threadIdx.x; i < ck.offset + ck.count; i += blockDim.x) {
+        const float p = t.param[i];
+#pragma unroll
+        for (int k = 0; k < NEMA; ++k) t.ema[k][i] = t.ema[k][i] * hp.ema_rate[k] + p * hp.ema_one_minus[k];
+      }
+    }
+    return;
+  }
   f32x4* __restrict__ P = reinterpret_cast<f32x4*>(t.param + ck.offset);
   const f32x4* __restrict__ G = reinterpret_cast<const f32x4*>(t.grad + ck.offset);
   f32x4* __restrict__ M = reinterpret_cast<f32x4*>(t.exp_avg + ck.offset);
@@ -581,6 +591,10 @@ __global__ __launch_bounds__(256) void sumsq_chunks_kernel(const mh_opt_tensor* 
                                                           float* __restrict__ partial) {
   __shared__ float red[4];
   const mh_opt_chunk ck = chunks[blockIdx.x];
+  if (!tensors[ck.tensor].grad) {   // a parameter without a gradient adds nothing (train_util.py:277 `if p.grad is not None`)
+    if (threadIdx.x == 0) partial[blockIdx.x] = 0.f;
+    return;
+  }
   const float* g = tensors[ck.tensor].grad + ck.offset;
   // fixed per-thread order: 16-byte pieces strided by the block, then the count % 4 tail
   float s = 0.f;
@@ -601,6 +615,7 @@ __global__ __launch_bounds__(256) void clip_grads_kernel(const mh_opt_tensor* __
   const float coef = fminf(max_norm / (norm[0] + 1e-6f), 1.0f);
   if (coef >= 1.0f) return;
   const mh_opt_chunk ck = chunks[blockIdx.x];
+  if (!tensors[ck.tensor].grad) return;
   float* g = const_cast<float*>(tensors[ck.tensor].grad) + ck.offset;
   const int64_t n4 = ck.count >> 2;
   for (int64_t i = threadIdx.x; i < n4; i += blockDim.x) {

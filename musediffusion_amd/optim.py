@@ -54,22 +54,35 @@ class FusedAdamWEMA:
         self._table = None
         self._table_key = None
         self._stage, self._stage_ev, self._stage_k = None, None, 0
+        # torch keeps optimizer state only for parameters that have taken a step (a frozen one never appears in `state`)
+        self._stepped = [False] * len(self.params)
+        self._with_grad = [True] * len(self.params)
 
     def _tensor_table(self):
-        grads = [p.grad for p in self.params]
-        if any(g is None for g in grads):
-            raise RuntimeError("every parameter needs a gradient (the reference runs DDP with find_unused_parameters=False)")
-        key = tuple(g.data_ptr() for g in grads)
+        # torch.optim.AdamW skips a parameter whose gradient is None (frozen by requires_grad_(False) - the reference's
+        # --freeze_embedding, utils/initialization.py:64-65 - or never reached by the backward); update_ema still walks it
+        # (train_util.py:21-31, :253-254).  Such a row carries a NULL gradient pointer and the kernels do the same.
+        grads = [p.grad if p.requires_grad else None for p in self.params]
+        if all(g is None for g in grads):
+            raise RuntimeError("no parameter has a gradient: call backward() before the optimizer step")
+        for i, g in enumerate(grads):
+            if g is None:
+                continue
+            if g.dtype != torch.float32 or not g.is_contiguous():
+                raise ValueError("gradients must be contiguous fp32")
+            if g.data_ptr() & 15:     # the kernels read 16-byte pieces: an autograd view at an odd offset is copied once
+                self.params[i].grad = grads[i] = g.clone()
+        key = tuple(0 if g is None else g.data_ptr() for g in grads)
         if self._table is None or key != self._table_key:
             rows = np.zeros((len(self.params), 8), dtype=np.int64)
             for i, p in enumerate(self.params):
                 g = grads[i]
-                if g.dtype != torch.float32 or not g.is_contiguous():
-                    raise ValueError("gradients must be contiguous fp32")
-                rows[i, 0], rows[i, 1] = p.data_ptr(), g.data_ptr()
+                rows[i, 0], rows[i, 1] = p.data_ptr(), 0 if g is None else g.data_ptr()
                 rows[i, 2], rows[i, 3] = self.exp_avg[i].data_ptr(), self.exp_avg_sq[i].data_ptr()
                 for e in range(len(self.ema_rates)):
                     rows[i, 4 + e] = self.ema[e][i].data_ptr()
+            if (rows[:, [0, 2, 3] + [4 + e for e in range(len(self.ema_rates))]] & 15).any():
+                raise ValueError("parameters, moments and EMA copies must be 16-byte aligned")
             # gradients that were dropped and re-created move: the table follows through a pinned staging buffer and a
             # stream-ordered copy (no host synchronisation); two staging buffers, each re-used only once its last copy has run
             if self._stage is None:
@@ -85,6 +98,7 @@ class FusedAdamWEMA:
             ev.record()
             self._stage_ev[k] = ev
             self._table_key = key
+        self._with_grad = [g is not None for g in grads]
         return self._table
 
     def grad_norm(self):
@@ -109,6 +123,8 @@ class FusedAdamWEMA:
             self.lr = float(lr)
         t = self._tensor_table()
         self.step_count += 1
+        for i, w in enumerate(self._with_grad):
+            self._stepped[i] = self._stepped[i] or w
         b1, b2 = self.betas
         hp = OptHParams()
         hp.beta1, hp.beta2, hp.eps = b1, b2, self.eps
@@ -124,7 +140,8 @@ class FusedAdamWEMA:
               "mh_adamw_ema_step")
         # the kernel wrote the parameters behind autograd's back: bump their version counters (no launch) so the
         # packed weight arena (network.TransformerNetModel.engine) is rebuilt on the next inference call
-        torch._C._autograd._unsafe_set_version_counter(tuple(self.params), tuple(p._version + 1 for p in self.params))
+        moved = tuple(p for p, w in zip(self.params, self._with_grad) if w)
+        torch._C._autograd._unsafe_set_version_counter(moved, tuple(p._version + 1 for p in moved))
 
     def zero_grad(self, set_to_none=False):
         for p in self.params:
@@ -138,7 +155,7 @@ class FusedAdamWEMA:
     def state_dict(self):
         """torch.optim.AdamW layout (what `opt_{step}.pt` holds, train_util.py:310-315)."""
         state = {i: {"step": torch.tensor(float(self.step_count)), "exp_avg": self.exp_avg[i], "exp_avg_sq": self.exp_avg_sq[i]}
-                 for i in range(len(self.params))} if self.step_count else {}
+                 for i in range(len(self.params)) if self._stepped[i]}
         group = {"lr": self.lr, "betas": self.betas, "eps": self.eps, "weight_decay": self.weight_decay, "amsgrad": False,
                  "maximize": False, "params": list(range(len(self.params)))}
         return {"state": state, "param_groups": [group]}
@@ -151,6 +168,7 @@ class FusedAdamWEMA:
             self.exp_avg[i].copy_(st["exp_avg"])
             self.exp_avg_sq[i].copy_(st["exp_avg_sq"])
             self.step_count = int(float(st["step"]))
+            self._stepped[i] = True
 
     def ema_state_dict(self, index, model):
         """EMA copy `index` under the model's state_dict keys (`_master_params_to_state_dict`, train_util.py:321-333)."""
@@ -158,6 +176,8 @@ class FusedAdamWEMA:
         by_ptr = {p.data_ptr(): i for i, p in enumerate(self.params)}
         for name, p in model.named_parameters():
             sd[name] = self.ema[index][by_ptr[p.data_ptr()]]
-        if "lm_head.weight" in sd and "word_embedding.weight" in sd:
-            sd["lm_head.weight"] = sd["word_embedding.weight"]
+        # `lm_head.weight` is not a key of named_parameters() while it is tied to the embedding (one Parameter, listed once): the
+        # reference's _master_params_to_state_dict (train_util.py:321-333) then leaves the MODEL's tensor under that key, which is the
+        # live embedding - kept as it is.  After overload_embedding (utils/initialization.py:61-63) the two are different Parameters,
+        # both named, and each EMA copy goes under its own key.
         return sd

@@ -26,26 +26,35 @@ def broadcast_weights(model, src=0, packed=False):
     (training start-up, DDP).
     packed=True (sampling ranks, GPU only): the unit is the engine's packed inference arena (compute-dtype
     matrices + fp32 vectors, 78 MB at config 2 instead of 157 MB of fp32 parameters) followed in the same buffer
-    by the two fp32 tensors the sampling path reads outside the arena (the embedding table for get_embeds /
-    rounding / argmax and lm_head.bias).  Receivers do NOT re-pack: their engine is pinned to the received arena.
+    by the three fp32 tensors the sampling path reads outside the arena (the embedding table for get_embeds /
+    rounding, lm_head.bias and lm_head.weight for the argmax - the same tensor as the embedding unless overload_embedding untied it).  Receivers do NOT re-pack: their engine is pinned to the received arena.
     Their other fp32 `nn.Parameter`s keep their old values, so the model is marked `weights_from_arena` and
     refuses to train or re-pack until `load_state_dict` / a flat broadcast refreshes it."""
     if world() == 1:
         return model
     if packed:
         eng = model.engine()                       # src: packed from its parameters; others: allocated with the same plan
-        extra = [model.word_embedding.weight.data, model.lm_head.bias.data]
+        # lm_head.weight travels too: it is the embedding tensor only until overload_embedding (utils/initialization.py:61-63)
+        # replaces the embedding's Parameter, and argmax_tokens / get_logits read lm_head.weight
+        extra = [model.word_embedding.weight.data, model.lm_head.bias.data, model.lm_head.weight.data]
         tail = torch.cat([t.reshape(-1) for t in extra]).contiguous().view(torch.uint8)
         flat = torch.cat([eng.arena, tail])
         dist.broadcast(flat, src=src)
         if rank() != src:
             n = eng.arena.numel()
             eng.arena.copy_(flat[:n])
-            off = n
+            off, got = n, []
             for t in extra:
                 nb = t.numel() * 4
-                t.copy_(flat[off:off + nb].view(torch.float32).view_as(t))
+                got.append(flat[off:off + nb].view(torch.float32).view_as(t))
                 off += nb
+            tied_here = model.lm_head.weight is model.word_embedding.weight
+            if tied_here and not torch.equal(got[0], got[2]):     # the source's head left the tie: leave it here as well
+                with torch.no_grad():
+                    model.lm_head.weight = torch.nn.Parameter(got[2].clone(), requires_grad=model.lm_head.weight.requires_grad)
+                extra[2] = model.lm_head.weight.data
+            for t, g in zip(extra, got):
+                t.copy_(g)
             model.pin_engine()
         return model
     params = [p.data for p in model.parameters()]

@@ -38,12 +38,15 @@ class TrainStep:
         self.schedule_sampler = schedule_sampler or UniformSampler(diffusion)
         # train_util.py:63-67: a float, or the config's comma-separated string ("0.5,0.9,0.99"); a sequence of floats is accepted
         # too, None (the reference's empty list) means no EMA copies
-        if isinstance(ema_rate, (int, float)):
+        # the reference's falsy rule comes first (`... if ema_rate else []`): 0.0, "", None and () all mean no EMA copies
+        if not ema_rate:
+            self.ema_rate = []
+        elif isinstance(ema_rate, (int, float)):
             self.ema_rate = [float(ema_rate)]
         elif isinstance(ema_rate, str):
             self.ema_rate = [float(x) for x in ema_rate.split(",") if x.strip()]
         else:
-            self.ema_rate = [float(r) for r in (ema_rate or ())]
+            self.ema_rate = [float(r) for r in ema_rate]
         self.model_params = list(model.parameters())
         # `optimizer`: anything with grad_norm() / step(lr=) (tests inject a host stand-in; the product is the fused kernel)
         self.opt = optimizer or FusedAdamWEMA(self.model_params, lr=self.lr, weight_decay=weight_decay, ema_rates=self.ema_rate)
@@ -104,8 +107,11 @@ class TrainStep:
         return self.lr * (1 - frac_done)
 
     def optimize(self):
-        if self.gradient_clipping > 0:            # train_util.py:248-249 (`grad_clip`): the library's norm + one scale kernel, no host sync
-            self.opt.clip_grad_norm(self.gradient_clipping)
+        if self.gradient_clipping > 0:            # train_util.py:248-249, :255-264 (`grad_clip`)
+            if hasattr(self.opt, "clip_grad_norm"):   # the fused optimizer: the library's norm + one scale kernel, no host sync
+                self.opt.clip_grad_norm(self.gradient_clipping)
+            else:                                     # an injected optimizer without one: the reference's fallback
+                torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.gradient_clipping)
         # device scalar (the reference logs it, :274-280); a copy: the optimizer's norm buffer is overwritten by the next step
         grad_norm = self.opt.grad_norm().clone()
         self.opt.step(lr=self._anneal_lr())

@@ -108,13 +108,15 @@ def _dropped_grad(ctx_ln, drop, dy, dt):
     if ctx_ln is not None and ctx_ln.dym is not None:
         src, dym = ctx_ln.dym
         ctx_ln.dym = None
-        if src.data_ptr() == dy.data_ptr():
+        if src is dy or (src.data_ptr() == dy.data_ptr() and src.shape == dy.shape and src.dtype == dy.dtype and src._version == dy._version):
             return dym
     return drop.apply(dy, dt)
 
 
 def _active(drop):
-    return drop is not None and drop.p > 0.0
+    """A site drops something: an explicit mask, or a rate the 16-bit threshold of the kernels can express (csrc/common.h drop_thr:
+    round(65536 p) > 0 - below 2^-17 the kernels' own test `thr == 0` reads "off", and every host decision must agree with it)."""
+    return drop is not None and (drop.mask is not None or drop.bits is not None or int(drop.p * 65536.0 + 0.5) > 0)
 
 
 def _gemm_drop(A, W, bias, dt, N, K, out, residual, drop):

@@ -29,3 +29,12 @@ def free_port():
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
         s.bind(("127.0.0.1", 0))
         return s.getsockname()[1]
+
+
+@pytest.fixture
+def dbg_lib():
+    """The test compares an alternative kernel form with the default one: it needs the switches of include/musehip_dbg.h, which only
+    libmusehip_dbg.so exports.  Every library call of the test goes through that build; the production library is restored after."""
+    from musediffusion_amd import _lib
+    with _lib.debug_library() as handle:
+        yield handle

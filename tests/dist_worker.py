@@ -154,10 +154,38 @@ def case_ddp(rank, world, dev):
     assert all(torch.equal(parts[0], p) for p in parts[1:]), "gradients differ across ranks after DDP"
 
 
+def case_untied(rank, world, dev):
+    """After the reference's overload_embedding (utils/initialization.py:61-63) the head's weight is no longer the embedding tensor.
+    Rank 0 overloads, every other rank starts with the default tie: after the packed broadcast every rank must hold rank 0's
+    embedding AND rank 0's (different) lm_head.weight, and argmax_tokens - which reads lm_head.weight - must agree everywhere."""
+    from musediffusion_amd import sharding
+    from musediffusion_amd.utils.initialization import overload_embedding
+    tag = "tiny"
+    m, diff, c = build(tag, dev, rank, "fp32")
+    emb = fx.seeded_randn(4242, c["V"], c["E"]) * fx.EMB_STD
+    if rank == 0:
+        overload_embedding(m, emb.to(dev), False)
+        m.eval().requires_grad_(False)
+        assert m.lm_head.weight is not m.word_embedding.weight
+    else:
+        assert m.lm_head.weight is m.word_embedding.weight
+    sharding.broadcast_weights(m, src=0, packed=True)
+    assert torch.equal(m.word_embedding.weight.cpu(), emb), "embedding did not arrive (rank %d)" % rank
+    assert torch.equal(m.lm_head.weight.cpu(), fx.state_dict(tag)["word_embedding.weight"]), "stale lm_head.weight (rank %d)" % rank
+    assert torch.equal(m.lm_head.bias.cpu(), fx.state_dict(tag)["lm_head.bias"])
+    x = fx.seeded_randn(99, c["B"], c["L"], c["E"]).to(dev)
+    tok = m.argmax_tokens(x)
+    ref = torch.argmax(x.cpu() @ fx.state_dict(tag)["word_embedding.weight"].T + fx.state_dict(tag)["lm_head.bias"], dim=-1)
+    assert float((tok.cpu() == ref).float().mean()) > 0.999, "argmax does not use rank 0's head (rank %d)" % rank
+    toks = [torch.empty_like(tok) for _ in range(world)]
+    dist.all_gather(toks, tok)
+    assert all(torch.equal(toks[0], t) for t in toks[1:])
+
+
 if __name__ == "__main__":
     rank, world, dev = setup()
     try:
-        {"generate": case_generate, "ddp": case_ddp}[sys.argv[1]](rank, world, dev)
+        {"generate": case_generate, "ddp": case_ddp, "untied": case_untied}[sys.argv[1]](rank, world, dev)
         torch.cuda.synchronize()
         dist.barrier()
     finally:

@@ -16,7 +16,7 @@ DEV = "cuda"
 
 
 @pytest.mark.parametrize("H,nh,F,L", [(512, 8, 2048, 512), (768, 12, 3072, 512), (256, 4, 1024, 528)])
-def test_defer_modes_agree_and_track_oracle(H, nh, F, L):
+def test_defer_modes_agree_and_track_oracle(H, nh, F, L, dbg_lib):
     B, E, nL, V, Tt = 2, 128, 3, 729, 64
     sd = odn.random_state_dict(E, H, F, nL, V, L, Tt, seed=21, emb_std=0.5)
     _lib.check(_lib.lib().mh_denoiser_set_defer_ln(2))      # the engine packs the folded operands when mode 2 is on at construction
@@ -49,7 +49,7 @@ def test_defer_modes_agree_and_track_oracle(H, nh, F, L):
     assert not torch.equal(outs[0], outs[2])          # really two different kernel sequences
 
 
-def test_defer_ln_on_trained_like_statistics_at_bert_base_width():
+def test_defer_ln_on_trained_like_statistics_at_bert_base_width(dbg_lib):
     """Deferred LayerNorm is the default exactly at the reference's only real width (d_model 768): its variance is the one-pass
     E[x^2] - mean^2 of per-tile partial sums and the normalisation subtracts mean x c1 from W'x - terms that cancel badly when a row
     has a large mean or a few outlier channels, as trained BERT-style residual streams do.  Trained-like weights: 12 layers, LayerNorm

@@ -123,16 +123,34 @@ def test_alias_modules_and_factory():
     assert default.hidden_size == 768 and len(default.input_transformers.layer) == 12   # bert-base like network.py:44
 
 
+def _exports(path):
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+    return {ln.split()[-1] for ln in out.splitlines() if ln.split() and ln.split()[-1].startswith("mh_")}
+
+
 def test_library_exports_every_declared_symbol():
+    """include/musehip.h <-> libmusehip.so, include/musehip_dbg.h <-> libmusehip_dbg.so only.  The production library carries no
+    process-global switch: nothing named mh_*_set_* (A/B variants, timing-only ablations, staggers, diagnostics) is exported by it."""
     from musediffusion_amd import _lib
-    header = open(os.path.join(REPO, "include", "musehip.h")).read()
-    declared = set(re.findall(r"\b(mh_[a-z0-9_]+)\s*\(", header))
-    assert declared, "no prototypes parsed"
+    proto = lambda name: set(re.findall(r"\b(mh_[a-z0-9_]+)\s*\(", open(os.path.join(REPO, "include", name)).read()))
+    declared, dbg_declared = proto("musehip.h"), proto("musehip_dbg.h")
+    assert declared and dbg_declared and not (declared & dbg_declared)
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    assert dbg_declared == set(_lib.DBG_SIGNATURES), dbg_declared ^ set(_lib.DBG_SIGNATURES)
     handle = _lib.lib()
     for name in declared:
         assert hasattr(handle, name), name
     assert handle.mh_abi_version() == 1
+    prod, dbg = _exports(_lib.LIB_PATH), _exports(_lib.DBG_LIB_PATH)
+    assert prod == declared, prod ^ declared
+    assert dbg == declared | dbg_declared, dbg ^ (declared | dbg_declared)
+    deny = re.compile(r"^mh_.*_set_|skip|debug|ablation|stagger|spread|plain_stores")
+    assert not [n for n in prod if deny.search(n)]
+    with _lib.debug_library() as d:
+        for name in dbg_declared:
+            assert hasattr(d, name), name
+    assert _lib.lib() is handle
 
 
 def test_product_path_refuses_cpu_instead_of_falling_back():
@@ -198,3 +216,53 @@ def test_reference_written_checkpoint_loads_on_cpu():
     assert checkpoint.find_ema_checkpoint(main, 7, "0.9999").endswith("ema_0.9999_000007.pt")
     osd = torch.load(os.path.join(d, "opt_000007.pt"), map_location="cpu")
     assert len(osd["state"]) == len(list(m.parameters())) and set(osd["state"][0]) >= {"step", "exp_avg", "exp_avg_sq"}
+
+
+def test_pretrained_weight_helpers_of_the_reference(tmp_path):
+    """utils/initialization.py:29-105 as run/train.py:93-100 and scripts/run_train.sh use them: fetch / overload the embedding (the
+    Parameter is replaced, so lm_head keeps the old tensor; freeze takes only the new embedding out of training), fetch / overload
+    a denoiser state_dict (only keys the model has), newest .pt of the newest sub-directory."""
+    import argparse
+    import os
+    import time
+    from types import SimpleNamespace
+
+    from musediffusion_amd.models.network import TransformerNetModel
+    from musediffusion_amd.utils import initialization as ini
+    m = TransformerNetModel(16, 16, 16, 40, 8, bert_hidden=32, bert_layers=1, bert_heads=2, bert_ffn=64)
+    emb = torch.nn.Embedding(40, 16)
+    torch.save(emb.state_dict(), tmp_path / "emb.pt")
+    args = SimpleNamespace(pretrained_embedding=str(tmp_path / "emb.pt"), hidden_dim=24, freeze_embedding=True, pretrained_denoiser="")
+    with pytest.warns(UserWarning):
+        w = ini.fetch_pretrained_embedding(args)
+    assert args.hidden_dim == 16 and torch.equal(w, emb.weight)        # the file's width overwrites the config's
+    with pytest.raises(argparse.ArgumentTypeError):
+        ini.fetch_pretrained_embedding(SimpleNamespace(pretrained_embedding="", hidden_dim=16, freeze_embedding=True))
+    assert ini.fetch_pretrained_embedding(SimpleNamespace(pretrained_embedding="", hidden_dim=16, freeze_embedding=False)) is None
+    old = m.word_embedding.weight
+    assert ini.overload_embedding(m, w, True) is m
+    assert torch.equal(m.word_embedding.weight, emb.weight) and not m.word_embedding.weight.requires_grad
+    assert m.lm_head.weight is old and old.requires_grad               # the head keeps the OLD tensor and keeps training
+    assert {"word_embedding.weight", "lm_head.weight"} <= {n for n, _ in m.named_parameters()}
+    with pytest.raises(AssertionError):
+        ini.overload_embedding(m, torch.zeros(41, 16), False)
+    assert ini.fetch_pretrained_denoiser(args) is None
+    sd = {"time_embed.0.bias": torch.full((64,), 0.5), "not.a.key": torch.zeros(3)}
+    torch.save(sd, tmp_path / "den.pt")
+    got = ini.fetch_pretrained_denoiser(SimpleNamespace(pretrained_denoiser=str(tmp_path / "den.pt")))
+    before = m.time_embed[2].bias.detach().clone()
+    assert ini.overload_denoiser(m, got) is m
+    assert float(m.time_embed[0].bias.min()) == 0.5 and torch.equal(m.time_embed[2].bias, before)
+    # get_latest_model_path: newest sub-directory, newest .pt in it
+    assert ini.get_latest_model_path(str(tmp_path / "none")) is None
+    base = tmp_path / "runs"
+    for i, d in enumerate(("a", "b")):
+        os.makedirs(base / d)
+        for j, f in enumerate(("model_000001.pt", "model_000002.pt", "notes.txt")):
+            (base / d / f).write_text("x")
+            os.utime(base / d / f, (time.time() + 10 * i + j, time.time() + 10 * i + j))
+        os.utime(base / d, (time.time() + 100 * i, time.time() + 100 * i))
+    assert ini.get_latest_model_path(str(base)) == str(base / "b" / "model_000002.pt")
+    os.makedirs(base / "c")
+    os.utime(base / "c", (time.time() + 1000, time.time() + 1000))
+    assert ini.get_latest_model_path(str(base)) is None                # the newest directory holds no checkpoint

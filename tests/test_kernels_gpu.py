@@ -97,7 +97,17 @@ def test_gemm_bias_act(case, dtype, glds):
     M, N, K, act, use_res, out_f32 = case
     if dtype == MH_F32 and glds:
         pytest.skip("kernel variants exist for bf16 only")
-    lib().mh_gemm_set_variant(glds)
+    # the default kernel choice (2) is tested in the production library; the alternatives need the debug build's switch
+    import contextlib
+    from musediffusion_amd import _lib as L_
+    with (L_.debug_library() if glds != 2 else contextlib.nullcontext()):
+        _gemm_bias_act_case(case, dtype, glds)
+
+
+def _gemm_bias_act_case(case, dtype, glds):
+    M, N, K, act, use_res, out_f32 = case
+    if glds != 2:
+        lib().mh_gemm_set_variant(glds)
     try:
         A = rnd(M, K, seed=10, scale=0.5)
         W = rnd(N, K, seed=11, scale=1.0 / math.sqrt(K))
@@ -116,7 +126,8 @@ def test_gemm_bias_act(case, dtype, glds):
             atol += 2e-3  # fp32 accumulation-order noise on top of the output rounding
         assert_close(out, ref, atol, rtol, what="gemm %s" % (case,))
     finally:
-        lib().mh_gemm_set_variant(2)
+        if glds != 2:
+            lib().mh_gemm_set_variant(2)
 
 
 @pytest.mark.parametrize("dtype", [MH_F32, MH_BF16], ids=["f32", "bf16"])
@@ -185,14 +196,16 @@ def test_attention_stream(dh, L, B, nh):
     check(lib().mh_attention_stream_fwd(qd.data_ptr(), kd.data_ptr(), vt_dev.data_ptr(), out.data_ptr(), nh * dh, 0, B, L, nh, dh,
                                         scale, current_stream()))
     assert_close(out, ref, 2e-2, what="attention_stream dh=%d L=%d" % (dh, L))
-    lib().mh_attention_set_stream(2)          # 8-wave / 128-key-stage blocks: same arithmetic per query tile, same bits
-    try:
-        out2 = torch.zeros_like(out)
-        check(lib().mh_attention_stream_fwd(qd.data_ptr(), kd.data_ptr(), vt_dev.data_ptr(), out2.data_ptr(), nh * dh, 0, B, L, nh, dh,
-                                            scale, current_stream()))
-        assert torch.equal(out2, out)
-    finally:
-        lib().mh_attention_set_stream(1)
+    from musediffusion_amd import _lib as L_
+    with L_.debug_library():      # (the geometry switch lives in the debug build; everything else here runs the production library)
+        lib().mh_attention_set_stream(2)          # 8-wave / 128-key-stage blocks: same arithmetic per query tile, same bits
+        try:
+            out2 = torch.zeros_like(out)
+            check(lib().mh_attention_stream_fwd(qd.data_ptr(), kd.data_ptr(), vt_dev.data_ptr(), out2.data_ptr(), nh * dh, 0, B, L, nh, dh,
+                                                scale, current_stream()))
+            assert torch.equal(out2, out)
+        finally:
+            lib().mh_attention_set_stream(1)
     outp = torch.zeros(nh * dh // 32, B * L, 32, device=DEV, dtype=torch.bfloat16)
     check(lib().mh_attention_stream_fwd(qd.data_ptr(), kd.data_ptr(), vt_dev.data_ptr(), outp.data_ptr(), B * L, 1, B, L, nh, dh,
                                         scale, current_stream()))
@@ -539,7 +552,7 @@ def test_gemm_panel_layouts(case):
 
 
 @pytest.mark.parametrize("variant", [3, 4, 5])
-def test_gemm_big_tile_variants(variant):
+def test_gemm_big_tile_variants(variant, dbg_lib):
     """both big-tile configurations (256x128 / 256x256) against the fp32 matmul of the bf16-rounded operands"""
     lib().mh_gemm_set_variant(variant)
     try:
@@ -569,13 +582,16 @@ def test_gemm_big_tile_variants(variant):
 @pytest.mark.parametrize("panel", [0, 1])
 def test_gemm_bias_residual_layernorm(N, panel, rows64):
     """dense + residual + LayerNorm in one kernel == the three separate steps (BertSelfOutput / BertOutput); rows64: the 64-row
-    full-row tile (twice the blocks; selectable with mh_gemm_set_plain_stores bit 16)"""
-    from musediffusion_amd._lib import check, current_stream
-    lib().mh_gemm_set_plain_stores(16 if rows64 else 0)
-    try:
-        _gemm_bias_residual_layernorm(N, panel)
-    finally:
-        lib().mh_gemm_set_plain_stores(0)
+    full-row tile (twice the blocks; selectable with the debug library's mh_gemm_set_plain_stores bit 16)"""
+    from musediffusion_amd import _lib as L_
+    if not rows64:
+        return _gemm_bias_residual_layernorm(N, panel)
+    with L_.debug_library():
+        lib().mh_gemm_set_plain_stores(16)
+        try:
+            _gemm_bias_residual_layernorm(N, panel)
+        finally:
+            lib().mh_gemm_set_plain_stores(0)
 
 
 def _gemm_bias_residual_layernorm(N, panel):

@@ -103,3 +103,107 @@ def test_resume_from_a_checkpoint_the_reference_wrote():
     m.eval().requires_grad_(False)
     y = m(torch.from_numpy(f["x"]).to(DEV), torch.from_numpy(f["t"]).to(DEV)).cpu().numpy()
     assert float(np.abs(y - f["y"]).max()) < 1e-4
+
+
+def test_parameters_without_a_gradient_are_skipped_like_torch_adamw():
+    """torch.optim.AdamW (train_util.py:95) skips `p.grad is None`; update_ema (:21-31) does not.  A frozen tensor (requires_grad
+    False) and one the backward never reached: values untouched, no optimizer state, nothing in the norm, the clip leaves them, their
+    EMA copies still take the EMA step; a gradient at an address that is not 16-byte aligned is served too."""
+    g = torch.Generator().manual_seed(3)
+    shapes = [(300, 7), (70001,), (64, 64), (5,)]
+    cpu = [torch.nn.Parameter(torch.randn(*s, generator=g)) for s in shapes]
+    dev = [torch.nn.Parameter(p.detach().clone().to(DEV)) for p in cpu]
+    cpu[0].requires_grad_(False); dev[0].requires_grad_(False)
+    rates = (0.9,)
+    ref = torch.optim.AdamW(cpu, lr=1e-3, weight_decay=0.01)
+    ref_ema = [p.detach().clone() for p in cpu]
+    opt = FusedAdamWEMA(dev, lr=1e-3, weight_decay=0.01, ema_rates=rates)
+    with pytest.raises(RuntimeError):
+        opt.step()                                         # nothing has a gradient yet
+    for step in range(3):
+        for i in (1, 2):                                   # tensor 3 never gets one, tensor 0 is frozen
+            gr = torch.randn(*shapes[i], generator=g)
+            cpu[i].grad = gr.clone()
+            if i == 1:                                     # a view 4 bytes into a larger buffer: not 16-byte aligned
+                buf = torch.empty(gr.numel() + 1, device=DEV)
+                buf[1:].copy_(gr)
+                dev[i].grad = buf[1:]
+                assert dev[i].grad.data_ptr() % 16 != 0
+            else:
+                dev[i].grad = gr.clone().to(DEV)
+        norm_ref = float(torch.sqrt(sum((cpu[i].grad ** 2).sum() for i in (1, 2))))
+        assert abs(float(opt.clip_grad_norm(0.5)) - norm_ref) < 1e-3 * norm_ref
+        torch.nn.utils.clip_grad_norm_(cpu, 0.5)
+        v_frozen, v_live = dev[0]._version, dev[1]._version
+        ref.step()
+        for t, s in zip(ref_ema, cpu):
+            t.mul_(rates[0]).add_(s.detach(), alpha=1 - rates[0])
+        opt.step()
+        assert dev[0]._version == v_frozen and dev[1]._version > v_live
+        for p, q in zip(cpu, dev):
+            assert torch.allclose(q.detach().cpu(), p.detach(), rtol=2e-6, atol=2e-7)
+        for a, b in zip(ref_ema, opt.ema[0]):
+            assert torch.allclose(b.cpu(), a, rtol=2e-6, atol=2e-7)
+    assert torch.equal(dev[0].detach().cpu(), cpu[0].detach()) and torch.equal(dev[3].detach().cpu(), cpu[3].detach())
+    assert sorted(opt.state_dict()["state"]) == sorted(ref.state_dict()["state"]) == [1, 2]
+
+
+def test_overload_embedding_freeze_and_one_step_match_the_reference():
+    """tests/golden/overload_freeze_tiny.npz (tools/make_golden.py overload): the reference's model after overload_embedding with
+    freeze_embedding (utils/initialization.py:54-68), its training_losses, backward, one torch.optim.AdamW step and update_ema.
+    Here: the same helpers, TrainStep over the fused optimizer.  The embedding stays put (and out of the optimizer state), the
+    UNTIED lm_head.weight trains, EMA copies of every parameter - the frozen one included - match; the EMA checkpoint keeps
+    the two tensors apart."""
+    from conftest import load_golden
+    from musediffusion_amd.models.diffusion import SpacedDiffusion, get_named_beta_schedule, space_timesteps
+    from musediffusion_amd.models.network import TransformerNetModel
+    from musediffusion_amd.train_step import TrainStep
+    from musediffusion_amd.utils.initialization import overload_embedding
+    from oracle import fixtures as fx
+    from test_training_gpu import CpuDraws, close
+    g = load_golden("overload_freeze_tiny.npz")
+    tag = "tiny"
+    c = fx.CONFIGS[tag]
+    m = TransformerNetModel(c["E"], c["E"], c["Tt"], c["V"], c["L"], dropout=0.0, bert_hidden=c["H"], bert_layers=c["nL"], bert_heads=c["nh"],
+                            bert_ffn=c["F"], compute_dtype="fp32", bert_hidden_dropout=0.0, bert_attention_dropout=0.0)
+    m.load_state_dict(fx.state_dict(tag))
+    overload_embedding(m, torch.from_numpy(g["emb"]).clone(), True)
+    m.train().to(DEV)
+    assert [n for n, _ in m.named_parameters()] == list(g["param_names"])
+    diff = SpacedDiffusion(use_timesteps=space_timesteps(2000, [2000]), betas=get_named_beta_schedule("sqrt", 2000),
+                           rescale_timesteps=True, predict_xstart=True)
+    li = fx.loss_inputs(tag)
+    t_fix, w_fix = li["t"], li["w"]
+
+    class FixedSampler:
+        def sample(self, n, device):
+            return t_fix.to(device), w_fix.to(device)
+    lr, wd, rate = float(g["lr"]), float(g["wd"]), float(g["ema_rate"])
+    ts = TrainStep(m, diff, microbatch=-1, lr=lr, weight_decay=wd, ema_rate=rate, schedule_sampler=FixedSampler())
+    with CpuDraws(fx.loss_seed(tag)):
+        losses = ts.forward_backward(dict(li["batch"]))
+    for k in ("mse", "nll", "loss"):
+        close(k, losses[k], float((torch.from_numpy(g[k]) * w_fix).mean()), 5e-4)
+    by = dict(m.named_parameters())
+    watch = {"lmw": "lm_head.weight", "lmb": "lm_head.bias", "q0": "input_transformers.layer.0.attention.self.query.weight",
+             "te0": "time_embed.0.weight", "ff2": "input_transformers.layer.0.output.dense.weight", "pos": "position_embeddings.weight"}
+    assert m.word_embedding.weight.grad is None
+    for k, n in watch.items():
+        close("grad " + n, by[n].grad, g["g_" + k], 2e-3)
+    ts.optimize()
+    names = list(g["param_names"])
+    for k, n in watch.items():
+        # one AdamW step moves a weight by ~lr whatever the gradient's size: compare the MOVE, within 2 % of lr (sign(g) is what
+        # the first step applies; elements whose reference gradient is ~0 are the ones a 2e-3 gradient error can flip)
+        p1, ref = by[n].detach().cpu(), torch.from_numpy(g["p_" + k])
+        big = torch.from_numpy(np.abs(g["g_" + k]) > 0.05 * np.abs(g["g_" + k]).max())
+        assert float((p1 - ref)[big].abs().max()) < 0.02 * lr, n
+        e1, eref = ts.opt.ema[0][names.index(n)].cpu(), torch.from_numpy(g["ema_" + k])
+        assert float((e1 - eref)[big].abs().max()) < 0.02 * lr, n
+    wi = int(g["word_index"])
+    assert torch.equal(m.word_embedding.weight.cpu(), torch.from_numpy(g["p_word"]))
+    assert torch.equal(ts.opt.ema[0][wi].cpu(), torch.from_numpy(g["ema_word"]))         # update_ema of an unchanged tensor, bit for bit
+    assert sorted(ts.opt.state_dict()["state"]) == list(g["opt_state_keys"])
+    esd = ts.opt.ema_state_dict(0, m)
+    assert esd["lm_head.weight"].data_ptr() != esd["word_embedding.weight"].data_ptr()
+    assert torch.equal(esd["lm_head.weight"], ts.opt.ema[0][names.index("lm_head.weight")])

@@ -238,3 +238,42 @@ def test_training_losses_with_dropout_masks(tag):
     np.testing.assert_allclose((y[:, ::8] if big else y).numpy(), g["fwd_y_train"], rtol=0, atol=2e-5)
     # and the masks matter: eval-mode output differs
     assert float((odn.forward(sd, inp["fwd_x"], inp["fwd_t"], cfg["nh"]) - y).abs().max()) > 1e-2
+
+
+def test_overload_embedding_with_frozen_embedding_and_one_optimizer_step():
+    """The reference's pretrained-embedding start (utils/initialization.py:54-68 with freeze_embedding, then train_util.py:246-254):
+    the oracle's losses and gradients with the head UNTIED from the replaced embedding, then torch.optim.AdamW's rule restated in
+    numpy-style torch ops for the parameters that have a gradient, update_ema for all of them."""
+    g = load_golden("overload_freeze_tiny.npz")
+    tag = "tiny"
+    cfg = fx.CONFIGS[tag]
+    li = fx.loss_inputs(tag)
+    batch, t, w = li["batch"], li["t"], li["w"]
+    d = osc.make_diffusion()
+    sd = {k: v.clone() for k, v in fx.state_dict(tag).items()}
+    sd["lm_head.weight"] = sd["word_embedding.weight"].clone()          # the old embedding tensor stays the head's weight
+    sd["word_embedding.weight"] = torch.from_numpy(g["emb"]).clone()    # the pretrained table; frozen
+    watch = {"lmw": "lm_head.weight", "lmb": "lm_head.bias", "q0": "input_transformers.layer.0.attention.self.query.weight",
+             "te0": "time_embed.0.weight", "ff2": "input_transformers.layer.0.output.dense.weight", "pos": "position_embeddings.weight"}
+    for n in watch.values():
+        sd[n].requires_grad_(True)
+    torch.manual_seed(fx.loss_seed(tag))
+    terms = olo.training_losses(d, lambda x, ts: odn.forward(sd, x, ts, cfg["nh"]), lambda ids: odn.get_embeds(sd, ids),
+                                lambda h: odn.get_logits(sd, h), t, batch["input_ids"], batch["input_mask"], correct_ids=batch["correct_ids"])
+    for k in ("mse", "nll", "loss"):
+        np.testing.assert_allclose(terms[k].detach().numpy(), g[k], rtol=2e-5, atol=2e-5)
+    (terms["loss"] * w).mean().backward()
+    lr, wd, rate = float(g["lr"]), float(g["wd"]), float(g["ema_rate"])
+    for k, n in watch.items():
+        np.testing.assert_allclose(sd[n].grad.numpy(), g["g_" + k], rtol=1e-3, atol=2e-6, err_msg=k)
+        # torch.optim.AdamW, first step (zero moments): p (1 - lr wd) - lr / (1 - b1) * m / (sqrt(v) / sqrt(1 - b2) + eps)
+        p0, gr = sd[n].detach(), torch.from_numpy(g["g_" + k])
+        m, v = 0.1 * gr, 0.001 * gr * gr
+        p1 = p0 * (1 - lr * wd) - (lr / (1 - 0.9)) * (m / (v.sqrt() / (1 - 0.999) ** 0.5 + 1e-8))
+        np.testing.assert_allclose(p1.numpy(), g["p_" + k], rtol=2e-6, atol=2e-7, err_msg=k)
+        np.testing.assert_allclose((p0 * rate + p1 * (1 - rate)).numpy(), g["ema_" + k], rtol=2e-6, atol=2e-7, err_msg=k)
+    # the frozen embedding: no optimizer state, value untouched, EMA copy = update_ema of an unchanged parameter
+    assert int(g["word_index"]) not in set(g["opt_state_keys"].tolist())
+    np.testing.assert_array_equal(g["p_word"], g["emb"])
+    e = torch.from_numpy(g["emb"])
+    np.testing.assert_array_equal(g["ema_word"], e.clone().mul_(rate).add_(e, alpha=1 - rate).numpy())

@@ -26,7 +26,7 @@ def rnd(*shape, seed=0, scale=1.0):
 
 
 @pytest.mark.parametrize("K,M,N,colsum", [(8192, 2048, 512, 1), (8192, 512, 2048, 1), (4096, 1536, 512, 0), (4096, 512, 256, 1)])
-def test_gemm_dw_wide_and_narrow_tiles_agree(K, M, N, colsum):
+def test_gemm_dw_wide_and_narrow_tiles_agree(K, M, N, colsum, dbg_lib):
     A = rnd(K, M, seed=901, scale=0.5).to(DEV).bfloat16().contiguous()
     B = rnd(K, N, seed=902, scale=0.5).to(DEV).bfloat16().contiguous()
     outs = []
@@ -50,7 +50,7 @@ def test_gemm_dw_wide_and_narrow_tiles_agree(K, M, N, colsum):
     assert torch.allclose(outs[0][1], outs[1][1], rtol=1e-5, atol=1e-4)
 
 
-def test_row_major_gemm_takes_the_wide_tile_with_the_same_result():
+def test_row_major_gemm_takes_the_wide_tile_with_the_same_result(dbg_lib):
     M, N, K = 16384, 1024, 256            # 64 x 4 = 256 wide tiles: one per CU, so the automatic rule switches
     A = rnd(M, K, seed=903, scale=0.5).to(DEV).bfloat16()
     W = (rnd(N, K, seed=904) / math.sqrt(K)).to(DEV).bfloat16()
@@ -203,7 +203,7 @@ def test_dense_site_keep_flags_follow_the_documented_rule():
     assert np.array_equal(got, keep.reshape(-1))
 
 
-def test_training_epilogues_on_the_wide_tile_match_the_narrow_tile():
+def test_training_epilogues_on_the_wide_tile_match_the_narrow_tile(dbg_lib):
     """The tape's full-batch launches take the 256 x 256 tile (auto rule: row-major operands, every CU gets a tile); its epilogue
     variants - stored GELU derivative, multiply-by-derivative, dropout + residual - must give what the 256 x 128 tile gives, bit for bit
     (same K order per output element, same Philox element numbering)."""

@@ -142,3 +142,59 @@ def test_optimize_clips_through_the_optimizer_and_returns_a_copy_of_the_norm():
     g1 = ts.optimize()
     g2 = ts.optimize()
     assert opt.clipped == [0.5, 0.5] and float(g1) == 1.0 and float(g2) == 2.0 and g1.data_ptr() != opt.buf.data_ptr()
+
+
+def test_clip_falls_back_to_torch_when_the_optimizer_has_no_clip_and_zero_ema_rate_means_none():
+    """train_util.py:255-264: an optimizer without `clip_grad_norm` gets torch.nn.utils.clip_grad_norm_; :63-67: a falsy ema_rate
+    (0.0, '', None) is the empty list."""
+    torch.manual_seed(1)
+    model = torch.nn.Linear(3, 1)
+    ts = TrainStep(model, ToyDiffusion(), gradient_clipping=0.25, ema_rate=0.0, optimizer=HostOpt(list(model.parameters())))
+    assert ts.ema_rate == []
+    assert TrainStep(model, ToyDiffusion(), ema_rate="", optimizer=HostOpt(list(model.parameters()))).ema_rate == []
+    ts.forward_backward({"input_ids": torch.randn(4, 3) * 10})
+    assert float(torch.sqrt(sum((p.grad ** 2).sum() for p in model.parameters()))) > 0.25
+    ts.optimize()
+    assert abs(float(torch.sqrt(sum((p.grad ** 2).sum() for p in model.parameters()))) - 0.25) < 1e-4
+
+
+def test_train_loop_has_the_reference_constructor_cadence_and_files(tmp_path):
+    """utils/train_util.py:34-186: keyword-only constructor as run/train.py:132-151 calls it; run_loop stops after learning_steps,
+    evaluates every eval_interval, saves every save_interval and once more at the end; a second TrainLoop on the same directory
+    resumes from the newest model file (step parsed from its name) and anneals from there."""
+    import inspect
+    import itertools
+    from musediffusion_amd.utils.train_util import TrainLoop, update_ema
+    want = ["model", "diffusion", "data", "batch_size", "microbatch", "lr", "ema_rate", "log_interval", "save_interval", "resume_checkpoint",
+            "schedule_sampler", "weight_decay", "learning_steps", "checkpoint_path", "gradient_clipping", "eval_data", "eval_interval",
+            "eval_callbacks"]
+    sig = inspect.signature(TrainLoop.__init__)
+    assert [n for n in sig.parameters if n != "self"][:len(want)] == want
+    assert all(sig.parameters[n].kind is inspect.Parameter.KEYWORD_ONLY for n in want)
+    torch.manual_seed(0)
+    model = torch.nn.Linear(4, 1)
+    data = ({"input_ids": torch.randn(4, 4)} for _ in itertools.count())
+    logs, evals = [], []
+    mk = lambda m, steps, resume="": TrainLoop(
+        model=m, diffusion=ToyDiffusion(), data=data, batch_size=4, microbatch=2, lr=1.0, ema_rate="0.9", log_interval=2,
+        save_interval=3, resume_checkpoint=resume, schedule_sampler=CountingSampler(), weight_decay=0.0, learning_steps=steps,
+        checkpoint_path=str(tmp_path), gradient_clipping=-1., eval_data=data, eval_interval=4, eval_callbacks=[lambda tl: evals.append(tl.step)],
+        optimizer=HostOpt(list(m.parameters())), log_fn=logs.append)
+    loop = mk(model, 7)
+    assert loop.microbatch == 2 and loop.global_batch == 4 and loop.ema_rate == [0.9] and not loop.use_ddp and loop.resume_step == 0
+    loop.run_loop()
+    assert loop.step == 7 and loop.opt.lrs == [1.0 * (1 - k / 7) for k in range(7)]
+    assert evals == [0, 4]                                             # step % eval_interval == 0
+    assert sorted(os.listdir(tmp_path)) == ["model_000003.pt", "model_000006.pt"]   # steps 3 and 6; (7 - 1) % 3 == 0: no extra save
+    assert any("eval_loss" in d for d in logs) and logs[0]["step"] == 0 and logs[0]["samples"] == 4 and "grad_norm" in logs[0]
+    # resume: newest model file wins over the command-line checkpoint, lr anneals from its step
+    m2 = torch.nn.Linear(4, 1)
+    loop2 = mk(m2, 9, resume=str(tmp_path / "model_000003.pt"))
+    assert loop2.resume_step == 6 and all(torch.equal(a, b) for a, b in zip(m2.state_dict().values(), model.state_dict().values()))
+    loop2.run_loop()
+    assert loop2.step == 3 and loop2.opt.lrs == [1.0 * (1 - (6 + k) / 9) for k in range(3)]
+    assert "model_000009.pt" in os.listdir(tmp_path)                   # (step - 1) % save_interval != 0 -> the closing save
+    assert TrainLoop.parse_resume_step_from_filename("x/model_000123.pt") == 123
+    a, b = [torch.ones(2)], [torch.zeros(2)]
+    update_ema(a, b, rate=0.75)
+    assert torch.allclose(a[0], torch.full((2,), 0.75))

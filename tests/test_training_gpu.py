@@ -487,7 +487,7 @@ def test_bf16_fused_training_at_seq_len_1024_against_oracle():
     assert worst[0] > 0.99, worst
 
 
-def test_full_size_training_step_is_invariant_to_the_tile_choice():
+def test_full_size_training_step_is_invariant_to_the_tile_choice(dbg_lib):
     """The benchmarked training shape (BASELINE config 5 per GPU: 32 sequences x seq_len 1024, d_model 512, 12 layers, bf16, dropout 0.1)
     is the only place where the tape's GEMMs take the 256 x 256 tile and the weight-gradient GEMM its 8-wave variant.  Every such form is
     bit-identical with the 256 x 128 form per kernel (tests/test_round3_kernels_gpu.py), so the WHOLE step must be: the same losses and

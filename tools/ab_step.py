@@ -15,6 +15,7 @@ BASE = ["bench.py", "--steps", "40", "--warmup", "5", "--no-cpu-baseline", "--no
 sys.argv = list(BASE)
 import bench  # noqa: E402
 from musediffusion_amd import _lib  # noqa: E402
+_lib.use_debug_library()   # the A/B switches live in libmusehip_dbg.so (include/musehip_dbg.h)
 
 setters = {"gemm_debug": lambda v: _lib.lib().mh_gemm_set_debug(v), "plain_stores": lambda v: _lib.lib().mh_gemm_set_plain_stores(v), "fuse_ln": lambda v: _lib.lib().mh_denoiser_set_fuse_ln(v),
            "v3_fuse_ln": lambda v: (_lib.lib().mh_gemm_set_variant(3), _lib.lib().mh_denoiser_set_fuse_ln(v)),

@@ -16,6 +16,7 @@ from musediffusion_amd import training  # noqa: E402
 
 if KNOB in ("stagger", "dw_wide", "gemm_variant", "auto_wide"):      # library knobs: python tools/ab_train.py stagger 0 -500 -1500 1500 | dw_wide 0 1
     from musediffusion_amd import _lib
+    _lib.use_debug_library()   # the A/B switches live in libmusehip_dbg.so (include/musehip_dbg.h)
     vals = VALS
     for rnd in range(3):
         for v in vals:

@@ -4,6 +4,7 @@ import argparse, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from musediffusion_amd import _lib, ops  # noqa: E402
+_lib.use_debug_library()   # the A/B switches live in libmusehip_dbg.so (include/musehip_dbg.h)
 ap = argparse.ArgumentParser()
 ap.add_argument("--B", type=int, default=64); ap.add_argument("--L", type=int, default=512)
 ap.add_argument("--nh", type=int, default=8); ap.add_argument("--dh", type=int, default=64)

@@ -10,6 +10,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from musediffusion_amd import _lib  # noqa: E402
+_lib.use_debug_library()   # the A/B switches live in libmusehip_dbg.so (include/musehip_dbg.h)
 from musediffusion_amd._lib import check, current_stream, lib, ptr  # noqa: E402
 
 B, L, nh, dh = 32, 1024, 8, 64

@@ -1,6 +1,7 @@
 import sys, os, math, torch, ctypes as C
 sys.path.insert(0, os.getcwd())
 from musediffusion_amd import _lib
+_lib.use_debug_library()   # the A/B switches live in libmusehip_dbg.so (include/musehip_dbg.h)
 from musediffusion_amd._lib import check, current_stream, lib, ptr
 B, L, nh, dh = 32, 1024, 8, 64
 H = nh * dh

@@ -8,6 +8,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from musediffusion_amd import _lib  # noqa: E402
+_lib.use_debug_library()   # the A/B switches live in libmusehip_dbg.so (include/musehip_dbg.h)
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--variant", type=int, default=2)

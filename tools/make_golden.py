@@ -309,6 +309,60 @@ def gen_losses_dropout(tag, slim=False):
     print("losses_%s_dropout.npz" % tag, len(out), "arrays")
 
 
+def gen_overload_freeze(tag="tiny"):
+    """The reference's pretrained-embedding start (run/train.py:93-95 -> utils/initialization.py:54-68, config/train.py:67-68
+    `freeze_embedding`) followed by one optimizer step of its TrainLoop (train_util.py:246-254: torch.optim.AdamW.step, then
+    update_ema over every master parameter), on the reference's own model / diffusion classes.
+    `overload_embedding` itself cannot be imported here (its first statement imports utils/dist_util.py, which needs `blobfile`),
+    so its three effective statements are applied to the reference's model object verbatim in effect:
+    `model.word_embedding.weight = Parameter(emb_weight)`; `model.word_embedding.requires_grad_(False)`.
+    Recorded: losses, gradients (lm_head.weight is a separate trainable Parameter from here on; the new embedding has none),
+    parameters and EMA copies after the step, AdamW's per-parameter state keys."""
+    cfg = fx.CONFIGS[tag]
+    model, diffusion = build(cfg, dropout=0.0)
+    sd = fx.state_dict(tag)
+    model.load_state_dict(sd)
+    emb = fx.seeded_randn(4242, cfg["V"], cfg["E"]) * fx.EMB_STD
+    with torch.no_grad():
+        model.word_embedding.weight = torch.nn.Parameter(emb.clone())
+    model.word_embedding.requires_grad_(False)
+    assert model.lm_head.weight is not model.word_embedding.weight and model.lm_head.weight.requires_grad
+    model.train()
+    names = [n for n, _ in model.named_parameters()]
+    params = list(model.parameters())
+    lr, wd, rate = 1e-3, 0.01, 0.9
+    opt = torch.optim.AdamW(params, lr=lr, weight_decay=wd)
+    ema = [p.detach().clone() for p in params]
+    li = fx.loss_inputs(tag)
+    batch, t, w = li["batch"], li["t"], li["w"]
+    out = {"sd_sha256": np.array(sd_digest(sd)), "emb": npy(emb), "t": npy(t), "loss_w": npy(w), "lr": np.array(lr), "wd": np.array(wd),
+           "ema_rate": np.array(rate), "param_names": np.array(names)}
+    torch.manual_seed(fx.loss_seed(tag))
+    terms = diffusion.training_losses(model, t, model_kwargs=dict(batch))
+    (terms["loss"] * w).mean().backward()
+    for k in ("mse", "nll", "loss"):
+        out[k] = npy(terms[k])
+    assert model.word_embedding.weight.grad is None
+    watch = {"lmw": "lm_head.weight", "lmb": "lm_head.bias", "q0": "input_transformers.layer.0.attention.self.query.weight",
+             "te0": "time_embed.0.weight", "ff2": "input_transformers.layer.0.output.dense.weight", "pos": "position_embeddings.weight"}
+    byname = dict(model.named_parameters())
+    for k, n in watch.items():
+        out["g_" + k] = npy(byname[n].grad)
+    opt.step()
+    for trg, src in zip(ema, params):                       # update_ema, train_util.py:21-31
+        trg.detach().mul_(rate).add_(src, alpha=1 - rate)
+    for k, n in watch.items():
+        out["p_" + k] = npy(byname[n])
+        out["ema_" + k] = npy(ema[names.index(n)])
+    out["p_word"] = npy(model.word_embedding.weight)
+    out["ema_word"] = npy(ema[names.index("word_embedding.weight")])
+    out["opt_state_keys"] = np.array(sorted(opt.state_dict()["state"].keys()))
+    out["word_index"] = np.array(names.index("word_embedding.weight"))
+    np.savez_compressed(os.path.join(OUT, "overload_freeze_%s.npz" % tag), **out)
+    print("overload_freeze_%s.npz" % tag, len(out), "arrays; params without optimizer state:",
+          sorted(set(range(len(params))) - set(opt.state_dict()["state"].keys())))
+
+
 def gen_reference_checkpoint():
     """A checkpoint directory as the REFERENCE writes it (utils/train_util.py:294-319: `th.save(model.state_dict())`,
     `th.save(opt.state_dict())`, one `ema_{rate}_{step:06d}.pt` per rate) from the reference's own model class and
@@ -349,6 +403,8 @@ if __name__ == "__main__":
         gen_model_case("same", compact=False)
         gen_model_case("c1", compact=True)
         gen_losses("tiny")
+    if not only or "overload" in only:
+        gen_overload_freeze("tiny")
     if not only or "dropout" in only:
         gen_losses_dropout("tiny")
     if not only or "bench" in only:
