@@ -5,7 +5,8 @@ Everything here is host arithmetic over T (= a few thousand) float64 numbers, as
 `np.random` run picks the same timesteps.  What differs is the loss-aware sampler's exchange between ranks: the
 reference pads and all-gathers batch sizes, timesteps and losses separately and then reads every element with
 `.item()` (step_sample.py:100-122); here a rank ships its (timesteps, losses) as one [2, max_local_batch] float64
-block in a single all_gather (plus the usual size exchange) and unpacks on the host once.
+block in a single all_gather and the host unpacks it once - later, when the sampler's state is next read, so that the copy to
+the host runs under the backward pass instead of stalling the launch queue between forward and backward.
 """
 import numpy as np
 import torch
@@ -59,31 +60,79 @@ class FixSampler(_TableSampler):
 
 class LossAwareSampler(ScheduleSampler):
     """Samplers that adapt to the training losses.  `update_with_local_losses` makes every rank see every rank's
-    (timestep, loss) pairs in rank order and then applies `update_with_all_losses` - identical state everywhere."""
+    (timestep, loss) pairs in rank order and then applies `update_with_all_losses` - identical state everywhere.
+
+    No host round trip between the forward and the backward (the reference's version, step_sample.py:90-122, runs two
+    all_gathers, `.item()` per element and Python loops right there, every micro-batch): with device tensors the call only ENQUEUES
+    - one packed all_gather (world > 1) and one device -> pinned-host copy of [count, timesteps, losses] - and returns; the host
+    applies `update_with_all_losses` when the state is next read (`weights()` / `sample()` of the next micro-batch, or the
+    `_loss_history` / `_loss_counts` attributes), by which time the copy has finished under the backward pass.  The order of
+    updates and every value are the reference's: nothing reads the state in between."""
+
+    _pending = None
+    _GROUP = 64       # ranks must bring micro-batches whose sizes round up to the same multiple of this (checked after the fact)
 
     def update_with_all_losses(self, ts, losses):
         raise NotImplementedError
 
-    def update_with_local_losses(self, local_ts, local_losses):
-        ts64 = local_ts.detach().to(torch.float64)
-        ls64 = local_losses.detach().to(torch.float64)
-        if not dist.is_initialized() or dist.get_world_size() == 1:
-            self.update_with_all_losses([int(v) for v in ts64.tolist()], ls64.tolist())
+    def _flush(self):
+        """apply the update whose copy was enqueued by the last update_with_local_losses (no-op when there is none)"""
+        pend, self._pending = self._pending, None
+        if pend is None:
             return
-        world, dev, count = dist.get_world_size(), local_ts.device, int(local_ts.numel())
-        counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
-        dist.all_gather(counts, torch.tensor([count], dtype=torch.int64, device=dev))
-        counts = [int(c) for c in counts]
-        block = torch.zeros(2, max(counts), dtype=torch.float64, device=dev)
-        block[0, :count], block[1, :count] = ts64, ls64
-        blocks = [torch.zeros_like(block) for _ in range(world)]
-        dist.all_gather(blocks, block)
+        host, event, world, cap = pend
+        event.synchronize()
+        rows = host.view(world, 1 + 2 * cap).numpy()
         all_ts, all_losses = [], []
-        for blk, n in zip(blocks, counts):
-            host = blk[:, :n].cpu()
-            all_ts.extend(int(v) for v in host[0].tolist())
-            all_losses.extend(host[1].tolist())
+        for r in range(world):
+            n = int(rows[r, 0])
+            if n > cap:
+                raise RuntimeError("loss-aware sampler: rank %d brought %d losses, more than this rank's padded size %d - every rank "
+                                   "must run micro-batches of sizes within the same group of %d" % (r, n, cap, self._GROUP))
+            all_ts.extend(int(v) for v in rows[r, 1:1 + n])
+            all_losses.extend(float(v) for v in rows[r, 1 + cap:1 + cap + n])
         self.update_with_all_losses(all_ts, all_losses)
+
+    def update_with_local_losses(self, local_ts, local_losses):
+        self._flush()                                   # updates apply in call order
+        ts64 = local_ts.detach().to(torch.float64)
+        ls64 = local_losses.detach().to(device=local_ts.device, dtype=torch.float64)
+        world = dist.get_world_size() if dist.is_initialized() else 1
+        count = int(local_ts.numel())
+        if not local_ts.is_cuda:                         # host tensors (CPU tests, gloo): nothing to overlap with
+            if world == 1:
+                self.update_with_all_losses([int(v) for v in ts64.tolist()], ls64.tolist())
+                return
+            counts = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+            dist.all_gather(counts, torch.tensor([count], dtype=torch.int64))
+            counts = [int(c) for c in counts]
+            block = torch.zeros(2, max(counts), dtype=torch.float64)
+            block[0, :count], block[1, :count] = ts64, ls64
+            blocks = [torch.zeros_like(block) for _ in range(world)]
+            dist.all_gather(blocks, block)
+            all_ts, all_losses = [], []
+            for blk, n in zip(blocks, counts):
+                all_ts.extend(int(v) for v in blk[0, :n].tolist())
+                all_losses.extend(blk[1, :n].tolist())
+            self.update_with_all_losses(all_ts, all_losses)
+            return
+        dev = local_ts.device
+        cap = (count + self._GROUP - 1) // self._GROUP * self._GROUP
+        block = torch.zeros(1 + 2 * cap, dtype=torch.float64, device=dev)
+        block[0] = count
+        block[1:1 + count] = ts64
+        block[1 + cap:1 + cap + count] = ls64
+        if world > 1:
+            gathered = torch.empty(world * (1 + 2 * cap), dtype=torch.float64, device=dev)
+            dist.all_gather_into_tensor(gathered, block)     # one collective per micro-batch; stream-ordered under RCCL
+        else:
+            gathered = block
+        host = torch.empty(gathered.shape, dtype=torch.float64).pin_memory()
+        host.copy_(gathered, non_blocking=True)
+        event = torch.cuda.Event()
+        event.record()
+        self._keep = gathered                                # (alive until the copy has run)
+        self._pending = (host, event, world, cap)
 
 
 class LossSecondMomentResampler(LossAwareSampler):
@@ -96,12 +145,37 @@ class LossSecondMomentResampler(LossAwareSampler):
         self.history_per_term = history_per_term
         self.uniform_prob = uniform_prob
         T = diffusion.num_timesteps
-        self._loss_history = np.zeros([T, history_per_term], dtype=np.float64)
-        self._loss_counts = np.zeros([T], dtype=int)
+        self._history = np.zeros([T, history_per_term], dtype=np.float64)
+        self._counts = np.zeros([T], dtype=int)
+
+    # the reference's attribute names; reading them first applies an update that is still on its way from the device
+    @property
+    def _loss_history(self):
+        self._flush()
+        return self._history
+
+    @_loss_history.setter
+    def _loss_history(self, value):
+        self._flush()
+        self._history = value
+
+    @property
+    def _loss_counts(self):
+        self._flush()
+        return self._counts
+
+    @_loss_counts.setter
+    def _loss_counts(self, value):
+        self._flush()
+        self._counts = value
+
+    def _warmed_up(self):
+        """step_sample.py:172-173"""
+        return bool((self._loss_counts == self.history_per_term).all())
 
     def weights(self):
         T = self.diffusion.num_timesteps
-        if (self._loss_counts < self.history_per_term).any():
+        if not self._warmed_up():
             return np.ones([T], dtype=np.float64)
         rms = np.sqrt(np.mean(self._loss_history ** 2, axis=-1))
         rms /= np.sum(rms)
@@ -110,12 +184,12 @@ class LossSecondMomentResampler(LossAwareSampler):
         return rms
 
     def update_with_all_losses(self, ts, losses):
-        window = self._loss_history
+        window, counts = self._history, self._counts
         for t, value in zip(ts, losses):
-            filled = self._loss_counts[t]
+            filled = counts[t]
             if filled < self.history_per_term:
                 window[t, filled] = value
-                self._loss_counts[t] = filled + 1
+                counts[t] = filled + 1
             else:                                   # slide: forget the oldest entry
                 window[t] = np.append(window[t, 1:], value)
 
