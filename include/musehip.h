@@ -590,6 +590,21 @@ int mh_gemm_qkv_vtperm_defer(const void* A, int64_t lda, const void* Wqkv, int64
  * (network.py:141-149), layers = the encoder (network.py:151), tail = down-projection (network.py:153-157).  A batch slice passes a row
  * window of a full-batch buffer (pointer + first_row * 32 elements, ld = the full batch's rows), so head and tail can run once for the
  * whole batch while the encoder layers run per slice on concurrent streams.  Workspace: mh_denoiser_workspace_bytes(m, B, L) of the call. */
+/* Head and tail of the denoiser as one kernel each (bf16 K32-panel operands; d_model 256 / 512; E_pad <= 128), a block owning 64 complete
+ * rows with the [64, d_model] intermediate of the first dense layer kept in LDS (csrc/headtail.hip):
+ *   mh_up_proj_ln_fused:  out = LayerNorm((pos[l] + (tanh(x W0^T + b0) W2^T + b2)) + emb_t[emb_row[b]]) * gamma + beta  - input_up_proj,
+ *     position / time add and the embedding LayerNorm of models/network.py:141-149 (x [B L, E] fp32 row-major, W0 [E_pad / 32][H][32],
+ *     W2 [H / 32][H][32], out bf16 [H / 32][ldo][32]); replaces mh_pack_panel + 2 x mh_gemm_bias_act_ex + mh_add_pos_time_layernorm_panel.
+ *   mh_down_proj_fused:   out = tanh(X W0^T + b0) W2^T + b2  - output_down_proj of models/network.py:153-157 (X bf16 [H / 32][ldx][32],
+ *     W2 [H / 32][E][32], out [rows, E] fp32 row-major); replaces 2 x mh_gemm_bias_act_ex.
+ * ..._supported: 1 when the shape is served (the engine falls back to the separate launches otherwise). */
+int mh_up_proj_ln_fused_supported(int E, int E_pad, int H);
+int mh_down_proj_fused_supported(int E, int H);
+int mh_up_proj_ln_fused(const float* x, int E, int E_pad, const void* w0, const float* b0, const void* w2, const float* b2,
+                        const float* pos, const float* emb_t, const int32_t* emb_row, const float* gamma, const float* beta,
+                        float eps, void* out, int64_t ldo, int B, int L, int H, mh_stream_t stream);
+int mh_down_proj_fused(const void* X, int64_t ldx, const void* w0, const float* b0, const void* w2, const float* b2, float* out,
+                       int64_t rows, int E, int H, mh_stream_t stream);
 int mh_denoiser_phases_supported(const mh_denoiser* m);
 int mh_denoiser_head(const mh_denoiser* m, const float* x, const float* emb_t, const int32_t* emb_row, void* x_out, int64_t ld_out, int B, int L,
                      void* workspace, size_t workspace_bytes, mh_stream_t stream);

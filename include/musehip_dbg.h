@@ -70,6 +70,10 @@ int mh_denoiser_set_prescale_q(int on);
  * MFMAs, 4 no P.V MFMAs, 8 no LDS fragment reads, 16 no stage DMA (built: 1 2 4 6 7 8 16 24 31); 0 = the real kernel */
 int mh_attention_set_ablation(int bits);
 
+/* A/B: 1 (default) = head and tail of the bf16 panel forward as one kernel each (mh_up_proj_ln_fused / mh_down_proj_fused), 0 = the
+ * separate launches of rounds 1-3 */
+int mh_denoiser_set_fuse_headtail(int on);
+
 /* experiment knob (A/B only): co-resident partner blocks of the big-tile GEMMs start `ticks` x 10 ns late */
 int mh_gemm_set_stagger(int ticks);
 

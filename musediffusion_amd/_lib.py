@@ -186,6 +186,10 @@ SIGNATURES = {
     "mh_denoiser_workspace_bytes": (C.c_size_t, [C.POINTER(Denoiser), INT, INT]),
     "mh_time_embed": (INT, [C.POINTER(Denoiser), VP, VP, INT, VP, C.c_size_t, VP]),
     "mh_denoiser_forward": (INT, [C.POINTER(Denoiser), VP, VP, VP, VP, INT, INT, VP, C.c_size_t, VP]),
+    "mh_up_proj_ln_fused_supported": (INT, [INT, INT, INT]),
+    "mh_down_proj_fused_supported": (INT, [INT, INT]),
+    "mh_up_proj_ln_fused": (INT, [VP, INT, INT, VP, VP, VP, VP, VP, VP, VP, VP, VP, F32, VP, I64, INT, INT, INT, VP]),
+    "mh_down_proj_fused": (INT, [VP, I64, VP, VP, VP, VP, VP, I64, INT, INT, VP]),
     "mh_denoiser_phases_supported": (INT, [C.POINTER(Denoiser)]),
     "mh_denoiser_head": (INT, [C.POINTER(Denoiser), VP, VP, VP, VP, I64, INT, INT, VP, C.c_size_t, VP]),
     "mh_denoiser_layers": (INT, [C.POINTER(Denoiser), VP, I64, VP, I64, INT, INT, VP, C.c_size_t, VP]),
@@ -194,6 +198,7 @@ SIGNATURES = {
 
 # include/musehip_dbg.h: exported by libmusehip_dbg.so only (A/B switches, ablation knobs, diagnostics)
 DBG_SIGNATURES = {
+    "mh_denoiser_set_fuse_headtail": (INT, [INT]),
     "mh_attention_set_stream": (INT, [INT]),
     "mh_attention_set_variant": (INT, [INT]),
     "mh_attention_set_profile": (INT, [VP]),

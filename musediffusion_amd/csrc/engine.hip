@@ -307,6 +307,11 @@ int denoiser_run(const mh_denoiser* m, const float* x, const float* emb_t, const
                    : mh_attention_stream_fwd(w.q, w.k, w.vt, w.buf0, N, P, B, L, m->nh, dh, scale, stream);
     };
     if (!(ph.mask & 1) || (m->has_proj && (g_skip & 32))) {
+    } else if (m->has_proj && mh_up_proj_ln_fused_supported(m->E, m->E_pad, H)) {
+      // one kernel: up-projection (both dense layers), + position / time, embedding LayerNorm (csrc/headtail.hip)
+      if ((rc = mh_up_proj_ln_fused(x, m->E, m->E_pad, m->w_up0, m->b_up0, m->w_up2, m->b_up2, m->pos, emb_t, emb_row, m->ln0_g, m->ln0_b,
+                                    m->ln_eps, XH, ldH, B, L, H, stream)))
+        return rc;
     } else if (m->has_proj) {
       if ((rc = mh_pack_panel(x, m->E, w.xin, N, N, m->E, m->E_pad, stream))) return rc;
       if ((rc = gemm(w.xin, N, m->w_up0, H, m->b_up0, nullptr, 0, w.buf0, 0, N, H, m->E_pad, MH_ACT_TANH))) return rc;
@@ -411,6 +416,8 @@ int denoiser_run(const mh_denoiser* m, const float* x, const float* emb_t, const
     if (!(ph.mask & 4)) return MH_OK;
     if (m->has_proj) {
       if (g_skip & 64) return MH_OK;
+      if (mh_down_proj_fused_supported(m->E, H))   // one kernel for both dense layers of the down-projection (csrc/headtail.hip)
+        return mh_down_proj_fused(XT, ldT, m->w_dn0, m->b_dn0, m->w_dn2, m->b_dn2, out, N, m->E, H, stream);
       if ((rc = gemm(XT, ldT, m->w_dn0, H, m->b_dn0, nullptr, 0, w.buf0, 0, N, H, H, MH_ACT_TANH))) return rc;
       return gemm(w.buf0, N, m->w_dn2, m->E, m->b_dn2, nullptr, 0, out, 1, m->E, m->E, H, MH_ACT_NONE);
     }

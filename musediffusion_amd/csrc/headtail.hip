@@ -1,0 +1,372 @@
+// Head and tail of the denoiser as ONE kernel each (bf16 K32-panel path, d_model 256 / 512, E_pad <= 128):
+//
+//   head (network.py:141-149):  x [rows, E] fp32 -> tanh(x W0^T + b0) -> . W2^T + b2 -> (+ pos[l]) + emb_t[b] -> LayerNorm -> bf16 panel rows
+//   tail (network.py:153-157):  X bf16 panel rows -> tanh(X W0^T + b0) -> . W2^T + b2 -> y [rows, E] fp32
+//
+// Before: pack_panel + 2 GEMMs + add-pos-time-LayerNorm (4 launches, the [rows, 512] intermediate written and re-read twice) and
+// 2 GEMMs on tiles whose K or N is 128 (150 - 400 TFLOP/s).  Here a block owns 64 complete rows: the [64, H] intermediate of the
+// first dense layer stays in LDS as the second one's A operand, only the weights stream (L2 -> LDS by LDS-DMA, 3-stage ring of
+// whole K32 steps: H rows x 64 B), and the LayerNorm runs on the fp32 accumulators.
+//
+// Layouts are gemm.hip's: LDS rows of 64 B (one K32 step), 16-byte chunk c of row r at c ^ G[(r >> 2) & 3], G = {0, 2, 3, 1}
+// (conflict-free ds_read_b128 fragments); DMA pieces of 16 rows x 64 B with the swizzle on the SOURCE address; MFMA 16x16x32 bf16
+// issued as D = W_tile . A_tile^T with the W rows of a wave's 64 columns dealt to the MFMA input rows as
+// 32 (jj >> 1) + 8 (p >> 2) + 4 (jj & 1) + (p & 3), so that a lane owns 8 CONSECUTIVE output columns of one row.
+#include "common.h"
+
+namespace {
+
+constexpr int HT_ROWS = 64;                 // token rows per block
+constexpr int HT_SLAB = HT_ROWS * 64;       // bytes of one K32 step of the A operand (64 rows x 64 B)
+// G = {0, 2, 3, 1} as a packed table (no memory lookup)
+__device__ __forceinline__ int ht_g(int x) { return (0x78 >> (2 * x)) & 3; }
+
+struct HeadArgs {
+  const float* x; int64_t rows; int E, E_pad, L;
+  const bf16* w0; const float* b0;      // [E_pad / 32][H][32]
+  const bf16* w2; const float* b2;      // [H / 32][H][32]
+  const float* pos; const float* emb_t; const int32_t* emb_row;
+  const float* gamma; const float* beta; float eps;
+  bf16* out; int64_t ldo;               // [H / 32][ldo][32]
+};
+
+struct TailArgs {
+  const bf16* X; int64_t ldx; int64_t rows; int E;
+  const bf16* w0; const float* b0;      // [H / 32][H][32]
+  const bf16* w2; const float* b2;      // [H / 32][E][32]  (E rows: the down-projection's outputs)
+  float* out;                           // [rows, E] fp32
+};
+
+template <int N> __device__ __forceinline__ void ht_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void ht_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+// one W stage (K32 step kt of a [K / 32][WROWS][32] panel matrix) into an LDS slot: WROWS / 16 pieces dealt over NW waves
+template <int WROWS, int NW>
+__device__ __forceinline__ void ht_issue_w(const bf16* __restrict__ w, int kt, char* slot, int wave, int lane) {
+  constexpr int PIECES = WROWS / 16, PER = (PIECES + NW - 1) / NW;
+  const int rl = lane >> 2, pc = lane & 3, lc = pc ^ ht_g((rl >> 2) & 3);
+#pragma unroll
+  for (int j = 0; j < PER; ++j) {
+    const int p = (wave * PER + j) % PIECES;    // (fewer pieces than waves: the upper waves repeat a piece - same bytes, same address - so every wave's count is the same)
+    const bf16* src = w + ((int64_t)kt * WROWS + p * 16 + rl) * 32 + lc * 8;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)(slot + p * 1024), 16, 0, 0);
+  }
+}
+
+// 16 MFMAs of a wave's 64 x 64 sub-tile for one K32 step: A rows from a 64-row slab, W rows from a ring slot
+__device__ __forceinline__ void ht_kstep(f32x4 (&acc)[4][4], const char* a_slab, const char* w_slot, int a_off, const int (&b_offs)[4]) {
+  bf16x8 a[4], b[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const bf16x8*>(w_slot + b_offs[j]);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const bf16x8*>(a_slab + a_off + i * 1024);
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+}
+
+// K loop over nk K32 steps: A slabs resident in LDS (a_base + kt * HT_SLAB), W streamed through a 3-slot ring.  `issued`: stages the
+// caller already put in flight (0 .. 2, issued as the wave's LAST vector-memory operations).  PER = pieces per wave and stage.
+template <int WROWS, int NW>
+__device__ __forceinline__ void ht_loop(f32x4 (&acc)[4][4], const bf16* __restrict__ w, int nk, const char* a_base, char* ring, int slot_bytes,
+                                        int a_off, const int (&b_offs)[4], int wave, int lane, int issued) {
+  constexpr int PER = (WROWS / 16 + NW - 1) / NW;
+  for (int st = issued; st < 2 && st < nk; ++st) ht_issue_w<WROWS, NW>(w, st, ring + (st % 3) * slot_bytes, wave, lane);
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) ht_wait_vmcnt<PER>(); else ht_wait_vmcnt<0>();    // stage kt has landed (stage kt + 1 may still fly)
+    ht_lgkm0();                                                          // this wave's reads of stage kt - 1 are done
+    __builtin_amdgcn_s_barrier();
+    if (kt + 2 < nk) ht_issue_w<WROWS, NW>(w, kt + 2, ring + ((kt + 2) % 3) * slot_bytes, wave, lane);   // slot of stage kt - 1: free
+    ht_kstep(acc, a_base + kt * HT_SLAB, ring + (kt % 3) * slot_bytes, a_off, b_offs);
+  }
+}
+
+template <int H>
+__global__ __launch_bounds__(H / 64 * 64, H / 256) void head_fused_kernel(const HeadArgs g) {
+  constexpr int NW = H / 64, THREADS = NW * 64, NK2 = H / 32, SLOT = H * 64;
+  constexpr int H1_BYTES = NK2 * HT_SLAB, LDS_BYTES = H1_BYTES + 3 * SLOT;
+  static_assert(LDS_BYTES <= 160 * 1024, "head: LDS");
+  __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
+  char* const h1 = smem;                 // phase 1: the x tile (E_pad / 32 slabs); phase 2: tanh(up0) as A operand (H / 32 slabs)
+  char* const ring = smem + H1_BYTES;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 15, fg = lane >> 4;
+  const int64_t row0 = (int64_t)blockIdx.x * HT_ROWS;
+  const int nk1 = g.E_pad / 32;
+  // the first two weight stages fly while the x tile is converted
+  for (int st = 0; st < 2 && st < nk1; ++st) ht_issue_w<H, NW>(g.w0, st, ring + (st % 3) * SLOT, wave, lane);
+  // x tile: fp32 [64, E] -> bf16 slabs; a thread owns 16-byte chunks (row, 8 columns)
+  for (int c = tid; c < HT_ROWS * (g.E_pad / 8); c += THREADS) {
+    const int row = c / (g.E_pad / 8), ch = c % (g.E_pad / 8), col = ch * 8;
+    int64_t r = row0 + row; if (r >= g.rows) r = g.rows - 1;
+    float v[8];
+    if (col + 8 <= g.E) load8(g.x + r * g.E + col, v);
+    else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = col + e < g.E ? g.x[r * g.E + col + e] : 0.f;
+    }
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
+    *reinterpret_cast<bf16x8*>(h1 + (ch >> 2) * HT_SLAB + row * 64 + (((ch & 3) ^ ht_g((row >> 2) & 3)) << 4)) = o;
+  }
+  const int a_off = fr * 64 + ((fg ^ ht_g((fr >> 2) & 3)) << 4);
+  int b_offs[4];
+#pragma unroll
+  for (int jj = 0; jj < 4; ++jj) {
+    const int row = wave * 64 + 32 * (jj >> 1) + 8 * (fr >> 2) + 4 * (jj & 1) + (fr & 3);
+    b_offs[jj] = row * 64 + ((fg ^ ht_g((row >> 2) & 3)) << 4);
+  }
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // ---- phase 1: [64, E_pad] . W0^T   (the loop's first barrier also publishes the x tile: every wave drains lgkmcnt before it)
+  ht_loop<H, NW>(acc, g.w0, nk1, h1, ring, SLOT, a_off, b_offs, wave, lane, nk1 < 2 ? nk1 : 2);
+  ht_lgkm0();
+  __builtin_amdgcn_s_barrier();           // every wave is done with the x tile and the ring
+  for (int st = 0; st < 2; ++st) ht_issue_w<H, NW>(g.w2, st, ring + (st % 3) * SLOT, wave, lane);   // phase 2's first stages fly under the epilogue
+  // epilogue 1: tanh(acc + b0) -> bf16 -> the A slabs of phase 2.  Lane: row 16 i + fr, columns 64 wave + 32 h + 8 fg + e
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    float bv[8];
+    load8(g.b0 + wave * 64 + 32 * h + 8 * fg, bv);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = 16 * i + fr;
+      bf16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (bf16)tanh_fast(acc[i][2 * h + (e >> 2)][e & 3] + bv[e]);
+      *reinterpret_cast<bf16x8*>(h1 + (2 * wave + h) * HT_SLAB + row * 64 + ((fg ^ ht_g((row >> 2) & 3)) << 4)) = o;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // ---- phase 2: [64, H] . W2^T   (its first barrier publishes the slabs)
+  ht_loop<H, NW>(acc, g.w2, NK2, h1, ring, SLOT, a_off, b_offs, wave, lane, 2);
+  ht_lgkm0();
+  __builtin_amdgcn_s_barrier();           // the ring is idle: its first bytes take the row statistics
+  // ---- epilogue 2: (pos + (acc + b2)) + emb_t, LayerNorm over the row (two passes: in-lane -> 4 lanes -> NW waves through LDS)
+  float* red = reinterpret_cast<float*>(ring);          // [64][NW]
+  const float* trow[4];
+  const float* prow[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int64_t r = row0 + 16 * i + fr; if (r >= g.rows) r = g.rows - 1;
+    const int64_t b = r / g.L, l = r - b * g.L;
+    prow[i] = g.pos + l * H;
+    trow[i] = g.emb_t + (int64_t)(g.emb_row ? g.emb_row[b] : (int)b) * H;
+  }
+  float rs[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int col = wave * 64 + 32 * h + 8 * fg;
+    float bv[8];
+    load8(g.b2 + col, bv);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float p[8], t[8];
+      load8(prow[i] + col, p);
+      load8(trow[i] + col, t);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float v = (p[e] + (acc[i][2 * h + (e >> 2)][e & 3] + bv[e])) + t[e];     // the reference's association: (pos + x) + emb
+        acc[i][2 * h + (e >> 2)][e & 3] = v;
+        rs[i] += v;
+      }
+    }
+  }
+  const float invH = 1.0f / (float)H;
+  float mean[4], rstd[4];
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float v = rs[i];
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      if (fg == 0) red[(16 * i + fr) * NW + wave] = v;
+    }
+    ht_lgkm0();
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) t += red[(16 * i + fr) * NW + w];
+      if (pass == 0) {
+        mean[i] = t * invH;
+        float sq = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { const float d = acc[i][j][r] - mean[i]; sq += d * d; }
+        rs[i] = sq;
+      } else {
+        rstd[i] = 1.0f / sqrtf(t * invH + g.eps);
+      }
+    }
+    ht_lgkm0();
+    __builtin_amdgcn_s_barrier();
+  }
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int col = wave * 64 + 32 * h + 8 * fg;
+    float gv[8], bt[8];
+    load8(g.gamma + col, gv);
+    load8(g.beta + col, bt);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int64_t r = row0 + 16 * i + fr;
+      if (r < g.rows) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (acc[i][2 * h + (e >> 2)][e & 3] - mean[i]) * rstd[i] * gv[e] + bt[e];
+        store8(g.out + ((int64_t)(col >> 5) * g.ldo + r) * 32 + (col & 31), v);
+      }
+    }
+  }
+}
+
+// tail: the block's 64 x H input rows are DMA'd whole into the slab area (they are the A operand of the first dense layer), its
+// tanh output replaces them there, and the E outputs of the second layer are spread over the waves 16 columns each
+// (E = 128 on 8 waves; E_pad = 64: the upper waves repeat the lower ones' columns and do not store).
+template <int H>
+__global__ __launch_bounds__(H / 64 * 64, H / 256) void tail_fused_kernel(const TailArgs g) {
+  constexpr int NW = H / 64, NK = H / 32, SLOT = H * 64;
+  constexpr int H1_BYTES = NK * HT_SLAB, LDS_BYTES = H1_BYTES + 3 * SLOT;
+  __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
+  char* const h1 = smem;
+  char* const ring = smem + H1_BYTES;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 15, fg = lane >> 4;
+  const int64_t row0 = (int64_t)blockIdx.x * HT_ROWS;
+  // A rows: 4 pieces (16 rows x 64 B) per K32 step, NK steps, dealt over the waves; then the first two weight stages
+  {
+    const int rl = lane >> 2, pc = lane & 3, lc = pc ^ ht_g((rl >> 2) & 3);
+    constexpr int PIECES = NK * 4, PER = PIECES / NW;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      const int p = wave * PER + j, kt = p >> 2, rb = (p & 3) * 16;
+      int64_t r = row0 + rb + rl; if (r >= g.rows) r = g.rows - 1;
+      const bf16* src = g.X + ((int64_t)kt * g.ldx + r) * 32 + lc * 8;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(h1 + kt * HT_SLAB + rb * 64), 16, 0, 2);   // nt: read once
+    }
+  }
+  for (int st = 0; st < 2; ++st) ht_issue_w<H, NW>(g.w0, st, ring + (st % 3) * SLOT, wave, lane);
+  const int a_off = fr * 64 + ((fg ^ ht_g((fr >> 2) & 3)) << 4);
+  int b_offs[4];
+#pragma unroll
+  for (int jj = 0; jj < 4; ++jj) {
+    const int row = wave * 64 + 32 * (jj >> 1) + 8 * (fr >> 2) + 4 * (jj & 1) + (fr & 3);
+    b_offs[jj] = row * 64 + ((fg ^ ht_g((row >> 2) & 3)) << 4);
+  }
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  ht_loop<H, NW>(acc, g.w0, NK, h1, ring, SLOT, a_off, b_offs, wave, lane, 2);   // (the A pieces are older than stage 0: its wait covers them)
+  ht_lgkm0();
+  __builtin_amdgcn_s_barrier();
+  // second layer's weight stages: E rows x 64 B each
+  const int E16 = g.E / 16;                       // 16-column groups of the output (8 for E = 128)
+  auto issue2 = [&](int kt) {
+    const int rl = lane >> 2, pc = lane & 3, lc = pc ^ ht_g((rl >> 2) & 3);
+    const int p = wave % E16;
+    const bf16* src = g.w2 + ((int64_t)kt * g.E + p * 16 + rl) * 32 + lc * 8;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)(ring + (kt % 3) * SLOT + p * 1024), 16, 0, 0);
+  };
+  issue2(0);
+  issue2(1);
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    float bv[8];
+    load8(g.b0 + wave * 64 + 32 * h + 8 * fg, bv);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = 16 * i + fr;
+      bf16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (bf16)tanh_fast(acc[i][2 * h + (e >> 2)][e & 3] + bv[e]);
+      *reinterpret_cast<bf16x8*>(h1 + (2 * wave + h) * HT_SLAB + row * 64 + ((fg ^ ht_g((row >> 2) & 3)) << 4)) = o;
+    }
+  }
+  // ---- second layer: wave -> output columns 16 p .. 16 p + 15, p = wave % (E / 16); D[m = 4 fg + r][n = fr]: 4 consecutive columns of row fr
+  const int p2 = wave % E16;
+  const int b2_off = (p2 * 16 + fr) * 64 + ((fg ^ ht_g((fr >> 2) & 3)) << 4);
+  f32x4 y[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) y[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int kt = 0; kt < NK; ++kt) {
+    if (kt + 1 < NK) ht_wait_vmcnt<1>(); else ht_wait_vmcnt<0>();
+    ht_lgkm0();
+    __builtin_amdgcn_s_barrier();                 // (kt = 0: also publishes the tanh slabs)
+    if (kt + 2 < NK) issue2(kt + 2);
+    const bf16x8 b = *reinterpret_cast<const bf16x8*>(ring + (kt % 3) * SLOT + b2_off);
+    bf16x8 a[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const bf16x8*>(h1 + kt * HT_SLAB + a_off + i * 1024);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) y[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, a[i], y[i], 0, 0, 0);
+  }
+  if (wave < E16) {
+    const int col = p2 * 16 + 4 * fg;
+    const f32x4 bv = *reinterpret_cast<const f32x4*>(g.b2 + col);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int64_t r = row0 + 16 * i + fr;
+      if (r < g.rows) *reinterpret_cast<f32x4*>(g.out + r * g.E + col) = y[i] + bv;
+    }
+  }
+}
+
+MH_KNOB(int, g_fuse_headtail, 1);
+
+}  // namespace
+
+#ifdef MH_ABLATE
+extern "C" int mh_denoiser_set_fuse_headtail(int on) {
+  g_fuse_headtail = on != 0;
+  return MH_OK;
+}
+#endif
+
+extern "C" int mh_up_proj_ln_fused_supported(int E, int E_pad, int H) {
+  return g_fuse_headtail && (H == 256 || H == 512) && E_pad % 32 == 0 && E_pad <= 128 && E <= E_pad && E % 4 == 0;
+}
+extern "C" int mh_down_proj_fused_supported(int E, int H) { return g_fuse_headtail && (H == 256 || H == 512) && E % 16 == 0 && E / 16 <= H / 64 && E >= 16; }
+
+extern "C" int mh_up_proj_ln_fused(const float* x, int E, int E_pad, const void* w0, const float* b0, const void* w2, const float* b2,
+                                   const float* pos, const float* emb_t, const int32_t* emb_row, const float* gamma, const float* beta,
+                                   float eps, void* out, int64_t ldo, int B, int L, int H, mh_stream_t stream) {
+  MH_CHECK_ARG(x && w0 && b0 && w2 && b2 && pos && emb_t && gamma && beta && out && B > 0 && L > 0, "up_proj_ln_fused: bad arguments");
+  MH_CHECK_ARG(mh_up_proj_ln_fused_supported(E, E_pad, H), "up_proj_ln_fused: shape E=%d E_pad=%d H=%d not served", E, E_pad, H);
+  HeadArgs g{x, (int64_t)B * L, E, E_pad, L, (const bf16*)w0, b0, (const bf16*)w2, b2, pos, emb_t, emb_row, gamma, beta, eps, (bf16*)out, ldo};
+  const dim3 grid((unsigned)((g.rows + HT_ROWS - 1) / HT_ROWS));
+  mh_prof_note("head rows=%lld E=%d H=%d", (long long)g.rows, E, H);
+  if (H == 512) MH_LAUNCH((head_fused_kernel<512>), grid, dim3(512), 0, (hipStream_t)stream, g);
+  else MH_LAUNCH((head_fused_kernel<256>), grid, dim3(256), 0, (hipStream_t)stream, g);
+  MH_CHECK_LAUNCH();
+  return MH_OK;
+}
+
+extern "C" int mh_down_proj_fused(const void* X, int64_t ldx, const void* w0, const float* b0, const void* w2, const float* b2, float* out,
+                                  int64_t rows, int E, int H, mh_stream_t stream) {
+  MH_CHECK_ARG(X && w0 && b0 && w2 && b2 && out && rows > 0 && ldx >= rows, "down_proj_fused: bad arguments");
+  MH_CHECK_ARG(mh_down_proj_fused_supported(E, H), "down_proj_fused: shape E=%d H=%d not served", E, H);
+  TailArgs g{(const bf16*)X, ldx, rows, E, (const bf16*)w0, b0, (const bf16*)w2, b2, out};
+  const dim3 grid((unsigned)((rows + HT_ROWS - 1) / HT_ROWS));
+  mh_prof_note("tail rows=%lld E=%d H=%d", (long long)rows, E, H);
+  if (H == 512) MH_LAUNCH((tail_fused_kernel<512>), grid, dim3(512), 0, (hipStream_t)stream, g);
+  else MH_LAUNCH((tail_fused_kernel<256>), grid, dim3(256), 0, (hipStream_t)stream, g);
+  MH_CHECK_LAUNCH();
+  return MH_OK;
+}

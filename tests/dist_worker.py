@@ -159,12 +159,14 @@ def case_untied(rank, world, dev):
     Rank 0 overloads, every other rank starts with the default tie: after the packed broadcast every rank must hold rank 0's
     embedding AND rank 0's (different) lm_head.weight, and argmax_tokens - which reads lm_head.weight - must agree everywhere."""
     from musediffusion_amd import sharding
-    from musediffusion_amd.utils.initialization import overload_embedding
     tag = "tiny"
     m, diff, c = build(tag, dev, rank, "fp32")
     emb = fx.seeded_randn(4242, c["V"], c["E"]) * fx.EMB_STD
     if rank == 0:
-        overload_embedding(m, emb.to(dev), False)
+        # what overload_embedding does to the model (utils/initialization.py:61-63; the helper itself ends in a barrier EVERY rank
+        # must reach, and here only rank 0 overloads): the embedding's Parameter is replaced, the head keeps the old tensor
+        with torch.no_grad():
+            m.word_embedding.weight = torch.nn.Parameter(emb.to(dev))
         m.eval().requires_grad_(False)
         assert m.lm_head.weight is not m.word_embedding.weight
     else:

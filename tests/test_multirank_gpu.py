@@ -45,7 +45,7 @@ def test_two_rank_ddp_gradients_match_golden():
 
 
 def test_two_rank_packed_broadcast_ships_an_untied_head():
-    run_ranks("untied")
+    run_ranks("untied", timeout=240)
 
 
 @pytest.mark.parametrize("workload", ["c2", "c4", "train"])
