@@ -18,7 +18,7 @@ ap.add_argument("--rounds", type=int, default=3)
 ap.add_argument("--steps", type=int, default=40)
 ap.add_argument("extra", nargs="*")
 a = ap.parse_args()
-cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", str(a.steps), "--warmup", "5", "--no-cpu-baseline", "--no-kernel-timing",
+cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", str(a.steps), "--warmup", "5", "--no-cpu-baseline", "--no-kernel-timing", "--no-secondary",
        "--workload", a.workload] + a.extra
 res = {"base": [], "new": []}
 for rnd in range(a.rounds):

@@ -8,7 +8,7 @@ TAG=${1:-r02}
 WL=${2:-c2}
 OUT=gpurun_out/${TAG}_${WL}
 mkdir -p $OUT
-B="python3 bench.py --workload $WL --no-cpu-baseline --no-kernel-timing"
+B="python3 bench.py --workload $WL --no-cpu-baseline --no-kernel-timing --no-secondary"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o p -- $B --steps 30 --warmup 3 > $OUT/trace.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_f -o p -- $B --steps 3 --warmup 1 --no-graph > $OUT/pmc_f.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_w -o p -- $B --steps 3 --warmup 1 --no-graph > $OUT/pmc_w.log 2>&1
