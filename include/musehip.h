@@ -371,7 +371,7 @@ typedef struct mh_loop_state {
   uint32_t pos;        /* iteration counter (also the RNG step counter) */
   uint32_t n_steps;
   int32_t cur_t;       /* steps[pos], written by mh_step_begin */
-  uint32_t pad;
+  uint32_t rng_step;   /* mh_step_advance: the iteration number of the step in flight (pos already counts the next one) */
 } mh_loop_state;
 
 /* Reads state->pos, looks up t = steps[pos], writes state->cur_t, emb_row[0..B) = t and
@@ -380,6 +380,11 @@ int mh_step_begin(mh_loop_state* state, const int32_t* steps, const mh_step_coef
                   mh_step_coef* cur_coef, int32_t* emb_row, int B, mh_stream_t stream);
 /* state->pos += 1.  Last node of a captured step. */
 int mh_step_end(mh_loop_state* state, mh_stream_t stream);
+/* mh_step_begin and mh_step_end as ONE first node: looks up the step as mh_step_begin does, stores its iteration number in
+ * state->rng_step (the counter the in-graph noise reads: pass &state->rng_step to mh_trunc_normal) and advances state->pos at once,
+ * so that nothing follows the step's last kernel. */
+int mh_step_advance(mh_loop_state* state, const int32_t* steps, const mh_step_coef* coef_table, mh_step_coef* cur_coef,
+                    int32_t* emb_row, int B, mh_stream_t stream);
 
 /* Thin hipGraph wrappers so the host can capture a sequence of the calls above on `stream` and
  * replay it (hipStreamBeginCapture / EndCapture / GraphInstantiate / GraphLaunch). */
@@ -604,7 +609,24 @@ int mh_up_proj_ln_fused(const float* x, int E, int E_pad, const void* w0, const 
                         const float* pos, const float* emb_t, const int32_t* emb_row, const float* gamma, const float* beta,
                         float eps, void* out, int64_t ldo, int B, int L, int H, mh_stream_t stream);
 int mh_down_proj_fused(const void* X, int64_t ldx, const void* w0, const float* b0, const void* w2, const float* b2, float* out,
-                       int64_t rows, int E, int H, mh_stream_t stream);
+                       float* out_sqnorm /* optional [rows]: |out row|^2 */, int64_t rows, int E, int H, mh_stream_t stream);
+/* mh_denoiser_forward that also writes |out row|^2 per token (the |x_n|^2 of the rounding scores, models/rounding.py:23) - available when
+ * the forward ends in mh_down_proj_fused (mh_denoiser_gives_sqnorm) */
+int mh_denoiser_gives_sqnorm(const mh_denoiser* m);
+int mh_denoiser_forward_sqnorm(const mh_denoiser* m, const float* x, const float* emb_t, const int32_t* emb_row, float* out,
+                               float* out_sqnorm, int B, int L, void* workspace, size_t workspace_bytes, mh_stream_t stream);
+/* Rounding (models/rounding.py:21-28) split for a captured step: mh_round_scores = the exact-fp32 score GEMM of
+ * mh_round_to_embedding_mfma with |x_n|^2 supplied by the caller, leaving the winners of every column slot in pbest / pidx
+ * [n_tokens][mh_round_slots(V)]; mh_step_epilogue_slots = mh_p_sample_epilogue (ddim = 0) / mh_ddim_epilogue (ddim = 1) folding
+ * those slots itself (larger score, then smaller index - the rule of the separate reduce) and optionally writing the index per row.
+ * Together with mh_denoiser_forward_sqnorm: two launches less per batch slice and step.  E % 16 == 0. */
+int mh_round_slots(int V);
+int mh_round_scores(const float* x, const float* x_sqnorm, const float* table_pad, const float* table_norm, float* pbest,
+                    int32_t* pidx, int64_t n_tokens, int E, int V, mh_stream_t stream);
+int mh_step_epilogue_slots(int ddim, const float* x_t, const float* noise, const float* pbest, const int32_t* pidx, int nslots,
+                           const float* table, const mh_step_coef* coef, int coef_per_batch, int clip, const int32_t* mask,
+                           int mask_per_elem, const float* x_start, float* out, float* pred_xstart, float* mean_out,
+                           int32_t* round_idx_out, int B, int64_t per_batch, int E, mh_stream_t stream);
 int mh_denoiser_phases_supported(const mh_denoiser* m);
 int mh_denoiser_head(const mh_denoiser* m, const float* x, const float* emb_t, const int32_t* emb_row, void* x_out, int64_t ld_out, int B, int L,
                      void* workspace, size_t workspace_bytes, mh_stream_t stream);

@@ -33,7 +33,7 @@ class StepCoef(C.Structure):
 
 class LoopState(C.Structure):
     """mh_loop_state"""
-    _fields_ = [("pos", C.c_uint32), ("n_steps", C.c_uint32), ("cur_t", C.c_int32), ("pad", C.c_uint32)]
+    _fields_ = [("pos", C.c_uint32), ("n_steps", C.c_uint32), ("cur_t", C.c_int32), ("rng_step", C.c_uint32)]
 
 
 class OptHParams(C.Structure):
@@ -189,7 +189,13 @@ SIGNATURES = {
     "mh_up_proj_ln_fused_supported": (INT, [INT, INT, INT]),
     "mh_down_proj_fused_supported": (INT, [INT, INT]),
     "mh_up_proj_ln_fused": (INT, [VP, INT, INT, VP, VP, VP, VP, VP, VP, VP, VP, VP, F32, VP, I64, INT, INT, INT, VP]),
-    "mh_down_proj_fused": (INT, [VP, I64, VP, VP, VP, VP, VP, I64, INT, INT, VP]),
+    "mh_down_proj_fused": (INT, [VP, I64, VP, VP, VP, VP, VP, VP, I64, INT, INT, VP]),
+    "mh_denoiser_gives_sqnorm": (INT, [C.POINTER(Denoiser)]),
+    "mh_denoiser_forward_sqnorm": (INT, [C.POINTER(Denoiser), VP, VP, VP, VP, VP, INT, INT, VP, C.c_size_t, VP]),
+    "mh_round_slots": (INT, [INT]),
+    "mh_round_scores": (INT, [VP, VP, VP, VP, VP, VP, I64, INT, INT, VP]),
+    "mh_step_epilogue_slots": (INT, [INT, VP, VP, VP, VP, INT, VP, VP, INT, INT, VP, INT, VP, VP, VP, VP, VP, INT, I64, INT, VP]),
+    "mh_step_advance": (INT, [VP, VP, VP, VP, VP, INT, VP]),
     "mh_denoiser_phases_supported": (INT, [C.POINTER(Denoiser)]),
     "mh_denoiser_head": (INT, [C.POINTER(Denoiser), VP, VP, VP, VP, I64, INT, INT, VP, C.c_size_t, VP]),
     "mh_denoiser_layers": (INT, [C.POINTER(Denoiser), VP, I64, VP, I64, INT, INT, VP, C.c_size_t, VP]),

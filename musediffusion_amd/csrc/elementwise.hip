@@ -159,20 +159,39 @@ __global__ void step_epilogue_kernel(const float* __restrict__ model_out, const 
 // The same arithmetic on 4 consecutive elements per thread (16-byte loads / stores, 32-bit index math, one coefficient / index / mask
 // lookup per group): E % 4 == 0 and 16-byte aligned tensors - the shapes of the sampling loops.  The per-element statements are the
 // scalar kernel's, so the results are bit-identical.
-template <bool DDIM>
+// SLOTS: the nearest-embedding index of a row is still spread over `nslots` partial (score, index) pairs (the rounding GEMM's
+// per-column-slot winners, mh_round_scores): the group folds them itself - same rule as argbest_reduce_kernel: the larger score, on a
+// tie the smaller index - so the separate reduce launch and its [rows] index round trip go; the thread of a row's first group also
+// writes the index to round_idx_out (may be NULL).
+template <bool DDIM, bool SLOTS = false>
 __global__ __launch_bounds__(256) void step_epilogue4_kernel(const float* __restrict__ model_out, const float* __restrict__ x_t,
                                                              const float* __restrict__ noise, const int32_t* __restrict__ round_idx,
                                                              const float* __restrict__ table, const mh_step_coef* __restrict__ coef,
                                                              int coef_per_batch, int clip, const int32_t* __restrict__ mask, int mask_per_elem,
                                                              const float* __restrict__ x_start, float* __restrict__ out,
                                                              float* __restrict__ pred_xstart, float* __restrict__ mean_out, int64_t ngroups,
-                                                             uint32_t groups_per_batch, uint32_t groups_per_row, int E) {
+                                                             uint32_t groups_per_batch, uint32_t groups_per_row, int E,
+                                                             const float* __restrict__ pbest = nullptr, const int32_t* __restrict__ pidx = nullptr,
+                                                             int nslots = 0, int32_t* __restrict__ round_idx_out = nullptr) {
   for (int64_t gi = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; gi < ngroups; gi += (int64_t)gridDim.x * blockDim.x) {
     const uint32_t g = (uint32_t)gi;                      // (ngroups < 2^32: checked by the launcher)
     const uint32_t b = g / groups_per_batch, row = g / groups_per_row, cg = g - row * groups_per_row;
     const mh_step_coef c = coef[coef_per_batch ? b : 0];
     const int64_t i = (int64_t)g * 4;
     f32x4 x0;
+    if constexpr (SLOTS) {
+      float best = -INFINITY;
+      int bi = 0x7fffffff;
+      const int64_t s0 = (int64_t)row * nslots;
+      for (int sl = 0; sl < nslots; ++sl) {               // (the lanes of a row read the same addresses: one broadcast line per step)
+        const float v = pbest[s0 + sl];
+        const int k = pidx[s0 + sl];
+        if (v > best || (v == best && k < bi)) { best = v; bi = k; }
+      }
+      if (bi == 0x7fffffff) bi = 0;
+      if (round_idx_out && cg == 0) round_idx_out[row] = bi;
+      x0 = *reinterpret_cast<const f32x4*>(table + (int64_t)bi * E + cg * 4);
+    } else
     if (round_idx) x0 = *reinterpret_cast<const f32x4*>(table + (int64_t)round_idx[row] * E + cg * 4);
     else x0 = *reinterpret_cast<const f32x4*>(model_out + i);
     const f32x4 xt = *reinterpret_cast<const f32x4*>(x_t + i);
@@ -273,6 +292,23 @@ __global__ void step_begin_kernel(mh_loop_state* state, const int32_t* __restric
   }
 }
 __global__ void step_end_kernel(mh_loop_state* state) { state->pos += 1; }
+// step_begin and step_end as ONE node at the head of a captured step (the two single-thread launches and the dependent kernel
+// boundary between the step's last kernel and step_end come off the serial chain at every step boundary): the step in flight keeps
+// its iteration number in state->rng_step (what the in-graph noise generator reads), state->pos already counts the next one
+__global__ void step_advance_kernel(mh_loop_state* state, const int32_t* __restrict__ steps, const mh_step_coef* __restrict__ coef_table,
+                                    mh_step_coef* cur_coef, int32_t* emb_row, int B) {
+  const uint32_t raw = state->pos;
+  const uint32_t pos = raw >= state->n_steps ? state->n_steps - 1 : raw;
+  const int32_t t = steps[pos];
+  for (int b = threadIdx.x; b < B; b += blockDim.x) emb_row[b] = t;
+  __syncthreads();                                    // every thread has read state->pos before it moves
+  if (threadIdx.x == 0) {
+    state->cur_t = t;
+    state->rng_step = raw;
+    state->pos = raw + 1;
+    *cur_coef = coef_table[t];
+  }
+}
 
 }  // namespace
 
@@ -408,6 +444,30 @@ extern "C" int mh_ddim_epilogue(const float* model_out, const float* x_t, const 
   return MH_OK;
 }
 
+extern "C" int mh_step_epilogue_slots(int ddim, const float* x_t, const float* noise, const float* pbest, const int32_t* pidx, int nslots,
+                                      const float* table, const mh_step_coef* coef, int coef_per_batch, int clip, const int32_t* mask,
+                                      int mask_per_elem, const float* x_start, float* out, float* pred_xstart, float* mean_out,
+                                      int32_t* round_idx_out, int B, int64_t per_batch, int E, mh_stream_t stream) {
+  MH_CHECK_ARG(x_t && coef && out && pbest && pidx && table && nslots > 0, "step_epilogue_slots: null pointer");
+  MH_CHECK_ARG(!mask || x_start, "step_epilogue_slots: mask needs x_start");
+  MH_CHECK_ARG(B > 0 && per_batch > 0 && E > 0 && per_batch % E == 0, "step_epilogue_slots: bad shape");
+  MH_CHECK_ARG(step_epilogue_vec_ok(nullptr, x_t, noise, table, x_start, out, pred_xstart, ddim ? nullptr : mean_out, B, per_batch, E),
+               "step_epilogue_slots: needs E %% 4 == 0 and 16-byte aligned tensors");
+  const int64_t ng = (int64_t)B * per_batch / 4;
+  const float* none = nullptr;
+  const int32_t* nidx = nullptr;
+  if (ddim)
+    MH_LAUNCH((step_epilogue4_kernel<true, true>), dim3(ew_grid(ng)), dim3(EW_BLOCK), 0, (hipStream_t)stream, none, x_t, noise, nidx, table, coef,
+              coef_per_batch, clip, mask, mask_per_elem, x_start, out, pred_xstart, (float*)nullptr, ng, (uint32_t)(per_batch / 4), (uint32_t)(E / 4), E,
+              pbest, pidx, nslots, round_idx_out);
+  else
+    MH_LAUNCH((step_epilogue4_kernel<false, true>), dim3(ew_grid(ng)), dim3(EW_BLOCK), 0, (hipStream_t)stream, none, x_t, noise, nidx, table, coef,
+              coef_per_batch, clip, mask, mask_per_elem, x_start, out, pred_xstart, mean_out, ng, (uint32_t)(per_batch / 4), (uint32_t)(E / 4), E,
+              pbest, pidx, nslots, round_idx_out);
+  MH_CHECK_LAUNCH();
+  return MH_OK;
+}
+
 extern "C" int mh_trunc_normal_at(float* out, int64_t n, int64_t first, float bound, uint64_t seed, uint32_t stream_id,
                                   const uint32_t* step_counter, mh_stream_t stream) {
   MH_CHECK_ARG(out && n >= 0 && first >= 0 && first % 4 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0,
@@ -445,6 +505,14 @@ extern "C" int mh_step_begin(mh_loop_state* state, const int32_t* steps, const m
   MH_CHECK_ARG(state && steps && coef_table && cur_coef && emb_row && B > 0, "step_begin: bad arguments");
   MH_LAUNCH(step_begin_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, state, steps, coef_table, cur_coef,
                      emb_row, B);
+  MH_CHECK_LAUNCH();
+  return MH_OK;
+}
+
+extern "C" int mh_step_advance(mh_loop_state* state, const int32_t* steps, const mh_step_coef* coef_table, mh_step_coef* cur_coef,
+                               int32_t* emb_row, int B, mh_stream_t stream) {
+  MH_CHECK_ARG(state && steps && coef_table && cur_coef && emb_row && B > 0, "step_advance: bad arguments");
+  MH_LAUNCH(step_advance_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, state, steps, coef_table, cur_coef, emb_row, B);
   MH_CHECK_LAUNCH();
   return MH_OK;
 }

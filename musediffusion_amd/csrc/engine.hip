@@ -238,7 +238,8 @@ namespace {
 // batch's rows) the sampler runs head and tail once for the whole batch and only the encoder layers per batch slice: the head / tail
 // launches are latency-bound at a half batch (16 K-steps, a quarter to a half of the chip's block slots), so two half-size launches
 // cost twice one full-size launch.
-struct Phases { int mask; void* xh; int64_t ldh; const void* xi; int64_t ldi; void* xo; int64_t ldo; const void* xt; int64_t ldt; };
+struct Phases { int mask; void* xh; int64_t ldh; const void* xi; int64_t ldi; void* xo; int64_t ldo; const void* xt; int64_t ldt;
+                float* sq; };   // sq: optional [B L] |output row|^2, written by the fused down-projection (mh_denoiser_gives_sqnorm)
 int denoiser_run(const mh_denoiser* m, const float* x, const float* emb_t, const int32_t* emb_row, float* out, int B, int L,
                  void* workspace, size_t workspace_bytes, mh_stream_t stream, const Phases& ph);
 }  // namespace
@@ -248,6 +249,18 @@ extern "C" int mh_denoiser_forward(const mh_denoiser* m, const float* x, const f
                                    mh_stream_t stream) {
   MH_CHECK_ARG(x && emb_t && out, "denoiser_forward: null pointer");
   return denoiser_run(m, x, emb_t, emb_row, out, B, L, workspace, workspace_bytes, stream, Phases{7, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, 0});
+}
+
+// The forward that also leaves |out row|^2 per token (what the rounding scores add to |W_v|^2, models/rounding.py:23) - only on the
+// path whose last kernel is the fused down-projection; ask mh_denoiser_gives_sqnorm first
+extern "C" int mh_denoiser_gives_sqnorm(const mh_denoiser* m) {
+  return m && m->panel && m->has_proj && mh_down_proj_fused_supported(m->E, m->H);
+}
+extern "C" int mh_denoiser_forward_sqnorm(const mh_denoiser* m, const float* x, const float* emb_t, const int32_t* emb_row, float* out,
+                                          float* out_sqnorm, int B, int L, void* workspace, size_t workspace_bytes, mh_stream_t stream) {
+  MH_CHECK_ARG(x && emb_t && out && out_sqnorm, "denoiser_forward_sqnorm: null pointer");
+  MH_CHECK_ARG(mh_denoiser_gives_sqnorm(m), "denoiser_forward_sqnorm: this model's forward does not end in the fused down-projection");
+  return denoiser_run(m, x, emb_t, emb_row, out, B, L, workspace, workspace_bytes, stream, Phases{7, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, 0, out_sqnorm});
 }
 
 // Phased entry points (bf16 K32-panel models with up / down projections only; see Phases).  X buffers: bf16 [H / 32][ld rows][32].
@@ -417,7 +430,7 @@ int denoiser_run(const mh_denoiser* m, const float* x, const float* emb_t, const
     if (m->has_proj) {
       if (g_skip & 64) return MH_OK;
       if (mh_down_proj_fused_supported(m->E, H))   // one kernel for both dense layers of the down-projection (csrc/headtail.hip)
-        return mh_down_proj_fused(XT, ldT, m->w_dn0, m->b_dn0, m->w_dn2, m->b_dn2, out, N, m->E, H, stream);
+        return mh_down_proj_fused(XT, ldT, m->w_dn0, m->b_dn0, m->w_dn2, m->b_dn2, out, ph.sq, N, m->E, H, stream);
       if ((rc = gemm(XT, ldT, m->w_dn0, H, m->b_dn0, nullptr, 0, w.buf0, 0, N, H, H, MH_ACT_TANH))) return rc;
       return gemm(w.buf0, N, m->w_dn2, m->E, m->b_dn2, nullptr, 0, out, 1, m->E, m->E, H, MH_ACT_NONE);
     }

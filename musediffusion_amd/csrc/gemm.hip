@@ -1724,6 +1724,21 @@ extern "C" int mh_round_to_embedding_mfma(const float* x, const float* table_pad
   return MH_OK;
 }
 
+// The score GEMM of mh_round_to_embedding_mfma alone: |x_n|^2 comes from the caller (the fused down-projection writes it beside its
+// rows, csrc/headtail.hip) and the per-slot winners stay in pbest / pidx [n_tokens][mh_round_slots(V)] for mh_step_epilogue_slots to
+// fold - two launches less per batch slice and step.  E % 16 == 0 (no padded copy here).
+extern "C" int mh_round_slots(int V) { return 2 * ceil_div(V, BN); }
+extern "C" int mh_round_scores(const float* x, const float* x_sqnorm, const float* table_pad, const float* table_norm, float* pbest,
+                               int32_t* pidx, int64_t n_tokens, int E, int V, mh_stream_t stream) {
+  MH_CHECK_ARG(x && x_sqnorm && table_pad && table_norm && pbest && pidx && n_tokens > 0 && V > 0, "round_scores: bad arguments");
+  MH_CHECK_ARG(E > 0 && E % 16 == 0, "round_scores: E = %d must be a multiple of 16", E);
+  GemmArgs g{};
+  g.A = x; g.lda = E; g.W = table_pad; g.ldw = E; g.ldr = 8; g.ldo = 8;
+  g.M = n_tokens; g.N = V; g.K = E;
+  g.aux = table_norm; g.rown = x_sqnorm; g.pbest = pbest; g.pidx = pidx; g.nslots = mh_round_slots(V);
+  return launch<2>(g, MH_F32, (hipStream_t)stream);
+}
+
 // =====================================================================================================
 // Weight-gradient GEMM ("TN"): dW[m][n] = sum_k A[k][m] * B[k][n] with BOTH operands stored k-major (A = dY [tokens, out
 // features], B = X [tokens, in features], exactly as the forward wrote them) - no transposed copies.  The reduction runs over

@@ -35,6 +35,7 @@ struct TailArgs {
   const bf16* w0; const float* b0;      // [H / 32][H][32]
   const bf16* w2; const float* b2;      // [H / 32][E][32]  (E rows: the down-projection's outputs)
   float* out;                           // [rows, E] fp32
+  float* sqnorm;                        // optional [rows]: |out row|^2 (the rounding scores' |x_n|^2, models/rounding.py:23)
 };
 
 template <int N> __device__ __forceinline__ void ht_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
@@ -317,13 +318,35 @@ __global__ __launch_bounds__(H / 64 * 64, H / 256) void tail_fused_kernel(const 
 #pragma unroll
     for (int i = 0; i < 4; ++i) y[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, a[i], y[i], 0, 0, 0);
   }
+  float ss[4] = {0.f, 0.f, 0.f, 0.f};
   if (wave < E16) {
     const int col = p2 * 16 + 4 * fg;
     const f32x4 bv = *reinterpret_cast<const f32x4*>(g.b2 + col);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int64_t r = row0 + 16 * i + fr;
-      if (r < g.rows) *reinterpret_cast<f32x4*>(g.out + r * g.E + col) = y[i] + bv;
+      const f32x4 v = y[i] + bv;
+      ss[i] = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+      if (r < g.rows) *reinterpret_cast<f32x4*>(g.out + r * g.E + col) = v;
+    }
+  }
+  if (g.sqnorm) {   // |row|^2: 4 columns in the lane -> the 4 lanes of a row (xor 16, 32) -> the E / 16 waves through LDS, fixed order
+    ht_lgkm0();
+    __builtin_amdgcn_s_barrier();           // every wave is past its last fragment read: the ring's first bytes are free
+    float* red = reinterpret_cast<float*>(ring);          // [64][NW]
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float v = ss[i];
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      if (fg == 0) red[(16 * i + fr) * NW + wave] = v;
+    }
+    ht_lgkm0();
+    __builtin_amdgcn_s_barrier();
+    if (tid < HT_ROWS) {
+      float t = 0.f;
+      for (int w = 0; w < E16 && w < NW; ++w) t += red[tid * NW + w];
+      if (row0 + tid < g.rows) g.sqnorm[row0 + tid] = t;
     }
   }
 }
@@ -359,10 +382,10 @@ extern "C" int mh_up_proj_ln_fused(const float* x, int E, int E_pad, const void*
 }
 
 extern "C" int mh_down_proj_fused(const void* X, int64_t ldx, const void* w0, const float* b0, const void* w2, const float* b2, float* out,
-                                  int64_t rows, int E, int H, mh_stream_t stream) {
+                                  float* out_sqnorm, int64_t rows, int E, int H, mh_stream_t stream) {
   MH_CHECK_ARG(X && w0 && b0 && w2 && b2 && out && rows > 0 && ldx >= rows, "down_proj_fused: bad arguments");
   MH_CHECK_ARG(mh_down_proj_fused_supported(E, H), "down_proj_fused: shape E=%d H=%d not served", E, H);
-  TailArgs g{(const bf16*)X, ldx, rows, E, (const bf16*)w0, b0, (const bf16*)w2, b2, out};
+  TailArgs g{(const bf16*)X, ldx, rows, E, (const bf16*)w0, b0, (const bf16*)w2, b2, out, out_sqnorm};
   const dim3 grid((unsigned)((rows + HT_ROWS - 1) / HT_ROWS));
   mh_prof_note("tail rows=%lld E=%d H=%d", (long long)rows, E, H);
   if (H == 512) MH_LAUNCH((tail_fused_kernel<512>), grid, dim3(512), 0, (hipStream_t)stream, g);

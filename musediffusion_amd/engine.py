@@ -227,9 +227,10 @@ class DenoiserEngine:
         p, ld = self._window(rows, first)
         check(lib().mh_denoiser_tail(C.byref(self._desc), p, ld, ptr(out), B, L, ptr(ws), ws.numel(), current_stream()), "mh_denoiser_tail")
 
-    def forward(self, x, emb_t, emb_row=None, out=None, ws=None):
+    def forward(self, x, emb_t, emb_row=None, out=None, ws=None, sqnorm=None):
         """x [B,L,E] fp32 -> [B,L,E] fp32 (models/network.py:131-158).  emb_t [*,H] fp32,
-        emb_row [B] int32 selecting the emb_t row of each batch element (None: row b)."""
+        emb_row [B] int32 selecting the emb_t row of each batch element (None: row b).
+        sqnorm [B L] fp32 (optional, only when mh_denoiser_gives_sqnorm): receives |out row|^2 per token."""
         _lib.require_device(x, emb_t, emb_row)
         B, L, E = x.shape
         if E != self.cfg["E"]:
@@ -237,6 +238,10 @@ class DenoiserEngine:
         x = x.to(torch.float32).contiguous()
         out = torch.empty_like(x) if out is None else out
         ws = self._workspace(B, L) if ws is None else ws
+        if sqnorm is not None:
+            check(lib().mh_denoiser_forward_sqnorm(C.byref(self._desc), ptr(x), ptr(emb_t), ptr(emb_row), ptr(out), ptr(sqnorm), B, L, ptr(ws),
+                                                   ws.numel(), current_stream()), "mh_denoiser_forward_sqnorm")
+            return out
         check(lib().mh_denoiser_forward(C.byref(self._desc), ptr(x), ptr(emb_t), ptr(emb_row), ptr(out), B, L, ptr(ws),
                                         ws.numel(), current_stream()), "mh_denoiser_forward")
         return out

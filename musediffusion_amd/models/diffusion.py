@@ -19,6 +19,7 @@ different is the execution model:
     `rng_mode="philox"` uses the in-graph counter-based truncated normal (`mh_trunc_normal`);
     `noise_fn` injects draws (parity tests).
 """
+import ctypes as C
 import math
 
 import numpy as np
@@ -174,6 +175,9 @@ class GaussianDiffusion:
     # neutral (3.658 vs 3.660 ms / step at config 2, +0.7 % at c2-bertbase): the head / tail launches are NOT latency-bound - a
     # full-batch launch of them takes twice a half-batch launch - so off by default
     shared_head_tail = False
+    # the step's rounding without its two small launches (row_sqnorm, argbest_reduce): |row|^2 from the fused down-projection, the
+    # slot fold inside the update kernel.  False = the round-3 launch sequence (A/B, tests)
+    fuse_rounding = True
 
     def __init__(self, *, betas, predict_xstart, rescale_timesteps=False):
         self.rescale_timesteps = rescale_timesteps
@@ -661,6 +665,17 @@ class _ReverseLoop:
         self.cur_coef = torch.zeros(8, dtype=torch.float32, device=dev)
         self.emb_row = torch.zeros(B, dtype=torch.int32, device=dev)
         self.graphs = {}
+        # fused step pieces (round 4): the forward's last kernel leaves |out row|^2 beside its rows (mh_denoiser_forward_sqnorm), the
+        # score GEMM keeps its per-slot winners (mh_round_scores) and the update kernel folds them itself (mh_step_epilogue_slots):
+        # row_sqnorm and argbest_reduce are gone as launches.  Needs the bf16 panel forward with the fused down-projection and E % 16 == 0.
+        L_ = _lib.lib()
+        self.fused_round = bool(table is not None and E % 16 == 0 and getattr(diff, "fuse_rounding", True) and
+                                L_.mh_denoiser_gives_sqnorm(C.byref(eng._desc)))
+        if self.fused_round:
+            self.nslots = int(L_.mh_round_slots(self.table32.shape[0]))
+            self.sqnorm = torch.empty(B * L, dtype=torch.float32, device=dev)
+            self.pbest = torch.empty(B * L * self.nslots, dtype=torch.float32, device=dev)
+            self.pidx = torch.empty(B * L * self.nslots, dtype=torch.int32, device=dev)
         split = getattr(diff, "batch_split", None)
         if split is None:
             # two half-batch branches overlap one half's attention / epilogues with the other's GEMM main loops (+4% at
@@ -688,6 +703,8 @@ class _ReverseLoop:
             # shared head / tail: full-batch hand-over buffers (the slices read / write row windows of them) and a full-batch workspace
             self.shared = bool(getattr(diff, "shared_head_tail", False) and eng.phases_supported())
             if self.shared:
+                self.fused_round = False        # (the phased tail entry point does not write |row|^2)
+            if self.shared:
                 self.rows_in, self.rows_out = eng.new_rows(B * L), eng.new_rows(B * L)
                 self.full_ws = eng.new_workspace(B, L)
         self.decoupled = False
@@ -698,6 +715,19 @@ class _ReverseLoop:
         per_batch = self.L * self.E
         nb = sl.stop - sl.start
         tok = slice(sl.start * self.L, sl.stop * self.L)
+        if use_round and self.fused_round:
+            ns = self.nslots
+            slots = slice(tok.start * ns, tok.stop * ns)
+            V = self.table32.shape[0]
+            _lib.check(L_.mh_round_scores(P(self.model_out[sl]), P(self.sqnorm[tok]), P(self.table_pad), P(self.table_norm), P(self.pbest[slots]),
+                                          P(self.pidx[slots]), nb * self.L, self.E, V, stream_h), "mh_round_scores")
+            _lib.check(L_.mh_step_epilogue_slots(0 if self.kind == "p" else 1, P(self.x[sl]), P(self.noise[sl]), P(self.pbest[slots]),
+                                                 P(self.pidx[slots]), ns, P(self.table32), P(cur_coef), 0, int(self.clip),
+                                                 P(self.mask[sl]) if self.mask is not None else None, self.mask_per_elem,
+                                                 P(self.x_start[sl]) if self.x_start is not None else None, P(self.x[sl]), P(self.pred[sl]),
+                                                 P(self.mean[sl]) if (self.mean is not None and self.kind == "p") else None,
+                                                 P(self.round_idx[tok]), nb, per_batch, self.E, stream_h), "mh_step_epilogue_slots")
+            return
         if use_round:
             _lib.check(L_.mh_round_to_embedding_mfma(P(self.model_out[sl]), P(self.table_pad), P(self.table_norm),
                                                      P(self.round_idx[tok]), nb * self.L, self.E, self.table32.shape[0],
@@ -712,13 +742,23 @@ class _ReverseLoop:
         else:
             _lib.check(L_.mh_ddim_epilogue(*args, nb, per_batch, self.E, stream_h), "mh_ddim_epilogue")
 
+    def _forward(self, sl, ws, use_round):
+        """the denoiser on batch slice `sl` (with |out row|^2 when the fused rounding wants it)"""
+        sq = self.sqnorm[sl.start * self.L: sl.stop * self.L] if (use_round and self.fused_round) else None
+        self.eng.forward(self.x[sl], self.emb_table, self.emb_row[sl], out=self.model_out[sl], ws=ws, sqnorm=sq)
+
+    def _rng_counter(self, state):
+        """device address of the step counter the in-graph noise reads: mh_loop_state.rng_step, written by mh_step_advance"""
+        return state.data_ptr() + 12
+
     # one reverse step as a fixed launch sequence (capturable: no allocation, no sync)
     def _body(self, use_round, in_graph_rng):
         L_ = _lib.lib()
         st = _lib.current_stream()
         P = _lib.ptr
-        _lib.check(L_.mh_step_begin(P(self.state), P(self.steps), P(self.coef_table), P(self.cur_coef), P(self.emb_row),
-                                    self.B, st), "mh_step_begin")
+        # (mh_step_advance = step_begin + step_end as one first node: nothing follows the step's last kernel)
+        _lib.check(L_.mh_step_advance(P(self.state), P(self.steps), P(self.coef_table), P(self.cur_coef), P(self.emb_row),
+                                      self.B, st), "mh_step_advance")
         nsplit = self.nsplit
         per_batch = self.L * self.E
 
@@ -728,10 +768,10 @@ class _ReverseLoop:
         def draw_noise(stream_h):
             if in_graph_rng:
                 _lib.check(L_.mh_trunc_normal(P(self.noise), self.noise.numel(), float(self.top_p), int(self.diff.rng_seed),
-                                              int(self.diff.rng_stream), P(self.state), stream_h), "mh_trunc_normal")
+                                              int(self.diff.rng_stream), self._rng_counter(self.state), stream_h), "mh_trunc_normal")
 
         if nsplit <= 1:
-            self.eng.forward(self.x, self.emb_table, self.emb_row, out=self.model_out, ws=self.own_ws)
+            self._forward(slice(0, self.B), self.own_ws, use_round)
             draw_noise(st)
             tail(slice(0, self.B), st, self.round_ws)
         elif getattr(self, "shared", False):
@@ -771,18 +811,17 @@ class _ReverseLoop:
                     if j == 1:
                         draw_noise(sh)
                         self.ev_noise.record(side)
-                    self.eng.forward(self.x[sl], self.emb_table, self.emb_row[sl], out=self.model_out[sl], ws=self.split_ws[j])
+                    self._forward(sl, self.split_ws[j], use_round)
                     if j > 1:
                         side.wait_event(self.ev_noise)
                     tail(sl, sh, self.split_round_ws[j])
                     self.ev_join[j - 1].record(side)
             sl0 = slice(0, hb)
-            self.eng.forward(self.x[sl0], self.emb_table, self.emb_row[sl0], out=self.model_out[sl0], ws=self.split_ws[0])
+            self._forward(sl0, self.split_ws[0], use_round)
             main.wait_event(self.ev_noise)
             tail(sl0, st, self.split_round_ws[0])
             for j in range(1, nsplit):
                 main.wait_event(self.ev_join[j - 1])
-        _lib.check(L_.mh_step_end(P(self.state), st), "mh_step_end")
 
     def _branch_body(self, j, use_round):
         """One reverse step of batch slice j alone, on the current stream: its own loop state, its slice of the in-graph noise
@@ -794,13 +833,12 @@ class _ReverseLoop:
         sl = self.slices[j]
         nb = sl.stop - sl.start
         state, coef = self.br_state[j], self.br_coef[j]
-        _lib.check(L_.mh_step_begin(P(state), P(self.steps), P(self.coef_table), P(coef), P(self.emb_row[sl]), nb, st), "mh_step_begin")
+        _lib.check(L_.mh_step_advance(P(state), P(self.steps), P(self.coef_table), P(coef), P(self.emb_row[sl]), nb, st), "mh_step_advance")
         per_batch = self.L * self.E
         _lib.check(L_.mh_trunc_normal_at(P(self.noise[sl]), nb * per_batch, sl.start * per_batch, float(self.top_p), int(self.diff.rng_seed),
-                                         int(self.diff.rng_stream), P(state), st), "mh_trunc_normal_at")
-        self.eng.forward(self.x[sl], self.emb_table, self.emb_row[sl], out=self.model_out[sl], ws=self.split_ws[j])
+                                         int(self.diff.rng_stream), self._rng_counter(state), st), "mh_trunc_normal_at")
+        self._forward(sl, self.split_ws[j], use_round)
         self._tail(sl, st, self.split_round_ws[j], coef, use_round)
-        _lib.check(L_.mh_step_end(P(state), st), "mh_step_end")
 
     def begin(self):
         """Warm-up launch outside capture (one-time lazy initialisation inside the launchers), state restored."""

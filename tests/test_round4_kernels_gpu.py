@@ -77,15 +77,17 @@ def test_down_proj_fused(H, E, N):
     ld = N + 64                                                             # a row window of a larger panel buffer
     Xp = torch.zeros(H // 32, ld, 32, device=DEV, dtype=torch.bfloat16)
     Xp[:, :N] = X.bfloat16().reshape(N, H // 32, 32).permute(1, 0, 2).to(DEV)
-    out = torch.zeros(N, E, device=DEV)
+    out, sq = torch.zeros(N, E, device=DEV), torch.zeros(N, device=DEV)
     assert lib().mh_down_proj_fused_supported(E, H) == 1 and lib().mh_down_proj_fused_supported(500, H) == 0
     d = lambda t: t.to(DEV).contiguous()
     w0p, w2p, b0d, b2d = to_panel(W0), to_panel(W2), d(b0), d(b2)
-    check(lib().mh_down_proj_fused(Xp.data_ptr(), ld, w0p.data_ptr(), b0d.data_ptr(), w2p.data_ptr(), b2d.data_ptr(), out.data_ptr(), N, E, H,
+    check(lib().mh_down_proj_fused(Xp.data_ptr(), ld, w0p.data_ptr(), b0d.data_ptr(), w2p.data_ptr(), b2d.data_ptr(), out.data_ptr(), sq.data_ptr(), N, E, H,
                                    current_stream()), "mh_down_proj_fused")
     err = (out.cpu() - ref).abs()
     print("tail H=%d rows=%d: max |d| %.2e" % (H, N, float(err.max())))
     assert float(err.max()) < 2e-3                                          # fp32 output: only the accumulation order differs
+    sq_ref = (out.double() ** 2).sum(dim=1)
+    assert float(((sq.double() - sq_ref).abs() / sq_ref).max()) < 1e-5       # |row|^2 of the rows the kernel itself wrote
 
 
 def test_forward_with_fused_head_and_tail_tracks_the_separate_launches():
@@ -119,3 +121,54 @@ def test_forward_with_fused_head_and_tail_tracks_the_separate_launches():
     assert float(d_fs.mean()) < 5e-3 and float(d_fs.max()) < 0.1
     assert float(d_f.mean()) < 0.02 and float(d_f.max()) < 0.25                # the stated bf16 tolerance
     assert float(d_f.mean()) <= float(d_s.mean()) * 1.1                          # and no worse than the separate launches
+
+
+@pytest.mark.parametrize("kind", ["p", "ddim"])
+def test_step_with_fused_rounding_pieces_equals_the_separate_launches(kind):
+    """One captured step with |row|^2 from the fused down-projection + mh_round_scores + mh_step_epilogue_slots against the round-3
+    sequence (row_sqnorm, score GEMM, argbest_reduce, update) on the same bf16 model, same start latent, same Philox noise, 3 steps.
+    The only arithmetic difference is the summation order inside |x_n|^2, which enters a score as (|W_v|^2 + |x_n|^2) - 2 x.W_v: rows
+    change their nearest embedding only on last-bit ties.  mh_step_advance must leave the loop state where begin + end left it."""
+    from functools import partial
+    from musediffusion_amd import synthetic
+    from musediffusion_amd.models.diffusion import SpacedDiffusion, get_named_beta_schedule, space_timesteps, _ReverseLoop
+    from musediffusion_amd.models.network import TransformerNetModel
+    from musediffusion_amd.models.rounding import denoised_fn_round
+    torch.manual_seed(7)
+    E, H, L, B, V = 128, 512, 512, 4, 729
+    m = TransformerNetModel(E, E, 128, V, L, dropout=0.0, bert_hidden=H, bert_layers=2, bert_heads=8, bert_ffn=2048, compute_dtype="bf16")
+    m.eval().requires_grad_(False).to(DEV)
+    batch = synthetic.generation_batch(B, L, seed=1)
+    ids, mask = batch["input_ids"].to(DEV), batch["input_mask"].to(DEV)
+    x_start = m.get_embeds(ids)
+    mask3 = torch.broadcast_to(mask.unsqueeze(-1), x_start.shape)
+    torch.manual_seed(105)
+    x0 = torch.where(mask3 == 0, x_start, torch.randn_like(x_start))
+    emb = torch.nn.Embedding(V, E, _weight=m.word_embedding.weight.clone()).eval().requires_grad_(False)
+    fn = partial(denoised_fn_round, emb, dist=None)
+    res = {}
+    for fused in (True, False):
+        for graph in (True, False):
+            diff = SpacedDiffusion(use_timesteps=space_timesteps(2000, [2000]), betas=get_named_beta_schedule("sqrt", 2000),
+                                   rescale_timesteps=True, predict_xstart=True)
+            diff.rng_mode, diff.rng_seed, diff.rng_stream, diff.use_graph, diff.fuse_rounding, diff.batch_split = "philox", 105, 0, graph, fused, 2
+            idx = list(range(2000))[::-1][:3]
+            loop = _ReverseLoop.try_build(diff, kind, m, x0, True, fn, 1 if kind == "p" else None, mask3, x_start, 0.0, idx, lambda i: fn, False)
+            assert loop is not None and loop.fused_round == fused
+            with torch.no_grad():
+                loop.begin()
+                for k in range(3):
+                    loop.advance(k)
+                loop.finish()
+            torch.cuda.synchronize()
+            st = loop.state.cpu().tolist()
+            assert st[0] == 3 and st[1] == 3 and st[2] == idx[2]              # pos, n_steps, cur_t after three steps
+            res[(fused, graph)] = (loop.x.clone(), loop.round_idx.clone(), loop.pred.clone())
+    for fused in (True, False):                                             # eager and captured step: the same launches
+        assert torch.equal(res[(fused, True)][0], res[(fused, False)][0]) and torch.equal(res[(fused, True)][1], res[(fused, False)][1])
+    (xa, ia, pa), (xb, ib, pb) = res[(True, True)], res[(False, True)]
+    same = float((ia == ib).float().mean())
+    print("%s: rounded index agreement fused vs separate %.6f" % (kind, same))
+    assert same >= 0.9995
+    rows_same = (ia == ib).view(B, L, 1).expand_as(xa)
+    assert torch.equal(xa[rows_same], xb[rows_same]) and torch.equal(pa[rows_same], pb[rows_same])
