@@ -623,10 +623,16 @@ int mh_denoiser_forward_sqnorm(const mh_denoiser* m, const float* x, const float
 int mh_round_slots(int V);
 int mh_round_scores(const float* x, const float* x_sqnorm, const float* table_pad, const float* table_norm, float* pbest,
                     int32_t* pidx, int64_t n_tokens, int E, int V, mh_stream_t stream);
+/* rng != NULL: the update kernel draws the step's noise itself - for element group (first_elem / 4 + g) exactly the four values
+ * mh_trunc_normal_at(out, n, first_elem, bound, seed, stream_id, step_counter) writes (diffusion.py:378-388 top-p rejection resolved in
+ * registers; bound 0 = plain normals) - and `noise` is not read. */
+typedef struct mh_step_rng {
+  uint64_t seed; uint32_t stream_id; float bound; const uint32_t* step_counter; int64_t first_elem;
+} mh_step_rng;
 int mh_step_epilogue_slots(int ddim, const float* x_t, const float* noise, const float* pbest, const int32_t* pidx, int nslots,
                            const float* table, const mh_step_coef* coef, int coef_per_batch, int clip, const int32_t* mask,
                            int mask_per_elem, const float* x_start, float* out, float* pred_xstart, float* mean_out,
-                           int32_t* round_idx_out, int B, int64_t per_batch, int E, mh_stream_t stream);
+                           int32_t* round_idx_out, const mh_step_rng* rng, int B, int64_t per_batch, int E, mh_stream_t stream);
 int mh_denoiser_phases_supported(const mh_denoiser* m);
 int mh_denoiser_head(const mh_denoiser* m, const float* x, const float* emb_t, const int32_t* emb_row, void* x_out, int64_t ld_out, int B, int L,
                      void* workspace, size_t workspace_bytes, mh_stream_t stream);

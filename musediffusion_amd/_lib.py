@@ -48,6 +48,11 @@ class Dropout(C.Structure):
     _fields_ = [("p", F32), ("seed", C.c_uint64), ("offset", C.c_uint64), ("mask", VP)]
 
 
+class StepRng(C.Structure):
+    """mh_step_rng"""
+    _fields_ = [("seed", C.c_uint64), ("stream_id", C.c_uint32), ("bound", F32), ("step_counter", VP), ("first_elem", C.c_int64)]
+
+
 class WPrepItem(C.Structure):
     """mh_wprep_item"""
     _fields_ = [("src", VP), ("dst", VP), ("dst_t", VP), ("rows", C.c_int32), ("cols", C.c_int32), ("ld_dst", C.c_int64),
@@ -194,7 +199,7 @@ SIGNATURES = {
     "mh_denoiser_forward_sqnorm": (INT, [C.POINTER(Denoiser), VP, VP, VP, VP, VP, INT, INT, VP, C.c_size_t, VP]),
     "mh_round_slots": (INT, [INT]),
     "mh_round_scores": (INT, [VP, VP, VP, VP, VP, VP, I64, INT, INT, VP]),
-    "mh_step_epilogue_slots": (INT, [INT, VP, VP, VP, VP, INT, VP, VP, INT, INT, VP, INT, VP, VP, VP, VP, VP, INT, I64, INT, VP]),
+    "mh_step_epilogue_slots": (INT, [INT, VP, VP, VP, VP, INT, VP, VP, INT, INT, VP, INT, VP, VP, VP, VP, VP, VP, INT, I64, INT, VP]),
     "mh_step_advance": (INT, [VP, VP, VP, VP, VP, INT, VP]),
     "mh_denoiser_phases_supported": (INT, [C.POINTER(Denoiser)]),
     "mh_denoiser_head": (INT, [C.POINTER(Denoiser), VP, VP, VP, VP, I64, INT, INT, VP, C.c_size_t, VP]),

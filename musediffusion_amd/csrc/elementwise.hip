@@ -122,6 +122,43 @@ __global__ void q_sample_kernel(const float* __restrict__ x0, const float* __res
   }
 }
 
+// ---------------------------------------------------------------- Philox4x32-10 truncated normal
+__device__ __forceinline__ float u01(uint32_t r) { return ((float)(r >> 8) + 0.5f) * (1.0f / 16777216.0f); }
+
+// One thread owns the 4 consecutive elements of a group; Philox call (group, step, stream, attempt) yields four Box-Muller
+// normals, candidate k going to element k of the group if that element has not accepted one yet (rejection against the bound,
+// resolved in registers: no host sync, diffusion.py:378-388).  Elements are numbered GLOBALLY (first + local index), so a batch
+// slice drawn on its own (the decoupled graph branches of _ReverseLoop) gets exactly the values the whole-batch launch gives it.
+// Hardware transcendentals (v_log / v_sqrt / v_sin / v_cos: sin and cos take revolutions, so 2 pi u needs no range reduction).
+// the four truncated normals of element group g (elements 4 g .. 4 g + 3, numbered globally) at loop step `step`
+__device__ __forceinline__ void trunc_normal4(uint64_t g, uint32_t step, float bound, uint32_t seed_lo, uint32_t seed_hi, uint32_t stream_id,
+                                              float (&z)[4]) {
+  z[0] = z[1] = z[2] = z[3] = 0.f;
+  uint32_t pending = 0xfu;
+  // up to 1024 calls per group (the loop ends with the group's last acceptance: the usual cost is 1 - 2 calls); attempts beyond
+  // 255 continue in the top byte of the second counter word, so every value an earlier build drew is unchanged
+  for (uint32_t attempt = 0; attempt < 1024 && pending; ++attempt) {
+    uint32_t c[4] = {(uint32_t)g, (uint32_t)(g >> 32) | ((attempt >> 8) << 24), step, (stream_id << 8) | (attempt & 0xffu)};
+    mh_philox<10>(c, seed_lo, seed_hi);
+    // sqrt(-2 ln u) = sqrt(-2 ln 2 log2 u)
+    const float r0 = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u01(c[0])));
+    const float r1 = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u01(c[2])));
+    const float a0 = u01(c[1]), a1 = u01(c[3]);
+    const float cand[4] = {r0 * __builtin_amdgcn_cosf(a0), r0 * __builtin_amdgcn_sinf(a0), r1 * __builtin_amdgcn_cosf(a1),
+                           r1 * __builtin_amdgcn_sinf(a1)};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (((pending >> k) & 1u) && (bound <= 0.f || fabsf(cand[k]) <= bound)) {
+        z[k] = cand[k];
+        pending &= ~(1u << k);
+      }
+    }
+  }
+  // an element keeps z = 0 only after 1024 rejected candidates in a row: (1 - 0.0797)^1024 = 1e-37 at the tightest bound the entry
+  // point accepts (0.1: acceptance probability 0.0797), 3e-172 at bound 0.2; the reference loops until every element is accepted
+  // (diffusion.py:378-388)
+}
+
 template <bool DDIM>
 __global__ void step_epilogue_kernel(const float* __restrict__ model_out, const float* __restrict__ x_t,
                                      const float* __restrict__ noise, const int32_t* __restrict__ round_idx,
@@ -163,7 +200,11 @@ __global__ void step_epilogue_kernel(const float* __restrict__ model_out, const 
 // per-column-slot winners, mh_round_scores): the group folds them itself - same rule as argbest_reduce_kernel: the larger score, on a
 // tie the smaller index - so the separate reduce launch and its [rows] index round trip go; the thread of a row's first group also
 // writes the index to round_idx_out (may be NULL).
-template <bool DDIM, bool SLOTS = false>
+// RNG (with SLOTS): the group draws its own four truncated normals - the values mh_trunc_normal_at writes for these elements
+// (same Philox counters: global group number, loop step, stream) - instead of reading `noise`: the generator launch at the head of
+// a step and the noise tensor's write + read are gone, and the batch slices of a step start level.
+struct StepRng { uint32_t seed_lo, seed_hi, stream_id; float bound; const uint32_t* step; uint64_t first_group; };
+template <bool DDIM, bool SLOTS = false, bool RNG = false>
 __global__ __launch_bounds__(256) void step_epilogue4_kernel(const float* __restrict__ model_out, const float* __restrict__ x_t,
                                                              const float* __restrict__ noise, const int32_t* __restrict__ round_idx,
                                                              const float* __restrict__ table, const mh_step_coef* __restrict__ coef,
@@ -172,7 +213,9 @@ __global__ __launch_bounds__(256) void step_epilogue4_kernel(const float* __rest
                                                              float* __restrict__ pred_xstart, float* __restrict__ mean_out, int64_t ngroups,
                                                              uint32_t groups_per_batch, uint32_t groups_per_row, int E,
                                                              const float* __restrict__ pbest = nullptr, const int32_t* __restrict__ pidx = nullptr,
-                                                             int nslots = 0, int32_t* __restrict__ round_idx_out = nullptr) {
+                                                             int nslots = 0, int32_t* __restrict__ round_idx_out = nullptr, const StepRng rng = StepRng{}) {
+  uint32_t rng_step = 0;
+  if constexpr (RNG) rng_step = rng.step ? *rng.step : 0u;
   for (int64_t gi = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; gi < ngroups; gi += (int64_t)gridDim.x * blockDim.x) {
     const uint32_t g = (uint32_t)gi;                      // (ngroups < 2^32: checked by the launcher)
     const uint32_t b = g / groups_per_batch, row = g / groups_per_row, cg = g - row * groups_per_row;
@@ -196,6 +239,11 @@ __global__ __launch_bounds__(256) void step_epilogue4_kernel(const float* __rest
     else x0 = *reinterpret_cast<const f32x4*>(model_out + i);
     const f32x4 xt = *reinterpret_cast<const f32x4*>(x_t + i);
     f32x4 nz = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (RNG) {
+      float z[4];
+      trunc_normal4(rng.first_group + g, rng_step, rng.bound, rng.seed_lo, rng.seed_hi, rng.stream_id, z);
+      nz = f32x4{z[0], z[1], z[2], z[3]};
+    } else
     if (noise) nz = *reinterpret_cast<const f32x4*>(noise + i);
     f32x4 mean, sample;
 #pragma unroll
@@ -234,44 +282,13 @@ inline bool step_epilogue_vec_ok(const float* model_out, const float* x_t, const
 }
 }  // namespace
 
-// ---------------------------------------------------------------- Philox4x32-10 truncated normal
-__device__ __forceinline__ float u01(uint32_t r) { return ((float)(r >> 8) + 0.5f) * (1.0f / 16777216.0f); }
-
-// One thread owns the 4 consecutive elements of a group; Philox call (group, step, stream, attempt) yields four Box-Muller
-// normals, candidate k going to element k of the group if that element has not accepted one yet (rejection against the bound,
-// resolved in registers: no host sync, diffusion.py:378-388).  Elements are numbered GLOBALLY (first + local index), so a batch
-// slice drawn on its own (the decoupled graph branches of _ReverseLoop) gets exactly the values the whole-batch launch gives it.
-// Hardware transcendentals (v_log / v_sqrt / v_sin / v_cos: sin and cos take revolutions, so 2 pi u needs no range reduction).
 __global__ __launch_bounds__(256) void trunc_normal_kernel(float* __restrict__ out, int64_t n, int64_t first, float bound, uint32_t seed_lo,
                                                           uint32_t seed_hi, uint32_t stream_id, const uint32_t* __restrict__ step_counter) {
   const uint32_t step = step_counter ? *step_counter : 0u;
   const int64_t ngroups = (n + 3) >> 2;
   for (int64_t gi = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; gi < ngroups; gi += (int64_t)gridDim.x * blockDim.x) {
-    const uint64_t g = (uint64_t)((first >> 2) + gi);
-    float z[4] = {0.f, 0.f, 0.f, 0.f};
-    uint32_t pending = 0xfu;
-    // up to 1024 calls per group (the loop ends with the group's last acceptance: the usual cost is 1 - 2 calls); attempts beyond
-    // 255 continue in the top byte of the second counter word, so every value an earlier build drew is unchanged
-    for (uint32_t attempt = 0; attempt < 1024 && pending; ++attempt) {
-      uint32_t c[4] = {(uint32_t)g, (uint32_t)(g >> 32) | ((attempt >> 8) << 24), step, (stream_id << 8) | (attempt & 0xffu)};
-      mh_philox<10>(c, seed_lo, seed_hi);
-      // sqrt(-2 ln u) = sqrt(-2 ln 2 log2 u)
-      const float r0 = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u01(c[0])));
-      const float r1 = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u01(c[2])));
-      const float a0 = u01(c[1]), a1 = u01(c[3]);
-      const float cand[4] = {r0 * __builtin_amdgcn_cosf(a0), r0 * __builtin_amdgcn_sinf(a0), r1 * __builtin_amdgcn_cosf(a1),
-                             r1 * __builtin_amdgcn_sinf(a1)};
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        if (((pending >> k) & 1u) && (bound <= 0.f || fabsf(cand[k]) <= bound)) {
-          z[k] = cand[k];
-          pending &= ~(1u << k);
-        }
-      }
-    }
-    // an element keeps z = 0 only after 1024 rejected candidates in a row: (1 - 0.0797)^1024 = 1e-37 at the tightest bound the entry
-    // point accepts (0.1: acceptance probability 0.0797), 3e-172 at bound 0.2; the reference loops until every element is accepted
-    // (diffusion.py:378-388)
+    float z[4];
+    trunc_normal4((uint64_t)((first >> 2) + gi), step, bound, seed_lo, seed_hi, stream_id, z);
     const int64_t i = gi << 2;
     if (i + 4 <= n) *reinterpret_cast<f32x4*>(out + i) = f32x4{z[0], z[1], z[2], z[3]};
     else for (int k = 0; k < 4 && i + k < n; ++k) out[i + k] = z[k];
@@ -447,8 +464,9 @@ extern "C" int mh_ddim_epilogue(const float* model_out, const float* x_t, const 
 extern "C" int mh_step_epilogue_slots(int ddim, const float* x_t, const float* noise, const float* pbest, const int32_t* pidx, int nslots,
                                       const float* table, const mh_step_coef* coef, int coef_per_batch, int clip, const int32_t* mask,
                                       int mask_per_elem, const float* x_start, float* out, float* pred_xstart, float* mean_out,
-                                      int32_t* round_idx_out, int B, int64_t per_batch, int E, mh_stream_t stream) {
+                                      int32_t* round_idx_out, const mh_step_rng* rng, int B, int64_t per_batch, int E, mh_stream_t stream) {
   MH_CHECK_ARG(x_t && coef && out && pbest && pidx && table && nslots > 0, "step_epilogue_slots: null pointer");
+  MH_CHECK_ARG(!rng || (rng->first_elem % 4 == 0 && (rng->bound <= 0.f || rng->bound >= 0.1f)), "step_epilogue_slots: bad rng descriptor");
   MH_CHECK_ARG(!mask || x_start, "step_epilogue_slots: mask needs x_start");
   MH_CHECK_ARG(B > 0 && per_batch > 0 && E > 0 && per_batch % E == 0, "step_epilogue_slots: bad shape");
   MH_CHECK_ARG(step_epilogue_vec_ok(nullptr, x_t, noise, table, x_start, out, pred_xstart, ddim ? nullptr : mean_out, B, per_batch, E),
@@ -456,6 +474,19 @@ extern "C" int mh_step_epilogue_slots(int ddim, const float* x_t, const float* n
   const int64_t ng = (int64_t)B * per_batch / 4;
   const float* none = nullptr;
   const int32_t* nidx = nullptr;
+  if (rng) {
+    const StepRng r{(uint32_t)rng->seed, (uint32_t)(rng->seed >> 32), rng->stream_id, rng->bound, rng->step_counter, (uint64_t)(rng->first_elem >> 2)};
+    if (ddim)
+      MH_LAUNCH((step_epilogue4_kernel<true, true, true>), dim3(ew_grid(ng)), dim3(EW_BLOCK), 0, (hipStream_t)stream, none, x_t, none, nidx, table, coef,
+                coef_per_batch, clip, mask, mask_per_elem, x_start, out, pred_xstart, (float*)nullptr, ng, (uint32_t)(per_batch / 4), (uint32_t)(E / 4), E,
+                pbest, pidx, nslots, round_idx_out, r);
+    else
+      MH_LAUNCH((step_epilogue4_kernel<false, true, true>), dim3(ew_grid(ng)), dim3(EW_BLOCK), 0, (hipStream_t)stream, none, x_t, none, nidx, table, coef,
+                coef_per_batch, clip, mask, mask_per_elem, x_start, out, pred_xstart, mean_out, ng, (uint32_t)(per_batch / 4), (uint32_t)(E / 4), E,
+                pbest, pidx, nslots, round_idx_out, r);
+    MH_CHECK_LAUNCH();
+    return MH_OK;
+  }
   if (ddim)
     MH_LAUNCH((step_epilogue4_kernel<true, true>), dim3(ew_grid(ng)), dim3(EW_BLOCK), 0, (hipStream_t)stream, none, x_t, noise, nidx, table, coef,
               coef_per_batch, clip, mask, mask_per_elem, x_start, out, pred_xstart, (float*)nullptr, ng, (uint32_t)(per_batch / 4), (uint32_t)(E / 4), E,

@@ -178,6 +178,7 @@ class GaussianDiffusion:
     # the step's rounding without its two small launches (row_sqnorm, argbest_reduce): |row|^2 from the fused down-projection, the
     # slot fold inside the update kernel.  False = the round-3 launch sequence (A/B, tests)
     fuse_rounding = True
+    fuse_noise = True          # ... and the update kernel draws the in-graph Philox noise itself (same values as mh_trunc_normal)
 
     def __init__(self, *, betas, predict_xstart, rescale_timesteps=False):
         self.rescale_timesteps = rescale_timesteps
@@ -709,8 +710,14 @@ class _ReverseLoop:
                 self.full_ws = eng.new_workspace(B, L)
         self.decoupled = False
 
-    def _tail(self, sl, stream_h, ws, cur_coef, use_round):
-        """rounding + posterior / DDIM update of the batch slice `sl` on the given stream"""
+    def _rng_in_update(self, use_round, in_graph_rng):
+        """the update kernel draws the step's noise itself (no generator launch, no noise tensor): in-graph Philox noise on the fused
+        rounding path"""
+        return bool(in_graph_rng and use_round and self.fused_round and getattr(self.diff, "fuse_noise", True))
+
+    def _tail(self, sl, stream_h, ws, cur_coef, use_round, state=None):
+        """rounding + posterior / DDIM update of the batch slice `sl` on the given stream (state: the loop state whose step counter
+        numbers the noise when the update kernel draws it)"""
         L_, P = _lib.lib(), _lib.ptr
         per_batch = self.L * self.E
         nb = sl.stop - sl.start
@@ -721,12 +728,18 @@ class _ReverseLoop:
             V = self.table32.shape[0]
             _lib.check(L_.mh_round_scores(P(self.model_out[sl]), P(self.sqnorm[tok]), P(self.table_pad), P(self.table_norm), P(self.pbest[slots]),
                                           P(self.pidx[slots]), nb * self.L, self.E, V, stream_h), "mh_round_scores")
-            _lib.check(L_.mh_step_epilogue_slots(0 if self.kind == "p" else 1, P(self.x[sl]), P(self.noise[sl]), P(self.pbest[slots]),
-                                                 P(self.pidx[slots]), ns, P(self.table32), P(cur_coef), 0, int(self.clip),
+            rng = None
+            if state is not None:
+                rng = _lib.StepRng()
+                rng.seed, rng.stream_id, rng.bound = int(self.diff.rng_seed) & (2 ** 64 - 1), int(self.diff.rng_stream), float(self.top_p)
+                rng.step_counter, rng.first_elem = self._rng_counter(state), sl.start * per_batch
+            _lib.check(L_.mh_step_epilogue_slots(0 if self.kind == "p" else 1, P(self.x[sl]), None if rng is not None else P(self.noise[sl]),
+                                                 P(self.pbest[slots]), P(self.pidx[slots]), ns, P(self.table32), P(cur_coef), 0, int(self.clip),
                                                  P(self.mask[sl]) if self.mask is not None else None, self.mask_per_elem,
                                                  P(self.x_start[sl]) if self.x_start is not None else None, P(self.x[sl]), P(self.pred[sl]),
                                                  P(self.mean[sl]) if (self.mean is not None and self.kind == "p") else None,
-                                                 P(self.round_idx[tok]), nb, per_batch, self.E, stream_h), "mh_step_epilogue_slots")
+                                                 P(self.round_idx[tok]), C.byref(rng) if rng is not None else None, nb, per_batch, self.E,
+                                                 stream_h), "mh_step_epilogue_slots")
             return
         if use_round:
             _lib.check(L_.mh_round_to_embedding_mfma(P(self.model_out[sl]), P(self.table_pad), P(self.table_norm),
@@ -762,11 +775,13 @@ class _ReverseLoop:
         nsplit = self.nsplit
         per_batch = self.L * self.E
 
+        rng_in_update = self._rng_in_update(use_round, in_graph_rng)
+
         def tail(sl, stream_h, ws):
-            self._tail(sl, stream_h, ws, self.cur_coef, use_round)
+            self._tail(sl, stream_h, ws, self.cur_coef, use_round, self.state if rng_in_update else None)
 
         def draw_noise(stream_h):
-            if in_graph_rng:
+            if in_graph_rng and not rng_in_update:
                 _lib.check(L_.mh_trunc_normal(P(self.noise), self.noise.numel(), float(self.top_p), int(self.diff.rng_seed),
                                               int(self.diff.rng_stream), self._rng_counter(self.state), stream_h), "mh_trunc_normal")
 
@@ -835,10 +850,12 @@ class _ReverseLoop:
         state, coef = self.br_state[j], self.br_coef[j]
         _lib.check(L_.mh_step_advance(P(state), P(self.steps), P(self.coef_table), P(coef), P(self.emb_row[sl]), nb, st), "mh_step_advance")
         per_batch = self.L * self.E
-        _lib.check(L_.mh_trunc_normal_at(P(self.noise[sl]), nb * per_batch, sl.start * per_batch, float(self.top_p), int(self.diff.rng_seed),
-                                         int(self.diff.rng_stream), self._rng_counter(state), st), "mh_trunc_normal_at")
+        rng_here = self._rng_in_update(use_round, True)        # (decoupled branches exist only with in-graph noise)
+        if not rng_here:
+            _lib.check(L_.mh_trunc_normal_at(P(self.noise[sl]), nb * per_batch, sl.start * per_batch, float(self.top_p), int(self.diff.rng_seed),
+                                             int(self.diff.rng_stream), self._rng_counter(state), st), "mh_trunc_normal_at")
         self._forward(sl, self.split_ws[j], use_round)
-        self._tail(sl, st, self.split_round_ws[j], coef, use_round)
+        self._tail(sl, st, self.split_round_ws[j], coef, use_round, state if rng_here else None)
 
     def begin(self):
         """Warm-up launch outside capture (one-time lazy initialisation inside the launchers), state restored."""

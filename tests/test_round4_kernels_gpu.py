@@ -147,11 +147,12 @@ def test_step_with_fused_rounding_pieces_equals_the_separate_launches(kind):
     emb = torch.nn.Embedding(V, E, _weight=m.word_embedding.weight.clone()).eval().requires_grad_(False)
     fn = partial(denoised_fn_round, emb, dist=None)
     res = {}
-    for fused in (True, False):
-        for graph in (True, False):
+    for fused, graph, own_noise in ((True, True, True), (True, False, True), (False, True, True), (False, False, True), (True, True, False)):
+        if True:
             diff = SpacedDiffusion(use_timesteps=space_timesteps(2000, [2000]), betas=get_named_beta_schedule("sqrt", 2000),
                                    rescale_timesteps=True, predict_xstart=True)
             diff.rng_mode, diff.rng_seed, diff.rng_stream, diff.use_graph, diff.fuse_rounding, diff.batch_split = "philox", 105, 0, graph, fused, 2
+            diff.fuse_noise = own_noise          # True: the update kernel draws the noise; False: mh_trunc_normal at the head of the step
             idx = list(range(2000))[::-1][:3]
             loop = _ReverseLoop.try_build(diff, kind, m, x0, True, fn, 1 if kind == "p" else None, mask3, x_start, 0.0, idx, lambda i: fn, False)
             assert loop is not None and loop.fused_round == fused
@@ -163,7 +164,9 @@ def test_step_with_fused_rounding_pieces_equals_the_separate_launches(kind):
             torch.cuda.synchronize()
             st = loop.state.cpu().tolist()
             assert st[0] == 3 and st[1] == 3 and st[2] == idx[2]              # pos, n_steps, cur_t after three steps
-            res[(fused, graph)] = (loop.x.clone(), loop.round_idx.clone(), loop.pred.clone())
+            res[(fused, graph) if own_noise else "separate noise launch"] = (loop.x.clone(), loop.round_idx.clone(), loop.pred.clone())
+    # the noise drawn inside the update kernel is the noise mh_trunc_normal writes: identical samples, bit for bit
+    assert all(torch.equal(a, b) for a, b in zip(res[(True, True)], res["separate noise launch"]))
     for fused in (True, False):                                             # eager and captured step: the same launches
         assert torch.equal(res[(fused, True)][0], res[(fused, False)][0]) and torch.equal(res[(fused, True)][1], res[(fused, False)][1])
     (xa, ia, pa), (xb, ib, pb) = res[(True, True)], res[(False, True)]

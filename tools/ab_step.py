@@ -24,6 +24,7 @@ setters = {"gemm_debug": lambda v: _lib.lib().mh_gemm_set_debug(v), "plain_store
 from musediffusion_amd.models.diffusion import GaussianDiffusion  # noqa: E402
 setters["decouple"] = lambda v: setattr(GaussianDiffusion, "decouple_branches", bool(v))
 setters["shared"] = lambda v: setattr(GaussianDiffusion, "shared_head_tail", bool(v))
+setters["fuse_noise"] = lambda v: setattr(GaussianDiffusion, "fuse_noise", bool(v))
 setters["fuse_rounding"] = lambda v: setattr(GaussianDiffusion, "fuse_rounding", bool(v))
 setters["skew"] = lambda v: setattr(GaussianDiffusion, "branch_skew_us", None if v < 0 else v)       # microseconds; -1 = automatic
 res = {v: [] for v in values}
