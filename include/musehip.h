@@ -615,10 +615,27 @@ int mh_down_proj_fused(const void* X, int64_t ldx, const void* w0, const float* 
 int mh_denoiser_gives_sqnorm(const mh_denoiser* m);
 int mh_denoiser_forward_sqnorm(const mh_denoiser* m, const float* x, const float* emb_t, const int32_t* emb_row, float* out,
                                float* out_sqnorm, int B, int L, void* workspace, size_t workspace_bytes, mh_stream_t stream);
+/* Rounding INSIDE the forward's last kernel (bf16 throughput mode; E = 128, d_model 512, 640 < V <= 768 - the ComMU vocabulary on
+ * BASELINE config 2's width): the fused down-projection splits its fp32 rows into bf16 hi + lo parts and contracts
+ * [x_hi | x_lo | x_hi] with the table's [T_hi | T_hi | T_lo] on the bf16 matrix pipe (three products per element, fp32 accumulation:
+ * fp32-grade scores to 2^-16), then takes -(clamp((|T_v|^2 + |x_n|^2) - 2 x.T_v, 0)) and the first-index argmax of
+ * models/rounding.py:21-28.  mh_round_split_table prepares the table operand once per loop (buf: mh_round_split_bytes; table_norm:
+ * optional caller-computed |T_v|^2 [V]).  The fp32 parity mode keeps the exact-fp32 score GEMM (mh_round_to_embedding_mfma). */
+int mh_down_proj_round_supported(int E, int H, int V);
+size_t mh_round_split_bytes(int E, int V);
+int mh_round_split_table(const float* table, const float* table_norm, int V, int E, void* buf, mh_stream_t stream);
+int mh_down_proj_round_fused(const void* X, int64_t ldx, const void* w0, const float* b0, const void* w2, const float* b2, float* out,
+                             float* out_sqnorm, const void* table_split, int V, int32_t* idx_out, int64_t rows, int E, int H,
+                             mh_stream_t stream);
+int mh_denoiser_rounds_in_forward(const mh_denoiser* m, int V);
+int mh_denoiser_forward_round(const mh_denoiser* m, const float* x, const float* emb_t, const int32_t* emb_row, float* out,
+                              const void* table_split, int V, int32_t* idx_out, int B, int L, void* workspace, size_t workspace_bytes,
+                              mh_stream_t stream);
 /* Rounding (models/rounding.py:21-28) split for a captured step: mh_round_scores = the exact-fp32 score GEMM of
  * mh_round_to_embedding_mfma with |x_n|^2 supplied by the caller, leaving the winners of every column slot in pbest / pidx
  * [n_tokens][mh_round_slots(V)]; mh_step_epilogue_slots = mh_p_sample_epilogue (ddim = 0) / mh_ddim_epilogue (ddim = 1) folding
- * those slots itself (larger score, then smaller index - the rule of the separate reduce) and optionally writing the index per row.
+ * those slots itself (larger score, then smaller index - the rule of the separate reduce) and optionally writing the index per row;
+ * nslots = 0: pidx already holds the final index per row (mh_denoiser_forward_round) and pbest is not read.
  * Together with mh_denoiser_forward_sqnorm: two launches less per batch slice and step.  E % 16 == 0. */
 int mh_round_slots(int V);
 int mh_round_scores(const float* x, const float* x_sqnorm, const float* table_pad, const float* table_norm, float* pbest,

@@ -74,6 +74,10 @@ int mh_attention_set_ablation(int bits);
  * separate launches of rounds 1-3 */
 int mh_denoiser_set_fuse_headtail(int on);
 
+/* A/B: K32-panel launches (the sampler's engine) on the 256 x 256 tile by role - bit 0 dense + GELU (FFN1), bit 1 the QKV projection,
+ * bit 2 every other launch whose N is a multiple of 256; 0 (default) = all of them on the 256 x 128 tile */
+int mh_gemm_set_wide_roles(int mask);
+
 /* experiment knob (A/B only): co-resident partner blocks of the big-tile GEMMs start `ticks` x 10 ns late */
 int mh_gemm_set_stagger(int ticks);
 

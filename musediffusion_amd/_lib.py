@@ -197,6 +197,12 @@ SIGNATURES = {
     "mh_down_proj_fused": (INT, [VP, I64, VP, VP, VP, VP, VP, VP, I64, INT, INT, VP]),
     "mh_denoiser_gives_sqnorm": (INT, [C.POINTER(Denoiser)]),
     "mh_denoiser_forward_sqnorm": (INT, [C.POINTER(Denoiser), VP, VP, VP, VP, VP, INT, INT, VP, C.c_size_t, VP]),
+    "mh_down_proj_round_supported": (INT, [INT, INT, INT]),
+    "mh_round_split_bytes": (C.c_size_t, [INT, INT]),
+    "mh_round_split_table": (INT, [VP, VP, INT, INT, VP, VP]),
+    "mh_down_proj_round_fused": (INT, [VP, I64, VP, VP, VP, VP, VP, VP, VP, INT, VP, I64, INT, INT, VP]),
+    "mh_denoiser_rounds_in_forward": (INT, [C.POINTER(Denoiser), INT]),
+    "mh_denoiser_forward_round": (INT, [C.POINTER(Denoiser), VP, VP, VP, VP, VP, INT, VP, INT, INT, VP, C.c_size_t, VP]),
     "mh_round_slots": (INT, [INT]),
     "mh_round_scores": (INT, [VP, VP, VP, VP, VP, VP, I64, INT, INT, VP]),
     "mh_step_epilogue_slots": (INT, [INT, VP, VP, VP, VP, INT, VP, VP, INT, INT, VP, INT, VP, VP, VP, VP, VP, VP, INT, I64, INT, VP]),
@@ -209,6 +215,7 @@ SIGNATURES = {
 
 # include/musehip_dbg.h: exported by libmusehip_dbg.so only (A/B switches, ablation knobs, diagnostics)
 DBG_SIGNATURES = {
+    "mh_gemm_set_wide_roles": (INT, [INT]),
     "mh_denoiser_set_fuse_headtail": (INT, [INT]),
     "mh_attention_set_stream": (INT, [INT]),
     "mh_attention_set_variant": (INT, [INT]),

@@ -226,6 +226,7 @@ __global__ __launch_bounds__(256) void step_epilogue4_kernel(const float* __rest
       float best = -INFINITY;
       int bi = 0x7fffffff;
       const int64_t s0 = (int64_t)row * nslots;
+      if (nslots == 0) bi = pidx[row];                    // (already folded: the index itself)
       for (int sl = 0; sl < nslots; ++sl) {               // (the lanes of a row read the same addresses: one broadcast line per step)
         const float v = pbest[s0 + sl];
         const int k = pidx[s0 + sl];
@@ -465,7 +466,7 @@ extern "C" int mh_step_epilogue_slots(int ddim, const float* x_t, const float* n
                                       const float* table, const mh_step_coef* coef, int coef_per_batch, int clip, const int32_t* mask,
                                       int mask_per_elem, const float* x_start, float* out, float* pred_xstart, float* mean_out,
                                       int32_t* round_idx_out, const mh_step_rng* rng, int B, int64_t per_batch, int E, mh_stream_t stream) {
-  MH_CHECK_ARG(x_t && coef && out && pbest && pidx && table && nslots > 0, "step_epilogue_slots: null pointer");
+  MH_CHECK_ARG(x_t && coef && out && pidx && table && nslots >= 0 && (pbest || nslots == 0), "step_epilogue_slots: null pointer");
   MH_CHECK_ARG(!rng || (rng->first_elem % 4 == 0 && (rng->bound <= 0.f || rng->bound >= 0.1f)), "step_epilogue_slots: bad rng descriptor");
   MH_CHECK_ARG(!mask || x_start, "step_epilogue_slots: mask needs x_start");
   MH_CHECK_ARG(B > 0 && per_batch > 0 && E > 0 && per_batch % E == 0, "step_epilogue_slots: bad shape");

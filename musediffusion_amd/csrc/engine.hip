@@ -239,7 +239,8 @@ namespace {
 // launches are latency-bound at a half batch (16 K-steps, a quarter to a half of the chip's block slots), so two half-size launches
 // cost twice one full-size launch.
 struct Phases { int mask; void* xh; int64_t ldh; const void* xi; int64_t ldi; void* xo; int64_t ldo; const void* xt; int64_t ldt;
-                float* sq; };   // sq: optional [B L] |output row|^2, written by the fused down-projection (mh_denoiser_gives_sqnorm)
+                float* sq;      // sq: optional [B L] |output row|^2, written by the fused down-projection (mh_denoiser_gives_sqnorm)
+                const void* tsplit; int V; int32_t* idx; };   // rounding inside the down-projection kernel (mh_denoiser_forward_round)
 int denoiser_run(const mh_denoiser* m, const float* x, const float* emb_t, const int32_t* emb_row, float* out, int B, int L,
                  void* workspace, size_t workspace_bytes, mh_stream_t stream, const Phases& ph);
 }  // namespace
@@ -261,6 +262,20 @@ extern "C" int mh_denoiser_forward_sqnorm(const mh_denoiser* m, const float* x, 
   MH_CHECK_ARG(x && emb_t && out && out_sqnorm, "denoiser_forward_sqnorm: null pointer");
   MH_CHECK_ARG(mh_denoiser_gives_sqnorm(m), "denoiser_forward_sqnorm: this model's forward does not end in the fused down-projection");
   return denoiser_run(m, x, emb_t, emb_row, out, B, L, workspace, workspace_bytes, stream, Phases{7, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, 0, out_sqnorm});
+}
+
+// The forward whose last kernel also rounds its rows to the nearest embedding (models/rounding.py:21-28 on the split-bf16 matrix pipe,
+// csrc/headtail.hip): idx_out [B L] receives the nearest table row per token.  table_split: mh_round_split_table's buffer.
+extern "C" int mh_denoiser_rounds_in_forward(const mh_denoiser* m, int V) {
+  return m && m->panel && m->has_proj && mh_down_proj_round_supported(m->E, m->H, V);
+}
+extern "C" int mh_denoiser_forward_round(const mh_denoiser* m, const float* x, const float* emb_t, const int32_t* emb_row, float* out,
+                                         const void* table_split, int V, int32_t* idx_out, int B, int L, void* workspace,
+                                         size_t workspace_bytes, mh_stream_t stream) {
+  MH_CHECK_ARG(x && emb_t && out && table_split && idx_out, "denoiser_forward_round: null pointer");
+  MH_CHECK_ARG(mh_denoiser_rounds_in_forward(m, V), "denoiser_forward_round: this model / vocabulary is not served by the fused rounding");
+  return denoiser_run(m, x, emb_t, emb_row, out, B, L, workspace, workspace_bytes, stream,
+                      Phases{7, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, table_split, V, idx_out});
 }
 
 // Phased entry points (bf16 K32-panel models with up / down projections only; see Phases).  X buffers: bf16 [H / 32][ld rows][32].
@@ -429,6 +444,8 @@ int denoiser_run(const mh_denoiser* m, const float* x, const float* emb_t, const
     if (!(ph.mask & 4)) return MH_OK;
     if (m->has_proj) {
       if (g_skip & 64) return MH_OK;
+      if (ph.idx)   // ... and the nearest-embedding rounding of its rows
+        return mh_down_proj_round_fused(XT, ldT, m->w_dn0, m->b_dn0, m->w_dn2, m->b_dn2, out, ph.sq, ph.tsplit, ph.V, ph.idx, N, m->E, H, stream);
       if (mh_down_proj_fused_supported(m->E, H))   // one kernel for both dense layers of the down-projection (csrc/headtail.hip)
         return mh_down_proj_fused(XT, ldT, m->w_dn0, m->b_dn0, m->w_dn2, m->b_dn2, out, ph.sq, N, m->E, H, stream);
       if ((rc = gemm(XT, ldT, m->w_dn0, H, m->b_dn0, nullptr, 0, w.buf0, 0, N, H, H, MH_ACT_TANH))) return rc;

@@ -1305,9 +1305,14 @@ bool big_tile_ok(const GemmArgs& g) {
 // when it still gives every CU a block - bench.py --workload train -2.1 % (tools/ab_train.py gemm_variant 2 4); the engine's
 // K32-panel launches (two concurrent branches) keep the 256x128 tile.  mh_gemm_set_auto_wide(0) switches the rule off.
 MH_KNOB(int, g_auto_wide, 1);
+MH_KNOB(int, g_wide_roles, 0);   // A/B (mh_gemm_set_wide_roles): panel launches on the 256x256 tile by role: bit 0 dense + GELU, bit 1 QKV scatter, bit 2 the rest
 bool want_wide(const GemmArgs& g, int batch) {
   if (g.N % 256 != 0) return false;
   if (g_variant >= 4) return true;
+  if (g_wide_roles && (g.a_panel || g.w_panel)) {
+    const int role = g.act == MH_ACT_GELU_ERF ? 1 : (g.q ? 2 : 4);
+    if (g_wide_roles & role) return true;
+  }
   if (g_variant != 2 || !g_auto_wide || batch != 1) return false;
   if (g.a_panel || g.w_panel || g.o_panel || g.r_panel || g.q) return false;
   return (int64_t)ceil_div(g.M, 256) * (g.N / 256) >= device_cus();
@@ -1387,6 +1392,12 @@ extern "C" int mh_gemm_set_debug(int bits) {
 }
 #endif
 
+#ifdef MH_ABLATE
+extern "C" int mh_gemm_set_wide_roles(int mask) {
+  g_wide_roles = mask;
+  return MH_OK;
+}
+#endif
 #ifdef MH_ABLATE
 extern "C" int mh_gemm_set_auto_wide(int on) {
   g_auto_wide = on ? 1 : 0;

@@ -36,6 +36,11 @@ struct TailArgs {
   const bf16* w2; const float* b2;      // [H / 32][E][32]  (E rows: the down-projection's outputs)
   float* out;                           // [rows, E] fp32
   float* sqnorm;                        // optional [rows]: |out row|^2 (the rounding scores' |x_n|^2, models/rounding.py:23)
+  // ROUND (TJ3 > 0): nearest-embedding rounding of the block's rows inside the same kernel (models/rounding.py:21-28)
+  const bf16* tsplit;                   // [3 E / 32][Vp][32]: the table as bf16 hi | hi | lo parts (mh_round_split_table)
+  const float* tnorm;                   // [Vp]: |T_v|^2 fp32, +inf for rows >= V
+  int V;
+  int32_t* idx;                         // [rows]: nearest row per token
 };
 
 template <int N> __device__ __forceinline__ void ht_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
@@ -237,7 +242,13 @@ __global__ __launch_bounds__(H / 64 * 64, H / 256) void head_fused_kernel(const 
 // tail: the block's 64 x H input rows are DMA'd whole into the slab area (they are the A operand of the first dense layer), its
 // tanh output replaces them there, and the E outputs of the second layer are spread over the waves 16 columns each
 // (E = 128 on 8 waves; E_pad = 64: the upper waves repeat the lower ones' columns and do not store).
-template <int H>
+// TJ3 > 0: phase 3 - the rounding scores of the block's 64 rows against the whole embedding table on the bf16 matrix pipe at fp32
+// grade: x = x_hi + x_lo, T = T_hi + T_lo (bf16 parts), x . T ~ x_hi T_hi + x_lo T_hi + x_hi T_lo (three products per element, the
+// dropped x_lo T_lo term is 2^-16 of the product), as ONE K = 3 E contraction [x_hi | x_lo | x_hi] . [T_hi | T_hi | T_lo]^T with fp32
+// accumulation.  A wave owns 16 TJ3 table rows; -(clamp((|T_v|^2 + |x_n|^2) - 2 x.T_v, 0)) and the first-index argmax exactly as the
+// score GEMM's epilogue + argbest_reduce do them, folded lane -> 4 lanes -> waves through LDS.  Replaces the exact-fp32 score GEMM
+// launch (30 us per half batch) in the bf16 throughput mode; the fp32 parity mode keeps the exact-fp32 MFMA path.
+template <int H, int TJ3 = 0>
 __global__ __launch_bounds__(H / 64 * 64, H / 256) void tail_fused_kernel(const TailArgs g) {
   constexpr int NW = H / 64, NK = H / 32, SLOT = H * 64;
   constexpr int H1_BYTES = NK * HT_SLAB, LDS_BYTES = H1_BYTES + 3 * SLOT;
@@ -330,6 +341,123 @@ __global__ __launch_bounds__(H / 64 * 64, H / 256) void tail_fused_kernel(const 
       if (r < g.rows) *reinterpret_cast<f32x4*>(g.out + r * g.E + col) = v;
     }
   }
+  if constexpr (TJ3 > 0) {
+    constexpr int VP = 16 * TJ3 * NW, SLOT3 = VP * 64, NK3 = 3 * 4;      // (E = 128: 4 slabs per part, 12 K32 steps)
+    static_assert(2 * SLOT3 <= 3 * SLOT && NK3 * HT_SLAB <= H1_BYTES, "rounding phase: LDS");
+    ht_lgkm0();
+    __builtin_amdgcn_s_barrier();           // every wave is past its last fragment read of phase 2: slabs and ring are free
+    auto issue3 = [&](int kt) {
+      const int rl = lane >> 2, pc = lane & 3, lc = pc ^ ht_g((rl >> 2) & 3);
+#pragma unroll
+      for (int j = 0; j < TJ3; ++j) {
+        const int p = wave * TJ3 + j;
+        const bf16* src = g.tsplit + ((int64_t)kt * VP + p * 16 + rl) * 32 + lc * 8;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(ring + (kt & 1) * SLOT3 + p * 1024), 16, 0, 0);
+      }
+    };
+    issue3(0);
+    // x_hi | x_lo | x_hi slabs: this lane's 4 columns of row 16 i + fr -> 8 bytes in slab col / 32 (+ 4 for the low part, + 8 again the high part)
+    float* red = reinterpret_cast<float*>(h1 + NK3 * HT_SLAB);            // [64][NW] |row|^2 partials, then best scores
+    int* redi = reinterpret_cast<int*>(red + HT_ROWS * NW);               // [64][NW] best indices
+    float* xn = reinterpret_cast<float*>(redi + HT_ROWS * NW);            // [64] |x_n|^2
+    {
+      const int col = p2 * 16 + 4 * fg;
+      const f32x4 bv = *reinterpret_cast<const f32x4*>(g.b2 + col);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = 16 * i + fr;
+        const f32x4 v = y[i] + bv;
+        bf16x4 hi, lo;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { hi[e] = (bf16)v[e]; lo[e] = (bf16)(v[e] - (float)hi[e]); }
+        char* dst = h1 + (col >> 5) * HT_SLAB + row * 64 + (((((col & 31) >> 3)) ^ ht_g((row >> 2) & 3)) << 4) + (col & 4) * 2;
+        *reinterpret_cast<bf16x4*>(dst) = hi;
+        *reinterpret_cast<bf16x4*>(dst + 4 * HT_SLAB) = lo;
+        *reinterpret_cast<bf16x4*>(dst + 8 * HT_SLAB) = hi;
+        float v2 = ss[i];
+        v2 += __shfl_xor(v2, 16, 64);
+        v2 += __shfl_xor(v2, 32, 64);
+        if (fg == 0) red[row * NW + wave] = v2;
+      }
+    }
+    ht_lgkm0();
+    __builtin_amdgcn_s_barrier();
+    if (tid < HT_ROWS) {
+      float t = 0.f;
+      for (int w = 0; w < NW; ++w) t += red[tid * NW + w];
+      xn[tid] = t;
+      if (g.sqnorm && row0 + tid < g.rows) g.sqnorm[row0 + tid] = t;
+    }
+    f32x4 sc[4][TJ3];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < TJ3; ++j) sc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int b3_offs[TJ3];
+#pragma unroll
+    for (int j = 0; j < TJ3; ++j) b3_offs[j] = ((wave * TJ3 + j) * 16 + fr) * 64 + ((fg ^ ht_g((fr >> 2) & 3)) << 4);
+    for (int kt = 0; kt < NK3; ++kt) {
+      ht_wait_vmcnt<0>();
+      ht_lgkm0();
+      __builtin_amdgcn_s_barrier();             // stage kt landed everywhere; stage kt - 1's slot is free (kt = 0: also publishes the slabs and xn)
+      if (kt + 1 < NK3) issue3(kt + 1);
+      bf16x8 a[4], b[TJ3];
+#pragma unroll
+      for (int j = 0; j < TJ3; ++j) b[j] = *reinterpret_cast<const bf16x8*>(ring + (kt & 1) * SLOT3 + b3_offs[j]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const bf16x8*>(h1 + kt * HT_SLAB + a_off + i * 1024);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ3; ++j) sc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], sc[i][j], 0, 0, 0);
+    }
+    // scores -> the best (score, first index) of every row: D[m = 4 fg + r][n = fr] = table row 16 (wave TJ3 + j) + 4 fg + r, token row 16 i + fr
+    float tn[TJ3][4];
+#pragma unroll
+    for (int j = 0; j < TJ3; ++j) {
+      const f32x4 t4 = *reinterpret_cast<const f32x4*>(g.tnorm + (wave * TJ3 + j) * 16 + 4 * fg);
+      tn[j][0] = t4[0]; tn[j][1] = t4[1]; tn[j][2] = t4[2]; tn[j][3] = t4[3];
+    }
+    ht_lgkm0();
+    __builtin_amdgcn_s_barrier();               // (xn was written before the K loop's first barrier; `red` is reused below)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float x2 = xn[16 * i + fr];
+      float best = -INFINITY;
+      int bi = 0x7fffffff;
+#pragma unroll
+      for (int j = 0; j < TJ3; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int col = (wave * TJ3 + j) * 16 + 4 * fg + r;
+          float dist = (tn[j][r] + x2) - 2.0f * sc[i][j][r];
+          dist = fmaxf(dist, 0.0f);
+          const float s1 = -dist;
+          if (col < g.V && s1 > best) { best = s1; bi = col; }
+        }
+#pragma unroll
+      for (int off = 16; off < 64; off <<= 1) {
+        const float so = __shfl_xor(best, off, 64);
+        const int io = __shfl_xor(bi, off, 64);
+        if (so > best || (so == best && io < bi)) { best = so; bi = io; }
+      }
+      if (fg == 0) { red[(16 * i + fr) * NW + wave] = best; redi[(16 * i + fr) * NW + wave] = bi; }
+    }
+    ht_lgkm0();
+    __builtin_amdgcn_s_barrier();
+    if (tid < HT_ROWS && row0 + tid < g.rows) {
+      float best = -INFINITY;
+      int bi = 0x7fffffff;
+      for (int w = 0; w < NW; ++w) {              // waves hold increasing column ranges: strict > keeps the first index
+        const float v = red[tid * NW + w];
+        const int k = redi[tid * NW + w];
+        if (v > best || (v == best && k < bi)) { best = v; bi = k; }
+      }
+      g.idx[row0 + tid] = bi == 0x7fffffff ? 0 : bi;
+    }
+    return;
+  }
   if (g.sqnorm) {   // |row|^2: 4 columns in the lane -> the 4 lanes of a row (xor 16, 32) -> the E / 16 waves through LDS, fixed order
     ht_lgkm0();
     __builtin_amdgcn_s_barrier();           // every wave is past its last fragment read: the ring's first bytes are free
@@ -381,11 +509,64 @@ extern "C" int mh_up_proj_ln_fused(const float* x, int E, int E_pad, const void*
   return MH_OK;
 }
 
+// the rounding phase is built for the ComMU vocabulary on the config-2 width: E = 128 (8 waves x 16 output columns, 12 K32 steps of
+// hi | lo | hi parts), d_model 512, 640 < V <= 768 (six 16-row table tiles per wave)
+extern "C" int mh_down_proj_round_supported(int E, int H, int V) {
+  return mh_down_proj_fused_supported(E, H) && E == 128 && H == 512 && V > 640 && V <= 768;
+}
+extern "C" size_t mh_round_split_bytes(int E, int V) { return (size_t)(3 * E / 32) * 768 * 32 * 2 + 768 * 4; }
+namespace {
+__global__ void round_split_kernel(const float* __restrict__ table, int V, int E, bf16* __restrict__ tsplit, float* __restrict__ tnorm, int Vp) {
+  // tsplit [3 E / 32][Vp][32]: parts hi | hi | lo of every table row (zero rows beyond V); tnorm [Vp] = |T_v|^2 (exact fp32, the sum
+  // order of row_sqnorm_f32_kernel is not needed here: the value only has to be the same for every query) or +inf beyond V
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= Vp) return;
+  float n2 = 0.f;
+  for (int c = 0; c < E; ++c) {
+    const float t = v < V ? table[(int64_t)v * E + c] : 0.f;
+    const bf16 hi = (bf16)t;
+    const bf16 lo = (bf16)(t - (float)hi);
+    n2 += t * t;
+    const int64_t o = ((int64_t)(c >> 5) * Vp + v) * 32 + (c & 31);
+    const int64_t part = (int64_t)(E / 32) * Vp * 32;
+    tsplit[o] = hi;
+    tsplit[o + part] = hi;
+    tsplit[o + 2 * part] = lo;
+  }
+  tnorm[v] = v < V ? n2 : INFINITY;
+}
+}  // namespace
+// one-time preparation of the table operands of the rounding phase: `buf` (mh_round_split_bytes) <- the split panels, then |T_v|^2.
+// table_norm (optional): the caller's own |T_v|^2 [V] (mh_row_sqnorm of the table: what the separate score GEMM adds), copied instead
+extern "C" int mh_round_split_table(const float* table, const float* table_norm, int V, int E, void* buf, mh_stream_t stream) {
+  MH_CHECK_ARG(table && buf && E == 128 && V > 0 && V <= 768, "round_split_table: bad arguments");
+  bf16* ts = (bf16*)buf;
+  float* tn = (float*)((char*)buf + (size_t)(3 * E / 32) * 768 * 32 * 2);
+  MH_LAUNCH(round_split_kernel, dim3(3), dim3(256), 0, (hipStream_t)stream, table, V, E, ts, tn, 768);
+  MH_CHECK_LAUNCH();
+  if (table_norm) MH_HIP(hipMemcpyAsync(tn, table_norm, (size_t)V * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return MH_OK;
+}
+
+extern "C" int mh_down_proj_round_fused(const void* X, int64_t ldx, const void* w0, const float* b0, const void* w2, const float* b2, float* out,
+                                        float* out_sqnorm, const void* table_split, int V, int32_t* idx_out, int64_t rows, int E, int H,
+                                        mh_stream_t stream) {
+  MH_CHECK_ARG(X && w0 && b0 && w2 && b2 && out && table_split && idx_out && rows > 0 && ldx >= rows, "down_proj_round_fused: bad arguments");
+  MH_CHECK_ARG(mh_down_proj_round_supported(E, H, V), "down_proj_round_fused: shape E=%d H=%d V=%d not served", E, H, V);
+  const float* tn = (const float*)((const char*)table_split + (size_t)(3 * E / 32) * 768 * 32 * 2);
+  TailArgs g{(const bf16*)X, ldx, rows, E, (const bf16*)w0, b0, (const bf16*)w2, b2, out, out_sqnorm, (const bf16*)table_split, tn, V, idx_out};
+  const dim3 grid((unsigned)((rows + HT_ROWS - 1) / HT_ROWS));
+  mh_prof_note("tail+round rows=%lld E=%d H=%d V=%d", (long long)rows, E, H, V);
+  MH_LAUNCH((tail_fused_kernel<512, 6>), grid, dim3(512), 0, (hipStream_t)stream, g);
+  MH_CHECK_LAUNCH();
+  return MH_OK;
+}
+
 extern "C" int mh_down_proj_fused(const void* X, int64_t ldx, const void* w0, const float* b0, const void* w2, const float* b2, float* out,
                                   float* out_sqnorm, int64_t rows, int E, int H, mh_stream_t stream) {
   MH_CHECK_ARG(X && w0 && b0 && w2 && b2 && out && rows > 0 && ldx >= rows, "down_proj_fused: bad arguments");
   MH_CHECK_ARG(mh_down_proj_fused_supported(E, H), "down_proj_fused: shape E=%d H=%d not served", E, H);
-  TailArgs g{(const bf16*)X, ldx, rows, E, (const bf16*)w0, b0, (const bf16*)w2, b2, out, out_sqnorm};
+  TailArgs g{(const bf16*)X, ldx, rows, E, (const bf16*)w0, b0, (const bf16*)w2, b2, out, out_sqnorm, nullptr, nullptr, 0, nullptr};
   const dim3 grid((unsigned)((rows + HT_ROWS - 1) / HT_ROWS));
   mh_prof_note("tail rows=%lld E=%d H=%d", (long long)rows, E, H);
   if (H == 512) MH_LAUNCH((tail_fused_kernel<512>), grid, dim3(512), 0, (hipStream_t)stream, g);

@@ -227,7 +227,7 @@ class DenoiserEngine:
         p, ld = self._window(rows, first)
         check(lib().mh_denoiser_tail(C.byref(self._desc), p, ld, ptr(out), B, L, ptr(ws), ws.numel(), current_stream()), "mh_denoiser_tail")
 
-    def forward(self, x, emb_t, emb_row=None, out=None, ws=None, sqnorm=None):
+    def forward(self, x, emb_t, emb_row=None, out=None, ws=None, sqnorm=None, round_to=None):
         """x [B,L,E] fp32 -> [B,L,E] fp32 (models/network.py:131-158).  emb_t [*,H] fp32,
         emb_row [B] int32 selecting the emb_t row of each batch element (None: row b).
         sqnorm [B L] fp32 (optional, only when mh_denoiser_gives_sqnorm): receives |out row|^2 per token."""
@@ -238,6 +238,11 @@ class DenoiserEngine:
         x = x.to(torch.float32).contiguous()
         out = torch.empty_like(x) if out is None else out
         ws = self._workspace(B, L) if ws is None else ws
+        if round_to is not None:       # (split table buffer, V, idx_out [B L] int32): the last kernel also rounds its rows
+            tsplit, V, idx = round_to
+            check(lib().mh_denoiser_forward_round(C.byref(self._desc), ptr(x), ptr(emb_t), ptr(emb_row), ptr(out), ptr(tsplit), int(V), ptr(idx),
+                                                  B, L, ptr(ws), ws.numel(), current_stream()), "mh_denoiser_forward_round")
+            return out
         if sqnorm is not None:
             check(lib().mh_denoiser_forward_sqnorm(C.byref(self._desc), ptr(x), ptr(emb_t), ptr(emb_row), ptr(out), ptr(sqnorm), B, L, ptr(ws),
                                                    ws.numel(), current_stream()), "mh_denoiser_forward_sqnorm")

@@ -178,6 +178,7 @@ class GaussianDiffusion:
     # the step's rounding without its two small launches (row_sqnorm, argbest_reduce): |row|^2 from the fused down-projection, the
     # slot fold inside the update kernel.  False = the round-3 launch sequence (A/B, tests)
     fuse_rounding = True
+    round_in_forward = True    # ... and the forward's last kernel rounds its rows itself (split-bf16 scores; config-2 width, ComMU vocabulary)
     fuse_noise = True          # ... and the update kernel draws the in-graph Philox noise itself (same values as mh_trunc_normal)
 
     def __init__(self, *, betas, predict_xstart, rescale_timesteps=False):
@@ -677,6 +678,14 @@ class _ReverseLoop:
             self.sqnorm = torch.empty(B * L, dtype=torch.float32, device=dev)
             self.pbest = torch.empty(B * L * self.nslots, dtype=torch.float32, device=dev)
             self.pidx = torch.empty(B * L * self.nslots, dtype=torch.int32, device=dev)
+        # ... or the forward's last kernel rounds its rows itself (split-bf16 scores, csrc/headtail.hip): no score GEMM launch at all
+        self.round_in_tail = bool(self.fused_round and getattr(diff, "round_in_forward", True) and
+                                  L_.mh_denoiser_rounds_in_forward(C.byref(eng._desc), self.table32.shape[0]))
+        if self.round_in_tail:
+            V = self.table32.shape[0]
+            self.tsplit = torch.empty(int(L_.mh_round_split_bytes(E, V)), dtype=torch.uint8, device=dev)
+            _lib.check(L_.mh_round_split_table(_lib.ptr(self.table32), _lib.ptr(self.table_norm), V, E, _lib.ptr(self.tsplit), _lib.current_stream()),
+                       "mh_round_split_table")
         split = getattr(diff, "batch_split", None)
         if split is None:
             # two half-batch branches overlap one half's attention / epilogues with the other's GEMM main loops (+4% at
@@ -704,7 +713,7 @@ class _ReverseLoop:
             # shared head / tail: full-batch hand-over buffers (the slices read / write row windows of them) and a full-batch workspace
             self.shared = bool(getattr(diff, "shared_head_tail", False) and eng.phases_supported())
             if self.shared:
-                self.fused_round = False        # (the phased tail entry point does not write |row|^2)
+                self.fused_round = self.round_in_tail = False        # (the phased tail entry point does not write |row|^2)
             if self.shared:
                 self.rows_in, self.rows_out = eng.new_rows(B * L), eng.new_rows(B * L)
                 self.full_ws = eng.new_workspace(B, L)
@@ -723,22 +732,24 @@ class _ReverseLoop:
         nb = sl.stop - sl.start
         tok = slice(sl.start * self.L, sl.stop * self.L)
         if use_round and self.fused_round:
-            ns = self.nslots
+            ns = 0 if self.round_in_tail else self.nslots
             slots = slice(tok.start * ns, tok.stop * ns)
             V = self.table32.shape[0]
-            _lib.check(L_.mh_round_scores(P(self.model_out[sl]), P(self.sqnorm[tok]), P(self.table_pad), P(self.table_norm), P(self.pbest[slots]),
+            if not self.round_in_tail:
+              _lib.check(L_.mh_round_scores(P(self.model_out[sl]), P(self.sqnorm[tok]), P(self.table_pad), P(self.table_norm), P(self.pbest[slots]),
                                           P(self.pidx[slots]), nb * self.L, self.E, V, stream_h), "mh_round_scores")
+            best_p, idx_p = (None, P(self.round_idx[tok])) if self.round_in_tail else (P(self.pbest[slots]), P(self.pidx[slots]))
             rng = None
             if state is not None:
                 rng = _lib.StepRng()
                 rng.seed, rng.stream_id, rng.bound = int(self.diff.rng_seed) & (2 ** 64 - 1), int(self.diff.rng_stream), float(self.top_p)
                 rng.step_counter, rng.first_elem = self._rng_counter(state), sl.start * per_batch
             _lib.check(L_.mh_step_epilogue_slots(0 if self.kind == "p" else 1, P(self.x[sl]), None if rng is not None else P(self.noise[sl]),
-                                                 P(self.pbest[slots]), P(self.pidx[slots]), ns, P(self.table32), P(cur_coef), 0, int(self.clip),
+                                                 best_p, idx_p, ns, P(self.table32), P(cur_coef), 0, int(self.clip),
                                                  P(self.mask[sl]) if self.mask is not None else None, self.mask_per_elem,
                                                  P(self.x_start[sl]) if self.x_start is not None else None, P(self.x[sl]), P(self.pred[sl]),
                                                  P(self.mean[sl]) if (self.mean is not None and self.kind == "p") else None,
-                                                 P(self.round_idx[tok]), C.byref(rng) if rng is not None else None, nb, per_batch, self.E,
+                                                 None if self.round_in_tail else P(self.round_idx[tok]), C.byref(rng) if rng is not None else None, nb, per_batch, self.E,
                                                  stream_h), "mh_step_epilogue_slots")
             return
         if use_round:
@@ -757,7 +768,12 @@ class _ReverseLoop:
 
     def _forward(self, sl, ws, use_round):
         """the denoiser on batch slice `sl` (with |out row|^2 when the fused rounding wants it)"""
-        sq = self.sqnorm[sl.start * self.L: sl.stop * self.L] if (use_round and self.fused_round) else None
+        tok = slice(sl.start * self.L, sl.stop * self.L)
+        if use_round and self.round_in_tail:
+            self.eng.forward(self.x[sl], self.emb_table, self.emb_row[sl], out=self.model_out[sl], ws=ws,
+                             round_to=(self.tsplit, self.table32.shape[0], self.round_idx[tok]))
+            return
+        sq = self.sqnorm[tok] if (use_round and self.fused_round) else None
         self.eng.forward(self.x[sl], self.emb_table, self.emb_row[sl], out=self.model_out[sl], ws=ws, sqnorm=sq)
 
     def _rng_counter(self, state):

@@ -147,15 +147,18 @@ def test_step_with_fused_rounding_pieces_equals_the_separate_launches(kind):
     emb = torch.nn.Embedding(V, E, _weight=m.word_embedding.weight.clone()).eval().requires_grad_(False)
     fn = partial(denoised_fn_round, emb, dist=None)
     res = {}
-    for fused, graph, own_noise in ((True, True, True), (True, False, True), (False, True, True), (False, False, True), (True, True, False)):
+    for fused, graph, own_noise in ((True, True, True), (True, False, True), (False, True, True), (False, False, True), (True, True, False),
+                                    ("in the forward", True, True), ("in the forward", False, True)):
         if True:
             diff = SpacedDiffusion(use_timesteps=space_timesteps(2000, [2000]), betas=get_named_beta_schedule("sqrt", 2000),
                                    rescale_timesteps=True, predict_xstart=True)
             diff.rng_mode, diff.rng_seed, diff.rng_stream, diff.use_graph, diff.fuse_rounding, diff.batch_split = "philox", 105, 0, graph, fused, 2
             diff.fuse_noise = own_noise          # True: the update kernel draws the noise; False: mh_trunc_normal at the head of the step
+            diff.round_in_forward = fused == "in the forward"      # the forward's last kernel rounds its rows (split-bf16 scores)
+            fused_name, fused = fused, bool(fused)
             idx = list(range(2000))[::-1][:3]
             loop = _ReverseLoop.try_build(diff, kind, m, x0, True, fn, 1 if kind == "p" else None, mask3, x_start, 0.0, idx, lambda i: fn, False)
-            assert loop is not None and loop.fused_round == fused
+            assert loop is not None and loop.fused_round == fused and loop.round_in_tail == (fused_name == "in the forward")
             with torch.no_grad():
                 loop.begin()
                 for k in range(3):
@@ -164,9 +167,13 @@ def test_step_with_fused_rounding_pieces_equals_the_separate_launches(kind):
             torch.cuda.synchronize()
             st = loop.state.cpu().tolist()
             assert st[0] == 3 and st[1] == 3 and st[2] == idx[2]              # pos, n_steps, cur_t after three steps
-            res[(fused, graph) if own_noise else "separate noise launch"] = (loop.x.clone(), loop.round_idx.clone(), loop.pred.clone())
+            res[(fused_name, graph) if own_noise else "separate noise launch"] = (loop.x.clone(), loop.round_idx.clone(), loop.pred.clone())
     # the noise drawn inside the update kernel is the noise mh_trunc_normal writes: identical samples, bit for bit
     assert all(torch.equal(a, b) for a, b in zip(res[(True, True)], res["separate noise launch"]))
+    # rounding inside the forward (split-bf16 scores) against the exact-fp32 score GEMM: the same rows except on near-ties
+    same_f = float((res[("in the forward", True)][1] == res[(True, True)][1]).float().mean())
+    print("%s: rounded index agreement, scores inside the forward vs exact-fp32 score GEMM %.6f" % (kind, same_f))
+    assert same_f >= 0.999 and all(torch.equal(a, b) for a, b in zip(res[("in the forward", True)], res[("in the forward", False)]))
     for fused in (True, False):                                             # eager and captured step: the same launches
         assert torch.equal(res[(fused, True)][0], res[(fused, False)][0]) and torch.equal(res[(fused, True)][1], res[(fused, False)][1])
     (xa, ia, pa), (xb, ib, pb) = res[(True, True)], res[(False, True)]
@@ -175,3 +182,43 @@ def test_step_with_fused_rounding_pieces_equals_the_separate_launches(kind):
     assert same >= 0.9995
     rows_same = (ia == ib).view(B, L, 1).expand_as(xa)
     assert torch.equal(xa[rows_same], xb[rows_same]) and torch.equal(pa[rows_same], pb[rows_same])
+
+
+@pytest.mark.parametrize("N,V", [(128, 729), (1000, 729), (16384, 729), (192, 650)])
+def test_down_proj_with_rounding_inside(N, V):
+    """mh_down_proj_round_fused: the down-projection's rows AND their nearest embedding row (models/rounding.py:21-28) from one kernel,
+    the scores on the bf16 matrix pipe as hi / lo parts (x_hi T_hi + x_lo T_hi + x_hi T_lo, fp32 accumulation).  Checked against the
+    float64 argmin of |x - T_v|^2 on the rows the kernel itself wrote: every row whose two best distances differ by more than the
+    split's resolution must agree (the rest are reported), and planted exact matches (x = a table row) must be found."""
+    H, E = 512, 128
+    X = rnd(N, H, seed=31, scale=1.0)
+    W0, b0 = rnd(H, H, seed=32, scale=1 / math.sqrt(H)), rnd(H, seed=33, scale=0.1)
+    W2, b2 = rnd(E, H, seed=34, scale=1 / math.sqrt(H)), rnd(E, seed=35, scale=0.1)
+    table = rnd(V, E, seed=36, scale=1.0)
+    Xp = X.bfloat16().reshape(N, H // 32, 32).permute(1, 0, 2).contiguous().to(DEV)
+    out, sq, idx = torch.zeros(N, E, device=DEV), torch.zeros(N, device=DEV), torch.full((N,), -1, device=DEV, dtype=torch.int32)
+    d = lambda t: t.to(DEV).contiguous()
+    assert lib().mh_down_proj_round_supported(E, H, V) == 1 and lib().mh_down_proj_round_supported(E, H, 500) == 0
+    td = d(table)
+    buf = torch.empty(int(lib().mh_round_split_bytes(E, V)), dtype=torch.uint8, device=DEV)
+    check(lib().mh_round_split_table(td.data_ptr(), None, V, E, buf.data_ptr(), current_stream()), "mh_round_split_table")
+    w0p, w2p, b0d, b2d = to_panel(W0), to_panel(W2), d(b0), d(b2)
+    check(lib().mh_down_proj_round_fused(Xp.data_ptr(), N, w0p.data_ptr(), b0d.data_ptr(), w2p.data_ptr(), b2d.data_ptr(), out.data_ptr(),
+                                         sq.data_ptr(), buf.data_ptr(), V, idx.data_ptr(), N, E, H, current_stream()), "mh_down_proj_round_fused")
+    ref = q16(torch.tanh(q16(X) @ q16(W0).T + b0)) @ q16(W2).T + b2
+    assert float((out.cpu() - ref).abs().max()) < 2e-3
+    y = out.cpu().double()
+    dist = ((y[:, None, :] - table.double()[None]) ** 2).sum(-1) if N <= 1000 else None
+    if dist is None:
+        t2 = (table.double() ** 2).sum(1)
+        dist = (y ** 2).sum(1, keepdim=True) + t2[None] - 2 * y @ table.double().T
+    best2 = torch.topk(-dist, 2, dim=1)
+    margin = (best2.values[:, 0] - best2.values[:, 1])                     # >= 0: gap between the best and the second-best distance
+    got = idx.cpu().long()
+    assert int(got.min()) >= 0 and int(got.max()) < V
+    agree = got == best2.indices[:, 0]
+    clear = margin > 1e-3 * dist.abs().max()                                # split resolution 2^-16 of |x||T| ~ 1e-5 relative: 1e-3 is generous
+    print("rows %d: agreement %.5f, clear rows %.5f" % (N, float(agree.float().mean()), float(clear.float().mean())))
+    assert bool(agree[clear].all()) and float(agree.float().mean()) > 0.999
+    sq_ref = (y ** 2).sum(1)
+    assert float(((sq.cpu().double() - sq_ref).abs() / sq_ref).max()) < 1e-5
