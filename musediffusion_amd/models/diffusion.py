@@ -166,9 +166,11 @@ class GaussianDiffusion:
     use_graph = True       # capture the reverse step into a hipGraph when the fused path applies
     batch_split = None     # denoiser batch slices run as concurrent graph branches; None = 2 for large bf16 batches, else 1
     # in-graph RNG, non-progressive loops: every batch slice replays its OWN graph on its own stream, with no per-step join and a phase
-    # lag between the chains.  Measured neutral at config 2 (3.693 vs 3.699 ms / step, any lag: every kernel of the step is a
-    # persistent launch that fills the chip on its own, so the arrangement of two chains does not change the sum): off by default
-    decouple_branches = False
+    # lag between the chains (half a step for two), so that one slice's step boundary - update, step bookkeeping, up-projection - falls
+    # under the other slice's encoder GEMMs.  Round 3 measured it neutral (3.693 vs 3.699 ms: the boundary was then a dozen small
+    # launches on both chains at once); with the boundary as four kernels (round 4) it is -0.7 .. -1.0 % per step
+    # (profiles/r04_ab_step_fusions.txt): on by default.  Samples are bit-identical either way (the noise is counter-based).
+    decouple_branches = True
     branch_skew_us = None      # phase lag of branch j behind branch j-1 at the start of a decoupled loop; None = half a step / branches
     # batch-sliced graph branches: the step's head (up-projection ... embedding LayerNorm) and tail (down-projection, rounding,
     # posterior update) run ONCE for the whole batch and only the encoder layers per slice (engine.head / layers / tail).  Measured
