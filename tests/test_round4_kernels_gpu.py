@@ -165,8 +165,10 @@ def test_step_with_fused_rounding_pieces_equals_the_separate_launches(kind):
                     loop.advance(k)
                 loop.finish()
             torch.cuda.synchronize()
-            st = loop.state.cpu().tolist()
-            assert st[0] == 3 and st[1] == 3 and st[2] == idx[2]              # pos, n_steps, cur_t after three steps
+            for state in (loop.br_state if loop.decoupled else [loop.state]):   # (decoupled chains keep one loop state per batch slice)
+                st = state.cpu().tolist()
+                assert st[0] == 3 and st[1] == 3 and st[2] == idx[2]          # pos, n_steps, cur_t after three steps
+            assert loop.decoupled == (graph and diff.decouple_branches)
             res[(fused_name, graph) if own_noise else "separate noise launch"] = (loop.x.clone(), loop.round_idx.clone(), loop.pred.clone())
     # the noise drawn inside the update kernel is the noise mh_trunc_normal writes: identical samples, bit for bit
     assert all(torch.equal(a, b) for a, b in zip(res[(True, True)], res["separate noise launch"]))
