@@ -621,16 +621,30 @@ int mh_denoiser_forward_sqnorm(const mh_denoiser* m, const float* x, const float
  * fp32-grade scores to 2^-16), then takes -(clamp((|T_v|^2 + |x_n|^2) - 2 x.T_v, 0)) and the first-index argmax of
  * models/rounding.py:21-28.  mh_round_split_table prepares the table operand once per loop (buf: mh_round_split_bytes; table_norm:
  * optional caller-computed |T_v|^2 [V]).  The fp32 parity mode keeps the exact-fp32 score GEMM (mh_round_to_embedding_mfma). */
+/* rng != NULL: the update kernel draws the step's noise itself - for element group (first_elem / 4 + g) exactly the four values
+ * mh_trunc_normal_at(out, n, first_elem, bound, seed, stream_id, step_counter) writes (diffusion.py:378-388 top-p rejection resolved in
+ * registers; bound 0 = plain normals) - and `noise` is not read. */
+typedef struct mh_step_rng {
+  uint64_t seed; uint32_t stream_id; float bound; const uint32_t* step_counter; int64_t first_elem;
+} mh_step_rng;
+/* upd != NULL (mh_down_proj_round_fused, mh_denoiser_forward_round): the same kernel also takes the reverse step of its rows - the
+ * arithmetic of mh_p_sample_epilogue (ddim = 0) / mh_ddim_epilogue (ddim = 1) with x0 = table[nearest row]: x is x_t on entry and
+ * x_{t-1} on return (in place), rng as in mh_step_epilogue_slots (NULL: `noise` is read, or no noise when that is NULL too). */
+typedef struct mh_step_update {
+  float* x; const float* x_start; const int32_t* mask; int mask_per_elem;
+  const float* table; const mh_step_coef* coef; int clip; int ddim;
+  float* pred_xstart; float* mean_out; const float* noise; const mh_step_rng* rng;
+} mh_step_update;
 int mh_down_proj_round_supported(int E, int H, int V);
 size_t mh_round_split_bytes(int E, int V);
 int mh_round_split_table(const float* table, const float* table_norm, int V, int E, void* buf, mh_stream_t stream);
 int mh_down_proj_round_fused(const void* X, int64_t ldx, const void* w0, const float* b0, const void* w2, const float* b2, float* out,
-                             float* out_sqnorm, const void* table_split, int V, int32_t* idx_out, int64_t rows, int E, int H,
-                             mh_stream_t stream);
+                             float* out_sqnorm, const void* table_split, int V, int32_t* idx_out, const mh_step_update* upd, int64_t rows,
+                             int E, int H, mh_stream_t stream);
 int mh_denoiser_rounds_in_forward(const mh_denoiser* m, int V);
 int mh_denoiser_forward_round(const mh_denoiser* m, const float* x, const float* emb_t, const int32_t* emb_row, float* out,
-                              const void* table_split, int V, int32_t* idx_out, int B, int L, void* workspace, size_t workspace_bytes,
-                              mh_stream_t stream);
+                              const void* table_split, int V, int32_t* idx_out, const mh_step_update* upd, int B, int L, void* workspace,
+                              size_t workspace_bytes, mh_stream_t stream);
 /* Rounding (models/rounding.py:21-28) split for a captured step: mh_round_scores = the exact-fp32 score GEMM of
  * mh_round_to_embedding_mfma with |x_n|^2 supplied by the caller, leaving the winners of every column slot in pbest / pidx
  * [n_tokens][mh_round_slots(V)]; mh_step_epilogue_slots = mh_p_sample_epilogue (ddim = 0) / mh_ddim_epilogue (ddim = 1) folding
@@ -640,12 +654,6 @@ int mh_denoiser_forward_round(const mh_denoiser* m, const float* x, const float*
 int mh_round_slots(int V);
 int mh_round_scores(const float* x, const float* x_sqnorm, const float* table_pad, const float* table_norm, float* pbest,
                     int32_t* pidx, int64_t n_tokens, int E, int V, mh_stream_t stream);
-/* rng != NULL: the update kernel draws the step's noise itself - for element group (first_elem / 4 + g) exactly the four values
- * mh_trunc_normal_at(out, n, first_elem, bound, seed, stream_id, step_counter) writes (diffusion.py:378-388 top-p rejection resolved in
- * registers; bound 0 = plain normals) - and `noise` is not read. */
-typedef struct mh_step_rng {
-  uint64_t seed; uint32_t stream_id; float bound; const uint32_t* step_counter; int64_t first_elem;
-} mh_step_rng;
 int mh_step_epilogue_slots(int ddim, const float* x_t, const float* noise, const float* pbest, const int32_t* pidx, int nslots,
                            const float* table, const mh_step_coef* coef, int coef_per_batch, int clip, const int32_t* mask,
                            int mask_per_elem, const float* x_start, float* out, float* pred_xstart, float* mean_out,

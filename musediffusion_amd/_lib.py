@@ -53,6 +53,12 @@ class StepRng(C.Structure):
     _fields_ = [("seed", C.c_uint64), ("stream_id", C.c_uint32), ("bound", F32), ("step_counter", VP), ("first_elem", C.c_int64)]
 
 
+class StepUpdate(C.Structure):
+    """mh_step_update"""
+    _fields_ = [("x", VP), ("x_start", VP), ("mask", VP), ("mask_per_elem", INT), ("table", VP), ("coef", VP), ("clip", INT), ("ddim", INT),
+                ("pred_xstart", VP), ("mean_out", VP), ("noise", VP), ("rng", C.POINTER(StepRng))]
+
+
 class WPrepItem(C.Structure):
     """mh_wprep_item"""
     _fields_ = [("src", VP), ("dst", VP), ("dst_t", VP), ("rows", C.c_int32), ("cols", C.c_int32), ("ld_dst", C.c_int64),
@@ -200,9 +206,9 @@ SIGNATURES = {
     "mh_down_proj_round_supported": (INT, [INT, INT, INT]),
     "mh_round_split_bytes": (C.c_size_t, [INT, INT]),
     "mh_round_split_table": (INT, [VP, VP, INT, INT, VP, VP]),
-    "mh_down_proj_round_fused": (INT, [VP, I64, VP, VP, VP, VP, VP, VP, VP, INT, VP, I64, INT, INT, VP]),
+    "mh_down_proj_round_fused": (INT, [VP, I64, VP, VP, VP, VP, VP, VP, VP, INT, VP, VP, I64, INT, INT, VP]),
     "mh_denoiser_rounds_in_forward": (INT, [C.POINTER(Denoiser), INT]),
-    "mh_denoiser_forward_round": (INT, [C.POINTER(Denoiser), VP, VP, VP, VP, VP, INT, VP, INT, INT, VP, C.c_size_t, VP]),
+    "mh_denoiser_forward_round": (INT, [C.POINTER(Denoiser), VP, VP, VP, VP, VP, INT, VP, VP, INT, INT, VP, C.c_size_t, VP]),
     "mh_round_slots": (INT, [INT]),
     "mh_round_scores": (INT, [VP, VP, VP, VP, VP, VP, I64, INT, INT, VP]),
     "mh_step_epilogue_slots": (INT, [INT, VP, VP, VP, VP, INT, VP, VP, INT, INT, VP, INT, VP, VP, VP, VP, VP, VP, INT, I64, INT, VP]),

@@ -240,7 +240,7 @@ namespace {
 // cost twice one full-size launch.
 struct Phases { int mask; void* xh; int64_t ldh; const void* xi; int64_t ldi; void* xo; int64_t ldo; const void* xt; int64_t ldt;
                 float* sq;      // sq: optional [B L] |output row|^2, written by the fused down-projection (mh_denoiser_gives_sqnorm)
-                const void* tsplit; int V; int32_t* idx; };   // rounding inside the down-projection kernel (mh_denoiser_forward_round)
+                const void* tsplit; int V; int32_t* idx; const mh_step_update* upd; };   // rounding (+ update) inside the down-projection kernel (mh_denoiser_forward_round)
 int denoiser_run(const mh_denoiser* m, const float* x, const float* emb_t, const int32_t* emb_row, float* out, int B, int L,
                  void* workspace, size_t workspace_bytes, mh_stream_t stream, const Phases& ph);
 }  // namespace
@@ -270,12 +270,12 @@ extern "C" int mh_denoiser_rounds_in_forward(const mh_denoiser* m, int V) {
   return m && m->panel && m->has_proj && mh_down_proj_round_supported(m->E, m->H, V);
 }
 extern "C" int mh_denoiser_forward_round(const mh_denoiser* m, const float* x, const float* emb_t, const int32_t* emb_row, float* out,
-                                         const void* table_split, int V, int32_t* idx_out, int B, int L, void* workspace,
-                                         size_t workspace_bytes, mh_stream_t stream) {
+                                         const void* table_split, int V, int32_t* idx_out, const mh_step_update* upd, int B, int L,
+                                         void* workspace, size_t workspace_bytes, mh_stream_t stream) {
   MH_CHECK_ARG(x && emb_t && out && table_split && idx_out, "denoiser_forward_round: null pointer");
   MH_CHECK_ARG(mh_denoiser_rounds_in_forward(m, V), "denoiser_forward_round: this model / vocabulary is not served by the fused rounding");
   return denoiser_run(m, x, emb_t, emb_row, out, B, L, workspace, workspace_bytes, stream,
-                      Phases{7, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, table_split, V, idx_out});
+                      Phases{7, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, table_split, V, idx_out, upd});
 }
 
 // Phased entry points (bf16 K32-panel models with up / down projections only; see Phases).  X buffers: bf16 [H / 32][ld rows][32].
@@ -445,7 +445,7 @@ int denoiser_run(const mh_denoiser* m, const float* x, const float* emb_t, const
     if (m->has_proj) {
       if (g_skip & 64) return MH_OK;
       if (ph.idx)   // ... and the nearest-embedding rounding of its rows
-        return mh_down_proj_round_fused(XT, ldT, m->w_dn0, m->b_dn0, m->w_dn2, m->b_dn2, out, ph.sq, ph.tsplit, ph.V, ph.idx, N, m->E, H, stream);
+        return mh_down_proj_round_fused(XT, ldT, m->w_dn0, m->b_dn0, m->w_dn2, m->b_dn2, out, ph.sq, ph.tsplit, ph.V, ph.idx, ph.upd, N, m->E, H, stream);
       if (mh_down_proj_fused_supported(m->E, H))   // one kernel for both dense layers of the down-projection (csrc/headtail.hip)
         return mh_down_proj_fused(XT, ldT, m->w_dn0, m->b_dn0, m->w_dn2, m->b_dn2, out, ph.sq, N, m->E, H, stream);
       if ((rc = gemm(XT, ldT, m->w_dn0, H, m->b_dn0, nullptr, 0, w.buf0, 0, N, H, H, MH_ACT_TANH))) return rc;

@@ -13,6 +13,7 @@
 // issued as D = W_tile . A_tile^T with the W rows of a wave's 64 columns dealt to the MFMA input rows as
 // 32 (jj >> 1) + 8 (p >> 2) + 4 (jj & 1) + (p & 3), so that a lane owns 8 CONSECUTIVE output columns of one row.
 #include "common.h"
+#include "step_update.h"
 
 namespace {
 
@@ -41,6 +42,14 @@ struct TailArgs {
   const float* tnorm;                   // [Vp]: |T_v|^2 fp32, +inf for rows >= V
   int V;
   int32_t* idx;                         // [rows]: nearest row per token
+  // UPDATE (with ROUND): the posterior / DDIM step of the block's rows in the same kernel (models/diffusion.py:319-347, :390-397, :729-757)
+  float* x;                             // [rows, E] x_t in, x_{t-1} out (in place); NULL: no update here
+  const float* x_start; const int32_t* mask; int mask_per_elem;
+  const float* table;                   // [V, E] fp32 embedding rows (pred_xstart = table[idx])
+  const mh_step_coef* coef; int clip, ddim;
+  float* pred; float* mean;             // optional outputs
+  const float* noise;                   // read when has_rng == 0
+  StepRng rng; int has_rng;
 };
 
 template <int N> __device__ __forceinline__ void ht_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
@@ -454,7 +463,43 @@ __global__ __launch_bounds__(H / 64 * 64, H / 256) void tail_fused_kernel(const 
         const int k = redi[tid * NW + w];
         if (v > best || (v == best && k < bi)) { best = v; bi = k; }
       }
-      g.idx[row0 + tid] = bi == 0x7fffffff ? 0 : bi;
+      bi = bi == 0x7fffffff ? 0 : bi;
+      g.idx[row0 + tid] = bi;
+      redi[tid * NW] = bi;                        // (its own row's slot 0: only this thread read the row's slots)
+    }
+    if (!g.x) return;
+    // ---- the update of the block's rows: the arithmetic of step_epilogue4_kernel (step_update.h), 4 consecutive elements per thread
+    ht_lgkm0();
+    __builtin_amdgcn_s_barrier();
+    const mh_step_coef c = *g.coef;
+    uint32_t rng_step = 0;
+    if (g.has_rng) rng_step = g.rng.step ? *g.rng.step : 0u;
+    const int gpr = g.E / 4;                      // groups per row
+    for (int q = tid; q < HT_ROWS * gpr; q += NW * 64) {
+      const int row = q / gpr, cg = q - row * gpr;
+      const int64_t r = row0 + row;
+      if (r >= g.rows) continue;
+      const int64_t i = r * g.E + cg * 4;
+      f32x4 x0 = *reinterpret_cast<const f32x4*>(g.table + (int64_t)redi[row * NW] * g.E + cg * 4);
+      const f32x4 xt = *reinterpret_cast<const f32x4*>(g.x + i);
+      f32x4 nz = {0.f, 0.f, 0.f, 0.f};
+      if (g.has_rng) {
+        float z[4];
+        trunc_normal4(g.rng.first_group + (uint64_t)(i >> 2), rng_step, g.rng.bound, g.rng.seed_lo, g.rng.seed_hi, g.rng.stream_id, z);
+        nz = f32x4{z[0], z[1], z[2], z[3]};
+      } else if (g.noise) nz = *reinterpret_cast<const f32x4*>(g.noise + i);
+      f32x4 mean, sample;
+      if (g.ddim) step_update4<true>(x0, xt, nz, c, g.clip, mean, sample);
+      else step_update4<false>(x0, xt, nz, c, g.clip, mean, sample);
+      if (g.mask) {
+        if (g.mask_per_elem) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) if (g.mask[i + e] == 0) sample[e] = g.x_start[i + e];
+        } else if (g.mask[r] == 0) sample = *reinterpret_cast<const f32x4*>(g.x_start + i);
+      }
+      if (g.pred) *reinterpret_cast<f32x4*>(g.pred + i) = x0;
+      if (g.mean && !g.ddim) *reinterpret_cast<f32x4*>(g.mean + i) = mean;
+      *reinterpret_cast<f32x4*>(g.x + i) = sample;
     }
     return;
   }
@@ -549,14 +594,29 @@ extern "C" int mh_round_split_table(const float* table, const float* table_norm,
 }
 
 extern "C" int mh_down_proj_round_fused(const void* X, int64_t ldx, const void* w0, const float* b0, const void* w2, const float* b2, float* out,
-                                        float* out_sqnorm, const void* table_split, int V, int32_t* idx_out, int64_t rows, int E, int H,
-                                        mh_stream_t stream) {
+                                        float* out_sqnorm, const void* table_split, int V, int32_t* idx_out, const mh_step_update* upd,
+                                        int64_t rows, int E, int H, mh_stream_t stream) {
   MH_CHECK_ARG(X && w0 && b0 && w2 && b2 && out && table_split && idx_out && rows > 0 && ldx >= rows, "down_proj_round_fused: bad arguments");
   MH_CHECK_ARG(mh_down_proj_round_supported(E, H, V), "down_proj_round_fused: shape E=%d H=%d V=%d not served", E, H, V);
   const float* tn = (const float*)((const char*)table_split + (size_t)(3 * E / 32) * 768 * 32 * 2);
   TailArgs g{(const bf16*)X, ldx, rows, E, (const bf16*)w0, b0, (const bf16*)w2, b2, out, out_sqnorm, (const bf16*)table_split, tn, V, idx_out};
+  g.x = nullptr;
+  if (upd) {
+    MH_CHECK_ARG(upd->x && upd->table && upd->coef && (!upd->mask || upd->x_start), "down_proj_round_fused: bad update descriptor");
+    MH_CHECK_ARG(!upd->rng || (upd->rng->first_elem % 4 == 0 && (upd->rng->bound <= 0.f || upd->rng->bound >= 0.1f)),
+                 "down_proj_round_fused: bad rng descriptor");
+    auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    MH_CHECK_ARG(al(upd->x) && al(upd->x_start) && al(upd->table) && al(upd->pred_xstart) && al(upd->mean_out) && al(upd->noise),
+                 "down_proj_round_fused: the update's tensors must be 16-byte aligned");
+    g.x = upd->x; g.x_start = upd->x_start; g.mask = upd->mask; g.mask_per_elem = upd->mask_per_elem; g.table = upd->table;
+    g.coef = upd->coef; g.clip = upd->clip; g.ddim = upd->ddim; g.pred = upd->pred_xstart; g.mean = upd->mean_out; g.noise = upd->noise;
+    g.has_rng = upd->rng != nullptr;
+    if (upd->rng)
+      g.rng = StepRng{(uint32_t)upd->rng->seed, (uint32_t)(upd->rng->seed >> 32), upd->rng->stream_id, upd->rng->bound, upd->rng->step_counter,
+                      (uint64_t)(upd->rng->first_elem >> 2)};
+  }
   const dim3 grid((unsigned)((rows + HT_ROWS - 1) / HT_ROWS));
-  mh_prof_note("tail+round rows=%lld E=%d H=%d V=%d", (long long)rows, E, H, V);
+  mh_prof_note("tail+round%s rows=%lld E=%d H=%d V=%d", upd ? "+update" : "", (long long)rows, E, H, V);
   MH_LAUNCH((tail_fused_kernel<512, 6>), grid, dim3(512), 0, (hipStream_t)stream, g);
   MH_CHECK_LAUNCH();
   return MH_OK;
@@ -567,6 +627,7 @@ extern "C" int mh_down_proj_fused(const void* X, int64_t ldx, const void* w0, co
   MH_CHECK_ARG(X && w0 && b0 && w2 && b2 && out && rows > 0 && ldx >= rows, "down_proj_fused: bad arguments");
   MH_CHECK_ARG(mh_down_proj_fused_supported(E, H), "down_proj_fused: shape E=%d H=%d not served", E, H);
   TailArgs g{(const bf16*)X, ldx, rows, E, (const bf16*)w0, b0, (const bf16*)w2, b2, out, out_sqnorm, nullptr, nullptr, 0, nullptr};
+  g.x = nullptr;
   const dim3 grid((unsigned)((rows + HT_ROWS - 1) / HT_ROWS));
   mh_prof_note("tail rows=%lld E=%d H=%d", (long long)rows, E, H);
   if (H == 512) MH_LAUNCH((tail_fused_kernel<512>), grid, dim3(512), 0, (hipStream_t)stream, g);

@@ -238,10 +238,12 @@ class DenoiserEngine:
         x = x.to(torch.float32).contiguous()
         out = torch.empty_like(x) if out is None else out
         ws = self._workspace(B, L) if ws is None else ws
-        if round_to is not None:       # (split table buffer, V, idx_out [B L] int32): the last kernel also rounds its rows
-            tsplit, V, idx = round_to
+        if round_to is not None:       # (split table buffer, V, idx_out [B L] int32[, mh_step_update]): the last kernel also rounds its rows [and steps them]
+            tsplit, V, idx = round_to[:3]
+            upd = round_to[3] if len(round_to) > 3 else None
             check(lib().mh_denoiser_forward_round(C.byref(self._desc), ptr(x), ptr(emb_t), ptr(emb_row), ptr(out), ptr(tsplit), int(V), ptr(idx),
-                                                  B, L, ptr(ws), ws.numel(), current_stream()), "mh_denoiser_forward_round")
+                                                  C.byref(upd) if upd is not None else None, B, L, ptr(ws), ws.numel(), current_stream()),
+                  "mh_denoiser_forward_round")
             return out
         if sqnorm is not None:
             check(lib().mh_denoiser_forward_sqnorm(C.byref(self._desc), ptr(x), ptr(emb_t), ptr(emb_row), ptr(out), ptr(sqnorm), B, L, ptr(ws),

@@ -180,6 +180,7 @@ class GaussianDiffusion:
     # the step's rounding without its two small launches (row_sqnorm, argbest_reduce): |row|^2 from the fused down-projection, the
     # slot fold inside the update kernel.  False = the round-3 launch sequence (A/B, tests)
     fuse_rounding = True
+    update_in_forward = True   # ... and takes the reverse step of its rows too (one kernel from the encoder's last rows to x_{t-1})
     round_in_forward = True    # ... and the forward's last kernel rounds its rows itself (split-bf16 scores; config-2 width, ComMU vocabulary)
     fuse_noise = True          # ... and the update kernel draws the in-graph Philox noise itself (same values as mh_trunc_normal)
 
@@ -768,12 +769,38 @@ class _ReverseLoop:
         else:
             _lib.check(L_.mh_ddim_epilogue(*args, nb, per_batch, self.E, stream_h), "mh_ddim_epilogue")
 
-    def _forward(self, sl, ws, use_round):
-        """the denoiser on batch slice `sl` (with |out row|^2 when the fused rounding wants it)"""
+    def _update_in_forward(self, use_round, in_graph_rng):
+        """the forward's last kernel rounds AND steps its rows (mh_step_update): needs the rounding inside the forward and noise that is
+        either drawn in the kernel (in-graph Philox) or already in self.noise when the forward is launched (host-drawn / injected)"""
+        return bool(use_round and self.round_in_tail and getattr(self.diff, "update_in_forward", True) and
+                    (self._rng_in_update(use_round, in_graph_rng) or not in_graph_rng))
+
+    def _forward(self, sl, ws, use_round, upd_state=None, cur_coef=None, in_graph_rng=False):
+        """the denoiser on batch slice `sl` (with |out row|^2 when the fused rounding wants it; upd_state / cur_coef: the loop state and
+        coefficient row of the chain when the forward's last kernel also takes the reverse step - _update_in_forward)"""
         tok = slice(sl.start * self.L, sl.stop * self.L)
         if use_round and self.round_in_tail:
+            extra = ()
+            if cur_coef is not None:
+                P, per_batch = _lib.ptr, self.L * self.E
+                u = _lib.StepUpdate()
+                u.x, u.x_start = P(self.x[sl]), P(self.x_start[sl]) if self.x_start is not None else None
+                u.mask, u.mask_per_elem = (P(self.mask[sl]) if self.mask is not None else None), self.mask_per_elem
+                u.table, u.coef, u.clip, u.ddim = P(self.table32), P(cur_coef), int(self.clip), 0 if self.kind == "p" else 1
+                u.pred_xstart = P(self.pred[sl])
+                u.mean_out = P(self.mean[sl]) if (self.mean is not None and self.kind == "p") else None
+                self._upd_keep = getattr(self, "_upd_keep", [])
+                if in_graph_rng:
+                    rng = _lib.StepRng()
+                    rng.seed, rng.stream_id, rng.bound = int(self.diff.rng_seed) & (2 ** 64 - 1), int(self.diff.rng_stream), float(self.top_p)
+                    rng.step_counter, rng.first_elem = self._rng_counter(upd_state), sl.start * per_batch
+                    u.noise, u.rng = None, C.pointer(rng)
+                    self._upd_keep.append(rng)
+                else:
+                    u.noise, u.rng = P(self.noise[sl]), None
+                extra = (u,)
             self.eng.forward(self.x[sl], self.emb_table, self.emb_row[sl], out=self.model_out[sl], ws=ws,
-                             round_to=(self.tsplit, self.table32.shape[0], self.round_idx[tok]))
+                             round_to=(self.tsplit, self.table32.shape[0], self.round_idx[tok]) + extra)
             return
         sq = self.sqnorm[tok] if (use_round and self.fused_round) else None
         self.eng.forward(self.x[sl], self.emb_table, self.emb_row[sl], out=self.model_out[sl], ws=ws, sqnorm=sq)
@@ -794,9 +821,18 @@ class _ReverseLoop:
         per_batch = self.L * self.E
 
         rng_in_update = self._rng_in_update(use_round, in_graph_rng)
+        upd_in_fwd = self._update_in_forward(use_round, in_graph_rng) and not getattr(self, "shared", False)
 
         def tail(sl, stream_h, ws):
+            if upd_in_fwd:
+                return                      # (the forward's last kernel has taken the step)
             self._tail(sl, stream_h, ws, self.cur_coef, use_round, self.state if rng_in_update else None)
+
+        def forward(sl, ws):
+            if upd_in_fwd:
+                self._forward(sl, ws, use_round, self.state, self.cur_coef, in_graph_rng)
+            else:
+                self._forward(sl, ws, use_round)
 
         def draw_noise(stream_h):
             if in_graph_rng and not rng_in_update:
@@ -804,7 +840,7 @@ class _ReverseLoop:
                                               int(self.diff.rng_stream), self._rng_counter(self.state), stream_h), "mh_trunc_normal")
 
         if nsplit <= 1:
-            self._forward(slice(0, self.B), self.own_ws, use_round)
+            forward(slice(0, self.B), self.own_ws)
             draw_noise(st)
             tail(slice(0, self.B), st, self.round_ws)
         elif getattr(self, "shared", False):
@@ -844,13 +880,13 @@ class _ReverseLoop:
                     if j == 1:
                         draw_noise(sh)
                         self.ev_noise.record(side)
-                    self._forward(sl, self.split_ws[j], use_round)
+                    forward(sl, self.split_ws[j])
                     if j > 1:
                         side.wait_event(self.ev_noise)
                     tail(sl, sh, self.split_round_ws[j])
                     self.ev_join[j - 1].record(side)
             sl0 = slice(0, hb)
-            self._forward(sl0, self.split_ws[0], use_round)
+            forward(sl0, self.split_ws[0])
             main.wait_event(self.ev_noise)
             tail(sl0, st, self.split_round_ws[0])
             for j in range(1, nsplit):
@@ -872,8 +908,11 @@ class _ReverseLoop:
         if not rng_here:
             _lib.check(L_.mh_trunc_normal_at(P(self.noise[sl]), nb * per_batch, sl.start * per_batch, float(self.top_p), int(self.diff.rng_seed),
                                              int(self.diff.rng_stream), self._rng_counter(state), st), "mh_trunc_normal_at")
-        self._forward(sl, self.split_ws[j], use_round)
-        self._tail(sl, st, self.split_round_ws[j], coef, use_round, state if rng_here else None)
+        if self._update_in_forward(use_round, True):
+            self._forward(sl, self.split_ws[j], use_round, state, coef, True)
+        else:
+            self._forward(sl, self.split_ws[j], use_round)
+            self._tail(sl, st, self.split_round_ws[j], coef, use_round, state if rng_here else None)
 
     def begin(self):
         """Warm-up launch outside capture (one-time lazy initialisation inside the launchers), state restored."""

@@ -148,13 +148,16 @@ def test_step_with_fused_rounding_pieces_equals_the_separate_launches(kind):
     fn = partial(denoised_fn_round, emb, dist=None)
     res = {}
     for fused, graph, own_noise in ((True, True, True), (True, False, True), (False, True, True), (False, False, True), (True, True, False),
-                                    ("in the forward", True, True), ("in the forward", False, True)):
+                                    ("in the forward", True, True), ("in the forward", False, True), ("in the forward", True, "separate update")):
         if True:
             diff = SpacedDiffusion(use_timesteps=space_timesteps(2000, [2000]), betas=get_named_beta_schedule("sqrt", 2000),
                                    rescale_timesteps=True, predict_xstart=True)
             diff.rng_mode, diff.rng_seed, diff.rng_stream, diff.use_graph, diff.fuse_rounding, diff.batch_split = "philox", 105, 0, graph, fused, 2
             diff.fuse_noise = own_noise          # True: the update kernel draws the noise; False: mh_trunc_normal at the head of the step
             diff.round_in_forward = fused == "in the forward"      # the forward's last kernel rounds its rows (split-bf16 scores)
+            diff.update_in_forward = own_noise is True             # ... and takes the reverse step of its rows
+            if own_noise == "separate update":
+                own_noise = True
             fused_name, fused = fused, bool(fused)
             idx = list(range(2000))[::-1][:3]
             loop = _ReverseLoop.try_build(diff, kind, m, x0, True, fn, 1 if kind == "p" else None, mask3, x_start, 0.0, idx, lambda i: fn, False)
@@ -169,9 +172,14 @@ def test_step_with_fused_rounding_pieces_equals_the_separate_launches(kind):
                 st = state.cpu().tolist()
                 assert st[0] == 3 and st[1] == 3 and st[2] == idx[2]          # pos, n_steps, cur_t after three steps
             assert loop.decoupled == (graph and diff.decouple_branches)
-            res[(fused_name, graph) if own_noise else "separate noise launch"] = (loop.x.clone(), loop.round_idx.clone(), loop.pred.clone())
+            key = (fused_name, graph) if own_noise else "separate noise launch"
+            if fused_name == "in the forward" and not diff.update_in_forward:
+                key = "separate update"
+            res[key] = (loop.x.clone(), loop.round_idx.clone(), loop.pred.clone())
     # the noise drawn inside the update kernel is the noise mh_trunc_normal writes: identical samples, bit for bit
     assert all(torch.equal(a, b) for a, b in zip(res[(True, True)], res["separate noise launch"]))
+    # the reverse step taken inside the forward's last kernel == the separate update kernel on the same indices, bit for bit
+    assert all(torch.equal(a, b) for a, b in zip(res[("in the forward", True)], res["separate update"]))
     # rounding inside the forward (split-bf16 scores) against the exact-fp32 score GEMM: the same rows except on near-ties
     same_f = float((res[("in the forward", True)][1] == res[(True, True)][1]).float().mean())
     print("%s: rounded index agreement, scores inside the forward vs exact-fp32 score GEMM %.6f" % (kind, same_f))

@@ -25,6 +25,7 @@ from musediffusion_amd.models.diffusion import GaussianDiffusion  # noqa: E402
 setters["decouple"] = lambda v: setattr(GaussianDiffusion, "decouple_branches", bool(v))
 setters["shared"] = lambda v: setattr(GaussianDiffusion, "shared_head_tail", bool(v))
 setters["fuse_noise"] = lambda v: setattr(GaussianDiffusion, "fuse_noise", bool(v))
+setters["update_in_forward"] = lambda v: setattr(GaussianDiffusion, "update_in_forward", bool(v))
 setters["round_in_forward"] = lambda v: setattr(GaussianDiffusion, "round_in_forward", bool(v))
 setters["fuse_rounding"] = lambda v: setattr(GaussianDiffusion, "fuse_rounding", bool(v))
 setters["skew"] = lambda v: setattr(GaussianDiffusion, "branch_skew_us", None if v < 0 else v)       # microseconds; -1 = automatic
