@@ -1290,6 +1290,25 @@ int launch_big(const GemmArgs& g0, hipStream_t s, int batch) {
   return MH_OK;
 }
 
+#ifdef MH_ABLATE
+// A/B (mh_gemm_set_wide_roles bits 3 / 4): the dense + GELU launch on the 128 x 512 tile of the LayerNorm kernels (8 waves, one block per
+// CU; bit 3 with the ping-pong main loop, bit 4 with the plain one) - the tile on which the FFN output dense runs at ~95 % of its CUs'
+// matrix rate
+template <class C>
+int launch_row_gelu(const GemmArgs& g0, hipStream_t s, int batch) {
+  GemmArgs g = g0;
+  const int64_t t2 = (int64_t)ceil_div(g.M, C::BM) * ceil_div(g.N, C::BN);
+  const int64_t slots = device_cus();
+  g.ntiles = (int)t2;
+  g.stagger = 0;
+  const dim3 grid((unsigned)(t2 < slots ? t2 : slots), (unsigned)batch), block(C::THREADS);
+  mh_prof_note("tile=%dx%d%s epi=0 act=%d M=%lld N=%d K=%d batch=%d", C::BM, C::BN, C::PP ? "pp" : "", g.act, (long long)g.M, g.N, g.K, batch);
+  MH_LAUNCH((gemm_big_kernel<C, 0, MH_ACT_GELU_ERF>), grid, block, 0, s, g);
+  MH_CHECK_LAUNCH();
+  return MH_OK;
+}
+#endif
+
 bool big_tile_ok(const GemmArgs& g) {
   // N % 8 == 0: a lane's 8 output columns are all valid; an fp32 row-major output may end on a half group (N % 4 == 0, e.g. the
   // released checkpoints' E = 500 down-projection): the epilogue stores only the first four of the last lane's columns
@@ -1337,6 +1356,12 @@ int launch(const GemmArgs& g, int dtype, hipStream_t s, int batch = 1) {
       // QKV scatter: a wave's columns must not straddle the q/k/v boundary (H % 64 == 0 for the wide tile)
       else {
         if (g.d.a_stats || g.d.r_stats || g.d.o_stats) return launch_big<CfgStd, EPI>(g, s, batch);   // deferred LayerNorm: 256x128 only
+#ifdef MH_ABLATE
+        if constexpr (EPI == 0) {
+          if ((g_wide_roles & 24) && g.act == MH_ACT_GELU_ERF && g.N % 512 == 0 && (g.a_panel || g.w_panel) && !g.pre_out && !g.residual)
+            return (g_wide_roles & 8) ? launch_row_gelu<CfgRowPP>(g, s, batch) : launch_row_gelu<CfgRow>(g, s, batch);
+        }
+#endif
         if (want_wide(g, batch) && (EPI != 1 || g.H % 64 == 0))
           return g_variant == 5 ? launch_big<CfgWidePP, EPI>(g, s, batch) : launch_big<CfgWide, EPI>(g, s, batch);
         return launch_big<CfgStd, EPI>(g, s, batch);

@@ -214,7 +214,7 @@ def test_down_proj_with_rounding_inside(N, V):
     check(lib().mh_round_split_table(td.data_ptr(), None, V, E, buf.data_ptr(), current_stream()), "mh_round_split_table")
     w0p, w2p, b0d, b2d = to_panel(W0), to_panel(W2), d(b0), d(b2)
     check(lib().mh_down_proj_round_fused(Xp.data_ptr(), N, w0p.data_ptr(), b0d.data_ptr(), w2p.data_ptr(), b2d.data_ptr(), out.data_ptr(),
-                                         sq.data_ptr(), buf.data_ptr(), V, idx.data_ptr(), N, E, H, current_stream()), "mh_down_proj_round_fused")
+                                         sq.data_ptr(), buf.data_ptr(), V, idx.data_ptr(), None, N, E, H, current_stream()), "mh_down_proj_round_fused")
     ref = q16(torch.tanh(q16(X) @ q16(W0).T + b0)) @ q16(W2).T + b2
     assert float((out.cpu() - ref).abs().max()) < 2e-3
     y = out.cpu().double()

@@ -3,6 +3,7 @@
 // Build: hipcc --offload-arch=gfx950 -O3 valu_rate.hip -o valu_rate
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 
 #define CHAIN32(STMT) _Pragma("unroll") for (int r = 0; r < 4; ++r) _Pragma("unroll") for (int i = 0; i < 32; ++i) { STMT; }
@@ -56,6 +57,19 @@ __global__ void k(float* out, unsigned long long* clk, int iters, float seed) {
     if (KIND == 35) CHAIN32(asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(u[i]) : "v"(u[(i + 1) & 31]), "v"(u[(i + 2) & 31])))
     if (KIND == 36) CHAIN32(asm volatile("v_mul_f32 %0, 0x3fb8aa3b, %0" : "+v"(v[i])))
     if (KIND == 37) CHAIN32(asm volatile("v_fmaak_f32 %0, %0, %1, 0x3fb8aa3b" : "+v"(v[i]) : "v"(c)))
+    // round 4: the fp16 forms a packed-fp16 GELU would be made of (two results per v_pk_* instruction)
+    if (KIND == 40) CHAIN32(asm volatile("v_pk_fma_f16 %0, %0, %1, %0" : "+v"(u[i]) : "v"(u[(i + 1) & 31])))
+    if (KIND == 41) CHAIN32(asm volatile("v_pk_mul_f16 %0, %0, %1" : "+v"(u[i]) : "v"(u[(i + 1) & 31])))
+    if (KIND == 42) CHAIN32(asm volatile("v_pk_add_f16 %0, %0, %1" : "+v"(u[i]) : "v"(u[(i + 1) & 31])))
+    if (KIND == 43) CHAIN32(asm volatile("v_pk_min_f16 %0, %0, %1" : "+v"(u[i]) : "v"(u[(i + 1) & 31])))
+    if (KIND == 44) CHAIN32(asm volatile("v_cvt_pkrtz_f16_f32 %0, %0, %1" : "+v"(v[i]) : "v"(c)))
+    if (KIND == 45) CHAIN32(asm volatile("v_exp_f16 %0, %0" : "+v"(u[i])))
+    if (KIND == 46) CHAIN32(asm volatile("v_rcp_f16 %0, %0" : "+v"(u[i])))
+    if (KIND == 47) CHAIN32(asm volatile("v_cvt_f32_f16 %0, %0" : "+v"(u[i])))
+    if (KIND == 48) CHAIN32(asm volatile("v_cvt_f32_f16_sdwa %0, %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" : "+v"(u[i])))
+    if (KIND == 49) CHAIN32(asm volatile("v_exp_f16_sdwa %0, %0 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1" : "+v"(u[i])))
+    if (KIND == 50) CHAIN32(asm volatile("v_med3_f32 %0, %0, %1, %2" : "+v"(v[i]) : "v"(c), "v"(v[(i + 1) & 31])))
+    if (KIND == 51) CHAIN32(asm volatile("v_dot2_f32_bf16 %0, %1, %2, %0" : "+v"(v[i]) : "v"(u[(i + 1) & 31]), "v"(u[(i + 2) & 31])))
   }
   const unsigned long long t1 = __builtin_readcyclecounter();
   float s = 0.f;
@@ -117,6 +131,11 @@ int main() {
   run<16>("v_add_f32"); run<28>("v_sub_f32"); run<17>("v_mul_f32"); run<36>("v_mul_f32 lit"); run<29>("v_fmac_f32"); run<37>("v_fmaak_f32"); run<33>("v_pk_add_f32");
   run<30>("v_cvt_f32_u32"); run<27>("v_mov_b32"); run<18>("v_and_b32"); run<19>("v_lshlrev_b32"); run<20>("v_add_u32"); run<35>("v_add3_u32");
  run<31>("v_or3_b32"); run<32>("v_and_or_b32"); run<24>("v_lshl_or_b32"); run<23>("v_bfe_u32"); run<22>("v_alignbit_b32");
+  if (getenv("VALU_F16")) {
+    run<40>("v_pk_fma_f16"); run<41>("v_pk_mul_f16"); run<42>("v_pk_add_f16"); run<43>("v_pk_min_f16"); run<44>("v_cvt_pkrtz_f16"); run<45>("v_exp_f16");
+    run<46>("v_rcp_f16"); run<47>("v_cvt_f32_f16"); run<48>("v_cvt_f32_f16 hi"); run<49>("v_exp_f16 sdwa hi"); run<50>("v_med3_f32"); run<51>("v_dot2_f32_bf16");
+    return 0;
+  }
   run<21>("v_sub_u32_sdwa"); run<34>("v_and_b32_sdwa"); run<25>("v_cmp+cndmask x2");
   return 0;
 }
