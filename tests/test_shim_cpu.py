@@ -77,3 +77,20 @@ def test_the_reference_factory_file_runs_over_the_shim(shim_path):
         assert k in sd, k
     assert sd["lm_head.weight"].data_ptr() == sd["word_embedding.weight"].data_ptr()       # tied (network.py:56-58)
     assert isinstance(model, torch.nn.Module) and model.training
+
+
+def test_train_side_names_of_run_train_py(shim_path):
+    """run/train.py:22-27 imports: create_named_schedule_sampler, the five initialization helpers, TrainLoop - all reachable through
+    the reference's module names over the shim, with the reference's call signatures (keyword-only TrainLoop constructor)."""
+    import inspect
+    tu = importlib.import_module("MuseDiffusion.utils.train_util")
+    import musediffusion_amd.utils.initialization as ours_i
+    import musediffusion_amd.utils.train_util as ours_t
+    assert tu.TrainLoop is ours_t.TrainLoop and callable(tu.update_ema)
+    for name in ("create_model_and_diffusion", "seed_all", "fetch_pretrained_embedding", "overload_embedding", "fetch_pretrained_denoiser",
+                 "overload_denoiser", "get_latest_model_path"):
+        assert callable(getattr(ours_i, name)), name
+    assert list(inspect.signature(ours_i.overload_embedding).parameters) == ["model", "emb_weight", "freeze_embedding"]
+    assert list(inspect.signature(ours_i.overload_denoiser).parameters) == ["model", "denoiser_state_dict"]
+    kinds = {p.kind for n, p in inspect.signature(tu.TrainLoop.__init__).parameters.items() if n != "self"}
+    assert kinds == {inspect.Parameter.KEYWORD_ONLY}
