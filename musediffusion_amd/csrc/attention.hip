@@ -970,7 +970,7 @@ int launch_bf16(const bf16* q, const bf16* k, const bf16* vt, bf16* ctx, int64_t
 namespace { MH_KNOB(int, g_attn_stream, 1); }
 #ifdef MH_ABLATE
 extern "C" int mh_attention_set_stream(int on) {
-  g_attn_stream = on < 0 ? 0 : (on > 4 ? 4 : on);
+  g_attn_stream = on < 0 ? 0 : (on > 6 ? 6 : on);
   return MH_OK;
 }
 #endif
@@ -1051,9 +1051,12 @@ int stream_fwd_impl(const void* q, const void* k, const void* vt_perm, void* ctx
   // registers more than the 128 a 16-wave block leaves each wave (the 16-wave build spilled 82 dwords per lane: 3.5x slower)
   // the in-kernel generator runs on the 8-wave geometry (its Philox state does not fit the 128 registers of a 16-wave block without
   // spilling 25 dwords per lane; mode 3 = A/B: generator on 16 waves); the bit reader fits 16 waves
-  const bool small = !pre && (g_attn_stream == 2 || (dropping && !bits_in && g_attn_stream != 3));
+  // modes 5 / 6 (A/B): the 8-wave geometry on ONE block per CU (each block then walks two half-items back to back, the second one's
+  // first stage and queries arriving under the first one's tiles, and half of the CU's LDS and registers stay free for a block of the
+  // other graph branch's kernel); 6: the 16-wave geometry with as many blocks as half the CUs (two items per block)
+  const bool small = !pre && (g_attn_stream == 2 || g_attn_stream == 5 || (dropping && !bits_in && g_attn_stream != 3));
   const int qper = small ? 256 : 512, nitems = nbh * ((L + qper - 1) / qper);
-  const int slots = small ? 2 * cus : cus;
+  const int slots = g_attn_stream == 5 ? cus : (g_attn_stream == 6 ? cus / 2 : (small ? 2 * cus : cus));
   const dim3 grid((unsigned)(nitems < slots ? nitems : slots)), block(small ? 512 : 1024);
   auto go = [&](auto kern, int bytes) -> int {
     // all instantiations share one function-pointer type, so this lambda body exists once: the attribute is tracked per kernel

@@ -84,16 +84,20 @@ __device__ __forceinline__ void ht_kstep(f32x4 (&acc)[4][4], const char* a_slab,
 
 // K loop over nk K32 steps: A slabs resident in LDS (a_base + kt * HT_SLAB), W streamed through a 3-slot ring.  `issued`: stages the
 // caller already put in flight (0 .. 2, issued as the wave's LAST vector-memory operations).  PER = pieces per wave and stage.
+// NO block barrier inside: the pieces a wave DMAs (rows 64 wave .. 64 wave + 63 of the stage) are exactly the W rows its own 64 output
+// columns read, so a stage is private to the wave that loaded it - its own counted vmcnt says when the bytes have landed, its own
+// lgkmcnt when the slot may be refilled - and the eight waves of a block drift apart instead of meeting 16 MFMAs apart.  The caller
+// publishes the (shared) A slabs with one barrier before the loop.
 template <int WROWS, int NW>
 __device__ __forceinline__ void ht_loop(f32x4 (&acc)[4][4], const bf16* __restrict__ w, int nk, const char* a_base, char* ring, int slot_bytes,
                                         int a_off, const int (&b_offs)[4], int wave, int lane, int issued) {
   constexpr int PER = (WROWS / 16 + NW - 1) / NW;
+  static_assert(WROWS / 16 == PER * NW, "a wave must load exactly its own rows");
   for (int st = issued; st < 2 && st < nk; ++st) ht_issue_w<WROWS, NW>(w, st, ring + (st % 3) * slot_bytes, wave, lane);
   for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) ht_wait_vmcnt<PER>(); else ht_wait_vmcnt<0>();    // stage kt has landed (stage kt + 1 may still fly)
-    ht_lgkm0();                                                          // this wave's reads of stage kt - 1 are done
-    __builtin_amdgcn_s_barrier();
-    if (kt + 2 < nk) ht_issue_w<WROWS, NW>(w, kt + 2, ring + ((kt + 2) % 3) * slot_bytes, wave, lane);   // slot of stage kt - 1: free
+    if (kt + 1 < nk) ht_wait_vmcnt<PER>(); else ht_wait_vmcnt<0>();    // this wave's stage kt has landed (stage kt + 1 may still fly)
+    ht_lgkm0();                                                          // ... and its reads of stage kt - 1 are done: that slot is free
+    if (kt + 2 < nk) ht_issue_w<WROWS, NW>(w, kt + 2, ring + ((kt + 2) % 3) * slot_bytes, wave, lane);
     ht_kstep(acc, a_base + kt * HT_SLAB, ring + (kt % 3) * slot_bytes, a_off, b_offs);
   }
 }
@@ -139,7 +143,9 @@ __global__ __launch_bounds__(H / 64 * 64, H / 256) void head_fused_kernel(const 
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  // ---- phase 1: [64, E_pad] . W0^T   (the loop's first barrier also publishes the x tile: every wave drains lgkmcnt before it)
+  // ---- phase 1: [64, E_pad] . W0^T
+  ht_lgkm0();
+  __builtin_amdgcn_s_barrier();           // the x tile is complete (the K loop itself has no barrier: its W stages are wave-private)
   ht_loop<H, NW>(acc, g.w0, nk1, h1, ring, SLOT, a_off, b_offs, wave, lane, nk1 < 2 ? nk1 : 2);
   ht_lgkm0();
   __builtin_amdgcn_s_barrier();           // every wave is done with the x tile and the ring
@@ -162,19 +168,29 @@ __global__ __launch_bounds__(H / 64 * 64, H / 256) void head_fused_kernel(const 
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  // ---- phase 2: [64, H] . W2^T   (its first barrier publishes the slabs)
+  // the position rows of the second epilogue (64 distinct table rows per block, 128 KB from L2) are requested here and arrive under
+  // phase 2 instead of standing between its last MFMA and the LayerNorm: 64 registers held across the loop
+  float posv[2][4][8];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int64_t r = row0 + 16 * i + fr; if (r >= g.rows) r = g.rows - 1;
+    const float* prow = g.pos + (r % g.L) * H;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) load8(prow + wave * 64 + 32 * h + 8 * fg, posv[h][i]);
+  }
+  // ---- phase 2: [64, H] . W2^T
+  ht_lgkm0();
+  __builtin_amdgcn_s_barrier();           // the tanh slabs are complete
   ht_loop<H, NW>(acc, g.w2, NK2, h1, ring, SLOT, a_off, b_offs, wave, lane, 2);
   ht_lgkm0();
   __builtin_amdgcn_s_barrier();           // the ring is idle: its first bytes take the row statistics
   // ---- epilogue 2: (pos + (acc + b2)) + emb_t, LayerNorm over the row (two passes: in-lane -> 4 lanes -> NW waves through LDS)
   float* red = reinterpret_cast<float*>(ring);          // [64][NW]
   const float* trow[4];
-  const float* prow[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     int64_t r = row0 + 16 * i + fr; if (r >= g.rows) r = g.rows - 1;
-    const int64_t b = r / g.L, l = r - b * g.L;
-    prow[i] = g.pos + l * H;
+    const int64_t b = r / g.L;
     trow[i] = g.emb_t + (int64_t)(g.emb_row ? g.emb_row[b] : (int)b) * H;
   }
   float rs[4] = {0.f, 0.f, 0.f, 0.f};
@@ -185,12 +201,11 @@ __global__ __launch_bounds__(H / 64 * 64, H / 256) void head_fused_kernel(const 
     load8(g.b2 + col, bv);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      float p[8], t[8];
-      load8(prow[i] + col, p);
+      float t[8];
       load8(trow[i] + col, t);
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        const float v = (p[e] + (acc[i][2 * h + (e >> 2)][e & 3] + bv[e])) + t[e];     // the reference's association: (pos + x) + emb
+        const float v = (posv[h][i][e] + (acc[i][2 * h + (e >> 2)][e & 3] + bv[e])) + t[e];     // the reference's association: (pos + x) + emb
         acc[i][2 * h + (e >> 2)][e & 3] = v;
         rs[i] += v;
       }
@@ -293,7 +308,9 @@ __global__ __launch_bounds__(H / 64 * 64, H / 256) void tail_fused_kernel(const 
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  ht_loop<H, NW>(acc, g.w0, NK, h1, ring, SLOT, a_off, b_offs, wave, lane, 2);   // (the A pieces are older than stage 0: its wait covers them)
+  ht_wait_vmcnt<2 * (H / 16 / NW)>();     // this wave's pieces of the A rows have landed (the two weight stages behind them may still fly)
+  __builtin_amdgcn_s_barrier();           // ... and everybody else's: the A slabs are shared, the weight stages are wave-private
+  ht_loop<H, NW>(acc, g.w0, NK, h1, ring, SLOT, a_off, b_offs, wave, lane, 2);
   ht_lgkm0();
   __builtin_amdgcn_s_barrier();
   // second layer's weight stages: E rows x 64 B each
@@ -326,10 +343,11 @@ __global__ __launch_bounds__(H / 64 * 64, H / 256) void tail_fused_kernel(const 
   f32x4 y[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) y[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  ht_lgkm0();
+  __builtin_amdgcn_s_barrier();                   // the tanh slabs are complete (the loop's weight pieces are wave-private: no barrier inside)
   for (int kt = 0; kt < NK; ++kt) {
     if (kt + 1 < NK) ht_wait_vmcnt<1>(); else ht_wait_vmcnt<0>();
     ht_lgkm0();
-    __builtin_amdgcn_s_barrier();                 // (kt = 0: also publishes the tanh slabs)
     if (kt + 2 < NK) issue2(kt + 2);
     const bf16x8 b = *reinterpret_cast<const bf16x8*>(ring + (kt % 3) * SLOT + b2_off);
     bf16x8 a[4];
@@ -406,10 +424,9 @@ __global__ __launch_bounds__(H / 64 * 64, H / 256) void tail_fused_kernel(const 
     int b3_offs[TJ3];
 #pragma unroll
     for (int j = 0; j < TJ3; ++j) b3_offs[j] = ((wave * TJ3 + j) * 16 + fr) * 64 + ((fg ^ ht_g((fr >> 2) & 3)) << 4);
-    for (int kt = 0; kt < NK3; ++kt) {
-      ht_wait_vmcnt<0>();
-      ht_lgkm0();
-      __builtin_amdgcn_s_barrier();             // stage kt landed everywhere; stage kt - 1's slot is free (kt = 0: also publishes the slabs and xn)
+    for (int kt = 0; kt < NK3; ++kt) {            // (a wave's table rows are its own pieces: no barrier inside)
+      ht_wait_vmcnt<0>();                         // this wave's stage kt has landed
+      ht_lgkm0();                                 // ... and its reads of stage kt - 1 are done: that slot takes stage kt + 1
       if (kt + 1 < NK3) issue3(kt + 1);
       bf16x8 a[4], b[TJ3];
 #pragma unroll

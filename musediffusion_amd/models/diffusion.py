@@ -180,7 +180,10 @@ class GaussianDiffusion:
     # the step's rounding without its two small launches (row_sqnorm, argbest_reduce): |row|^2 from the fused down-projection, the
     # slot fold inside the update kernel.  False = the round-3 launch sequence (A/B, tests)
     fuse_rounding = True
-    update_in_forward = True   # ... and takes the reverse step of its rows too (one kernel from the encoder's last rows to x_{t-1})
+    # ... and can take the reverse step of its rows too (one kernel from the encoder's last rows to x_{t-1}).  Off by default: the
+    # in-kernel Philox generator runs at 8 waves per CU there (+21 us per launch alone), the separate update kernel at 32 - inside the
+    # step the two forms tie (3.492 vs 3.498 ms), and the lean kernel leaves more of the chip to the other chain
+    update_in_forward = False
     round_in_forward = True    # ... and the forward's last kernel rounds its rows itself (split-bf16 scores; config-2 width, ComMU vocabulary)
     fuse_noise = True          # ... and the update kernel draws the in-graph Philox noise itself (same values as mh_trunc_normal)
 
