@@ -209,3 +209,42 @@ def test_overload_embedding_freeze_and_one_step_match_the_reference():
     esd = ts.opt.ema_state_dict(0, m)
     assert esd["lm_head.weight"].data_ptr() != esd["word_embedding.weight"].data_ptr()
     assert torch.equal(esd["lm_head.weight"], ts.opt.ema[0][names.index("lm_head.weight")])
+
+
+def test_train_loop_with_the_fused_optimizer_saves_and_resumes(tmp_path):
+    """utils/train_util.TrainLoop (the reference's constructor) over the real training path: three optimizer steps with the fused AdamW +
+    EMA kernel, a checkpoint in the reference's file layout at step 2 and at the end, and a second TrainLoop on the same directory that
+    resumes model, optimizer moments, step count and the EMA copy bit for bit."""
+    import itertools
+    from musediffusion_amd import synthetic
+    from musediffusion_amd.models.diffusion import SpacedDiffusion, get_named_beta_schedule, space_timesteps
+    from musediffusion_amd.models.network import TransformerNetModel
+    from musediffusion_amd.utils.train_util import TrainLoop
+    torch.manual_seed(0)
+    np.random.seed(0)
+    mk = lambda: TransformerNetModel(32, 32, 32, 729, 64, dropout=0.1, bert_hidden=64, bert_layers=2, bert_heads=2, bert_ffn=128,
+                                     compute_dtype="fp32").train().to(DEV)
+    diff = SpacedDiffusion(use_timesteps=space_timesteps(2000, [2000]), betas=get_named_beta_schedule("sqrt", 2000),
+                           rescale_timesteps=True, predict_xstart=True)
+    batch = synthetic.training_batch(4, 64, seed=3)
+    data = (dict(batch) for _ in itertools.count())
+    logs = []
+    kw = dict(diffusion=diff, data=data, batch_size=4, microbatch=2, lr=1e-3, ema_rate="0.9", log_interval=1, save_interval=3,
+              resume_checkpoint="", weight_decay=0.01, checkpoint_path=str(tmp_path), gradient_clipping=1.0, log_fn=logs.append)
+    m = mk()
+    loop = TrainLoop(model=m, learning_steps=4, **kw)
+    loop.run_loop()
+    # steps 0 .. 3; the save at step 3 happens BEFORE that iteration's `step += 1`, i.e. after 4 optimizer steps; (4 - 1) % 3 == 0: no closing save
+    assert loop.step == 4 and sorted(os.listdir(tmp_path)) == ["ema_0.9_000003.pt", "model_000003.pt", "opt_000003.pt"]
+    assert all(np.isfinite(d["loss"]) and np.isfinite(d["grad_norm"]) for d in logs if "loss" in d) and logs[-1]["step"] == 3
+    m2 = mk()
+    loop2 = TrainLoop(model=m2, learning_steps=6, **kw)
+    assert loop2.resume_step == 3 and loop2.opt.step_count == loop.opt.step_count == 4
+    for a, b in zip(m.parameters(), m2.parameters()):
+        assert torch.equal(a, b)
+    for a, b in zip(loop.opt.exp_avg_sq, loop2.opt.exp_avg_sq):
+        assert torch.equal(a, b)
+    for a, b in zip(loop.opt.ema[0], loop2.opt.ema[0]):
+        assert torch.equal(a, b)
+    loop2.run_loop()
+    assert loop2.step == 3 and "model_000006.pt" in os.listdir(tmp_path)      # steps 3 .. 5 of 6, then the closing save ((3 - 1) % 3 != 0)
