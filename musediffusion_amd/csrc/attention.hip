@@ -913,6 +913,181 @@ __global__ __launch_bounds__(64 * NW) void attn_stream_bf16_kernel(const bf16* _
   }
 }
 
+// Streaming attention with TWO 32-query tiles per wave (8 waves x 64 queries = one 512-query item per block, 2 waves per SIMD at 256
+// registers): a K fragment read from LDS feeds the S^T chains of both query tiles and a V^T fragment both P.V products, so the
+// 2 MB of fragment reads per (batch, head) of the 16-wave form - every wave re-reads all of K and V - halve (its ablation: 5.9 of 27.8 us
+// per half-batch launch are those reads).  Same stages (256 keys, double-buffered LDS-DMA), same swizzles, same lazy-rescale softmax and
+// store path as attn_stream_bf16_kernel; head dim 64, seq_len % 256 == 0, no dropout.  A/B: mh_attention_set_stream(7).
+template <bool KVNT>
+__global__ __launch_bounds__(512, 2) void attn_stream2_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K, const bf16* __restrict__ VT,
+                                                              bf16* __restrict__ ctx, int64_t ld_ctx, int L, int nh, int nbh, float scale_log2e,
+                                                              int ctx_panel, int64_t qsB, int64_t qsH, int64_t qld) {
+  constexpr int DH = 64, NW = 8, SK = 256, QT = 2;
+  constexpr int CH = DH / 8, RPB = 128 / DH, KROWB = DH * 2, KS = DH / 16, DT = DH / 32;
+  constexpr int KST = SK * KROWB, VT_BYTES = DH * 128, PK = KST / 1024 / NW, KRP = 1024 / KROWB;
+  extern __shared__ __attribute__((aligned(16))) char smem_dyn[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = lane >> 5, lq = lane & 31;
+  const int nqb = L / (32 * NW * QT), nst = L / SK;
+  const int nitems = nbh * nqb;
+  const int my_items = (nitems - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int total = my_items * nst;
+  auto issue = [&](int g) {
+    const int item = blockIdx.x + (g / nst) * gridDim.x, st = g % nst;
+    const int bh = item / nqb;
+    const bf16* Kb = K + (int64_t)(bh / nh) * qsB + (int64_t)(bh % nh) * qsH + (int64_t)st * SK * qld;
+    const bf16* Vb = VT + (int64_t)bh * DH * L + (int64_t)st * SK;
+    char* kdst = smem_dyn + (g & 1) * (2 * KST);
+    char* vdst = kdst + KST;
+#pragma unroll
+    for (int j = 0; j < PK; ++j) {
+      const int p = wave + NW * j;
+      const int row = p * KRP + lane / CH, pc = lane % CH;
+      const int lc = pc ^ ((row / RPB) & (CH - 1));
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Kb + (int64_t)row * qld + lc * 8),
+                                       (__attribute__((address_space(3))) void*)(kdst + p * 1024), 16, 0, KVNT ? 2 : 0);
+    }
+#pragma unroll
+    for (int j = 0; j < PK; ++j) {
+      const int p = wave + NW * j;
+      const int t = p / (DH / 8), d = (p % (DH / 8)) * 8 + (lane >> 3), pc = lane & 7;
+      const int lc = pc ^ ((d >> 1) & 7);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Vb + (int64_t)d * L + t * 64 + lc * 8),
+                                       (__attribute__((address_space(3))) void*)(vdst + p * 1024), 16, 0, KVNT ? 2 : 0);
+    }
+  };
+  const int ksw0 = (lq / RPB) & (CH - 1), ksw1 = ((32 + lq) / RPB) & (CH - 1);
+  bf16x8 qf[QT][KS];
+  f32x16 o[QT][DT];
+  float m_run[QT], l_run[QT];
+  int q0 = 0;
+  if (total > 0) issue(0);
+  for (int g = 0; g < total; ++g) {
+    const int item = blockIdx.x + (g / nst) * gridDim.x, st = g % nst;
+    const int bh = item / nqb, qb = item % nqb;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (g + 1 < total) issue(g + 1);
+    if (st == 0) {
+      q0 = qb * (32 * NW * QT) + wave * (32 * QT);
+      const bf16* Qb = Q + (int64_t)(bh / nh) * qsB + (int64_t)(bh % nh) * qsH;
+#pragma unroll
+      for (int qt = 0; qt < QT; ++qt) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) qf[qt][ks] = *reinterpret_cast<const bf16x8*>(Qb + (int64_t)(q0 + 32 * qt + lq) * qld + 16 * ks + 8 * h);
+#pragma unroll
+        for (int i = 0; i < DT; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o[qt][i][r] = 0.f;
+        m_run[qt] = -INFINITY; l_run[qt] = 0.f;
+      }
+    }
+    const char* kbuf = smem_dyn + (g & 1) * (2 * KST);
+    const char* vbuf = kbuf + KST;
+    for (int t = 0; t < SK / 64; ++t) {
+      const char* kb = kbuf + t * (64 * KROWB);
+      const char* vb = vbuf + t * VT_BYTES;
+      f32x16 s[QT][2];
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt) {
+        bf16x8 kf[KS];
+        const int krow = 32 * kt + lq, ksw = kt ? ksw1 : ksw0;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) kf[ks] = *reinterpret_cast<const bf16x8*>(kb + krow * KROWB + (((2 * ks + h) ^ ksw) << 4));
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) s[qt][kt][r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+          for (int qt = 0; qt < QT; ++qt) s[qt][kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[qt][ks], s[qt][kt], 0, 0, 0);
+      }
+#pragma unroll
+      for (int qt = 0; qt < QT; ++qt) {
+        float mx4[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+          for (int r = 0; r < 16; r += 4)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) mx4[e] = fmaxf(mx4[e], s[qt][kt][r + e]);
+        float mx = fmaxf(fmaxf(mx4[0], mx4[1]), fmaxf(mx4[2], mx4[3]));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        if (__builtin_amdgcn_ballot_w64((mx - m_run[qt]) * scale_log2e > 8.0f) != 0) {      // lazy rescale (see attn_stream_bf16_kernel)
+          const float m_new = fmaxf(m_run[qt], mx);
+          const float alpha = __builtin_amdgcn_exp2f((m_run[qt] - m_new) * scale_log2e);
+          l_run[qt] *= alpha;
+          m_run[qt] = m_new;
+#pragma unroll
+          for (int i = 0; i < DT; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[qt][i][r] *= alpha;
+        }
+        const float mb = m_run[qt] * scale_log2e;
+        float ps4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float p = __builtin_amdgcn_exp2f(s[qt][kt][r] * scale_log2e - mb);
+            s[qt][kt][r] = p;
+            ps4[r & 3] += p;
+          }
+        l_run[qt] += (ps4[0] + ps4[1]) + (ps4[2] + ps4[3]);
+      }
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          bf16x8 pf[QT];
+#pragma unroll
+          for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pf[qt][j] = (bf16)s[qt][kt][8 * s2 + j];
+#pragma unroll
+          for (int dt = 0; dt < DT; ++dt) {
+            const int d = dt * 32 + lq;
+            const bf16x8 vf = *reinterpret_cast<const bf16x8*>(vb + d * 128 + (((2 * (2 * kt + s2) + h) ^ ((d >> 1) & 7)) << 4));
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt) o[qt][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[qt], o[qt][dt], 0, 0, 0);
+          }
+        }
+    }
+    if (st == nst - 1) {
+      const int b = bh / nh, head = bh % nh;
+#pragma unroll
+      for (int qt = 0; qt < QT; ++qt) {
+        const float l_tot = l_run[qt] + __shfl_xor(l_run[qt], 32, 64);
+        const float inv = 1.0f / l_tot;
+        const int64_t tok = (int64_t)b * L + q0 + 32 * qt + lq;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+          bf16* dst = ctx_panel ? ctx + (((int64_t)(head * DT + dt)) * ld_ctx + tok) * 32 : ctx + tok * ld_ctx + head * DH + dt * 32;
+          uint2 pk[4];
+#pragma unroll
+          for (int rg = 0; rg < 4; ++rg) {
+            bf16x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = (bf16)(o[qt][dt][rg * 4 + e] * inv);
+            __builtin_memcpy(&pk[rg], &v, 8);
+          }
+#pragma unroll
+          for (int k = 0; k < 4; k += 2) {
+            uint2 a = pk[k], bb = pk[k + 1];
+            auto rx = __builtin_amdgcn_permlane32_swap(a.x, bb.x, false, false);
+            auto ry = __builtin_amdgcn_permlane32_swap(a.y, bb.y, false, false);
+            *reinterpret_cast<uint4*>(dst + 8 * k + 8 * h) = uint4{rx[0], ry[0], rx[1], ry[1]};
+          }
+        }
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                      // every wave is done reading buffer g & 1
+  }
+}
+
 MH_KNOB(int, g_attn_abl, 0);        // timing-only ablation of the streaming kernel (mh_attention_set_ablation)
 MH_KNOB(int, g_attn_resident, 1);
 MH_KNOB(unsigned long long*, g_attn_prof, nullptr);   // diagnostic stamps (mh_attention_set_profile)
@@ -970,7 +1145,7 @@ int launch_bf16(const bf16* q, const bf16* k, const bf16* vt, bf16* ctx, int64_t
 namespace { MH_KNOB(int, g_attn_stream, 1); }
 #ifdef MH_ABLATE
 extern "C" int mh_attention_set_stream(int on) {
-  g_attn_stream = on < 0 ? 0 : (on > 6 ? 6 : on);
+  g_attn_stream = on < 0 ? 0 : (on > 7 ? 7 : on);
   return MH_OK;
 }
 #endif
@@ -1067,6 +1242,20 @@ int stream_fwd_impl(const void* q, const void* k, const void* vt_perm, void* ctx
     MH_LAUNCH(kern, grid, block, bytes, s, Q, K, V, (bf16*)ctx, ld_ctx, L, nh, nbh, sl2, ctx_panel, lse2, qsB, qsH, qld, da, keep_bits, bits_in);
     return MH_OK;
   };
+  if (g_attn_stream == 7 && !pre && !dropping && !lse2 && dh == 64 && L % 512 == 0 && (ctx_panel || (ld_ctx % 8 == 0 && (reinterpret_cast<uintptr_t>(ctx) & 15) == 0))) {
+    // A/B: 64 queries per wave (8 waves, two per SIMD): half the LDS fragment reads per (batch, head)
+    const int items2 = nbh * (L / 512);
+    const dim3 grid2((unsigned)(items2 < cus ? items2 : cus));
+    static std::set<std::pair<int, const void*>> attr2;
+    const bool kvnt = L <= 512;
+    const void* kp = kvnt ? reinterpret_cast<const void*>(&attn_stream2_kernel<true>) : reinterpret_cast<const void*>(&attn_stream2_kernel<false>);
+    if (attr2.insert({mh_current_device(), kp}).second) MH_HIP(hipFuncSetAttribute(kp, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 256 * 64 * 2));
+    mh_prof_note("attn_stream2 B*nh=%d L=%d dh=%d", nbh, L, dh);
+    if (kvnt) MH_LAUNCH((attn_stream2_kernel<true>), grid2, dim3(512), 4 * 256 * 64 * 2, s, Q, K, V, (bf16*)ctx, ld_ctx, L, nh, nbh, sl2, ctx_panel, qsB, qsH, qld);
+    else MH_LAUNCH((attn_stream2_kernel<false>), grid2, dim3(512), 4 * 256 * 64 * 2, s, Q, K, V, (bf16*)ctx, ld_ctx, L, nh, nbh, sl2, ctx_panel, qsB, qsH, qld);
+    MH_CHECK_LAUNCH();
+    return MH_OK;
+  }
   int rc;
   const bool full = L % 256 == 0 && g_attn_stream != 4;   // (mode 4 = A/B: the key-bound build on every length)
   if (dropping && bits_in && small) {   // (mode 2: the bit reader on the 8-wave geometry too)

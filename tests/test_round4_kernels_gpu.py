@@ -232,3 +232,32 @@ def test_down_proj_with_rounding_inside(N, V):
     assert bool(agree[clear].all()) and float(agree.float().mean()) > 0.999
     sq_ref = (y ** 2).sum(1)
     assert float(((sq.cpu().double() - sq_ref).abs() / sq_ref).max()) < 1e-5
+
+
+@pytest.mark.parametrize("L,B,nh", [(512, 3, 5), (1024, 2, 3)])
+def test_attention_with_two_query_tiles_per_wave_equals_the_16_wave_kernel(L, B, nh):
+    """A/B geometry (debug library, mh_attention_set_stream(7)): 8 waves x 64 queries instead of 16 x 32 - every query sees the same
+    arithmetic in the same order (one K / V^T fragment read feeds both of a wave's query tiles), so the context rows are bit-identical."""
+    from test_kernels_gpu import _vt_perm
+    dh = 64
+    qh, kh, vh = (rnd(B, nh, L, dh, seed=330 + i) for i in range(3))
+    kh = kh * 1.5
+    kh[:, :, 300] *= 4.0
+    vtp = _vt_perm(vh.transpose(-1, -2).contiguous())
+    vt_dev = torch.zeros(vtp.numel() + 128, device=DEV, dtype=torch.bfloat16)
+    vt_dev[: vtp.numel()] = vtp.to(DEV).bfloat16().flatten()
+    qd, kd = qh.to(DEV).bfloat16().contiguous(), kh.to(DEV).bfloat16().contiguous()
+    outs = []
+    with _lib.debug_library():
+        for mode in (1, 7):
+            _lib.lib().mh_attention_set_stream(mode)
+            try:
+                for panel in (0, 1):
+                    out = torch.zeros(nh * dh // 32, B * L, 32, device=DEV, dtype=torch.bfloat16) if panel else torch.zeros(B * L, nh * dh, device=DEV, dtype=torch.bfloat16)
+                    check(_lib.lib().mh_attention_stream_fwd(qd.data_ptr(), kd.data_ptr(), vt_dev.data_ptr(), out.data_ptr(), B * L if panel else nh * dh, panel,
+                                                             B, L, nh, dh, 1.0 / math.sqrt(dh), current_stream()))
+                    outs.append(out.clone())
+            finally:
+                _lib.lib().mh_attention_set_stream(1)
+    assert torch.equal(outs[0], outs[2]) and torch.equal(outs[1], outs[3])
+    assert float(outs[0].float().abs().max()) > 0.1
