@@ -265,7 +265,7 @@ __global__ __launch_bounds__(H / 64 * 64, H / 256) void head_fused_kernel(const 
 
 // tail: the block's 64 x H input rows are DMA'd whole into the slab area (they are the A operand of the first dense layer), its
 // tanh output replaces them there, and the E outputs of the second layer are spread over the waves 16 columns each
-// (E = 128 on 8 waves; E_pad = 64: the upper waves repeat the lower ones' columns and do not store).
+// (E = 128 on 8 waves, E = 64 on 4).
 // TJ3 > 0: phase 3 - the rounding scores of the block's 64 rows against the whole embedding table on the bf16 matrix pipe at fp32
 // grade: x = x_hi + x_lo, T = T_hi + T_lo (bf16 parts), x . T ~ x_hi T_hi + x_lo T_hi + x_hi T_lo (three products per element, the
 // dropped x_lo T_lo term is 2^-16 of the product), as ONE K = 3 E contraction [x_hi | x_lo | x_hi] . [T_hi | T_hi | T_lo]^T with fp32
@@ -555,7 +555,9 @@ extern "C" int mh_denoiser_set_fuse_headtail(int on) {
 extern "C" int mh_up_proj_ln_fused_supported(int E, int E_pad, int H) {
   return g_fuse_headtail && (H == 256 || H == 512) && E_pad % 32 == 0 && E_pad <= 128 && E <= E_pad && E % 4 == 0;
 }
-extern "C" int mh_down_proj_fused_supported(int E, int H) { return g_fuse_headtail && (H == 256 || H == 512) && E % 16 == 0 && E / 16 <= H / 64 && E >= 16; }
+// (E / 16 == H / 64: every wave owns exactly one 16-column group of the second layer, so its weight pieces are private to it and the K
+// loop needs no barrier; E = 128 at d_model 512, E = 64 at d_model 256)
+extern "C" int mh_down_proj_fused_supported(int E, int H) { return g_fuse_headtail && (H == 256 || H == 512) && E % 16 == 0 && E / 16 == H / 64; }
 
 extern "C" int mh_up_proj_ln_fused(const float* x, int E, int E_pad, const void* w0, const float* b0, const void* w2, const float* b2,
                                    const float* pos, const float* emb_t, const int32_t* emb_row, const float* gamma, const float* beta,
