@@ -261,3 +261,46 @@ def test_attention_with_two_query_tiles_per_wave_equals_the_16_wave_kernel(L, B,
                 _lib.lib().mh_attention_set_stream(1)
     assert torch.equal(outs[0], outs[2]) and torch.equal(outs[1], outs[3])
     assert float(outs[0].float().abs().max()) > 0.1
+
+
+def test_fused_head_and_tail_repeat_launches_are_bit_identical_under_load():
+    """Race screen for the barrier-free K loops (a wave's LDS-DMA stages are private to it, ordered by its own counted vmcnt / lgkmcnt
+    only): 120 launches of each kernel on the same operands while a second stream keeps the chip's L2 / DMA paths busy with GEMMs
+    of another size - every launch must reproduce the first one bit for bit (a read that overtakes its DMA shows up as a changed row)."""
+    H, E, V, B, L = 512, 128, 729, 8, 512
+    N = B * L
+    x = rnd(N, E, seed=41, scale=0.5).to(DEV)
+    w0, b0 = to_panel(rnd(H, E, seed=42, scale=1 / math.sqrt(E))), rnd(H, seed=43, scale=0.1).to(DEV)
+    w2, b2 = to_panel(rnd(H, H, seed=44, scale=1 / math.sqrt(H))), rnd(H, seed=45, scale=0.1).to(DEV)
+    pos, emb = rnd(L, H, seed=46, scale=0.5).to(DEV), rnd(B, H, seed=47, scale=0.5).to(DEV)
+    g, bt = (1 + rnd(H, seed=48, scale=0.2)).to(DEV), rnd(H, seed=49, scale=0.2).to(DEV)
+    d0, db0 = to_panel(rnd(H, H, seed=50, scale=1 / math.sqrt(H))), rnd(H, seed=51, scale=0.1).to(DEV)
+    d2, db2 = to_panel(rnd(E, H, seed=52, scale=1 / math.sqrt(H))), rnd(E, seed=53, scale=0.1).to(DEV)
+    table = rnd(V, E, seed=54).to(DEV)
+    buf = torch.empty(int(lib().mh_round_split_bytes(E, V)), dtype=torch.uint8, device=DEV)
+    check(lib().mh_round_split_table(table.data_ptr(), None, V, E, buf.data_ptr(), current_stream()))
+    X = torch.zeros(H // 32, N, 32, device=DEV, dtype=torch.bfloat16)
+    out, idx = torch.zeros(N, E, device=DEV), torch.zeros(N, device=DEV, dtype=torch.int32)
+    noise_a, noise_b = torch.randn(4096, 4096, device=DEV, dtype=torch.bfloat16), torch.randn(4096, 4096, device=DEV, dtype=torch.bfloat16)
+    side = torch.cuda.Stream()
+
+    def head():
+        check(lib().mh_up_proj_ln_fused(x.data_ptr(), E, E, w0.data_ptr(), b0.data_ptr(), w2.data_ptr(), b2.data_ptr(), pos.data_ptr(), emb.data_ptr(), None,
+                                        g.data_ptr(), bt.data_ptr(), 1e-12, X.data_ptr(), N, B, L, H, current_stream()))
+
+    def tail():
+        check(lib().mh_down_proj_round_fused(X.data_ptr(), N, d0.data_ptr(), db0.data_ptr(), d2.data_ptr(), db2.data_ptr(), out.data_ptr(), None, buf.data_ptr(), V,
+                                             idx.data_ptr(), None, N, E, H, current_stream()))
+    head(); tail()
+    torch.cuda.synchronize()
+    X0, out0, idx0 = X.clone(), out.clone(), idx.clone()
+    bad = 0
+    for rep in range(120):
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                noise_a @ noise_b
+        X.zero_(); out.zero_(); idx.zero_()
+        head(); tail()
+        torch.cuda.synchronize()
+        bad += int(not (torch.equal(X, X0) and torch.equal(out, out0) and torch.equal(idx, idx0)))
+    assert bad == 0, "%d of 120 repeated launches differ from the first" % bad
