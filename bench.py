@@ -800,6 +800,10 @@ def secondary_block(device, budget_note="short timed regions: <= 60 s in total")
                                                  "device -> pinned-host copy applied when the next draw reads the state, no host sync between forward and backward"))
     guarded("c2_fp32", lambda: dict(_time_loop(WORKLOADS["c2"], "fp32", device, steps=20, warmup=3),
                                     note="compute_dtype='fp32': the mode whose final tokens equal the reference's bit for bit (tests/test_diffusion_gpu.py)"))
+    for mode in ("bf16x3", "f16x3"):
+        guarded("c2_" + mode, lambda mode=mode: dict(_time_loop(WORKLOADS["c2"], mode, device, steps=20, warmup=3),
+                                                     note="compute_dtype=%r: split precision (csrc/split.hip) - every value as hi + lo 16-bit parts, three matrix-pipe products "
+                                                          "per reference product, fp32 sums; the golden loops end on the reference's tokens bit for bit in this mode too" % mode))
     guarded("c2_bertbase", lambda: dict(_time_loop(WORKLOADS["c2-bertbase"], "bf16", device, steps=60, warmup=5),
                                         note="the reference-true width (network.py:44: d_model 768, 12 heads, ffn 3072), same batch"))
 
@@ -807,11 +811,16 @@ def secondary_block(device, budget_note="short timed regions: <= 60 s in total")
         spec = importlib.util.spec_from_file_location("drift_c2", os.path.join(REPO, "tools", "drift_c2.py"))
         mod = importlib.util.module_from_spec(spec)
         spec.loader.exec_module(mod)
-        r = mod.run(steps=50, batch=64, segment="first")
-        return {"value": round(r["final_token_agreement"], 5), "unit": "share of generated positions whose final argmax token equals the fp32 mode's",
-                "steps": 50, "agreement_min_over_steps": round(r["agreement_min"], 5), "free_positions": r["free_positions"],
-                "how": "tools/drift_c2.py: config 2 at full size, same weights, same start latent, same Philox noise, 50 p_sample iterations "
-                       "from t = 1999 in bf16 and in fp32 mode"}
+        rs = mod.run(steps=50, batch=64, segment="first", modes=("bf16", "bf16x3", "f16x3"))
+        r = rs["bf16"]
+        out = {"value": round(r["final_token_agreement"], 5), "unit": "share of generated positions whose final argmax token equals the fp32 mode's",
+               "steps": 50, "agreement_min_over_steps": round(r["agreement_min"], 5), "free_positions": r["free_positions"],
+               "how": "tools/drift_c2.py: config 2 at full size, same weights, same start latent, same Philox noise, 50 p_sample iterations "
+                      "from t = 1999 in bf16 (and bf16x3, f16x3) and in fp32 mode"}
+        for mode in ("bf16x3", "f16x3"):
+            out[mode] = {"value": round(rs[mode]["final_token_agreement"], 6), "final_tokens_differing": rs[mode]["final_tokens_differing"],
+                         "agreement_min_over_steps": round(rs[mode]["agreement_min"], 6), "first_step_with_a_differing_token": rs[mode]["first_step_with_a_differing_token"]}
+        return out
     guarded("bf16_token_agreement", agreement)
     return sec
 
@@ -822,7 +831,7 @@ def main():
     ap.add_argument("--steps", type=int, default=None, help="timed steps (default 200: 0.8 s of replay; train: 10; c3: fixed by the config)")
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32", "bf16x3", "f16x3"])
     ap.add_argument("--rng", default="philox", choices=["philox", "torch"])
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")

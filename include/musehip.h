@@ -17,7 +17,7 @@
  *     MH_F32 (fp32 storage, fp32-input MFMA / VALU: the parity mode) or MH_BF16 (bf16 storage,
  *     bf16 MFMA with fp32 accumulation: the throughput mode).  Latents, biases, LayerNorm
  *     parameters, embeddings used for rounding / logits and all diffusion arithmetic are fp32 in
- *     both modes.
+ *     both modes.  MH_BF16X3 / MH_F16X3 (the denoiser forward only): the mode between the two - see "split precision" below.
  *   - "ld*" arguments are leading dimensions in ELEMENTS.
  */
 #ifndef MUSEHIP_H
@@ -33,7 +33,10 @@ extern "C" {
 typedef void* mh_stream_t; /* hipStream_t */
 
 enum mh_status { MH_OK = 0, MH_ERR_INVALID = -1, MH_ERR_HIP = -2, MH_ERR_UNSUPPORTED = -3 };
-enum mh_dtype { MH_F32 = 0, MH_BF16 = 1 };
+enum mh_dtype { MH_F32 = 0, MH_BF16 = 1,
+                /* split precision (csrc/split.hip): every value as hi + lo 16-bit parts, three matrix-pipe products per reference product,
+                 * fp32 accumulation - the denoiser forward only (mh_denoiser_*, mh_split_*), 4 bytes per element like MH_F32 */
+                MH_BF16X3 = 2, MH_F16X3 = 3 };
 enum mh_act { MH_ACT_NONE = 0, MH_ACT_TANH = 1, MH_ACT_GELU_ERF = 2, MH_ACT_SILU = 3,
               MH_ACT_DERIV = 4 /* mh_gemm_act_grad only: `pre` holds act'(pre) already (mh_gemm_bias_act_dact) */ };
 
@@ -447,7 +450,7 @@ typedef struct mh_layer_weights {
 } mh_layer_weights;
 
 typedef struct mh_denoiser {
-  int dtype;           /* mh_dtype of every `const void*` weight and of the activations */
+  int dtype;           /* mh_dtype of every `const void*` weight and of the activations (MH_BF16X3 / MH_F16X3: split panels, see mh_split_*) */
   int E, H, F, nh, nL, Tt, Tt_pad, T4_pad, E_pad, L_max;  /* *_pad: padded to a multiple of 64 */
   int panel;           /* bf16 only: weights and activations in the K32-panel layout (see mh_gemm_bias_act_ex) */
   int has_proj;        /* E != H: input_up_proj / output_down_proj present (network.py:67-72, :81-86) */
@@ -475,6 +478,34 @@ int mh_time_embed(const mh_denoiser* m, const float* t, float* emb_t_out, int B,
 int mh_denoiser_forward(const mh_denoiser* m, const float* x, const float* emb_t, const int32_t* emb_row,
                         float* out, int B, int L, void* workspace, size_t workspace_bytes,
                         mh_stream_t stream);
+
+/* ---- split precision: the mode between MH_BF16 (fast, ~4e-3 per product) and MH_F32 (exact, f32 matrix rate = 1/16) --------------
+ * dtype MH_BF16X3 or MH_F16X3.  A "split panel" matrix [rows, C] is [2][C / 32][ld rows][32] 16-bit values: the K32-panel layout once
+ * for hi = rn16(v) and once for lo = rn16(v - hi).  Products run as lo x hi + hi x lo + hi x hi on the bf16 / f16 matrix pipe with fp32
+ * accumulation (relative error per product 2^-16 / 2^-22 against 2^-9 for bf16); everything between the GEMMs is fp32 (exact-erf GELU,
+ * tanhf, two-pass LayerNorm) as in the MH_F32 mode.  Reference arithmetic: fp32 everywhere (models/network.py:131-158, diffusion.py:914).
+ * mh_denoiser_forward / mh_time_embed accept a descriptor with one of these dtypes (weights: split panels [2][K_pad/32][rows][32] from
+ * mh_split_pack; the time-MLP weights stay fp32 row-major; panel = 0; H % 64 == 0, head dim in {16, 32, 64}). */
+int mh_split_supported(int dtype);
+/* fp32 row-major [rows, cols] (ldx) -> split panels with the K dimension zero-padded to kpad (a multiple of 32) */
+int mh_split_pack(const float* x, int64_t ldx, void* out, int64_t ld_rows, int64_t rows, int cols, int kpad, int dtype, mh_stream_t stream);
+/* split panels (cpad / 32 panels per part) -> fp32 row-major [rows, cols]: hi + lo */
+int mh_split_join(const void* in, int64_t ld_rows, float* out, int64_t ldo, int64_t rows, int cols, int cpad, int dtype, mh_stream_t stream);
+/* LayerNorm of fp32 rows [rows, H] (ldx) -> split panels; pos != NULL: of (pos[row % L] + x) + emb_t[emb_row ? emb_row[row / L] : row / L]
+ * first (network.py:148-149) */
+int mh_split_layernorm(const float* x, int64_t ldx, const float* pos, const float* emb_t, const int32_t* emb_row, const float* gamma,
+                       const float* beta, void* out, int64_t ld_rows, int64_t rows, int L, int H, float eps, int dtype, mh_stream_t stream);
+/* out = act(A W^T + bias) [+ residual].  A: split panels, M rows, K columns (lda rows per panel); W: split panels, N rows (ldw);
+ * bias fp32 [N] (bias_rows = 0) or [M] (bias_rows = 1: the transposed V projection W_v X^T); residual: split panels [M, N] (ldr) or NULL;
+ * out_mode 0: split panels [2][N/32][ldo][32]; 1: split row-major [M][ldo], lo part out_part elements after hi; 2: fp32 row-major [M][ldo].
+ * act: MH_ACT_NONE / MH_ACT_TANH (tanhf) / MH_ACT_GELU_ERF (erff). */
+int mh_split_gemm(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, int bias_rows, const void* residual, int64_t ldr,
+                  void* out, int64_t ldo, int out_mode, int64_t out_part, int64_t M, int N, int K, int act, int dtype, mh_stream_t stream);
+/* unmasked multi-head self-attention on split operands (HF BertSelfAttention from network.py:151): q / k split row-major
+ * [2][B L][ld_qk] (q of head h at column h dh, k at column k_offset + h dh, lo part qk_part elements after hi), vt split row-major
+ * [2][nh dh][ld_vt] (column = token; lo part vt_part elements after hi), ctx -> split panels [2][nh dh / 32][ld_ctx][32] */
+int mh_split_attention(const void* qk, int64_t ld_qk, int k_offset, int64_t qk_part, const void* vt, int64_t ld_vt, int64_t vt_part, void* ctx,
+                       int64_t ld_ctx, int B, int L, int nh, int dh, float scale, int dtype, mh_stream_t stream);
 
 /* ---- batch producers and token validators.  Ragged int32 sequences:
  * `values` = all rows back to back, `offsets[B + 1]` int64; rows of at most mh_batch_max_row() tokens.

@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libmusehip.so")
 if os.environ.get("MUSEHIP_AB") == "1" and os.environ.get("MUSEHIP_LIB"):
     LIB_PATH = os.environ["MUSEHIP_LIB"]
 
-MH_F32, MH_BF16 = 0, 1
+MH_F32, MH_BF16, MH_BF16X3, MH_F16X3 = 0, 1, 2, 3
 ACT_NONE, ACT_TANH, ACT_GELU_ERF, ACT_SILU = 0, 1, 2, 3
 
 c_i32p = C.POINTER(C.c_int32)
@@ -96,6 +96,12 @@ SIGNATURES = {
     "mh_cast_to_f32": (INT, [VP, I64, VP, I64, I64, I64, INT, VP]),
     "mh_pack_panel": (INT, [VP, I64, VP, I64, I64, I64, I64, VP]),
     "mh_unpack_panel_f32": (INT, [VP, I64, VP, I64, I64, I64, VP]),
+    "mh_split_supported": (INT, [INT]),
+    "mh_split_pack": (INT, [VP, I64, VP, I64, I64, INT, INT, INT, VP]),
+    "mh_split_join": (INT, [VP, I64, VP, I64, I64, INT, INT, INT, VP]),
+    "mh_split_layernorm": (INT, [VP, I64, VP, VP, VP, VP, VP, VP, I64, I64, INT, INT, F32, INT, VP]),
+    "mh_split_gemm": (INT, [VP, I64, VP, I64, VP, INT, VP, I64, VP, I64, INT, I64, I64, INT, INT, INT, INT, VP]),
+    "mh_split_attention": (INT, [VP, I64, INT, I64, VP, I64, I64, VP, I64, INT, INT, INT, INT, F32, INT, VP]),
     "mh_row_sqnorm": (INT, [VP, VP, INT, INT, VP]),
     "mh_embed_gather": (INT, [VP, VP, VP, I64, INT, INT, VP]),
     "mh_timestep_embedding": (INT, [VP, VP, INT, INT, I64, F32, INT, VP]),

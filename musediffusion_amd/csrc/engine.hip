@@ -157,7 +157,8 @@ extern "C" int mh_graph_destroy(void* graph_exec) {
 // ---------------------------------------------------------------- denoiser forward
 namespace {
 
-inline size_t esize(int dtype) { return dtype == MH_BF16 ? 2 : 4; }
+inline size_t esize(int dtype) { return dtype == MH_BF16 ? 2 : 4; }   // (split precision: two 16-bit parts per element)
+inline bool is_split(int dtype) { return dtype == MH_BF16X3 || dtype == MH_F16X3; }
 inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct Workspace {
@@ -189,7 +190,11 @@ Workspace carve(const mh_denoiser* m, int B, int L, char* base) {
 
 int check_model(const mh_denoiser* m) {
   MH_CHECK_ARG(m, "denoiser: null descriptor");
-  MH_CHECK_ARG(m->dtype == MH_F32 || m->dtype == MH_BF16, "denoiser: unknown dtype %d", m->dtype);
+  MH_CHECK_ARG(m->dtype == MH_F32 || m->dtype == MH_BF16 || is_split(m->dtype), "denoiser: unknown dtype %d", m->dtype);
+  if (is_split(m->dtype)) {
+    const int dh = m->nh > 0 ? m->H / m->nh : 0;
+    MH_CHECK_ARG(!m->panel && (dh == 16 || dh == 32 || dh == 64) && m->H <= 2048, "denoiser(split precision): panel must be 0, head dim in {16, 32, 64}, hidden size <= 2048");
+  }
   MH_CHECK_ARG(m->H > 0 && m->H % 64 == 0 && m->H <= 2048, "denoiser: hidden size %d must be a multiple of 64, <= 2048", m->H);
   MH_CHECK_ARG(m->F > 0 && m->F % 64 == 0, "denoiser: ffn size %d must be a multiple of 64", m->F);
   MH_CHECK_ARG(m->nh > 0 && m->H % m->nh == 0, "denoiser: heads %d must divide hidden %d", m->nh, m->H);
@@ -216,18 +221,19 @@ extern "C" int mh_time_embed(const mh_denoiser* m, const float* t, float* emb_t_
   int rc = check_model(m);
   if (rc) return rc;
   MH_CHECK_ARG(t && emb_t_out && B > 0 && workspace, "time_embed: bad arguments");
-  const size_t es = esize(m->dtype);
+  const int tdt = is_split(m->dtype) ? MH_F32 : m->dtype;   // (split precision: the time MLP runs once per table build, in fp32)
+  const size_t es = esize(tdt);
   const size_t need = align256((size_t)B * m->Tt_pad * es) + align256((size_t)B * m->T4_pad * es);
   MH_CHECK_ARG(workspace_bytes >= need, "time_embed: workspace too small (%zu < %zu)", workspace_bytes, need);
   char* sin_buf = (char*)workspace;
   char* hid = sin_buf + align256((size_t)B * m->Tt_pad * es);
-  if ((rc = mh_timestep_embedding(t, sin_buf, B, m->Tt, m->Tt_pad, 10000.0f, m->dtype, stream))) return rc;
+  if ((rc = mh_timestep_embedding(t, sin_buf, B, m->Tt, m->Tt_pad, 10000.0f, tdt, stream))) return rc;
   if (m->T4_pad != 4 * m->Tt) MH_HIP(hipMemsetAsync(hid, 0, (size_t)B * m->T4_pad * es, (hipStream_t)stream));
   if ((rc = mh_gemm_bias_act(sin_buf, m->Tt_pad, m->w_t0, m->Tt_pad, m->b_t0, nullptr, 0, hid, m->T4_pad, 0, B,
-                             4 * m->Tt, m->Tt_pad, MH_ACT_SILU, m->dtype, stream)))
+                             4 * m->Tt, m->Tt_pad, MH_ACT_SILU, tdt, stream)))
     return rc;
   return mh_gemm_bias_act(hid, m->T4_pad, m->w_t2, m->T4_pad, m->b_t2, nullptr, 0, emb_t_out, m->H, 1, B, m->H,
-                          m->T4_pad, MH_ACT_NONE, m->dtype, stream);
+                          m->T4_pad, MH_ACT_NONE, tdt, stream);
 }
 
 namespace {
@@ -454,6 +460,43 @@ int denoiser_run(const mh_denoiser* m, const float* x, const float* emb_t, const
     return mh_unpack_panel_f32(XT, ldT, out, m->E, N, m->E, stream);
   }
   MH_CHECK_ARG(ph.mask == 7, "denoiser: the phased entry points serve the bf16 panel path only");
+  if (is_split(dt)) {
+    // ---- split precision (csrc/split.hip): activations as split panels (hi + lo 16-bit parts), three matrix-pipe products per
+    // reference product, LayerNorm on fp32 rows.  Buffers (4 bytes per element each): xin / buf0 / bufX / bufX1 / ffn split panels,
+    // buf1 fp32 rows, q..k = the packed [N, 2H] split row-major q | k projection, vt = the [H, N] split row-major V^T projection.
+    const int64_t part_qk = N * 2 * H, part_vt = (int64_t)H * N;
+    auto sgemm = [&](const void* A, const void* W, int64_t w_rows, const float* bias, const void* res, void* o, int64_t ldo, int mode, int64_t M2, int Nout,
+                     int K, int act) {
+      return mh_split_gemm(A, N, W, w_rows, bias, 0, res, N, o, ldo, mode, 0, M2, Nout, K, act, dt, stream);
+    };
+    if (m->has_proj) {   // network.py:141-149
+      if ((rc = mh_split_pack(x, m->E, w.xin, N, N, m->E, m->E_pad, dt, stream))) return rc;
+      if ((rc = sgemm(w.xin, m->w_up0, H, m->b_up0, nullptr, w.buf0, N, 0, N, H, m->E_pad, MH_ACT_TANH))) return rc;
+      if ((rc = sgemm(w.buf0, m->w_up2, H, m->b_up2, nullptr, w.buf1, H, 2, N, H, H, MH_ACT_NONE))) return rc;
+      if ((rc = mh_split_layernorm((const float*)w.buf1, H, m->pos, emb_t, emb_row, m->ln0_g, m->ln0_b, w.bufX, N, N, L, H, m->ln_eps, dt, stream))) return rc;
+    } else {
+      if ((rc = mh_split_layernorm(x, H, m->pos, emb_t, emb_row, m->ln0_g, m->ln0_b, w.bufX, N, N, L, H, m->ln_eps, dt, stream))) return rc;
+    }
+    for (int l = 0; l < m->nL; ++l) {   // HF BertLayer, post-LN (network.py:151)
+      const mh_layer_weights& lw = m->layers[l];
+      // q | k = X [W_q; W_k]^T + b  ->  [N, 2H];   V^T = W_v X^T + b_v (rows)  ->  [H, N]: the attention's operand images, no transposes
+      if ((rc = mh_split_gemm(w.bufX, N, lw.w_qkv, 3 * H, lw.b_qkv, 0, nullptr, 0, w.q, 2 * H, 1, part_qk, N, 2 * H, H, MH_ACT_NONE, dt, stream))) return rc;
+      if ((rc = mh_split_gemm((const char*)lw.w_qkv + (size_t)2 * H * 32 * 2, 3 * H, w.bufX, N, lw.b_qkv + 2 * H, 1, nullptr, 0, w.vt, N, 1, part_vt, H, (int)N, H,
+                              MH_ACT_NONE, dt, stream)))
+        return rc;
+      if ((rc = mh_split_attention(w.q, 2 * H, H, part_qk, w.vt, N, part_vt, w.buf0, N, B, L, m->nh, dh, scale, dt, stream))) return rc;
+      if ((rc = sgemm(w.buf0, lw.w_ao, H, lw.b_ao, w.bufX, w.buf1, H, 2, N, H, H, MH_ACT_NONE))) return rc;
+      if ((rc = mh_split_layernorm((const float*)w.buf1, H, nullptr, nullptr, nullptr, lw.ln1_g, lw.ln1_b, w.bufX1, N, N, L, H, m->ln_eps, dt, stream))) return rc;
+      if ((rc = sgemm(w.bufX1, lw.w_ff1, F, lw.b_ff1, nullptr, w.ffn, N, 0, N, F, H, MH_ACT_GELU_ERF))) return rc;
+      if ((rc = sgemm(w.ffn, lw.w_ff2, H, lw.b_ff2, w.bufX1, w.buf1, H, 2, N, H, F, MH_ACT_NONE))) return rc;
+      if ((rc = mh_split_layernorm((const float*)w.buf1, H, nullptr, nullptr, nullptr, lw.ln2_g, lw.ln2_b, w.bufX, N, N, L, H, m->ln_eps, dt, stream))) return rc;
+    }
+    if (m->has_proj) {   // network.py:153-157
+      if ((rc = sgemm(w.bufX, m->w_dn0, H, m->b_dn0, nullptr, w.buf0, N, 0, N, H, H, MH_ACT_TANH))) return rc;
+      return sgemm(w.buf0, m->w_dn2, m->E, m->b_dn2, nullptr, out, m->E, 2, N, m->E, H, MH_ACT_NONE);
+    }
+    return mh_split_join(w.bufX, N, out, m->E, N, m->E, H, dt, stream);
+  }
   // ---- embeddings: (up-projection) + position + time, LayerNorm          network.py:141-149
   if (m->has_proj) {
     if ((rc = mh_cast_pad(x, m->E, w.xin, m->E_pad, N, m->E, N, dt, stream))) return rc;

@@ -1,0 +1,661 @@
+// Split-precision kernels: the mode between "fast" (bf16) and "exact" (fp32) - compute_dtype "bf16x3" / "f16x3".
+//
+// Every operand value v is held as TWO 16-bit floats, hi = rn16(v) and lo = rn16(v - hi), and every product of the reference's fp32
+// arithmetic (models/network.py:131-158 run in fp32, models/diffusion.py:914) becomes three matrix-pipe products accumulated in fp32,
+//     x w  ~  x_lo w_hi + x_hi w_lo + x_hi w_hi          (x_lo w_lo, relative 2^-16 (bf16) / 2^-22 (f16), is dropped)
+// as ONE K loop of three times the depth: K-step kt of 3 K/32 reads part (kt < K/32 ? lo : hi) of A and part
+// (K/32 <= kt < 2 K/32 ? lo : hi) of W - the small terms first, the large one on top.  Measured on gfx950 (tools/micro/split_mfma.hip, K = 512,
+// max |error| / rms of the fp64 result): bf16 7.9e-3, f16 6.9e-4, bf16x3 1.2e-5, f16x3 2.5e-6, an fp32 fma chain 1.7e-6;
+// v_mfma_f32_*_f16 keeps subnormal inputs, so an f16 lo part below 2^-14 keeps an absolute precision of 2^-25.
+// f16 parts saturate at +-65504 (bf16 parts have fp32's range).
+//
+// Layout: a "split panel" matrix [rows, C] is [2][C / 32][ld rows][32] 16-bit - the K32-panel layout of the bf16 path (DESIGN.md
+// section 3) once for hi and once for lo, so every LDS-DMA piece of the GEMM is still 16 rows x 64 contiguous bytes.
+// LayerNorm / residual sums / softmax statistics stay fp32; GELU is the exact erf form, tanh is tanhf (as in the fp32 mode).
+#include "common.h"
+
+namespace {
+
+typedef _Float16 f16;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+
+template <typename T> struct Sp;
+template <> struct Sp<bf16> {
+  typedef bf16x8 x8;
+  typedef bf16x4 x4;
+  static __device__ __forceinline__ f32x4 mma16(x8 a, x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+  static __device__ __forceinline__ f32x16 mma32(x8 a, x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+  static __device__ __forceinline__ float sat(float v) { return v; }
+};
+template <> struct Sp<f16> {
+  typedef f16x8 x8;
+  typedef f16x4 x4;
+  static __device__ __forceinline__ f32x4 mma16(x8 a, x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+  static __device__ __forceinline__ f32x16 mma32(x8 a, x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+  static __device__ __forceinline__ float sat(float v) { return fminf(fmaxf(v, -65504.0f), 65504.0f); }
+};
+
+template <typename T, int N>
+__device__ __forceinline__ void split(const float (&v)[N], T (&hi)[N], T (&lo)[N]) {
+#pragma unroll
+  for (int e = 0; e < N; ++e) {
+    const float s = Sp<T>::sat(v[e]);
+    hi[e] = (T)s;
+    lo[e] = (T)(s - (float)hi[e]);
+  }
+}
+template <typename T>
+__device__ __forceinline__ void store_split8(T* hi_p, T* lo_p, const float (&v)[8]) {
+  T h[8], l[8];
+  split<T, 8>(v, h, l);
+  typename Sp<T>::x8 hv, lv;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { hv[e] = h[e]; lv[e] = l[e]; }
+  *reinterpret_cast<typename Sp<T>::x8*>(hi_p) = hv;
+  *reinterpret_cast<typename Sp<T>::x8*>(lo_p) = lv;
+}
+template <typename T>
+__device__ __forceinline__ void load_split8(const T* hi_p, const T* lo_p, float (&v)[8]) {
+  const typename Sp<T>::x8 hv = *reinterpret_cast<const typename Sp<T>::x8*>(hi_p), lv = *reinterpret_cast<const typename Sp<T>::x8*>(lo_p);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = (float)hv[e] + (float)lv[e];
+}
+
+// ------------------------------------------------------------------------------------------ fp32 rows <-> split panels
+// grid (ceil(rows / 64), kpad / 32): thread (r = tid / 4, c = tid % 4) moves 8 elements of one row of one panel
+template <typename T>
+__global__ __launch_bounds__(256) void split_pack_kernel(const float* __restrict__ x, int64_t ldx, T* __restrict__ out, int64_t ld, int64_t rows,
+                                                         int cols, int kpad) {
+  const int r = threadIdx.x >> 2, c = threadIdx.x & 3, panel = blockIdx.y;
+  const int64_t row = (int64_t)blockIdx.x * 64 + r;
+  if (row >= rows) return;
+  const int col = panel * 32 + c * 8;
+  float v[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = col + e < cols ? x[row * ldx + col + e] : 0.f;
+  T* hi = out + ((int64_t)panel * ld + row) * 32 + c * 8;
+  store_split8<T>(hi, hi + (int64_t)(kpad / 32) * ld * 32, v);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void split_join_kernel(const T* __restrict__ in, int64_t ld, int npanels, float* __restrict__ out, int64_t ldo,
+                                                         int64_t rows, int cols) {
+  const int r = threadIdx.x >> 2, c = threadIdx.x & 3, panel = blockIdx.y;
+  const int64_t row = (int64_t)blockIdx.x * 64 + r;
+  if (row >= rows) return;
+  const int col = panel * 32 + c * 8;
+  const T* hi = in + ((int64_t)panel * ld + row) * 32 + c * 8;
+  float v[8];
+  load_split8<T>(hi, hi + (int64_t)npanels * ld * 32, v);
+#pragma unroll
+  for (int e = 0; e < 8; ++e)
+    if (col + e < cols) out[row * ldo + col + e] = v[e];
+}
+
+// ------------------------------------------------------------------------------------------ LayerNorm: fp32 rows -> split panels
+// One wave per row, the row in registers, two in-register passes (as csrc/norm.hip).  ADD: (pos + x) + emb_t first (network.py:148).
+constexpr int LN_MAXCH = 4;   // 8-element chunks per lane: H <= 2048
+template <typename T, bool ADD>
+__global__ __launch_bounds__(256) void split_ln_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ pos,
+                                                       const float* __restrict__ emb_t, const int32_t* __restrict__ emb_row,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta, T* __restrict__ out,
+                                                       int64_t ld, int64_t rows, int L, int H, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int nch = H >> 3;
+  float v[LN_MAXCH][8];
+  float sum = 0.f;
+  const float* prow = nullptr;
+  const float* trow = nullptr;
+  if constexpr (ADD) {
+    const int64_t b = row / L, l = row % L;
+    prow = pos + l * H;
+    trow = emb_t + (int64_t)(emb_row ? emb_row[b] : (int)b) * H;
+  }
+#pragma unroll
+  for (int i = 0; i < LN_MAXCH; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nch) {
+      load8(x + row * ldx + c * 8, v[i]);
+      if constexpr (ADD) {
+        float p[8], t[8];
+        load8(prow + c * 8, p);
+        load8(trow + c * 8, t);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[i][e] = (p[e] + v[i][e]) + t[e];
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) sum += v[i][e];
+    }
+  }
+  const float mean = wave_sum(sum) / (float)H;
+  float sq = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXCH; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nch) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float d = v[i][e] - mean; sq += d * d; }
+    }
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(sq) / (float)H + eps);
+  const int64_t part = (int64_t)(H / 32) * ld * 32;
+#pragma unroll
+  for (int i = 0; i < LN_MAXCH; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nch) {
+      float g[8], bt[8], y[8];
+      load8(gamma + c * 8, g);
+      load8(beta + c * 8, bt);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) y[e] = (v[i][e] - mean) * rstd * g[e] + bt[e];
+      T* hi = out + ((int64_t)(c >> 2) * ld + row) * 32 + (c & 3) * 8;
+      store_split8<T>(hi, hi + part, y);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------ GEMM
+// out = act(A W^T + bias) [+ residual]: A split panels [2][K/32][lda][32] (M rows), W split panels [2][K/32][ldw][32] (N rows).
+// 256 x 128 tile, 4 waves (2 x 2, 128 x 64 each), 3-stage LDS-DMA ring of K-steps of 32, two blocks per CU: the bf16 path's
+// geometry (csrc/gemm.hip, BigCfg<256,128,2,2,3>), LDS rows of 64 B with the chunk swizzle c ^ G[(r >> 2) & 3], the W-row remap that
+// leaves a lane 8 consecutive output columns.
+struct SpGemmArgs {
+  const void* A; int64_t lda;
+  const void* W; int64_t ldw;
+  const float* bias; int bias_rows;       // bias_rows: bias[row] instead of bias[col] (the transposed V projection)
+  const void* res; int64_t ldr;           // residual: split panels [2][N/32][ldr][32]
+  void* out; int64_t ldo; int out_mode;   // 0 split panels [2][N/32][ldo][32], 1 split row-major (lo part o_part elements after hi), 2 fp32 row-major
+  int64_t o_part;
+  int64_t M; int N, K;
+};
+
+constexpr int GBM = 256, GBN = 128, GNST = 3, GSTAGE = (GBM + GBN) * 64, GTI = 8, GTJ = 4, GPA = 4, GPW = 2, GPIECES = GPA + GPW;
+
+template <int N> __device__ __forceinline__ void sp_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void sp_wait_stages(int stages) {
+  if (stages >= 2) sp_wait_vmcnt<2 * GPIECES>();
+  else if (stages == 1) sp_wait_vmcnt<GPIECES>();
+  else sp_wait_vmcnt<0>();
+}
+__device__ __forceinline__ int sp_xcd_remap(int bid, int nblk) {
+  const int q = nblk >> 3, r = nblk & 7, x = bid & 7;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+}
+
+template <typename T, int ACT>
+__global__ __launch_bounds__(256, 2) void split_gemm_kernel(const SpGemmArgs g) {
+  typedef typename Sp<T>::x8 x8;
+  __shared__ __attribute__((aligned(16))) char smem[GNST * GSTAGE];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int tiles_n = (g.N + GBN - 1) / GBN;
+  const int nk0 = g.K / 32, nk = 3 * nk0;
+  const int fr = lane & 15, fg = lane >> 4;
+  constexpr int GSW[4] = {0, 2, 3, 1};
+  const int bid = sp_xcd_remap(blockIdx.x, gridDim.x);
+  const int64_t m0 = (int64_t)(bid / tiles_n) * GBM;
+  const int n0 = (bid % tiles_n) * GBN;
+  // DMA coordinates: a piece = 16 rows x 64 B; lane i lands at row i / 4, physical chunk i % 4, which holds logical chunk pc ^ G[..]
+  const int rl = lane >> 2, pc = lane & 3, lc = pc ^ GSW[(rl >> 2) & 3];
+  const int64_t kstepA = g.lda * 64, kstepW = g.ldw * 64;
+  const char* srcA[GPA];
+  const char* srcW[GPW];
+#pragma unroll
+  for (int j = 0; j < GPA; ++j) {
+    int64_t ra = m0 + (wave * GPA + j) * 16 + rl; if (ra >= g.M) ra = g.M - 1;
+    srcA[j] = reinterpret_cast<const char*>(g.A) + (ra * 32 + lc * 8) * 2;
+  }
+#pragma unroll
+  for (int j = 0; j < GPW; ++j) {
+    int rw = n0 + (wave * GPW + j) * 16 + rl; if (rw >= g.N) rw = g.N - 1;
+    srcW[j] = reinterpret_cast<const char*>(g.W) + ((int64_t)rw * 32 + lc * 8) * 2;
+  }
+  // stage kt: term t = kt / nk0 (0: A lo x W hi, 1: A hi x W lo, 2: A hi x W hi), K-step kt % nk0 of it
+  auto issue = [&](int kt) {
+    const int t = (kt >= nk0) + (kt >= 2 * nk0), kk = kt - t * nk0;
+    const int64_t offA = (int64_t)((t == 0 ? nk0 : 0) + kk) * kstepA, offW = (int64_t)((t == 1 ? nk0 : 0) + kk) * kstepW;
+    char* base = smem + (kt % GNST) * GSTAGE;
+#pragma unroll
+    for (int j = 0; j < GPA; ++j)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcA[j] + offA),
+                                       (__attribute__((address_space(3))) void*)(base + (wave * GPA + j) * 1024), 16, 0, 0);
+#pragma unroll
+    for (int j = 0; j < GPW; ++j)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcW[j] + offW),
+                                       (__attribute__((address_space(3))) void*)(base + GBM * 64 + (wave * GPW + j) * 1024), 16, 0, 0);
+  };
+  const int frag_off = fr * 64 + ((fg ^ GSW[(fr >> 2) & 3]) << 4);
+  const int a_off = wm * (GTI * 16 * 64) + frag_off;
+  int b_offs[GTJ];
+#pragma unroll
+  for (int j = 0; j < GTJ; ++j) {
+    const int row = 32 * (j >> 1) + 8 * (fr >> 2) + 4 * (j & 1) + (fr & 3);
+    b_offs[j] = wn * (GTJ * 16 * 64) + row * 64 + ((fg ^ GSW[(row >> 2) & 3]) << 4);
+  }
+  f32x4 acc[GTI][GTJ];
+#pragma unroll
+  for (int i = 0; i < GTI; ++i)
+#pragma unroll
+    for (int j = 0; j < GTJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int npro = nk < GNST ? nk : GNST;
+  for (int st = 0; st < npro; ++st) issue(st);
+  sp_wait_stages(npro - 1);
+  __builtin_amdgcn_s_barrier();
+  x8 a[GTI], b[GTJ], bn[GTJ];
+#pragma unroll
+  for (int j = 0; j < GTJ; ++j) b[j] = *reinterpret_cast<const x8*>(smem + GBM * 64 + b_offs[j]);
+#pragma unroll
+  for (int i = 0; i < GTI; ++i) a[i] = *reinterpret_cast<const x8*>(smem + a_off + i * (16 * 64));
+  for (int kt = 0; kt + 1 < nk; ++kt) {
+    const char* As = smem + ((kt + 1) % GNST) * GSTAGE;
+    const char* Ws = As + GBM * 64;
+    const int younger = nk - 2 - kt < GNST - 2 ? nk - 2 - kt : GNST - 2;
+    sp_wait_stages(younger);
+    __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): this wave's reads of stage kt are done
+    __builtin_amdgcn_s_barrier();
+    if (kt + GNST < nk) issue(kt + GNST);   // slot kt % NST: every wave has read stage kt out of it
+#pragma unroll
+    for (int j = 0; j < GTJ; ++j) bn[j] = *reinterpret_cast<const x8*>(Ws + b_offs[j]);
+#pragma unroll
+    for (int i = 0; i < GTI; ++i) {
+#pragma unroll
+      for (int j = 0; j < GTJ; ++j) acc[i][j] = Sp<T>::mma16(b[j], a[i], acc[i][j]);
+      a[i] = *reinterpret_cast<const x8*>(As + a_off + i * (16 * 64));
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int j = 0; j < GTJ; ++j) b[j] = bn[j];
+  }
+#pragma unroll
+  for (int i = 0; i < GTI; ++i)
+#pragma unroll
+    for (int j = 0; j < GTJ; ++j) acc[i][j] = Sp<T>::mma16(b[j], a[i], acc[i][j]);
+
+  // ---- epilogue: lane's 8 consecutive columns of half qh: wcol0 + 32 qh + 8 fg, values acc[i][2 qh + (e >> 2)][e & 3]; row wrow0 + 16 i + fr
+  const int wcol0 = n0 + wn * 64;
+  const int64_t wrow0 = m0 + wm * 128;
+  T* outT = reinterpret_cast<T*>(g.out);
+  float* outF = reinterpret_cast<float*>(g.out);
+  const T* res = reinterpret_cast<const T*>(g.res);
+  const int64_t r_part = (int64_t)(g.N / 32) * g.ldr * 32;
+  const int64_t o_part = g.out_mode == 0 ? (int64_t)(g.N / 32) * g.ldo * 32 : g.o_part;
+#pragma unroll
+  for (int qh = 0; qh < 2; ++qh) {
+    const int col = wcol0 + 32 * qh + 8 * fg;
+    if (col >= g.N) continue;
+    const int nval = g.N - col >= 8 ? 8 : g.N - col;   // (a last group may be partial: fp32 row-major outputs only)
+    float bv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bv[e] = (g.bias && !g.bias_rows && e < nval) ? g.bias[col + e] : 0.f;
+#pragma unroll
+    for (int i = 0; i < GTI; ++i) {
+      const int64_t row = wrow0 + 16 * i + fr;
+      if (row >= g.M) continue;
+      float v[8];
+      const float br = (g.bias && g.bias_rows) ? g.bias[row] : 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = acc[i][2 * qh + (e >> 2)][e & 3] + bv[e] + br;
+      if constexpr (ACT == MH_ACT_TANH) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = tanhf(v[e]);
+      } else if constexpr (ACT == MH_ACT_GELU_ERF) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
+      }
+      if (res) {
+        const T* rp = res + ((int64_t)(col >> 5) * g.ldr + row) * 32 + (col & 31);
+        float rv[8];
+        load_split8<T>(rp, rp + r_part, rv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += rv[e];
+      }
+      if (g.out_mode == 2) {
+        if (nval == 8) store8(outF + row * g.ldo + col, v);
+        else
+          for (int e = 0; e < nval; ++e) outF[row * g.ldo + col + e] = v[e];
+      } else {
+        T* hp = g.out_mode == 0 ? outT + ((int64_t)(col >> 5) * g.ldo + row) * 32 + (col & 31) : outT + row * g.ldo + col;
+        store_split8<T>(hp, hp + o_part, v);
+      }
+    }
+  }
+}
+
+template <typename T>
+int launch_gemm(const SpGemmArgs& g, int act, hipStream_t s) {
+  const int64_t tiles = (int64_t)((g.M + GBM - 1) / GBM) * ((g.N + GBN - 1) / GBN);
+  MH_CHECK_ARG(tiles > 0 && tiles < (1ll << 31), "split_gemm: bad grid (M=%lld N=%d)", (long long)g.M, g.N);
+  const dim3 grid((unsigned)tiles), block(256);
+  mh_prof_note("split tile=256x128 act=%d M=%lld N=%d K=3x%d out=%d", act, (long long)g.M, g.N, g.K, g.out_mode);
+  switch (act) {
+    case MH_ACT_NONE: MH_LAUNCH((split_gemm_kernel<T, MH_ACT_NONE>), grid, block, 0, s, g); break;
+    case MH_ACT_TANH: MH_LAUNCH((split_gemm_kernel<T, MH_ACT_TANH>), grid, block, 0, s, g); break;
+    case MH_ACT_GELU_ERF: MH_LAUNCH((split_gemm_kernel<T, MH_ACT_GELU_ERF>), grid, block, 0, s, g); break;
+    default: mh_set_error("split_gemm: unsupported activation %d", act); return MH_ERR_UNSUPPORTED;
+  }
+  MH_CHECK_LAUNCH();
+  return MH_OK;
+}
+
+// ------------------------------------------------------------------------------------------ attention
+// Unmasked self-attention (HF BertSelfAttention from network.py:151) on split operands, flash style: one workgroup = 4 waves = 128
+// queries of one (batch, head), each wave 32 queries, keys in tiles of 64 - the geometry and LDS images of attn_bf16_kernel
+// (csrc/attention.hip), every fragment once for hi and once for lo:
+//   S^T  = K_hi Q_lo^T + K_lo Q_hi^T + K_hi Q_hi^T        (32x32x16, the query on the lane)
+//   P    = exp2((S - max) scale log2 e) in fp32, split into P_hi + P_lo in registers (no LDS round trip: the accumulator IS the B operand)
+//   O^T += V^T_hi P_lo^T + V^T_lo P_hi^T + V^T_hi P_hi^T
+// q / k: split row-major [2][tokens][ldq] (q at column head dh, k at column koff + head dh; lo part qk_part elements after hi);
+// vt: split row-major [2][H][ldv] (the transposed V projection: row head dh + d, column token); ctx: split panels [2][H/32][ld_ctx][32].
+template <typename T, int DH>
+__global__ __launch_bounds__(256) void split_attn_kernel(const T* __restrict__ QK, int64_t ldq, int koff, int64_t qk_part, const T* __restrict__ VT,
+                                                         int64_t ldv, int64_t vt_part, T* __restrict__ ctx, int64_t ld_ctx, int H, int L, int nh,
+                                                         float scale_log2e) {
+  typedef typename Sp<T>::x8 x8;
+  typedef typename Sp<T>::x4 x4;
+  constexpr int CH = DH / 8;            // 16-B chunks per K row
+  constexpr int RPB = 128 / DH;         // K rows per 256-B bank row
+  constexpr int KROWB = DH * 2;
+  constexpr int KT_BYTES = 64 * KROWB, VT_BYTES = DH * 128, PART = KT_BYTES + VT_BYTES, BUF = 2 * PART;
+  constexpr int KS = DH / 16;           // k-steps of QK^T
+  constexpr int DT = (DH + 31) / 32;    // 32-row d tiles of O^T (DH 16: half a tile, the upper rows are zero)
+  constexpr int KCH = (64 * CH + 255) / 256;   // K chunks per thread
+  constexpr int VCH = (DH * 8 + 255) / 256;    // V^T 16-B chunks per thread
+  __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = lane >> 5, lq = lane & 31;
+  const int bh = blockIdx.y, b = bh / nh, head = bh % nh;
+  const int q0 = blockIdx.x * 128 + wave * 32;
+  const T* Qb[2] = {QK + (int64_t)b * L * ldq + head * DH, QK + qk_part + (int64_t)b * L * ldq + head * DH};
+  const T* Kb[2] = {Qb[0] + koff, Qb[1] + koff};
+  const T* Vb[2] = {VT + (int64_t)head * DH * ldv + (int64_t)b * L, VT + vt_part + (int64_t)head * DH * ldv + (int64_t)b * L};
+
+  x8 qf[2][KS];   // [part][k-step]: lane holds Q[q0 + lq][16 ks + 8 h .. + 8]
+  {
+    int qr = q0 + lq; if (qr >= L) qr = L - 1;
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) qf[p][ks] = *reinterpret_cast<const x8*>(Qb[p] + (int64_t)qr * ldq + 16 * ks + 8 * h);
+  }
+  f32x16 o[DT];
+#pragma unroll
+  for (int i = 0; i < DT; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+
+  f32x4 stK[2][KCH], stV[2][VCH];
+  const int ntiles = (L + 63) / 64;
+  auto issue = [&](int t) {
+    const int k0 = t * 64;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+#pragma unroll
+      for (int j = 0; j < KCH; ++j) {
+        const int qd = tid + 256 * j;
+        if (qd < 64 * CH) {
+          const int row = qd / CH, c = qd % CH;
+          int kr = k0 + row; if (kr >= L) kr = L - 1;
+          stK[p][j] = *reinterpret_cast<const f32x4*>(Kb[p] + (int64_t)kr * ldq + c * 8);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < VCH; ++j) {
+        const int qd = tid + 256 * j, d = qd >> 3, c = qd & 7;
+        const int key = k0 + c * 8;
+        if (d < DH && key < L) stV[p][j] = *reinterpret_cast<const f32x4*>(Vb[p] + (int64_t)d * ldv + key);   // (L % 8 == 0)
+        else stV[p][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+  };
+  auto commit = [&](int buf) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      char* kb = smem + buf * BUF + p * PART;
+      char* vb = kb + KT_BYTES;
+#pragma unroll
+      for (int j = 0; j < KCH; ++j) {
+        const int qd = tid + 256 * j;
+        if (qd < 64 * CH) {
+          const int row = qd / CH, c = qd % CH;
+          *reinterpret_cast<f32x4*>(kb + row * KROWB + ((c ^ ((row / RPB) & (CH - 1))) << 4)) = stK[p][j];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < VCH; ++j) {
+        const int qd = tid + 256 * j, d = qd >> 3, c = qd & 7;
+        if (d < DH) {
+          const int sblk = c >> 1, sw = (d >> 1) & 7, half = (c & 1) * 8;
+          // keys 8c .. 8c+3 -> chunk 2 sblk, keys 8c+4 .. 8c+7 -> chunk 2 sblk + 1: the key order of the P fragment's registers
+          f32x2 lo = {stV[p][j][0], stV[p][j][1]}, hi = {stV[p][j][2], stV[p][j][3]};
+          *reinterpret_cast<f32x2*>(vb + d * 128 + (((2 * sblk) ^ sw) << 4) + half) = lo;
+          *reinterpret_cast<f32x2*>(vb + d * 128 + (((2 * sblk + 1) ^ sw) << 4) + half) = hi;
+        }
+      }
+    }
+  };
+
+  issue(0);
+  commit(0);
+  __syncthreads();
+  for (int t = 0; t < ntiles; ++t) {
+    const int cur = t & 1;
+    if (t + 1 < ntiles) issue(t + 1);
+    const char* kb0 = smem + cur * BUF;           // hi part; lo part PART bytes further
+    const char* vb0 = kb0 + KT_BYTES;
+    // ---- S^T tiles: [2 x 32 keys][32 queries]
+    f32x16 s[2];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
+      const int row = kt * 32 + lq;
+      const int sw = (row / RPB) & (CH - 1);
+      x8 kh[KS], kl[KS];
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        kh[ks] = *reinterpret_cast<const x8*>(kb0 + row * KROWB + (((2 * ks + h) ^ sw) << 4));
+        kl[ks] = *reinterpret_cast<const x8*>(kb0 + PART + row * KROWB + (((2 * ks + h) ^ sw) << 4));
+      }
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) s[kt] = Sp<T>::mma32(kh[ks], qf[1][ks], s[kt]);
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) s[kt] = Sp<T>::mma32(kl[ks], qf[0][ks], s[kt]);
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) s[kt] = Sp<T>::mma32(kh[ks], qf[0][ks], s[kt]);
+    }
+    // ---- online softmax; register r of tile kt is key t*64 + kt*32 + (r&3) + 8(r>>2) + 4h
+    const int k0 = t * 64;
+    if (k0 + 64 > L) {
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (k0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h >= L) s[kt][r] = -INFINITY;
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kt][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = exp2f((m_run - m_new) * scale_log2e);
+    const float mb = m_new * scale_log2e;
+    float psum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float p = exp2f(s[kt][r] * scale_log2e - mb);
+        s[kt][r] = p;
+        psum += p;
+      }
+    l_run = l_run * alpha + psum;
+    m_run = m_new;
+#pragma unroll
+    for (int i = 0; i < DT; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+    // ---- O^T += V^T P^T : k-step sp = 2kt + s2 takes registers 8*s2 .. 8*s2+7 of s[kt]
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        x8 ph, pl;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float p = s[kt][8 * s2 + j];
+          ph[j] = (T)p;
+          pl[j] = (T)(p - (float)ph[j]);
+        }
+        const int sp = 2 * kt + s2;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+          const int d = dt * 32 + lq;
+          x8 vh, vl;
+          if (DH % 32 == 0 || d < DH) {
+            vh = *reinterpret_cast<const x8*>(vb0 + d * 128 + (((2 * sp + h) ^ ((d >> 1) & 7)) << 4));
+            vl = *reinterpret_cast<const x8*>(vb0 + PART + d * 128 + (((2 * sp + h) ^ ((d >> 1) & 7)) << 4));
+          } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { vh[j] = (T)0.f; vl[j] = (T)0.f; }
+          }
+          o[dt] = Sp<T>::mma32(vh, pl, o[dt]);
+          o[dt] = Sp<T>::mma32(vl, ph, o[dt]);
+          o[dt] = Sp<T>::mma32(vh, ph, o[dt]);
+        }
+      }
+    if (t + 1 < ntiles) commit(cur ^ 1);
+    __syncthreads();
+  }
+  // ---- normalise and store: lane holds query q0+lq, d = dt*32 + 8*(r>>2) + 4h + (r&3)
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = 1.0f / l_tot;
+  const int qr = q0 + lq;
+  if (qr < L) {
+    const int64_t tok = (int64_t)b * L + qr;
+    const int64_t c_part = (int64_t)(H / 32) * ld_ctx * 32;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const int d = dt * 32 + 8 * rg + 4 * h;
+        if (DH % 32 != 0 && d >= DH) continue;
+        const int col = head * DH + d;
+        float v[4];
+        T hv[4], lv[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = o[dt][rg * 4 + e] * inv;
+        split<T, 4>(v, hv, lv);
+        x4 h4, l4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { h4[e] = hv[e]; l4[e] = lv[e]; }
+        T* dst = ctx + ((int64_t)(col >> 5) * ld_ctx + tok) * 32 + (col & 31);
+        *reinterpret_cast<x4*>(dst) = h4;
+        *reinterpret_cast<x4*>(dst + c_part) = l4;
+      }
+  }
+}
+
+template <typename T>
+int launch_attn(const void* qk, int64_t ldq, int koff, int64_t qk_part, const void* vt, int64_t ldv, int64_t vt_part, void* ctx, int64_t ld_ctx, int B, int L,
+                int nh, int dh, float scale, hipStream_t s) {
+  const dim3 grid((unsigned)((L + 127) / 128), (unsigned)(B * nh)), block(256);
+  const float sl2 = scale * 1.4426950408889634f;
+  const int H = nh * dh;
+  mh_prof_note("split attention B=%d L=%d nh=%d dh=%d", B, L, nh, dh);
+  switch (dh) {
+    case 16: MH_LAUNCH((split_attn_kernel<T, 16>), grid, block, 0, s, (const T*)qk, ldq, koff, qk_part, (const T*)vt, ldv, vt_part, (T*)ctx, ld_ctx, H, L, nh, sl2); break;
+    case 32: MH_LAUNCH((split_attn_kernel<T, 32>), grid, block, 0, s, (const T*)qk, ldq, koff, qk_part, (const T*)vt, ldv, vt_part, (T*)ctx, ld_ctx, H, L, nh, sl2); break;
+    case 64: MH_LAUNCH((split_attn_kernel<T, 64>), grid, block, 0, s, (const T*)qk, ldq, koff, qk_part, (const T*)vt, ldv, vt_part, (T*)ctx, ld_ctx, H, L, nh, sl2); break;
+    default: mh_set_error("split_attention: head dim %d not in {16, 32, 64}", dh); return MH_ERR_UNSUPPORTED;
+  }
+  MH_CHECK_LAUNCH();
+  return MH_OK;
+}
+
+}  // namespace
+
+#define SP_DISPATCH(dtype, CALL_BF16, CALL_F16)                                                   \
+  do {                                                                                            \
+    if ((dtype) == MH_BF16X3) return CALL_BF16;                                                   \
+    if ((dtype) == MH_F16X3) return CALL_F16;                                                     \
+    mh_set_error("split kernels: dtype %d is neither MH_BF16X3 nor MH_F16X3", (int)(dtype));      \
+    return MH_ERR_INVALID;                                                                        \
+  } while (0)
+
+namespace {
+template <typename T>
+int pack_impl(const float* x, int64_t ldx, void* out, int64_t ld, int64_t rows, int cols, int kpad, hipStream_t s) {
+  const dim3 grid((unsigned)((rows + 63) / 64), (unsigned)(kpad / 32)), block(256);
+  MH_LAUNCH((split_pack_kernel<T>), grid, block, 0, s, x, ldx, (T*)out, ld, rows, cols, kpad);
+  MH_CHECK_LAUNCH();
+  return MH_OK;
+}
+template <typename T>
+int join_impl(const void* in, int64_t ld, float* out, int64_t ldo, int64_t rows, int cols, int cpad, hipStream_t s) {
+  const dim3 grid((unsigned)((rows + 63) / 64), (unsigned)(cpad / 32)), block(256);
+  MH_LAUNCH((split_join_kernel<T>), grid, block, 0, s, (const T*)in, ld, cpad / 32, out, ldo, rows, cols);
+  MH_CHECK_LAUNCH();
+  return MH_OK;
+}
+template <typename T>
+int ln_impl(const float* x, int64_t ldx, const float* pos, const float* emb_t, const int32_t* emb_row, const float* gamma, const float* beta, void* out,
+            int64_t ld, int64_t rows, int L, int H, float eps, hipStream_t s) {
+  const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+  if (pos) MH_LAUNCH((split_ln_kernel<T, true>), grid, block, 0, s, x, ldx, pos, emb_t, emb_row, gamma, beta, (T*)out, ld, rows, L, H, eps);
+  else MH_LAUNCH((split_ln_kernel<T, false>), grid, block, 0, s, x, ldx, pos, emb_t, emb_row, gamma, beta, (T*)out, ld, rows, L, H, eps);
+  MH_CHECK_LAUNCH();
+  return MH_OK;
+}
+}  // namespace
+
+extern "C" int mh_split_supported(int dtype) { return dtype == MH_BF16X3 || dtype == MH_F16X3; }
+
+extern "C" int mh_split_pack(const float* x, int64_t ldx, void* out, int64_t ld_rows, int64_t rows, int cols, int kpad, int dtype, mh_stream_t stream) {
+  MH_CHECK_ARG(x && out && rows > 0 && cols > 0 && kpad >= cols && kpad % 32 == 0 && ld_rows >= rows && ldx >= cols, "split_pack: bad arguments");
+  SP_DISPATCH(dtype, pack_impl<bf16>(x, ldx, out, ld_rows, rows, cols, kpad, (hipStream_t)stream),
+              pack_impl<f16>(x, ldx, out, ld_rows, rows, cols, kpad, (hipStream_t)stream));
+}
+
+extern "C" int mh_split_join(const void* in, int64_t ld_rows, float* out, int64_t ldo, int64_t rows, int cols, int cpad, int dtype, mh_stream_t stream) {
+  MH_CHECK_ARG(in && out && rows > 0 && cols > 0 && cpad >= cols && cpad % 32 == 0 && ld_rows >= rows && ldo >= cols, "split_join: bad arguments");
+  SP_DISPATCH(dtype, join_impl<bf16>(in, ld_rows, out, ldo, rows, cols, cpad, (hipStream_t)stream),
+              join_impl<f16>(in, ld_rows, out, ldo, rows, cols, cpad, (hipStream_t)stream));
+}
+
+extern "C" int mh_split_layernorm(const float* x, int64_t ldx, const float* pos, const float* emb_t, const int32_t* emb_row, const float* gamma,
+                                  const float* beta, void* out, int64_t ld_rows, int64_t rows, int L, int H, float eps, int dtype, mh_stream_t stream) {
+  MH_CHECK_ARG(x && gamma && beta && out && rows > 0 && H % 32 == 0 && H <= 64 * 8 * LN_MAXCH && ldx >= H && ldx % 4 == 0 && ld_rows >= rows,
+               "split_layernorm: bad arguments (H %% 32 == 0, H <= 2048)");
+  MH_CHECK_ARG(!pos || (emb_t && L > 0 && rows % L == 0), "split_layernorm: position / time rows need emb_t and L | rows");
+  SP_DISPATCH(dtype, ln_impl<bf16>(x, ldx, pos, emb_t, emb_row, gamma, beta, out, ld_rows, rows, L, H, eps, (hipStream_t)stream),
+              ln_impl<f16>(x, ldx, pos, emb_t, emb_row, gamma, beta, out, ld_rows, rows, L, H, eps, (hipStream_t)stream));
+}
+
+extern "C" int mh_split_gemm(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, int bias_rows, const void* residual, int64_t ldr,
+                             void* out, int64_t ldo, int out_mode, int64_t out_part, int64_t M, int N, int K, int act, int dtype, mh_stream_t stream) {
+  MH_CHECK_ARG(A && W && out && M > 0 && N > 0 && K > 0 && K % 32 == 0 && lda >= M && ldw >= N, "split_gemm: bad operands (K %% 32 == 0, ld >= rows)");
+  MH_CHECK_ARG(out_mode >= 0 && out_mode <= 2, "split_gemm: out_mode %d not in 0..2", out_mode);
+  MH_CHECK_ARG(out_mode == 2 ? (ldo >= N && ldo % 4 == 0) : (N % 8 == 0 && (out_mode == 0 ? (N % 32 == 0 && ldo >= M) : (ldo >= N && ldo % 8 == 0 && out_part % 8 == 0))),
+               "split_gemm: output shape / stride not supported by mode %d (N=%d ldo=%lld)", out_mode, N, (long long)ldo);
+  MH_CHECK_ARG(!residual || (N % 32 == 0 && ldr >= M), "split_gemm: the residual is a split panel matrix [2][N/32][ldr][32]");
+  SpGemmArgs g{A, lda, W, ldw, bias, bias_rows, residual, ldr, out, ldo, out_mode, out_part, M, N, K};
+  SP_DISPATCH(dtype, launch_gemm<bf16>(g, act, (hipStream_t)stream), launch_gemm<f16>(g, act, (hipStream_t)stream));
+}
+
+extern "C" int mh_split_attention(const void* qk, int64_t ld_qk, int k_offset, int64_t qk_part, const void* vt, int64_t ld_vt, int64_t vt_part, void* ctx,
+                                  int64_t ld_ctx, int B, int L, int nh, int dh, float scale, int dtype, mh_stream_t stream) {
+  MH_CHECK_ARG(qk && vt && ctx && B > 0 && L > 0 && L % 8 == 0 && nh > 0 && ld_qk % 8 == 0 && k_offset % 8 == 0 && qk_part % 8 == 0 && ld_vt % 8 == 0 &&
+                   vt_part % 8 == 0 && (nh * dh) % 32 == 0 && ld_ctx >= (int64_t)B * L && (int64_t)B * nh <= 65535,
+               "split_attention: bad arguments (L %% 8 == 0, 16-byte aligned strides)");
+  SP_DISPATCH(dtype, launch_attn<bf16>(qk, ld_qk, k_offset, qk_part, vt, ld_vt, vt_part, ctx, ld_ctx, B, L, nh, dh, scale, (hipStream_t)stream),
+              launch_attn<f16>(qk, ld_qk, k_offset, qk_part, vt, ld_vt, vt_part, ctx, ld_ctx, B, L, nh, dh, scale, (hipStream_t)stream));
+}

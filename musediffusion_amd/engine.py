@@ -27,6 +27,7 @@ class DenoiserEngine:
         self.cfg = dict(cfg)
         self.dtype = ops.dtype_code(dtype)
         self.device = torch.device(device)
+        self.split = self.dtype in ops.SPLIT_DTYPES      # split precision: weights as hi + lo 16-bit panels, 4 bytes per element like fp32
         self.es = 2 if self.dtype == MH_BF16 else 4
         c = self.cfg
         c["E_pad"], c["Tt_pad"], c["T4_pad"] = ops.pad64(c["E"]), ops.pad64(c["Tt"]), ops.pad64(4 * c["Tt"])
@@ -112,7 +113,12 @@ class DenoiserEngine:
         r, k = w.shape
         assert r == rows and k <= kpad, (name, w.shape, rows, kpad)
         dst = self.arena.data_ptr() + off
-        if self.cfg["panel"] and not name.startswith("w_t"):   # time MLP runs once per table build: row-major kernel
+        if self.split:       # (the time MLP stays fp32 row-major: it runs once per table build)
+            if name.startswith("w_t"):
+                check(lib().mh_cast_pad(ptr(w), k, dst, kpad, r, k, r, _lib.MH_F32, current_stream()), "mh_cast_pad")
+            else:
+                check(lib().mh_split_pack(ptr(w), k, dst, rows, r, k, kpad, self.dtype, current_stream()), "mh_split_pack")
+        elif self.cfg["panel"] and not name.startswith("w_t"):   # time MLP runs once per table build: row-major kernel
             check(lib().mh_pack_panel(ptr(w), k, dst, rows, r, k, kpad, current_stream()), "mh_pack_panel")
         else:
             check(lib().mh_cast_pad(ptr(w), k, dst, kpad, r, k, r, self.dtype, current_stream()), "mh_cast_pad")

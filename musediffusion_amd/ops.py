@@ -7,20 +7,27 @@ import ctypes as C
 
 import torch
 
-from ._lib import MH_BF16, MH_F32, check, current_stream, lib, ptr, require_device
+from ._lib import MH_BF16, MH_BF16X3, MH_F16X3, MH_F32, check, current_stream, lib, ptr, require_device
 
 TORCH_DTYPE = {MH_F32: torch.float32, MH_BF16: torch.bfloat16}
 ACT = {None: 0, "none": 0, "tanh": 1, "gelu": 2, "silu": 3}
 
 
+SPLIT_DTYPES = (MH_BF16X3, MH_F16X3)   # split precision (csrc/split.hip): the denoiser forward only
+
+
 def dtype_code(dtype):
-    if dtype in (MH_F32, MH_BF16):
+    if isinstance(dtype, int) and dtype in (MH_F32, MH_BF16, MH_BF16X3, MH_F16X3):
         return dtype
     if dtype in (torch.float32, "fp32", "f32", "float32"):
         return MH_F32
     if dtype in (torch.bfloat16, "bf16", "bfloat16"):
         return MH_BF16
-    raise ValueError("compute dtype must be fp32 or bf16, got %r" % (dtype,))
+    if dtype == "bf16x3":
+        return MH_BF16X3
+    if dtype == "f16x3":
+        return MH_F16X3
+    raise ValueError("compute dtype must be fp32, bf16, bf16x3 or f16x3, got %r" % (dtype,))
 
 
 def pad64(n):

@@ -794,6 +794,8 @@ def denoiser_forward_with_grad(model, x, timesteps):
     """TransformerNetModel.forward (network.py:131-158) with a gradient tape made of libmusehip kernels."""
     _lib.require_device(x)
     dt = ops.dtype_code(model.compute_dtype)
+    if dt in ops.SPLIT_DTYPES:
+        raise NotImplementedError("compute_dtype %r is a sampling mode (the forward without a tape): train in 'bf16' or 'fp32'" % (model.compute_dtype,))
     B, L, E = x.shape
     H = model.hidden_size
     dev = x.device

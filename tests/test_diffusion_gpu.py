@@ -202,6 +202,26 @@ def test_loops_bf16_token_agreement(tag):
         assert agree >= 0.99, (key, agree)
 
 
+@pytest.mark.parametrize("mode", ["bf16x3", "f16x3"])
+@pytest.mark.parametrize("tag", ["tiny", "same", "c1", "bb", "bb500", "c2s"])
+def test_split_precision_forward_and_loops_token_exact(tag, mode):
+    """The mode between "fast" and "exact" (csrc/split.hip: every value as hi + lo 16-bit parts, three matrix-pipe products per reference
+    product): the forward sits within a small multiple of the fp32 mode's distance from the reference's fwd_y, and the three golden loops
+    end on the reference's own tokens, bit for bit, in the captured (hipGraph) form - what the fp32 mode is held to."""
+    m, diff, model_emb, inp, c = build(tag, mode)
+    g = load_golden("model_%s.npz" % tag)
+    y = m(inp["fwd_x"].to(DEV), inp["fwd_t"].to(DEV))
+    err = maxerr(sub(y, tag), G(g, "fwd_y"))
+    print("%s %s forward vs the reference: max |d| %.2e" % (mode, tag, err))
+    assert err < (2e-3 if mode == "bf16x3" else 5e-4), err
+    res = run_loops(tag, m, diff, model_emb, inp, c, True)
+    for key in ("ddim50", "p12", "mod"):
+        tokens = m.argmax_tokens(res[key]).cpu()
+        ref_tokens = G(g, "loop_%s_tokens" % key).long()
+        assert torch.equal(tokens, ref_tokens), "%s %s: %d token mismatches" % (mode, key, int((tokens != ref_tokens).sum()))
+        assert maxerr(sub(res[key], tag), G(g, "loop_%s" % key)) < (2e-3 if mode == "bf16x3" else 5e-4), key
+
+
 def test_progressive_and_full_history_match_only_last():
     tag = "tiny"
     m, diff, model_emb, inp, c = build(tag)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""bf16 against fp32 compute mode over a long clamped loop at BASELINE config 2's full size (seq_len 512, batch 64, d_model 512,
+"""bf16 (and the split-precision modes bf16x3 / f16x3) against fp32 compute mode over a long clamped loop at BASELINE config 2's full size (seq_len 512, batch 64, d_model 512,
 12 layers): same weights, same start latent, same Philox noise (counter-based: a function of (seed, step, element), so both runs
 draw identical noise whatever their latents are).  Every step snaps pred_xstart to an embedding row, so one flipped rounding changes
 the trajectory: prints, per step, the share of positions whose rounded token agrees, the first step at which any token differs, and
@@ -18,7 +18,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
-def run(steps=200, batch=64, L=512, seed=105, dev="cuda", segment="first"):
+def run(steps=200, batch=64, L=512, seed=105, dev="cuda", segment="first", modes=("bf16",)):
     """segment "first": iterations t = 1999 .. 2000 - steps of the 2000-step loop from the reference's start latent (run/sample.py:185-190,
     `t_enc=steps`); "last": iterations t = steps - 1 .. 0 - the same process restricted to its last `steps` timesteps (SpacedDiffusion
     over the contiguous set {0 .. steps - 1}: identical betas), started from q_sample(x_start, steps - 1), where the tokens settle."""
@@ -28,13 +28,15 @@ def run(steps=200, batch=64, L=512, seed=105, dev="cuda", segment="first"):
     from musediffusion_amd.models.rounding import denoised_fn_round
     c = dict(L=L, B=batch, E=128, H=512, nL=12, nh=8, F=2048, V=729, Tt=128)
     models = {}
-    for cd in ("bf16", "fp32"):
+    modes = tuple(modes)
+    for cd in modes + ("fp32",):
         torch.manual_seed(0)
         m = TransformerNetModel(c["E"], c["E"], c["Tt"], c["V"], c["L"], dropout=0.1, bert_hidden=c["H"], bert_layers=c["nL"],
                                 bert_heads=c["nh"], bert_ffn=c["F"], compute_dtype=cd)
         models[cd] = m.eval().requires_grad_(False).to(dev)
-    models["fp32"].load_state_dict(models["bf16"].state_dict())
-    m = models["bf16"]
+    for cd in modes[1:] + ("fp32",):
+        models[cd].load_state_dict(models[modes[0]].state_dict())
+    m = models[modes[0]]
     use = space_timesteps(2000, [2000]) if segment == "first" else set(range(steps))
     diff = SpacedDiffusion(use_timesteps=use, betas=get_named_beta_schedule("sqrt", 2000), rescale_timesteps=True, predict_xstart=True)
     b = synthetic.generation_batch(c["B"], c["L"], seed=1)
@@ -58,23 +60,29 @@ def run(steps=200, batch=64, L=512, seed=105, dev="cuda", segment="first"):
         for out in gen:
             preds.append(out["pred_xstart"].clone())
         traj[cd] = (preds, out["sample"].clone())
-    agree = []
-    for a, bb in zip(traj["bf16"][0], traj["fp32"][0]):
-        same = (a == bb).all(dim=-1)                             # rounded rows equal <=> same token decision
-        agree.append(float(same[free].float().mean()))
-    first = next((k for k, v in enumerate(agree) if v < 1.0), None)
     tok = {cd: models["fp32"].argmax_tokens(traj[cd][1]) for cd in traj}
-    final = float((tok["bf16"] == tok["fp32"])[free].float().mean())
-    return {"segment": segment, "steps": steps, "batch": batch, "seq_len": L, "free_positions": int(free.sum()),
-            "first_step_with_a_differing_token": first, "agreement_step0": agree[0], "agreement_min": min(agree),
-            "agreement_last_step": agree[-1], "final_token_agreement": final,
-            "agreement_every_20_steps": [round(v, 4) for v in agree[::20]]}
+    recs = {}
+    for cd in modes:
+        agree = []
+        for a, bb in zip(traj[cd][0], traj["fp32"][0]):
+            same = (a == bb).all(dim=-1)                             # rounded rows equal <=> same token decision
+            agree.append(float(same[free].float().mean()))
+        first = next((k for k, v in enumerate(agree) if v < 1.0), None)
+        final = float((tok[cd] == tok["fp32"])[free].float().mean())
+        recs[cd] = {"mode": cd, "segment": segment, "steps": steps, "batch": batch, "seq_len": L, "free_positions": int(free.sum()),
+                    "first_step_with_a_differing_token": first, "agreement_step0": agree[0], "agreement_min": min(agree),
+                    "agreement_last_step": agree[-1], "final_token_agreement": final,
+                    "final_tokens_differing": int((tok[cd] != tok["fp32"])[free].sum()),
+                    "max_abs_diff_of_final_sample": float((traj[cd][1] - traj["fp32"][1]).abs().max()),
+                    "agreement_every_20_steps": [round(v, 4) for v in agree[::20]]}
+    return recs[modes[0]] if len(modes) == 1 else recs
 
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--modes", default="bf16", help="comma-separated compute modes compared with fp32: bf16, bf16x3, f16x3")
     a = ap.parse_args()
     for seg in ("first", "last"):
-        print(json.dumps(run(a.steps, a.batch, segment=seg)), flush=True)
+        print(json.dumps(run(a.steps, a.batch, segment=seg, modes=tuple(a.modes.split(",")))), flush=True)
