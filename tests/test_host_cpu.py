@@ -266,3 +266,14 @@ def test_pretrained_weight_helpers_of_the_reference(tmp_path):
     os.makedirs(base / "c")
     os.utime(base / "c", (time.time() + 1000, time.time() + 1000))
     assert ini.get_latest_model_path(str(base)) is None                # the newest directory holds no checkpoint
+
+
+def test_compute_dtype_names():
+    """the four compute modes by name / torch dtype / code; anything else is refused (no silent default)"""
+    from musediffusion_amd import _lib, ops
+    assert [ops.dtype_code(n) for n in ("fp32", "bf16", "bf16x3", "f16x3")] == [_lib.MH_F32, _lib.MH_BF16, _lib.MH_BF16X3, _lib.MH_F16X3]
+    assert ops.dtype_code(torch.float32) == _lib.MH_F32 and ops.dtype_code(torch.bfloat16) == _lib.MH_BF16 and ops.dtype_code(_lib.MH_F16X3) == _lib.MH_F16X3
+    assert ops.SPLIT_DTYPES == (_lib.MH_BF16X3, _lib.MH_F16X3)
+    for bad in ("fp16", "f16", 7, None, torch.float16):
+        with pytest.raises(ValueError):
+            ops.dtype_code(bad)
