@@ -50,7 +50,7 @@ def case_generate(rank, world, dev):
     from musediffusion_amd import sampling, sharding
     from oracle import sampling as osa
     tag = sys.argv[2] if len(sys.argv) > 2 else "tiny"
-    m, diff, c = build(tag, dev, rank, "fp32")
+    m, diff, c = build(tag, dev, rank, sys.argv[3] if len(sys.argv) > 3 else "fp32")   # (the split-precision modes ship their hi / lo arena the same way)
     sharding.broadcast_weights(m, src=0, packed=True)
     sums = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
     dist.all_gather(sums, torch.tensor([sharding.weights_checksum(m)], dtype=torch.int64, device=dev))

@@ -35,9 +35,9 @@ def run_ranks(case, *extra, world=2, timeout=600):
         assert "rank %d ok" % r in out
 
 
-@pytest.mark.parametrize("tag", ["tiny", "c1"])
-def test_two_rank_sharded_sampling_matches_golden_tokens(tag):
-    run_ranks("generate", tag)
+@pytest.mark.parametrize("tag,mode", [("tiny", "fp32"), ("c1", "fp32"), ("c1", "f16x3")])
+def test_two_rank_sharded_sampling_matches_golden_tokens(tag, mode):
+    run_ranks("generate", tag, mode)
 
 
 def test_two_rank_ddp_gradients_match_golden():
