@@ -3,8 +3,8 @@
 // Every operand value v is held as TWO 16-bit floats, hi = rn16(v) and lo = rn16(v - hi), and every product of the reference's fp32
 // arithmetic (models/network.py:131-158 run in fp32, models/diffusion.py:914) becomes three matrix-pipe products accumulated in fp32,
 //     x w  ~  x_lo w_hi + x_hi w_lo + x_hi w_hi          (x_lo w_lo, relative 2^-16 (bf16) / 2^-22 (f16), is dropped)
-// as ONE K loop of three times the depth: K-step kt of 3 K/32 reads part (kt < K/32 ? lo : hi) of A and part
-// (K/32 <= kt < 2 K/32 ? lo : hi) of W - the small terms first, the large one on top.  Measured on gfx950 (tools/micro/split_mfma.hip, K = 512,
+// in ONE K loop: per K-step of 32 two LDS-DMA stages, {A lo, W hi} and {A hi, W lo}, and three sets of MFMAs - the third product runs on the
+// A hi fragments of the second stage and the W hi fragments kept in registers from the first.  Measured on gfx950 (tools/micro/split_mfma.hip, K = 512,
 // max |error| / rms of the fp64 result): bf16 7.9e-3, f16 6.9e-4, bf16x3 1.2e-5, f16x3 2.5e-6, an fp32 fma chain 1.7e-6;
 // v_mfma_f32_*_f16 keeps subnormal inputs, so an f16 lo part below 2^-14 keeps an absolute precision of 2^-25.
 // f16 parts saturate at +-65504 (bf16 parts have fp32's range).
@@ -12,6 +12,8 @@
 // Layout: a "split panel" matrix [rows, C] is [2][C / 32][ld rows][32] 16-bit - the K32-panel layout of the bf16 path (DESIGN.md
 // section 3) once for hi and once for lo, so every LDS-DMA piece of the GEMM is still 16 rows x 64 contiguous bytes.
 // LayerNorm / residual sums / softmax statistics stay fp32; GELU is the exact erf form, tanh is tanhf (as in the fp32 mode).
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -27,6 +29,15 @@ template <> struct Sp<bf16> {
   static __device__ __forceinline__ f32x4 mma16(x8 a, x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
   static __device__ __forceinline__ f32x16 mma32(x8 a, x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
   static __device__ __forceinline__ float sat(float v) { return v; }
+  // two values -> packed hi parts and packed lo parts, by TRUNCATION (3 vector instructions per value): hi = the top 16 bits of v (its float
+  // value needs no conversion back), lo = the top 16 bits of the exact remainder; |v - hi - lo| <= 2^-15 |v|.  For values whose split is
+  // made per use (the attention probabilities); stored operands use the round-to-nearest split().
+  static __device__ __forceinline__ void split2(float p0, float p1, uint32_t& hi, uint32_t& lo) {
+    const uint32_t u0 = __builtin_bit_cast(uint32_t, p0), u1 = __builtin_bit_cast(uint32_t, p1);
+    hi = __builtin_amdgcn_perm(u1, u0, 0x07060302u);
+    const float d0 = p0 - __builtin_bit_cast(float, u0 & 0xFFFF0000u), d1 = p1 - __builtin_bit_cast(float, u1 & 0xFFFF0000u);
+    lo = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, d1), __builtin_bit_cast(uint32_t, d0), 0x07060302u);
+  }
 };
 template <> struct Sp<f16> {
   typedef f16x8 x8;
@@ -34,6 +45,13 @@ template <> struct Sp<f16> {
   static __device__ __forceinline__ f32x4 mma16(x8 a, x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
   static __device__ __forceinline__ f32x16 mma32(x8 a, x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
   static __device__ __forceinline__ float sat(float v) { return fminf(fmaxf(v, -65504.0f), 65504.0f); }
+  // (v_cvt_pkrtz_f16_f32: two values per instruction, rounded toward zero; the remainder is exact, so hi + lo keeps 21 bits)
+  static __device__ __forceinline__ void split2(float p0, float p1, uint32_t& hi, uint32_t& lo) {
+    const auto h = __builtin_amdgcn_cvt_pkrtz(p0, p1);
+    hi = __builtin_bit_cast(uint32_t, h);
+    const auto l = __builtin_amdgcn_cvt_pkrtz(p0 - (float)h[0], p1 - (float)h[1]);
+    lo = __builtin_bit_cast(uint32_t, l);
+  }
 };
 
 template <typename T, int N>
@@ -193,7 +211,7 @@ __global__ __launch_bounds__(256, 2) void split_gemm_kernel(const SpGemmArgs g) 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const int tiles_n = (g.N + GBN - 1) / GBN;
-  const int nk0 = g.K / 32, nk = 3 * nk0;
+  const int nk0 = g.K / 32, nk = 2 * nk0;   // two DMA stages per K-step of 32 (three products: see `issue`)
   const int fr = lane & 15, fg = lane >> 4;
   constexpr int GSW[4] = {0, 2, 3, 1};
   const int bid = sp_xcd_remap(blockIdx.x, gridDim.x);
@@ -214,10 +232,12 @@ __global__ __launch_bounds__(256, 2) void split_gemm_kernel(const SpGemmArgs g) 
     int rw = n0 + (wave * GPW + j) * 16 + rl; if (rw >= g.N) rw = g.N - 1;
     srcW[j] = reinterpret_cast<const char*>(g.W) + ((int64_t)rw * 32 + lc * 8) * 2;
   }
-  // stage kt: term t = kt / nk0 (0: A lo x W hi, 1: A hi x W lo, 2: A hi x W hi), K-step kt % nk0 of it
+  // Two DMA stages per K-step kk serve its three products: stage 2kk = {A lo, W hi}, stage 2kk+1 = {A hi, W lo}; the third product,
+  // A hi x W hi, runs in the odd stage on the A fragments it holds and the W hi fragments KEPT IN REGISTERS from the even stage - no
+  // third load of either tile, no third round of LDS reads, no third barrier (a third less LDS-DMA, the path that paces these tiles).
   auto issue = [&](int kt) {
-    const int t = (kt >= nk0) + (kt >= 2 * nk0), kk = kt - t * nk0;
-    const int64_t offA = (int64_t)((t == 0 ? nk0 : 0) + kk) * kstepA, offW = (int64_t)((t == 1 ? nk0 : 0) + kk) * kstepW;
+    const int kk = kt >> 1, odd = kt & 1;
+    const int64_t offA = (int64_t)((odd ? 0 : nk0) + kk) * kstepA, offW = (int64_t)((odd ? nk0 : 0) + kk) * kstepW;
     char* base = smem + (kt % GNST) * GSTAGE;
 #pragma unroll
     for (int j = 0; j < GPA; ++j)
@@ -246,35 +266,50 @@ __global__ __launch_bounds__(256, 2) void split_gemm_kernel(const SpGemmArgs g) 
   for (int st = 0; st < npro; ++st) issue(st);
   sp_wait_stages(npro - 1);
   __builtin_amdgcn_s_barrier();
-  x8 a[GTI], b[GTJ], bn[GTJ];
+  x8 a[GTI], b[GTJ], bn[GTJ], bh[GTJ];
 #pragma unroll
   for (int j = 0; j < GTJ; ++j) b[j] = *reinterpret_cast<const x8*>(smem + GBM * 64 + b_offs[j]);
 #pragma unroll
   for (int i = 0; i < GTI; ++i) a[i] = *reinterpret_cast<const x8*>(smem + a_off + i * (16 * 64));
-  for (int kt = 0; kt + 1 < nk; ++kt) {
+  // one stage: the MFMAs of stage kt (odd stages: both W parts) with the fragments of stage kt + 1 read underneath them
+  auto stage = [&](int kt, auto oddc) {
+    constexpr bool ODD = decltype(oddc)::value;
+    const bool next = kt + 1 < nk;
     const char* As = smem + ((kt + 1) % GNST) * GSTAGE;
     const char* Ws = As + GBM * 64;
-    const int younger = nk - 2 - kt < GNST - 2 ? nk - 2 - kt : GNST - 2;
-    sp_wait_stages(younger);
-    __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): this wave's reads of stage kt are done
-    __builtin_amdgcn_s_barrier();
-    if (kt + GNST < nk) issue(kt + GNST);   // slot kt % NST: every wave has read stage kt out of it
+    if (next) {
+      const int younger = nk - 2 - kt < GNST - 2 ? nk - 2 - kt : GNST - 2;
+      sp_wait_stages(younger);
+      __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): this wave's reads of stage kt are done
+      __builtin_amdgcn_s_barrier();
+      if (kt + GNST < nk) issue(kt + GNST);   // slot kt % NST: every wave has read stage kt out of it
 #pragma unroll
-    for (int j = 0; j < GTJ; ++j) bn[j] = *reinterpret_cast<const x8*>(Ws + b_offs[j]);
+      for (int j = 0; j < GTJ; ++j) bn[j] = *reinterpret_cast<const x8*>(Ws + b_offs[j]);
+    }
 #pragma unroll
     for (int i = 0; i < GTI; ++i) {
 #pragma unroll
       for (int j = 0; j < GTJ; ++j) acc[i][j] = Sp<T>::mma16(b[j], a[i], acc[i][j]);
-      a[i] = *reinterpret_cast<const x8*>(As + a_off + i * (16 * 64));
+      if constexpr (ODD) {
+#pragma unroll
+        for (int j = 0; j < GTJ; ++j) acc[i][j] = Sp<T>::mma16(bh[j], a[i], acc[i][j]);
+      }
+      if (next) a[i] = *reinterpret_cast<const x8*>(As + a_off + i * (16 * 64));
       __builtin_amdgcn_sched_barrier(0);
     }
+    if constexpr (!ODD) {
 #pragma unroll
-    for (int j = 0; j < GTJ; ++j) b[j] = bn[j];
+      for (int j = 0; j < GTJ; ++j) bh[j] = b[j];
+    }
+    if (next) {
+#pragma unroll
+      for (int j = 0; j < GTJ; ++j) b[j] = bn[j];
+    }
+  };
+  for (int kk = 0; kk < nk0; ++kk) {
+    stage(2 * kk, std::false_type{});
+    stage(2 * kk + 1, std::true_type{});
   }
-#pragma unroll
-  for (int i = 0; i < GTI; ++i)
-#pragma unroll
-    for (int j = 0; j < GTJ; ++j) acc[i][j] = Sp<T>::mma16(b[j], a[i], acc[i][j]);
 
   // ---- epilogue: lane's 8 consecutive columns of half qh: wcol0 + 32 qh + 8 fg, values acc[i][2 qh + (e >> 2)][e & 3]; row wrow0 + 16 i + fr
   const int wcol0 = n0 + wn * 64;
@@ -483,17 +518,17 @@ __global__ __launch_bounds__(256) void split_attn_kernel(const T* __restrict__ Q
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kt][r]);
+      for (int r = 0; r < 16; r += 2) mx = fmaxf(fmaxf(mx, s[kt][r]), s[kt][r + 1]);   // (v_max3_f32)
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     const float m_new = fmaxf(m_run, mx);
-    const float alpha = exp2f((m_run - m_new) * scale_log2e);
+    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * scale_log2e);
     const float mb = m_new * scale_log2e;
     float psum = 0.f;
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float p = exp2f(s[kt][r] * scale_log2e - mb);
+        const float p = __builtin_amdgcn_exp2f(fmaf(s[kt][r], scale_log2e, -mb));   // one v_fma + one v_exp per score (2^-inf = 0: masked keys)
         s[kt][r] = p;
         psum += p;
       }
@@ -503,18 +538,17 @@ __global__ __launch_bounds__(256) void split_attn_kernel(const T* __restrict__ Q
     for (int i = 0; i < DT; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
-    // ---- O^T += V^T P^T : k-step sp = 2kt + s2 takes registers 8*s2 .. 8*s2+7 of s[kt]
+    // ---- O^T += V^T P^T : k-step sp = 2kt + s2 takes registers 8*s2 .. 8*s2+7 of s[kt], split pairwise into packed hi / lo parts
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
-        x8 ph, pl;
+        uint32_t hw[4], lw[4];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const float p = s[kt][8 * s2 + j];
-          ph[j] = (T)p;
-          pl[j] = (T)(p - (float)ph[j]);
-        }
+        for (int j = 0; j < 4; ++j) Sp<T>::split2(s[kt][8 * s2 + 2 * j], s[kt][8 * s2 + 2 * j + 1], hw[j], lw[j]);
+        x8 ph, pl;
+        __builtin_memcpy(&ph, hw, 16);
+        __builtin_memcpy(&pl, lw, 16);
         const int sp = 2 * kt + s2;
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
