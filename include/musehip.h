@@ -501,6 +501,12 @@ int mh_split_layernorm(const float* x, int64_t ldx, const float* pos, const floa
  * act: MH_ACT_NONE / MH_ACT_TANH (tanhf) / MH_ACT_GELU_ERF (erff). */
 int mh_split_gemm(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, int bias_rows, const void* residual, int64_t ldr,
                   void* out, int64_t ldo, int out_mode, int64_t out_part, int64_t M, int N, int K, int act, int dtype, mh_stream_t stream);
+/* out = LayerNorm(A W^T + bias + residual) as split panels, in ONE kernel whose blocks own complete rows (HF BertSelfOutput / BertOutput:
+ * dense -> + input -> LayerNorm; replaces mh_split_gemm (fp32 rows out) + mh_split_layernorm).  N must satisfy ..._supported (512). */
+int mh_split_gemm_res_ln_supported(int N);
+int mh_split_gemm_res_ln(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, const void* residual, int64_t ldr,
+                         const float* gamma, const float* beta, float eps, void* out, int64_t ldo, int64_t M, int N, int K, int dtype,
+                         mh_stream_t stream);
 /* unmasked multi-head self-attention on split operands (HF BertSelfAttention from network.py:151): q / k split row-major
  * [2][B L][ld_qk] (q of head h at column h dh, k at column k_offset + h dh, lo part qk_part elements after hi), vt split row-major
  * [2][nh dh][ld_vt] (column = token; lo part vt_part elements after hi), ctx -> split panels [2][nh dh / 32][ld_ctx][32] */

@@ -101,6 +101,8 @@ SIGNATURES = {
     "mh_split_join": (INT, [VP, I64, VP, I64, I64, INT, INT, INT, VP]),
     "mh_split_layernorm": (INT, [VP, I64, VP, VP, VP, VP, VP, VP, I64, I64, INT, INT, F32, INT, VP]),
     "mh_split_gemm": (INT, [VP, I64, VP, I64, VP, INT, VP, I64, VP, I64, INT, I64, I64, INT, INT, INT, INT, VP]),
+    "mh_split_gemm_res_ln_supported": (INT, [INT]),
+    "mh_split_gemm_res_ln": (INT, [VP, I64, VP, I64, VP, VP, I64, VP, VP, F32, VP, I64, I64, INT, INT, INT, VP]),
     "mh_split_attention": (INT, [VP, I64, INT, I64, VP, I64, I64, VP, I64, INT, INT, INT, INT, F32, INT, VP]),
     "mh_row_sqnorm": (INT, [VP, VP, INT, INT, VP]),
     "mh_embed_gather": (INT, [VP, VP, VP, I64, INT, INT, VP]),

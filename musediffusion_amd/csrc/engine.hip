@@ -485,11 +485,20 @@ int denoiser_run(const mh_denoiser* m, const float* x, const float* emb_t, const
                               MH_ACT_NONE, dt, stream)))
         return rc;
       if ((rc = mh_split_attention(w.q, 2 * H, H, part_qk, w.vt, N, part_vt, w.buf0, N, B, L, m->nh, dh, scale, dt, stream))) return rc;
-      if ((rc = sgemm(w.buf0, lw.w_ao, H, lw.b_ao, w.bufX, w.buf1, H, 2, N, H, H, MH_ACT_NONE))) return rc;
-      if ((rc = mh_split_layernorm((const float*)w.buf1, H, nullptr, nullptr, nullptr, lw.ln1_g, lw.ln1_b, w.bufX1, N, N, L, H, m->ln_eps, dt, stream))) return rc;
+      const bool fuse = mh_split_gemm_res_ln_supported(H);   // dense + residual + LayerNorm in one kernel (complete rows per block)
+      if (fuse) {
+        if ((rc = mh_split_gemm_res_ln(w.buf0, N, lw.w_ao, H, lw.b_ao, w.bufX, N, lw.ln1_g, lw.ln1_b, m->ln_eps, w.bufX1, N, N, H, H, dt, stream))) return rc;
+      } else {
+        if ((rc = sgemm(w.buf0, lw.w_ao, H, lw.b_ao, w.bufX, w.buf1, H, 2, N, H, H, MH_ACT_NONE))) return rc;
+        if ((rc = mh_split_layernorm((const float*)w.buf1, H, nullptr, nullptr, nullptr, lw.ln1_g, lw.ln1_b, w.bufX1, N, N, L, H, m->ln_eps, dt, stream))) return rc;
+      }
       if ((rc = sgemm(w.bufX1, lw.w_ff1, F, lw.b_ff1, nullptr, w.ffn, N, 0, N, F, H, MH_ACT_GELU_ERF))) return rc;
-      if ((rc = sgemm(w.ffn, lw.w_ff2, H, lw.b_ff2, w.bufX1, w.buf1, H, 2, N, H, F, MH_ACT_NONE))) return rc;
-      if ((rc = mh_split_layernorm((const float*)w.buf1, H, nullptr, nullptr, nullptr, lw.ln2_g, lw.ln2_b, w.bufX, N, N, L, H, m->ln_eps, dt, stream))) return rc;
+      if (fuse) {   // (the output rows overwrite the layer's input rows: X is not read by this launch)
+        if ((rc = mh_split_gemm_res_ln(w.ffn, N, lw.w_ff2, H, lw.b_ff2, w.bufX1, N, lw.ln2_g, lw.ln2_b, m->ln_eps, w.bufX, N, N, H, F, dt, stream))) return rc;
+      } else {
+        if ((rc = sgemm(w.ffn, lw.w_ff2, H, lw.b_ff2, w.bufX1, w.buf1, H, 2, N, H, F, MH_ACT_NONE))) return rc;
+        if ((rc = mh_split_layernorm((const float*)w.buf1, H, nullptr, nullptr, nullptr, lw.ln2_g, lw.ln2_b, w.bufX, N, N, L, H, m->ln_eps, dt, stream))) return rc;
+      }
     }
     if (m->has_proj) {   // network.py:153-157
       if ((rc = sgemm(w.bufX, m->w_dn0, H, m->b_dn0, nullptr, w.buf0, N, 0, N, H, H, MH_ACT_TANH))) return rc;

@@ -361,6 +361,198 @@ __global__ __launch_bounds__(256, 2) void split_gemm_kernel(const SpGemmArgs g) 
   }
 }
 
+// ---- dense + residual + LayerNorm in one kernel (hidden size 512): out = LN(A W^T + bias + residual) as split panels.
+// A block owns 128 COMPLETE rows (128 x 512 tile, 8 waves as 2 x 4, 64 x 128 each, 3 stages of 40 KB, one block per CU - the bf16 path's
+// full-row tile); stages per K-step: {A hi, W lo} then {A lo, W hi}, the hi x hi product on the A hi fragments kept from the first.
+// Epilogue as csrc/gemm.hip EPI 3: two-pass statistics, in-lane -> the 4 lanes of a row -> the 4 column waves through LDS.
+constexpr int RBM = 128, RBN = 512, RNST = 3, RSTAGE = (RBM + RBN) * 64, RTI = 4, RTJ = 8, RPW = 4, RPIECES = 1 + RPW;
+__device__ __forceinline__ void sp_wait_stages_r(int stages) {
+  if (stages >= 2) sp_wait_vmcnt<2 * RPIECES>();
+  else if (stages == 1) sp_wait_vmcnt<RPIECES>();
+  else sp_wait_vmcnt<0>();
+}
+template <typename T>
+__global__ __launch_bounds__(512, 1) void split_gemm_ln_kernel(const SpGemmArgs g, const float* __restrict__ gamma, const float* __restrict__ beta, float eps) {
+  typedef typename Sp<T>::x8 x8;
+  __shared__ __attribute__((aligned(16))) char smem[RNST * RSTAGE + RBM * 4 * 4];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int nk0 = g.K / 32, nk = 2 * nk0;
+  const int fr = lane & 15, fg = lane >> 4;
+  constexpr int GSW[4] = {0, 2, 3, 1};
+  const int64_t m0 = (int64_t)blockIdx.x * RBM;
+  const int rl = lane >> 2, pc = lane & 3, lc = pc ^ GSW[(rl >> 2) & 3];
+  const int64_t kstepA = g.lda * 64, kstepW = g.ldw * 64;
+  int64_t ra = m0 + wave * 16 + rl; if (ra >= g.M) ra = g.M - 1;
+  const char* srcA = reinterpret_cast<const char*>(g.A) + (ra * 32 + lc * 8) * 2;
+  const char* srcW[RPW];
+#pragma unroll
+  for (int j = 0; j < RPW; ++j) srcW[j] = reinterpret_cast<const char*>(g.W) + ((int64_t)((wave * RPW + j) * 16 + rl) * 32 + lc * 8) * 2;
+  auto issue = [&](int kt) {
+    const int kk = kt >> 1, odd = kt & 1;
+    const int64_t offA = (int64_t)((odd ? nk0 : 0) + kk) * kstepA, offW = (int64_t)((odd ? 0 : nk0) + kk) * kstepW;
+    char* base = smem + (kt % RNST) * RSTAGE;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcA + offA),
+                                     (__attribute__((address_space(3))) void*)(base + wave * 1024), 16, 0, 0);
+#pragma unroll
+    for (int j = 0; j < RPW; ++j)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcW[j] + offW),
+                                       (__attribute__((address_space(3))) void*)(base + RBM * 64 + (wave * RPW + j) * 1024), 16, 0, 0);
+  };
+  const int frag_off = fr * 64 + ((fg ^ GSW[(fr >> 2) & 3]) << 4);
+  const int a_off = wm * (RTI * 16 * 64) + frag_off;
+  int b_offs[RTJ];
+#pragma unroll
+  for (int j = 0; j < RTJ; ++j) {
+    const int jj = j & 3;
+    const int row = (j >> 2) * 64 + 32 * (jj >> 1) + 8 * (fr >> 2) + 4 * (jj & 1) + (fr & 3);
+    b_offs[j] = wn * (RTJ * 16 * 64) + row * 64 + ((fg ^ GSW[(row >> 2) & 3]) << 4);
+  }
+  f32x4 acc[RTI][RTJ];
+#pragma unroll
+  for (int i = 0; i < RTI; ++i)
+#pragma unroll
+    for (int j = 0; j < RTJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int npro = nk < RNST ? nk : RNST;
+  for (int st = 0; st < npro; ++st) issue(st);
+  sp_wait_stages_r(npro - 1);
+  __builtin_amdgcn_s_barrier();
+  // (column-group-major MFMA order: a W fragment is re-read in place right after its last use, so only the four A fragments need a second
+  // register set for the next stage - the tile's 128 accumulators leave no room for more at two waves per SIMD)
+  x8 a[RTI], an[RTI], ah[RTI], b[RTJ];
+#pragma unroll
+  for (int j = 0; j < RTJ; ++j) b[j] = *reinterpret_cast<const x8*>(smem + RBM * 64 + b_offs[j]);
+#pragma unroll
+  for (int i = 0; i < RTI; ++i) a[i] = *reinterpret_cast<const x8*>(smem + a_off + i * (16 * 64));
+  auto stage = [&](int kt, auto oddc) {
+    constexpr bool ODD = decltype(oddc)::value;
+    const bool next = kt + 1 < nk;
+    const char* As = smem + ((kt + 1) % RNST) * RSTAGE;
+    const char* Ws = As + RBM * 64;
+    if (next) {
+      const int younger = nk - 2 - kt < RNST - 2 ? nk - 2 - kt : RNST - 2;
+      sp_wait_stages_r(younger);
+      __builtin_amdgcn_s_waitcnt(0xC07F);
+      __builtin_amdgcn_s_barrier();
+      if (kt + RNST < nk) issue(kt + RNST);
+#pragma unroll
+      for (int i = 0; i < RTI; ++i) an[i] = *reinterpret_cast<const x8*>(As + a_off + i * (16 * 64));
+    }
+#pragma unroll
+    for (int j = 0; j < RTJ; ++j) {
+#pragma unroll
+      for (int i = 0; i < RTI; ++i) acc[i][j] = Sp<T>::mma16(b[j], a[i], acc[i][j]);
+      if constexpr (ODD) {   // b = W hi: the hi x hi product on the A hi fragments of the even stage
+#pragma unroll
+        for (int i = 0; i < RTI; ++i) acc[i][j] = Sp<T>::mma16(b[j], ah[i], acc[i][j]);
+      }
+      if (next) b[j] = *reinterpret_cast<const x8*>(Ws + b_offs[j]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if constexpr (!ODD) {
+#pragma unroll
+      for (int i = 0; i < RTI; ++i) ah[i] = a[i];
+    }
+    if (next) {
+#pragma unroll
+      for (int i = 0; i < RTI; ++i) a[i] = an[i];
+    }
+  };
+  for (int kk = 0; kk < nk0; ++kk) {
+    stage(2 * kk, std::false_type{});
+    stage(2 * kk + 1, std::true_type{});
+  }
+  // ---- epilogue: v = acc + bias + residual; LayerNorm over the row; split-panel store
+  float* red = reinterpret_cast<float*>(smem + RNST * RSTAGE);   // [RBM][4 column waves]
+  const T* res = reinterpret_cast<const T*>(g.res);
+  const int64_t r_part = (int64_t)(RBN / 32) * g.ldr * 32, o_part = (int64_t)(RBN / 32) * g.ldo * 32;
+  const int wcol0 = wn * 128;
+  const int64_t wrow0 = m0 + wm * 64;
+  float rs[RTI];
+#pragma unroll
+  for (int i = 0; i < RTI; ++i) rs[i] = 0.f;
+#pragma unroll
+  for (int qh = 0; qh < RTJ / 2; ++qh) {
+    const int col = wcol0 + 32 * qh + 8 * fg;
+    float bv[8];
+    load8(g.bias + col, bv);
+#pragma unroll
+    for (int i = 0; i < RTI; ++i) {
+      int64_t row = wrow0 + 16 * i + fr; if (row >= g.M) row = g.M - 1;
+      const T* rp = res + ((int64_t)(col >> 5) * g.ldr + row) * 32 + (col & 31);
+      float rv[8];
+      load_split8<T>(rp, rp + r_part, rv);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float v = (acc[i][2 * qh + (e >> 2)][e & 3] + bv[e]) + rv[e];
+        acc[i][2 * qh + (e >> 2)][e & 3] = v;
+        rs[i] += v;
+      }
+    }
+  }
+  const float invN = 1.0f / (float)RBN;
+  float mean[RTI], rstd[RTI];
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+    for (int i = 0; i < RTI; ++i) {
+      float v = rs[i];
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      if (fg == 0) red[(wm * 64 + 16 * i + fr) * 4 + wn] = v;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int i = 0; i < RTI; ++i) {
+      const f32x4 t4 = *reinterpret_cast<const f32x4*>(red + (wm * 64 + 16 * i + fr) * 4);
+      const float t = ((t4[0] + t4[1]) + t4[2]) + t4[3];
+      if (pass == 0) {
+        mean[i] = t * invN;
+        float sq = 0.f;
+#pragma unroll
+        for (int j = 0; j < RTJ; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { const float d = acc[i][j][r] - mean[i]; sq += d * d; }
+        rs[i] = sq;
+      } else {
+        rstd[i] = 1.0f / sqrtf(t * invN + eps);
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();   // reads done before the second pass overwrites `red`
+  }
+  T* outT = reinterpret_cast<T*>(g.out);
+#pragma unroll
+  for (int qh = 0; qh < RTJ / 2; ++qh) {
+    const int col = wcol0 + 32 * qh + 8 * fg;
+    float gv[8], bt[8];
+    load8(gamma + col, gv);
+    load8(beta + col, bt);
+#pragma unroll
+    for (int i = 0; i < RTI; ++i) {
+      const int64_t row = wrow0 + 16 * i + fr;
+      if (row < g.M) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (acc[i][2 * qh + (e >> 2)][e & 3] - mean[i]) * rstd[i] * gv[e] + bt[e];
+        T* hp = outT + ((int64_t)(col >> 5) * g.ldo + row) * 32 + (col & 31);
+        store_split8<T>(hp, hp + o_part, v);
+      }
+    }
+  }
+}
+
+template <typename T>
+int launch_gemm_ln(const SpGemmArgs& g, const float* gamma, const float* beta, float eps, hipStream_t s) {
+  const dim3 grid((unsigned)((g.M + RBM - 1) / RBM)), block(512);
+  mh_prof_note("split tile=128x512 +LN M=%lld N=%d K=3x%d", (long long)g.M, g.N, g.K);
+  MH_LAUNCH((split_gemm_ln_kernel<T>), grid, block, 0, s, g, gamma, beta, eps);
+  MH_CHECK_LAUNCH();
+  return MH_OK;
+}
+
 template <typename T>
 int launch_gemm(const SpGemmArgs& g, int act, hipStream_t s) {
   const int64_t tiles = (int64_t)((g.M + GBM - 1) / GBM) * ((g.N + GBN - 1) / GBN);
@@ -683,6 +875,17 @@ extern "C" int mh_split_gemm(const void* A, int64_t lda, const void* W, int64_t 
   MH_CHECK_ARG(!residual || (N % 32 == 0 && ldr >= M), "split_gemm: the residual is a split panel matrix [2][N/32][ldr][32]");
   SpGemmArgs g{A, lda, W, ldw, bias, bias_rows, residual, ldr, out, ldo, out_mode, out_part, M, N, K};
   SP_DISPATCH(dtype, launch_gemm<bf16>(g, act, (hipStream_t)stream), launch_gemm<f16>(g, act, (hipStream_t)stream));
+}
+
+extern "C" int mh_split_gemm_res_ln_supported(int N) { return N == RBN; }
+extern "C" int mh_split_gemm_res_ln(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, const void* residual, int64_t ldr,
+                                    const float* gamma, const float* beta, float eps, void* out, int64_t ldo, int64_t M, int N, int K, int dtype,
+                                    mh_stream_t stream) {
+  MH_CHECK_ARG(A && W && bias && residual && gamma && beta && out && M > 0 && K > 0 && K % 32 == 0 && lda >= M && ldw >= N && ldr >= M && ldo >= M,
+               "split_gemm_res_ln: bad operands");
+  MH_CHECK_ARG(mh_split_gemm_res_ln_supported(N), "split_gemm_res_ln: the full-row tile is built for N = %d (got %d)", RBN, N);
+  SpGemmArgs g{A, lda, W, ldw, bias, 0, residual, ldr, out, ldo, 0, 0, M, N, K};
+  SP_DISPATCH(dtype, launch_gemm_ln<bf16>(g, gamma, beta, eps, (hipStream_t)stream), launch_gemm_ln<f16>(g, gamma, beta, eps, (hipStream_t)stream));
 }
 
 extern "C" int mh_split_attention(const void* qk, int64_t ld_qk, int k_offset, int64_t qk_part, const void* vt, int64_t ld_vt, int64_t vt_part, void* ctx,

@@ -156,3 +156,33 @@ def test_split_attention(dt, B, L, nh, dh):
     err = float((join(ctx, N, H, dt).double() - ref).abs().max())
     print("split attention L=%d dh=%d: max |err| %.2e" % (L, dh, err))
     assert err <= (5e-5 if dt == MH_BF16X3 else 6e-6), err
+
+
+@pytest.mark.parametrize("dt", MODES)
+@pytest.mark.parametrize("M,K", [(256, 512), (1000, 2048), (4096, 512)])
+def test_split_gemm_res_ln_fused(dt, M, K):
+    """LayerNorm(A W^T + b + residual) in one kernel (hidden size 512: a block owns complete rows) against float64, and against the two
+    launches it replaces (same tolerance class: the pre-LayerNorm rows never leave fp32 in either form)"""
+    N = 512
+    assert lib().mh_split_gemm_res_ln_supported(N) == 1 and lib().mh_split_gemm_res_ln_supported(768) == 0
+    A, W, b, R = rnd(M, K, seed=20), rnd(N, K, seed=21, scale=1 / math.sqrt(K)), rnd(N, seed=22, scale=0.3), rnd(M, N, seed=23)
+    g, bt = 1 + rnd(N, seed=24, scale=0.2), rnd(N, seed=25, scale=0.2)
+    pre = A.double() @ W.double().T + b.double() + R.double()
+    ref = torch.nn.functional.layer_norm(pre, (N,), g.double(), bt.double(), 1e-12)
+    Ap, Wp, Rp = pack(A, dt), pack(W, dt), pack(R, dt)
+    d = lambda t: t.to(DEV).contiguous()
+    bd, gd, btd = d(b), d(g), d(bt)
+    out = torch.zeros(2 * (N // 32) * M * 32, dtype=TDT[dt], device=DEV)
+    check(lib().mh_split_gemm_res_ln(Ap.data_ptr(), M, Wp.data_ptr(), N, bd.data_ptr(), Rp.data_ptr(), M, gd.data_ptr(), btd.data_ptr(), 1e-12, out.data_ptr(), M,
+                                     M, N, K, dt, current_stream()), "mh_split_gemm_res_ln")
+    got = join(out, M, N, dt).double()
+    err = float((got - ref).abs().max())
+    # the two launches it replaces
+    rows = torch.zeros(M, N, device=DEV)
+    check(lib().mh_split_gemm(Ap.data_ptr(), M, Wp.data_ptr(), N, bd.data_ptr(), 0, Rp.data_ptr(), M, rows.data_ptr(), N, 2, 0, M, N, K, 0, dt, current_stream()), "mh_split_gemm")
+    out2 = torch.zeros_like(out)
+    check(lib().mh_split_layernorm(rows.data_ptr(), N, None, None, None, gd.data_ptr(), btd.data_ptr(), out2.data_ptr(), M, M, 1, N, 1e-12, dt, current_stream()), "mh_split_layernorm")
+    err2 = float((join(out2, M, N, dt).double() - ref).abs().max())
+    print("fused dense + LN M=%d K=%d: max |err| %.2e (separate launches %.2e)" % (M, K, err, err2))
+    tol = (2e-4 if dt == MH_BF16X3 else 3e-5) * (2 if K > 1024 else 1)
+    assert err <= tol and err2 <= tol, (err, err2)
