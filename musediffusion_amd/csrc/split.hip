@@ -74,6 +74,19 @@ __device__ __forceinline__ void store_split8(T* hi_p, T* lo_p, const float (&v)[
   *reinterpret_cast<typename Sp<T>::x8*>(lo_p) = lv;
 }
 template <typename T>
+__device__ __forceinline__ void store_split8_nt(T* hi_p, T* lo_p, const float (&v)[8]) {
+  T h[8], l[8];
+  split<T, 8>(v, h, l);
+  typename Sp<T>::x8 hv, lv;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { hv[e] = h[e]; lv[e] = l[e]; }
+  f32x4 hr, lr;
+  __builtin_memcpy(&hr, &hv, 16);
+  __builtin_memcpy(&lr, &lv, 16);
+  __builtin_nontemporal_store(hr, reinterpret_cast<f32x4*>(hi_p));
+  __builtin_nontemporal_store(lr, reinterpret_cast<f32x4*>(lo_p));
+}
+template <typename T>
 __device__ __forceinline__ void load_split8(const T* hi_p, const T* lo_p, float (&v)[8]) {
   const typename Sp<T>::x8 hv = *reinterpret_cast<const typename Sp<T>::x8*>(hi_p), lv = *reinterpret_cast<const typename Sp<T>::x8*>(lo_p);
 #pragma unroll
@@ -185,6 +198,7 @@ struct SpGemmArgs {
   const void* W; int64_t ldw;
   const float* bias; int bias_rows;       // bias_rows: bias[row] instead of bias[col] (the transposed V projection)
   const void* res; int64_t ldr;           // residual: split panels [2][N/32][ldr][32]
+  int stream_out;                         // split-panel output larger than the Infinity Cache, read back by a later launch: non-temporal stores
   void* out; int64_t ldo; int out_mode;   // 0 split panels [2][N/32][ldo][32], 1 split row-major (lo part o_part elements after hi), 2 fp32 row-major
   int64_t o_part;
   int64_t M; int N, K;
@@ -274,7 +288,7 @@ __global__ __launch_bounds__(256, 2) void split_gemm_kernel(const SpGemmArgs g) 
   // one stage: the MFMAs of stage kt (odd stages: both W parts) with the fragments of stage kt + 1 read underneath them
   auto stage = [&](int kt, auto oddc) {
     constexpr bool ODD = decltype(oddc)::value;
-    const bool next = kt + 1 < nk;
+    const bool next = kt + 1 < nk;   // (a run-time flag on purpose: as a compile-time one the scheduler hoists the fragment reads and spills)
     const char* As = smem + ((kt + 1) % GNST) * GSTAGE;
     const char* Ws = As + GBM * 64;
     if (next) {
@@ -355,7 +369,8 @@ __global__ __launch_bounds__(256, 2) void split_gemm_kernel(const SpGemmArgs g) 
           for (int e = 0; e < nval; ++e) outF[row * g.ldo + col + e] = v[e];
       } else {
         T* hp = g.out_mode == 0 ? outT + ((int64_t)(col >> 5) * g.ldo + row) * 32 + (col & 31) : outT + row * g.ldo + col;
-        store_split8<T>(hp, hp + o_part, v);
+        if (g.stream_out) store_split8_nt<T>(hp, hp + o_part, v);
+        else store_split8<T>(hp, hp + o_part, v);
       }
     }
   }
@@ -402,13 +417,15 @@ __global__ __launch_bounds__(512, 1) void split_gemm_ln_kernel(const SpGemmArgs 
   };
   const int frag_off = fr * 64 + ((fg ^ GSW[(fr >> 2) & 3]) << 4);
   const int a_off = wm * (RTI * 16 * 64) + frag_off;
-  int b_offs[RTJ];
+  // W fragment j reads row (j>>2) 64 + 32 ((j&3)>>1) + 8 (fr>>2) + 4 (j&1) + (fr&3) of the wave's 128: the lane's part of the address (and the
+  // swizzle, which sees the row only through (2 (fr>>2) + (j&1)) & 3) takes two registers, the rest is a compile-time offset per j
+  int b_base[2];
 #pragma unroll
-  for (int j = 0; j < RTJ; ++j) {
-    const int jj = j & 3;
-    const int row = (j >> 2) * 64 + 32 * (jj >> 1) + 8 * (fr >> 2) + 4 * (jj & 1) + (fr & 3);
-    b_offs[j] = wn * (RTJ * 16 * 64) + row * 64 + ((fg ^ GSW[(row >> 2) & 3]) << 4);
+  for (int p = 0; p < 2; ++p) {
+    const int row = 8 * (fr >> 2) + 4 * p + (fr & 3);
+    b_base[p] = wn * (RTJ * 16 * 64) + row * 64 + ((fg ^ GSW[(row >> 2) & 3]) << 4);
   }
+  auto b_off = [&](int j) { return b_base[j & 1] + ((j >> 2) * 64 + 32 * ((j & 3) >> 1)) * 64; };
   f32x4 acc[RTI][RTJ];
 #pragma unroll
   for (int i = 0; i < RTI; ++i)
@@ -422,7 +439,7 @@ __global__ __launch_bounds__(512, 1) void split_gemm_ln_kernel(const SpGemmArgs 
   // register set for the next stage - the tile's 128 accumulators leave no room for more at two waves per SIMD)
   x8 a[RTI], an[RTI], ah[RTI], b[RTJ];
 #pragma unroll
-  for (int j = 0; j < RTJ; ++j) b[j] = *reinterpret_cast<const x8*>(smem + RBM * 64 + b_offs[j]);
+  for (int j = 0; j < RTJ; ++j) b[j] = *reinterpret_cast<const x8*>(smem + RBM * 64 + b_off(j));
 #pragma unroll
   for (int i = 0; i < RTI; ++i) a[i] = *reinterpret_cast<const x8*>(smem + a_off + i * (16 * 64));
   auto stage = [&](int kt, auto oddc) {
@@ -447,7 +464,7 @@ __global__ __launch_bounds__(512, 1) void split_gemm_ln_kernel(const SpGemmArgs 
 #pragma unroll
         for (int i = 0; i < RTI; ++i) acc[i][j] = Sp<T>::mma16(b[j], ah[i], acc[i][j]);
       }
-      if (next) b[j] = *reinterpret_cast<const x8*>(Ws + b_offs[j]);
+      if (next) b[j] = *reinterpret_cast<const x8*>(Ws + b_off(j));
       __builtin_amdgcn_sched_barrier(0);
     }
     if constexpr (!ODD) {
@@ -873,7 +890,8 @@ extern "C" int mh_split_gemm(const void* A, int64_t lda, const void* W, int64_t 
   MH_CHECK_ARG(out_mode == 2 ? (ldo >= N && ldo % 4 == 0) : (N % 8 == 0 && (out_mode == 0 ? (N % 32 == 0 && ldo >= M) : (ldo >= N && ldo % 8 == 0 && out_part % 8 == 0))),
                "split_gemm: output shape / stride not supported by mode %d (N=%d ldo=%lld)", out_mode, N, (long long)ldo);
   MH_CHECK_ARG(!residual || (N % 32 == 0 && ldr >= M), "split_gemm: the residual is a split panel matrix [2][N/32][ldr][32]");
-  SpGemmArgs g{A, lda, W, ldw, bias, bias_rows, residual, ldr, out, ldo, out_mode, out_part, M, N, K};
+  const int stream_out = out_mode == 0 && (int64_t)M * N * 4 > (192ll << 20);   // (config 2: FFN1's 268 MB intermediate)
+  SpGemmArgs g{A, lda, W, ldw, bias, bias_rows, residual, ldr, stream_out, out, ldo, out_mode, out_part, M, N, K};
   SP_DISPATCH(dtype, launch_gemm<bf16>(g, act, (hipStream_t)stream), launch_gemm<f16>(g, act, (hipStream_t)stream));
 }
 
@@ -884,7 +902,7 @@ extern "C" int mh_split_gemm_res_ln(const void* A, int64_t lda, const void* W, i
   MH_CHECK_ARG(A && W && bias && residual && gamma && beta && out && M > 0 && K > 0 && K % 32 == 0 && lda >= M && ldw >= N && ldr >= M && ldo >= M,
                "split_gemm_res_ln: bad operands");
   MH_CHECK_ARG(mh_split_gemm_res_ln_supported(N), "split_gemm_res_ln: the full-row tile is built for N = %d (got %d)", RBN, N);
-  SpGemmArgs g{A, lda, W, ldw, bias, 0, residual, ldr, out, ldo, 0, 0, M, N, K};
+  SpGemmArgs g{A, lda, W, ldw, bias, 0, residual, ldr, 0, out, ldo, 0, 0, M, N, K};
   SP_DISPATCH(dtype, launch_gemm_ln<bf16>(g, gamma, beta, eps, (hipStream_t)stream), launch_gemm_ln<f16>(g, gamma, beta, eps, (hipStream_t)stream));
 }
 
