@@ -147,6 +147,15 @@ def classify_launch(kernel, note, c, branches):
     N_tok = (c["B"] // branches) * c["L"]
     H, F, E, L = c["H"], c["F"], c["E"], c["L"]
     Ep = (E + 63) // 64 * 64
+    if "split_gemm" in kernel:      # split precision (csrc/split.hip): ALGORITHMIC flops 2 M N K; the kernel issues three times that on the matrix pipe
+        M, N, K, act = int(kv["M"]), int(kv["N"]), int(kv["K"].split("x")[-1]), int(kv.get("act", 0))
+        role = "dense+residual+LayerNorm" if "ln_kernel" in kernel else ("dense+GELU (FFN1)" if act == 2 else "dense+tanh" if act == 1 else "dense")
+        return "split_gemm<%s> %s [%d x %d x %d], 3 products per reference product" % (kv.get("tile", "?"), role, M, N, K), "mfma", 2.0 * M * N * K, "flop"
+    if "split_attn" in kernel:
+        bh, dh = int(kv.get("B", 0)) * int(kv.get("nh", 0)), int(kv.get("dh", 0))
+        return "split_attn_kernel<dh=%d> [B*nh=%d, L=%d], 3 products per reference product" % (dh, bh, L), "valu+mfma", 4.0 * L * dh * bh * L, "flop"
+    if "split_ln_kernel" in kernel:
+        return "split_ln_kernel (fp32 rows -> split panels)", "hbm", float(2 * N_tok * H * 4), "B"
     if "gemm_big_kernel" in kernel or "gemm_kernel<bf16" in kernel:
         M, N, K, epi, act = int(kv["M"]), int(kv["N"]), int(kv["K"]), int(kv["epi"]), int(kv["act"])
         role = {3: "dense+bias+residual+LayerNorm", 1: "QKV projection + head scatter"}.get(epi) or (
@@ -936,9 +945,10 @@ def main():
         }
         if not args.no_kernel_timing:
             out["roofline"], out["kernels"] = step_tables(loop, c, args, ms_per_step, total, PROF_STEPS)
-            iso_ms, iso_f, _, _ = time_dominant_kernel(c, args.dtype, device, reps=5, branches=int(loop.nsplit))
-            out["roofline"]["isolated"] = {"avg_launch_ms": round(iso_ms, 5), "achieved": round(iso_f / (iso_ms * 1e-3) / 1e12, 2),
-                                           "note": "secondary: the full-row GEMM + LayerNorm kernel alone in a loop on fresh operands"}
+            if args.dtype in ("bf16", "fp32"):
+                iso_ms, iso_f, _, _ = time_dominant_kernel(c, args.dtype, device, reps=5, branches=int(loop.nsplit))
+                out["roofline"]["isolated"] = {"avg_launch_ms": round(iso_ms, 5), "achieved": round(iso_f / (iso_ms * 1e-3) / 1e12, 2),
+                                               "note": "secondary: the full-row GEMM + LayerNorm kernel alone in a loop on fresh operands"}
         if not args.no_cpu_baseline and world == 1:     # the host baseline is a rank-0, N = 1 measurement
             out["cpu_baseline"] = cpu_baseline(c)
             out["cpu_baseline"]["value"] = round(out["cpu_baseline"]["value"], 5)
