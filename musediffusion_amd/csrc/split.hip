@@ -202,6 +202,7 @@ struct SpGemmArgs {
   void* out; int64_t ldo; int out_mode;   // 0 split panels [2][N/32][ldo][32], 1 split row-major (lo part o_part elements after hi), 2 fp32 row-major
   int64_t o_part;
   int64_t M; int N, K;
+  int ntiles;                             // persistent launch: output tiles walked by gridDim.x blocks
 };
 
 constexpr int GBM = 256, GBN = 128, GNST = 3, GSTAGE = (GBM + GBN) * 64, GTI = 8, GTJ = 4, GPA = 4, GPW = 2, GPIECES = GPA + GPW;
@@ -228,24 +229,23 @@ __global__ __launch_bounds__(256, 2) void split_gemm_kernel(const SpGemmArgs g) 
   const int nk0 = g.K / 32, nk = 2 * nk0;   // two DMA stages per K-step of 32 (three products: see `issue`)
   const int fr = lane & 15, fg = lane >> 4;
   constexpr int GSW[4] = {0, 2, 3, 1};
-  const int bid = sp_xcd_remap(blockIdx.x, gridDim.x);
-  const int64_t m0 = (int64_t)(bid / tiles_n) * GBM;
-  const int n0 = (bid % tiles_n) * GBN;
   // DMA coordinates: a piece = 16 rows x 64 B; lane i lands at row i / 4, physical chunk i % 4, which holds logical chunk pc ^ G[..]
   const int rl = lane >> 2, pc = lane & 3, lc = pc ^ GSW[(rl >> 2) & 3];
   const int64_t kstepA = g.lda * 64, kstepW = g.ldw * 64;
   const char* srcA[GPA];
   const char* srcW[GPW];
+  auto set_sources = [&](int64_t m0, int n0) {
 #pragma unroll
-  for (int j = 0; j < GPA; ++j) {
-    int64_t ra = m0 + (wave * GPA + j) * 16 + rl; if (ra >= g.M) ra = g.M - 1;
-    srcA[j] = reinterpret_cast<const char*>(g.A) + (ra * 32 + lc * 8) * 2;
-  }
+    for (int j = 0; j < GPA; ++j) {
+      int64_t ra = m0 + (wave * GPA + j) * 16 + rl; if (ra >= g.M) ra = g.M - 1;
+      srcA[j] = reinterpret_cast<const char*>(g.A) + (ra * 32 + lc * 8) * 2;
+    }
 #pragma unroll
-  for (int j = 0; j < GPW; ++j) {
-    int rw = n0 + (wave * GPW + j) * 16 + rl; if (rw >= g.N) rw = g.N - 1;
-    srcW[j] = reinterpret_cast<const char*>(g.W) + ((int64_t)rw * 32 + lc * 8) * 2;
-  }
+    for (int j = 0; j < GPW; ++j) {
+      int rw = n0 + (wave * GPW + j) * 16 + rl; if (rw >= g.N) rw = g.N - 1;
+      srcW[j] = reinterpret_cast<const char*>(g.W) + ((int64_t)rw * 32 + lc * 8) * 2;
+    }
+  };
   // Two DMA stages per K-step kk serve its three products: stage 2kk = {A lo, W hi}, stage 2kk+1 = {A hi, W lo}; the third product,
   // A hi x W hi, runs in the odd stage on the A fragments it holds and the W hi fragments KEPT IN REGISTERS from the even stage - no
   // third load of either tile, no third round of LDS reads, no third barrier (a third less LDS-DMA, the path that paces these tiles).
@@ -270,15 +270,26 @@ __global__ __launch_bounds__(256, 2) void split_gemm_kernel(const SpGemmArgs g) 
     const int row = 32 * (j >> 1) + 8 * (fr >> 2) + 4 * (j & 1) + (fr & 3);
     b_offs[j] = wn * (GTJ * 16 * 64) + row * 64 + ((fg ^ GSW[(row >> 2) & 3]) << 4);
   }
+  // Persistent: gridDim.x blocks (two per CU) walk the g.ntiles output tiles; a tile's first stages are put in flight BEFORE the previous
+  // tile's epilogue (the ring is idle then), so the pipeline fill of a 16-K-step tile hides behind the stores.
+  const int npro = nk < GNST ? nk : GNST;
+  bool pre = false;
+  for (int tile = blockIdx.x; tile < g.ntiles; tile += gridDim.x) {
+  const int bid = sp_xcd_remap(tile, g.ntiles);
+  const int64_t m0 = (int64_t)(bid / tiles_n) * GBM;
+  const int n0 = (bid % tiles_n) * GBN;
+  set_sources(m0, n0);   // (recomputed when prefetched: the pointers do not live across the epilogue)
   f32x4 acc[GTI][GTJ];
 #pragma unroll
   for (int i = 0; i < GTI; ++i)
 #pragma unroll
     for (int j = 0; j < GTJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  const int npro = nk < GNST ? nk : GNST;
-  for (int st = 0; st < npro; ++st) issue(st);
-  sp_wait_stages(npro - 1);
+  if (pre) {
+    sp_wait_vmcnt<0>();   // the prefetched stages and the previous epilogue's stores (one counter)
+  } else {
+    for (int st = 0; st < npro; ++st) issue(st);
+    sp_wait_stages(npro - 1);
+  }
   __builtin_amdgcn_s_barrier();
   x8 a[GTI], b[GTJ], bn[GTJ], bh[GTJ];
 #pragma unroll
@@ -328,6 +339,15 @@ __global__ __launch_bounds__(256, 2) void split_gemm_kernel(const SpGemmArgs g) 
   // ---- epilogue: lane's 8 consecutive columns of half qh: wcol0 + 32 qh + 8 fg, values acc[i][2 qh + (e >> 2)][e & 3]; row wrow0 + 16 i + fr
   const int wcol0 = n0 + wn * 64;
   const int64_t wrow0 = m0 + wm * 128;
+  pre = false;
+  if (tile + (int)gridDim.x < g.ntiles) {
+    const int nb = sp_xcd_remap(tile + (int)gridDim.x, g.ntiles);
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_s_barrier();       // every wave has read the last stages out of the ring
+    set_sources((int64_t)(nb / tiles_n) * GBM, (nb % tiles_n) * GBN);
+    for (int st = 0; st < npro; ++st) issue(st);
+    pre = true;
+  }
   T* outT = reinterpret_cast<T*>(g.out);
   float* outF = reinterpret_cast<float*>(g.out);
   const T* res = reinterpret_cast<const T*>(g.res);
@@ -374,6 +394,7 @@ __global__ __launch_bounds__(256, 2) void split_gemm_kernel(const SpGemmArgs g) 
       }
     }
   }
+  }   // persistent tile loop
 }
 
 // ---- dense + residual + LayerNorm in one kernel (hidden size 512): out = LN(A W^T + bias + residual) as split panels.
@@ -570,11 +591,23 @@ int launch_gemm_ln(const SpGemmArgs& g, const float* gamma, const float* beta, f
   return MH_OK;
 }
 
+inline int sp_device_cus() {
+  static int cus[MH_MAX_DEVICES] = {0};
+  const int dev = mh_current_device();
+  if (!cus[dev]) {
+    int n = 0;
+    cus[dev] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+  }
+  return cus[dev];
+}
 template <typename T>
-int launch_gemm(const SpGemmArgs& g, int act, hipStream_t s) {
-  const int64_t tiles = (int64_t)((g.M + GBM - 1) / GBM) * ((g.N + GBN - 1) / GBN);
-  MH_CHECK_ARG(tiles > 0 && tiles < (1ll << 31), "split_gemm: bad grid (M=%lld N=%d)", (long long)g.M, g.N);
-  const dim3 grid((unsigned)tiles), block(256);
+int launch_gemm(const SpGemmArgs& g0, int act, hipStream_t s) {
+  const int64_t tiles = (int64_t)((g0.M + GBM - 1) / GBM) * ((g0.N + GBN - 1) / GBN);
+  MH_CHECK_ARG(tiles > 0 && tiles < (1ll << 31), "split_gemm: bad grid (M=%lld N=%d)", (long long)g0.M, g0.N);
+  SpGemmArgs g = g0;
+  g.ntiles = (int)tiles;
+  const int64_t slots = 2 * (int64_t)sp_device_cus();
+  const dim3 grid((unsigned)(tiles < slots ? tiles : slots)), block(256);
   mh_prof_note("split tile=256x128 act=%d M=%lld N=%d K=3x%d out=%d", act, (long long)g.M, g.N, g.K, g.out_mode);
   switch (act) {
     case MH_ACT_NONE: MH_LAUNCH((split_gemm_kernel<T, MH_ACT_NONE>), grid, block, 0, s, g); break;
