@@ -186,3 +186,44 @@ def test_split_gemm_res_ln_fused(dt, M, K):
     print("fused dense + LN M=%d K=%d: max |err| %.2e (separate launches %.2e)" % (M, K, err, err2))
     tol = (2e-4 if dt == MH_BF16X3 else 3e-5) * (2 if K > 1024 else 1)
     assert err <= tol and err2 <= tol, (err, err2)
+
+
+@pytest.mark.parametrize("dt", MODES)
+def test_split_kernels_repeat_launches_are_bit_identical_under_load(dt):
+    """Race screen of the LDS-DMA rings (persistent blocks walking several tiles, the next tile's stages issued before the epilogue, W hi
+    fragments kept across two stages) and of the attention's double buffer: 60 launches of each kernel on the same operands while a second
+    stream keeps the chip busy - every launch must reproduce the first bit for bit."""
+    M, N, K, H = 8192, 2048, 512, 512
+    A, W, b = pack(rnd(M, K, seed=30), dt), pack(rnd(N, K, seed=31, scale=K ** -0.5), dt), rnd(N, seed=32).to(DEV)
+    W2, R = pack(rnd(H, N, seed=33, scale=N ** -0.5), dt), pack(rnd(M, H, seed=34), dt)
+    g, bt = torch.ones(H, device=DEV), torch.zeros(H, device=DEV)
+    T = TDT[dt]
+    out1 = torch.zeros(2 * (N // 32) * M * 32, dtype=T, device=DEV)
+    out2 = torch.zeros(2 * (H // 32) * M * 32, dtype=T, device=DEV)
+    B, L, nh, dh = 8, 512, 8, 64
+    Ntok = B * L
+    qk = (torch.randn(2, Ntok, 2 * H, generator=torch.Generator().manual_seed(35)) * 0.5).to(T).to(DEV)
+    vt = (torch.randn(2, H, Ntok, generator=torch.Generator().manual_seed(36)) * 0.5).to(T).to(DEV)
+    ctx = torch.zeros(2 * (H // 32) * Ntok * 32, dtype=T, device=DEV)
+    na, nb = torch.randn(4096, 4096, device=DEV, dtype=torch.bfloat16), torch.randn(4096, 4096, device=DEV, dtype=torch.bfloat16)
+    side = torch.cuda.Stream()
+
+    def run():
+        check(lib().mh_split_gemm(A.data_ptr(), M, W.data_ptr(), N, b.data_ptr(), 0, None, 0, out1.data_ptr(), M, 0, 0, M, N, K, 2, dt, current_stream()), "gemm")
+        check(lib().mh_split_gemm_res_ln(out1.data_ptr(), M, W2.data_ptr(), H, b.data_ptr(), R.data_ptr(), M, g.data_ptr(), bt.data_ptr(), 1e-12, out2.data_ptr(), M,
+                                         M, H, N, dt, current_stream()), "gemm_ln")
+        check(lib().mh_split_attention(qk.data_ptr(), 2 * H, H, Ntok * 2 * H, vt.data_ptr(), Ntok, H * Ntok, ctx.data_ptr(), Ntok, B, L, nh, dh, 0.125, dt,
+                                       current_stream()), "attention")
+    run()
+    torch.cuda.synchronize()
+    ref = (out1.clone(), out2.clone(), ctx.clone())
+    assert all(bool(torch.isfinite(t.float()).all()) for t in ref)
+    bad = 0
+    for rep in range(60):
+        with torch.cuda.stream(side):
+            na @ nb
+        out1.zero_(); out2.zero_(); ctx.zero_()
+        run()
+        torch.cuda.synchronize()
+        bad += int(not (torch.equal(out1, ref[0]) and torch.equal(out2, ref[1]) and torch.equal(ctx, ref[2])))
+    assert bad == 0, "%d of 60 repeated launches differ from the first" % bad
