@@ -1214,7 +1214,10 @@ int device_cus() {
   return cus;
 }
 
-MH_KNOB(int, g_plain_stores, 0);   // A/B: bit 0 QKV streaming instead of ordinary stores, bit 1 dense+GELU ordinary instead of streaming stores; bit 2: full-row tile without ping-pong; bits 3 / 4: 64-row full-row tile
+#ifndef MH_PLAIN_STORES_DEFAULT
+#define MH_PLAIN_STORES_DEFAULT 0
+#endif
+MH_KNOB(int, g_plain_stores, MH_PLAIN_STORES_DEFAULT);   // A/B: bit 0 QKV streaming instead of ordinary stores, bit 1 dense+GELU ordinary instead of streaming stores; bit 2: full-row tile without ping-pong; bits 3 / 4: 64-row full-row tile
 
 template <class C, int EPI>
 int launch_big(const GemmArgs& g0, hipStream_t s, int batch) {
