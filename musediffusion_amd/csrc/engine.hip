@@ -173,14 +173,22 @@ Workspace carve(const mh_denoiser* m, int B, int L, char* base) {
   size_t off = 0;
   auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += align256(bytes); return p; };
   w.xin = take(N * (size_t)m->E_pad * es);
-  w.buf0 = take(N * m->H * es);
   w.buf1 = take(N * m->H * es);
   w.bufX = take(N * m->H * es);
   w.bufX1 = take(N * m->H * es);
+  const size_t qkv0 = off;
   w.q = take(N * m->H * es);
   w.k = take(N * m->H * es);
   w.vt = take(N * m->H * es + 256);  // slack: the last V^T row may be over-read by one 16-B chunk
-  w.ffn = take(N * (size_t)m->F * es);
+  w.buf0 = take(N * m->H * es);      // (attention output; up / down projection intermediates)
+  // The FFN intermediate lives where q | k | V^T | attention output lived: all four are dead when FFN1 writes it and it is dead when the
+  // next layer's projections write them (one stream orders the launches).  A batch slice then touches 121 MB instead of 188 MB at
+  // config 2 - two slices' buffers fit the 256 MB Infinity Cache (MH_WS_ALIAS=0: separate buffers, A/B)
+#ifndef MH_WS_ALIAS
+#define MH_WS_ALIAS 1
+#endif
+  if (MH_WS_ALIAS && N * (size_t)m->F * es <= off - qkv0) w.ffn = base ? base + qkv0 : nullptr;   // (every path runs its launches in this order; F <= 4 H)
+  else w.ffn = take(N * (size_t)m->F * es);
   const size_t slots = (size_t)(m->H + 127) / 128;
   w.stats1 = (float*)take(N * slots * 2 * sizeof(float));
   w.stats2 = (float*)take(N * slots * 2 * sizeof(float));
