@@ -943,6 +943,11 @@ def main():
                        "step_tflops_achieved": round(flops / (ms_per_step * 1e-3) / 1e12, 2),
                        "sequences_steps_per_s": round(value * c["B"], 1)},
         }
+        run_secondary = world == 1 and args.workload == "c2" and args.dtype == "bf16" and not args.no_secondary and not args.no_graph
+        if run_secondary:
+            # right after the headline's timed region and BEFORE the eager per-launch profile below: measured after it, the bert-base-width
+            # loop runs 15 - 20 % slower than alone in a fresh process (117 against 138 steps/s on one box; the other entries do not move)
+            secondary = secondary_block(device)
         if not args.no_kernel_timing:
             out["roofline"], out["kernels"] = step_tables(loop, c, args, ms_per_step, total, PROF_STEPS)
             if args.dtype in ("bf16", "fp32"):
@@ -952,9 +957,8 @@ def main():
         if not args.no_cpu_baseline and world == 1:     # the host baseline is a rank-0, N = 1 measurement
             out["cpu_baseline"] = cpu_baseline(c)
             out["cpu_baseline"]["value"] = round(out["cpu_baseline"]["value"], 5)
-        if world == 1 and args.workload == "c2" and args.dtype == "bf16" and not args.no_secondary and not args.no_graph:
-            del loop
-            out["secondary"] = secondary_block(device)
+        if run_secondary:
+            out["secondary"] = secondary
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
