@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Which part of bench.py's kernel-timing phase makes a bert-base-width loop measured AFTER it read 15 - 20 % low?
-    python tools/debug/after_profile.py {none|iso|profile|alloc}"""
+    python tools/debug/after_profile.py {none|iso|profile|both|alloc}"""
 import os
 import sys
 
@@ -15,7 +15,7 @@ dev = torch.device("cuda:0")
 c2, bb = bench.WORKLOADS["c2"], bench.WORKLOADS["c2-bertbase"]
 if what == "iso":
     bench.time_dominant_kernel(c2, "bf16", dev, reps=5, branches=2)
-elif what == "profile":
+elif what in ("profile", "both"):
     model, diff = bench.build(c2, "bf16", dev, seed=0)
     diff.rng_mode, diff.rng_seed, diff.rng_stream, diff.use_graph = "philox", 105, 0, True
     loop = bench.make_loop(model, diff, c2, "p", dev, 0, 20)
@@ -27,6 +27,8 @@ elif what == "profile":
         rows, span = bench.profile_step(loop, c2, 5, 4, 3.6)
         loop.finish()
     del loop, model, diff
+    if what == "both":
+        bench.time_dominant_kernel(c2, "bf16", dev, reps=5, branches=2)
 elif what == "alloc":
     xs = [torch.empty(64 << 20, dtype=torch.uint8, device=dev) for _ in range(12)]
     del xs
