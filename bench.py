@@ -854,7 +854,8 @@ def main():
     ap.add_argument("--spread", type=int, default=None, help="A/B: 1 = LDS-DMA pieces of the 256x128 GEMMs issued between the MFMA rows (mh_gemm_set_spread)")
     ap.add_argument("--defer-ln", type=int, default=None, help="A/B: deferred LayerNorm 0 never / 1 where no fused epilogue exists (default) / 2 always")
     ap.add_argument("--no-stream-attn", action="store_true", help="A/B: LDS-resident attention instead of the streaming kernel")
-    ap.add_argument("--no-decouple", action="store_true", help="A/B: one graph per step with a fork / join of the batch slices instead of one free-running graph per slice (the default since round 4)")
+    ap.add_argument("--no-decouple", action="store_true", help="A/B: one graph per step with a fork / join of the batch slices instead of one free-running graph per slice (the default where the fused step boundary runs)")
+    ap.add_argument("--decouple", action="store_true", help="A/B: force the free-running graphs (widths without the fused boundary default to the fork / join)")
     ap.add_argument("--skew-us", type=int, default=None, help="phase lag between the decoupled batch-slice chains in microseconds (default: half a step)")
     args = ap.parse_args()
     if args.steps is None:
@@ -900,6 +901,8 @@ def main():
         diff.batch_split = args.split
     if args.no_decouple:
         diff.decouple_branches = False
+    if args.decouple:
+        diff.decouple_branches = True
     if args.skew_us is not None:
         diff.branch_skew_us = args.skew_us
 

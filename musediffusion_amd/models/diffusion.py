@@ -169,8 +169,10 @@ class GaussianDiffusion:
     # lag between the chains (half a step for two), so that one slice's step boundary - update, step bookkeeping, up-projection - falls
     # under the other slice's encoder GEMMs.  Round 3 measured it neutral (3.693 vs 3.699 ms: the boundary was then a dozen small
     # launches on both chains at once); with the boundary as four kernels (round 4) it is -0.7 .. -1.0 % per step
-    # (profiles/r04_ab_step_fusions.txt): on by default.  Samples are bit-identical either way (the noise is counter-based).
-    decouple_branches = True
+    # (profiles/r04_ab_step_fusions.txt; -2.0 % on the round's final library).  Where the boundary is still a dozen launches (no fused
+    # head / tail kernels for the width: bert-base's 768) the per-step fork / join stays 1.8 % ahead (profiles/r04_ab_nulls.txt), so
+    # None = decoupled exactly where the fused boundary runs; True / False force it.  Samples are bit-identical either way (counter-based noise).
+    decouple_branches = None
     branch_skew_us = None      # phase lag of branch j behind branch j-1 at the start of a decoupled loop; None = half a step / branches
     # batch-sliced graph branches: the step's head (up-projection ... embedding LayerNorm) and tail (down-projection, rounding,
     # posterior update) run ONCE for the whole batch and only the encoder layers per slice (engine.head / layers / tail).  Measured
@@ -922,7 +924,8 @@ class _ReverseLoop:
         diff = self.diff
         self.in_graph_rng = diff.noise_fn is None and diff.rng_mode == "philox"
         self.stream = torch.cuda.current_stream()
-        self.decoupled = bool(self.nsplit > 1 and self.in_graph_rng and not self.progressive and diff.use_graph and diff.decouple_branches
+        want = self.fused_round if diff.decouple_branches is None else bool(diff.decouple_branches)
+        self.decoupled = bool(self.nsplit > 1 and self.in_graph_rng and not self.progressive and diff.use_graph and want
                               and (self.L * self.E) % 4 == 0)
         if diff.use_graph:
             snap = (self.x.clone(), self.state.clone())

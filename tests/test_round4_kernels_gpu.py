@@ -171,7 +171,7 @@ def test_step_with_fused_rounding_pieces_equals_the_separate_launches(kind):
             for state in (loop.br_state if loop.decoupled else [loop.state]):   # (decoupled chains keep one loop state per batch slice)
                 st = state.cpu().tolist()
                 assert st[0] == 3 and st[1] == 3 and st[2] == idx[2]          # pos, n_steps, cur_t after three steps
-            assert loop.decoupled == (graph and diff.decouple_branches)
+            assert loop.decoupled == bool(graph and (loop.fused_round if diff.decouple_branches is None else diff.decouple_branches))
             key = (fused_name, graph) if own_noise else "separate noise launch"
             if fused_name == "in the forward" and not diff.update_in_forward:
                 key = "separate update"

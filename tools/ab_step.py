@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """In-process A/B of library switches on the captured reverse step (bench.py workload c2): alternates settings over several
 rounds and prints the median ms/step of each (boxes of the pool differ by several percent; only same-process numbers compare).
-    python tools/ab_step.py plain_stores 0 1 2 4 7          (AB_WORKLOAD=c2-bertbase selects another bench workload)"""
+    python tools/ab_step.py plain_stores 0 1 2 4 7          (AB_WORKLOAD=c2-bertbase selects another bench workload; AB_ROUNDS / AB_STEPS: alternations and timed steps, default 3 x 40)"""
 import contextlib
 import io
 import json
@@ -11,7 +11,7 @@ import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 knob, values = sys.argv[1], [int(v) for v in sys.argv[2:]]
-BASE = ["bench.py", "--steps", "40", "--warmup", "5", "--no-cpu-baseline", "--no-kernel-timing", "--no-secondary", "--workload", os.environ.get("AB_WORKLOAD", "c2")]
+BASE = ["bench.py", "--steps", os.environ.get("AB_STEPS", "40"), "--warmup", "5", "--no-cpu-baseline", "--no-kernel-timing", "--no-secondary", "--workload", os.environ.get("AB_WORKLOAD", "c2")]
 sys.argv = list(BASE)
 import bench  # noqa: E402
 from musediffusion_amd import _lib  # noqa: E402
@@ -30,7 +30,7 @@ setters["round_in_forward"] = lambda v: setattr(GaussianDiffusion, "round_in_for
 setters["fuse_rounding"] = lambda v: setattr(GaussianDiffusion, "fuse_rounding", bool(v))
 setters["skew"] = lambda v: setattr(GaussianDiffusion, "branch_skew_us", None if v < 0 else v)       # microseconds; -1 = automatic
 res = {v: [] for v in values}
-for rnd in range(3):
+for rnd in range(int(os.environ.get("AB_ROUNDS", "3"))):
     for v in values:
         if knob == "v3_split":
             _lib.lib().mh_gemm_set_variant(3)
