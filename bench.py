@@ -948,8 +948,8 @@ def main():
         }
         run_secondary = world == 1 and args.workload == "c2" and args.dtype == "bf16" and not args.no_secondary and not args.no_graph
         if run_secondary:
-            # right after the headline's timed region and BEFORE the eager per-launch profile below: measured after it, the bert-base-width
-            # loop runs 15 - 20 % slower than alone in a fresh process (117 against 138 steps/s on one box; the other entries do not move)
+            # right after the headline's timed region (its two-chain loops choose their streams by an overlap probe: DESIGN section 5,
+            # "Streams are not queues")
             secondary = secondary_block(device)
         if not args.no_kernel_timing:
             out["roofline"], out["kernels"] = step_tables(loop, c, args, ms_per_step, total, PROF_STEPS)

@@ -942,20 +942,23 @@ class _ReverseLoop:
                     t1.synchronize()
                     skew = int(1e3 * t0.elapsed_time(t1) / self.nsplit)
                 self.skew_us = int(skew)
+                # the chains run on streams of their own that are KNOWN to overlap (ops.concurrent_streams): on the caller's stream and
+                # an arbitrary pool stream every fourth loop of a process ran its two chains back to back (+25 % per step)
+                self.chain_streams = ops.concurrent_streams(self.nsplit, self.x.device)
                 ev = torch.cuda.Event()
                 ev.record(self.stream)
-                for j in range(1, self.nsplit):
-                    side = self.side_streams[j - 1]
-                    side.wait_event(ev)
-                    _lib.check(_lib.lib().mh_stream_delay(min(100000, self.skew_us * j), side.cuda_stream), "mh_stream_delay")
+                for j, cs in enumerate(self.chain_streams):
+                    cs.wait_event(ev)
+                    if j:
+                        _lib.check(_lib.lib().mh_stream_delay(min(100000, self.skew_us * j), cs.cuda_stream), "mh_stream_delay")
         return self
 
     def finish(self):
         """Joins the decoupled branches into the loop's stream (the samples are complete behind it)."""
         if self.decoupled:
-            for side in self.side_streams:
+            for cs in self.chain_streams:
                 ev = torch.cuda.Event()
-                ev.record(side)
+                ev.record(cs)
                 self.stream.wait_event(ev)
 
     def _branch_graph(self, j, ur):
@@ -991,7 +994,7 @@ class _ReverseLoop:
         ur = self.use_round[k]
         if self.decoupled:
             for j in range(self.nsplit):
-                stream = self.stream if j == 0 else self.side_streams[j - 1]
+                stream = self.chain_streams[j]
                 if diff.use_graph:
                     self._branch_graph(j, ur).launch(stream)
                 else:                       # (per-launch profiling of the same chains, bench.py)

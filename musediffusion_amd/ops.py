@@ -240,6 +240,36 @@ def trunc_normal(shape, bound, seed, stream_id=0, step_counter=None, device="cud
     return out
 
 
+def streams_overlap(a, b, microseconds=120):
+    """True when work on streams a and b runs CONCURRENTLY.  HIP multiplexes a process's streams onto a few hardware queues and two
+    streams on one queue run back to back (torch's default stream against every fourth pool stream: 4.44 instead of 3.55 ms per step for
+    two batch-slice chains, tools/debug/chain_streams.py): a one-wave delay kernel on each, bracketed by events."""
+    torch.cuda.synchronize()
+    e0, e1, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), torch.cuda.Event()
+    e0.record(a)
+    b.wait_event(e0)
+    check(lib().mh_stream_delay(int(microseconds), a.cuda_stream), "mh_stream_delay")
+    check(lib().mh_stream_delay(int(microseconds), b.cuda_stream), "mh_stream_delay")
+    eb.record(b)
+    a.wait_event(eb)
+    e1.record(a)
+    e1.synchronize()
+    return e0.elapsed_time(e1) * 1e3 < 1.6 * microseconds
+
+
+def concurrent_streams(n, device=None, tries=8):
+    """n torch streams that pairwise run concurrently (see streams_overlap); after `tries` replacements the last candidates are returned
+    as they are - the results do not depend on it, only the overlap does."""
+    streams = [torch.cuda.Stream(device=device) for _ in range(n)]
+    streams_overlap(streams[0], streams[-1])          # (first use of a stream pays one-time setup: not a measurement)
+    for _ in range(tries):
+        clash = next(((i, j) for i in range(n) for j in range(i + 1, n) if not streams_overlap(streams[i], streams[j])), None)
+        if clash is None:
+            break
+        streams[clash[1]] = torch.cuda.Stream(device=device)
+    return streams
+
+
 class Graph:
     """A captured sequence of libmusehip launches (hipGraph) that can be replayed."""
 

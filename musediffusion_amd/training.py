@@ -697,9 +697,13 @@ class _DropSites:
         if self.p_att <= 0.0 or not (FUSED_ATTENTION and dt == ops.MH_BF16 and bool(lib().mh_attention_stream_bwd_supported(L, dh))):
             return
         side = getattr(model, "_bits_stream", None)
-        if side is None:
-            side = model._bits_stream = torch.cuda.Stream()
         main = torch.cuda.current_stream()
+        if side is None:     # a stream that really runs beside the caller's (HIP shares hardware queues between streams: ops.streams_overlap)
+            for _ in range(6):
+                side = torch.cuda.Stream()
+                if ops.streams_overlap(main, side):
+                    break
+            model._bits_stream = side
         side.wait_stream(main)
         nwords = int(lib().mh_dropout_bits_words(B * nh, L))
         for li in range(len(model.input_transformers.layer)):

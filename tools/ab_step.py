@@ -45,4 +45,5 @@ for rnd in range(int(os.environ.get("AB_ROUNDS", "3"))):
             bench.main()
         res[v].append(json.loads(buf.getvalue().strip().splitlines()[-1])["ms_per_step"])
 for v in values:
-    print("%s=%d: median %.4f ms/step (min %.4f)" % (knob, v, statistics.median(res[v]), min(res[v])), flush=True)
+    print("%s=%d: median %.4f ms/step (min %.4f)%s" % (knob, v, statistics.median(res[v]), min(res[v]),
+                                                       "  all: " + " ".join("%.3f" % t for t in res[v]) if os.environ.get("AB_ALL") else ""), flush=True)
