@@ -304,3 +304,16 @@ def test_fused_head_and_tail_repeat_launches_are_bit_identical_under_load():
         torch.cuda.synchronize()
         bad += int(not (torch.equal(X, X0) and torch.equal(out, out0) and torch.equal(idx, idx0)))
     assert bad == 0, "%d of 120 repeated launches differ from the first" % bad
+
+
+def test_concurrent_streams_really_overlap():
+    """HIP multiplexes streams onto a few hardware queues: two streams on one queue run back to back (every fourth pool stream against a
+    given one).  ops.concurrent_streams returns streams a probe has SEEN overlap - what the loop's decoupled chains run on."""
+    from musediffusion_amd import ops
+    ss = ops.concurrent_streams(2, torch.device(DEV))
+    assert len(ss) == 2 and ss[0] != ss[1]
+    assert sum(ops.streams_overlap(ss[0], ss[1]) for _ in range(5)) >= 4        # (a one-off hiccup of the timer is tolerated)
+    pool = [torch.cuda.Stream() for _ in range(12)]
+    ops.streams_overlap(pool[0], pool[1])
+    clashes = sum(not ops.streams_overlap(pool[0], s) for s in pool[1:])
+    print("pool streams that do NOT overlap with the first of 12: %d" % clashes)   # (2 - 3 on this runtime; 0 would make the probe moot, not wrong)
