@@ -244,6 +244,8 @@ def streams_overlap(a, b, microseconds=120):
     """True when work on streams a and b runs CONCURRENTLY.  HIP multiplexes a process's streams onto a few hardware queues and two
     streams on one queue run back to back (torch's default stream against every fourth pool stream: 4.44 instead of 3.55 ms per step for
     two batch-slice chains, tools/debug/chain_streams.py): a one-wave delay kernel on each, bracketed by events."""
+    for st in (a, b):        # (a stream's first launch pays a one-time setup of a few hundred microseconds: not part of the measurement)
+        check(lib().mh_stream_delay(1, st.cuda_stream), "mh_stream_delay")
     torch.cuda.synchronize()
     e0, e1, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), torch.cuda.Event()
     e0.record(a)
@@ -261,7 +263,6 @@ def concurrent_streams(n, device=None, tries=8):
     """n torch streams that pairwise run concurrently (see streams_overlap); after `tries` replacements the last candidates are returned
     as they are - the results do not depend on it, only the overlap does."""
     streams = [torch.cuda.Stream(device=device) for _ in range(n)]
-    streams_overlap(streams[0], streams[-1])          # (first use of a stream pays one-time setup: not a measurement)
     for _ in range(tries):
         clash = next(((i, j) for i in range(n) for j in range(i + 1, n) if not streams_overlap(streams[i], streams[j])), None)
         if clash is None:

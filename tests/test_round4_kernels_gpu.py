@@ -314,6 +314,6 @@ def test_concurrent_streams_really_overlap():
     assert len(ss) == 2 and ss[0] != ss[1]
     assert sum(ops.streams_overlap(ss[0], ss[1]) for _ in range(5)) >= 4        # (a one-off hiccup of the timer is tolerated)
     pool = [torch.cuda.Stream() for _ in range(12)]
-    ops.streams_overlap(pool[0], pool[1])
     clashes = sum(not ops.streams_overlap(pool[0], s) for s in pool[1:])
-    print("pool streams that do NOT overlap with the first of 12: %d" % clashes)   # (2 - 3 on this runtime; 0 would make the probe moot, not wrong)
+    print("pool streams that do NOT overlap with the first of 12: %d" % clashes)   # (3 on this runtime; 0 would make the probe moot, not wrong)
+    assert clashes <= 6
