@@ -698,7 +698,8 @@ class _ReverseLoop:
         if split is None:
             # two half-batch branches overlap one half's attention / epilogues with the other's GEMM main loops (+4% at
             # config 2, bit-identical samples); small batches would only halve the tile count of every GEMM
-            split = 2 if (B % 2 == 0 and B * L >= 32768 and getattr(net, "compute_dtype", "fp32") == "bf16") else 1
+            # (the split-precision modes: two DECOUPLED chains, +1 .. 3 % - their fork / join form measured 2 % behind one chain)
+            split = 2 if (B % 2 == 0 and B * L >= 32768 and getattr(net, "compute_dtype", "fp32") in ("bf16", "bf16x3", "f16x3")) else 1
         self.nsplit = max(1, min(int(split), B))
         # the captured graph bakes in raw workspace pointers: the loop owns its scratch (the engine's shared buffer may be
         # reallocated by any other forward between two replays of a progressive loop)
@@ -924,7 +925,8 @@ class _ReverseLoop:
         diff = self.diff
         self.in_graph_rng = diff.noise_fn is None and diff.rng_mode == "philox"
         self.stream = torch.cuda.current_stream()
-        want = self.fused_round if diff.decouple_branches is None else bool(diff.decouple_branches)
+        auto = self.fused_round or getattr(self.net, "compute_dtype", "fp32") in ("bf16x3", "f16x3")
+        want = auto if diff.decouple_branches is None else bool(diff.decouple_branches)
         self.decoupled = bool(self.nsplit > 1 and self.in_graph_rng and not self.progressive and diff.use_graph and want
                               and (self.L * self.E) % 4 == 0)
         if diff.use_graph:
