@@ -164,7 +164,7 @@ class GaussianDiffusion:
     rng_stream = 0
     noise_fn = None        # optional callable (k, i, x) -> noise tensor (parity tests)
     use_graph = True       # capture the reverse step into a hipGraph when the fused path applies
-    batch_split = None     # denoiser batch slices run as concurrent graph branches; None = 2 for large bf16 batches, else 1
+    batch_split = None     # denoiser batch slices run as concurrent graph branches; None = 2 for large batches (>= 32768 tokens), else 1
     # in-graph RNG, non-progressive loops: every batch slice replays its OWN graph on its own stream, with no per-step join and a phase
     # lag between the chains (half a step for two), so that one slice's step boundary - update, step bookkeeping, up-projection - falls
     # under the other slice's encoder GEMMs.  Round 3 measured it neutral (3.693 vs 3.699 ms: the boundary was then a dozen small
@@ -699,7 +699,8 @@ class _ReverseLoop:
             # two half-batch branches overlap one half's attention / epilogues with the other's GEMM main loops (+4% at
             # config 2, bit-identical samples); small batches would only halve the tile count of every GEMM
             # (the split-precision modes: two DECOUPLED chains, +1 .. 3 % - their fork / join form measured 2 % behind one chain)
-            split = 2 if (B % 2 == 0 and B * L >= 32768 and getattr(net, "compute_dtype", "fp32") in ("bf16", "bf16x3", "f16x3")) else 1
+            # (fp32 mode: +7.6 %, 29.6 -> 31.8 steps/s at config 2, fork / join or decoupled alike)
+            split = 2 if (B % 2 == 0 and B * L >= 32768) else 1
         self.nsplit = max(1, min(int(split), B))
         # the captured graph bakes in raw workspace pointers: the loop owns its scratch (the engine's shared buffer may be
         # reallocated by any other forward between two replays of a progressive loop)
