@@ -2,7 +2,7 @@
 """A/B of two BUILDS of libmusehip.so on one box: alternates `bench.py` child processes that load the in-tree library and a saved
 copy (MUSEHIP_AB=1 MUSEHIP_LIB=<copy>, the gate of musediffusion_amd/_lib.py) and prints the median ms/step of each.
     cp musediffusion_amd/csrc/libmusehip.so tools/ab/libmusehip_base.so     # before the change
-    python tools/ab_lib.py tools/ab/libmusehip_base.so [--workload c2] [--rounds 3] [-- extra bench.py flags]"""
+    python tools/ab_lib.py tools/ab/libmusehip_base.so [--workload c2] [--rounds 3] [extra bench.py flags]"""
 import argparse
 import json
 import os
@@ -16,10 +16,9 @@ ap.add_argument("base")
 ap.add_argument("--workload", default="c2")
 ap.add_argument("--rounds", type=int, default=3)
 ap.add_argument("--steps", type=int, default=40)
-ap.add_argument("extra", nargs="*")
-a = ap.parse_args()
+a, extra = ap.parse_known_args()      # everything it does not know goes to bench.py (e.g. --dtype f16x3)
 cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", str(a.steps), "--warmup", "5", "--no-cpu-baseline", "--no-kernel-timing", "--no-secondary",
-       "--workload", a.workload] + a.extra
+       "--workload", a.workload] + extra
 res = {"base": [], "new": []}
 for rnd in range(a.rounds):
     for which in ("base", "new"):
