@@ -37,9 +37,19 @@ def save(directory, step, model, optimizer=None, ema_rates=()):
     os.makedirs(directory, exist_ok=True)
     cpu = lambda sd: {k: (v.detach().cpu() if torch.is_tensor(v) else v) for k, v in sd.items()}
     torch.save(cpu(model.state_dict()), os.path.join(directory, f"model_{step:06d}.pt"))
-    if optimizer is not None:
-        for i, rate in enumerate(ema_rates):
-            torch.save(cpu(optimizer.ema_state_dict(i, model)), os.path.join(directory, f"ema_{rate}_{step:06d}.pt"))
+    if optimizer is None:
+        return
+    if ema_rates:
+        if not hasattr(optimizer, "ema_state_dict"):
+            # the reference always writes its EMA copies (train_util.py:300-308): an optimizer that keeps none cannot stand in for
+            # them, and a resume would silently restart the averages from the live weights
+            import warnings
+            warnings.warn("checkpoint.save: ema_rates %s are configured but %s keeps no EMA copies (no ema_state_dict): no ema_*.pt "
+                          "is written and a resume restarts the averages from the live weights" % (list(ema_rates), type(optimizer).__name__))
+        else:
+            for i, rate in enumerate(ema_rates):
+                torch.save(cpu(optimizer.ema_state_dict(i, model)), os.path.join(directory, f"ema_{rate}_{step:06d}.pt"))
+    if hasattr(optimizer, "state_dict"):         # opt_{step}.pt whenever there is optimizer state (train_util.py:310-315)
         osd = optimizer.state_dict()
         osd["state"] = {k: cpu(v) for k, v in osd["state"].items()}
         torch.save(osd, os.path.join(directory, f"opt_{step:06d}.pt"))

@@ -399,6 +399,9 @@ using CfgStd = BigCfg<256, 128, 2, 2, 3>;
 using CfgWide = BigCfg<256, 256, 2, 4, 4>;
 using CfgRow = BigCfg<128, 512, 2, 4, 3>;
 using CfgWidePP = BigCfg<256, 256, 2, 4, 4, true>;
+// 256x256 on FOUR waves: one wave per SIMD with a 128x128 wave tile (256 accumulator registers of a 512-register wave) - 16 fragment
+// reads per 64 MFMAs instead of 24, 8 DMA pieces per wave and K-step.  A/B only (variant 6 / wide_roles bit 5; VERDICT r4 item 1's geometry)
+using CfgWide4 = BigCfg<256, 256, 2, 2, 4>;
 using CfgRowPP = BigCfg<128, 512, 2, 4, 3, true>;
 using CfgRow64 = BigCfg<64, 512, 1, 8, 3>;   // full-row tile over 64 rows: twice the blocks of CfgRow (short K: the epilogue dominates)
 constexpr int B2K = 32;
@@ -1365,8 +1368,12 @@ int launch(const GemmArgs& g, int dtype, hipStream_t s, int batch = 1) {
             return (g_wide_roles & 8) ? launch_row_gelu<CfgRowPP>(g, s, batch) : launch_row_gelu<CfgRow>(g, s, batch);
         }
 #endif
-        if (want_wide(g, batch) && (EPI != 1 || g.H % 64 == 0))
+        if (want_wide(g, batch) && (EPI != 1 || g.H % 64 == 0)) {
+#ifdef MH_ABLATE
+          if ((g_variant == 6 || (g_wide_roles & 32)) && (EPI != 1 || g.H % 128 == 0)) return launch_big<CfgWide4, EPI>(g, s, batch);
+#endif
           return g_variant == 5 ? launch_big<CfgWidePP, EPI>(g, s, batch) : launch_big<CfgWide, EPI>(g, s, batch);
+        }
         return launch_big<CfgStd, EPI>(g, s, batch);
       }
     } else if (g_variant == 1) {
@@ -1435,7 +1442,7 @@ extern "C" int mh_gemm_set_auto_wide(int on) {
 
 #ifdef MH_ABLATE
 extern "C" int mh_gemm_set_variant(int variant) {
-  MH_CHECK_ARG(variant >= 0 && variant <= 5, "gemm_set_variant: variant must be 0..5");
+  MH_CHECK_ARG(variant >= 0 && variant <= 6, "gemm_set_variant: variant must be 0..6");
   g_variant = variant;
   return MH_OK;
 }

@@ -70,7 +70,12 @@ class LossAwareSampler(ScheduleSampler):
     updates and every value are the reference's: nothing reads the state in between."""
 
     _pending = None
-    _GROUP = 64       # ranks must bring micro-batches whose sizes round up to the same multiple of this (checked after the fact)
+    _GROUP = 64       # gather blocks are padded to a multiple of this many (timestep, loss) pairs
+    # A bound on the micro-batch size that EVERY rank agrees on (train_step.TrainStep sets its configured `microbatch`).  The gather
+    # block of the device path is sized from it, so all ranks enter the collective with equal buffers whatever their own counts are.
+    # None: the ranks exchange their counts first and pad to the largest, as the reference does (step_sample.py:100-113; one host
+    # read per micro-batch).
+    max_local_batch = None
 
     def update_with_all_losses(self, ts, losses):
         raise NotImplementedError
@@ -86,9 +91,8 @@ class LossAwareSampler(ScheduleSampler):
         all_ts, all_losses = [], []
         for r in range(world):
             n = int(rows[r, 0])
-            if n > cap:
-                raise RuntimeError("loss-aware sampler: rank %d brought %d losses, more than this rank's padded size %d - every rank "
-                                   "must run micro-batches of sizes within the same group of %d" % (r, n, cap, self._GROUP))
+            if n > cap:   # (cannot happen: every rank checks its own count against the shared bound before the collective)
+                raise RuntimeError("loss-aware sampler: rank %d brought %d losses, more than the padded size %d" % (r, n, cap))
             all_ts.extend(int(v) for v in rows[r, 1:1 + n])
             all_losses.extend(float(v) for v in rows[r, 1 + cap:1 + cap + n])
         self.update_with_all_losses(all_ts, all_losses)
@@ -117,7 +121,15 @@ class LossAwareSampler(ScheduleSampler):
             self.update_with_all_losses(all_ts, all_losses)
             return
         dev = local_ts.device
-        cap = (count + self._GROUP - 1) // self._GROUP * self._GROUP
+        bound = self.max_local_batch if world > 1 else count
+        if bound is None:      # no agreed bound: learn the largest count first (the reference's size exchange)
+            sizes = torch.empty(world, dtype=torch.int64, device=dev)
+            dist.all_gather_into_tensor(sizes, torch.full((1,), count, dtype=torch.int64, device=dev))
+            bound = int(sizes.max())
+        if count > bound:
+            raise ValueError("loss-aware sampler: a micro-batch of %d rows exceeds max_local_batch = %d, the size every rank "
+                             "pads its gather block to" % (count, bound))
+        cap = (max(int(bound), 1) + self._GROUP - 1) // self._GROUP * self._GROUP
         block = torch.zeros(1 + 2 * cap, dtype=torch.float64, device=dev)
         block[0] = count
         block[1:1 + count] = ts64

@@ -243,10 +243,12 @@ def trunc_normal(shape, bound, seed, stream_id=0, step_counter=None, device="cud
 def streams_overlap(a, b, microseconds=120):
     """True when work on streams a and b runs CONCURRENTLY.  HIP multiplexes a process's streams onto a few hardware queues and two
     streams on one queue run back to back (torch's default stream against every fourth pool stream: 4.44 instead of 3.55 ms per step for
-    two batch-slice chains, tools/debug/chain_streams.py): a one-wave delay kernel on each, bracketed by events."""
+    two batch-slice chains, tools/debug/chain_streams.py): a one-wave delay kernel on each, bracketed by events.  Only a and b are
+    waited for - other streams of the process (a training loop that also samples, a second sampling loop) keep running."""
     for st in (a, b):        # (a stream's first launch pays a one-time setup of a few hundred microseconds: not part of the measurement)
         check(lib().mh_stream_delay(1, st.cuda_stream), "mh_stream_delay")
-    torch.cuda.synchronize()
+    a.synchronize()
+    b.synchronize()
     e0, e1, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), torch.cuda.Event()
     e0.record(a)
     b.wait_event(e0)
@@ -259,15 +261,24 @@ def streams_overlap(a, b, microseconds=120):
     return e0.elapsed_time(e1) * 1e3 < 1.6 * microseconds
 
 
-def concurrent_streams(n, device=None, tries=8):
+_STREAM_SETS = {}     # (device index, n) -> streams a probe has seen overlap: one probe per process and device, not one per loop
+
+
+def concurrent_streams(n, device=None, tries=8, reprobe=False):
     """n torch streams that pairwise run concurrently (see streams_overlap); after `tries` replacements the last candidates are returned
-    as they are - the results do not depend on it, only the overlap does."""
-    streams = [torch.cuda.Stream(device=device) for _ in range(n)]
+    as they are - the results do not depend on it, only the overlap does.  The verified set is kept per device: later callers get the
+    same streams without another probe (`reprobe=True` measures again)."""
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), int(n))
+    if not reprobe and key in _STREAM_SETS:
+        return list(_STREAM_SETS[key])
+    streams = [torch.cuda.Stream(device=dev) for _ in range(n)]
     for _ in range(tries):
         clash = next(((i, j) for i in range(n) for j in range(i + 1, n) if not streams_overlap(streams[i], streams[j])), None)
         if clash is None:
             break
-        streams[clash[1]] = torch.cuda.Stream(device=device)
+        streams[clash[1]] = torch.cuda.Stream(device=dev)
+    _STREAM_SETS[key] = list(streams)
     return streams
 
 

@@ -56,6 +56,7 @@ class FusedAdamWEMA:
         self._stage, self._stage_ev, self._stage_k = None, None, 0
         # torch keeps optimizer state only for parameters that have taken a step (a frozen one never appears in `state`)
         self._stepped = [False] * len(self.params)
+        self._steps = [0] * len(self.params)     # per-parameter step numbers, as torch.optim.AdamW keeps them (state[p]["step"])
         self._with_grad = [True] * len(self.params)
 
     def _tensor_table(self):
@@ -122,9 +123,18 @@ class FusedAdamWEMA:
         if lr is not None:
             self.lr = float(lr)
         t = self._tensor_table()
+        # one launch applies ONE bias correction: every parameter that steps now must have taken every earlier step too.  A parameter
+        # that gets its first gradient later (unfrozen mid-run) would need its own correction, as torch.optim.AdamW's per-parameter
+        # `step` gives it - refused rather than stepped with the wrong one (the reference's TrainLoop never changes what is frozen)
+        behind = [i for i, w in enumerate(self._with_grad) if w and self._steps[i] != self.step_count]
+        if behind:
+            raise NotImplementedError("FusedAdamWEMA: parameter %d has taken %d of the optimizer's %d steps - parameters that start to "
+                                      "receive gradients mid-run need per-parameter bias correction" % (behind[0], self._steps[behind[0]], self.step_count))
         self.step_count += 1
         for i, w in enumerate(self._with_grad):
             self._stepped[i] = self._stepped[i] or w
+            if w:
+                self._steps[i] = self.step_count
         b1, b2 = self.betas
         hp = OptHParams()
         hp.beta1, hp.beta2, hp.eps = b1, b2, self.eps
@@ -154,7 +164,7 @@ class FusedAdamWEMA:
     # ------------------------------------------------------------------ checkpoint format of the reference
     def state_dict(self):
         """torch.optim.AdamW layout (what `opt_{step}.pt` holds, train_util.py:310-315)."""
-        state = {i: {"step": torch.tensor(float(self.step_count)), "exp_avg": self.exp_avg[i], "exp_avg_sq": self.exp_avg_sq[i]}
+        state = {i: {"step": torch.tensor(float(self._steps[i])), "exp_avg": self.exp_avg[i], "exp_avg_sq": self.exp_avg_sq[i]}
                  for i in range(len(self.params)) if self._stepped[i]}
         group = {"lr": self.lr, "betas": self.betas, "eps": self.eps, "weight_decay": self.weight_decay, "amsgrad": False,
                  "maximize": False, "params": list(range(len(self.params)))}
@@ -167,7 +177,8 @@ class FusedAdamWEMA:
             i = int(i)
             self.exp_avg[i].copy_(st["exp_avg"])
             self.exp_avg_sq[i].copy_(st["exp_avg_sq"])
-            self.step_count = int(float(st["step"]))
+            self._steps[i] = int(float(st["step"]))
+            self.step_count = max(self.step_count, self._steps[i])
             self._stepped[i] = True
 
     def ema_state_dict(self, index, model):

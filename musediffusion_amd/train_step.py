@@ -36,6 +36,10 @@ class TrainStep:
         self.microbatch = microbatch
         self.lr, self.learning_steps, self.gradient_clipping = float(lr), int(learning_steps), float(gradient_clipping)
         self.schedule_sampler = schedule_sampler or UniformSampler(diffusion)
+        # every rank is built with the same `microbatch`: the loss-aware sampler sizes its gather block from it, so ranks whose last
+        # micro-batch is shorter (or whose `data` iterators yield different batch sizes) still enter the collective with equal buffers
+        if isinstance(self.schedule_sampler, LossAwareSampler) and microbatch > 0 and self.schedule_sampler.max_local_batch is None:
+            self.schedule_sampler.max_local_batch = int(microbatch)
         # train_util.py:63-67: a float, or the config's comma-separated string ("0.5,0.9,0.99"); a sequence of floats is accepted
         # too, None (the reference's empty list) means no EMA copies
         # the reference's falsy rule comes first (`... if ema_rate else []`): 0.0, "", None and () all mean no EMA copies

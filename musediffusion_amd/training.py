@@ -611,6 +611,31 @@ class _QSample(Function):
         return dx, None, None, None, None
 
 
+class _AxPy(Function):
+    """a[b] x + s[b] y with gradients to BOTH operands: `_predict_xstart_from_eps` (diffusion.py:228-236) inside training_losses when
+    the model output is read as the noise (predict_xstart=False, `_x0_helper`, diffusion.py:586-590)."""
+
+    @staticmethod
+    def forward(ctx, x, y, a, s):
+        ctx.save_for_backward(a, s)
+        return ops.q_sample(x, y, a, s, None)
+
+    @staticmethod
+    def backward(ctx, g):
+        a, s = ctx.saved_tensors
+        g = g.contiguous()
+        B = g.shape[0]
+        outs = []
+        for k, coef in enumerate((a, s)):
+            if not ctx.needs_input_grad[k]:
+                outs.append(None)
+                continue
+            d = torch.empty_like(g)
+            check(lib().mh_scale_rows(ptr(g), ptr(coef), None, ptr(d), 0, B, g.numel() // B, g.shape[-1], current_stream()), "mh_scale_rows")
+            outs.append(d)
+        return outs[0], outs[1], None, None
+
+
 class _SqDiffMean(Function):
     """mean_flat((scale * a - b)^2) per batch row (diffusion.py:15-19 applied at :627-639)."""
 
@@ -897,15 +922,19 @@ def training_losses(diffusion, model, t, model_kwargs, noise=None, with_corrupti
     x_t = _QSample.apply(x_start, noise, a, s, mask)                                               # diffusion.py:618
     model_output = model(x_t, diffusion._scale_timesteps(t), **model_kwargs)                        # diffusion.py:624
     assert model_output.shape == x_start.shape
-    if not diffusion.predict_xstart:
-        raise NotImplementedError("training with predict_xstart=False (the reference never builds it, "
-                                  "utils/initialization.py:129-134)")
+    if diffusion.predict_xstart:                                                                   # _x0_helper, :577-592
+        pred_x0 = model_output
+    else:   # the output is the noise: x0 = sqrt(1 / ab_t) x_t - sqrt(1 / ab_t - 1) eps (:228-236); t_loss below still compares the
+        #     raw output with the target latent, as the reference does (:627 / :679)
+        r1 = _device_table(diffusion.sqrt_recip_alphas_cumprod, dev)[t]
+        r2 = _device_table(diffusion.sqrt_recipm1_alphas_cumprod, dev)[t]
+        pred_x0 = _AxPy.apply(x_t, model_output, r1, -r2)
     t_loss = _SqDiffMean.apply(tgt_start, model_output, 1.0)                                       # :627 / :679
-    t0_loss = _SqDiffMean.apply(tgt_mean, model_output, 1.0)                                       # :630 / :682
+    t0_loss = _SqDiffMean.apply(tgt_mean, pred_x0, 1.0)                                            # :630 / :682
     terms = {"mse": torch.where(t == 0, t0_loss, t_loss)}
     sqrt_ab_T = float(diffusion.sqrt_alphas_cumprod[diffusion.num_timesteps - 1].astype("float32"))
     tT_loss = _SqDiffMean.apply(x_start, None, sqrt_ab_T)                                          # :634-639
     decoder_nll = _token_nll(net, x_start, ids)                                                    # :641
-    terms["nll"] = _token_nll(net, model_output, tgt_ids, mask=mask)                               # :642 / :694
+    terms["nll"] = _token_nll(net, pred_x0, tgt_ids, mask=mask)                                    # :642 / :694
     terms["loss"] = terms["mse"] + decoder_nll + tT_loss                                           # :645
     return terms

@@ -86,18 +86,17 @@ def overload_denoiser(model, denoiser_state_dict):
 
 
 def get_latest_model_path(base_path):
-    """utils/initialization.py:90-105: the most recently modified `.pt` file of the most recently modified sub-directory of
-    `base_path`; None when there is none (or on any OSError)."""
+    """utils/initialization.py:90-105: the newest `.pt` file (by mtime) inside the newest sub-directory (by mtime) of `base_path`;
+    None when either level is empty or unreadable."""
     import os
+
+    def newest(folder, keep):
+        with os.scandir(folder) as entries:
+            return max((e.path for e in entries if keep(e)), key=os.path.getmtime, default=None)
+
     try:
-        candidates = filter(os.path.isdir, (os.path.join(base_path, x) for x in os.listdir(base_path)))
-        candidates_sort = sorted(candidates, key=os.path.getmtime, reverse=True)
-        if not candidates_sort:
-            return None
-        ckpt_path = candidates_sort[0]
-        candidates = filter(os.path.isfile, (os.path.join(ckpt_path, x) for x in os.listdir(ckpt_path)))
-        candidates_sort = sorted((c for c in candidates if c.endswith(".pt")), key=os.path.getmtime, reverse=True)
-        return candidates_sort[0] if candidates_sort else None
+        run_dir = newest(base_path, lambda e: e.is_dir())
+        return None if run_dir is None else newest(run_dir, lambda e: e.is_file() and e.name.endswith(".pt"))
     except OSError:
         return None
 

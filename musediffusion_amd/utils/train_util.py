@@ -188,8 +188,7 @@ class TrainLoop:
     # ------------------------------------------------------------------ files (:294-371)
     def save(self):
         if _rank() == 0:
-            ckpt.save(self.checkpoint_path, self.step + self.resume_step, self.model,
-                      self.opt if hasattr(self.opt, "ema_state_dict") else None, self.ema_rate)
+            ckpt.save(self.checkpoint_path, self.step + self.resume_step, self.model, self.opt, self.ema_rate)
         if dist.is_available() and dist.is_initialized():
             dist.barrier()
 

@@ -184,10 +184,41 @@ def case_untied(rank, world, dev):
     assert all(torch.equal(toks[0], t) for t in toks[1:])
 
 
+def case_lossaware(rank, world, dev):
+    """The loss-aware sampler's DEVICE path with ranks whose micro-batches straddle a padding group (64 and 65 rows): with
+    the shared bound TrainStep configures and with none (size exchange first) every rank enters the collective with equal buffers
+    and ends in the state a host replay of the rank-ordered (timestep, loss) pairs gives."""
+    from types import SimpleNamespace
+    from musediffusion_amd.models.step_sample import LossSecondMomentResampler
+    T = 7
+    counts = [64, 65][:world] + [3] * max(0, world - 2)
+    gen = torch.Generator().manual_seed(5)
+    all_ts = [torch.randint(0, T, (n,), generator=gen) for n in counts]
+    all_ls = [torch.rand(n, generator=gen, dtype=torch.float64) for n in counts]
+    ref = LossSecondMomentResampler(SimpleNamespace(num_timesteps=T), history_per_term=4)
+    for _ in range(2):
+        ref.update_with_all_losses([int(v) for t in all_ts for v in t], [float(v) for l in all_ls for v in l])
+    for bound in (70, None):
+        s = LossSecondMomentResampler(SimpleNamespace(num_timesteps=T), history_per_term=4)
+        s.max_local_batch = bound
+        for _ in range(2):
+            s.update_with_local_losses(all_ts[rank].to(dev), all_ls[rank].to(dev))
+        assert np.array_equal(s._loss_counts, ref._loss_counts) and np.array_equal(s._loss_history, ref._loss_history), \
+            "sampler state differs from the host replay (rank %d, bound %s)" % (rank, bound)
+    s = LossSecondMomentResampler(SimpleNamespace(num_timesteps=T), history_per_term=4)
+    s.max_local_batch = 8
+    try:
+        s.update_with_local_losses(all_ts[rank].to(dev), all_ls[rank].to(dev))
+    except ValueError:
+        pass          # every rank's count exceeds the bound: all of them refuse before the collective
+    else:
+        raise AssertionError("a micro-batch beyond max_local_batch was accepted")
+
+
 if __name__ == "__main__":
     rank, world, dev = setup()
     try:
-        {"generate": case_generate, "ddp": case_ddp, "untied": case_untied}[sys.argv[1]](rank, world, dev)
+        {"generate": case_generate, "ddp": case_ddp, "untied": case_untied, "lossaware": case_lossaware}[sys.argv[1]](rank, world, dev)
         torch.cuda.synchronize()
         dist.barrier()
     finally:

@@ -67,12 +67,16 @@ def loop_noises(seed, shape, n, top_p):
 
 # bb / bb500: the only encoder shape the reference itself instantiates (H 768, 12 heads of 64, ffn 3072; network.py:44-46), with
 # E = 128 and with the released checkpoints' E = 500.  c2s: BASELINE config 2's width and seq_len 512 (the benchmarked shape; 2 layers)
-@pytest.mark.parametrize("tag", ["tiny", "same", "c1", "bb", "bb500", "c2s"])
+# c2d / bbd (round 5): config 2's denoiser and bert-base at their TRUE depth of 12 layers
+@pytest.mark.parametrize("tag", ["tiny", "same", "c1", "bb", "bb500", "c2s", "c2d", "bbd"])
 def test_model_surface(tag):
     m, diff, model_emb, inp, c = build(tag)
     g = load_golden("model_%s.npz" % tag)
     y = m(inp["fwd_x"].to(DEV), inp["fwd_t"].to(DEV), input_ids="ignored", anything_else=1)   # **_ is dropped
-    assert maxerr(sub(y, tag), G(g, "fwd_y")) < (2e-4 if c["H"] >= 512 else 1e-4)   # 512- ... 3072-term fp32 sums in another order
+    err = maxerr(sub(y, tag), G(g, "fwd_y"))
+    print("fp32 %s forward vs the reference: max |d| %.2e" % (tag, err))
+    # 512- ... 3072-term fp32 sums in another order; twelve layers of them at the deep cases
+    assert err < (4e-4 if c["nL"] >= 12 else 2e-4 if c["H"] >= 512 else 1e-4)
     ids = inp["batch"]["correct_ids"]
     assert torch.equal(m.get_embeds(ids.to(DEV)).cpu(), inp["x_start"])
     assert torch.equal(m.get_embeds(ids.int().to(DEV)).cpu(), inp["x_start"])
@@ -104,7 +108,7 @@ def test_start_latents_and_q_sample_bit_exact(tag):
     assert torch.equal(sub(q, tag), G(g, "q_out"))
 
 
-@pytest.mark.parametrize("tag", ["tiny", "same", "c1", "c2s"])
+@pytest.mark.parametrize("tag", ["tiny", "same", "c1", "c2s", "c2d"])
 def test_single_reverse_steps(tag):
     m, diff, model_emb, inp, c = build(tag)
     g = load_golden("model_%s.npz" % tag)
@@ -165,7 +169,7 @@ def run_loops(tag, m, diff, model_emb, inp, c, use_graph):
 
 
 @pytest.mark.parametrize("use_graph", [False, True], ids=["eager", "hipgraph"])
-@pytest.mark.parametrize("tag", ["tiny", "same", "c1", "bb", "bb500", "c2s"])
+@pytest.mark.parametrize("tag", ["tiny", "same", "c1", "bb", "bb500", "c2s", "c2d", "bbd"])
 def test_loops_final_tokens_exact_fp32(tag, use_graph):
     m, diff, model_emb, inp, c = build(tag)
     g = load_golden("model_%s.npz" % tag)
@@ -180,7 +184,7 @@ def test_loops_final_tokens_exact_fp32(tag, use_graph):
         assert maxerr(sub(s, tag), G(g, "loop_%s" % key)) < 2e-5, key
 
 
-@pytest.mark.parametrize("tag", ["c1", "bb", "bb500", "c2s"])
+@pytest.mark.parametrize("tag", ["c1", "bb", "bb500", "c2s", "c2d", "bbd"])
 def test_loops_bf16_token_agreement(tag):
     """bf16 throughput mode (panel layout; bb500: E = 500 zero-padded inside the arena) against the reference's fp32 tokens.
     c2s (d_model 512, seq_len 512): the kernels of the benchmarked step - streaming attention, 128x512 full-row tile with the LayerNorm
@@ -188,10 +192,10 @@ def test_loops_bf16_token_agreement(tag):
     m, diff, model_emb, inp, c = build(tag, "bf16")
     assert m.engine().cfg["panel"] == 1
     g = load_golden("model_%s.npz" % tag)
-    if tag == "c2s":
+    if tag in ("c2s", "c2d", "bbd"):
         y = m(inp["fwd_x"].to(DEV), inp["fwd_t"].to(DEV))
         d = (sub(y, tag) - G(g, "fwd_y")).abs()
-        print("bf16 c2s forward vs the reference: mean |d| %.4f max %.4f (ref absmax %.2f)" % (float(d.mean()), float(d.max()), float(G(g, "fwd_y").abs().max())))
+        print("bf16 %s forward vs the reference: mean |d| %.4f max %.4f (ref absmax %.2f)" % (tag, float(d.mean()), float(d.max()), float(G(g, "fwd_y").abs().max())))
         assert float(d.mean()) < 0.02 and float(d.max()) < 0.25
     res = run_loops(tag, m, diff, model_emb, inp, c, True)
     for key in ("ddim50", "p12", "mod"):
@@ -203,7 +207,7 @@ def test_loops_bf16_token_agreement(tag):
 
 
 @pytest.mark.parametrize("mode", ["bf16x3", "f16x3"])
-@pytest.mark.parametrize("tag", ["tiny", "same", "c1", "bb", "bb500", "c2s"])
+@pytest.mark.parametrize("tag", ["tiny", "same", "c1", "bb", "bb500", "c2s", "c2d", "bbd"])
 def test_split_precision_forward_and_loops_token_exact(tag, mode):
     """The mode between "fast" and "exact" (csrc/split.hip: every value as hi + lo 16-bit parts, three matrix-pipe products per reference
     product): the forward sits within a small multiple of the fp32 mode's distance from the reference's fwd_y, and the three golden loops
@@ -376,6 +380,24 @@ def test_bf16_drift_over_200_steps_at_full_config2_size(segment):
     print(r)
     assert r["agreement_min"] >= 0.99 and r["final_token_agreement"] >= 0.99, r
     assert r["agreement_last_step"] >= r["agreement_step0"] - 0.005, "token agreement decays along the loop: %s" % r
+
+
+@pytest.mark.parametrize("segment", ["first", "last"])
+def test_split_precision_final_tokens_at_full_config2_size(segment):
+    """The exact-token claim of the split-precision modes, as a test: BASELINE config 2 at FULL size (64 x 512 tokens,
+    12 layers), 50 clamped iterations, same weights / start latent / Philox noise as compute_dtype="fp32": f16x3 ends on the fp32 mode's
+    final argmax tokens at every one of the 30 848 generated positions, in both segments of the loop; bf16x3 is held to at most 4 differing
+    tokens (measured 0 - 2, profiles/r04_split_token_agreement.txt) and >= 0.9998 agreement at every intermediate step.  The yardstick here
+    is the fp32 MODE; what ties that mode (and these) to the reference at this depth is the c2d golden case above."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import drift_c2
+    r = drift_c2.run(steps=50, batch=64, segment=segment, modes=("f16x3", "bf16x3"))
+    print(r)
+    assert r["f16x3"]["final_tokens_differing"] == 0 and r["f16x3"]["final_token_agreement"] == 1.0, r["f16x3"]
+    assert r["f16x3"]["agreement_min"] >= 0.9999, r["f16x3"]
+    assert r["bf16x3"]["final_tokens_differing"] <= 4 and r["bf16x3"]["agreement_min"] >= 0.9998, r["bf16x3"]
 
 
 def test_full_size_config2_properties():

@@ -48,6 +48,10 @@ def test_two_rank_packed_broadcast_ships_an_untied_head():
     run_ranks("untied", timeout=240)
 
 
+def test_two_rank_lossaware_gather_with_unequal_micro_batches():
+    run_ranks("lossaware", timeout=240)
+
+
 @pytest.mark.parametrize("workload", ["c2", "c4", "train"])
 def test_bench_gpus_2_self_launches_and_reports_two_ranks(workload):
     """`python bench.py --gpus 2` with NO launcher around it (what a SCALE run does): the parent starts two ranks through

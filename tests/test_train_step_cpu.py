@@ -198,3 +198,19 @@ def test_train_loop_has_the_reference_constructor_cadence_and_files(tmp_path):
     a, b = [torch.ones(2)], [torch.zeros(2)]
     update_ema(a, b, rate=0.75)
     assert torch.allclose(a[0], torch.full((2,), 0.75))
+
+
+def test_checkpoint_save_writes_optimizer_state_without_ema_support_and_warns(tmp_path):
+    """train_util.py:310-315 always writes opt_{step}.pt; an injected optimizer that has state but keeps no EMA copies still gets
+    its file, and configured ema rates that nothing can serve are reported instead of silently skipped."""
+    import pytest
+    from musediffusion_amd import checkpoint as ckpt
+
+    class StatefulOpt(HostOpt):
+        def state_dict(self):
+            return {"state": {0: {"step": torch.tensor(3.0)}}, "param_groups": [{"lr": 0.5}]}
+    model = torch.nn.Linear(2, 1)
+    with pytest.warns(UserWarning, match="keeps no EMA copies"):
+        ckpt.save(str(tmp_path), 5, model, StatefulOpt(list(model.parameters())), [0.9])
+    assert sorted(os.listdir(tmp_path)) == ["model_000005.pt", "opt_000005.pt"]
+    assert float(torch.load(tmp_path / "opt_000005.pt")["state"][0]["step"]) == 3.0

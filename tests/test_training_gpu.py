@@ -79,6 +79,32 @@ def test_training_losses_and_grads_match_reference(variant):
         assert p.grad is not None and torch.isfinite(p.grad).all(), n
 
 
+@pytest.mark.parametrize("variant", ["plain", "corrupt"])
+def test_training_losses_with_predict_xstart_false_match_reference(variant):
+    """`_x0_helper` (diffusion.py:577-592) with predict_xstart=False: the model output is read as the noise, the t == 0 rows' loss and
+    the logged nll use x0 = sqrt(1 / ab_t) x_t - sqrt(1 / ab_t - 1) eps while the t > 0 rows still compare the raw output with the target
+    latent.  Fixture: tests/golden/losses_tiny_eps.npz, the reference run with that flag (tools/make_golden.py eps)."""
+    tag = "tiny"
+    g = load_golden("losses_tiny_eps.npz")
+    m, _, c = build(tag)
+    diff = SpacedDiffusion(use_timesteps=space_timesteps(2000, [2000]), betas=get_named_beta_schedule("sqrt", 2000),
+                           rescale_timesteps=True, predict_xstart=False)
+    li = fx.loss_inputs(tag)
+    batch, t, w = li["batch"], li["t"].to(DEV), li["w"].to(DEV)
+    assert int(t[0]) == 0                      # the row that takes the x0-from-eps branch
+    kw = {k: v for k, v in batch.items() if variant == "corrupt" or k != "correct_ids"}
+    with CpuDraws(fx.loss_seed(tag)):
+        terms = diff.training_losses(m, t, model_kwargs=kw)
+    for k in ("mse", "nll", "loss"):
+        close("eps %s %s" % (variant, k), terms[k], g["%s_%s" % (variant, k)], 5e-4)
+    assert not np.allclose(g[variant + "_nll"], load_golden("losses_tiny.npz")[variant + "_nll"])   # the flag changes what is measured
+    (terms["loss"] * w).mean().backward()
+    close("eps " + variant + " grad word_embedding", m.word_embedding.weight.grad, g[variant + "_g_word"], 2e-3)
+    close("eps " + variant + " grad layer0.query", m.input_transformers.layer[0].attention.self.query.weight.grad, g[variant + "_g_q0"], 2e-3)
+    close("eps " + variant + " grad time_embed.0", m.time_embed[0].weight.grad, g[variant + "_g_te0"], 2e-3)
+    close("eps " + variant + " grad lm_head.bias", m.lm_head.bias.grad, g[variant + "_g_lmb"], 2e-3)
+
+
 @pytest.mark.parametrize("compute_dtype", ["fp32", "bf16"])
 @pytest.mark.parametrize("variant", ["plain", "corrupt"])
 def test_training_losses_at_config5_shape_match_reference(variant, compute_dtype):

@@ -49,7 +49,7 @@ def npy(t):
     return t.detach().cpu().numpy() if torch.is_tensor(t) else np.asarray(t)
 
 
-def build(cfg, dropout=0.0):
+def build(cfg, dropout=0.0, predict_xstart=True):
     """create_model_and_diffusion through the reference factory (utils/initialization.py:108-136)."""
     _BERT.clear()
     _BERT.update(hidden_size=cfg["H"], num_hidden_layers=cfg["nL"], num_attention_heads=cfg["nh"],
@@ -58,7 +58,7 @@ def build(cfg, dropout=0.0):
     args = SimpleNamespace(hidden_dim=cfg["E"], hidden_t_dim=cfg["Tt"], vocab_size=cfg["V"],
                            seq_len=cfg["L"], dropout=dropout, noise_schedule="sqrt",
                            diffusion_steps=2000, timestep_respacing="",
-                           rescale_timesteps=True, predict_xstart=True)
+                           rescale_timesteps=True, predict_xstart=predict_xstart)
     return create_model_and_diffusion(args)
 
 
@@ -156,7 +156,8 @@ def gen_model_case(tag, compact):
     keep("fwd_y", y)
     keep("fwd_emb_t", model.time_embed(model.timestep_embedding(inp["fwd_t"], model.hidden_t_dim)))
     for i, h in enumerate(hiddens):
-        keep("fwd_hidden%d" % i, h)
+        if i in fx.HIDDEN_KEEP.get(tag, range(len(hiddens))):
+            keep("fwd_hidden%d" % i, h)
     # ---- logits / rounding (network.py:91-93, rounding.py:21-47)
     keep("logits", model.get_logits(y))
     keep("logits_argmax", torch.argmax(model.get_logits(y), dim=-1))
@@ -213,12 +214,13 @@ def gen_model_case(tag, compact):
     print("model_%s.npz" % tag, len(out), "arrays")
 
 
-def gen_losses(tag, slim=False):
+def gen_losses(tag, slim=False, eps=False):
     """training_losses both variants (diffusion.py:594-699), dropout 0, grads of four parameters (slim: + two more, large
-    matrices kept as every 4th row and column - oracle.fixtures.slim)."""
+    matrices kept as every 4th row and column - oracle.fixtures.slim).  eps: predict_xstart=False (the `_x0_helper` branch of
+    diffusion.py:586-590: the model output is read as the noise) -> losses_<tag>_eps.npz."""
     keepg = (lambda t: npy(fx.slim(t))) if slim else npy
     cfg = fx.CONFIGS[tag]
-    model, diffusion = build(cfg, dropout=0.0)
+    model, diffusion = build(cfg, dropout=0.0, predict_xstart=not eps)
     sd = fx.state_dict(tag)
     model.load_state_dict(sd)
     model.train().requires_grad_(True)
@@ -240,8 +242,9 @@ def gen_losses(tag, slim=False):
         if slim:
             out["%s_g_v1" % variant] = keepg(model.input_transformers.layer[1].attention.self.value.weight.grad)
             out["%s_g_ff2" % variant] = keepg(model.input_transformers.layer[0].output.dense.weight.grad)
-    np.savez_compressed(os.path.join(OUT, "losses_%s.npz" % tag), **out)
-    print("losses_%s.npz" % tag, len(out), "arrays")
+    name = "losses_%s%s.npz" % (tag, "_eps" if eps else "")
+    np.savez_compressed(os.path.join(OUT, name), **out)
+    print(name, len(out), "arrays")
 
 
 class InjectedDropout:
@@ -411,6 +414,11 @@ if __name__ == "__main__":
         gen_model_case("c2s", compact=True)      # BASELINE config 2's width and seq_len (2 layers, 2 sequences)
         gen_losses("c5s", slim=True)             # config 5's seq_len 1024, same width
         gen_losses_dropout("c5s", slim=True)
+    if not only or "eps" in only:
+        gen_losses("tiny", eps=True)             # training_losses with predict_xstart=False (diffusion.py:577-592)
+    if not only or "deep" in only:
+        gen_model_case("c2d", compact=True)      # config 2's TRUE depth: 12 layers, seq_len 512, 2 sequences
+        gen_model_case("bbd", compact=True)      # bert-base as the reference instantiates it: 12 layers of H 768
     if not only or "bertbase" in only:
         gen_model_case("bb", compact=True)       # the reference-true width (H 768, 12 heads of 64, ffn 3072)
         gen_model_case("bb500", compact=True)    # ... with the released weights' E = 500
