@@ -17,8 +17,10 @@
 
 namespace {
 
-constexpr int HT_ROWS = 64;                 // token rows per block
-constexpr int HT_SLAB = HT_ROWS * 64;       // bytes of one K32 step of the A operand (64 rows x 64 B)
+// token rows per block (template parameter ROWS): 64 at d_model 256 / 512; 32 at d_model 768 (bert-base, the reference-true width:
+// network.py:44-46), where 64 rows of a 768-wide intermediate plus three weight stages would need 240 KB of LDS - there the ring has
+// TWO slots, refilled between a K step's fragment reads and its MFMAs (the same two stages in flight).  One K32 step of the A operand
+// = ROWS x 64 B (a "slab").
 // G = {0, 2, 3, 1} as a packed table (no memory lookup)
 __device__ __forceinline__ int ht_g(int x) { return (0x78 >> (2 * x)) & 3; }
 
@@ -69,55 +71,76 @@ __device__ __forceinline__ void ht_issue_w(const bf16* __restrict__ w, int kt, c
   }
 }
 
-// 16 MFMAs of a wave's 64 x 64 sub-tile for one K32 step: A rows from a 64-row slab, W rows from a ring slot
-__device__ __forceinline__ void ht_kstep(f32x4 (&acc)[4][4], const char* a_slab, const char* w_slot, int a_off, const int (&b_offs)[4]) {
-  bf16x8 a[4], b[4];
+// 4 RT MFMAs of a wave's (16 RT) x 64 sub-tile for one K32 step: A rows from a slab, W rows from a ring slot
+template <int RT>
+__device__ __forceinline__ void ht_kstep(f32x4 (&acc)[RT][4], const char* a_slab, const char* w_slot, int a_off, const int (&b_offs)[4]) {
+  bf16x8 a[RT], b[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const bf16x8*>(w_slot + b_offs[j]);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const bf16x8*>(a_slab + a_off + i * 1024);
+  for (int i = 0; i < RT; ++i) a[i] = *reinterpret_cast<const bf16x8*>(a_slab + a_off + i * 1024);
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < RT; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
 }
 
-// K loop over nk K32 steps: A slabs resident in LDS (a_base + kt * HT_SLAB), W streamed through a 3-slot ring.  `issued`: stages the
-// caller already put in flight (0 .. 2, issued as the wave's LAST vector-memory operations).  PER = pieces per wave and stage.
+// K loop over nk K32 steps: A slabs resident in LDS (a_base + kt * slab bytes), W streamed through an NSLOT-slot ring.  `issued`: stages
+// the caller already put in flight (0 .. 2, issued as the wave's LAST vector-memory operations).  PER = pieces per wave and stage.
 // NO block barrier inside: the pieces a wave DMAs (rows 64 wave .. 64 wave + 63 of the stage) are exactly the W rows its own 64 output
 // columns read, so a stage is private to the wave that loaded it - its own counted vmcnt says when the bytes have landed, its own
-// lgkmcnt when the slot may be refilled - and the eight waves of a block drift apart instead of meeting 16 MFMAs apart.  The caller
+// lgkmcnt when the slot may be refilled - and the waves of a block drift apart instead of meeting 16 MFMAs apart.  The caller
 // publishes the (shared) A slabs with one barrier before the loop.
-template <int WROWS, int NW>
-__device__ __forceinline__ void ht_loop(f32x4 (&acc)[4][4], const bf16* __restrict__ w, int nk, const char* a_base, char* ring, int slot_bytes,
+// NSLOT 3: stage kt + 2 goes into the slot stage kt - 1 was read from, before stage kt's reads.  NSLOT 2: stage kt's fragments go to
+// registers first, then its own slot takes stage kt + 2 - two stages in flight either way.
+template <int WROWS, int NW, int RT, int NSLOT>
+__device__ __forceinline__ void ht_loop(f32x4 (&acc)[RT][4], const bf16* __restrict__ w, int nk, const char* a_base, char* ring, int slot_bytes,
                                         int a_off, const int (&b_offs)[4], int wave, int lane, int issued) {
-  constexpr int PER = (WROWS / 16 + NW - 1) / NW;
+  constexpr int PER = (WROWS / 16 + NW - 1) / NW, SLAB = RT * 16 * 64;
   static_assert(WROWS / 16 == PER * NW, "a wave must load exactly its own rows");
-  for (int st = issued; st < 2 && st < nk; ++st) ht_issue_w<WROWS, NW>(w, st, ring + (st % 3) * slot_bytes, wave, lane);
+  static_assert(NSLOT == 2 || NSLOT == 3, "ring of two or three slots");
+  for (int st = issued; st < 2 && st < nk; ++st) ht_issue_w<WROWS, NW>(w, st, ring + (st % NSLOT) * slot_bytes, wave, lane);
   for (int kt = 0; kt < nk; ++kt) {
     if (kt + 1 < nk) ht_wait_vmcnt<PER>(); else ht_wait_vmcnt<0>();    // this wave's stage kt has landed (stage kt + 1 may still fly)
-    ht_lgkm0();                                                          // ... and its reads of stage kt - 1 are done: that slot is free
-    if (kt + 2 < nk) ht_issue_w<WROWS, NW>(w, kt + 2, ring + ((kt + 2) % 3) * slot_bytes, wave, lane);
-    ht_kstep(acc, a_base + kt * HT_SLAB, ring + (kt % 3) * slot_bytes, a_off, b_offs);
+    if constexpr (NSLOT == 3) {
+      ht_lgkm0();                                                        // ... and its reads of stage kt - 1 are done: that slot is free
+      if (kt + 2 < nk) ht_issue_w<WROWS, NW>(w, kt + 2, ring + ((kt + 2) % 3) * slot_bytes, wave, lane);
+      ht_kstep<RT>(acc, a_base + kt * SLAB, ring + (kt % 3) * slot_bytes, a_off, b_offs);
+    } else {
+      const char* a_slab = a_base + kt * SLAB;
+      const char* w_slot = ring + (kt & 1) * slot_bytes;
+      bf16x8 a[RT], b[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const bf16x8*>(w_slot + b_offs[j]);
+#pragma unroll
+      for (int i = 0; i < RT; ++i) a[i] = *reinterpret_cast<const bf16x8*>(a_slab + a_off + i * 1024);
+      ht_lgkm0();                                                        // stage kt is in registers: its slot takes stage kt + 2
+      if (kt + 2 < nk) ht_issue_w<WROWS, NW>(w, kt + 2, ring + (kt & 1) * slot_bytes, wave, lane);
+#pragma unroll
+      for (int i = 0; i < RT; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+    }
   }
 }
 
-template <int H>
+template <int H, int ROWS = 64>
 __global__ __launch_bounds__(H / 64 * 64, H / 256) void head_fused_kernel(const HeadArgs g) {
-  constexpr int NW = H / 64, THREADS = NW * 64, NK2 = H / 32, SLOT = H * 64;
-  constexpr int H1_BYTES = NK2 * HT_SLAB, LDS_BYTES = H1_BYTES + 3 * SLOT;
+  constexpr int NW = H / 64, THREADS = NW * 64, NK2 = H / 32, SLOT = H * 64, RT = ROWS / 16, SLAB = ROWS * 64;
+  constexpr int NSLOT = NK2 * SLAB + 3 * SLOT <= 160 * 1024 ? 3 : 2;
+  constexpr int H1_BYTES = NK2 * SLAB, LDS_BYTES = H1_BYTES + NSLOT * SLOT;
   static_assert(LDS_BYTES <= 160 * 1024, "head: LDS");
   __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
   char* const h1 = smem;                 // phase 1: the x tile (E_pad / 32 slabs); phase 2: tanh(up0) as A operand (H / 32 slabs)
   char* const ring = smem + H1_BYTES;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fr = lane & 15, fg = lane >> 4;
-  const int64_t row0 = (int64_t)blockIdx.x * HT_ROWS;
+  const int64_t row0 = (int64_t)blockIdx.x * ROWS;
   const int nk1 = g.E_pad / 32;
   // the first two weight stages fly while the x tile is converted
-  for (int st = 0; st < 2 && st < nk1; ++st) ht_issue_w<H, NW>(g.w0, st, ring + (st % 3) * SLOT, wave, lane);
+  for (int st = 0; st < 2 && st < nk1; ++st) ht_issue_w<H, NW>(g.w0, st, ring + (st % NSLOT) * SLOT, wave, lane);
   // x tile: fp32 [64, E] -> bf16 slabs; a thread owns 16-byte chunks (row, 8 columns)
-  for (int c = tid; c < HT_ROWS * (g.E_pad / 8); c += THREADS) {
+  for (int c = tid; c < ROWS * (g.E_pad / 8); c += THREADS) {
     const int row = c / (g.E_pad / 8), ch = c % (g.E_pad / 8), col = ch * 8;
     int64_t r = row0 + row; if (r >= g.rows) r = g.rows - 1;
     float v[8];
@@ -129,7 +152,7 @@ __global__ __launch_bounds__(H / 64 * 64, H / 256) void head_fused_kernel(const 
     bf16x8 o;
 #pragma unroll
     for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
-    *reinterpret_cast<bf16x8*>(h1 + (ch >> 2) * HT_SLAB + row * 64 + (((ch & 3) ^ ht_g((row >> 2) & 3)) << 4)) = o;
+    *reinterpret_cast<bf16x8*>(h1 + (ch >> 2) * SLAB + row * 64 + (((ch & 3) ^ ht_g((row >> 2) & 3)) << 4)) = o;
   }
   const int a_off = fr * 64 + ((fg ^ ht_g((fr >> 2) & 3)) << 4);
   int b_offs[4];
@@ -138,41 +161,41 @@ __global__ __launch_bounds__(H / 64 * 64, H / 256) void head_fused_kernel(const 
     const int row = wave * 64 + 32 * (jj >> 1) + 8 * (fr >> 2) + 4 * (jj & 1) + (fr & 3);
     b_offs[jj] = row * 64 + ((fg ^ ht_g((row >> 2) & 3)) << 4);
   }
-  f32x4 acc[4][4];
+  f32x4 acc[RT][4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < RT; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   // ---- phase 1: [64, E_pad] . W0^T
   ht_lgkm0();
   __builtin_amdgcn_s_barrier();           // the x tile is complete (the K loop itself has no barrier: its W stages are wave-private)
-  ht_loop<H, NW>(acc, g.w0, nk1, h1, ring, SLOT, a_off, b_offs, wave, lane, nk1 < 2 ? nk1 : 2);
+  ht_loop<H, NW, RT, NSLOT>(acc, g.w0, nk1, h1, ring, SLOT, a_off, b_offs, wave, lane, nk1 < 2 ? nk1 : 2);
   ht_lgkm0();
   __builtin_amdgcn_s_barrier();           // every wave is done with the x tile and the ring
-  for (int st = 0; st < 2; ++st) ht_issue_w<H, NW>(g.w2, st, ring + (st % 3) * SLOT, wave, lane);   // phase 2's first stages fly under the epilogue
+  for (int st = 0; st < 2; ++st) ht_issue_w<H, NW>(g.w2, st, ring + (st % NSLOT) * SLOT, wave, lane);   // phase 2's first stages fly under the epilogue
   // epilogue 1: tanh(acc + b0) -> bf16 -> the A slabs of phase 2.  Lane: row 16 i + fr, columns 64 wave + 32 h + 8 fg + e
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     float bv[8];
     load8(g.b0 + wave * 64 + 32 * h + 8 * fg, bv);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < RT; ++i) {
       const int row = 16 * i + fr;
       bf16x8 o;
 #pragma unroll
       for (int e = 0; e < 8; ++e) o[e] = (bf16)tanh_fast(acc[i][2 * h + (e >> 2)][e & 3] + bv[e]);
-      *reinterpret_cast<bf16x8*>(h1 + (2 * wave + h) * HT_SLAB + row * 64 + ((fg ^ ht_g((row >> 2) & 3)) << 4)) = o;
+      *reinterpret_cast<bf16x8*>(h1 + (2 * wave + h) * SLAB + row * 64 + ((fg ^ ht_g((row >> 2) & 3)) << 4)) = o;
     }
   }
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < RT; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   // the position rows of the second epilogue (64 distinct table rows per block, 128 KB from L2) are requested here and arrive under
   // phase 2 instead of standing between its last MFMA and the LayerNorm: 64 registers held across the loop
-  float posv[2][4][8];
+  float posv[2][RT][8];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < RT; ++i) {
     int64_t r = row0 + 16 * i + fr; if (r >= g.rows) r = g.rows - 1;
     const float* prow = g.pos + (r % g.L) * H;
 #pragma unroll
@@ -181,26 +204,28 @@ __global__ __launch_bounds__(H / 64 * 64, H / 256) void head_fused_kernel(const 
   // ---- phase 2: [64, H] . W2^T
   ht_lgkm0();
   __builtin_amdgcn_s_barrier();           // the tanh slabs are complete
-  ht_loop<H, NW>(acc, g.w2, NK2, h1, ring, SLOT, a_off, b_offs, wave, lane, 2);
+  ht_loop<H, NW, RT, NSLOT>(acc, g.w2, NK2, h1, ring, SLOT, a_off, b_offs, wave, lane, 2);
   ht_lgkm0();
   __builtin_amdgcn_s_barrier();           // the ring is idle: its first bytes take the row statistics
   // ---- epilogue 2: (pos + (acc + b2)) + emb_t, LayerNorm over the row (two passes: in-lane -> 4 lanes -> NW waves through LDS)
   float* red = reinterpret_cast<float*>(ring);          // [64][NW]
-  const float* trow[4];
+  const float* trow[RT];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < RT; ++i) {
     int64_t r = row0 + 16 * i + fr; if (r >= g.rows) r = g.rows - 1;
     const int64_t b = r / g.L;
     trow[i] = g.emb_t + (int64_t)(g.emb_row ? g.emb_row[b] : (int)b) * H;
   }
-  float rs[4] = {0.f, 0.f, 0.f, 0.f};
+  float rs[RT];
+#pragma unroll
+  for (int i = 0; i < RT; ++i) rs[i] = 0.f;
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     const int col = wave * 64 + 32 * h + 8 * fg;
     float bv[8];
     load8(g.b2 + col, bv);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < RT; ++i) {
       float t[8];
       load8(trow[i] + col, t);
 #pragma unroll
@@ -212,11 +237,11 @@ __global__ __launch_bounds__(H / 64 * 64, H / 256) void head_fused_kernel(const 
     }
   }
   const float invH = 1.0f / (float)H;
-  float mean[4], rstd[4];
+  float mean[RT], rstd[RT];
 #pragma unroll
   for (int pass = 0; pass < 2; ++pass) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < RT; ++i) {
       float v = rs[i];
       v += __shfl_xor(v, 16, 64);
       v += __shfl_xor(v, 32, 64);
@@ -225,7 +250,7 @@ __global__ __launch_bounds__(H / 64 * 64, H / 256) void head_fused_kernel(const 
     ht_lgkm0();
     __builtin_amdgcn_s_barrier();
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < RT; ++i) {
       float t = 0.f;
 #pragma unroll
       for (int w = 0; w < NW; ++w) t += red[(16 * i + fr) * NW + w];
@@ -251,7 +276,7 @@ __global__ __launch_bounds__(H / 64 * 64, H / 256) void head_fused_kernel(const 
     load8(g.gamma + col, gv);
     load8(g.beta + col, bt);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < RT; ++i) {
       const int64_t r = row0 + 16 * i + fr;
       if (r < g.rows) {
         float v[8];
@@ -272,30 +297,32 @@ __global__ __launch_bounds__(H / 64 * 64, H / 256) void head_fused_kernel(const 
 // accumulation.  A wave owns 16 TJ3 table rows; -(clamp((|T_v|^2 + |x_n|^2) - 2 x.T_v, 0)) and the first-index argmax exactly as the
 // score GEMM's epilogue + argbest_reduce do them, folded lane -> 4 lanes -> waves through LDS.  Replaces the exact-fp32 score GEMM
 // launch (30 us per half batch) in the bf16 throughput mode; the fp32 parity mode keeps the exact-fp32 MFMA path.
-template <int H, int TJ3 = 0>
+template <int H, int TJ3 = 0, int ROWS = 64>
 __global__ __launch_bounds__(H / 64 * 64, H / 256) void tail_fused_kernel(const TailArgs g) {
-  constexpr int NW = H / 64, NK = H / 32, SLOT = H * 64;
-  constexpr int H1_BYTES = NK * HT_SLAB, LDS_BYTES = H1_BYTES + 3 * SLOT;
+  constexpr int NW = H / 64, NK = H / 32, SLOT = H * 64, RT = ROWS / 16, SLAB = ROWS * 64;
+  constexpr int NSLOT = NK * SLAB + 3 * SLOT <= 160 * 1024 ? 3 : 2;
+  constexpr int H1_BYTES = NK * SLAB, LDS_BYTES = H1_BYTES + NSLOT * SLOT;
   __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
   char* const h1 = smem;
   char* const ring = smem + H1_BYTES;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fr = lane & 15, fg = lane >> 4;
-  const int64_t row0 = (int64_t)blockIdx.x * HT_ROWS;
+  const int64_t row0 = (int64_t)blockIdx.x * ROWS;
   // A rows: 4 pieces (16 rows x 64 B) per K32 step, NK steps, dealt over the waves; then the first two weight stages
   {
     const int rl = lane >> 2, pc = lane & 3, lc = pc ^ ht_g((rl >> 2) & 3);
-    constexpr int PIECES = NK * 4, PER = PIECES / NW;
+    constexpr int PIECES = NK * RT, PER = PIECES / NW;
+    static_assert(PIECES == PER * NW, "tail: the A pieces must deal evenly over the waves");
 #pragma unroll
     for (int j = 0; j < PER; ++j) {
-      const int p = wave * PER + j, kt = p >> 2, rb = (p & 3) * 16;
+      const int p = wave * PER + j, kt = p / RT, rb = (p % RT) * 16;
       int64_t r = row0 + rb + rl; if (r >= g.rows) r = g.rows - 1;
       const bf16* src = g.X + ((int64_t)kt * g.ldx + r) * 32 + lc * 8;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(h1 + kt * HT_SLAB + rb * 64), 16, 0, 2);   // nt: read once
+                                       (__attribute__((address_space(3))) void*)(h1 + kt * SLAB + rb * 64), 16, 0, 2);   // nt: read once
     }
   }
-  for (int st = 0; st < 2; ++st) ht_issue_w<H, NW>(g.w0, st, ring + (st % 3) * SLOT, wave, lane);
+  for (int st = 0; st < 2; ++st) ht_issue_w<H, NW>(g.w0, st, ring + (st % NSLOT) * SLOT, wave, lane);
   const int a_off = fr * 64 + ((fg ^ ht_g((fr >> 2) & 3)) << 4);
   int b_offs[4];
 #pragma unroll
@@ -303,65 +330,81 @@ __global__ __launch_bounds__(H / 64 * 64, H / 256) void tail_fused_kernel(const 
     const int row = wave * 64 + 32 * (jj >> 1) + 8 * (fr >> 2) + 4 * (jj & 1) + (fr & 3);
     b_offs[jj] = row * 64 + ((fg ^ ht_g((row >> 2) & 3)) << 4);
   }
-  f32x4 acc[4][4];
+  f32x4 acc[RT][4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < RT; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   ht_wait_vmcnt<2 * (H / 16 / NW)>();     // this wave's pieces of the A rows have landed (the two weight stages behind them may still fly)
   __builtin_amdgcn_s_barrier();           // ... and everybody else's: the A slabs are shared, the weight stages are wave-private
-  ht_loop<H, NW>(acc, g.w0, NK, h1, ring, SLOT, a_off, b_offs, wave, lane, 2);
+  ht_loop<H, NW, RT, NSLOT>(acc, g.w0, NK, h1, ring, SLOT, a_off, b_offs, wave, lane, 2);
   ht_lgkm0();
   __builtin_amdgcn_s_barrier();
   // second layer's weight stages: E rows x 64 B each
   const int E16 = g.E / 16;                       // 16-column groups of the output (8 for E = 128)
-  auto issue2 = [&](int kt) {
+  // (d_model 768: 12 waves for E / 16 = 8 column groups - the upper waves sit this layer out; a wave that repeated a lower wave's piece
+  // would refill a slot that wave may still be reading)
+  const bool w2_active = wave < E16;
+  auto issue2 = [&](int kt, int slot) {
     const int rl = lane >> 2, pc = lane & 3, lc = pc ^ ht_g((rl >> 2) & 3);
     const int p = wave % E16;
     const bf16* src = g.w2 + ((int64_t)kt * g.E + p * 16 + rl) * 32 + lc * 8;
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                     (__attribute__((address_space(3))) void*)(ring + (kt % 3) * SLOT + p * 1024), 16, 0, 0);
+                                     (__attribute__((address_space(3))) void*)(ring + slot * SLOT + p * 1024), 16, 0, 0);
   };
-  issue2(0);
-  issue2(1);
+  if (w2_active) {
+    issue2(0, 0);
+    issue2(1, 1);
+  }
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     float bv[8];
     load8(g.b0 + wave * 64 + 32 * h + 8 * fg, bv);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < RT; ++i) {
       const int row = 16 * i + fr;
       bf16x8 o;
 #pragma unroll
       for (int e = 0; e < 8; ++e) o[e] = (bf16)tanh_fast(acc[i][2 * h + (e >> 2)][e & 3] + bv[e]);
-      *reinterpret_cast<bf16x8*>(h1 + (2 * wave + h) * HT_SLAB + row * 64 + ((fg ^ ht_g((row >> 2) & 3)) << 4)) = o;
+      *reinterpret_cast<bf16x8*>(h1 + (2 * wave + h) * SLAB + row * 64 + ((fg ^ ht_g((row >> 2) & 3)) << 4)) = o;
     }
   }
   // ---- second layer: wave -> output columns 16 p .. 16 p + 15, p = wave % (E / 16); D[m = 4 fg + r][n = fr]: 4 consecutive columns of row fr
   const int p2 = wave % E16;
   const int b2_off = (p2 * 16 + fr) * 64 + ((fg ^ ht_g((fr >> 2) & 3)) << 4);
-  f32x4 y[4];
+  f32x4 y[RT];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) y[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int i = 0; i < RT; ++i) y[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   ht_lgkm0();
   __builtin_amdgcn_s_barrier();                   // the tanh slabs are complete (the loop's weight pieces are wave-private: no barrier inside)
+  if (w2_active)
   for (int kt = 0; kt < NK; ++kt) {
     if (kt + 1 < NK) ht_wait_vmcnt<1>(); else ht_wait_vmcnt<0>();
-    ht_lgkm0();
-    if (kt + 2 < NK) issue2(kt + 2);
-    const bf16x8 b = *reinterpret_cast<const bf16x8*>(ring + (kt % 3) * SLOT + b2_off);
-    bf16x8 a[4];
+    bf16x8 b, a[RT];
+    if constexpr (NSLOT == 3) {
+      ht_lgkm0();
+      if (kt + 2 < NK) issue2(kt + 2, (kt + 2) % 3);
+      b = *reinterpret_cast<const bf16x8*>(ring + (kt % 3) * SLOT + b2_off);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const bf16x8*>(h1 + kt * HT_SLAB + a_off + i * 1024);
+      for (int i = 0; i < RT; ++i) a[i] = *reinterpret_cast<const bf16x8*>(h1 + kt * SLAB + a_off + i * 1024);
+    } else {   // two slots: the stage's fragments go to registers first, then its own slot takes stage kt + 2
+      b = *reinterpret_cast<const bf16x8*>(ring + (kt & 1) * SLOT + b2_off);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) y[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, a[i], y[i], 0, 0, 0);
+      for (int i = 0; i < RT; ++i) a[i] = *reinterpret_cast<const bf16x8*>(h1 + kt * SLAB + a_off + i * 1024);
+      ht_lgkm0();
+      if (kt + 2 < NK) issue2(kt + 2, kt & 1);
+    }
+#pragma unroll
+    for (int i = 0; i < RT; ++i) y[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, a[i], y[i], 0, 0, 0);
   }
-  float ss[4] = {0.f, 0.f, 0.f, 0.f};
-  if (wave < E16) {
+  float ss[RT];
+#pragma unroll
+  for (int i = 0; i < RT; ++i) ss[i] = 0.f;
+  if (w2_active) {
     const int col = p2 * 16 + 4 * fg;
     const f32x4 bv = *reinterpret_cast<const f32x4*>(g.b2 + col);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < RT; ++i) {
       const int64_t r = row0 + 16 * i + fr;
       const f32x4 v = y[i] + bv;
       ss[i] = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
@@ -370,7 +413,7 @@ __global__ __launch_bounds__(H / 64 * 64, H / 256) void tail_fused_kernel(const 
   }
   if constexpr (TJ3 > 0) {
     constexpr int VP = 16 * TJ3 * NW, SLOT3 = VP * 64, NK3 = 3 * 4;      // (E = 128: 4 slabs per part, 12 K32 steps)
-    static_assert(2 * SLOT3 <= 3 * SLOT && NK3 * HT_SLAB <= H1_BYTES, "rounding phase: LDS");
+    static_assert(2 * SLOT3 <= NSLOT * SLOT && NK3 * SLAB + (2 * ROWS * NW + ROWS) * 4 <= H1_BYTES, "rounding phase: LDS");
     ht_lgkm0();
     __builtin_amdgcn_s_barrier();           // every wave is past its last fragment read of phase 2: slabs and ring are free
     auto issue3 = [&](int kt) {
@@ -385,23 +428,25 @@ __global__ __launch_bounds__(H / 64 * 64, H / 256) void tail_fused_kernel(const 
     };
     issue3(0);
     // x_hi | x_lo | x_hi slabs: this lane's 4 columns of row 16 i + fr -> 8 bytes in slab col / 32 (+ 4 for the low part, + 8 again the high part)
-    float* red = reinterpret_cast<float*>(h1 + NK3 * HT_SLAB);            // [64][NW] |row|^2 partials, then best scores
-    int* redi = reinterpret_cast<int*>(red + HT_ROWS * NW);               // [64][NW] best indices
-    float* xn = reinterpret_cast<float*>(redi + HT_ROWS * NW);            // [64] |x_n|^2
+    float* red = reinterpret_cast<float*>(h1 + NK3 * SLAB);            // [64][NW] |row|^2 partials, then best scores
+    int* redi = reinterpret_cast<int*>(red + ROWS * NW);               // [64][NW] best indices
+    float* xn = reinterpret_cast<float*>(redi + ROWS * NW);            // [64] |x_n|^2
     {
       const int col = p2 * 16 + 4 * fg;
       const f32x4 bv = *reinterpret_cast<const f32x4*>(g.b2 + col);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < RT; ++i) {
         const int row = 16 * i + fr;
         const f32x4 v = y[i] + bv;
         bf16x4 hi, lo;
 #pragma unroll
         for (int e = 0; e < 4; ++e) { hi[e] = (bf16)v[e]; lo[e] = (bf16)(v[e] - (float)hi[e]); }
-        char* dst = h1 + (col >> 5) * HT_SLAB + row * 64 + (((((col & 31) >> 3)) ^ ht_g((row >> 2) & 3)) << 4) + (col & 4) * 2;
-        *reinterpret_cast<bf16x4*>(dst) = hi;
-        *reinterpret_cast<bf16x4*>(dst + 4 * HT_SLAB) = lo;
-        *reinterpret_cast<bf16x4*>(dst + 8 * HT_SLAB) = hi;
+        char* dst = h1 + (col >> 5) * SLAB + row * 64 + (((((col & 31) >> 3)) ^ ht_g((row >> 2) & 3)) << 4) + (col & 4) * 2;
+        if (w2_active) {          // (the waves that hold y; the others add a zero partial below)
+          *reinterpret_cast<bf16x4*>(dst) = hi;
+          *reinterpret_cast<bf16x4*>(dst + 4 * SLAB) = lo;
+          *reinterpret_cast<bf16x4*>(dst + 8 * SLAB) = hi;
+        }
         float v2 = ss[i];
         v2 += __shfl_xor(v2, 16, 64);
         v2 += __shfl_xor(v2, 32, 64);
@@ -410,15 +455,15 @@ __global__ __launch_bounds__(H / 64 * 64, H / 256) void tail_fused_kernel(const 
     }
     ht_lgkm0();
     __builtin_amdgcn_s_barrier();
-    if (tid < HT_ROWS) {
+    if (tid < ROWS) {
       float t = 0.f;
       for (int w = 0; w < NW; ++w) t += red[tid * NW + w];
       xn[tid] = t;
       if (g.sqnorm && row0 + tid < g.rows) g.sqnorm[row0 + tid] = t;
     }
-    f32x4 sc[4][TJ3];
+    f32x4 sc[RT][TJ3];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < RT; ++i)
 #pragma unroll
       for (int j = 0; j < TJ3; ++j) sc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     int b3_offs[TJ3];
@@ -428,13 +473,13 @@ __global__ __launch_bounds__(H / 64 * 64, H / 256) void tail_fused_kernel(const 
       ht_wait_vmcnt<0>();                         // this wave's stage kt has landed
       ht_lgkm0();                                 // ... and its reads of stage kt - 1 are done: that slot takes stage kt + 1
       if (kt + 1 < NK3) issue3(kt + 1);
-      bf16x8 a[4], b[TJ3];
+      bf16x8 a[RT], b[TJ3];
 #pragma unroll
       for (int j = 0; j < TJ3; ++j) b[j] = *reinterpret_cast<const bf16x8*>(ring + (kt & 1) * SLOT3 + b3_offs[j]);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const bf16x8*>(h1 + kt * HT_SLAB + a_off + i * 1024);
+      for (int i = 0; i < RT; ++i) a[i] = *reinterpret_cast<const bf16x8*>(h1 + kt * SLAB + a_off + i * 1024);
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < RT; ++i)
 #pragma unroll
         for (int j = 0; j < TJ3; ++j) sc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], sc[i][j], 0, 0, 0);
     }
@@ -448,7 +493,7 @@ __global__ __launch_bounds__(H / 64 * 64, H / 256) void tail_fused_kernel(const 
     ht_lgkm0();
     __builtin_amdgcn_s_barrier();               // (xn was written before the K loop's first barrier; `red` is reused below)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < RT; ++i) {
       const float x2 = xn[16 * i + fr];
       float best = -INFINITY;
       int bi = 0x7fffffff;
@@ -472,7 +517,7 @@ __global__ __launch_bounds__(H / 64 * 64, H / 256) void tail_fused_kernel(const 
     }
     ht_lgkm0();
     __builtin_amdgcn_s_barrier();
-    if (tid < HT_ROWS && row0 + tid < g.rows) {
+    if (tid < ROWS && row0 + tid < g.rows) {
       float best = -INFINITY;
       int bi = 0x7fffffff;
       for (int w = 0; w < NW; ++w) {              // waves hold increasing column ranges: strict > keeps the first index
@@ -492,7 +537,7 @@ __global__ __launch_bounds__(H / 64 * 64, H / 256) void tail_fused_kernel(const 
     uint32_t rng_step = 0;
     if (g.has_rng) rng_step = g.rng.step ? *g.rng.step : 0u;
     const int gpr = g.E / 4;                      // groups per row
-    for (int q = tid; q < HT_ROWS * gpr; q += NW * 64) {
+    for (int q = tid; q < ROWS * gpr; q += NW * 64) {
       const int row = q / gpr, cg = q - row * gpr;
       const int64_t r = row0 + row;
       if (r >= g.rows) continue;
@@ -525,7 +570,7 @@ __global__ __launch_bounds__(H / 64 * 64, H / 256) void tail_fused_kernel(const 
     __builtin_amdgcn_s_barrier();           // every wave is past its last fragment read: the ring's first bytes are free
     float* red = reinterpret_cast<float*>(ring);          // [64][NW]
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < RT; ++i) {
       float v = ss[i];
       v += __shfl_xor(v, 16, 64);
       v += __shfl_xor(v, 32, 64);
@@ -533,7 +578,7 @@ __global__ __launch_bounds__(H / 64 * 64, H / 256) void tail_fused_kernel(const 
     }
     ht_lgkm0();
     __builtin_amdgcn_s_barrier();
-    if (tid < HT_ROWS) {
+    if (tid < ROWS) {
       float t = 0.f;
       for (int w = 0; w < E16 && w < NW; ++w) t += red[tid * NW + w];
       if (row0 + tid < g.rows) g.sqnorm[row0 + tid] = t;
@@ -553,11 +598,14 @@ extern "C" int mh_denoiser_set_fuse_headtail(int on) {
 #endif
 
 extern "C" int mh_up_proj_ln_fused_supported(int E, int E_pad, int H) {
-  return g_fuse_headtail && (H == 256 || H == 512) && E_pad % 32 == 0 && E_pad <= 128 && E <= E_pad && E % 4 == 0;
+  return g_fuse_headtail && (H == 256 || H == 512 || H == 768) && E_pad % 32 == 0 && E_pad <= 128 && E <= E_pad && E % 4 == 0;
 }
 // (E / 16 == H / 64: every wave owns exactly one 16-column group of the second layer, so its weight pieces are private to it and the K
 // loop needs no barrier; E = 128 at d_model 512, E = 64 at d_model 256)
-extern "C" int mh_down_proj_fused_supported(int E, int H) { return g_fuse_headtail && (H == 256 || H == 512) && E % 16 == 0 && E / 16 == H / 64; }
+// (d_model 768 - bert-base, the width network.py:44-46 builds - has 12 waves: E = 128 occupies eight of them in the second layer)
+extern "C" int mh_down_proj_fused_supported(int E, int H) {
+  return g_fuse_headtail && E % 16 == 0 && (((H == 256 || H == 512) && E / 16 == H / 64) || (H == 768 && E == 128));
+}
 
 extern "C" int mh_up_proj_ln_fused(const float* x, int E, int E_pad, const void* w0, const float* b0, const void* w2, const float* b2,
                                    const float* pos, const float* emb_t, const int32_t* emb_row, const float* gamma, const float* beta,
@@ -565,9 +613,11 @@ extern "C" int mh_up_proj_ln_fused(const float* x, int E, int E_pad, const void*
   MH_CHECK_ARG(x && w0 && b0 && w2 && b2 && pos && emb_t && gamma && beta && out && B > 0 && L > 0, "up_proj_ln_fused: bad arguments");
   MH_CHECK_ARG(mh_up_proj_ln_fused_supported(E, E_pad, H), "up_proj_ln_fused: shape E=%d E_pad=%d H=%d not served", E, E_pad, H);
   HeadArgs g{x, (int64_t)B * L, E, E_pad, L, (const bf16*)w0, b0, (const bf16*)w2, b2, pos, emb_t, emb_row, gamma, beta, eps, (bf16*)out, ldo};
-  const dim3 grid((unsigned)((g.rows + HT_ROWS - 1) / HT_ROWS));
+  const int rpb = H == 768 ? 32 : 64;      // token rows per block
+  const dim3 grid((unsigned)((g.rows + rpb - 1) / rpb));
   mh_prof_note("head rows=%lld E=%d H=%d", (long long)g.rows, E, H);
-  if (H == 512) MH_LAUNCH((head_fused_kernel<512>), grid, dim3(512), 0, (hipStream_t)stream, g);
+  if (H == 768) MH_LAUNCH((head_fused_kernel<768, 32>), grid, dim3(768), 0, (hipStream_t)stream, g);
+  else if (H == 512) MH_LAUNCH((head_fused_kernel<512>), grid, dim3(512), 0, (hipStream_t)stream, g);
   else MH_LAUNCH((head_fused_kernel<256>), grid, dim3(256), 0, (hipStream_t)stream, g);
   MH_CHECK_LAUNCH();
   return MH_OK;
@@ -576,7 +626,7 @@ extern "C" int mh_up_proj_ln_fused(const float* x, int E, int E_pad, const void*
 // the rounding phase is built for the ComMU vocabulary on the config-2 width: E = 128 (8 waves x 16 output columns, 12 K32 steps of
 // hi | lo | hi parts), d_model 512, 640 < V <= 768 (six 16-row table tiles per wave)
 extern "C" int mh_down_proj_round_supported(int E, int H, int V) {
-  return mh_down_proj_fused_supported(E, H) && E == 128 && H == 512 && V > 640 && V <= 768;
+  return mh_down_proj_fused_supported(E, H) && E == 128 && (H == 512 || H == 768) && V > 640 && V <= 768;
 }
 extern "C" size_t mh_round_split_bytes(int E, int V) { return (size_t)(3 * E / 32) * 768 * 32 * 2 + 768 * 4; }
 namespace {
@@ -634,9 +684,11 @@ extern "C" int mh_down_proj_round_fused(const void* X, int64_t ldx, const void* 
       g.rng = StepRng{(uint32_t)upd->rng->seed, (uint32_t)(upd->rng->seed >> 32), upd->rng->stream_id, upd->rng->bound, upd->rng->step_counter,
                       (uint64_t)(upd->rng->first_elem >> 2)};
   }
-  const dim3 grid((unsigned)((rows + HT_ROWS - 1) / HT_ROWS));
+  const int rpb = H == 768 ? 32 : 64;
+  const dim3 grid((unsigned)((rows + rpb - 1) / rpb));
   mh_prof_note("tail+round%s rows=%lld E=%d H=%d V=%d", upd ? "+update" : "", (long long)rows, E, H, V);
-  MH_LAUNCH((tail_fused_kernel<512, 6>), grid, dim3(512), 0, (hipStream_t)stream, g);
+  if (H == 768) MH_LAUNCH((tail_fused_kernel<768, 4, 32>), grid, dim3(768), 0, (hipStream_t)stream, g);   // 12 waves x 4 table tiles of 16 rows = 768
+  else MH_LAUNCH((tail_fused_kernel<512, 6>), grid, dim3(512), 0, (hipStream_t)stream, g);
   MH_CHECK_LAUNCH();
   return MH_OK;
 }
@@ -647,9 +699,11 @@ extern "C" int mh_down_proj_fused(const void* X, int64_t ldx, const void* w0, co
   MH_CHECK_ARG(mh_down_proj_fused_supported(E, H), "down_proj_fused: shape E=%d H=%d not served", E, H);
   TailArgs g{(const bf16*)X, ldx, rows, E, (const bf16*)w0, b0, (const bf16*)w2, b2, out, out_sqnorm, nullptr, nullptr, 0, nullptr};
   g.x = nullptr;
-  const dim3 grid((unsigned)((rows + HT_ROWS - 1) / HT_ROWS));
+  const int rpb = H == 768 ? 32 : 64;
+  const dim3 grid((unsigned)((rows + rpb - 1) / rpb));
   mh_prof_note("tail rows=%lld E=%d H=%d", (long long)rows, E, H);
-  if (H == 512) MH_LAUNCH((tail_fused_kernel<512>), grid, dim3(512), 0, (hipStream_t)stream, g);
+  if (H == 768) MH_LAUNCH((tail_fused_kernel<768, 0, 32>), grid, dim3(768), 0, (hipStream_t)stream, g);
+  else if (H == 512) MH_LAUNCH((tail_fused_kernel<512>), grid, dim3(512), 0, (hipStream_t)stream, g);
   else MH_LAUNCH((tail_fused_kernel<256>), grid, dim3(256), 0, (hipStream_t)stream, g);
   MH_CHECK_LAUNCH();
   return MH_OK;

@@ -223,7 +223,10 @@ class _Linear(Function):
     Output [M, pad64(N)] with zero padding columns."""
 
     @staticmethod
-    def forward(ctx, x, W, b, act, residual, dt, drop=None, prep=None, ln=None):
+    def forward(ctx, x, W, b, act, residual, dt, drop=None, prep=None, ln=None, passthrough=False):
+        # passthrough: also return x itself as a second output.  A consumer that takes THAT as its residual sends the residual branch's
+        # gradient back through this node, where the input-gradient GEMM adds it in its epilogue (fp32 accumulator + residual, one
+        # rounding) - instead of autograd summing the two branches with a separate bf16 add kernel per layer and step
         M, Kp = x.shape
         N, K = W.shape
         Np = ops.pad64(N)
@@ -254,10 +257,10 @@ class _Linear(Function):
         ctx.save_for_backward(x, Wc, pre if act is not None else None)
         ctx.ln = ln
         ctx.meta = (act, dt, N, K, Kp, Np, residual is not None, b is not None)
-        return y
+        return (y, x.view_as(x)) if passthrough else y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dx_branch=None):
         x, Wc, pre = ctx.saved_tensors
         act, dt, N, K, Kp, Np, has_res, has_b = ctx.meta
         M = x.shape[0]
@@ -272,10 +275,10 @@ class _Linear(Function):
         # dX = dpre W : reduction over the N outputs
         WT = ctx.WT if ctx.WT is not None else _transpose(Wc, N, Kp, dt, ld_out=Np)                      # [Kp, Np]
         dx = _zeros(M, Kp, dt, x.device, Kp)
-        _gemm(dpre, WT, None, dt, Kp, Np, out=dx)
+        _gemm(dpre, WT, None, dt, Kp, Np, out=dx, residual=None if dx_branch is None else dx_branch.contiguous())
         # dW = dpre^T X : reduction over the M rows
         dW, db = _dw(dpre, x, N, Kp, M, dt, bias=True) if has_b else (_dw(dpre, x, N, Kp, M, dt), None)
-        return dx, dW[:, :K].contiguous(), db, None, (dy if has_res else None), None, None, None, None
+        return dx, dW[:, :K].contiguous(), db, None, (dy if has_res else None), None, None, None, None, None
 
 
 class _FFN(Function):
@@ -690,6 +693,45 @@ class _TokenCE(Function):
 
 
 # ---------------------------------------------------------------------------------------------- composites
+class _StackRows(Function):
+    """The [3H, K] weight of the fused query | key | value projection as a TAPE node: with _WeightPrep's packed working copy its values
+    are never read (_Linear takes the shape from it and the operand from `prep`), so nothing is copied - round 4 ran a 3 MB fp32
+    torch.cat per layer and step plus its CatBackward here.  Without the working copy (fp32 mode, shapes _WeightPrep does not serve)
+    the rows are concatenated as before.  The backward hands each parameter its rows of the stacked gradient (views, no copy)."""
+
+    @staticmethod
+    def forward(ctx, copy, *parts):
+        ctx.rows = [int(p.shape[0]) for p in parts]
+        if copy:
+            return torch.cat([p.detach() for p in parts], dim=0)
+        return parts[0].new_empty((sum(ctx.rows),) + tuple(parts[0].shape[1:]))
+
+    @staticmethod
+    def backward(ctx, g):
+        return (None,) + tuple(g.split(ctx.rows, dim=0))
+
+
+class _PackVectors(Function):
+    """Every layer's query | key | value bias as ONE concatenation per forward (36 small tensors, one launch; round 4: a torch.cat per
+    layer): returns one [3H] view per layer; the backward splits each layer's gradient back into its three parameters (views)."""
+
+    @staticmethod
+    def forward(ctx, group, *vecs):
+        ctx.sizes = [int(v.numel()) for v in vecs]
+        ctx.group = int(group)
+        packed = torch.cat([v.detach().reshape(-1) for v in vecs])
+        per = [sum(ctx.sizes[i:i + group]) for i in range(0, len(vecs), group)]
+        return tuple(packed.split(per))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        out = []
+        for li, g in enumerate(gs):
+            sz = ctx.sizes[li * ctx.group:(li + 1) * ctx.group]
+            out += [None] * len(sz) if g is None else list(g.split(sz))
+        return (None,) + tuple(out)
+
+
 def _linear(x, lin, act, dt, residual=None, drop=None, prep=None, ln=None):
     return _Linear.apply(x, lin.weight, lin.bias, act, residual, dt, drop, prep, ln)
 
@@ -847,14 +889,16 @@ def denoiser_forward_with_grad(model, x, timesteps):
     d_emb = sites.site("emb", sites.p_emb)
     if d_emb is not None:
         X = _Dropout.apply(X, dt, d_emb)                                                          # network.py:149
+    selfs = [getattr(layer.attention, "self") for layer in model.input_transformers.layer]
+    bqkv_all = _PackVectors.apply(3, *[lin.bias for sa in selfs for lin in (sa.query, sa.key, sa.value)]) if selfs else ()
     for li, layer in enumerate(model.input_transformers.layer):
-        sa = getattr(layer.attention, "self")
-        Wqkv = torch.cat([sa.query.weight, sa.key.weight, sa.value.weight], dim=0)
-        bqkv = torch.cat([sa.query.bias, sa.key.bias, sa.value.bias], dim=0)
-        qkv = _Linear.apply(X, Wqkv, bqkv, None, None, dt, None, None if wp is None else (wp.qkv[li], wp.qkv_t[li]))   # [N, 3H]
+        sa = selfs[li]
+        Wqkv = _StackRows.apply(wp is None, sa.query.weight, sa.key.weight, sa.value.weight)      # (values unused when wp holds the copy)
+        # (Xr is X: the attention-output dense takes it as its residual, so that branch's gradient returns through the projection's node)
+        qkv, Xr = _Linear.apply(X, Wqkv, bqkv_all[li], None, None, dt, None, None if wp is None else (wp.qkv[li], wp.qkv_t[li]), None, True)   # [N, 3H]
         ctxv = _Attention.apply(qkv, B, L, model.num_heads, dt, sites.site("l%d.attn" % li, sites.p_att))
         ln1 = _FusedLN(layer.attention.output.LayerNorm)
-        y1 = _linear(ctxv, layer.attention.output.dense, None, dt, residual=X, drop=sites.site("l%d.ao" % li, sites.p_hid),
+        y1 = _linear(ctxv, layer.attention.output.dense, None, dt, residual=Xr, drop=sites.site("l%d.ao" % li, sites.p_hid),
                      prep=None if wp is None else (wp.ao[li], wp.ao_t[li]), ln=ln1)
         X1 = _LayerNorm.apply(y1, layer.attention.output.LayerNorm.weight, layer.attention.output.LayerNorm.bias,
                               layer.attention.output.LayerNorm.eps, dt, ln1)

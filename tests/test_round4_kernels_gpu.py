@@ -33,10 +33,12 @@ def from_panel(p):
     return p.permute(1, 0, 2).reshape(p.shape[1], -1).float().cpu()
 
 
-@pytest.mark.parametrize("H,E,B,L", [(512, 128, 2, 64), (512, 128, 3, 200), (256, 64, 2, 72), (512, 128, 32, 512)])
+# H 768: bert-base, the width the reference itself builds (network.py:44-46) - 32 rows per block, 12 waves, two-slot weight ring
+@pytest.mark.parametrize("H,E,B,L", [(512, 128, 2, 64), (512, 128, 3, 200), (256, 64, 2, 72), (512, 128, 32, 512),
+                                     (768, 128, 2, 64), (768, 128, 3, 200), (768, 96, 2, 72), (768, 128, 16, 512)])
 def test_up_proj_ln_fused(H, E, B, L):
     """(pos + (tanh(x W0^T + b0) W2^T + b2)) + emb, LayerNorm: the intermediate rounded to bf16 once (the second GEMM's operand), fp32
-    from there to the normalised row.  Rows that do not fill the last 64-row block (3 x 200, 2 x 72) are covered."""
+    from there to the normalised row.  Rows that do not fill the last row block (3 x 200, 2 x 72) are covered."""
     N = B * L
     x = rnd(N, E, seed=1, scale=0.5)
     W0, b0 = rnd(H, E, seed=2, scale=1 / math.sqrt(E)), rnd(H, seed=3, scale=0.1)
@@ -68,7 +70,8 @@ def test_up_proj_ln_fused(H, E, B, L):
     assert float((from_panel(out) - ref2).abs().max()) < 4e-2
 
 
-@pytest.mark.parametrize("H,E,N", [(512, 128, 128), (512, 128, 600), (256, 64, 136), (512, 128, 16384)])
+@pytest.mark.parametrize("H,E,N", [(512, 128, 128), (512, 128, 600), (256, 64, 136), (512, 128, 16384),
+                                   (768, 128, 128), (768, 128, 600), (768, 128, 8200)])
 def test_down_proj_fused(H, E, N):
     X = rnd(N, H, seed=11, scale=1.0)
     W0, b0 = rnd(H, H, seed=12, scale=1 / math.sqrt(H)), rnd(H, seed=13, scale=0.1)
@@ -194,13 +197,14 @@ def test_step_with_fused_rounding_pieces_equals_the_separate_launches(kind):
     assert torch.equal(xa[rows_same], xb[rows_same]) and torch.equal(pa[rows_same], pb[rows_same])
 
 
+@pytest.mark.parametrize("H", [512, 768])
 @pytest.mark.parametrize("N,V", [(128, 729), (1000, 729), (16384, 729), (192, 650)])
-def test_down_proj_with_rounding_inside(N, V):
+def test_down_proj_with_rounding_inside(N, V, H):
     """mh_down_proj_round_fused: the down-projection's rows AND their nearest embedding row (models/rounding.py:21-28) from one kernel,
     the scores on the bf16 matrix pipe as hi / lo parts (x_hi T_hi + x_lo T_hi + x_hi T_lo, fp32 accumulation).  Checked against the
     float64 argmin of |x - T_v|^2 on the rows the kernel itself wrote: every row whose two best distances differ by more than the
     split's resolution must agree (the rest are reported), and planted exact matches (x = a table row) must be found."""
-    H, E = 512, 128
+    E = 128
     X = rnd(N, H, seed=31, scale=1.0)
     W0, b0 = rnd(H, H, seed=32, scale=1 / math.sqrt(H)), rnd(H, seed=33, scale=0.1)
     W2, b2 = rnd(E, H, seed=34, scale=1 / math.sqrt(H)), rnd(E, seed=35, scale=0.1)
@@ -263,11 +267,12 @@ def test_attention_with_two_query_tiles_per_wave_equals_the_16_wave_kernel(L, B,
     assert float(outs[0].float().abs().max()) > 0.1
 
 
-def test_fused_head_and_tail_repeat_launches_are_bit_identical_under_load():
+@pytest.mark.parametrize("H", [512, 768])
+def test_fused_head_and_tail_repeat_launches_are_bit_identical_under_load(H):
     """Race screen for the barrier-free K loops (a wave's LDS-DMA stages are private to it, ordered by its own counted vmcnt / lgkmcnt
     only): 120 launches of each kernel on the same operands while a second stream keeps the chip's L2 / DMA paths busy with GEMMs
     of another size - every launch must reproduce the first one bit for bit (a read that overtakes its DMA shows up as a changed row)."""
-    H, E, V, B, L = 512, 128, 729, 8, 512
+    E, V, B, L = 128, 729, 8, 512
     N = B * L
     x = rnd(N, E, seed=41, scale=0.5).to(DEV)
     w0, b0 = to_panel(rnd(H, E, seed=42, scale=1 / math.sqrt(E))), rnd(H, seed=43, scale=0.1).to(DEV)

@@ -31,6 +31,7 @@ ap.add_argument("--width", type=int, default=512, help="d_model: 512 (BASELINE c
 ap.add_argument("--reps", type=int, default=20)
 ap.add_argument("--rounds", type=int, default=7)
 ap.add_argument("--sets", type=int, default=6, help="operand sets of the cold variant")
+ap.add_argument("--only", default="", help="comma list of variants to run (lib, ours, ours+epi); under rocprofv3 `--only lib` names the vendor kernels")
 a = ap.parse_args()
 dev, bf = "cuda", torch.bfloat16
 H = a.width
@@ -84,6 +85,8 @@ def shape_case(name, M, N, K, act, ln):
     v = {"lib": lib, "ours": ours}
     if act or (ln and L.mh_gemm_bias_res_ln_supported(N)):
         v["ours+epi"] = ours_epi
+    if a.only:
+        v = {k: f for k, f in v.items() if k in a.only.split(",")}
     return v
 
 
