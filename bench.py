@@ -846,6 +846,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--sampler", default="uniform", choices=["uniform", "lossaware"], help="train: the timestep sampler (lossaware = the reference's default)")
+    ap.add_argument("--repeats", type=int, default=4, help="sampling workloads: further back-to-back repetitions of the timed region, reported in config.repeats (value = the first region)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the `secondary` object (train / fp32 / bertbase / token agreement) of the default N = 1 config-2 line")
     ap.add_argument("--accum", type=int, default=1, help="train: micro-batches per optimizer step (the reference's batch_size // microbatch)")
     ap.add_argument("--split", type=int, default=None, help="batch slices run as concurrent graph branches (default: the library's choice)")
@@ -908,7 +909,11 @@ def main():
 
     total = args.warmup + args.steps
     PROF_STEPS = 4
-    loop = make_loop(model, diff, c, "p", device, rank, total + PROF_STEPS + 2)
+    # `repeats`: the same K-step region timed again, back to back in the same loop, so that the line carries its own spread (boxes of the
+    # pool differ by several percent and a 20-step region is 72 ms; `value` is the FIRST region, the contract's)
+    reps = max(0, min(args.repeats, (c["T"] - 16 - total - PROF_STEPS) // max(1, args.steps)))
+    loop = make_loop(model, diff, c, "p", device, rank, total + reps * args.steps + PROF_STEPS + 2)
+    rep_ms = []
     with torch.no_grad():
         loop.begin()
         for k in range(args.warmup):
@@ -918,6 +923,15 @@ def main():
             for k in range(args.warmup, total):
                 loop.advance(k)
         elapsed, _ = timed_region(timed, world, device)
+        for r in range(reps):
+            k0 = total + r * args.steps
+
+            def again():
+                for k in range(k0, k0 + args.steps):
+                    loop.advance(k)
+            el, _ = timed_region(again, world, device)
+            rep_ms.append(el / args.steps * 1e3)
+        total += reps * args.steps
         loop.finish()
     tokens = model.argmax_tokens(loop.x)       # the loop's product: discrete tokens (run/sample.py:219-220)
     assert tokens.shape == (c["B"], c["L"]) and bool(torch.isfinite(loop.x).all())
@@ -942,6 +956,11 @@ def main():
                        "arena_checksum_after_broadcast": None if arena_sum is None else int(arena_sum),
                        "rng": args.rng, "hipgraph": not args.no_graph, "graph_branches": int(loop.nsplit),
                        "decoupled_branches": bool(loop.decoupled), "branch_skew_us": int(getattr(loop, "skew_us", 0)),
+                       "repeats": {"regions": 1 + len(rep_ms), "steps_each": args.steps,
+                                   "ms_per_step": [round(ms_per_step, 4)] + [round(v, 4) for v in rep_ms],
+                                   "median_ms": round(sorted([ms_per_step] + rep_ms)[(len(rep_ms) + 1) // 2], 4),
+                                   "min_ms": round(min([ms_per_step] + rep_ms), 4), "max_ms": round(max([ms_per_step] + rep_ms), 4),
+                                   "note": "the timed region repeated back to back in the same loop; value / ms_per_step = the first region"},
                        "step_tflop": round(flops / 1e12, 4),
                        "step_tflops_achieved": round(flops / (ms_per_step * 1e-3) / 1e12, 2),
                        "sequences_steps_per_s": round(value * c["B"], 1)},

@@ -628,8 +628,10 @@ int launch_gemm(const SpGemmArgs& g0, int act, hipStream_t s) {
 //   O^T += V^T_hi P_lo^T + V^T_lo P_hi^T + V^T_hi P_hi^T
 // q / k: split row-major [2][tokens][ldq] (q at column head dh, k at column koff + head dh; lo part qk_part elements after hi);
 // vt: split row-major [2][H][ldv] (the transposed V projection: row head dh + d, column token); ctx: split panels [2][H/32][ld_ctx][32].
-template <typename T, int DH>
-__global__ __launch_bounds__(256) void split_attn_kernel(const T* __restrict__ QK, int64_t ldq, int koff, int64_t qk_part, const T* __restrict__ VT,
+// NW waves of 32 queries per block: 4 (128 queries), or 8 when the sequence has 256 queries or more - every block streams ALL keys and
+// values of its (batch, head) through LDS, so twice the queries per block halve the global loads and LDS writes per query.
+template <typename T, int DH, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void split_attn_kernel(const T* __restrict__ QK, int64_t ldq, int koff, int64_t qk_part, const T* __restrict__ VT,
                                                          int64_t ldv, int64_t vt_part, T* __restrict__ ctx, int64_t ld_ctx, int H, int L, int nh,
                                                          float scale_log2e) {
   typedef typename Sp<T>::x8 x8;
@@ -640,14 +642,15 @@ __global__ __launch_bounds__(256) void split_attn_kernel(const T* __restrict__ Q
   constexpr int KT_BYTES = 64 * KROWB, VT_BYTES = DH * 128, PART = KT_BYTES + VT_BYTES, BUF = 2 * PART;
   constexpr int KS = DH / 16;           // k-steps of QK^T
   constexpr int DT = (DH + 31) / 32;    // 32-row d tiles of O^T (DH 16: half a tile, the upper rows are zero)
-  constexpr int KCH = (64 * CH + 255) / 256;   // K chunks per thread
-  constexpr int VCH = (DH * 8 + 255) / 256;    // V^T 16-B chunks per thread
+  constexpr int THREADS = 64 * NW;
+  constexpr int KCH = (64 * CH + THREADS - 1) / THREADS;   // K chunks per thread
+  constexpr int VCH = (DH * 8 + THREADS - 1) / THREADS;    // V^T 16-B chunks per thread
   __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = lane >> 5, lq = lane & 31;
   const int bh = blockIdx.y, b = bh / nh, head = bh % nh;
-  const int q0 = blockIdx.x * 128 + wave * 32;
+  const int q0 = blockIdx.x * (32 * NW) + wave * 32;
   const T* Qb[2] = {QK + (int64_t)b * L * ldq + head * DH, QK + qk_part + (int64_t)b * L * ldq + head * DH};
   const T* Kb[2] = {Qb[0] + koff, Qb[1] + koff};
   const T* Vb[2] = {VT + (int64_t)head * DH * ldv + (int64_t)b * L, VT + vt_part + (int64_t)head * DH * ldv + (int64_t)b * L};
@@ -675,7 +678,7 @@ __global__ __launch_bounds__(256) void split_attn_kernel(const T* __restrict__ Q
     for (int p = 0; p < 2; ++p) {
 #pragma unroll
       for (int j = 0; j < KCH; ++j) {
-        const int qd = tid + 256 * j;
+        const int qd = tid + THREADS * j;
         if (qd < 64 * CH) {
           const int row = qd / CH, c = qd % CH;
           int kr = k0 + row; if (kr >= L) kr = L - 1;
@@ -684,7 +687,7 @@ __global__ __launch_bounds__(256) void split_attn_kernel(const T* __restrict__ Q
       }
 #pragma unroll
       for (int j = 0; j < VCH; ++j) {
-        const int qd = tid + 256 * j, d = qd >> 3, c = qd & 7;
+        const int qd = tid + THREADS * j, d = qd >> 3, c = qd & 7;
         const int key = k0 + c * 8;
         if (d < DH && key < L) stV[p][j] = *reinterpret_cast<const f32x4*>(Vb[p] + (int64_t)d * ldv + key);   // (L % 8 == 0)
         else stV[p][j] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -698,7 +701,7 @@ __global__ __launch_bounds__(256) void split_attn_kernel(const T* __restrict__ Q
       char* vb = kb + KT_BYTES;
 #pragma unroll
       for (int j = 0; j < KCH; ++j) {
-        const int qd = tid + 256 * j;
+        const int qd = tid + THREADS * j;
         if (qd < 64 * CH) {
           const int row = qd / CH, c = qd % CH;
           *reinterpret_cast<f32x4*>(kb + row * KROWB + ((c ^ ((row / RPB) & (CH - 1))) << 4)) = stK[p][j];
@@ -706,9 +709,9 @@ __global__ __launch_bounds__(256) void split_attn_kernel(const T* __restrict__ Q
       }
 #pragma unroll
       for (int j = 0; j < VCH; ++j) {
-        const int qd = tid + 256 * j, d = qd >> 3, c = qd & 7;
+        const int qd = tid + THREADS * j, d = qd >> 3, c = qd & 7;
         if (d < DH) {
-          const int sblk = c >> 1, sw = (d >> 1) & 7, half = (c & 1) * 8;
+          const int sblk = c >> 1, sw = ((d >> 1) ^ d) & 7, half = (c & 1) * 8;   // (^ d: rows d, d + 1 of one 16-lane ds_write_b64 group take chunks of opposite parity - with (d >> 1) alone they met on the same banks: 2 M conflict cycles per launch)
           // keys 8c .. 8c+3 -> chunk 2 sblk, keys 8c+4 .. 8c+7 -> chunk 2 sblk + 1: the key order of the P fragment's registers
           f32x2 lo = {stV[p][j][0], stV[p][j][1]}, hi = {stV[p][j][2], stV[p][j][3]};
           *reinterpret_cast<f32x2*>(vb + d * 128 + (((2 * sblk) ^ sw) << 4) + half) = lo;
@@ -797,8 +800,8 @@ __global__ __launch_bounds__(256) void split_attn_kernel(const T* __restrict__ Q
           const int d = dt * 32 + lq;
           x8 vh, vl;
           if (DH % 32 == 0 || d < DH) {
-            vh = *reinterpret_cast<const x8*>(vb0 + d * 128 + (((2 * sp + h) ^ ((d >> 1) & 7)) << 4));
-            vl = *reinterpret_cast<const x8*>(vb0 + PART + d * 128 + (((2 * sp + h) ^ ((d >> 1) & 7)) << 4));
+            vh = *reinterpret_cast<const x8*>(vb0 + d * 128 + (((2 * sp + h) ^ (((d >> 1) ^ d) & 7)) << 4));
+            vl = *reinterpret_cast<const x8*>(vb0 + PART + d * 128 + (((2 * sp + h) ^ (((d >> 1) ^ d) & 7)) << 4));
           } else {
 #pragma unroll
             for (int j = 0; j < 8; ++j) { vh[j] = (T)0.f; vl[j] = (T)0.f; }
@@ -843,10 +846,16 @@ __global__ __launch_bounds__(256) void split_attn_kernel(const T* __restrict__ Q
 template <typename T>
 int launch_attn(const void* qk, int64_t ldq, int koff, int64_t qk_part, const void* vt, int64_t ldv, int64_t vt_part, void* ctx, int64_t ld_ctx, int B, int L,
                 int nh, int dh, float scale, hipStream_t s) {
-  const dim3 grid((unsigned)((L + 127) / 128), (unsigned)(B * nh)), block(256);
   const float sl2 = scale * 1.4426950408889634f;
   const int H = nh * dh;
   mh_prof_note("split attention B=%d L=%d nh=%d dh=%d", B, L, nh, dh);
+  if (dh == 64 && L >= 256) {   // eight waves: 256 queries per block
+    const dim3 grid8((unsigned)((L + 255) / 256), (unsigned)(B * nh)), block8(512);
+    MH_LAUNCH((split_attn_kernel<T, 64, 8>), grid8, block8, 0, s, (const T*)qk, ldq, koff, qk_part, (const T*)vt, ldv, vt_part, (T*)ctx, ld_ctx, H, L, nh, sl2);
+    MH_CHECK_LAUNCH();
+    return MH_OK;
+  }
+  const dim3 grid((unsigned)((L + 127) / 128), (unsigned)(B * nh)), block(256);
   switch (dh) {
     case 16: MH_LAUNCH((split_attn_kernel<T, 16>), grid, block, 0, s, (const T*)qk, ldq, koff, qk_part, (const T*)vt, ldv, vt_part, (T*)ctx, ld_ctx, H, L, nh, sl2); break;
     case 32: MH_LAUNCH((split_attn_kernel<T, 32>), grid, block, 0, s, (const T*)qk, ldq, koff, qk_part, (const T*)vt, ldv, vt_part, (T*)ctx, ld_ctx, H, L, nh, sl2); break;
