@@ -35,6 +35,9 @@ WORKLOADS = {
     "c2": dict(L=512, B=64, E=128, H=512, nL=12, nh=8, F=2048, V=729, Tt=128, T=2000),
     # the reference-true BERT-base denoiser at the same batch (network.py:44)
     "c2-bertbase": dict(L=512, B=64, E=128, H=768, nL=12, nh=12, F=3072, V=729, Tt=128, T=2000),
+    # the configuration the reference itself ships (config/train.py: seq_len 2096, hidden_dim 500 -> README.md:534 "embedding dim 500"; bert-base
+    # encoder, network.py:44-46) at about config 2's token count: 16 sequences x 2096 = 33 536 tokens per step
+    "ref-default": dict(L=2096, B=16, E=500, H=768, nL=12, nh=12, F=3072, V=729, Tt=128, T=2000),
     # BASELINE.json configs[0] shape (plumbing)
     "c1": dict(L=128, B=8, E=128, H=128, nL=2, nh=4, F=512, V=729, Tt=128, T=2000),
     # BASELINE.json configs[2]: modification (run/sample.py:109-114, :195-197): 200 DDIM steps (gap 10), strength 0.75 -> 150 iterations
@@ -815,6 +818,8 @@ def secondary_block(device, budget_note="short timed regions: <= 60 s in total")
                                                           "per reference product, fp32 sums; the golden loops end on the reference's tokens bit for bit in this mode too" % mode))
     guarded("c2_bertbase", lambda: dict(_time_loop(WORKLOADS["c2-bertbase"], "bf16", device, steps=60, warmup=5),
                                         note="the reference-true width (network.py:44: d_model 768, 12 heads, ffn 3072), same batch"))
+    guarded("ref_default", lambda: dict(_time_loop(WORKLOADS["ref-default"], "bf16", device, steps=30, warmup=3),
+                                        note="the reference's own shipped shape: seq_len 2096, embedding dim 500, bert-base encoder; 16 sequences (33 536 tokens per step)"))
 
     def agreement():
         spec = importlib.util.spec_from_file_location("drift_c2", os.path.join(REPO, "tools", "drift_c2.py"))

@@ -571,7 +571,9 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(const float* __restrict__
 // no multiply-subtract per score - 32 of the ~170 vector instructions of a 64-key tile (the kernel is VALU-bound)
 // ABL: timing-only ablations (tools/attn_bench.py --ablate; results are garbage): 1 no softmax vector work, 2 no S^T MFMAs, 4 no P.V MFMAs,
 // 8 no LDS fragment reads, 16 no K / V stage DMA
-template <int DH, int NW = 16, int SK = 256, int DROP = 0, bool FULL = false, bool KVNT = false, bool PRE = false, int ABL = 0>
+// PRIO (A/B, mh_attention_set_stream 9 / 10): one static s_setprio 1 for the younger half of the block's waves (MI355X_MICROARCH.md, two waves
+// per SIMD, item 4: the later-dispatched waves lose every issue arbitration at equal priority)
+template <int DH, int NW = 16, int SK = 256, int DROP = 0, bool FULL = false, bool KVNT = false, bool PRE = false, int ABL = 0, int PRIO = 0>
 __global__ __launch_bounds__(64 * NW) void attn_stream_bf16_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K,
                                                                 const bf16* __restrict__ VT, bf16* __restrict__ ctx,
                                                                 int64_t ld_ctx, int L, int nh, int nbh, float scale_log2e,
@@ -590,6 +592,7 @@ __global__ __launch_bounds__(64 * NW) void attn_stream_bf16_kernel(const bf16* _
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h = lane >> 5, lq = lane & 31;
+  if constexpr (PRIO != 0) { if (wave >= NW / 2) __builtin_amdgcn_s_setprio(1); }
   const int nqb = (L + 32 * NW - 1) / (32 * NW), nst = (L + SK - 1) / SK;   // the last stage / tile may be partial (L % 16 == 0)
   const int nitems = nbh * nqb;
   const int my_items = (nitems - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
@@ -1145,7 +1148,7 @@ int launch_bf16(const bf16* q, const bf16* k, const bf16* vt, bf16* ctx, int64_t
 namespace { MH_KNOB(int, g_attn_stream, 1); }
 #ifdef MH_ABLATE
 extern "C" int mh_attention_set_stream(int on) {
-  g_attn_stream = on < 0 ? 0 : (on > 7 ? 7 : on);
+  g_attn_stream = on < 0 ? 0 : (on > 10 ? 10 : on);
   return MH_OK;
 }
 #endif
@@ -1289,6 +1292,14 @@ int stream_fwd_impl(const void* q, const void* k, const void* vt_perm, void* ctx
       default: mh_set_error("attention_stream: ablation %d not built (1 2 4 6 7 8 16 24 31)", g_attn_abl); return MH_ERR_UNSUPPORTED;
     }
   }
+#ifdef MH_ABLATE
+  // A/B: 8 = 128-key stages on the 16-wave block (first MFMA after 32 KB instead of 64 KB have landed, 64 KB of LDS per block), 9 = static
+  // priority for the younger half of the waves, 10 = both
+  else if (g_attn_stream >= 8 && full && !small && L <= qper && dh == 64)
+    rc = g_attn_stream == 8 ? go(&attn_stream_bf16_kernel<64, 16, 128, 0, true, true>, 4 * 128 * 64 * 2)
+       : g_attn_stream == 9 ? go(&attn_stream_bf16_kernel<64, 16, 256, 0, true, true, false, 0, 1>, 4 * 256 * 64 * 2)
+                            : go(&attn_stream_bf16_kernel<64, 16, 128, 0, true, true, false, 0, 1>, 4 * 128 * 64 * 2);
+#endif
   else if (full && !small && L <= qper)   // one block streams a (batch, head)'s K / V once: nt policy
     rc = dh == 64 ? go(&attn_stream_bf16_kernel<64, 16, 256, 0, true, true>, 4 * 256 * 64 * 2) : go(&attn_stream_bf16_kernel<32, 16, 256, 0, true, true>, 4 * 256 * 32 * 2);
   else if (full && dh == 64) rc = small ? go(&attn_stream_bf16_kernel<64, 8, 128, 0, true>, 4 * 128 * 64 * 2) : go(&attn_stream_bf16_kernel<64, 16, 256, 0, true>, 4 * 256 * 64 * 2);

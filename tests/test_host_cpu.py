@@ -277,3 +277,31 @@ def test_compute_dtype_names():
     for bad in ("fp16", "f16", 7, None, torch.float16):
         with pytest.raises(ValueError):
             ops.dtype_code(bad)
+
+
+def test_ema_file_of_a_tied_model_loads_the_way_the_reference_loads_it():
+    """An `ema_*.pt` file of a model whose head is tied to the embedding carries the EMA embedding under `word_embedding.weight` and the
+    LIVE embedding under `lm_head.weight` (the reference's `_master_params_to_state_dict` walks named_parameters(), which lists the
+    shared Parameter once: utils/train_util.py:321-333; optim.FusedAdamWEMA.ema_state_dict writes the same file).  The reference samples
+    from such a file with a plain `model.load_state_dict(torch.load(path))` (run/sample.py), where the later key wins on the shared tensor:
+    EMA transformer, live embedding / head.  A drop-in must give the same tensors - pinned here (decide explicitly): the
+    product loads through nn.Module.load_state_dict and does NOT prefer either key."""
+    import torch
+    from musediffusion_amd.models.network import TransformerNetModel
+    c = fx.CONFIGS["tiny"]
+    mk = lambda: TransformerNetModel(c["E"], c["E"], c["Tt"], c["V"], c["L"], dropout=0.0, bert_hidden=c["H"], bert_layers=c["nL"],
+                                     bert_heads=c["nh"], bert_ffn=c["F"])
+    m = mk()
+    sd = {k: v.clone() for k, v in fx.state_dict("tiny").items()}
+    ema_emb, live_emb = sd["word_embedding.weight"] * 0.5, sd["word_embedding.weight"] + 1.0
+    sd["word_embedding.weight"], sd["lm_head.weight"] = ema_emb, live_emb
+    m.load_state_dict(sd)
+    keys = list(m.state_dict())
+    assert keys.index("word_embedding.weight") < keys.index("lm_head.weight")      # load order = key order: the head's entry is copied last
+    assert m.lm_head.weight is m.word_embedding.weight and torch.equal(m.word_embedding.weight, live_emb)
+    # what torch itself does with the same dict on an equally tied pair of stock modules (the reference's model is exactly that)
+    emb, head = torch.nn.Embedding(c["V"], c["E"]), torch.nn.Linear(c["E"], c["V"])
+    head.weight = emb.weight
+    pair = torch.nn.ModuleDict({"word_embedding": emb, "lm_head": head})
+    pair.load_state_dict({"word_embedding.weight": ema_emb, "lm_head.weight": live_emb, "lm_head.bias": sd["lm_head.bias"]})
+    assert torch.equal(emb.weight, m.word_embedding.weight)
