@@ -32,8 +32,9 @@ CONFIGS.update({
     # through twelve post-LN layers is held against outputs of the reference itself, not against another mode of this library
     "c2d": dict(H=512, nL=12, nh=8, F=2048, E=128, Tt=128, L=512, B=2, V=729),     # BASELINE config 2's denoiser, 2 sequences
     "bbd": dict(H=768, nL=12, nh=12, F=3072, E=128, Tt=128, L=64, B=2, V=729),     # bert-base as network.py:44-46 builds it
+    "c5d": dict(H=512, nL=12, nh=8, F=2048, E=128, Tt=128, L=1024, B=2, V=729),    # BASELINE config 5's denoiser (training_losses), 2 sequences
 })
-SEEDS = {"tiny": 0, "same": 1, "c1": 2, "bb": 3, "bb500": 4, "c2s": 5, "c5s": 6, "c2d": 7, "bbd": 8}
+SEEDS = {"tiny": 0, "same": 1, "c1": 2, "bb": 3, "bb500": 4, "c2s": 5, "c5s": 6, "c2d": 7, "bbd": 8, "c5d": 9}
 COMPACT = ("c1", "bb", "bb500", "c2s", "c2d", "bbd")   # model fixtures that keep every 8th position of [B, L, *] outputs and no inputs
 HIDDEN_KEEP = {"c2d": (0, 3, 7, 11), "bbd": (0, 3, 7, 11)}   # deep fixtures record these layers' outputs only
 

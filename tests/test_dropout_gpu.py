@@ -255,13 +255,15 @@ def test_training_losses_with_injected_masks_match_reference(variant):
     close(variant + " grad lm_head.bias", m.lm_head.bias.grad, g[variant + "_g_lmb"], 2e-3)
 
 
+@pytest.mark.parametrize("tag", ["c5s", "c5d"])
 @pytest.mark.parametrize("compute_dtype", ["fp32", "bf16"])
-def test_training_losses_with_injected_masks_at_config5_shape(compute_dtype):
+def test_training_losses_with_injected_masks_at_config5_shape(compute_dtype, tag):
     """c5s (seq_len 1024, d_model 512): the reference ran in TRAIN mode with the masks of fixtures.dropout_masks; the product fed the
     same masks - in bf16 through the streaming attention's keep-bit reader, the dropout epilogue of the one-kernel dense + LayerNorm
     and the fused backward kernels - against the reference's recorded losses and gradients ("corrupt" variant)."""
-    tag, variant = "c5s", "corrupt"
-    g = load_golden("losses_c5s_dropout.npz")
+    # c5d (round 5): config 5's true depth of 12 layers
+    variant = "corrupt"
+    g = load_golden("losses_%s_dropout.npz" % tag)
     m, diff, c = build(tag, compute_dtype)
     inject(m, tag)
     li = fx.loss_inputs(tag)

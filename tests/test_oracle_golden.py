@@ -166,7 +166,7 @@ def test_model_case(tag):
     np.testing.assert_array_equal(odn.get_logits(sd, s).argmax(-1).numpy(), g["loop_mod_tokens"])
 
 
-@pytest.mark.parametrize("tag", ["tiny", "c5s", "tiny_eps"])
+@pytest.mark.parametrize("tag", ["tiny", "c5s", "tiny_eps", "c5d"])
 def test_training_losses(tag):
     """c5s: BASELINE config 5's seq_len 1024 at config 2's width (2 layers, 2 sequences); its fixture keeps every 4th row and
     column of the large gradients (fixtures.slim) and two more of them.  tiny_eps: the reference run with predict_xstart=False
@@ -174,7 +174,7 @@ def test_training_losses(tag):
     g = load_golden("losses_%s.npz" % tag)
     eps = tag.endswith("_eps")
     tag = tag.replace("_eps", "")
-    big = tag == "c5s"
+    big = tag in ("c5s", "c5d")          # (c5d, round 5: config 5's true depth of 12 layers)
     cfg = fx.CONFIGS[tag]
     li = fx.loss_inputs(tag)
     batch, t, w = li["batch"], li["t"], li["w"]
@@ -205,12 +205,12 @@ def test_training_losses(tag):
                                        atol=2e-6 if not big else 2e-4 * float(np.abs(ref).max()), err_msg=variant + key)
 
 
-@pytest.mark.parametrize("tag", ["tiny", "c5s"])
+@pytest.mark.parametrize("tag", ["tiny", "c5s", "c5d"])
 def test_training_losses_with_dropout_masks(tag):
     """Train mode: the reference ran with dropout 0.1 at its three kinds of site and the masks of fixtures.dropout_masks
     injected (tools/make_golden.py InjectedDropout); the oracle fed the same masks must give the same losses and gradients."""
     g = load_golden("losses_%s_dropout.npz" % tag)
-    big = tag == "c5s"
+    big = tag in ("c5s", "c5d")
     cfg = fx.CONFIGS[tag]
     p = float(g["p"])
     assert p == fx.DROPOUT_P

@@ -105,15 +105,16 @@ def test_training_losses_with_predict_xstart_false_match_reference(variant):
     close("eps " + variant + " grad lm_head.bias", m.lm_head.bias.grad, g[variant + "_g_lmb"], 2e-3)
 
 
+@pytest.mark.parametrize("tag", ["c5s", "c5d"])
 @pytest.mark.parametrize("compute_dtype", ["fp32", "bf16"])
 @pytest.mark.parametrize("variant", ["plain", "corrupt"])
-def test_training_losses_at_config5_shape_match_reference(variant, compute_dtype):
+def test_training_losses_at_config5_shape_match_reference(variant, compute_dtype, tag):
     """c5s = BASELINE config 5's seq_len 1024 at d_model 512 (2 layers, 2 sequences), losses and six gradients recorded from the
     REFERENCE (tools/make_golden.py bench).  fp32 mode: the parity tolerances of the tiny fixture.  bf16 mode - the benchmarked
     training path: streaming attention forward + fused backward, the one-kernel dense + LayerNorm (N = 512), k-major weight
     gradients - is held to: losses 3e-2, every recorded gradient cosine >= 0.99 and max error <= 6 % of its max-abs."""
-    tag = "c5s"
-    g = load_golden("losses_c5s.npz")
+    # c5d (round 5): the same at config 5's TRUE depth of 12 layers - the tape's error growth through twelve layers against the reference
+    g = load_golden("losses_%s.npz" % tag)
     m, diff, c = build(tag, compute_dtype)
     li = fx.loss_inputs(tag)
     batch, t, w = li["batch"], li["t"].to(DEV), li["w"].to(DEV)

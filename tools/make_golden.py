@@ -419,6 +419,9 @@ if __name__ == "__main__":
     if not only or "deep" in only:
         gen_model_case("c2d", compact=True)      # config 2's TRUE depth: 12 layers, seq_len 512, 2 sequences
         gen_model_case("bbd", compact=True)      # bert-base as the reference instantiates it: 12 layers of H 768
+    if not only or "deeptrain" in only:
+        gen_losses("c5d", slim=True)             # config 5's TRUE depth: training_losses at 12 layers, seq_len 1024
+        gen_losses_dropout("c5d", slim=True)
     if not only or "bertbase" in only:
         gen_model_case("bb", compact=True)       # the reference-true width (H 768, 12 heads of 64, ffn 3072)
         gen_model_case("bb500", compact=True)    # ... with the released weights' E = 500
