@@ -286,6 +286,9 @@ def test_training_losses_with_injected_masks_at_config5_shape(compute_dtype, tag
         else:
             ref = torch.from_numpy(g["%s_%s" % (variant, key)]).flatten()
             got = fx.slim(gr).detach().float().cpu().flatten()
+            if float(ref.abs().max()) < 1e-6:       # lm_head.bias: rounding noise around 0 in the reference (1e-8) - a direction of noise means nothing
+                assert float(got.abs().max()) < 1e-6, key
+                continue
             cos = float(torch.nn.functional.cosine_similarity(got, ref, dim=0))
             print("bf16 dropout %s: cosine %.5f" % (key, cos))
             assert cos >= 0.99, (key, cos)

@@ -140,6 +140,9 @@ def test_training_losses_at_config5_shape_match_reference(variant, compute_dtype
         for key, gr in grads.items():
             ref = torch.from_numpy(g["%s_%s" % (variant, key)]).flatten()
             got = fx.slim(gr).detach().float().cpu().flatten()
+            if float(ref.abs().max()) < 1e-6:       # lm_head.bias at this shape: rounding noise around 0 in the reference (1e-8)
+                assert float(got.abs().max()) < 1e-6, key
+                continue
             cos = float(torch.nn.functional.cosine_similarity(got, ref, dim=0))
             err = float((got - ref).abs().max()) / (float(ref.abs().max()) + 1e-12)
             print("bf16 %s %s: cosine %.5f, max err / absmax %.4f" % (variant, key, cos, err))
