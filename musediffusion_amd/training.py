@@ -30,6 +30,10 @@ GELU_DERIV_FWD = True        # the FFN node keeps gelu'(pre) instead of pre (mh_
 ACT_DERIV = 4                # MH_ACT_DERIV
 WEIGHT_PREP = True      # bf16: the encoder's weight casts / transposes of a forward + backward in one launch (_WeightPrep)
 FUSED_DENSE_LN = True   # bf16, d_model 512: BertSelfOutput / BertOutput dense -> dropout -> + input -> LayerNorm as one kernel
+# round 5: the fused q | k | v projection as tape-only stacking of its three parameters (no fp32 torch.cat per layer and step, one bias pack per
+# forward) and the attention-output dense taking the projection node's pass-through of X as its residual (the residual branch's gradient is
+# added in the projection's input-gradient GEMM, not by an autograd add kernel).  False = round 4's tape (A/B: tools/ab_train.py TAPE_STACK)
+TAPE_STACK = True
 
 
 class _FusedLN:
@@ -890,12 +894,18 @@ def denoiser_forward_with_grad(model, x, timesteps):
     if d_emb is not None:
         X = _Dropout.apply(X, dt, d_emb)                                                          # network.py:149
     selfs = [getattr(layer.attention, "self") for layer in model.input_transformers.layer]
-    bqkv_all = _PackVectors.apply(3, *[lin.bias for sa in selfs for lin in (sa.query, sa.key, sa.value)]) if selfs else ()
+    bqkv_all = _PackVectors.apply(3, *[lin.bias for sa in selfs for lin in (sa.query, sa.key, sa.value)]) if (selfs and TAPE_STACK) else ()
     for li, layer in enumerate(model.input_transformers.layer):
         sa = selfs[li]
-        Wqkv = _StackRows.apply(wp is None, sa.query.weight, sa.key.weight, sa.value.weight)      # (values unused when wp holds the copy)
-        # (Xr is X: the attention-output dense takes it as its residual, so that branch's gradient returns through the projection's node)
-        qkv, Xr = _Linear.apply(X, Wqkv, bqkv_all[li], None, None, dt, None, None if wp is None else (wp.qkv[li], wp.qkv_t[li]), None, True)   # [N, 3H]
+        if TAPE_STACK:
+            Wqkv = _StackRows.apply(wp is None, sa.query.weight, sa.key.weight, sa.value.weight)      # (values unused when wp holds the copy)
+            # (Xr is X: the attention-output dense takes it as its residual, so that branch's gradient returns through the projection's node)
+            qkv, Xr = _Linear.apply(X, Wqkv, bqkv_all[li], None, None, dt, None, None if wp is None else (wp.qkv[li], wp.qkv_t[li]), None, True)   # [N, 3H]
+        else:
+            Wqkv = torch.cat([sa.query.weight, sa.key.weight, sa.value.weight], dim=0)
+            bqkv = torch.cat([sa.query.bias, sa.key.bias, sa.value.bias], dim=0)
+            qkv = _Linear.apply(X, Wqkv, bqkv, None, None, dt, None, None if wp is None else (wp.qkv[li], wp.qkv_t[li]))   # [N, 3H]
+            Xr = X
         ctxv = _Attention.apply(qkv, B, L, model.num_heads, dt, sites.site("l%d.attn" % li, sites.p_att))
         ln1 = _FusedLN(layer.attention.output.LayerNorm)
         y1 = _linear(ctxv, layer.attention.output.dense, None, dt, residual=Xr, drop=sites.site("l%d.ao" % li, sites.p_hid),

@@ -438,6 +438,51 @@ def test_one_launch_weight_copies_give_the_same_tape():
         training.WEIGHT_PREP = True
 
 
+@pytest.mark.parametrize("compute_dtype", ["bf16", "fp32"])
+def test_stacked_projection_tape_equals_the_concatenating_tape(compute_dtype):
+    """training.TAPE_STACK (round 5): the q | k | v projection's three parameters stacked on the tape only (no fp32 torch.cat per layer and
+    step; one bias pack per forward) and the residual branch's gradient added inside the projection's input-gradient GEMM, against round
+    4's tape (torch.cat + an autograd add per layer).  Same losses bit for bit (the forward is unchanged); every parameter's gradient
+    agrees to the one rounding the new form saves (the sum of the two branches is rounded once instead of twice in bf16; fp32: reorder)."""
+    from musediffusion_amd import training
+    torch.manual_seed(6)
+    E, H, B, V, L = 32, 128, 2, 97, 64
+    m = TransformerNetModel(E, E, 32, V, L, dropout=0.0, bert_hidden=H, bert_layers=3, bert_heads=2, bert_ffn=256,
+                            compute_dtype=compute_dtype, bert_hidden_dropout=0.0, bert_attention_dropout=0.0)
+    m.train().requires_grad_(True).to(DEV)
+    diff = SpacedDiffusion(use_timesteps=space_timesteps(2000, [2000]), betas=get_named_beta_schedule("sqrt", 2000),
+                           rescale_timesteps=True, predict_xstart=True)
+    gen = torch.Generator().manual_seed(9)
+    ids = torch.randint(3, V, (B, L), generator=gen)
+    batch = {"input_ids": ids, "input_mask": torch.ones(B, L, dtype=torch.long), "correct_ids": ids.clone()}
+    t = torch.tensor([400, 1500], device=DEV)
+
+    def run():
+        m.zero_grad(set_to_none=True)
+        with CpuDraws(11):
+            terms = diff.training_losses(m, t, model_kwargs=batch)
+        terms["loss"].mean().backward()
+        return terms["loss"].detach().clone(), {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None}
+    try:
+        training.TAPE_STACK = True
+        l1, g1 = run()
+        training.TAPE_STACK = False
+        l0, g0 = run()
+    finally:
+        training.TAPE_STACK = True
+    assert torch.equal(l0, l1) and g0.keys() == g1.keys()
+    for n in g0:
+        a, b = g1[n].float().flatten(), g0[n].float().flatten()
+        if float(b.abs().max()) < 1e-5:          # the key bias: its gradient is zero in exact arithmetic (softmax is shift-invariant per query)
+            assert float(a.abs().max()) < 1e-5, n
+            continue
+        cos = float(torch.nn.functional.cosine_similarity(a, b, dim=0))
+        err = float((a - b).abs().max()) / (float(b.abs().max()) + 1e-20)
+        assert cos > (0.9995 if compute_dtype == "bf16" else 0.999999) and err < (3e-2 if compute_dtype == "bf16" else 1e-4), (n, cos, err)
+    sa = getattr(m.input_transformers.layer[0].attention, "self")
+    assert sa.query.weight.grad.data_ptr() % 16 == 0 and sa.key.weight.grad.data_ptr() % 16 == 0       # the optimizer reads 16-byte pieces
+
+
 @pytest.mark.parametrize("tag,variant", [("c1", "corrupt"), ("same", "plain")])
 def test_every_parameter_gradient_matches_oracle(tag, variant):
     """EVERY parameter's gradient (LayerNorm gains / biases, position table, projections, ... - the golden file holds four) of
