@@ -402,6 +402,9 @@ using CfgWidePP = BigCfg<256, 256, 2, 4, 4, true>;
 // 256x256 on FOUR waves: one wave per SIMD with a 128x128 wave tile (256 accumulator registers of a 512-register wave) - 16 fragment
 // reads per 64 MFMAs instead of 24, 8 DMA pieces per wave and K-step.  A/B only (variant 6 / wide_roles bit 5; VERDICT r4 item 1's geometry)
 using CfgWide4 = BigCfg<256, 256, 2, 2, 4>;
+// 256x128 on EIGHT waves (64x64 wave tiles, one block per CU): the geometry whose accumulators (64 registers) would leave room to carry the
+// previous tile's epilogue through the K loop.  A/B only (variant 7): what the geometry itself costs before any carrying
+using CfgStd8 = BigCfg<256, 128, 4, 2, 3>;
 using CfgRowPP = BigCfg<128, 512, 2, 4, 3, true>;
 using CfgRow64 = BigCfg<64, 512, 1, 8, 3>;   // full-row tile over 64 rows: twice the blocks of CfgRow (short K: the epilogue dominates)
 constexpr int B2K = 32;
@@ -1170,7 +1173,13 @@ __global__ __launch_bounds__(C::THREADS, C::STAGE * C::NST <= 80 * 1024 ? 2 : 1)
                 } else {
                   // streaming stores for outputs read once, much later or by a streaming reader; the deferred-LayerNorm producers' raw
                   // rows are re-read at once as A operand and residual: ordinary stores (c2-bertbase -2.0 % step time, A/B of two builds)
-                  if constexpr ((DBG & 32) != 0 || DO) store8(outT + oo, v); else store8_nt(outT + oo, v);
+                  if constexpr ((DBG & 2048) != 0) {   // timing-only ablation: the epilogue's arithmetic without its stores (values kept live)
+                    float keep = 0.f;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) keep += v[e];
+                    if (keep == 12345.678f) store8(outT + oo, v);
+                  }
+                  else if constexpr ((DBG & 32) != 0 || DO) store8(outT + oo, v); else store8_nt(outT + oo, v);
                 }
               }
             }
@@ -1229,7 +1238,7 @@ int launch_big(const GemmArgs& g0, hipStream_t s, int batch) {
   MH_CHECK_ARG(t2 > 0 && t2 < (1ll << 31), "gemm: bad grid (M=%lld N=%d)", (long long)g.M, g.N);
   // persistent: one block per CU slot walks the tiles (no re-launch, the ring stays allocated)
   const int cus = device_cus();
-  const int per_cu = C::STAGE * C::NST <= 80 * 1024 ? 2 : 1;
+  const int per_cu = (C::STAGE * C::NST <= 80 * 1024 && C::NW <= 4) ? 2 : 1;
   const int64_t slots = (int64_t)cus * per_cu;
   g.ntiles = (int)t2;
   g.stagger = g_stagger;
@@ -1265,6 +1274,9 @@ int launch_big(const GemmArgs& g0, hipStream_t s, int batch) {
         case 13: MH_LAUNCH((gemm_big_kernel<C, 0, MH_ACT_NONE, 13>), grid, block, 0, s, g); break;
         case 20: MH_LAUNCH((gemm_big_kernel<C, 0, MH_ACT_NONE, 20>), grid, block, 0, s, g); break;
         case 28: MH_LAUNCH((gemm_big_kernel<C, 0, MH_ACT_NONE, 28>), grid, block, 0, s, g); break;
+        case 3: MH_LAUNCH((gemm_big_kernel<C, 0, MH_ACT_GELU_ERF, 2048>), grid, block, 0, s, g); break;      // bias + GELU, no stores
+        case 7: MH_LAUNCH((gemm_big_kernel<C, 0, MH_ACT_GELU_ERF, 2049>), grid, block, 0, s, g); break;      // ... and no stage DMA
+        case 9: MH_LAUNCH((gemm_big_kernel<C, 0, MH_ACT_NONE, 2048>), grid, block, 0, s, g); break;          // bias only, no stores
         default: MH_LAUNCH((gemm_big_kernel<C, 0, MH_ACT_NONE, 14>), grid, block, 0, s, g); break;
       }
     } else if (defer) {
@@ -1368,6 +1380,9 @@ int launch(const GemmArgs& g, int dtype, hipStream_t s, int batch = 1) {
             return (g_wide_roles & 8) ? launch_row_gelu<CfgRowPP>(g, s, batch) : launch_row_gelu<CfgRow>(g, s, batch);
         }
 #endif
+#ifdef MH_ABLATE
+        if constexpr (EPI == 0) { if (g_variant == 7) return launch_big<CfgStd8, EPI>(g, s, batch); }
+#endif
         if (want_wide(g, batch) && (EPI != 1 || g.H % 64 == 0)) {
 #ifdef MH_ABLATE
           if ((g_variant == 6 || (g_wide_roles & 32)) && (EPI != 1 || g.H % 128 == 0)) return launch_big<CfgWide4, EPI>(g, s, batch);
@@ -1442,7 +1457,7 @@ extern "C" int mh_gemm_set_auto_wide(int on) {
 
 #ifdef MH_ABLATE
 extern "C" int mh_gemm_set_variant(int variant) {
-  MH_CHECK_ARG(variant >= 0 && variant <= 6, "gemm_set_variant: variant must be 0..6");
+  MH_CHECK_ARG(variant >= 0 && variant <= 7, "gemm_set_variant: variant must be 0..7");
   g_variant = variant;
   return MH_OK;
 }
