@@ -434,6 +434,7 @@ __device__ __forceinline__ void issue_stage(const char* smem, const char* const 
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcA[j] + kt * kstepA),
                                        (__attribute__((address_space(3))) void*)(base + ldsA[j]), 16, 0, 0);
   }
+  if constexpr ((DBG & 4096) != 0) return;   // timing-only ablation: the W pieces are not issued (what their issue costs the loop)
 #pragma unroll
   for (int j = 0; j < C::PW; ++j)
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcW[j] + kt * kstepW),
@@ -482,6 +483,7 @@ __device__ __forceinline__ void big_mainloop(f32x4 (&acc)[C::TI][C::TJ], const c
                                              int nk, int a_off, const int (&b_offs)[C::TJ], int64_t kstepA, int64_t kstepW,
                                              int pre, unsigned* prof = nullptr) {
   constexpr int TI = C::TI, TJ = C::TJ;
+  constexpr int NPIECES = (DBG & 4096) != 0 ? C::PA : C::PIECES;   // (ablation 4096: only the A pieces are issued)
   // DBG bit 4 (tools/gemm_bench.py --dbg 28): per-wave shader-clock totals of the three phases of a K-step
   unsigned long long pt_wait = 0, pt_bar = 0, pt_work = 0, pt0 = 0, pt1 = 0;
   auto tick = [&]() -> unsigned long long { if constexpr ((DBG & 16) != 0) return __builtin_amdgcn_s_memtime(); else return 0ull; };
@@ -493,14 +495,14 @@ __device__ __forceinline__ void big_mainloop(f32x4 (&acc)[C::TI][C::TJ], const c
   unsigned long long pc0 = 0, pr0 = 0;
   if constexpr ((DBG & 16) != 0) { pc0 = __builtin_amdgcn_s_memtime(); pr0 = __builtin_amdgcn_s_memrealtime(); }
   const int npro = nk < C::NST ? nk : C::NST;
-  constexpr bool COUNTED = NSTORE > 0 && (C::NST - 1) * C::PIECES + NSTORE <= 63;
+  constexpr bool COUNTED = NSTORE > 0 && (C::NST - 1) * NPIECES + NSTORE <= 63;
   if (pre == 2 && COUNTED) {
-    wait_stages<C::PIECES, COUNTED ? NSTORE : 0>(npro - 1);   // stage 0 landed; stages 1.. and the stores stay in flight
+    wait_stages<NPIECES, COUNTED ? NSTORE : 0>(npro - 1);   // stage 0 landed; stages 1.. and the stores stay in flight
   } else if (pre) {   // the stages were issued before the previous tile's epilogue, whose stores share the counter: drain all
     wait_vmcnt<0>();
   } else {
     for (int st = 0; st < npro; ++st) issue(st);
-    wait_stages<C::PIECES>(npro - 1);
+    wait_stages<NPIECES>(npro - 1);
   }
   __builtin_amdgcn_s_barrier();
   bf16x8 a[TI], b[TJ], bn[TJ];
@@ -530,8 +532,8 @@ __device__ __forceinline__ void big_mainloop(f32x4 (&acc)[C::TI][C::TJ], const c
     pt0 = tick();
     if (kt > 0) pt_work += pt0 - pt1;
     // stage kt+1 was prefetched before the stores for kt + 1 < NST: the stores are younger than it
-    if (pre == 2 && COUNTED && kt + 1 < C::NST) wait_stages<C::PIECES, COUNTED ? NSTORE : 0>(younger);
-    else wait_stages<C::PIECES>(younger);
+    if (pre == 2 && COUNTED && kt + 1 < C::NST) wait_stages<NPIECES, COUNTED ? NSTORE : 0>(younger);
+    else wait_stages<NPIECES>(younger);
     __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0)
     pt1 = tick();
     pt_wait += pt1 - pt0;
@@ -1277,6 +1279,7 @@ int launch_big(const GemmArgs& g0, hipStream_t s, int batch) {
         case 3: MH_LAUNCH((gemm_big_kernel<C, 0, MH_ACT_GELU_ERF, 2048>), grid, block, 0, s, g); break;      // bias + GELU, no stores
         case 7: MH_LAUNCH((gemm_big_kernel<C, 0, MH_ACT_GELU_ERF, 2049>), grid, block, 0, s, g); break;      // ... and no stage DMA
         case 9: MH_LAUNCH((gemm_big_kernel<C, 0, MH_ACT_NONE, 2048>), grid, block, 0, s, g); break;          // bias only, no stores
+        case 10: MH_LAUNCH((gemm_big_kernel<C, 0, MH_ACT_NONE, 4096 + 4>), grid, block, 0, s, g); break;     // no epilogue, no W pieces
         default: MH_LAUNCH((gemm_big_kernel<C, 0, MH_ACT_NONE, 14>), grid, block, 0, s, g); break;
       }
     } else if (defer) {
