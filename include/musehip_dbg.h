@@ -84,6 +84,11 @@ int mh_gemm_set_stagger(int ticks);
 /* experiment knob (A/B only): LDS-DMA pieces of the 256x128 kernels issued between the MFMA rows instead of as one burst */
 int mh_gemm_set_spread(int on);
 
+/* A/B: 1 = the plain 256x128 kernels (dense + GELU, the QKV projection) start their accumulators from the bias - an LDS-DMA piece per wave in
+ * front of the tile's first stage - and their epilogues have no bias add; 0 (default: the other form measured 4 % slower inside the step) = the
+ * bias added in the epilogue */
+int mh_gemm_set_bias_acc(int on);
+
 #ifdef __cplusplus
 }
 #endif

@@ -247,6 +247,7 @@ DBG_SIGNATURES = {
     "mh_denoiser_set_prescale_q": (INT, [INT]),
     "mh_attention_set_ablation": (INT, [INT]),
     "mh_gemm_set_stagger": (INT, [INT]),
+    "mh_gemm_set_bias_acc": (INT, [INT]),
     "mh_gemm_set_spread": (INT, [INT]),
 }
 

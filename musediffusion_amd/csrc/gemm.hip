@@ -477,11 +477,13 @@ template <int PIECES, int EXTRA = 0> __device__ __forceinline__ void wait_stages
 // `pre`: 0 = issue the first stages here; 1 = they were issued before the previous tile's epilogue: drain everything (stores
 // included); 2 = the same, and that epilogue issued exactly NSTORE stores per wave (a full tile): the waits for the prefetched
 // stages count the stores as younger operations instead of waiting for them, so the stores drain under this tile's first K-steps.
+// bias_lds (DBG bit 8192 kernels): the wave's 64 bias values (fp32, in column order) as its own LDS-DMA piece, issued before the tile's first
+// stage: the accumulators START from the bias (one register write each, which the zero fill cost anyway) and the epilogue has no bias add.
 template <class C, bool SWAP, int DBG, int NSTORE = 0>
 __device__ __forceinline__ void big_mainloop(f32x4 (&acc)[C::TI][C::TJ], const char* smem, const char* const (&srcA)[C::PA],
                                              const char* const (&srcW)[C::PW], const int (&ldsA)[C::PA], const int (&ldsW)[C::PW],
                                              int nk, int a_off, const int (&b_offs)[C::TJ], int64_t kstepA, int64_t kstepW,
-                                             int pre, unsigned* prof = nullptr) {
+                                             int pre, unsigned* prof = nullptr, const char* bias_lds = nullptr) {
   constexpr int TI = C::TI, TJ = C::TJ;
   constexpr int NPIECES = (DBG & 4096) != 0 ? C::PA : C::PIECES;   // (ablation 4096: only the A pieces are issued)
   // DBG bit 4 (tools/gemm_bench.py --dbg 28): per-wave shader-clock totals of the three phases of a K-step
@@ -505,6 +507,24 @@ __device__ __forceinline__ void big_mainloop(f32x4 (&acc)[C::TI][C::TJ], const c
     wait_stages<NPIECES>(npro - 1);
   }
   __builtin_amdgcn_s_barrier();
+  if constexpr ((DBG & 8192) != 0) {   // (the wave's own piece: its counted wait above covers it)
+    const int fr_ = threadIdx.x & 15, fg_ = (threadIdx.x & 63) >> 4;
+    if constexpr (SWAP) {   // acc[i][2 qh + (e >> 2)][e & 3] <- bias of column 32 qh + 8 fg + e of the wave's 64-column groups
+#pragma unroll
+      for (int j = 0; j < TJ; ++j) {
+        const f32x4 bj = *reinterpret_cast<const f32x4*>(bias_lds + ((j >> 2) * 64 + 32 * ((j >> 1) & 1) + 8 * fg_ + 4 * (j & 1)) * 4);
+#pragma unroll
+        for (int i = 0; i < TI; ++i) acc[i][j] = bj;
+      }
+    } else {                // un-swapped (V^T waves): acc[i][j][r] is column 16 j + fr of the wave
+#pragma unroll
+      for (int j = 0; j < TJ; ++j) {
+        const float bj = *reinterpret_cast<const float*>(bias_lds + (16 * j + fr_) * 4);
+#pragma unroll
+        for (int i = 0; i < TI; ++i) acc[i][j] = f32x4{bj, bj, bj, bj};
+      }
+    }
+  }
   bf16x8 a[TI], b[TJ], bn[TJ];
 #pragma unroll
   for (int j = 0; j < TJ; ++j) b[j] = read_frag(smem + C::BM * 64 + b_offs[j]);
@@ -639,9 +659,10 @@ template <class C, bool SWAP, int DBG, int NSTORE = 0>
 __device__ __forceinline__ void run_mainloop(f32x4 (&acc)[C::TI][C::TJ], const char* smem, const char* const (&srcA)[C::PA],
                                              const char* const (&srcW)[C::PW], const int (&ldsA)[C::PA], const int (&ldsW)[C::PW],
                                              int nk, int a_off, const int (&b_offs)[C::TJ], int64_t kstepA, int64_t kstepW,
-                                             int group, int pre, unsigned* prof = nullptr) {
+                                             int group, int pre, unsigned* prof = nullptr, const char* bias_lds = nullptr) {
+  static_assert(!(C::PP && (DBG & 8192) != 0), "bias-initialised accumulators: plain main loop only");
   if constexpr (C::PP) pp_mainloop<C, SWAP, DBG>(acc, smem, srcA, srcW, ldsA, ldsW, nk, a_off, b_offs, kstepA, kstepW, group, pre != 0);
-  else big_mainloop<C, SWAP, DBG, NSTORE>(acc, smem, srcA, srcW, ldsA, ldsW, nk, a_off, b_offs, kstepA, kstepW, pre, prof);
+  else big_mainloop<C, SWAP, DBG, NSTORE>(acc, smem, srcA, srcW, ldsA, ldsW, nk, a_off, b_offs, kstepA, kstepW, pre, prof, bias_lds);
 }
 
 // EPI: 0 generic (bias / act / residual), 1 QKV head scatter, 3 bias + residual + LayerNorm over complete rows
@@ -654,6 +675,9 @@ __global__ __launch_bounds__(C::THREADS, C::STAGE * C::NST <= 80 * 1024 ? 2 : 1)
   // deferred LayerNorm (DeferArgs), one compiled variant per operand combination so that unused vectors cost no registers:
   // DA = A rows raw, DR = residual rows raw, DO = write the output rows' partial statistics
   constexpr bool DA = (DBG & 128) != 0, DR = (DBG & 256) != 0, DO = (DBG & 512) != 0, DEFER = DA || DR || DO;
+  // BIASACC (round 5): the accumulators start from the bias (big_mainloop), one 1-KiB LDS piece per wave behind the ring
+  constexpr bool BIASACC = (DBG & 8192) != 0;
+  static_assert(!BIASACC || (!DEFER && EPI != 3 && !C::PP && C::TJ == 4), "bias-initialised accumulators: plain 256x128 kernels only");
   constexpr int TI_ = C::TI, TJ_ = C::TJ;
   // (EPI 3 stages the tile's residual rows through LDS after the main loop: each wave's TI x TJ/2 KiB go where the ring was;
   // a last wave that does not fit - the 128x512 tile: 8 x 16 KiB against a 120 KiB ring - gets its own area at the end)
@@ -661,7 +685,7 @@ __global__ __launch_bounds__(C::THREADS, C::STAGE * C::NST <= 80 * 1024 ? 2 : 1)
   constexpr bool RES_EXTRA = EPI == 3 && C::NW * RES_W > RING;
   static_assert(EPI != 3 || (C::NW - 1) * RES_W <= RING, "residual staging: at most the last wave may overflow the ring");
   __shared__ __attribute__((aligned(16))) char smem[C::NST * C::STAGE + (EPI == 3 ? C::BM * C::WN * 4 + 3 * C::BN * 4 : 0) +
-                                                    (DEFER ? C::BM * 8 * (2 + C::WN) : 0) + (RES_EXTRA ? RES_W : 0)];
+                                                    (DEFER ? C::BM * 8 * (2 + C::WN) : 0) + (RES_EXTRA ? RES_W : 0) + (BIASACC ? C::NW * 1024 : 0)];
   constexpr int TI = C::TI, TJ = C::TJ;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -713,6 +737,16 @@ __global__ __launch_bounds__(C::THREADS, C::STAGE * C::NST <= 80 * 1024 ? 2 : 1)
     }
     __syncthreads();
   }
+  const char* const bias_lds = smem + C::NST * C::STAGE + wave * 1024;     // (BIASACC only)
+  // the wave's 64 bias values of tile `tile` -> its LDS piece (lanes 0 - 15 carry them, the others repeat: an LDS-DMA piece is 64 x 16 B)
+  auto issue_bias = [&](int tile) {
+    if constexpr (BIASACC) {
+      const int tn0 = (xcd_remap(tile, g.ntiles) % tiles_n) * C::BN;
+      const float* src = g.bias + tn0 + wn * (TJ_ * 16) + 4 * (lane & 15);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)const_cast<char*>(bias_lds), 16, 0, 0);
+    }
+  };
   int pre = 0;   // 1 / 2: this tile's first stages were issued before the previous tile's epilogue (2: a full tile's, see big_mainloop)
   // persistent: after a tile's main loop the ring is idle, so the next tile's first stages are put in flight
   // BEFORE the epilogue: their latency (an HBM miss for the A rows) hides behind the stores
@@ -729,6 +763,7 @@ __global__ __launch_bounds__(C::THREADS, C::STAGE * C::NST <= 80 * 1024 ? 2 : 1)
         __builtin_amdgcn_s_barrier();
       }
       const int npro = nk < C::PRO ? nk : C::PRO;
+      issue_bias(vn);   // (older than the stages: every wait that covers stage 0 covers it)
       for (int st = 0; st < npro; ++st) issue_stage<C, DBG>(smem, srcA, srcW, ldsA, ldsW, st, kstepA, kstepW);
       pre = (full_tile && nk >= C::NST && !(g.dbg & 64)) ? 2 : 1;   // (dbg bit 64: A/B, always drain)
     }
@@ -765,6 +800,7 @@ __global__ __launch_bounds__(C::THREADS, C::STAGE * C::NST <= 80 * 1024 ? 2 : 1)
       __builtin_amdgcn_s_barrier();
     }
     set_sources(vt);
+    issue_bias(vt);   // (the main loop issues this tile's first stages behind it)
   }
   const int bid = xcd_remap(vt, g.ntiles);
   const int64_t m0 = (int64_t)(bid / tiles_n) * C::BM;
@@ -805,7 +841,7 @@ __global__ __launch_bounds__(C::THREADS, C::STAGE * C::NST <= 80 * 1024 ? 2 : 1)
     const int which = wcol0 / g.H;   // wave-uniform: 0 q, 1 k, 2 v
     const int M32 = (int)g.M, r0 = (int)wrow0;
     if (which == 2) {
-      run_mainloop<C, false, DBG, TI * TJ>(acc, smem, srcA, srcW, ldsA, ldsW, nk, a_off, b_offs, kstepA, kstepW, wm, pre);
+      run_mainloop<C, false, DBG, TI * TJ>(acc, smem, srcA, srcW, ldsA, ldsW, nk, a_off, b_offs, kstepA, kstepW, wm, pre, nullptr, bias_lds);
       prefetch_next(vt, full_tile);
       // acc[i][j][r] = D[m = 16i + 4fg + r][n = 16j + fr]: 4 consecutive tokens per lane -> V^T rows
       // FULL (interior tile, wave-uniform): no per-lane guards, so the epilogue is straight-line code.  With divergent guards
@@ -820,7 +856,7 @@ __global__ __launch_bounds__(C::THREADS, C::STAGE * C::NST <= 80 * 1024 ? 2 : 1)
         for (int j = 0; j < TJ; ++j) {
           const int col = wcol0 + 16 * j + fr;
           const int cc = (FULL || col < g.N) ? col : g.N - 1;
-          bv[j] = g.bias[cc];
+          bv[j] = BIASACC ? 0.f : g.bias[cc];
           if constexpr (DA) c1v[j] = g.d.c1[cc];
           const int c = cc - 2 * g.H, head = c / g.dh, d = c % g.dh;
           coloff[j] = (FULL || col < g.N) ? ((int64_t)head * g.dh + d) * g.L : -1;
@@ -847,6 +883,7 @@ __global__ __launch_bounds__(C::THREADS, C::STAGE * C::NST <= 80 * 1024 ? 2 : 1)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                   if constexpr (DA) v[r] = (bf16)fmaf(rsd[r], fmaf(-mu[r], c1v[j], acc[i][j][r]), bv[j]);
+                  else if constexpr (BIASACC) v[r] = (bf16)acc[i][j][r];
                   else v[r] = (bf16)(acc[i][j][r] + bv[j]);
                 }
                 *reinterpret_cast<bf16x4*>(base + coloff[j]) = v;
@@ -857,7 +894,7 @@ __global__ __launch_bounds__(C::THREADS, C::STAGE * C::NST <= 80 * 1024 ? 2 : 1)
       };
       if (full_tile) epi_v(std::true_type{}); else epi_v(std::false_type{});
     } else {
-      run_mainloop<C, true, DBG, TI * (TJ / 2)>(acc, smem, srcA, srcW, ldsA, ldsW, nk, a_off, b_offs, kstepA, kstepW, wm, pre);
+      run_mainloop<C, true, DBG, TI * (TJ / 2)>(acc, smem, srcA, srcW, ldsA, ldsW, nk, a_off, b_offs, kstepA, kstepW, wm, pre, nullptr, bias_lds);
       prefetch_next(vt, full_tile);
       auto epi_qk = [&](auto fullc) {
         constexpr bool FULL = decltype(fullc)::value;
@@ -869,7 +906,7 @@ __global__ __launch_bounds__(C::THREADS, C::STAGE * C::NST <= 80 * 1024 ? 2 : 1)
 #pragma unroll
         for (int qh = 0; qh < TJ / 2; ++qh) {
           const int col = wcol0 + 32 * qh + 8 * fg;
-          load8(g.bias + ((FULL || col < g.N) ? col : 0), bv[qh]);
+          if constexpr (!BIASACC) load8(g.bias + ((FULL || col < g.N) ? col : 0), bv[qh]);
           if constexpr (DA) load8(g.d.c1 + ((FULL || col < g.N) ? col : 0), c1v[qh]);
         }
         if constexpr (DA) {
@@ -894,6 +931,7 @@ __global__ __launch_bounds__(C::THREADS, C::STAGE * C::NST <= 80 * 1024 ? 2 : 1)
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                   if constexpr (DA) v[e] = fmaf(rsd[i], fmaf(-mu[i], c1v[qh][e], acc[i][2 * qh + (e >> 2)][e & 3]), bv[qh][e]);
+                  else if constexpr (BIASACC) v[e] = acc[i][2 * qh + (e >> 2)][e & 3];
                   else v[e] = acc[i][2 * qh + (e >> 2)][e & 3] + bv[qh][e];
                 }
                 if (scale_q) {
@@ -912,7 +950,7 @@ __global__ __launch_bounds__(C::THREADS, C::STAGE * C::NST <= 80 * 1024 ? 2 : 1)
   } else {
     // stores per wave of a full tile: one 16-byte store per (row tile, 32-column half); a second one with pre_out
     run_mainloop<C, true, DBG, TI * (TJ / 2)>(acc, smem, srcA, srcW, ldsA, ldsW, nk, a_off, b_offs, kstepA, kstepW, wm, pre,
-                                              reinterpret_cast<unsigned*>(g.out) + 64 + ((int64_t)bid * C::NW + wave) * 8);
+                                              reinterpret_cast<unsigned*>(g.out) + 64 + ((int64_t)bid * C::NW + wave) * 8, bias_lds);
     prefetch_next(vt, full_tile && !g.pre_out && !g.out_f32);
     bf16* outT = reinterpret_cast<bf16*>(g.out) + (int64_t)blockIdx.y * g.sO;
     float* outF = reinterpret_cast<float*>(g.out) + (int64_t)blockIdx.y * g.sO;
@@ -1080,6 +1118,7 @@ __global__ __launch_bounds__(C::THREADS, C::STAGE * C::NST <= 80 * 1024 ? 2 : 1)
           const int col = wcol0 + 32 * qh + 8 * fg;
 #pragma unroll
           for (int e = 0; e < 8; ++e) bv[qh][e] = 0.f;
+          if constexpr (BIASACC) continue;
           if (g.bias && (FULL || col < g.N)) {
             if (FULL || col + 8 <= g.N) load8(g.bias + col, bv[qh]);
             else { const f32x4 b4 = *reinterpret_cast<const f32x4*>(g.bias + col); bv[qh][0] = b4[0]; bv[qh][1] = b4[1]; bv[qh][2] = b4[2]; bv[qh][3] = b4[3]; }
@@ -1116,6 +1155,9 @@ __global__ __launch_bounds__(C::THREADS, C::STAGE * C::NST <= 80 * 1024 ? 2 : 1)
                   const float2 sa = lds_a[rt];
 #pragma unroll
                   for (int e = 0; e < 8; ++e) v[e] = fmaf(sa.y, fmaf(-sa.x, c1v[e], acc[i][2 * qh + (e >> 2)][e & 3]), bv[qh][e]);
+                } else if constexpr (BIASACC) {
+#pragma unroll
+                  for (int e = 0; e < 8; ++e) v[e] = acc[i][2 * qh + (e >> 2)][e & 3];
                 } else {
 #pragma unroll
                   for (int e = 0; e < 8; ++e) v[e] = acc[i][2 * qh + (e >> 2)][e & 3] + bv[qh][e];
@@ -1231,6 +1273,10 @@ int device_cus() {
 #ifndef MH_PLAIN_STORES_DEFAULT
 #define MH_PLAIN_STORES_DEFAULT 0
 #endif
+// A/B (mh_gemm_set_bias_acc): 1 = the accumulators start from the bias.  Measured inside the captured step: 3.610 -> 3.770 ms (+4.4 %; bert-base
+// width +0.3 %): the 128 epilogue adds it removes are cheaper than what it adds to the head of every tile (the bias piece's LDS round trip and 128
+// dependent register writes between the first barrier and the first MFMA, where the zero fill used to sit under the DMA wait).  Default off.
+MH_KNOB(int, g_bias_acc, 0);
 MH_KNOB(int, g_plain_stores, MH_PLAIN_STORES_DEFAULT);   // A/B: bit 0 QKV streaming instead of ordinary stores, bit 1 dense+GELU ordinary instead of streaming stores; bit 2: full-row tile without ping-pong; bits 3 / 4: 64-row full-row tile
 
 template <class C, int EPI>
@@ -1247,6 +1293,9 @@ int launch_big(const GemmArgs& g0, hipStream_t s, int batch) {
   const dim3 grid((unsigned)(t2 < slots ? t2 : slots), (unsigned)batch), block(C::THREADS);
   mh_prof_note("tile=%dx%d%s epi=%d act=%d M=%lld N=%d K=%d batch=%d", C::BM, C::BN, C::PP ? "pp" : "", EPI, g.act, (long long)g.M, g.N, g.K, batch);
   const bool defer = g.d.a_stats || g.d.r_stats || g.d.o_stats;
+  // the accumulators start from the bias (DBG bit 8192 kernels): whole column tiles of the plain 256x128 kernels, no training outputs
+  const bool bias_acc = g_bias_acc && C::TJ == 4 && !C::PP && g.bias && g.N % C::BN == 0 && !defer && !g.pre_out && !g.out_f32 && !g.drop.thr &&
+                        !g.act_grad && !(g.dbg & 31);
   if constexpr (EPI == 1) {
     if (defer) {
       if constexpr (C::NW == 4) {
@@ -1258,6 +1307,7 @@ int launch_big(const GemmArgs& g0, hipStream_t s, int batch) {
     // q / k leave with ordinary stores: the attention kernel reads them back at once (round 2, after the epilogue restructuring:
     // +0.9 % steps/s over streaming stores, tools/ab_step.py plain_stores 0 1; round 1 had measured the opposite); bit 0 = streaming
     else if (g_plain_stores & 1) MH_LAUNCH((gemm_big_kernel<C, 1, MH_ACT_NONE>), grid, block, 0, s, g);
+    else if (bias_acc) { if constexpr (C::TJ == 4 && !C::PP) MH_LAUNCH((gemm_big_kernel<C, 1, MH_ACT_NONE, 32 + 8192>), grid, block, 0, s, g); }
     else MH_LAUNCH((gemm_big_kernel<C, 1, MH_ACT_NONE, 32>), grid, block, 0, s, g);
   } else if constexpr (EPI == 3) {
     if (g.drop.thr || g.pre_out) {   // the training build: dropout (p may be 0) + the un-normalised rows kept for the backward
@@ -1297,6 +1347,7 @@ int launch_big(const GemmArgs& g0, hipStream_t s, int batch) {
       case MH_ACT_GELU_ERF:
         if (g_spread && C::NW == 4) { if constexpr (C::NW == 4) MH_LAUNCH((gemm_big_kernel<C, 0, MH_ACT_GELU_ERF, 1024>), grid, block, 0, s, g); }
         else if (g_plain_stores & 2) MH_LAUNCH((gemm_big_kernel<C, 0, MH_ACT_GELU_ERF, 32>), grid, block, 0, s, g);
+        else if (bias_acc && !g.residual) { if constexpr (C::TJ == 4 && !C::PP) MH_LAUNCH((gemm_big_kernel<C, 0, MH_ACT_GELU_ERF, 8192>), grid, block, 0, s, g); }
         else MH_LAUNCH((gemm_big_kernel<C, 0, MH_ACT_GELU_ERF>), grid, block, 0, s, g);
         break;
       case MH_ACT_SILU: MH_LAUNCH((gemm_big_kernel<C, 0, MH_ACT_SILU>), grid, block, 0, s, g); break;
@@ -1418,6 +1469,13 @@ extern "C" int mh_gemm_bias_res_ln_supported(int N) { return N == 128 || N == 25
 #ifdef MH_ABLATE
 extern "C" int mh_gemm_set_plain_stores(int mask) {
   g_plain_stores = mask;
+  return MH_OK;
+}
+#endif
+
+#ifdef MH_ABLATE
+extern "C" int mh_gemm_set_bias_acc(int on) {
+  g_bias_acc = on != 0;
   return MH_OK;
 }
 #endif
