@@ -109,3 +109,30 @@ def test_lossaware_sampler_state_identical_on_all_ranks():
     np.testing.assert_array_equal(w0, w1)
     np.testing.assert_array_equal(c0, [2, 2, 2, 2])
     np.testing.assert_array_equal(h0, [[1, 6], [2, 7], [3, 8], [4, 5]])   # rank order, then arrival order
+
+
+def _case_eight_ranks(rank, world):
+    """BASELINE config 4's plumbing at its real world size: 512 sequences over 8 ranks (64 each, contiguous), one flat weight broadcast from
+    rank 0, one token all-gather.  Host tensors over gloo: the collectives' call sites and the rank arithmetic, not the kernels."""
+    from musediffusion_amd.models.network import TransformerNetModel
+    torch.manual_seed(100 + rank)
+    m = TransformerNetModel(32, 32, 32, 50, 16, bert_hidden=64, bert_layers=1, bert_heads=2, bert_ffn=128)
+    sharding.broadcast_weights(m, src=0)
+    flat = torch.cat([p.detach().reshape(-1) for p in m.parameters()])
+    B, L = 512, 6
+    batch = {"input_ids": torch.arange(B * L).view(B, L), "input_mask": torch.ones(B, L, dtype=torch.int)}
+    lo, hi = sharding.shard_bounds(B)
+    local = sharding.shard_batch(batch)
+    assert (lo, hi) == (64 * rank, 64 * (rank + 1)) and local["input_ids"].shape[0] == 64
+    tokens = local["input_ids"] * 3 + 1
+    full = sharding.gather_rows(tokens, B)
+    return float(flat.double().sum()), full.numpy()
+
+
+def test_eight_rank_broadcast_shards_and_gather():
+    out = _spawn("_case_eight_ranks", world=8)
+    sums = {round(v[0], 6) for v in out.values()}
+    assert len(sums) == 1                                          # every rank holds rank 0's weights
+    expect = (torch.arange(512 * 6).view(512, 6) * 3 + 1).numpy()
+    for r in range(8):
+        np.testing.assert_array_equal(out[r][1], expect)          # every rank holds all 512 rows in batch order
