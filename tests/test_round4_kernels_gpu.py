@@ -35,7 +35,7 @@ def from_panel(p):
 
 # H 768: bert-base, the width the reference itself builds (network.py:44-46) - 32 rows per block, 12 waves, two-slot weight ring
 @pytest.mark.parametrize("H,E,B,L", [(512, 128, 2, 64), (512, 128, 3, 200), (256, 64, 2, 72), (512, 128, 32, 512),
-                                     (768, 128, 2, 64), (768, 128, 3, 200), (768, 96, 2, 72), (768, 128, 16, 512)])
+                                     (768, 128, 2, 64), (768, 128, 3, 200), (768, 96, 2, 72), (768, 128, 16, 512), (768, 128, 1, 8), (512, 128, 1, 8)])
 def test_up_proj_ln_fused(H, E, B, L):
     """(pos + (tanh(x W0^T + b0) W2^T + b2)) + emb, LayerNorm: the intermediate rounded to bf16 once (the second GEMM's operand), fp32
     from there to the normalised row.  Rows that do not fill the last row block (3 x 200, 2 x 72) are covered."""
@@ -71,7 +71,7 @@ def test_up_proj_ln_fused(H, E, B, L):
 
 
 @pytest.mark.parametrize("H,E,N", [(512, 128, 128), (512, 128, 600), (256, 64, 136), (512, 128, 16384),
-                                   (768, 128, 128), (768, 128, 600), (768, 128, 8200)])
+                                   (768, 128, 128), (768, 128, 600), (768, 128, 8200), (768, 128, 8), (512, 128, 8)])
 def test_down_proj_fused(H, E, N):
     X = rnd(N, H, seed=11, scale=1.0)
     W0, b0 = rnd(H, H, seed=12, scale=1 / math.sqrt(H)), rnd(H, seed=13, scale=0.1)
