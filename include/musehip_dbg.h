@@ -84,6 +84,11 @@ int mh_gemm_set_stagger(int ticks);
 /* experiment knob (A/B only): LDS-DMA pieces of the 256x128 kernels issued between the MFMA rows instead of as one burst */
 int mh_gemm_set_spread(int on);
 
+/* A/B: 1 (default) = K32-panel launches of the big-tile kernels issue their stage DMA as `buffer_load_dwordx4 ... lds` (tile base in a descriptor,
+ * K step as the scalar offset, a wave's pieces as immediate offsets: no vector address arithmetic per piece; bit-identical results);
+ * 0 = global_load_lds with per-piece 64-bit addresses (rounds 1 - 4) */
+int mh_gemm_set_buf_dma(int on);
+
 /* A/B: 1 = the plain 256x128 kernels (dense + GELU, the QKV projection) start their accumulators from the bias - an LDS-DMA piece per wave in
  * front of the tile's first stage - and their epilogues have no bias add; 0 (default: the other form measured 4 % slower inside the step) = the
  * bias added in the epilogue */

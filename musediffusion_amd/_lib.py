@@ -248,6 +248,7 @@ DBG_SIGNATURES = {
     "mh_attention_set_ablation": (INT, [INT]),
     "mh_gemm_set_stagger": (INT, [INT]),
     "mh_gemm_set_bias_acc": (INT, [INT]),
+    "mh_gemm_set_buf_dma": (INT, [INT]),
     "mh_gemm_set_spread": (INT, [INT]),
 }
 

@@ -419,6 +419,34 @@ constexpr int B2K = 32;
 #ifndef MH_PP_A_AUX
 #define MH_PP_A_AUX 2
 #endif
+// DBG bit 16384 kernels (K32-panel operands only): the stage DMA as `buffer_load_dwordx4 ... lds` - ONE per-lane byte offset per operand for the
+// whole kernel (a lane's chunk of its piece), the tile's base in a buffer descriptor (scalar registers), the K step as the instruction's
+// scalar offset and a wave's consecutive pieces (16 rows x 64 B apart) as its immediate offset: no vector instruction per piece, where the
+// `global_load_lds` form spends two 64-bit vector adds on every piece of every K step.  Rows beyond M / N are not clamped: inside the buffer they
+// read other rows (their outputs are never stored), beyond it the descriptor's bound makes them zeros.
+struct BufDma {
+  __amdgpu_buffer_rsrc_t ra, rw;   // tile bases: A rows tm0.., W rows tn0.. of panel 0
+  int va, vw;                      // this lane's byte offset inside its first piece's rows
+  int ka, kw;                      // bytes per K32 panel
+};
+template <int J, int N, class F> __device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (J < N) { f(std::integral_constant<int, J>{}); static_for<J + 1, N>(f); }
+}
+template <class C>
+__device__ __forceinline__ void issue_stage_buf(const char* smem, const BufDma& b, const int (&ldsA)[C::PA], const int (&ldsW)[C::PW], int kt) {
+  char* base = const_cast<char*>(smem) + (kt % C::NST) * C::STAGE;
+  constexpr int AUX_A = C::PP ? MH_PP_A_AUX : 0;     // (the full-row tile's A rows: nt, as in issue_stage)
+  static_for<0, C::PA>([&](auto jc) {
+    constexpr int j = decltype(jc)::value;
+    // (the instruction's immediate offset advances the LDS address as well as the buffer address: every piece names the FIRST piece's slot)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(b.ra, (__attribute__((address_space(3))) void*)(base + ldsA[0]), 16, b.va, kt * b.ka, j * 1024, AUX_A);
+  });
+  static_for<0, C::PW>([&](auto jc) {
+    constexpr int j = decltype(jc)::value;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(b.rw, (__attribute__((address_space(3))) void*)(base + C::BM * 64 + ldsW[0]), 16, b.vw, kt * b.kw, j * 1024, 0);
+  });
+}
+
 template <class C, int DBG>
 __device__ __forceinline__ void issue_stage(const char* smem, const char* const (&srcA)[C::PA], const char* const (&srcW)[C::PW],
                                             const int (&ldsA)[C::PA], const int (&ldsW)[C::PW], int kt, int64_t kstepA,
@@ -483,13 +511,16 @@ template <class C, bool SWAP, int DBG, int NSTORE = 0>
 __device__ __forceinline__ void big_mainloop(f32x4 (&acc)[C::TI][C::TJ], const char* smem, const char* const (&srcA)[C::PA],
                                              const char* const (&srcW)[C::PW], const int (&ldsA)[C::PA], const int (&ldsW)[C::PW],
                                              int nk, int a_off, const int (&b_offs)[C::TJ], int64_t kstepA, int64_t kstepW,
-                                             int pre, unsigned* prof = nullptr, const char* bias_lds = nullptr) {
+                                             int pre, unsigned* prof = nullptr, const char* bias_lds = nullptr, const BufDma* bd = nullptr) {
   constexpr int TI = C::TI, TJ = C::TJ;
   constexpr int NPIECES = (DBG & 4096) != 0 ? C::PA : C::PIECES;   // (ablation 4096: only the A pieces are issued)
   // DBG bit 4 (tools/gemm_bench.py --dbg 28): per-wave shader-clock totals of the three phases of a K-step
   unsigned long long pt_wait = 0, pt_bar = 0, pt_work = 0, pt0 = 0, pt1 = 0;
   auto tick = [&]() -> unsigned long long { if constexpr ((DBG & 16) != 0) return __builtin_amdgcn_s_memtime(); else return 0ull; };
-  auto issue = [&](int kt) { issue_stage<C, DBG>(smem, srcA, srcW, ldsA, ldsW, kt, kstepA, kstepW); };
+  auto issue = [&](int kt) {
+    if constexpr ((DBG & 16384) != 0) issue_stage_buf<C>(smem, *bd, ldsA, ldsW, kt);
+    else issue_stage<C, DBG>(smem, srcA, srcW, ldsA, ldsW, kt, kstepA, kstepW);
+  };
   auto read_frag = [&](const char* p) -> bf16x8 {
     if constexpr ((DBG & 8) != 0) { bf16x8 v; asm volatile("" : "=v"(v)); return v; }   // ablation: no LDS reads
     else return *reinterpret_cast<const bf16x8*>(p);
@@ -601,10 +632,13 @@ template <class C, bool SWAP, int DBG>
 __device__ __forceinline__ void pp_mainloop(f32x4 (&acc)[C::TI][C::TJ], const char* smem, const char* const (&srcA)[C::PA],
                                             const char* const (&srcW)[C::PW], const int (&ldsA)[C::PA], const int (&ldsW)[C::PW],
                                             int nk, int a_off, const int (&b_offs)[C::TJ], int64_t kstepA, int64_t kstepW,
-                                            int group, bool pre) {
+                                            int group, bool pre, const BufDma* bd = nullptr) {
   constexpr int TI = C::TI, TJ = C::TJ, D = C::NST - 1;
   static_assert(C::WM == 2, "ping-pong needs exactly two wave rows");
-  auto issue = [&](int kt) { issue_stage<C, DBG>(smem, srcA, srcW, ldsA, ldsW, kt, kstepA, kstepW); };
+  auto issue = [&](int kt) {
+    if constexpr ((DBG & 16384) != 0) issue_stage_buf<C>(smem, *bd, ldsA, ldsW, kt);
+    else issue_stage<C, DBG>(smem, srcA, srcW, ldsA, ldsW, kt, kstepA, kstepW);
+  };
   auto read_frag = [&](const char* p) -> bf16x8 {
     if constexpr ((DBG & 8) != 0) { bf16x8 v; asm volatile("" : "=v"(v)); return v; }
     else return *reinterpret_cast<const bf16x8*>(p);
@@ -659,10 +693,10 @@ template <class C, bool SWAP, int DBG, int NSTORE = 0>
 __device__ __forceinline__ void run_mainloop(f32x4 (&acc)[C::TI][C::TJ], const char* smem, const char* const (&srcA)[C::PA],
                                              const char* const (&srcW)[C::PW], const int (&ldsA)[C::PA], const int (&ldsW)[C::PW],
                                              int nk, int a_off, const int (&b_offs)[C::TJ], int64_t kstepA, int64_t kstepW,
-                                             int group, int pre, unsigned* prof = nullptr, const char* bias_lds = nullptr) {
+                                             int group, int pre, unsigned* prof = nullptr, const char* bias_lds = nullptr, const BufDma* bd = nullptr) {
   static_assert(!(C::PP && (DBG & 8192) != 0), "bias-initialised accumulators: plain main loop only");
-  if constexpr (C::PP) pp_mainloop<C, SWAP, DBG>(acc, smem, srcA, srcW, ldsA, ldsW, nk, a_off, b_offs, kstepA, kstepW, group, pre != 0);
-  else big_mainloop<C, SWAP, DBG, NSTORE>(acc, smem, srcA, srcW, ldsA, ldsW, nk, a_off, b_offs, kstepA, kstepW, pre, prof, bias_lds);
+  if constexpr (C::PP) pp_mainloop<C, SWAP, DBG>(acc, smem, srcA, srcW, ldsA, ldsW, nk, a_off, b_offs, kstepA, kstepW, group, pre != 0, bd);
+  else big_mainloop<C, SWAP, DBG, NSTORE>(acc, smem, srcA, srcW, ldsA, ldsW, nk, a_off, b_offs, kstepA, kstepW, pre, prof, bias_lds, bd);
 }
 
 // EPI: 0 generic (bias / act / residual), 1 QKV head scatter, 3 bias + residual + LayerNorm over complete rows
@@ -706,10 +740,28 @@ __global__ __launch_bounds__(C::THREADS, C::STAGE * C::NST <= 80 * 1024 ? 2 : 1)
   for (int j = 0; j < C::PA; ++j) ldsA[j] = ((wave * C::PA + j) % C::APIECES) * 16 * 64;
 #pragma unroll
   for (int j = 0; j < C::PW; ++j) ldsW[j] = (wave * C::PW + j) * 16 * 64;
+  constexpr bool BUFDMA = (DBG & 16384) != 0;
+  static_assert(!BUFDMA || ((C::APIECES % C::NW == 0 || C::PA == 1) && C::PA * 1024 <= 4096 && C::PW * 1024 <= 4096),
+                "buffer DMA: a wave's pieces of a stage must be consecutive (immediate offsets of 1 KiB, 12 bits)");
+  BufDma bd;
+  if constexpr (BUFDMA) {
+    const int rl = lane >> 2, lc = (lane & 3) ^ GSW[(rl >> 2) & 3];
+    bd.va = (((wave * C::PA) % C::APIECES) * 16 + rl) * 64 + lc * 16;
+    bd.vw = ((wave * C::PW) * 16 + rl) * 64 + lc * 16;
+    bd.ka = (int)(g.lda * 64);
+    bd.kw = (int)(g.ldw * 64);
+  }
   auto set_sources = [&](int tile) {
     const int b2 = xcd_remap(tile, g.ntiles);
     const int64_t tm0 = (int64_t)(b2 / tiles_n) * C::BM;
     const int tn0 = (b2 % tiles_n) * C::BN;
+    if constexpr (BUFDMA) {   // (panel operands: row r of panel 0 at byte 64 r; everything here is wave-uniform)
+      const int64_t offA = ((int64_t)blockIdx.y * g.sA) * 2 + tm0 * 64, offW = ((int64_t)blockIdx.y * g.sW) * 2 + (int64_t)tn0 * 64;
+      const int64_t bytesA = (int64_t)(g.K / 32) * g.lda * 64 - tm0 * 64, bytesW = (int64_t)(g.K / 32) * g.ldw * 64 - (int64_t)tn0 * 64;
+      bd.ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(g.A)) + offA, 0, (int)bytesA, 0x00020000);
+      bd.rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(g.W)) + offW, 0, (int)bytesW, 0x00020000);
+      return;
+    }
     const int rl = lane >> 2, pc = lane & 3;
     const int lc = pc ^ GSW[(rl >> 2) & 3];          // logical chunk stored at this physical slot
 #pragma unroll
@@ -764,7 +816,10 @@ __global__ __launch_bounds__(C::THREADS, C::STAGE * C::NST <= 80 * 1024 ? 2 : 1)
       }
       const int npro = nk < C::PRO ? nk : C::PRO;
       issue_bias(vn);   // (older than the stages: every wait that covers stage 0 covers it)
-      for (int st = 0; st < npro; ++st) issue_stage<C, DBG>(smem, srcA, srcW, ldsA, ldsW, st, kstepA, kstepW);
+      for (int st = 0; st < npro; ++st) {
+        if constexpr (BUFDMA) issue_stage_buf<C>(smem, bd, ldsA, ldsW, st);
+        else issue_stage<C, DBG>(smem, srcA, srcW, ldsA, ldsW, st, kstepA, kstepW);
+      }
       pre = (full_tile && nk >= C::NST && !(g.dbg & 64)) ? 2 : 1;   // (dbg bit 64: A/B, always drain)
     }
   };
@@ -830,7 +885,10 @@ __global__ __launch_bounds__(C::THREADS, C::STAGE * C::NST <= 80 * 1024 ? 2 : 1)
     // fetched underneath them, instead of standing between the main loop and the epilogue
     if (!pre) {
       const int npro = nk < C::PRO ? nk : C::PRO;
-      for (int st = 0; st < npro; ++st) issue_stage<C, DBG>(smem, srcA, srcW, ldsA, ldsW, st, kstepA, kstepW);
+      for (int st = 0; st < npro; ++st) {
+        if constexpr (BUFDMA) issue_stage_buf<C>(smem, bd, ldsA, ldsW, st);
+        else issue_stage<C, DBG>(smem, srcA, srcW, ldsA, ldsW, st, kstepA, kstepW);
+      }
       pre = 1;
     }
     stage_row_stats(m0);
@@ -841,7 +899,7 @@ __global__ __launch_bounds__(C::THREADS, C::STAGE * C::NST <= 80 * 1024 ? 2 : 1)
     const int which = wcol0 / g.H;   // wave-uniform: 0 q, 1 k, 2 v
     const int M32 = (int)g.M, r0 = (int)wrow0;
     if (which == 2) {
-      run_mainloop<C, false, DBG, TI * TJ>(acc, smem, srcA, srcW, ldsA, ldsW, nk, a_off, b_offs, kstepA, kstepW, wm, pre, nullptr, bias_lds);
+      run_mainloop<C, false, DBG, TI * TJ>(acc, smem, srcA, srcW, ldsA, ldsW, nk, a_off, b_offs, kstepA, kstepW, wm, pre, nullptr, bias_lds, &bd);
       prefetch_next(vt, full_tile);
       // acc[i][j][r] = D[m = 16i + 4fg + r][n = 16j + fr]: 4 consecutive tokens per lane -> V^T rows
       // FULL (interior tile, wave-uniform): no per-lane guards, so the epilogue is straight-line code.  With divergent guards
@@ -894,7 +952,7 @@ __global__ __launch_bounds__(C::THREADS, C::STAGE * C::NST <= 80 * 1024 ? 2 : 1)
       };
       if (full_tile) epi_v(std::true_type{}); else epi_v(std::false_type{});
     } else {
-      run_mainloop<C, true, DBG, TI * (TJ / 2)>(acc, smem, srcA, srcW, ldsA, ldsW, nk, a_off, b_offs, kstepA, kstepW, wm, pre, nullptr, bias_lds);
+      run_mainloop<C, true, DBG, TI * (TJ / 2)>(acc, smem, srcA, srcW, ldsA, ldsW, nk, a_off, b_offs, kstepA, kstepW, wm, pre, nullptr, bias_lds, &bd);
       prefetch_next(vt, full_tile);
       auto epi_qk = [&](auto fullc) {
         constexpr bool FULL = decltype(fullc)::value;
@@ -950,7 +1008,7 @@ __global__ __launch_bounds__(C::THREADS, C::STAGE * C::NST <= 80 * 1024 ? 2 : 1)
   } else {
     // stores per wave of a full tile: one 16-byte store per (row tile, 32-column half); a second one with pre_out
     run_mainloop<C, true, DBG, TI * (TJ / 2)>(acc, smem, srcA, srcW, ldsA, ldsW, nk, a_off, b_offs, kstepA, kstepW, wm, pre,
-                                              reinterpret_cast<unsigned*>(g.out) + 64 + ((int64_t)bid * C::NW + wave) * 8, bias_lds);
+                                              reinterpret_cast<unsigned*>(g.out) + 64 + ((int64_t)bid * C::NW + wave) * 8, bias_lds, &bd);
     prefetch_next(vt, full_tile && !g.pre_out && !g.out_f32);
     bf16* outT = reinterpret_cast<bf16*>(g.out) + (int64_t)blockIdx.y * g.sO;
     float* outF = reinterpret_cast<float*>(g.out) + (int64_t)blockIdx.y * g.sO;
@@ -1277,6 +1335,9 @@ int device_cus() {
 // width +0.3 %): the 128 epilogue adds it removes are cheaper than what it adds to the head of every tile (the bias piece's LDS round trip and 128
 // dependent register writes between the first barrier and the first MFMA, where the zero fill used to sit under the DMA wait).  Default off.
 MH_KNOB(int, g_bias_acc, 0);
+// round 5: K32-panel launches (the engine's) issue their stage DMA as buffer loads (BufDma above): bit-identical results, no vector address
+// arithmetic per piece.  A/B: mh_gemm_set_buf_dma(0) = global_load_lds with per-piece 64-bit addresses (rounds 1 - 4)
+MH_KNOB(int, g_buf_dma, 1);
 MH_KNOB(int, g_plain_stores, MH_PLAIN_STORES_DEFAULT);   // A/B: bit 0 QKV streaming instead of ordinary stores, bit 1 dense+GELU ordinary instead of streaming stores; bit 2: full-row tile without ping-pong; bits 3 / 4: 64-row full-row tile
 
 template <class C, int EPI>
@@ -1296,24 +1357,32 @@ int launch_big(const GemmArgs& g0, hipStream_t s, int batch) {
   // the accumulators start from the bias (DBG bit 8192 kernels): whole column tiles of the plain 256x128 kernels, no training outputs
   const bool bias_acc = g_bias_acc && C::TJ == 4 && !C::PP && g.bias && g.N % C::BN == 0 && !defer && !g.pre_out && !g.out_f32 && !g.drop.thr &&
                         !g.act_grad && !(g.dbg & 31);
+  // the stage DMA as buffer loads (BufDma): K32-panel operands (the engine's launches) whose byte extents fit a 32-bit descriptor
+  const bool buf_dma = g_buf_dma && g.a_panel && g.w_panel && !(g.dbg & 31) && !g_spread &&
+                       (int64_t)(g.K / 32) * g.lda * 64 < (1ll << 31) && (int64_t)(g.K / 32) * g.ldw * 64 < (1ll << 31);
+#define MH_LAUNCH_BIG(EPI_, ACT_, BITS_)                                                                             \
+  do {                                                                                                                \
+    if (buf_dma) MH_LAUNCH((gemm_big_kernel<C, EPI_, ACT_, (BITS_) | 16384>), grid, block, 0, s, g);                  \
+    else MH_LAUNCH((gemm_big_kernel<C, EPI_, ACT_, (BITS_)>), grid, block, 0, s, g);                                  \
+  } while (0)
   if constexpr (EPI == 1) {
     if (defer) {
       if constexpr (C::NW == 4) {
         MH_CHECK_ARG(g.d.a_stats && !g.d.r_stats && !g.d.o_stats, "gemm_qkv: deferred LayerNorm applies to the A operand only");
-        MH_LAUNCH((gemm_big_kernel<C, 1, MH_ACT_NONE, 128>), grid, block, 0, s, g);
+        MH_LAUNCH_BIG(1, MH_ACT_NONE, 128);
       } else { mh_set_error("gemm: deferred LayerNorm needs the 256x128 tile"); return MH_ERR_UNSUPPORTED; }
     }
     else if (g_spread && C::NW == 4) { if constexpr (C::NW == 4) MH_LAUNCH((gemm_big_kernel<C, 1, MH_ACT_NONE, 1024>), grid, block, 0, s, g); }
     // q / k leave with ordinary stores: the attention kernel reads them back at once (round 2, after the epilogue restructuring:
     // +0.9 % steps/s over streaming stores, tools/ab_step.py plain_stores 0 1; round 1 had measured the opposite); bit 0 = streaming
     else if (g_plain_stores & 1) MH_LAUNCH((gemm_big_kernel<C, 1, MH_ACT_NONE>), grid, block, 0, s, g);
-    else if (bias_acc) { if constexpr (C::TJ == 4 && !C::PP) MH_LAUNCH((gemm_big_kernel<C, 1, MH_ACT_NONE, 32 + 8192>), grid, block, 0, s, g); }
-    else MH_LAUNCH((gemm_big_kernel<C, 1, MH_ACT_NONE, 32>), grid, block, 0, s, g);
+    else if (bias_acc && !buf_dma) { if constexpr (C::TJ == 4 && !C::PP) MH_LAUNCH((gemm_big_kernel<C, 1, MH_ACT_NONE, 32 + 8192>), grid, block, 0, s, g); }
+    else MH_LAUNCH_BIG(1, MH_ACT_NONE, 32);
   } else if constexpr (EPI == 3) {
     if (g.drop.thr || g.pre_out) {   // the training build: dropout (p may be 0) + the un-normalised rows kept for the backward
       if constexpr (C::BN == 512 && C::PP) MH_LAUNCH((gemm_big_kernel<C, 3, MH_ACT_NONE, 64>), grid, block, 0, s, g);
       else { mh_set_error("gemm: the dropout + LayerNorm epilogue is built for the 128x512 tile only"); return MH_ERR_UNSUPPORTED; }
-    } else MH_LAUNCH((gemm_big_kernel<C, 3, MH_ACT_NONE>), grid, block, 0, s, g);
+    } else MH_LAUNCH_BIG(3, MH_ACT_NONE, 0);
   } else {
     if (g.dbg & 31) {   // timing-only ablations (tools/gemm_bench.py): 1 no DMA, 2 no MFMA, 4 no epilogue, 8 no LDS reads
       switch (g.dbg & 31) {
@@ -1335,29 +1404,30 @@ int launch_big(const GemmArgs& g0, hipStream_t s, int batch) {
     } else if (defer) {
       if constexpr (C::NW == 4) {   // the operand combinations a post-LN encoder layer needs (engine.hip)
         const int da = g.d.a_stats ? 1 : 0, dr = g.d.r_stats ? 1 : 0, dd = g.d.o_stats ? 1 : 0;
-        if (da && !dr && !dd && g.act == MH_ACT_GELU_ERF) MH_LAUNCH((gemm_big_kernel<C, 0, MH_ACT_GELU_ERF, 128>), grid, block, 0, s, g);   // FFN1
-        else if (da && !dr && !dd && g.act == MH_ACT_TANH) MH_LAUNCH((gemm_big_kernel<C, 0, MH_ACT_TANH, 128>), grid, block, 0, s, g);      // (down-projection)
-        else if (!da && !dr && dd && g.act == MH_ACT_NONE) MH_LAUNCH((gemm_big_kernel<C, 0, MH_ACT_NONE, 512>), grid, block, 0, s, g);      // first attention-output dense
-        else if (!da && dr && dd && g.act == MH_ACT_NONE) MH_LAUNCH((gemm_big_kernel<C, 0, MH_ACT_NONE, 768>), grid, block, 0, s, g);       // dense + raw residual -> raw rows
-        else if (!da && dr && !dd && g.act == MH_ACT_NONE) MH_LAUNCH((gemm_big_kernel<C, 0, MH_ACT_NONE, 256>), grid, block, 0, s, g);      // last FFN output dense
+        if (da && !dr && !dd && g.act == MH_ACT_GELU_ERF) MH_LAUNCH_BIG(0, MH_ACT_GELU_ERF, 128);   // FFN1
+        else if (da && !dr && !dd && g.act == MH_ACT_TANH) MH_LAUNCH_BIG(0, MH_ACT_TANH, 128);      // (down-projection)
+        else if (!da && !dr && dd && g.act == MH_ACT_NONE) MH_LAUNCH_BIG(0, MH_ACT_NONE, 512);      // first attention-output dense
+        else if (!da && dr && dd && g.act == MH_ACT_NONE) MH_LAUNCH_BIG(0, MH_ACT_NONE, 768);       // dense + raw residual -> raw rows
+        else if (!da && dr && !dd && g.act == MH_ACT_NONE) MH_LAUNCH_BIG(0, MH_ACT_NONE, 256);      // last FFN output dense
         else { mh_set_error("gemm: unsupported deferred-LayerNorm operand combination (a=%d r=%d o=%d act=%d)", da, dr, dd, g.act); return MH_ERR_UNSUPPORTED; }
       } else { mh_set_error("gemm: deferred LayerNorm needs the 256x128 tile"); return MH_ERR_UNSUPPORTED; }
     } else switch (g.act) {
-      case MH_ACT_TANH: MH_LAUNCH((gemm_big_kernel<C, 0, MH_ACT_TANH>), grid, block, 0, s, g); break;
+      case MH_ACT_TANH: MH_LAUNCH_BIG(0, MH_ACT_TANH, 0); break;
       case MH_ACT_GELU_ERF:
         if (g_spread && C::NW == 4) { if constexpr (C::NW == 4) MH_LAUNCH((gemm_big_kernel<C, 0, MH_ACT_GELU_ERF, 1024>), grid, block, 0, s, g); }
         else if (g_plain_stores & 2) MH_LAUNCH((gemm_big_kernel<C, 0, MH_ACT_GELU_ERF, 32>), grid, block, 0, s, g);
-        else if (bias_acc && !g.residual) { if constexpr (C::TJ == 4 && !C::PP) MH_LAUNCH((gemm_big_kernel<C, 0, MH_ACT_GELU_ERF, 8192>), grid, block, 0, s, g); }
-        else MH_LAUNCH((gemm_big_kernel<C, 0, MH_ACT_GELU_ERF>), grid, block, 0, s, g);
+        else if (bias_acc && !buf_dma && !g.residual) { if constexpr (C::TJ == 4 && !C::PP) MH_LAUNCH((gemm_big_kernel<C, 0, MH_ACT_GELU_ERF, 8192>), grid, block, 0, s, g); }
+        else MH_LAUNCH_BIG(0, MH_ACT_GELU_ERF, 0);
         break;
       case MH_ACT_SILU: MH_LAUNCH((gemm_big_kernel<C, 0, MH_ACT_SILU>), grid, block, 0, s, g); break;
       default:
         if (g_spread && C::NW == 4 && !g.drop.thr) { if constexpr (C::NW == 4) MH_LAUNCH((gemm_big_kernel<C, 0, MH_ACT_NONE, 1024>), grid, block, 0, s, g); }
         else if (g.drop.thr) MH_LAUNCH((gemm_big_kernel<C, 0, MH_ACT_NONE, 64>), grid, block, 0, s, g);
-        else MH_LAUNCH((gemm_big_kernel<C, 0, MH_ACT_NONE>), grid, block, 0, s, g);
+        else MH_LAUNCH_BIG(0, MH_ACT_NONE, 0);
         break;
     }
   }
+#undef MH_LAUNCH_BIG
   MH_CHECK_LAUNCH();
   return MH_OK;
 }
@@ -1469,6 +1539,13 @@ extern "C" int mh_gemm_bias_res_ln_supported(int N) { return N == 128 || N == 25
 #ifdef MH_ABLATE
 extern "C" int mh_gemm_set_plain_stores(int mask) {
   g_plain_stores = mask;
+  return MH_OK;
+}
+#endif
+
+#ifdef MH_ABLATE
+extern "C" int mh_gemm_set_buf_dma(int on) {
+  g_buf_dma = on != 0;
   return MH_OK;
 }
 #endif

@@ -20,7 +20,7 @@ _lib.use_debug_library()   # the A/B switches live in libmusehip_dbg.so (include
 setters = {"gemm_debug": lambda v: _lib.lib().mh_gemm_set_debug(v), "plain_stores": lambda v: _lib.lib().mh_gemm_set_plain_stores(v), "fuse_ln": lambda v: _lib.lib().mh_denoiser_set_fuse_ln(v),
            "v3_fuse_ln": lambda v: (_lib.lib().mh_gemm_set_variant(3), _lib.lib().mh_denoiser_set_fuse_ln(v)),
            "v3_split": None, "v4_split": None, "skip": lambda v: _lib.lib().mh_denoiser_set_skip(v), "ln_rows4": lambda v: _lib.lib().mh_layernorm_set_rows4(v), "prescale_q": lambda v: _lib.lib().mh_denoiser_set_prescale_q(v),
-           "stream_attn": lambda v: _lib.lib().mh_attention_set_stream(v), "wide_roles": lambda v: _lib.lib().mh_gemm_set_wide_roles(v), "fuse_headtail": lambda v: _lib.lib().mh_denoiser_set_fuse_headtail(v), "gemm_variant": lambda v: _lib.lib().mh_gemm_set_variant(v), "bias_acc": lambda v: _lib.lib().mh_gemm_set_bias_acc(v), "spread": lambda v: _lib.lib().mh_gemm_set_spread(v)}
+           "stream_attn": lambda v: _lib.lib().mh_attention_set_stream(v), "wide_roles": lambda v: _lib.lib().mh_gemm_set_wide_roles(v), "fuse_headtail": lambda v: _lib.lib().mh_denoiser_set_fuse_headtail(v), "gemm_variant": lambda v: _lib.lib().mh_gemm_set_variant(v), "bias_acc": lambda v: _lib.lib().mh_gemm_set_bias_acc(v), "spread": lambda v: _lib.lib().mh_gemm_set_spread(v), "buf_dma": lambda v: _lib.lib().mh_gemm_set_buf_dma(v)}
 from musediffusion_amd.models.diffusion import GaussianDiffusion  # noqa: E402
 setters["decouple"] = lambda v: setattr(GaussianDiffusion, "decouple_branches", bool(v))
 setters["shared"] = lambda v: setattr(GaussianDiffusion, "shared_head_tail", bool(v))
