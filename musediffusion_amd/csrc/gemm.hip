@@ -432,9 +432,9 @@ struct BufDma {
 template <int J, int N, class F> __device__ __forceinline__ void static_for(F&& f) {
   if constexpr (J < N) { f(std::integral_constant<int, J>{}); static_for<J + 1, N>(f); }
 }
-template <class C>
+template <class C, int SLOT = -1>   // SLOT >= 0: the stage's ring slot as a compile-time constant (= kt % NST)
 __device__ __forceinline__ void issue_stage_buf(const char* smem, const BufDma& b, const int (&ldsA)[C::PA], const int (&ldsW)[C::PW], int kt) {
-  char* base = const_cast<char*>(smem) + (kt % C::NST) * C::STAGE;
+  char* base = const_cast<char*>(smem) + (SLOT >= 0 ? SLOT : kt % C::NST) * C::STAGE;
   constexpr int AUX_A = C::PP ? MH_PP_A_AUX : 0;     // (the full-row tile's A rows: nt, as in issue_stage)
   static_for<0, C::PA>([&](auto jc) {
     constexpr int j = decltype(jc)::value;
@@ -507,6 +507,12 @@ template <int PIECES, int EXTRA = 0> __device__ __forceinline__ void wait_stages
 // stages count the stores as younger operations instead of waiting for them, so the stores drain under this tile's first K-steps.
 // bias_lds (DBG bit 8192 kernels): the wave's 64 bias values (fp32, in column order) as its own LDS-DMA piece, issued before the tile's first
 // stage: the accumulators START from the bias (one register write each, which the zero fill cost anyway) and the epilogue has no bias add.
+// K loop with the ring slots as compile-time constants (NST steps per iteration, every fragment read `base + immediate`): built and A/B'd as two
+// libraries on one box (tools/ab_lib.sh nounroll . -DMH_KLOOP_UNROLL=0): 3.588 -> 4.306 ms per step at config 2 (+20 %), 7.38 -> 9.60 at the
+// bert-base width - four copies of a K step of 32 MFMAs + 12 reads + the DMA issue do not fit what the instruction cache keeps per CU.  Off.
+#ifndef MH_KLOOP_UNROLL
+#define MH_KLOOP_UNROLL 0
+#endif
 template <class C, bool SWAP, int DBG, int NSTORE = 0>
 __device__ __forceinline__ void big_mainloop(f32x4 (&acc)[C::TI][C::TJ], const char* smem, const char* const (&srcA)[C::PA],
                                              const char* const (&srcW)[C::PW], const int (&ldsA)[C::PA], const int (&ldsW)[C::PW],
@@ -517,8 +523,8 @@ __device__ __forceinline__ void big_mainloop(f32x4 (&acc)[C::TI][C::TJ], const c
   // DBG bit 4 (tools/gemm_bench.py --dbg 28): per-wave shader-clock totals of the three phases of a K-step
   unsigned long long pt_wait = 0, pt_bar = 0, pt_work = 0, pt0 = 0, pt1 = 0;
   auto tick = [&]() -> unsigned long long { if constexpr ((DBG & 16) != 0) return __builtin_amdgcn_s_memtime(); else return 0ull; };
-  auto issue = [&](int kt) {
-    if constexpr ((DBG & 16384) != 0) issue_stage_buf<C>(smem, *bd, ldsA, ldsW, kt);
+  auto issue = [&](int kt, auto slotc) {
+    if constexpr ((DBG & 16384) != 0) issue_stage_buf<C, decltype(slotc)::value>(smem, *bd, ldsA, ldsW, kt);
     else issue_stage<C, DBG>(smem, srcA, srcW, ldsA, ldsW, kt, kstepA, kstepW);
   };
   auto read_frag = [&](const char* p) -> bf16x8 {
@@ -534,7 +540,7 @@ __device__ __forceinline__ void big_mainloop(f32x4 (&acc)[C::TI][C::TJ], const c
   } else if (pre) {   // the stages were issued before the previous tile's epilogue, whose stores share the counter: drain all
     wait_vmcnt<0>();
   } else {
-    for (int st = 0; st < npro; ++st) issue(st);
+    for (int st = 0; st < npro; ++st) issue(st, std::integral_constant<int, -1>{});
     wait_stages<NPIECES>(npro - 1);
   }
   __builtin_amdgcn_s_barrier();
@@ -574,8 +580,11 @@ __device__ __forceinline__ void big_mainloop(f32x4 (&acc)[C::TI][C::TJ], const c
       }
     }
   };
-  for (int kt = 0; kt + 1 < nk; ++kt) {
-    const char* As = smem + ((kt + 1) % C::NST) * C::STAGE;
+  // One K step.  S >= 0: the ring slot of stage kt + 1 as a compile-time constant, so that every fragment read is `base + immediate` and the
+  // refill names its slot without scalar arithmetic (the loop below runs NST steps per iteration); S = -1: computed (the remainder steps)
+  auto kstep = [&](int kt, auto sc) {
+    constexpr int S = decltype(sc)::value;
+    const char* As = smem + (S >= 0 ? S : (kt + 1) % C::NST) * C::STAGE;
     const char* Ws = As + C::BM * 64;
     // stage kt+1 must have landed (stages kt+2 .. kt+NST-1 stay in flight across the barrier); this wave's
     // reads of stage kt were issued a whole MFMA phase ago, so the lgkmcnt wait is free
@@ -594,7 +603,7 @@ __device__ __forceinline__ void big_mainloop(f32x4 (&acc)[C::TI][C::TJ], const c
     pt1 = pt0;
     constexpr bool SPREAD = (DBG & 1024) != 0 && C::PIECES <= TI;   // one DMA piece behind each MFMA row instead of a burst
     const bool refill = kt + C::NST < nk;
-    if (!SPREAD && refill) issue(kt + C::NST);   // slot kt % NST: every wave has read stage kt out of it
+    if (!SPREAD && refill) issue(kt + C::NST, std::integral_constant<int, (S >= 0 ? (S + C::NST - 1) % C::NST : -1)>{});   // slot kt % NST: every wave has read stage kt out of it
 #pragma unroll
     for (int j = 0; j < TJ; ++j) bn[j] = read_frag(Ws + b_offs[j]);
 #pragma unroll
@@ -606,7 +615,13 @@ __device__ __forceinline__ void big_mainloop(f32x4 (&acc)[C::TI][C::TJ], const c
     }
 #pragma unroll
     for (int j = 0; j < TJ; ++j) b[j] = bn[j];
-  }
+  };
+  int kt = 0;
+#if MH_KLOOP_UNROLL
+  for (; kt + C::NST < nk; kt += C::NST)     // kt % NST == 0 here: the group's steps read slots 1, 2, .., NST - 1, 0
+    static_for<0, C::NST>([&](auto rc) { kstep(kt + decltype(rc)::value, std::integral_constant<int, (decltype(rc)::value + 1) % C::NST>{}); });
+#endif
+  for (; kt + 1 < nk; ++kt) kstep(kt, std::integral_constant<int, -1>{});
 #pragma unroll
   for (int i = 0; i < TI; ++i) mfma_row(i);
   if constexpr ((DBG & 16) != 0) {
