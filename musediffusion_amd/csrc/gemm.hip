@@ -513,6 +513,13 @@ template <int PIECES, int EXTRA = 0> __device__ __forceinline__ void wait_stages
 #ifndef MH_KLOOP_UNROLL
 #define MH_KLOOP_UNROLL 0
 #endif
+// 1 (round 5): the next K step's W fragments are read straight into their registers behind the last MFMA row - their latency falls under the next
+// step's wait + barrier - instead of into a second register set at the head of the step and copied over at its end (8 64-bit moves and 16
+// registers per step).  Two libraries alternated on one box (tools/ab_lib.sh lateb . -DMH_LATE_B=1): 3.496 -> 3.464 ms per step at config 2
+// (-0.9 %), 7.23 -> 7.21 at the bert-base width; same arithmetic, bit-identical outputs.  0 = the double-buffered form of rounds 1 - 4.
+#ifndef MH_LATE_B
+#define MH_LATE_B 1
+#endif
 template <class C, bool SWAP, int DBG, int NSTORE = 0>
 __device__ __forceinline__ void big_mainloop(f32x4 (&acc)[C::TI][C::TJ], const char* smem, const char* const (&srcA)[C::PA],
                                              const char* const (&srcW)[C::PW], const int (&ldsA)[C::PA], const int (&ldsW)[C::PW],
@@ -604,6 +611,19 @@ __device__ __forceinline__ void big_mainloop(f32x4 (&acc)[C::TI][C::TJ], const c
     constexpr bool SPREAD = (DBG & 1024) != 0 && C::PIECES <= TI;   // one DMA piece behind each MFMA row instead of a burst
     const bool refill = kt + C::NST < nk;
     if (!SPREAD && refill) issue(kt + C::NST, std::integral_constant<int, (S >= 0 ? (S + C::NST - 1) % C::NST : -1)>{});   // slot kt % NST: every wave has read stage kt out of it
+#if MH_LATE_B
+    // the W fragments of stage kt + 1 are read straight into b[] behind the LAST MFMA row of this step (their latency falls under the next
+    // step's wait + barrier): no second register set, no copy
+#pragma unroll
+    for (int i = 0; i < TI; ++i) {
+      mfma_row(i);
+      a[i] = read_frag(As + a_off + i * (16 * 64));
+      if constexpr (SPREAD) { if (refill && i < C::PIECES) issue_piece<C>(smem, srcA, srcW, ldsA, ldsW, kt + C::NST, kstepA, kstepW, i); }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) b[j] = read_frag(Ws + b_offs[j]);
+#else
 #pragma unroll
     for (int j = 0; j < TJ; ++j) bn[j] = read_frag(Ws + b_offs[j]);
 #pragma unroll
@@ -615,6 +635,7 @@ __device__ __forceinline__ void big_mainloop(f32x4 (&acc)[C::TI][C::TJ], const c
     }
 #pragma unroll
     for (int j = 0; j < TJ; ++j) b[j] = bn[j];
+#endif
   };
   int kt = 0;
 #if MH_KLOOP_UNROLL
