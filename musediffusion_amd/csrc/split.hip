@@ -231,36 +231,33 @@ __global__ __launch_bounds__(256, 2) void split_gemm_kernel(const SpGemmArgs g) 
   constexpr int GSW[4] = {0, 2, 3, 1};
   // DMA coordinates: a piece = 16 rows x 64 B; lane i lands at row i / 4, physical chunk i % 4, which holds logical chunk pc ^ G[..]
   const int rl = lane >> 2, pc = lane & 3, lc = pc ^ GSW[(rl >> 2) & 3];
-  const int64_t kstepA = g.lda * 64, kstepW = g.ldw * 64;
-  const char* srcA[GPA];
-  const char* srcW[GPW];
+  // The stage DMA as `buffer_load_dwordx4 ... lds` (round 5, as csrc/gemm.hip BufDma): the tile's rows of part 0, panel 0 as the base of a buffer
+  // descriptor (scalar registers), the (part, panel) of the stage as the instruction's scalar offset, a wave's consecutive pieces as its
+  // immediate offset (which advances the LDS address with the buffer address) and ONE per-lane offset: no vector address arithmetic per piece.
+  // Rows beyond M / N are not clamped: inside the buffer they read other rows (never stored), beyond it the descriptor's bound gives zeros.
+  const int kbA = (int)(g.lda * 64), kbW = (int)(g.ldw * 64);
+  const int va = ((wave * GPA) * 16 + rl) * 64 + lc * 16, vw = ((wave * GPW) * 16 + rl) * 64 + lc * 16;
+  __amdgpu_buffer_rsrc_t rA, rW;
   auto set_sources = [&](int64_t m0, int n0) {
-#pragma unroll
-    for (int j = 0; j < GPA; ++j) {
-      int64_t ra = m0 + (wave * GPA + j) * 16 + rl; if (ra >= g.M) ra = g.M - 1;
-      srcA[j] = reinterpret_cast<const char*>(g.A) + (ra * 32 + lc * 8) * 2;
-    }
-#pragma unroll
-    for (int j = 0; j < GPW; ++j) {
-      int rw = n0 + (wave * GPW + j) * 16 + rl; if (rw >= g.N) rw = g.N - 1;
-      srcW[j] = reinterpret_cast<const char*>(g.W) + ((int64_t)rw * 32 + lc * 8) * 2;
-    }
+    rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(g.A)) + m0 * 64, 0, (int)(2ll * nk0 * g.lda * 64 - m0 * 64), 0x00020000);
+    rW = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(g.W)) + (int64_t)n0 * 64, 0, (int)(2ll * nk0 * g.ldw * 64 - (int64_t)n0 * 64), 0x00020000);
   };
   // Two DMA stages per K-step kk serve its three products: stage 2kk = {A lo, W hi}, stage 2kk+1 = {A hi, W lo}; the third product,
   // A hi x W hi, runs in the odd stage on the A fragments it holds and the W hi fragments KEPT IN REGISTERS from the even stage - no
   // third load of either tile, no third round of LDS reads, no third barrier (a third less LDS-DMA, the path that paces these tiles).
   auto issue = [&](int kt) {
     const int kk = kt >> 1, odd = kt & 1;
-    const int64_t offA = (int64_t)((odd ? 0 : nk0) + kk) * kstepA, offW = (int64_t)((odd ? nk0 : 0) + kk) * kstepW;
+    const int offA = ((odd ? 0 : nk0) + kk) * kbA, offW = ((odd ? nk0 : 0) + kk) * kbW;
     char* base = smem + (kt % GNST) * GSTAGE;
-#pragma unroll
-    for (int j = 0; j < GPA; ++j)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcA[j] + offA),
-                                       (__attribute__((address_space(3))) void*)(base + (wave * GPA + j) * 1024), 16, 0, 0);
-#pragma unroll
-    for (int j = 0; j < GPW; ++j)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcW[j] + offW),
-                                       (__attribute__((address_space(3))) void*)(base + GBM * 64 + (wave * GPW + j) * 1024), 16, 0, 0);
+    auto la = (__attribute__((address_space(3))) void*)(base + (wave * GPA) * 1024);
+    auto lw = (__attribute__((address_space(3))) void*)(base + GBM * 64 + (wave * GPW) * 1024);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, la, 16, va, offA, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, la, 16, va, offA, 1024, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, la, 16, va, offA, 2048, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, la, 16, va, offA, 3072, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, lw, 16, vw, offW, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, lw, 16, vw, offW, 1024, 0);
+    static_assert(GPA == 4 && GPW == 2, "piece counts are written out (immediate offsets must be literals)");
   };
   const int frag_off = fr * 64 + ((fg ^ GSW[(fr >> 2) & 3]) << 4);
   const int a_off = wm * (GTI * 16 * 64) + frag_off;
@@ -419,22 +416,23 @@ __global__ __launch_bounds__(512, 1) void split_gemm_ln_kernel(const SpGemmArgs 
   constexpr int GSW[4] = {0, 2, 3, 1};
   const int64_t m0 = (int64_t)blockIdx.x * RBM;
   const int rl = lane >> 2, pc = lane & 3, lc = pc ^ GSW[(rl >> 2) & 3];
-  const int64_t kstepA = g.lda * 64, kstepW = g.ldw * 64;
-  int64_t ra = m0 + wave * 16 + rl; if (ra >= g.M) ra = g.M - 1;
-  const char* srcA = reinterpret_cast<const char*>(g.A) + (ra * 32 + lc * 8) * 2;
-  const char* srcW[RPW];
-#pragma unroll
-  for (int j = 0; j < RPW; ++j) srcW[j] = reinterpret_cast<const char*>(g.W) + ((int64_t)((wave * RPW + j) * 16 + rl) * 32 + lc * 8) * 2;
+  // (stage DMA as buffer loads: see split_gemm_kernel)
+  const int kbA = (int)(g.lda * 64), kbW = (int)(g.ldw * 64);
+  const int va = (wave * 16 + rl) * 64 + lc * 16, vw = ((wave * RPW) * 16 + rl) * 64 + lc * 16;
+  const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(g.A)) + m0 * 64, 0,
+                                                                      (int)(2ll * nk0 * g.lda * 64 - m0 * 64), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(g.W)), 0, (int)(2ll * nk0 * g.ldw * 64), 0x00020000);
   auto issue = [&](int kt) {
     const int kk = kt >> 1, odd = kt & 1;
-    const int64_t offA = (int64_t)((odd ? nk0 : 0) + kk) * kstepA, offW = (int64_t)((odd ? 0 : nk0) + kk) * kstepW;
+    const int offA = ((odd ? nk0 : 0) + kk) * kbA, offW = ((odd ? 0 : nk0) + kk) * kbW;
     char* base = smem + (kt % RNST) * RSTAGE;
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcA + offA),
-                                     (__attribute__((address_space(3))) void*)(base + wave * 1024), 16, 0, 0);
-#pragma unroll
-    for (int j = 0; j < RPW; ++j)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcW[j] + offW),
-                                       (__attribute__((address_space(3))) void*)(base + RBM * 64 + (wave * RPW + j) * 1024), 16, 0, 0);
+    auto lw = (__attribute__((address_space(3))) void*)(base + RBM * 64 + (wave * RPW) * 1024);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (__attribute__((address_space(3))) void*)(base + wave * 1024), 16, va, offA, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, lw, 16, vw, offW, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, lw, 16, vw, offW, 1024, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, lw, 16, vw, offW, 2048, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, lw, 16, vw, offW, 3072, 0);
+    static_assert(RPW == 4, "piece counts are written out (immediate offsets must be literals)");
   };
   const int frag_off = fr * 64 + ((fg ^ GSW[(fr >> 2) & 3]) << 4);
   const int a_off = wm * (RTI * 16 * 64) + frag_off;
@@ -584,6 +582,8 @@ __global__ __launch_bounds__(512, 1) void split_gemm_ln_kernel(const SpGemmArgs 
 
 template <typename T>
 int launch_gemm_ln(const SpGemmArgs& g, const float* gamma, const float* beta, float eps, hipStream_t s) {
+  MH_CHECK_ARG((int64_t)(g.K / 16) * g.lda * 64 < (1ll << 31) && (int64_t)(g.K / 16) * g.ldw * 64 < (1ll << 31),
+               "split_gemm_res_ln: an operand beyond 2 GiB (K=%d lda=%lld ldw=%lld): buffer-descriptor addressing is 32-bit", g.K, (long long)g.lda, (long long)g.ldw);
   const dim3 grid((unsigned)((g.M + RBM - 1) / RBM)), block(512);
   mh_prof_note("split tile=128x512 +LN M=%lld N=%d K=3x%d", (long long)g.M, g.N, g.K);
   MH_LAUNCH((split_gemm_ln_kernel<T>), grid, block, 0, s, g, gamma, beta, eps);
@@ -604,6 +604,9 @@ template <typename T>
 int launch_gemm(const SpGemmArgs& g0, int act, hipStream_t s) {
   const int64_t tiles = (int64_t)((g0.M + GBM - 1) / GBM) * ((g0.N + GBN - 1) / GBN);
   MH_CHECK_ARG(tiles > 0 && tiles < (1ll << 31), "split_gemm: bad grid (M=%lld N=%d)", (long long)g0.M, g0.N);
+  MH_CHECK_ARG((int64_t)(g0.K / 16) * g0.lda * 64 < (1ll << 31) && (int64_t)(g0.K / 16) * g0.ldw * 64 < (1ll << 31),
+               "split_gemm: an operand of [2][K/32][ld][32] beyond 2 GiB (K=%d lda=%lld ldw=%lld): buffer-descriptor addressing is 32-bit", g0.K,
+               (long long)g0.lda, (long long)g0.ldw);
   SpGemmArgs g = g0;
   g.ntiles = (int)tiles;
   const int64_t slots = 2 * (int64_t)sp_device_cus();
