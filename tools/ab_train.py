@@ -10,17 +10,17 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 KNOB = sys.argv[1] if len(sys.argv) > 1 else "FUSED_FFN"
 VALS = [int(v) for v in sys.argv[2:]]
-sys.argv = ["bench.py", "--workload", "train", "--steps", "4", "--warmup", "2", "--no-cpu-baseline", "--no-kernel-timing"]
+sys.argv = ["bench.py", "--workload", "train", "--steps", os.environ.get("AB_STEPS", "4"), "--warmup", "2", "--no-cpu-baseline", "--no-kernel-timing"]
 import bench  # noqa: E402
 from musediffusion_amd import training  # noqa: E402
 
-if KNOB in ("stagger", "dw_wide", "gemm_variant", "auto_wide"):      # library knobs: python tools/ab_train.py stagger 0 -500 -1500 1500 | dw_wide 0 1
+if KNOB in ("stagger", "dw_wide", "gemm_variant", "auto_wide", "buf_dma"):      # library knobs: python tools/ab_train.py stagger 0 -500 -1500 1500 | dw_wide 0 1
     from musediffusion_amd import _lib
     _lib.use_debug_library()   # the A/B switches live in libmusehip_dbg.so (include/musehip_dbg.h)
     vals = VALS
     for rnd in range(3):
         for v in vals:
-            {"stagger": _lib.lib().mh_gemm_set_stagger, "dw_wide": _lib.lib().mh_gemm_dw_set_wide, "gemm_variant": _lib.lib().mh_gemm_set_variant, "auto_wide": _lib.lib().mh_gemm_set_auto_wide}[KNOB](v)
+            {"stagger": _lib.lib().mh_gemm_set_stagger, "dw_wide": _lib.lib().mh_gemm_dw_set_wide, "gemm_variant": _lib.lib().mh_gemm_set_variant, "auto_wide": _lib.lib().mh_gemm_set_auto_wide, "buf_dma": _lib.lib().mh_gemm_set_buf_dma}[KNOB](v)
             buf = io.StringIO()
             with contextlib.redirect_stdout(buf):
                 bench.main()
@@ -28,6 +28,7 @@ if KNOB in ("stagger", "dw_wide", "gemm_variant", "auto_wide"):      # library k
     _lib.lib().mh_gemm_set_stagger(0)
     _lib.lib().mh_gemm_dw_set_wide(1)
     _lib.lib().mh_gemm_set_variant(2)
+    _lib.lib().mh_gemm_set_buf_dma(1)
     _lib.lib().mh_gemm_set_auto_wide(1)
     raise SystemExit(0)
 for rnd in range(3):

@@ -23,6 +23,7 @@ ap.add_argument("--ab", type=str, default="", help="comma list of debug-bit valu
 ap.add_argument("--noact", action="store_true")
 ap.add_argument("--panel", type=int, default=0, help="bit0 A, bit1 W, bit2 out, bit3 residual in K32-panel layout (timing only)")
 ap.add_argument("--spread", action="store_true", help="A/B the interleaved LDS-DMA issue (mh_gemm_set_spread) against the burst")
+ap.add_argument("--bufdma", action="store_true", help="A/B the stage DMA as buffer loads (mh_gemm_set_buf_dma) against global_load_lds")
 ap.add_argument("--stagger", type=str, default="", help="comma list of partner-block start delays (10-ns ticks) to A/B")
 ap.add_argument("--pad", type=int, default=0, help="extra elements on every leading dimension")
 a = ap.parse_args()
@@ -78,6 +79,8 @@ b_h, b_f, b_q = torch.zeros(H, device=dev), torch.zeros(F, device=dev), torch.ze
 o_h, o_f = torch.empty(M, H + P, device=dev, dtype=bf), torch.empty(M, F + P, device=dev, dtype=bf)
 q, k, vt = (torch.empty(M * H + 256, device=dev, dtype=bf) for _ in range(3))
 flops = {"ao_ln": 2.0 * M * H * H, "ffn2_ln": 2.0 * M * H * F, "ln": 0.0, "ao": 2.0 * M * H * H, "ffn1": 2.0 * M * H * F, "ffn2": 2.0 * M * H * F, "qkv": 2.0 * M * H * 3 * H}
+if a.bufdma:
+    a.spread = True
 if a.spread:
     import statistics
     for name in a.shapes.split(","):
@@ -85,7 +88,7 @@ if a.spread:
         res = {0: [], 1: []}
         for rnd in range(7):
             for v in (0, 1):
-                _lib.lib().mh_gemm_set_spread(v)
+                (_lib.lib().mh_gemm_set_buf_dma if a.bufdma else _lib.lib().mh_gemm_set_spread)(v)
                 fn(); torch.cuda.synchronize()
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
@@ -93,7 +96,7 @@ if a.spread:
                     fn()
                 e1.record(); torch.cuda.synchronize()
                 res[v].append(e0.elapsed_time(e1) / a.reps * 1e3)
-        print("spread %-8s: burst %.1f us  interleaved %.1f us" % (name, statistics.median(res[0]), statistics.median(res[1])), flush=True)
+        print(("buf_dma %-8s: global_load_lds %.1f us  buffer_load lds %.1f us" if a.bufdma else "spread %-8s: burst %.1f us  interleaved %.1f us") % (name, statistics.median(res[0]), statistics.median(res[1])), flush=True)
     sys.exit(0)
 if a.stagger:
     import statistics
