@@ -288,9 +288,12 @@ __global__ __launch_bounds__(256, 2) void split_gemm_kernel(const SpGemmArgs g) 
     sp_wait_stages(npro - 1);
   }
   __builtin_amdgcn_s_barrier();
-  x8 a[GTI], b[GTJ], bn[GTJ], bh[GTJ];
+  // W fragments by PART, not by stage: bA = W hi (the even stage's operand, used again by the odd stage's hi x hi product), bB = W lo (odd stages
+  // only).  bB is idle during an even stage, so the odd stage's fragments are read straight into it; bA is busy until the odd stage's last MFMA
+  // row and is re-read behind it.  No second register set and no copies (round 5; the sums keep their order: bit-identical).
+  x8 a[GTI], bA[GTJ], bB[GTJ];
 #pragma unroll
-  for (int j = 0; j < GTJ; ++j) b[j] = *reinterpret_cast<const x8*>(smem + GBM * 64 + b_offs[j]);
+  for (int j = 0; j < GTJ; ++j) bA[j] = *reinterpret_cast<const x8*>(smem + GBM * 64 + b_offs[j]);
 #pragma unroll
   for (int i = 0; i < GTI; ++i) a[i] = *reinterpret_cast<const x8*>(smem + a_off + i * (16 * 64));
   // one stage: the MFMAs of stage kt (odd stages: both W parts) with the fragments of stage kt + 1 read underneath them
@@ -305,27 +308,27 @@ __global__ __launch_bounds__(256, 2) void split_gemm_kernel(const SpGemmArgs g) 
       __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): this wave's reads of stage kt are done
       __builtin_amdgcn_s_barrier();
       if (kt + GNST < nk) issue(kt + GNST);   // slot kt % NST: every wave has read stage kt out of it
+      if constexpr (!ODD) {
 #pragma unroll
-      for (int j = 0; j < GTJ; ++j) bn[j] = *reinterpret_cast<const x8*>(Ws + b_offs[j]);
+        for (int j = 0; j < GTJ; ++j) bB[j] = *reinterpret_cast<const x8*>(Ws + b_offs[j]);
+      }
     }
 #pragma unroll
     for (int i = 0; i < GTI; ++i) {
-#pragma unroll
-      for (int j = 0; j < GTJ; ++j) acc[i][j] = Sp<T>::mma16(b[j], a[i], acc[i][j]);
       if constexpr (ODD) {
 #pragma unroll
-        for (int j = 0; j < GTJ; ++j) acc[i][j] = Sp<T>::mma16(bh[j], a[i], acc[i][j]);
+        for (int j = 0; j < GTJ; ++j) acc[i][j] = Sp<T>::mma16(bB[j], a[i], acc[i][j]);
       }
+#pragma unroll
+      for (int j = 0; j < GTJ; ++j) acc[i][j] = Sp<T>::mma16(bA[j], a[i], acc[i][j]);
       if (next) a[i] = *reinterpret_cast<const x8*>(As + a_off + i * (16 * 64));
       __builtin_amdgcn_sched_barrier(0);
     }
-    if constexpr (!ODD) {
+    if constexpr (ODD) {
+      if (next) {
 #pragma unroll
-      for (int j = 0; j < GTJ; ++j) bh[j] = b[j];
-    }
-    if (next) {
-#pragma unroll
-      for (int j = 0; j < GTJ; ++j) b[j] = bn[j];
+        for (int j = 0; j < GTJ; ++j) bA[j] = *reinterpret_cast<const x8*>(Ws + b_offs[j]);
+      }
     }
   };
   for (int kk = 0; kk < nk0; ++kk) {
@@ -456,11 +459,13 @@ __global__ __launch_bounds__(512, 1) void split_gemm_ln_kernel(const SpGemmArgs 
   __builtin_amdgcn_s_barrier();
   // (column-group-major MFMA order: a W fragment is re-read in place right after its last use, so only the four A fragments need a second
   // register set for the next stage - the tile's 128 accumulators leave no room for more at two waves per SIMD)
-  x8 a[RTI], an[RTI], ah[RTI], b[RTJ];
+  // A fragments by PART (as the W fragments of split_gemm_kernel): aX = A hi (even stages, and the odd stage's hi x hi product), aY = A lo (odd
+  // stages only, read during the even stage); aX is re-read behind the odd stage's last column group.
+  x8 aX[RTI], aY[RTI], b[RTJ];
 #pragma unroll
   for (int j = 0; j < RTJ; ++j) b[j] = *reinterpret_cast<const x8*>(smem + RBM * 64 + b_off(j));
 #pragma unroll
-  for (int i = 0; i < RTI; ++i) a[i] = *reinterpret_cast<const x8*>(smem + a_off + i * (16 * 64));
+  for (int i = 0; i < RTI; ++i) aX[i] = *reinterpret_cast<const x8*>(smem + a_off + i * (16 * 64));
   auto stage = [&](int kt, auto oddc) {
     constexpr bool ODD = decltype(oddc)::value;
     const bool next = kt + 1 < nk;
@@ -472,27 +477,27 @@ __global__ __launch_bounds__(512, 1) void split_gemm_ln_kernel(const SpGemmArgs 
       __builtin_amdgcn_s_waitcnt(0xC07F);
       __builtin_amdgcn_s_barrier();
       if (kt + RNST < nk) issue(kt + RNST);
+      if constexpr (!ODD) {
 #pragma unroll
-      for (int i = 0; i < RTI; ++i) an[i] = *reinterpret_cast<const x8*>(As + a_off + i * (16 * 64));
+        for (int i = 0; i < RTI; ++i) aY[i] = *reinterpret_cast<const x8*>(As + a_off + i * (16 * 64));
+      }
     }
 #pragma unroll
     for (int j = 0; j < RTJ; ++j) {
+      if constexpr (ODD) {   // b = W hi: the lo part of A first, then the hi x hi product on the A hi fragments of the even stage
 #pragma unroll
-      for (int i = 0; i < RTI; ++i) acc[i][j] = Sp<T>::mma16(b[j], a[i], acc[i][j]);
-      if constexpr (ODD) {   // b = W hi: the hi x hi product on the A hi fragments of the even stage
-#pragma unroll
-        for (int i = 0; i < RTI; ++i) acc[i][j] = Sp<T>::mma16(b[j], ah[i], acc[i][j]);
+        for (int i = 0; i < RTI; ++i) acc[i][j] = Sp<T>::mma16(b[j], aY[i], acc[i][j]);
       }
+#pragma unroll
+      for (int i = 0; i < RTI; ++i) acc[i][j] = Sp<T>::mma16(b[j], aX[i], acc[i][j]);
       if (next) b[j] = *reinterpret_cast<const x8*>(Ws + b_off(j));
       __builtin_amdgcn_sched_barrier(0);
     }
-    if constexpr (!ODD) {
+    if constexpr (ODD) {
+      if (next) {
 #pragma unroll
-      for (int i = 0; i < RTI; ++i) ah[i] = a[i];
-    }
-    if (next) {
-#pragma unroll
-      for (int i = 0; i < RTI; ++i) a[i] = an[i];
+        for (int i = 0; i < RTI; ++i) aX[i] = *reinterpret_cast<const x8*>(As + a_off + i * (16 * 64));
+      }
     }
   };
   for (int kk = 0; kk < nk0; ++kk) {
