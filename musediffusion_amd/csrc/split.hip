@@ -297,12 +297,12 @@ __global__ __launch_bounds__(256, 2) void split_gemm_kernel(const SpGemmArgs g) 
 #pragma unroll
   for (int i = 0; i < GTI; ++i) a[i] = *reinterpret_cast<const x8*>(smem + a_off + i * (16 * 64));
   // one stage: the MFMAs of stage kt (odd stages: both W parts) with the fragments of stage kt + 1 read underneath them
-  auto stage = [&](int kt, auto oddc) {
+  auto stage = [&](int kt, auto oddc, auto nextc) {
     constexpr bool ODD = decltype(oddc)::value;
-    const bool next = kt + 1 < nk;   // (a run-time flag on purpose: as a compile-time one the scheduler hoists the fragment reads and spills)
+    constexpr bool next = decltype(nextc)::value;   // (compile-time since round 5: the tile's last stage is peeled; as a run-time flag every fragment read sat behind a scalar branch)
     const char* As = smem + ((kt + 1) % GNST) * GSTAGE;
     const char* Ws = As + GBM * 64;
-    if (next) {
+    if constexpr (next) {
       const int younger = nk - 2 - kt < GNST - 2 ? nk - 2 - kt : GNST - 2;
       sp_wait_stages(younger);
       __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): this wave's reads of stage kt are done
@@ -321,20 +321,22 @@ __global__ __launch_bounds__(256, 2) void split_gemm_kernel(const SpGemmArgs g) 
       }
 #pragma unroll
       for (int j = 0; j < GTJ; ++j) acc[i][j] = Sp<T>::mma16(bA[j], a[i], acc[i][j]);
-      if (next) a[i] = *reinterpret_cast<const x8*>(As + a_off + i * (16 * 64));
+      if constexpr (next) a[i] = *reinterpret_cast<const x8*>(As + a_off + i * (16 * 64));
       __builtin_amdgcn_sched_barrier(0);
     }
-    if constexpr (ODD) {
-      if (next) {
+    if constexpr (ODD && next) {
+      {
 #pragma unroll
         for (int j = 0; j < GTJ; ++j) bA[j] = *reinterpret_cast<const x8*>(Ws + b_offs[j]);
       }
     }
   };
-  for (int kk = 0; kk < nk0; ++kk) {
-    stage(2 * kk, std::false_type{});
-    stage(2 * kk + 1, std::true_type{});
+  for (int kk = 0; kk < nk0 - 1; ++kk) {
+    stage(2 * kk, std::false_type{}, std::true_type{});
+    stage(2 * kk + 1, std::true_type{}, std::true_type{});
   }
+  stage(nk - 2, std::false_type{}, std::true_type{});
+  stage(nk - 1, std::true_type{}, std::false_type{});
 
   // ---- epilogue: lane's 8 consecutive columns of half qh: wcol0 + 32 qh + 8 fg, values acc[i][2 qh + (e >> 2)][e & 3]; row wrow0 + 16 i + fr
   const int wcol0 = n0 + wn * 64;
@@ -466,12 +468,12 @@ __global__ __launch_bounds__(512, 1) void split_gemm_ln_kernel(const SpGemmArgs 
   for (int j = 0; j < RTJ; ++j) b[j] = *reinterpret_cast<const x8*>(smem + RBM * 64 + b_off(j));
 #pragma unroll
   for (int i = 0; i < RTI; ++i) aX[i] = *reinterpret_cast<const x8*>(smem + a_off + i * (16 * 64));
-  auto stage = [&](int kt, auto oddc) {
+  auto stage = [&](int kt, auto oddc, auto nextc) {
     constexpr bool ODD = decltype(oddc)::value;
-    const bool next = kt + 1 < nk;
+    constexpr bool next = decltype(nextc)::value;
     const char* As = smem + ((kt + 1) % RNST) * RSTAGE;
     const char* Ws = As + RBM * 64;
-    if (next) {
+    if constexpr (next) {
       const int younger = nk - 2 - kt < RNST - 2 ? nk - 2 - kt : RNST - 2;
       sp_wait_stages_r(younger);
       __builtin_amdgcn_s_waitcnt(0xC07F);
@@ -490,20 +492,22 @@ __global__ __launch_bounds__(512, 1) void split_gemm_ln_kernel(const SpGemmArgs 
       }
 #pragma unroll
       for (int i = 0; i < RTI; ++i) acc[i][j] = Sp<T>::mma16(b[j], aX[i], acc[i][j]);
-      if (next) b[j] = *reinterpret_cast<const x8*>(Ws + b_off(j));
+      if constexpr (next) b[j] = *reinterpret_cast<const x8*>(Ws + b_off(j));
       __builtin_amdgcn_sched_barrier(0);
     }
-    if constexpr (ODD) {
-      if (next) {
+    if constexpr (ODD && next) {
+      {
 #pragma unroll
         for (int i = 0; i < RTI; ++i) aX[i] = *reinterpret_cast<const x8*>(As + a_off + i * (16 * 64));
       }
     }
   };
-  for (int kk = 0; kk < nk0; ++kk) {
-    stage(2 * kk, std::false_type{});
-    stage(2 * kk + 1, std::true_type{});
+  for (int kk = 0; kk < nk0 - 1; ++kk) {
+    stage(2 * kk, std::false_type{}, std::true_type{});
+    stage(2 * kk + 1, std::true_type{}, std::true_type{});
   }
+  stage(nk - 2, std::false_type{}, std::true_type{});
+  stage(nk - 1, std::true_type{}, std::false_type{});
   // ---- epilogue: v = acc + bias + residual; LayerNorm over the row; split-panel store
   float* red = reinterpret_cast<float*>(smem + RNST * RSTAGE);   // [RBM][4 column waves]
   const T* res = reinterpret_cast<const T*>(g.res);
