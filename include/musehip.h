@@ -713,6 +713,75 @@ int mh_attention_stream_fwd_prescaled(const void* q, const void* k, const void* 
                                       int B, int L, int nh, int dh, mh_stream_t stream);
 int mh_denoiser_get_defer_ln(void);
 
+/* ---------------------------------------------------------------- training step on K32 panels (round 6)
+ * The encoder layers of training_losses (models/diffusion.py:594-699 through models/network.py:151 -> HF BertLayer forward, and its
+ * autograd backward) with every GEMM operand in the K32-panel layout of the sampler's kernels: the reference runs ~40 ATen kernels
+ * per layer forward and as many backward; here one call per layer and direction launches the layer's kernels (csrc/train_layer.hip).
+ *
+ * mh_gemm_desc_launch: one descriptor for every bf16 dense launch of that path - out = [LayerNorm](drop(act(A W^T + bias)) [+ | o act'] residual):
+ * each of A / W / residual / out / pre_out row-major (ld = row pitch) or K32 panels (ld = rows of the panel buffer); pre_out: the
+ * pre-activation (pre_kind 0) or act'(pre) (1) of a dense + activation, in out's layout - or, with ln_gamma, the bf16-rounded
+ * pre-LayerNorm rows in its own layout (ldp / p_panel) while out receives the normalised rows (N = 512, the full-row tile);
+ * act_grad: `residual` holds a stored pre-activation / derivative and multiplies the product (mh_gemm_act_grad). */
+typedef struct mh_gemm_desc {
+  const void* A; int64_t lda; int a_panel;
+  const void* W; int64_t ldw; int w_panel;
+  const float* bias;
+  const void* residual; int64_t ldr; int r_panel;
+  void* out; int64_t ldo; int o_panel; int out_f32;
+  void* pre_out; int64_t ldp; int p_panel; int pre_kind;
+  int act, act_grad;
+  const float* ln_gamma; const float* ln_beta; float ln_eps;
+  const mh_dropout* drop;
+  int64_t M; int N, K;
+} mh_gemm_desc;
+int mh_gemm_desc_launch(const mh_gemm_desc* d, mh_stream_t stream);
+/* mh_gemm_dw_bias with both operands as K32 panels [cols / 32][ld rows][32] (panel != 0; M, N multiples of 32) */
+int mh_gemm_dw_bias_ex(const void* A, int64_t lda, const void* B, int64_t ldb, int panel, float* out_partials, int splits, int64_t K, int M,
+                       int N, int with_colsum, mh_stream_t stream);
+/* mh_layernorm_bwd_drop whose second output (dx o keep / (1 - p)) has its own layout: row-major with pitch ldm or (m_panel) K32 panels
+ * [H / 32][ldm rows][32]; always != 0: written even when the site drops nothing (a copy of dx in that layout) */
+int mh_layernorm_bwd_ex(const void* x, const void* dy, const float* gamma, void* dx, void* dx_dropped, int64_t ldm, int m_panel, int always,
+                        const mh_dropout* drop, float* partial, int n_partial, float* dgamma, float* dbeta, int accumulate, int64_t rows, int H,
+                        float eps, int dtype, mh_stream_t stream);
+/* mh_attention_stream_bwd_drop with O read from, and dq / dk / dv written as, K32 panels of the token-major tensors (o_panel / d_panel) */
+int mh_attention_stream_bwd_layout(const void* q, const void* k, const void* v, const void* dO, const void* o, int o_panel, int64_t o_ld,
+                                   const float* lse2, float* D, void* dq, void* dk, void* dv, int64_t ld_d, int d_panel, int B, int L, int nh,
+                                   int dh, float scale, int64_t qkv_batch_stride, int64_t qkv_head_stride, int64_t qkv_row_stride,
+                                   int64_t do_batch_stride, int64_t do_head_stride, int64_t do_row_stride, const uint32_t* keep_bits,
+                                   float drop_p, mh_stream_t stream);
+/* bf16 [rows, cols] row-major (pitch ld) <-> K32 panels [cols / 32][ld rows][32] (cols % 32 == 0); to_panel != 0: row-major in, panels out */
+int mh_repack_panel(const void* in, int64_t ld_in, void* out, int64_t ld_out, int64_t rows, int cols, int to_panel, mh_stream_t stream);
+
+/* One encoder layer of the training step.  N = B L tokens; "panel" = bf16 K32 panels [cols / 32][ld][32], "rows" = bf16 row-major.
+ * Weights: the bf16 working copies mh_weight_prep writes with its panel flags (mh_wprep_item.pad_ bits 0 / 1): w* = W [out][in] as panels
+ * over `in`, w*_t = W^T [in][out] as panels over `out` (the input-gradient GEMMs' operand).  The forward keeps what the backward reads:
+ * qkv rows [N][3H], vt (V^T in the streaming attention's key order, B nh dh L + 256 elements), ctx panel, lse [B nh L], pre1 / pre2
+ * rows (pre-LayerNorm), x1 panel, g / dact panels [F / 32][N][32] (gelu and gelu' of the FFN pre-activation), keep_bits.
+ * Dropout: p = 0 switches a site off; keep_bits (mh_dropout_bits_words(B nh, L) words) is read when bits_in != 0 (drawn ahead by
+ * mh_dropout_bits), else written by the forward.
+ * Backward: dy rows [N][H] in, dx rows out; `grads` fp32: dWqkv [3H][H] | dbqkv [3H] | dWao [H][H] | dbao [H] | dW1 [F][H] | db1 [F] |
+ * dW2 [H][F] | db2 [H] | dln1_g | dln1_b | dln2_g | dln2_b (mh_train_layer_grad_floats in all), summation order fixed.  With side_stream the
+ * folds of the split-K and LayerNorm partials run there, under the GEMMs that follow, and are joined into `stream` before the call returns.
+ * H = 512 (the full-row LayerNorm tile), F % 256 == 0, L % 64 == 0, L >= 512, head dim 32 or 64: mh_train_layer_supported. */
+typedef struct mh_train_layer {
+  int B, L, H, F, nh; float ln_eps;
+  int64_t ld;   /* rows of every activation / gradient panel buffer (>= B L; not a power of two: panels 2^k bytes apart share their HBM channels) */
+  const void *wqkv, *wqkv_t, *wao, *wao_t, *w1, *w1_t, *w2, *w2_t;
+  const float *bqkv, *bao, *b1, *b2, *ln1_g, *ln1_b, *ln2_g, *ln2_b;
+  mh_dropout drop_attn, drop_ao, drop_ffn;
+  uint32_t* keep_bits; int bits_in;
+  const void* x; int y_panel;
+  void *qkv, *vt, *ctx; float* lse; void *pre1, *x1, *g, *dact, *pre2, *y;
+  const void* dy; void* dx; void* scratch; size_t scratch_bytes; float* grads;
+  mh_stream_t side_stream;   /* backward: a second stream of the same device for the gradient folds (NULL: everything on `stream`) */
+} mh_train_layer;
+int mh_train_layer_supported(int B, int L, int H, int F, int nh);
+size_t mh_train_layer_scratch_bytes(int B, int L, int H, int F, int nh, int64_t ld);
+int64_t mh_train_layer_grad_floats(int H, int F);
+int mh_train_layer_fwd(const mh_train_layer* t, mh_stream_t stream);
+int mh_train_layer_bwd(const mh_train_layer* t, mh_stream_t stream);
+
 /* ---------------------------------------------------------------- per-launch timing (measurement)
  * Between mh_profile_start() and mh_profile_stop() every kernel this library launches is bracketed by two HIP events on its own
  * stream (not capturable: call outside hipGraph capture).  mh_profile_stop synchronises the device and writes one line per launch,

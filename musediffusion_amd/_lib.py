@@ -65,6 +65,25 @@ class WPrepItem(C.Structure):
                 ("ld_t", C.c_int64), ("tile_start", C.c_int32), ("pad_", C.c_int32)]
 
 
+class GemmDesc(C.Structure):
+    """mh_gemm_desc"""
+    _fields_ = [("A", VP), ("lda", I64), ("a_panel", INT), ("W", VP), ("ldw", I64), ("w_panel", INT), ("bias", VP),
+                ("residual", VP), ("ldr", I64), ("r_panel", INT), ("out", VP), ("ldo", I64), ("o_panel", INT), ("out_f32", INT),
+                ("pre_out", VP), ("ldp", I64), ("p_panel", INT), ("pre_kind", INT), ("act", INT), ("act_grad", INT),
+                ("ln_gamma", VP), ("ln_beta", VP), ("ln_eps", F32), ("drop", C.POINTER(Dropout)), ("M", I64), ("N", INT), ("K", INT)]
+
+
+class TrainLayer(C.Structure):
+    """mh_train_layer"""
+    _fields_ = ([(n, INT) for n in ("B", "L", "H", "F", "nh")] + [("ln_eps", F32), ("ld", I64)] +
+                [(n, VP) for n in ("wqkv", "wqkv_t", "wao", "wao_t", "w1", "w1_t", "w2", "w2_t")] +
+                [(n, VP) for n in ("bqkv", "bao", "b1", "b2", "ln1_g", "ln1_b", "ln2_g", "ln2_b")] +
+                [("drop_attn", Dropout), ("drop_ao", Dropout), ("drop_ffn", Dropout), ("keep_bits", VP), ("bits_in", INT),
+                 ("x", VP), ("y_panel", INT)] +
+                [(n, VP) for n in ("qkv", "vt", "ctx", "lse", "pre1", "x1", "g", "dact", "pre2", "y")] +
+                [("dy", VP), ("dx", VP), ("scratch", VP), ("scratch_bytes", C.c_size_t), ("grads", VP), ("side_stream", VP)])
+
+
 class LayerWeights(C.Structure):
     """mh_layer_weights"""
     _fields_ = [(n, VP) for n in ("w_qkv", "b_qkv", "w_ao", "b_ao", "ln1_g", "ln1_b", "w_ff1", "b_ff1",
@@ -175,6 +194,16 @@ SIGNATURES = {
     "mh_gemm_dw": (INT, [VP, I64, VP, I64, VP, INT, I64, INT, INT, VP]),
     "mh_gemm_dw_splits": (INT, [I64, INT, INT]),
     "mh_weight_prep": (INT, [VP, INT, INT, VP]),
+    "mh_gemm_desc_launch": (INT, [C.POINTER(GemmDesc), VP]),
+    "mh_gemm_dw_bias_ex": (INT, [VP, I64, VP, I64, INT, VP, INT, I64, INT, INT, INT, VP]),
+    "mh_layernorm_bwd_ex": (INT, [VP, VP, VP, VP, VP, I64, INT, INT, VP, VP, INT, VP, VP, INT, I64, INT, F32, INT, VP]),
+    "mh_attention_stream_bwd_layout": (INT, [VP, VP, VP, VP, VP, INT, I64, VP, VP, VP, VP, VP, I64, INT, INT, INT, INT, INT, F32, I64, I64, I64, I64, I64, I64, VP, F32, VP]),
+    "mh_repack_panel": (INT, [VP, I64, VP, I64, I64, INT, INT, VP]),
+    "mh_train_layer_supported": (INT, [INT, INT, INT, INT, INT]),
+    "mh_train_layer_scratch_bytes": (C.c_size_t, [INT, INT, INT, INT, INT, I64]),
+    "mh_train_layer_grad_floats": (I64, [INT, INT]),
+    "mh_train_layer_fwd": (INT, [C.POINTER(TrainLayer), VP]),
+    "mh_train_layer_bwd": (INT, [C.POINTER(TrainLayer), VP]),
     "mh_gemm_dw_bias": (INT, [VP, I64, VP, I64, VP, INT, I64, INT, INT, INT, VP]),
     "mh_gemm_act_grad": (INT, [VP, I64, VP, I64, VP, I64, VP, I64, I64, INT, INT, INT, VP]),
     "mh_gemm_bias_act_pre": (INT, [VP, I64, VP, I64, VP, VP, VP, I64, I64, INT, INT, INT, VP]),

@@ -108,7 +108,10 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const bf16* __restrict
                                                           const float* __restrict__ lse2, float* __restrict__ Dv,
                                                           bf16* __restrict__ dQ, int64_t ld_dq,
                                                           int L, int nh, int nbh, float scale, float scale_log2e, RowLayout lq_,
-                                                          RowLayout lo_, const uint32_t* __restrict__ keep_bits, float rscale) {
+                                                          RowLayout lo_, const uint32_t* __restrict__ keep_bits, float rscale,
+                                                          int o_panel, int64_t o_ld, int d_panel) {
+  // o_panel: O (the forward's context rows) as K32 panels [H / 32][o_ld rows][32] of the token-major [B L, H] tensor; d_panel: dQ likewise
+  // ([.][ld_dq rows][32]) - the layouts the training step's GEMMs read (csrc/train_layer.hip); dO stays in lo_'s row layout
   constexpr int NW = 8;
   constexpr int KS = DH / 16, DT = DH / 32;
   constexpr int ST = SKB * DH * 2;                 // bytes of one operand stage
@@ -181,7 +184,9 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const bf16* __restrict
       D_q = 0.f;
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
-        const bf16x8 of = *reinterpret_cast<const bf16x8*>(O + lo_.at(bh, nh, qc) + 16 * ks + 8 * h);
+        const bf16* op = o_panel ? O + ((int64_t)((bh % nh) * DT + (ks >> 1)) * o_ld + (int64_t)(bh / nh) * L + qc) * 32 + 16 * (ks & 1) + 8 * h
+                                 : O + lo_.at(bh, nh, qc) + 16 * ks + 8 * h;
+        const bf16x8 of = *reinterpret_cast<const bf16x8*>(op);
 #pragma unroll
         for (int j = 0; j < 8; ++j) D_q += (float)dof[ks][j] * (float)of[j];
       }
@@ -258,7 +263,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const bf16* __restrict
       const int64_t tok = (int64_t)b * L + q0 + lq;
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) {
-        bf16* dst = dQ + tok * ld_dq + head * DH + dt * 32;
+        bf16* dst = d_panel ? dQ + ((int64_t)(head * DT + dt) * ld_dq + tok) * 32 : dQ + tok * ld_dq + head * DH + dt * 32;
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) {
           bf16x4 v;
@@ -294,7 +299,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const bf16* __restric
                                                            const float* __restrict__ lse2, const float* __restrict__ Dv,
                                                            bf16* __restrict__ dK, bf16* __restrict__ dV, int64_t ld_d, int L,
                                                            int nh, int nbh, float scale, float scale_log2e, RowLayout lq_,
-                                                           RowLayout lo_, const uint32_t* __restrict__ keep_bits, float rscale) {
+                                                           RowLayout lo_, const uint32_t* __restrict__ keep_bits, float rscale, int d_panel) {
   constexpr int NW = 8;
   constexpr int KS = DH / 16, DT = DH / 32;
   constexpr int ST = SKB * DH * 2;
@@ -468,8 +473,9 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const bf16* __restric
       const int64_t tok = (int64_t)b * L + k0 + lq;
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) {
-        bf16* dstk = dK + tok * ld_d + head * DH + dt * 32;
-        bf16* dstv = dV + tok * ld_d + head * DH + dt * 32;
+        const int64_t doff = d_panel ? ((int64_t)(head * DT + dt) * ld_d + tok) * 32 : tok * ld_d + head * DH + dt * 32;
+        bf16* dstk = dK + doff;
+        bf16* dstv = dV + doff;
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) {
           bf16x4 a, c;
@@ -510,7 +516,7 @@ __global__ void attn_bwd_rowdot_kernel(const bf16* __restrict__ dctx, const bf16
 template <int DH, bool DROP, bool FULL>
 int launch_bwd(const bf16* q, const bf16* k, const bf16* v, const bf16* qT, const bf16* kT, const bf16* dO, const bf16* dOT, const bf16* o,
                const float* lse2, float* Dv, bf16* dq, bf16* dk, bf16* dv, int64_t ld, int B, int L, int nh, float scale,
-               RowLayout lqkv, RowLayout ldo, const uint32_t* keep_bits, float rscale, hipStream_t s) {
+               RowLayout lqkv, RowLayout ldo, const uint32_t* keep_bits, float rscale, hipStream_t s, int o_panel = 0, int64_t o_ld = 0, int d_panel = 0) {
   constexpr int ST = SKB * DH * 2;
   constexpr int bytes_dq = 2 * 2 * ST + (DROP && FULL ? 2 * 8 * (SKB / 64) * 256 : 0), bytes_dkv = 2 * (2 * ST + 2 * SKB * 4 + (DROP && FULL ? (SKB / 32) * 1024 : 0));
   (void)qT; (void)kT; (void)dOT;   // (the transposed copies of the round-2 interface: no longer read)
@@ -528,11 +534,11 @@ int launch_bwd(const bf16* q, const bf16* k, const bf16* v, const bf16* qT, cons
   const float sl2 = scale * 1.4426950408889634f;
   mh_prof_note("attn_bwd B*nh=%d L=%d dh=%d", nbh, L, DH);
   MH_LAUNCH((attn_bwd_dq_kernel<DH, DROP, FULL>), grid, block, bytes_dq, s, q, k, v, dO, o, lse2, Dv, dq, ld, L, nh, nbh, scale, sl2, lqkv, ldo,
-            keep_bits, rscale);
+            keep_bits, rscale, o_panel, o_ld, d_panel);
   MH_CHECK_LAUNCH();
   mh_prof_note("attn_bwd B*nh=%d L=%d dh=%d", nbh, L, DH);
   MH_LAUNCH((attn_bwd_dkv_kernel<DH, DROP, FULL>), grid, block, bytes_dkv, s, q, k, v, dO, lse2, Dv, dk, dv, ld, L, nh, nbh, scale, sl2, lqkv, ldo,
-            keep_bits, rscale);
+            keep_bits, rscale, d_panel);
   MH_CHECK_LAUNCH();
   return MH_OK;
 }
@@ -551,6 +557,10 @@ extern "C" int mh_attention_bwd_rowdot(const void* dctx, const void* ctx, int64_
   return MH_OK;
 }
 
+extern "C" int mh_attention_stream_bwd_layout(const void* q, const void* k, const void* v, const void* dO, const void* o, int o_panel, int64_t o_ld,
+                                              const float* lse2, float* D, void* dq, void* dk, void* dv, int64_t ld_d, int d_panel, int B, int L,
+                                              int nh, int dh, float scale, int64_t qsB, int64_t qsH, int64_t qld, int64_t osB, int64_t osH,
+                                              int64_t old_, const uint32_t* keep_bits, float drop_p, mh_stream_t stream);
 extern "C" int mh_attention_stream_bwd_ex(const void* q, const void* k, const void* v, const void* qT_perm, const void* kT_perm,
                                           const void* dO, const void* dOT_perm, const void* o, const float* lse2, float* D, void* dq, void* dk,
                                           void* dv, int64_t ld_d, int B, int L, int nh, int dh, float scale, int64_t qkv_batch_stride,
@@ -586,6 +596,20 @@ extern "C" int mh_attention_stream_bwd_drop(const void* q, const void* k, const 
                                             void* dv, int64_t ld_d, int B, int L, int nh, int dh, float scale, int64_t qsB, int64_t qsH,
                                             int64_t qld, int64_t osB, int64_t osH, int64_t old_, const uint32_t* keep_bits, float drop_p,
                                             mh_stream_t stream) {
+  (void)qT_perm; (void)kT_perm; (void)dOT_perm;
+  return mh_attention_stream_bwd_layout(q, k, v, dO, o, 0, 0, lse2, D, dq, dk, dv, ld_d, 0, B, L, nh, dh, scale, qsB, qsH, qld, osB, osH, old_, keep_bits,
+                                        drop_p, stream);
+}
+
+// The same with the layouts of O and of the three outputs chosen by the caller: o_panel / d_panel != 0: K32 panels [H / 32][o_ld | ld_d rows][32]
+// of the token-major tensors (dq / dk / dv then point at the first panel of their column block); dO (and, row-major, O) in the os* row layout.
+extern "C" int mh_attention_stream_bwd_layout(const void* q, const void* k, const void* v, const void* dO, const void* o, int o_panel, int64_t o_ld,
+                                              const float* lse2, float* D, void* dq, void* dk, void* dv, int64_t ld_d, int d_panel, int B, int L,
+                                              int nh, int dh, float scale, int64_t qsB, int64_t qsH, int64_t qld, int64_t osB, int64_t osH,
+                                              int64_t old_, const uint32_t* keep_bits, float drop_p, mh_stream_t stream) {
+  const void* qT_perm = nullptr; const void* kT_perm = nullptr; const void* dOT_perm = nullptr;
+  MH_CHECK_ARG(!o_panel || o_ld >= (int64_t)B * L, "attention_stream_bwd: o_ld must cover the B L token rows");
+  MH_CHECK_ARG(!d_panel || ld_d >= (int64_t)B * L, "attention_stream_bwd: ld_d must cover the B L token rows");
   MH_CHECK_ARG(qsB % 8 == 0 && qsH % 8 == 0 && qld % 8 == 0 && osB % 8 == 0 && osH % 8 == 0 && old_ % 8 == 0 && qld >= dh && old_ >= dh,
                "attention_stream_bwd: row strides must be multiples of 8 elements");
   const RowLayout lqkv{qsB, qsH, qld}, ldo{osB, osH, old_};
@@ -597,7 +621,8 @@ extern "C" int mh_attention_stream_bwd_drop(const void* q, const void* k, const 
   hipStream_t s = (hipStream_t)stream;
   const float rs = 1.0f / (1.0f - drop_p);
 #define MH_BWD_ARGS (const bf16*)q, (const bf16*)k, (const bf16*)v, (const bf16*)qT_perm, (const bf16*)kT_perm, (const bf16*)dO, \
-                    (const bf16*)dOT_perm, (const bf16*)o, lse2, D, (bf16*)dq, (bf16*)dk, (bf16*)dv, ld_d, B, L, nh, scale, lqkv, ldo, keep_bits, rs, s
+                    (const bf16*)dOT_perm, (const bf16*)o, lse2, D, (bf16*)dq, (bf16*)dk, (bf16*)dv, ld_d, B, L, nh, scale, lqkv, ldo, keep_bits, rs, s, \
+                    o_panel, o_ld, d_panel
   if (L % 256 == 0 && mh_attention_stream_enabled() != 4) {   // (mode 4 = A/B: the bound-checking build on every length)
     if (drop_p > 0.f) return dh == 64 ? launch_bwd<64, true, true>(MH_BWD_ARGS) : launch_bwd<32, true, true>(MH_BWD_ARGS);
     return dh == 64 ? launch_bwd<64, false, true>(MH_BWD_ARGS) : launch_bwd<32, false, true>(MH_BWD_ARGS);

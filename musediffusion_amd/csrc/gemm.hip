@@ -50,6 +50,7 @@ struct GemmArgs {
   // QKV scatter
   void* q; void* k; void* vt;
   void* pre_out;   // EPI 0 with an activation (big tile): also store the pre-activation (bias added) here, same layout as out
+  int64_t ldp; int p_panel;   // EPI 3 (training form): pre_out's own layout (row pitch / panel rows; 0 = as `out`: ldo, row-major)
   int act_grad;    // EPI 0 (big tile): `residual` holds a PRE-activation and the result is multiplied by act'(it) instead of added to
   int L, H, nh, dh;
   // EPI 2 (nearest-embedding scores): aux[col] = |W_col|^2, rown[row] = |x_row|^2, partial best per (row, slot)
@@ -793,7 +794,9 @@ __global__ __launch_bounds__(C::THREADS, C::STAGE * C::NST <= 80 * 1024 ? 2 : 1)
     const int tn0 = (b2 % tiles_n) * C::BN;
     if constexpr (BUFDMA) {   // (panel operands: row r of panel 0 at byte 64 r; everything here is wave-uniform)
       const int64_t offA = ((int64_t)blockIdx.y * g.sA) * 2 + tm0 * 64, offW = ((int64_t)blockIdx.y * g.sW) * 2 + (int64_t)tn0 * 64;
-      const int64_t bytesA = (int64_t)(g.K / 32) * g.lda * 64 - tm0 * 64, bytesW = (int64_t)(g.K / 32) * g.ldw * 64 - (int64_t)tn0 * 64;
+      // bound = the rows this operand OWNS in its last panel (g.A may be a row window of a larger panel buffer: lda > M, first row > 0): rows
+      // beyond M / N of the last panel are zero-filled by the descriptor instead of being fetched from behind the allocation
+      const int64_t bytesA = (int64_t)(g.K / 32 - 1) * g.lda * 64 + (g.M - tm0) * 64, bytesW = (int64_t)(g.K / 32 - 1) * g.ldw * 64 + ((int64_t)g.N - tn0) * 64;
       bd.ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(g.A)) + offA, 0, (int)bytesA, 0x00020000);
       bd.rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(g.W)) + offW, 0, (int)bytesW, 0x00020000);
       return;
@@ -1134,7 +1137,8 @@ __global__ __launch_bounds__(C::THREADS, C::STAGE * C::NST <= 80 * 1024 ? 2 : 1)
 #pragma unroll
               for (int e = 0; e < 8; ++e) v[e] = (float)(bf16)v[e];
               const int64_t row = wrow0 + 16 * i + fr;
-              if (row < g.M) store8_nt(preT + row * g.ldo + col, v);
+              const int64_t ldp = g.ldp ? g.ldp : g.ldo;
+              if (row < g.M) store8_nt(preT + (g.p_panel ? ((int64_t)(col >> 5) * ldp + row) * 32 + (col & 31) : row * ldp + col), v);
             }
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
@@ -1416,7 +1420,7 @@ int launch_big(const GemmArgs& g0, hipStream_t s, int batch) {
     else MH_LAUNCH_BIG(1, MH_ACT_NONE, 32);
   } else if constexpr (EPI == 3) {
     if (g.drop.thr || g.pre_out) {   // the training build: dropout (p may be 0) + the un-normalised rows kept for the backward
-      if constexpr (C::BN == 512 && C::PP) MH_LAUNCH((gemm_big_kernel<C, 3, MH_ACT_NONE, 64>), grid, block, 0, s, g);
+      if constexpr (C::BN == 512 && C::PP) MH_LAUNCH_BIG(3, MH_ACT_NONE, 64);
       else { mh_set_error("gemm: the dropout + LayerNorm epilogue is built for the 128x512 tile only"); return MH_ERR_UNSUPPORTED; }
     } else MH_LAUNCH_BIG(3, MH_ACT_NONE, 0);
   } else {
@@ -1570,6 +1574,7 @@ int launch(const GemmArgs& g, int dtype, hipStream_t s, int batch = 1) {
 
 }  // namespace
 
+int mh_drop_args(const mh_dropout* d, DropArgs* out);
 extern "C" int mh_gemm_bias_res_ln_supported(int N) { return N == 128 || N == 256 || N == 512; }
 
 #ifdef MH_ABLATE
@@ -1804,6 +1809,35 @@ extern "C" int mh_gemm_act_grad(const void* A, int64_t lda, const void* W, int64
   return launch<0>(g, MH_BF16, (hipStream_t)stream);
 }
 
+// One descriptor for every bf16 dense launch of the training step (csrc/train_layer.hip): each operand row-major or K32-panel on its own,
+// optional second output (pre-activation / act'(pre) / the pre-LayerNorm rows), activation-gradient epilogue, dropout, full-row LayerNorm.
+extern "C" int mh_gemm_desc_launch(const mh_gemm_desc* d, mh_stream_t stream) {
+  MH_CHECK_ARG(d && d->A && d->W && d->out, "gemm_desc: null pointer");
+  MH_CHECK_ARG(d->M > 0 && d->N > 0 && d->K > 0 && d->K % B2K == 0, "gemm_desc: bad problem M=%lld N=%d K=%d", (long long)d->M, d->N, d->K);
+  MH_CHECK_ARG(d->act >= MH_ACT_NONE && d->act <= MH_ACT_SILU, "gemm_desc: unknown activation %d", d->act);
+  MH_CHECK_ARG(!(d->o_panel && d->out_f32), "gemm_desc: fp32 output is row-major only");
+  MH_CHECK_ARG(g_variant >= 2, "gemm_desc: needs the big-tile bf16 kernel");
+  GemmArgs g{};
+  g.A = d->A; g.lda = d->lda; g.a_panel = d->a_panel; g.W = d->W; g.ldw = d->ldw; g.w_panel = d->w_panel; g.bias = d->bias;
+  g.residual = d->residual; g.ldr = d->residual ? d->ldr : 8; g.r_panel = d->residual ? d->r_panel : 0;
+  g.out = d->out; g.ldo = d->ldo; g.o_panel = d->o_panel; g.out_f32 = d->out_f32;
+  g.pre_out = d->pre_out; g.ldp = d->ldp; g.p_panel = d->p_panel; g.pre_kind = d->pre_kind;
+  g.M = d->M; g.N = d->N; g.K = d->K; g.act = d->act; g.act_grad = d->act_grad;
+  int rc = mh_drop_args(d->drop, &g.drop);
+  if (rc) return rc;
+  MH_CHECK_ARG((g.a_panel || g.lda % 8 == 0) && (g.w_panel || g.ldw % 8 == 0) && big_tile_ok(g), "gemm_desc: leading dimensions must be multiples of 8");
+  if (d->ln_gamma) {
+    MH_CHECK_ARG(d->ln_beta && d->bias && d->residual && d->pre_out, "gemm_desc: the LayerNorm epilogue needs bias, residual, beta and pre_out");
+    MH_CHECK_ARG(d->N == 512 && d->act == MH_ACT_NONE && !d->act_grad && !d->out_f32, "gemm_desc: the dropout + LayerNorm epilogue is built for N = 512");
+    MH_CHECK_ARG(d->p_panel || (d->ldp ? d->ldp : d->ldo) % 8 == 0, "gemm_desc: ldp must be a multiple of 8");
+    g.ln_gamma = d->ln_gamma; g.ln_beta = d->ln_beta; g.ln_eps = d->ln_eps;
+    return launch_big<CfgRowPP, 3>(g, (hipStream_t)stream, 1);
+  }
+  MH_CHECK_ARG(!d->pre_out || d->act != MH_ACT_NONE, "gemm_desc: pre_out without a LayerNorm needs an activation");
+  MH_CHECK_ARG(!d->act_grad || d->residual, "gemm_desc: act_grad reads the stored pre-activation / derivative through `residual`");
+  return launch<0>(g, MH_BF16, (hipStream_t)stream);
+}
+
 extern "C" int mh_gemm_batched(const void* A, int64_t lda, int64_t strideA, const void* W, int64_t ldw, int64_t strideW,
                                const float* bias, void* out, int64_t ldo, int64_t strideO, int out_f32, int batch, int64_t M,
                                int N, int K, int dtype, mh_stream_t stream) {
@@ -1990,7 +2024,7 @@ struct TnArgs {
   const bf16* B; int64_t ldb;   // [K, ldb], columns = n
   float* out;                   // [splits][slice]: M x N products, then (CS) the M column sums of A
   int M, N;
-  int64_t Kslice;               // tokens per slice (multiple of 32)
+  int64_t Ksteps;               // K steps (32 tokens each) in all; slice s of gridDim.y runs steps [s Ksteps / gridDim.y, (s + 1) Ksteps / gridDim.y)
   int64_t slice;                // floats per split slice: M N (+ M)
 };
 
@@ -2006,7 +2040,11 @@ __device__ __forceinline__ int tn_f(int row) { return ((row & 3) | (((row >> 3) 
 // one block per CU - the same waves per SIMD and the same wave tile, but HALF the blocks for the same chip occupancy: the fp32
 // partials of a launch (one tile per block: blocks x 128 KiB, whatever the shape) and their fold by mh_sum_slices halve, and both
 // operand panels are read once per 256 x 256 outputs.
-template <int CS, int WN = 2>
+// PANEL (round 6): both operands as K32 panels [cols / 32][ld rows][32] - the layout every GEMM operand of the training step has since the
+// forward and input-gradient GEMMs moved onto the sampler's panel tiles.  A stage keeps the panels apart ([panel][32 k][64 B]: one DMA piece =
+// 16 consecutive tokens of one panel = 1 KiB of contiguous memory), the transposing reads address 64-byte rows, and the 32-byte halves of a row
+// swap for k rows 8 - 15 / 24 - 31 (on the DMA source address) so that the 8 rows of a 32-lane half fall on 8 different 32-byte bank slots.
+template <int CS, int WN = 2, bool PANEL = false>
 __global__ __launch_bounds__(128 * WN, WN == 2 ? 2 : 1) void gemm_tn_kernel(const TnArgs g) {
   constexpr int BMt = 256, BNt = 64 * WN, NWt = 2 * WN, NSTt = 3, ASTAGE = 32 * BMt * 2, BSTAGE = 32 * BNt * 2, STAGEt = ASTAGE + BSTAGE;
   constexpr int TIt = 8, TJt = 4;
@@ -2018,13 +2056,33 @@ __global__ __launch_bounds__(128 * WN, WN == 2 ? 2 : 1) void gemm_tn_kernel(cons
   const int wm = wave / WN, wn = wave % WN;
   const int tiles_n = (g.N + BNt - 1) / BNt;
   const int m0 = (blockIdx.x / tiles_n) * BMt, n0 = (blockIdx.x % tiles_n) * BNt;
-  const int64_t k_begin = (int64_t)blockIdx.y * g.Kslice;
-  const int nk = (int)(g.Kslice / 32);
+  // (uneven slices: the split count is chosen to fill the chip - 21 slices of a 12-tile output on 256 CUs - not to divide the K steps)
+  const int64_t ks0 = (int64_t)blockIdx.y * g.Ksteps / gridDim.y, ks1 = (int64_t)(blockIdx.y + 1) * g.Ksteps / gridDim.y;
+  const int64_t k_begin = ks0 * 32;
+  const int nk = (int)(ks1 - ks0);
   const int fr = lane & 15, fg = lane >> 4;
 
   // DMA: A stage = 16 pieces of (2 k-rows x 512 B); B stage = pieces of (RPPB k-rows x BNt * 2 B)
   const bf16* srcA[PAt];
   const bf16* srcB[PBt];
+  if constexpr (PANEL) {
+    // piece = (panel of the tile, half of the stage's 32 tokens); lane i lands at token i / 4, physical chunk i % 4
+    const int rl = lane >> 2, pc = lane & 3;
+#pragma unroll
+    for (int j = 0; j < PAt; ++j) {
+      const int piece = wave * PAt + j, row = (piece & 1) * 16 + rl, lc = pc ^ (((row >> 3) & 1) << 1);
+      int pn = (m0 >> 5) + (piece >> 1);
+      if (pn > (g.M >> 5) - 1) pn = (g.M >> 5) - 1;         // M % 32 == 0: clamp whole panels (results beyond M are not stored)
+      srcA[j] = g.A + ((int64_t)pn * g.lda + k_begin + row) * 32 + lc * 8;
+    }
+#pragma unroll
+    for (int j = 0; j < PBt; ++j) {
+      const int piece = wave * PBt + j, row = (piece & 1) * 16 + rl, lc = pc ^ (((row >> 3) & 1) << 1);
+      int pn = (n0 >> 5) + (piece >> 1);
+      if (pn > (g.N >> 5) - 1) pn = (g.N >> 5) - 1;
+      srcB[j] = g.B + ((int64_t)pn * g.ldb + k_begin + row) * 32 + lc * 8;
+    }
+  } else {
 #pragma unroll
   for (int j = 0; j < PAt; ++j) {
     const int piece = wave * PAt + j, row = piece * 2 + (lane >> 5), pc = lane & 31;
@@ -2039,15 +2097,17 @@ __global__ __launch_bounds__(128 * WN, WN == 2 ? 2 : 1) void gemm_tn_kernel(cons
     if (col > g.N - 8) col = g.N - 8;
     srcB[j] = g.B + (k_begin + row) * g.ldb + col;
   }
+  }
+  const int64_t kadvA = PANEL ? 32 * 32 : 32 * g.lda, kadvB = PANEL ? 32 * 32 : 32 * g.ldb;   // elements per K step (32 tokens)
   auto issue = [&](int kt) {
     char* base = smem + (kt % NSTt) * STAGEt;
 #pragma unroll
     for (int j = 0; j < PAt; ++j)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcA[j] + (int64_t)kt * 32 * g.lda),
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcA[j] + (int64_t)kt * kadvA),
                                        (__attribute__((address_space(3))) void*)(base + (wave * PAt + j) * 1024), 16, 0, 0);
 #pragma unroll
     for (int j = 0; j < PBt; ++j)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcB[j] + (int64_t)kt * 32 * g.ldb),
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcB[j] + (int64_t)kt * kadvB),
                                        (__attribute__((address_space(3))) void*)(base + ASTAGE + (wave * PBt + j) * 1024), 16, 0, 0);
   };
   // transposing reads: lane 4q + p of a 16-lane group addresses row q, columns 4p .. 4p+3 of a (4 k) x (16 columns) block and
@@ -2058,6 +2118,11 @@ __global__ __launch_bounds__(128 * WN, WN == 2 ? 2 : 1) void gemm_tn_kernel(cons
   for (int half = 0; half < 2; ++half) {
     const int row = 8 * fg + 4 * half + q;
     const int f = tn_f(row);
+    if constexpr (PANEL) {   // (row start + the lane's 8 bytes inside a 32-byte half; frag_half adds the panel and the half)
+      offA[half] = row * 64 + ((p >> 1) << 4) + ((p & 1) << 3);
+      offB[half] = ASTAGE + offA[half];
+      continue;
+    }
     // column 4p of a 16-column tile starting at a multiple of 16: chunk (tile*2 + (p >> 1)) ^ f, byte (p & 1) * 8
     offA[half] = row * (BMt * 2) + ((((p >> 1)) ^ f) << 4) + ((p & 1) << 3);
     offB[half] = ASTAGE + row * (BNt * 2) + ((((p >> 1)) ^ f) << 4) + ((p & 1) << 3);
@@ -2070,9 +2135,14 @@ __global__ __launch_bounds__(128 * WN, WN == 2 ? 2 : 1) void gemm_tn_kernel(cons
   auto frag_half = [&](unsigned stage_off, const int (&off)[2], int tile16, int half) -> s16x4 {
     // tile16 = index of the 16-column tile: its two chunks are 2*tile16, 2*tile16 + 1, XOR-ed with the row's swizzle f
     const int row = 8 * fg + 4 * half + q;
+    unsigned addr;
+    if constexpr (PANEL) {   // panel tile16 / 2 of the operand's stage, 64-byte rows, 32-byte half (tile16 & 1) ^ (row bit 3)
+      addr = lds0 + stage_off + off[half] + (tile16 >> 1) * 2048 + (((tile16 & 1) ^ ((row >> 3) & 1)) << 5);
+    } else {
     const int f = tn_f(row);
     const int base = off[half] - (((p >> 1) ^ f) << 4);          // row start (+ byte-in-chunk)
-    const unsigned addr = lds0 + stage_off + base + ((((tile16 << 1) + (p >> 1)) ^ f) << 4);
+    addr = lds0 + stage_off + base + ((((tile16 << 1) + (p >> 1)) ^ f) << 4);
+    }
     s16x4 v;
     asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr));
     return v;
@@ -2186,15 +2256,23 @@ extern "C" int mh_gemm_dw_splits(int64_t K, int M, int N) {
   const bool wide = dw_wide(N);
   const int tiles = ceil_div(M, 256) * ceil_div(N, wide ? 256 : 128);
   const int target = wide ? (g_dw_blocks + 1) / 2 : g_dw_blocks;
-  int S = 1;
-  while (S < 64 && tiles * S < target && K % (2 * S * 32) == 0 && K / (2 * S) >= 512) S *= 2;
-  return S;
+  // as many slices as keep every block slot of the chip busy ONCE (round 6: any count - the slices may differ by one K step; rounds 2 - 5
+  // doubled the count until it reached the target, which ran the [1536 x 512] gradient's 12 tiles as 384 blocks = 1.5 rounds on 256 CUs),
+  // at most 64 and at least 16 K steps (512 tokens) per slice
+  int64_t S = target / tiles;
+  const int64_t ksteps = K / 32;
+  if (S > ksteps / 16) S = ksteps / 16;
+  if (S > 64) S = 64;
+  if (S < 1) S = 1;
+  return (int)S;
 }
 
 // dW = A^T B for k-major bf16 operands: out_partials [splits][M][N] fp32 (splits = mh_gemm_dw_splits(K, M, N); fold with
 // mh_sum_slices).  M, N multiples of 8, lda / ldb multiples of 8, K a multiple of 32 * splits.
 extern "C" int mh_gemm_dw_bias(const void* A, int64_t lda, const void* B, int64_t ldb, float* out_partials, int splits, int64_t K, int M,
                                int N, int with_colsum, mh_stream_t stream);
+extern "C" int mh_gemm_dw_bias_ex(const void* A, int64_t lda, const void* B, int64_t ldb, int panel, float* out_partials, int splits, int64_t K,
+                                  int M, int N, int with_colsum, mh_stream_t stream);
 
 extern "C" int mh_gemm_dw(const void* A, int64_t lda, const void* B, int64_t ldb, float* out_partials, int splits, int64_t K, int M,
                           int N, mh_stream_t stream) {
@@ -2205,16 +2283,34 @@ extern "C" int mh_gemm_dw(const void* A, int64_t lda, const void* B, int64_t ldb
 // the bias gradient of the linear whose weight gradient this is); one mh_sum_slices over M N + M elements folds both.
 extern "C" int mh_gemm_dw_bias(const void* A, int64_t lda, const void* B, int64_t ldb, float* out_partials, int splits, int64_t K, int M,
                                int N, int with_colsum, mh_stream_t stream) {
+  return mh_gemm_dw_bias_ex(A, lda, B, ldb, 0, out_partials, splits, K, M, N, with_colsum, stream);
+}
+
+// panel != 0: both operands as K32 panels [cols / 32][ld rows][32] (lda / ldb = rows of the panel buffers, M and N multiples of 32)
+extern "C" int mh_gemm_dw_bias_ex(const void* A, int64_t lda, const void* B, int64_t ldb, int panel, float* out_partials, int splits, int64_t K,
+                                  int M, int N, int with_colsum, mh_stream_t stream) {
   MH_CHECK_ARG(A && B && out_partials, "gemm_dw: null pointer");
+  MH_CHECK_ARG(!panel || (M % 32 == 0 && N % 32 == 0 && lda >= K && ldb >= K), "gemm_dw: panel operands need M, N multiples of 32 and ld >= K rows");
   MH_CHECK_ARG(M > 0 && N > 0 && M % 8 == 0 && N % 4 == 0 && N % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0, "gemm_dw: M, N, lda, ldb must be multiples of 8");
-  MH_CHECK_ARG(splits >= 1 && splits <= 65535 && K > 0 && K % ((int64_t)splits * 32) == 0, "gemm_dw: K=%lld must be a multiple of 32 * splits", (long long)K);
-  TnArgs g{(const bf16*)A, lda, (const bf16*)B, ldb, out_partials, M, N, K / splits, (int64_t)M * N + (with_colsum ? M : 0)};
+  MH_CHECK_ARG(splits >= 1 && splits <= 65535 && K > 0 && K % 32 == 0 && splits <= K / 32, "gemm_dw: K=%lld must be a multiple of 32 with at least one K step per split", (long long)K);
+  TnArgs g{(const bf16*)A, lda, (const bf16*)B, ldb, out_partials, M, N, K / 32, (int64_t)M * N + (with_colsum ? M : 0)};
   const bool wide = dw_wide(N);
   const int tiles_n = ceil_div(N, wide ? 256 : 128);
   const dim3 grid((unsigned)(ceil_div(M, 256) * tiles_n), (unsigned)splits);
   mh_prof_note("gemm_dw M=%d N=%d K=%lld splits=%d colsum=%d tile=256x%d", M, N, (long long)K, splits, with_colsum != 0, wide ? 256 : 128);
   hipStream_t st = (hipStream_t)stream;
-  if (wide) {   // column-sum workers = n-tiles x 4 wave columns
+  if (panel && wide) {
+    if (!with_colsum) MH_LAUNCH((gemm_tn_kernel<0, 4, true>), grid, dim3(512), 0, st, g);
+    else if (tiles_n >= 2) MH_LAUNCH((gemm_tn_kernel<8, 4, true>), grid, dim3(512), 0, st, g);
+    else MH_LAUNCH((gemm_tn_kernel<4, 4, true>), grid, dim3(512), 0, st, g);
+  }
+  else if (panel) {
+    if (!with_colsum) MH_LAUNCH((gemm_tn_kernel<0, 2, true>), grid, dim3(256), 0, st, g);
+    else if (tiles_n >= 4) MH_LAUNCH((gemm_tn_kernel<8, 2, true>), grid, dim3(256), 0, st, g);
+    else if (tiles_n >= 2) MH_LAUNCH((gemm_tn_kernel<4, 2, true>), grid, dim3(256), 0, st, g);
+    else MH_LAUNCH((gemm_tn_kernel<2, 2, true>), grid, dim3(256), 0, st, g);
+  }
+  else if (wide) {   // column-sum workers = n-tiles x 4 wave columns
     if (!with_colsum) MH_LAUNCH((gemm_tn_kernel<0, 4>), grid, dim3(512), 0, st, g);
     else if (tiles_n >= 2) MH_LAUNCH((gemm_tn_kernel<8, 4>), grid, dim3(512), 0, st, g);
     else MH_LAUNCH((gemm_tn_kernel<4, 4>), grid, dim3(512), 0, st, g);

@@ -234,13 +234,15 @@ __global__ __launch_bounds__(256, 2) void split_gemm_kernel(const SpGemmArgs g) 
   // The stage DMA as `buffer_load_dwordx4 ... lds` (round 5, as csrc/gemm.hip BufDma): the tile's rows of part 0, panel 0 as the base of a buffer
   // descriptor (scalar registers), the (part, panel) of the stage as the instruction's scalar offset, a wave's consecutive pieces as its
   // immediate offset (which advances the LDS address with the buffer address) and ONE per-lane offset: no vector address arithmetic per piece.
-  // Rows beyond M / N are not clamped: inside the buffer they read other rows (never stored), beyond it the descriptor's bound gives zeros.
+  // Rows beyond M / N are not clamped: inside the buffer they read other rows (never stored); the descriptor ends with the rows this operand OWNS in
+  // its last (part, panel) - A / W may be row windows of a larger buffer (the V^T projection: rows 2H.. of the stacked q | k | v weight) - so rows
+  // beyond them read as zeros instead of bytes behind the allocation.
   const int kbA = (int)(g.lda * 64), kbW = (int)(g.ldw * 64);
   const int va = ((wave * GPA) * 16 + rl) * 64 + lc * 16, vw = ((wave * GPW) * 16 + rl) * 64 + lc * 16;
   __amdgpu_buffer_rsrc_t rA, rW;
   auto set_sources = [&](int64_t m0, int n0) {
-    rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(g.A)) + m0 * 64, 0, (int)(2ll * nk0 * g.lda * 64 - m0 * 64), 0x00020000);
-    rW = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(g.W)) + (int64_t)n0 * 64, 0, (int)(2ll * nk0 * g.ldw * 64 - (int64_t)n0 * 64), 0x00020000);
+    rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(g.A)) + m0 * 64, 0, (int)((2ll * nk0 - 1) * g.lda * 64 + (g.M - m0) * 64), 0x00020000);
+    rW = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(g.W)) + (int64_t)n0 * 64, 0, (int)((2ll * nk0 - 1) * g.ldw * 64 + ((int64_t)g.N - n0) * 64), 0x00020000);
   };
   // Two DMA stages per K-step kk serve its three products: stage 2kk = {A lo, W hi}, stage 2kk+1 = {A hi, W lo}; the third product,
   // A hi x W hi, runs in the odd stage on the A fragments it holds and the W hi fragments KEPT IN REGISTERS from the even stage - no
@@ -425,8 +427,8 @@ __global__ __launch_bounds__(512, 1) void split_gemm_ln_kernel(const SpGemmArgs 
   const int kbA = (int)(g.lda * 64), kbW = (int)(g.ldw * 64);
   const int va = (wave * 16 + rl) * 64 + lc * 16, vw = ((wave * RPW) * 16 + rl) * 64 + lc * 16;
   const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(g.A)) + m0 * 64, 0,
-                                                                      (int)(2ll * nk0 * g.lda * 64 - m0 * 64), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(g.W)), 0, (int)(2ll * nk0 * g.ldw * 64), 0x00020000);
+                                                                      (int)((2ll * nk0 - 1) * g.lda * 64 + (g.M - m0) * 64), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(g.W)), 0, (int)((2ll * nk0 - 1) * g.ldw * 64 + (int64_t)g.N * 64), 0x00020000);
   auto issue = [&](int kt) {
     const int kk = kt >> 1, odd = kt & 1;
     const int offA = ((odd ? nk0 : 0) + kk) * kbA, offW = ((odd ? 0 : nk0) + kk) * kbW;

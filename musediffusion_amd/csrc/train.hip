@@ -254,7 +254,10 @@ __global__ void act_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x
 template <typename T, int LNCH, bool DROPM = false>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, const float* __restrict__ gamma,
                                                      T* __restrict__ dx, float* __restrict__ pg, float* __restrict__ pb,
-                                                     int64_t rows, int H, float eps, T* __restrict__ dxm = nullptr, const DropArgs drop = DropArgs{}) {
+                                                     int64_t rows, int H, float eps, T* __restrict__ dxm = nullptr, const DropArgs drop = DropArgs{},
+                                                     int64_t ldm = 0, int m_panel = 0) {
+  // (no FP contraction: the instantiation that also writes the dropped copy must round dx exactly as the one that does not)
+#pragma clang fp contract(off)
   __shared__ float red[2][4][512 * LNCH];  // [dgamma|dbeta][wave][col]
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int nch = H >> 3;
@@ -314,10 +317,13 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ x, co
         for (int e = 0; e < 8; ++e) o[e] = rstd * (gv[i][e] - s1 - xv[i][e] * s2);
         store8(dx + row * H + c * 8, o);
         if constexpr (DROPM) {
-          const uint32_t km = drop_keep8_at(drop, (uint64_t)row * H + c * 8);
+          if (drop.thr || drop.mask) {   // (block-uniform; a site without dropout still gets its second copy: the panel-layout GEMM operand)
+            const uint32_t km = drop_keep8_at(drop, (uint64_t)row * H + c * 8);
 #pragma unroll
-          for (int e = 0; e < 8; ++e) o[e] = (km >> e) & 1u ? to_f32(from_f32<T>(o[e])) * drop.rscale : 0.f;   // (of the ROUNDED dx, as the separate pass did)
-          store8(dxm + row * H + c * 8, o);
+            for (int e = 0; e < 8; ++e) o[e] = (km >> e) & 1u ? to_f32(from_f32<T>(o[e])) * drop.rscale : 0.f;   // (of the ROUNDED dx, as the separate pass did)
+          }
+          // row-major [rows][ldm] or K32 panels [H / 32][ldm rows][32] (what the input-gradient and weight-gradient GEMMs read: csrc/train_layer.hip)
+          store8(m_panel ? dxm + ((int64_t)(c >> 2) * ldm + row) * 32 + (c & 3) * 8 : dxm + row * ldm + c * 8, o);
         }
       }
     }
@@ -746,6 +752,9 @@ int mh_drop_args(const mh_dropout* d, DropArgs* out);
 extern "C" int mh_layernorm_bwd_drop(const void* x, const void* dy, const float* gamma, void* dx, void* dx_dropped, const mh_dropout* drop,
                                      float* partial, int n_partial, float* dgamma, float* dbeta, int accumulate, int64_t rows, int H,
                                      float eps, int dtype, mh_stream_t stream);
+extern "C" int mh_layernorm_bwd_ex(const void* x, const void* dy, const float* gamma, void* dx, void* dx_dropped, int64_t ldm, int m_panel,
+                                   int always, const mh_dropout* drop, float* partial, int n_partial, float* dgamma, float* dbeta, int accumulate,
+                                   int64_t rows, int H, float eps, int dtype, mh_stream_t stream);
 extern "C" int mh_layernorm_bwd(const void* x, const void* dy, const float* gamma, void* dx, float* partial, int n_partial,
                                 float* dgamma, float* dbeta, int accumulate, int64_t rows, int H, float eps, int dtype,
                                 mh_stream_t stream) {
@@ -756,17 +765,37 @@ extern "C" int mh_layernorm_bwd(const void* x, const void* dy, const float* gamm
 extern "C" int mh_layernorm_bwd_drop(const void* x, const void* dy, const float* gamma, void* dx, void* dx_dropped, const mh_dropout* drop,
                                      float* partial, int n_partial, float* dgamma, float* dbeta, int accumulate, int64_t rows, int H,
                                      float eps, int dtype, mh_stream_t stream) {
-  MH_CHECK_ARG(x && dy && gamma && dx && partial && dgamma && dbeta, "layernorm_bwd: null pointer");
+  return mh_layernorm_bwd_ex(x, dy, gamma, dx, dx_dropped, H, 0, 0, drop, partial, n_partial, dgamma, dbeta, accumulate, rows, H, eps, dtype, stream);
+}
+// mh_layernorm_bwd_drop with the second output's layout chosen by the caller: row-major with pitch ldm, or (m_panel) K32 panels
+// [H / 32][ldm rows][32]; always != 0: the second output is written even when the site drops nothing (then a copy of dx in that layout).
+int mh_ln_bwd_rows(const void* x, const void* dy, const float* gamma, void* dx, void* dx_dropped, int64_t ldm, int m_panel, int always,
+                   const mh_dropout* drop, float* partial, int n_partial, int64_t rows, int H, float eps, int dtype, mh_stream_t stream);
+int mh_ln_bwd_fold(const float* partial, int n_partial, int H, float* dgamma, float* dbeta, int accumulate, mh_stream_t stream);
+extern "C" int mh_layernorm_bwd_ex(const void* x, const void* dy, const float* gamma, void* dx, void* dx_dropped, int64_t ldm, int m_panel,
+                                   int always, const mh_dropout* drop, float* partial, int n_partial, float* dgamma, float* dbeta, int accumulate,
+                                   int64_t rows, int H, float eps, int dtype, mh_stream_t stream) {
+  MH_CHECK_ARG(dgamma && dbeta, "layernorm_bwd: null pointer");
+  int rc = mh_ln_bwd_rows(x, dy, gamma, dx, dx_dropped, ldm, m_panel, always, drop, partial, n_partial, rows, H, eps, dtype, stream);
+  if (rc) return rc;
+  return mh_ln_bwd_fold(partial, n_partial, H, dgamma, dbeta, accumulate, stream);
+}
+// the two halves of mh_layernorm_bwd_ex (library-internal: csrc/train_layer.hip folds the partials on a side stream, under the next GEMM):
+// the row kernel (dx, dx_dropped, per-block column partials) ...
+int mh_ln_bwd_rows(const void* x, const void* dy, const float* gamma, void* dx, void* dx_dropped, int64_t ldm, int m_panel, int always,
+                   const mh_dropout* drop, float* partial, int n_partial, int64_t rows, int H, float eps, int dtype, mh_stream_t stream) {
+  MH_CHECK_ARG(x && dy && gamma && dx && partial, "layernorm_bwd: null pointer");
   MH_CHECK_ARG(rows > 0 && H % 8 == 0 && H <= 2048 && n_partial > 0 && n_partial <= 1024, "layernorm_bwd: bad shape");
+  MH_CHECK_ARG(!m_panel || (H % 32 == 0 && ldm >= rows), "layernorm_bwd: a panel output needs H %% 32 == 0 and ldm >= rows");
   hipStream_t s = (hipStream_t)stream;
   float* pg = partial;
   float* pb = partial + (int64_t)n_partial * H;
   DropArgs da;
   int rcd = mh_drop_args(drop, &da);
   if (rcd) return rcd;
-  if (da.thr != 0 || da.mask) {
+  if (da.thr != 0 || da.mask || (always && dx_dropped)) {
     MH_CHECK_ARG(dx_dropped, "layernorm_bwd_drop: dropout needs the second output");
-#define MH_LNBD(T, N) MH_LAUNCH((ln_bwd_kernel<T, N, true>), dim3(n_partial), dim3(256), 0, s, (const T*)x, (const T*)dy, gamma, (T*)dx, pg, pb, rows, H, eps, (T*)dx_dropped, da)
+#define MH_LNBD(T, N) MH_LAUNCH((ln_bwd_kernel<T, N, true>), dim3(n_partial), dim3(256), 0, s, (const T*)x, (const T*)dy, gamma, (T*)dx, pg, pb, rows, H, eps, (T*)dx_dropped, da, ldm, m_panel)
     if (H <= 512) { MH_DTYPE_SWITCH(dtype, MH_LNBD(bf16, 1), MH_LNBD(float, 1), "layernorm_bwd_drop"); }
     else if (H <= 1024) { MH_DTYPE_SWITCH(dtype, MH_LNBD(bf16, 2), MH_LNBD(float, 2), "layernorm_bwd_drop"); }
     else { MH_DTYPE_SWITCH(dtype, MH_LNBD(bf16, 4), MH_LNBD(float, 4), "layernorm_bwd_drop"); }
@@ -779,6 +808,13 @@ extern "C" int mh_layernorm_bwd_drop(const void* x, const void* dy, const float*
 #undef MH_LNB
   }
   MH_CHECK_LAUNCH();
+  return MH_OK;
+}
+// ... and the fold of the partials into dgamma / dbeta (fixed order)
+int mh_ln_bwd_fold(const float* partial, int n_partial, int H, float* dgamma, float* dbeta, int accumulate, mh_stream_t stream) {
+  hipStream_t s = (hipStream_t)stream;
+  const float* pg = partial;
+  const float* pb = partial + (int64_t)n_partial * H;
   // (a colsum_final block folds 64 columns: 4 partial-lanes x 64)
   if (dbeta == dgamma + H) {   // the two gradients side by side (as the partials are): one launch folds both
     MH_LAUNCH(colsum_final_kernel, dim3((H + 63) / 64, 2), dim3(1024), 0, s, pg, n_partial, H, dgamma, accumulate);
@@ -901,6 +937,36 @@ extern "C" int mh_sum_slices(const float* in, int slices, int64_t n, float* out,
   return MH_OK;
 }
 
+// ------------------------------------------------------------------ bf16 row-major <-> K32 panels (the encoder stack's entry)
+namespace {
+__global__ void repack_panel_kernel(const bf16* __restrict__ in, int64_t ld_in, bf16* __restrict__ out, int64_t ld_out, int64_t rows, int cols,
+                                    int to_panel) {
+  const int cpr = cols >> 3;   // 16-byte chunks per row
+  const int64_t total = rows * cpr;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    // four consecutive threads move one 64-byte panel row, the next four the next token's: contiguous on the panel side, 64-byte row
+    // segments on the row-major side
+    const int64_t per_panel = rows * 4;
+    const int cp = (int)(i / per_panel);
+    const int64_t rem = i - (int64_t)cp * per_panel;
+    const int64_t r = rem >> 2;
+    const int c = cp * 4 + (int)(rem & 3);
+    const int64_t pan = ((int64_t)(c >> 2) * (to_panel ? ld_out : ld_in) + r) * 32 + (c & 3) * 8;
+    const int64_t rm = r * (to_panel ? ld_in : ld_out) + c * 8;
+    *reinterpret_cast<f32x4*>(out + (to_panel ? pan : rm)) = *reinterpret_cast<const f32x4*>(in + (to_panel ? rm : pan));
+  }
+}
+}  // namespace
+
+// bf16 [rows, cols] row-major (pitch ld) <-> K32 panels [cols / 32][ld rows][32]; cols % 32 == 0.  to_panel != 0: in row-major -> out panels.
+extern "C" int mh_repack_panel(const void* in, int64_t ld_in, void* out, int64_t ld_out, int64_t rows, int cols, int to_panel, mh_stream_t stream) {
+  MH_CHECK_ARG(in && out && rows > 0 && cols > 0 && cols % 32 == 0, "repack_panel: bad arguments (cols must be a multiple of 32)");
+  MH_CHECK_ARG(to_panel ? (ld_in % 8 == 0 && ld_in >= cols && ld_out >= rows) : (ld_out % 8 == 0 && ld_out >= cols && ld_in >= rows), "repack_panel: bad leading dimensions");
+  MH_LAUNCH(repack_panel_kernel, dim3(tgrid(rows * (cols >> 3))), dim3(TB), 0, (hipStream_t)stream, (const bf16*)in, ld_in, (bf16*)out, ld_out, rows, cols, to_panel);
+  MH_CHECK_LAUNCH();
+  return MH_OK;
+}
+
 // ------------------------------------------------------------------ bf16 working copies of the master weights, one launch
 namespace {
 __global__ __launch_bounds__(256) void weight_prep_kernel(const mh_wprep_item* __restrict__ items, int n_items) {
@@ -919,7 +985,9 @@ __global__ __launch_bounds__(256) void weight_prep_kernel(const mh_wprep_item* _
     bf16x4 b;
 #pragma unroll
     for (int e = 0; e < 4; ++e) { b[e] = (bf16)v[e]; tile[row][c4 + e] = b[e]; }
-    *reinterpret_cast<bf16x4*>(dst + (int64_t)(r0 + row) * w.ld_dst + c0 + c4) = b;
+    // pad_ bit 0: dst as K32 panels [cols / 32][ld_dst rows][32]
+    if (w.pad_ & 1) *reinterpret_cast<bf16x4*>(dst + ((int64_t)((c0 + c4) >> 5) * w.ld_dst + r0 + row) * 32 + ((c0 + c4) & 31)) = b;
+    else *reinterpret_cast<bf16x4*>(dst + (int64_t)(r0 + row) * w.ld_dst + c0 + c4) = b;
   }
   if (!w.dst_t) return;
   __syncthreads();
@@ -930,7 +998,9 @@ __global__ __launch_bounds__(256) void weight_prep_kernel(const mh_wprep_item* _
     bf16x4 b;
 #pragma unroll
     for (int e = 0; e < 4; ++e) b[e] = tile[c4 + e][col];
-    *reinterpret_cast<bf16x4*>(dstT + (int64_t)(c0 + col) * w.ld_t + r0 + c4) = b;
+    // pad_ bit 1: dst_t (the [cols][rows] transpose) as K32 panels [rows / 32][ld_t rows][32]
+    if (w.pad_ & 2) *reinterpret_cast<bf16x4*>(dstT + ((int64_t)((r0 + c4) >> 5) * w.ld_t + c0 + col) * 32 + ((r0 + c4) & 31)) = b;
+    else *reinterpret_cast<bf16x4*>(dstT + (int64_t)(c0 + col) * w.ld_t + r0 + c4) = b;
   }
 }
 }  // namespace

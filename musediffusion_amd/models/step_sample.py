@@ -19,7 +19,8 @@ def _draw_timesteps(weights, batch_size, device):
     prob = weights / np.sum(weights)
     t = np.random.choice(len(prob), size=(batch_size,), p=prob)
     importance = 1 / (len(prob) * prob[t])
-    return (torch.as_tensor(t, device=device, dtype=torch.long), torch.as_tensor(importance, device=device, dtype=torch.float))
+    from ..ops import to_device_async      # (a pinned staging copy: the draw must not drain the GPU's queue once per step)
+    return (to_device_async(torch.as_tensor(t, dtype=torch.long), device), to_device_async(torch.as_tensor(importance, dtype=torch.float), device))
 
 
 class ScheduleSampler:
@@ -91,8 +92,9 @@ class LossAwareSampler(ScheduleSampler):
         all_ts, all_losses = [], []
         for r in range(world):
             n = int(rows[r, 0])
-            if n > cap:   # (cannot happen: every rank checks its own count against the shared bound before the collective)
-                raise RuntimeError("loss-aware sampler: rank %d brought %d losses, more than the padded size %d" % (r, n, cap))
+            if n > cap:   # a rank's micro-batch exceeded the bound every rank pads to: all ranks see it here and fail together
+                raise ValueError("loss-aware sampler: rank %d brought a micro-batch of %d rows, more than max_local_batch allows "
+                                 "(padded size %d)" % (r, n, cap))
             all_ts.extend(int(v) for v in rows[r, 1:1 + n])
             all_losses.extend(float(v) for v in rows[r, 1 + cap:1 + cap + n])
         self.update_with_all_losses(all_ts, all_losses)
@@ -126,14 +128,18 @@ class LossAwareSampler(ScheduleSampler):
             sizes = torch.empty(world, dtype=torch.int64, device=dev)
             dist.all_gather_into_tensor(sizes, torch.full((1,), count, dtype=torch.int64, device=dev))
             bound = int(sizes.max())
-        if count > bound:
+        cap = (max(int(bound), 1) + self._GROUP - 1) // self._GROUP * self._GROUP
+        if count > cap and world == 1:
             raise ValueError("loss-aware sampler: a micro-batch of %d rows exceeds max_local_batch = %d, the size every rank "
                              "pads its gather block to" % (count, bound))
-        cap = (max(int(bound), 1) + self._GROUP - 1) // self._GROUP * self._GROUP
+        # world > 1 and this rank over the bound: the failure must be COLLECTIVE - a rank that raised here would leave the others
+        # waiting in the all_gather until the RCCL timeout.  It enters the collective with its true count in the header (and the pairs
+        # that fit); every rank then finds that count above the padded size when it unpacks (_flush) and raises there.
+        fit = min(count, cap)
         block = torch.zeros(1 + 2 * cap, dtype=torch.float64, device=dev)
         block[0] = count
-        block[1:1 + count] = ts64
-        block[1 + cap:1 + cap + count] = ls64
+        block[1:1 + fit] = ts64[:fit]
+        block[1 + cap:1 + cap + fit] = ls64[:fit]
         if world > 1:
             gathered = torch.empty(world * (1 + 2 * cap), dtype=torch.float64, device=dev)
             dist.all_gather_into_tensor(gathered, block)     # one collective per micro-batch; stream-ordered under RCCL

@@ -30,6 +30,18 @@ def dtype_code(dtype):
     raise ValueError("compute dtype must be fp32, bf16, bf16x3 or f16x3, got %r" % (dtype,))
 
 
+def to_device_async(x, device):
+    """A host tensor to the device without stalling the host behind the GPU's queue: `tensor.to(device)` from pageable memory waits
+    for the stream to drain (one bubble per copy, 15 of them per training step); a pinned staging copy + non_blocking does not - the
+    caching host allocator keeps the staging block until the copy has run."""
+    device = torch.device(device)
+    if not isinstance(x, torch.Tensor):
+        x = torch.as_tensor(x)
+    if x.device == device or device.type != "cuda" or x.is_cuda:
+        return x.to(device)
+    return x.pin_memory().to(device, non_blocking=True)
+
+
 def pad64(n):
     return (int(n) + 63) // 64 * 64
 

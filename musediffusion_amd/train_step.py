@@ -14,6 +14,7 @@ import contextlib
 import torch
 
 from .models.step_sample import LossAwareSampler, UniformSampler
+from .ops import to_device_async
 from .optim import FusedAdamWEMA
 
 
@@ -77,7 +78,7 @@ class TrainStep:
         sums, count = {}, 0
         try:
             for i in range(0, n, micro):
-                micro_cond = {k: v[i:i + micro].to(dev) for k, v in cond.items()}
+                micro_cond = {k: to_device_async(v[i:i + micro], dev) for k, v in cond.items()}
                 last_batch = (i + micro) >= n
                 t, weights = self.schedule_sampler.sample(micro_cond["input_ids"].shape[0], dev)
                 sync = contextlib.nullcontext() if (last_batch or not self.use_ddp) else self.ddp_model.no_sync()

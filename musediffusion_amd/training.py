@@ -34,6 +34,16 @@ FUSED_DENSE_LN = True   # bf16, d_model 512: BertSelfOutput / BertOutput dense -
 # forward) and the attention-output dense taking the projection node's pass-through of X as its residual (the residual branch's gradient is
 # added in the projection's input-gradient GEMM, not by an autograd add kernel).  False = round 4's tape (A/B: tools/ab_train.py TAPE_STACK)
 TAPE_STACK = True
+# round 6: the encoder layers as one tape node each over libmusehip's per-layer calls (csrc/train_layer.hip): every GEMM operand in the
+# K32-panel layout of the sampler's tiles.  Where the shape is served (d_model 512, ffn % 256 == 0, seq_len % 64 == 0 and >= 512, head dim
+# 32 / 64); other shapes and fp32 keep the node-per-op tape above.  False = that tape everywhere (A/B and the equivalence test)
+PANEL_LAYERS = True
+FOLD_SIDE_STREAM = True  # the panel layers' backward folds its gradient partials on the model's side stream (A/B: tools/ab_train.py)
+PANEL_LAYER_CALLS = 0   # forward calls of the panel-layer node so far (tests assert which tape ran)
+# rows added to every panel buffer of the panel layers: with exactly B L = 2^k rows the panels of a tensor lie 2^(k + 6) bytes apart and
+# the 16 panels a weight-gradient block streams, or a GEMM tile's K steps, fall on the same HBM channels
+import os as _os
+PANEL_LD_PAD = int(_os.environ.get("MUSE_PANEL_LD_PAD", "64"))
 
 
 class _FusedLN:
@@ -740,6 +750,21 @@ def _linear(x, lin, act, dt, residual=None, drop=None, prep=None, ln=None):
     return _Linear.apply(x, lin.weight, lin.bias, act, residual, dt, drop, prep, ln)
 
 
+def _side_stream(model):
+    """The model's second stream: one that really runs beside the caller's (HIP shares hardware queues between streams:
+    ops.streams_overlap).  Forward: the attention keep bits are drawn on it next to the first GEMMs; backward: the panel layers fold
+    their gradient partials on it under the GEMMs that follow (csrc/train_layer.hip)."""
+    side = getattr(model, "_bits_stream", None)
+    if side is None:
+        main = torch.cuda.current_stream()
+        for _ in range(6):
+            side = torch.cuda.Stream()
+            if ops.streams_overlap(main, side):
+                break
+        object.__setattr__(model, "_bits_stream", side)
+    return side
+
+
 class _DropSites:
     """The dropout sites of ONE training forward (reference: nn.Dropout at network.py:149; HF BertSelfAttention / BertSelfOutput /
     BertOutput dropouts inside network.py:151).  Every site gets its own Philox counter offset (call number, site index); rates
@@ -767,14 +792,8 @@ class _DropSites:
         dh = model.hidden_size // nh
         if self.p_att <= 0.0 or not (FUSED_ATTENTION and dt == ops.MH_BF16 and bool(lib().mh_attention_stream_bwd_supported(L, dh))):
             return
-        side = getattr(model, "_bits_stream", None)
+        side = _side_stream(model)
         main = torch.cuda.current_stream()
-        if side is None:     # a stream that really runs beside the caller's (HIP shares hardware queues between streams: ops.streams_overlap)
-            for _ in range(6):
-                side = torch.cuda.Stream()
-                if ops.streams_overlap(main, side):
-                    break
-            model._bits_stream = side
         side.wait_stream(main)
         nwords = int(lib().mh_dropout_bits_words(B * nh, L))
         for li in range(len(model.input_transformers.layer)):
@@ -809,10 +828,11 @@ class _WeightPrep:
     (mh_weight_prep) instead of a cast per dense layer in the forward and a transpose per layer in the backward.  The buffers and
     the device table live with the model; the table is rebuilt when a parameter moved (model.to(), a fresh state)."""
 
-    def __init__(self, model, dev):
+    def __init__(self, model, dev, panel=False):
         H, layers = model.hidden_size, list(model.input_transformers.layer)
         F = layers[0].intermediate.dense.weight.shape[0]
         bf = torch.bfloat16
+        self.panel = bool(panel)     # both copies as K32 panels (the per-layer calls of csrc/train_layer.hip) instead of row-major
         self.qkv = [torch.empty(3 * H, H, device=dev, dtype=bf) for _ in layers]
         self.qkv_t = [torch.empty(H, 3 * H, device=dev, dtype=bf) for _ in layers]
         self.ao = [torch.empty(H, H, device=dev, dtype=bf) for _ in layers]
@@ -825,13 +845,21 @@ class _WeightPrep:
 
         def add(W, dst, dst_t, ld_dst, ld_t):
             nonlocal tiles
-            it = _lib.WPrepItem(W.data_ptr(), dst, dst_t, W.shape[0], W.shape[1], ld_dst, ld_t, tiles, 0)
+            it = _lib.WPrepItem(W.data_ptr(), dst, dst_t, W.shape[0], W.shape[1], ld_dst, ld_t, tiles, 3 if self.panel else 0)
             tiles += (W.shape[0] // 64) * (W.shape[1] // 64)
             items.append(it)
         for li, layer in enumerate(layers):
             sa = getattr(layer.attention, "self")
             for j, lin in enumerate((sa.query, sa.key, sa.value)):      # three parameters, one [3H, H] operand
-                add(lin.weight, self.qkv[li].data_ptr() + j * H * H * 2, self.qkv_t[li].data_ptr() + j * H * 2, H, 3 * H)
+                if self.panel:   # W [3H][H] as panels over H: rows j H ..; W^T [H][3H] as panels over 3H: panels j H / 32 ..  (ld = rows of the panel buffer)
+                    add(lin.weight, self.qkv[li].data_ptr() + j * H * 32 * 2, self.qkv_t[li].data_ptr() + j * H * H * 2, 3 * H, H)
+                else:
+                    add(lin.weight, self.qkv[li].data_ptr() + j * H * H * 2, self.qkv_t[li].data_ptr() + j * H * 2, H, 3 * H)
+            if self.panel:
+                add(layer.attention.output.dense.weight, self.ao[li].data_ptr(), self.ao_t[li].data_ptr(), H, H)
+                add(layer.intermediate.dense.weight, self.w1[li].data_ptr(), self.w1_t[li].data_ptr(), F, H)
+                add(layer.output.dense.weight, self.w2[li].data_ptr(), self.w2_t[li].data_ptr(), H, F)
+                continue
             add(layer.attention.output.dense.weight, self.ao[li].data_ptr(), self.ao_t[li].data_ptr(), H, H)
             add(layer.intermediate.dense.weight, self.w1[li].data_ptr(), self.w1_t[li].data_ptr(), H, F)
             add(layer.output.dense.weight, self.w2[li].data_ptr(), self.w2_t[li].data_ptr(), F, H)
@@ -853,16 +881,127 @@ class _WeightPrep:
                 and all(p.dtype == torch.float32 and p.is_contiguous() for layer in layers for p in layer.parameters()))
 
     @staticmethod
-    def refresh(model, dt, dev):
+    def refresh(model, dt, dev, panel=False):
         """-> the model's _WeightPrep with this forward's copies queued on the current stream, or None (shapes / dtype not served)"""
         if not WEIGHT_PREP or not _WeightPrep.supported(model, dt):
             return None
         wp = getattr(model, "_weight_prep", None)
-        if wp is None or wp.key != _WeightPrep.key_of(model) or wp.table.device != dev:
-            wp = _WeightPrep(model, dev)
+        if wp is None or wp.key != _WeightPrep.key_of(model) or wp.table.device != dev or wp.panel != bool(panel):
+            wp = _WeightPrep(model, dev, panel)
             object.__setattr__(model, "_weight_prep", wp)
         check(lib().mh_weight_prep(ptr(wp.table), wp.n, wp.tiles, current_stream()), "mh_weight_prep")
         return wp
+
+
+_LAYER_SCRATCH = {}
+
+
+def _layer_scratch(dev, nbytes):
+    """One scratch buffer per device for the backward of the panel layers (gradients in flight, split-K partials): the layers run one
+    after the other on one stream, so they share it."""
+    buf = _LAYER_SCRATCH.get(dev)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(nbytes, device=dev, dtype=torch.uint8)
+        _LAYER_SCRATCH[dev] = buf
+    return buf
+
+
+class _PackPanel(Function):
+    """bf16 rows [N, H] -> K32 panels [H / 32][N][32] at the entry of the panel layers.  The panel tensor keeps the SHAPE [N, H] (autograd
+    checks gradient shapes); its memory is in panel order and only _EncoderLayer reads it.  Gradients of panel tensors travel as rows."""
+
+    @staticmethod
+    def forward(ctx, x):
+        N, H = x.shape
+        ld = N + PANEL_LD_PAD
+        out = torch.empty(ld, H, device=x.device, dtype=x.dtype)[:N]     # [H / 32][ld][32] in memory; presented as the first N "rows"
+        check(lib().mh_repack_panel(ptr(x), H, ptr(out), ld, N, H, 1, current_stream()), "mh_repack_panel")
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+class _EncoderLayer(Function):
+    """One HF BertLayer (network.py:151) of the training forward / backward as ONE tape node over mh_train_layer_fwd / _bwd: x, ctx, x1,
+    gelu, gelu' and every gradient a GEMM reads live as K32 panels.  Inputs: x (panels, shape [N, H]), the stacked q | k | v weight
+    (tape only) and packed bias, the other ten parameters; output y (panels, or rows for the last layer)."""
+
+    @staticmethod
+    def forward(ctx, x, cfg, wts, drops, y_panel, Wqkv, bqkv, Wao, bao, g1, be1, W1, b1, W2, b2, g2, be2):
+        import ctypes as C
+        B, L, H, F, nh, eps, side = cfg
+        N, dev, bf = B * L, x.device, torch.bfloat16
+        ld = N + PANEL_LD_PAD
+        t = _lib.TrainLayer()
+        t.B, t.L, t.H, t.F, t.nh, t.ln_eps, t.ld = B, L, H, F, nh, eps, ld
+        for name, w in zip(("wqkv", "wqkv_t", "wao", "wao_t", "w1", "w1_t", "w2", "w2_t"), wts):
+            setattr(t, name, w.data_ptr())
+        vecs = [v.detach() for v in (bqkv, bao, b1, b2, g1, be1, g2, be2)]
+        for name, v in zip(("bqkv", "bao", "b1", "b2", "ln1_g", "ln1_b", "ln2_g", "ln2_b"), vecs):
+            assert v.dtype == torch.float32 and v.is_contiguous()
+            setattr(t, name, v.data_ptr())
+        d_attn, d_ao, d_ffn = drops
+        keep = []
+        for name, d in (("drop_attn", d_attn), ("drop_ao", d_ao), ("drop_ffn", d_ffn)):
+            if d is not None:
+                cd = d.c()
+                setattr(t, name, cd)
+                keep.append(d.mask)
+        bits = None
+        if d_attn is not None:
+            if d_attn.ready is not None:      # keep bits drawn ahead on a side stream
+                torch.cuda.current_stream().wait_event(d_attn.ready)
+            t.bits_in = int(d_attn.bits is not None)
+            bits = d_attn.bits if t.bits_in else torch.empty(int(lib().mh_dropout_bits_words(B * nh, L)), device=dev, dtype=torch.int32)
+            t.keep_bits = bits.data_ptr()
+        qkv = torch.empty(N, 3 * H, device=dev, dtype=bf)
+        vt = torch.empty(N * H + 256, device=dev, dtype=bf)
+        lse = torch.empty(B * nh * L, device=dev, dtype=torch.float32)
+        pre1, pre2 = (torch.empty(N, H, device=dev, dtype=bf) for _ in range(2))
+        ctxv, x1 = (torch.empty(ld, H, device=dev, dtype=bf) for _ in range(2))                  # panels [H / 32][ld][32]
+        y = torch.empty(ld, H, device=dev, dtype=bf)[:N] if y_panel else torch.empty(N, H, device=dev, dtype=bf)
+        gact, dact = (torch.empty(ld, F, device=dev, dtype=bf) for _ in range(2))
+        t.x, t.y_panel = x.data_ptr(), int(y_panel)
+        for name, buf in zip(("qkv", "vt", "ctx", "lse", "pre1", "x1", "g", "dact", "pre2", "y"), (qkv, vt, ctxv, lse, pre1, x1, gact, dact, pre2, y)):
+            setattr(t, name, buf.data_ptr())
+        check(lib().mh_train_layer_fwd(C.byref(t), current_stream()), "mh_train_layer_fwd")
+        global PANEL_LAYER_CALLS
+        PANEL_LAYER_CALLS += 1
+        ctx.desc = t
+        ctx.keep = (wts, vecs, keep, bits, x, qkv, vt, ctxv, lse, pre1, x1, gact, dact, pre2)     # what the descriptor points at
+        ctx.cfg = cfg
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        import ctypes as C
+        B, L, H, F, nh, eps, side = ctx.cfg
+        N, dev = B * L, dy.device
+        t = ctx.desc
+        t.side_stream = side
+        dy = dy.contiguous()
+        dx = torch.empty(N, H, device=dev, dtype=torch.bfloat16)
+        grads = torch.empty(int(lib().mh_train_layer_grad_floats(H, F)), device=dev, dtype=torch.float32)
+        nbytes = int(lib().mh_train_layer_scratch_bytes(B, L, H, F, nh, t.ld))
+        scratch = _layer_scratch(dev, nbytes)
+        t.dy, t.dx, t.scratch, t.scratch_bytes, t.grads = dy.data_ptr(), dx.data_ptr(), scratch.data_ptr(), nbytes, grads.data_ptr()
+        check(lib().mh_train_layer_bwd(C.byref(t), current_stream()), "mh_train_layer_bwd")
+        ctx.keep = None
+        sizes = [3 * H * H, 3 * H, H * H, H, F * H, F, H * F, H, H, H, H, H]
+        gWqkv, gbqkv, gWao, gbao, gW1, gb1, gW2, gb2, gg1, gbe1, gg2, gbe2 = grads.split(sizes)
+        return (dx, None, None, None, None, gWqkv.view(3 * H, H), gbqkv, gWao.view(H, H), gbao, gg1, gbe1, gW1.view(F, H), gb1,
+                gW2.view(H, F), gb2, gg2, gbe2)
+
+
+def _panel_layers_ok(model, B, L, dt):
+    layers = list(model.input_transformers.layer)
+    if not (PANEL_LAYERS and TAPE_STACK and WEIGHT_PREP and FUSED_ATTENTION and dt == ops.MH_BF16 and layers):
+        return False
+    H = model.hidden_size
+    F = layers[0].intermediate.dense.weight.shape[0]
+    return bool(lib().mh_train_layer_supported(B, L, H, F, model.num_heads)) and _WeightPrep.supported(model, dt)
 
 
 def denoiser_forward_with_grad(model, x, timesteps):
@@ -887,7 +1026,8 @@ def denoiser_forward_with_grad(model, x, timesteps):
         h = xin
     sites = _DropSites(model)
     sites.pregenerate_attention_bits(model, B, L, dt, dev)
-    wp = _WeightPrep.refresh(model, dt, dev)
+    panel = _panel_layers_ok(model, B, L, dt)
+    wp = _WeightPrep.refresh(model, dt, dev, panel)
     pre = _AddPosTime.apply(h, model.position_embeddings.weight, emb_t, B, L, dt)
     X = _LayerNorm.apply(pre, model.LayerNorm.weight, model.LayerNorm.bias, model.LayerNorm.eps, dt)
     d_emb = sites.site("emb", sites.p_emb)
@@ -895,7 +1035,24 @@ def denoiser_forward_with_grad(model, x, timesteps):
         X = _Dropout.apply(X, dt, d_emb)                                                          # network.py:149
     selfs = [getattr(layer.attention, "self") for layer in model.input_transformers.layer]
     bqkv_all = _PackVectors.apply(3, *[lin.bias for sa in selfs for lin in (sa.query, sa.key, sa.value)]) if (selfs and TAPE_STACK) else ()
-    for li, layer in enumerate(model.input_transformers.layer):
+    nlayers = len(selfs)
+    if panel:
+        X = _PackPanel.apply(X)
+        F = model.input_transformers.layer[0].intermediate.dense.weight.shape[0]
+        cfg = (B, L, H, F, model.num_heads, float(model.input_transformers.layer[0].output.LayerNorm.eps),
+               _side_stream(model).cuda_stream if FOLD_SIDE_STREAM else None)
+    for li, layer in enumerate(model.input_transformers.layer if panel else ()):
+        sa = selfs[li]
+        Wqkv = _StackRows.apply(False, sa.query.weight, sa.key.weight, sa.value.weight)           # (tape only: the operand is wp's packed copy)
+        drops = tuple(d if _active(d) else None for d in (sites.site("l%d.attn" % li, sites.p_att), sites.site("l%d.ao" % li, sites.p_hid),
+                                                            sites.site("l%d.ffn" % li, sites.p_hid)))
+        ao, lo = layer.attention.output, layer.output
+        assert float(ao.LayerNorm.eps) == cfg[5] and float(lo.LayerNorm.eps) == cfg[5]
+        X = _EncoderLayer.apply(X, cfg, (wp.qkv[li], wp.qkv_t[li], wp.ao[li], wp.ao_t[li], wp.w1[li], wp.w1_t[li], wp.w2[li], wp.w2_t[li]), drops,
+                                li + 1 < nlayers, Wqkv, bqkv_all[li], ao.dense.weight, ao.dense.bias, ao.LayerNorm.weight, ao.LayerNorm.bias,
+                                layer.intermediate.dense.weight, layer.intermediate.dense.bias, lo.dense.weight, lo.dense.bias,
+                                lo.LayerNorm.weight, lo.LayerNorm.bias)
+    for li, layer in enumerate(() if panel else model.input_transformers.layer):
         sa = selfs[li]
         if TAPE_STACK:
             Wqkv = _StackRows.apply(wp is None, sa.query.weight, sa.key.weight, sa.value.weight)      # (values unused when wp holds the copy)

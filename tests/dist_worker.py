@@ -206,13 +206,14 @@ def case_lossaware(rank, world, dev):
         assert np.array_equal(s._loss_counts, ref._loss_counts) and np.array_equal(s._loss_history, ref._loss_history), \
             "sampler state differs from the host replay (rank %d, bound %s)" % (rank, bound)
     s = LossSecondMomentResampler(SimpleNamespace(num_timesteps=T), history_per_term=4)
-    s.max_local_batch = 8
+    s.max_local_batch = 64      # padded size 64: rank 0's 64 rows fit, rank 1's 65 do not - ONE rank over the bound
     try:
-        s.update_with_local_losses(all_ts[rank].to(dev), all_ls[rank].to(dev))
+        s.update_with_local_losses(all_ts[rank].to(dev), all_ls[rank].to(dev))    # every rank enters the collective ...
+        s._loss_counts                                                               # ... and every rank fails when it unpacks the blocks
     except ValueError:
-        pass          # every rank's count exceeds the bound: all of them refuse before the collective
+        pass
     else:
-        raise AssertionError("a micro-batch beyond max_local_batch was accepted")
+        raise AssertionError("a micro-batch beyond max_local_batch was accepted (rank %d)" % rank)
 
 
 if __name__ == "__main__":
