@@ -713,6 +713,11 @@ int mh_attention_stream_fwd_prescaled(const void* q, const void* k, const void* 
                                       int B, int L, int nh, int dh, mh_stream_t stream);
 int mh_denoiser_get_defer_ln(void);
 
+/* get_logits with logits_mode 2 (models/network.py:94-104, "standard cosine similarity": in fact the negative Euclidean distance to every
+ * lm_head row): out[n][v] = -sqrt(clamp((w_sqnorm[v] + x_sqnorm[n]) - 2 dots[n][v], 0, inf)); dots = x W^T from mh_gemm_bias_act (fp32). */
+int mh_distance_scores(const float* dots, int64_t ld, const float* w_sqnorm, const float* x_sqnorm, float* out, int64_t ldo, int64_t n, int V,
+                       mh_stream_t stream);
+
 /* ---------------------------------------------------------------- training step on K32 panels (round 6)
  * The encoder layers of training_losses (models/diffusion.py:594-699 through models/network.py:151 -> HF BertLayer forward, and its
  * autograd backward) with every GEMM operand in the K32-panel layout of the sampler's kernels: the reference runs ~40 ATen kernels
@@ -785,7 +790,10 @@ int mh_train_layer_bwd(const mh_train_layer* t, mh_stream_t stream);
 /* ---------------------------------------------------------------- per-launch timing (measurement)
  * Between mh_profile_start() and mh_profile_stop() every kernel this library launches is bracketed by two HIP events on its own
  * stream (not capturable: call outside hipGraph capture).  mh_profile_stop synchronises the device and writes one line per launch,
- * "kernel\tdetail\tgrid\tblock\tstream\tmilliseconds\n", into `out`; it returns the bytes the whole report needs. */
+ * "kernel\tdetail\tgrid\tblock\tstream\tmilliseconds\n", into `out`; it returns the bytes the whole report needs.
+ * The recorder is the only process-wide mutable state of libmusehip.so (everything else is per call or per device): one record list for the
+ * whole process, guarded by a mutex - launches from several host threads may interleave while it is on; a launch made by thread A between
+ * thread B's record and its kernel can attach to B's record, so time one thread at a time when the attribution matters. */
 int mh_profile_start(void);
 int64_t mh_profile_stop(char* out, size_t cap);
 

@@ -22,9 +22,11 @@ int mh_attention_set_variant(int resident);
  * stamps[block * 32 + {0: start, 1: K/V staged, 2 + w: wave w done}] (u64).  NULL (default) disables it. */
 int mh_attention_set_profile(void* stamps);
 
-/* A/B switch between the bf16 GEMM kernels: 0 = 128x128 tile, register-staged; 1 = 128x128 tile,
- * global_load_lds; 2 (default) and 3 = 256x128 tile (4 waves, 3-stage global_load_lds ring, two blocks per CU);
- * 4 = 256x256 (8 waves, 4-stage ring) where N % 256 == 0; 5 = 256x256 with the ping-pong main loop. */
+/* A/B switch between the bf16 GEMM kernels: 0 = 128x128 tile, register-staged (the production library's fallback for shapes the big
+ * tiles do not serve); 2 (default) = 256x128 tile (4 waves, 3-stage LDS-DMA ring, two blocks per CU; see mh_gemm_set_auto_wide);
+ * 4 = 256x256 (8 waves, 4-stage ring) where N % 256 == 0.  (Rounds 1 - 5 carried more forms - 128x128 with global_load_lds, 256x256
+ * ping-pong / four-wave, 256x128 on eight waves, bias-initialised accumulators, interleaved and staggered stage DMA: measured out and
+ * removed in round 6; their numbers are in profiles/r0*_ab_nulls.txt and their code in the git history.) */
 int mh_gemm_set_variant(int variant);
 
 /* 1 (default): with the default variant, launches whose operands are all row-major (the training tape, direct callers) take the
@@ -78,21 +80,10 @@ int mh_denoiser_set_fuse_headtail(int on);
  * bit 2 every other launch whose N is a multiple of 256; 0 (default) = all of them on the 256 x 128 tile */
 int mh_gemm_set_wide_roles(int mask);
 
-/* experiment knob (A/B only): co-resident partner blocks of the big-tile GEMMs start `ticks` x 10 ns late */
-int mh_gemm_set_stagger(int ticks);
-
-/* experiment knob (A/B only): LDS-DMA pieces of the 256x128 kernels issued between the MFMA rows instead of as one burst */
-int mh_gemm_set_spread(int on);
-
 /* A/B: 1 (default) = K32-panel launches of the big-tile kernels issue their stage DMA as `buffer_load_dwordx4 ... lds` (tile base in a descriptor,
  * K step as the scalar offset, a wave's pieces as immediate offsets: no vector address arithmetic per piece; bit-identical results);
  * 0 = global_load_lds with per-piece 64-bit addresses (rounds 1 - 4) */
 int mh_gemm_set_buf_dma(int on);
-
-/* A/B: 1 = the plain 256x128 kernels (dense + GELU, the QKV projection) start their accumulators from the bias - an LDS-DMA piece per wave in
- * front of the tile's first stage - and their epilogues have no bias add; 0 (default: the other form measured 4 % slower inside the step) = the
- * bias added in the epilogue */
-int mh_gemm_set_bias_acc(int on);
 
 #ifdef __cplusplus
 }

@@ -194,6 +194,7 @@ SIGNATURES = {
     "mh_gemm_dw": (INT, [VP, I64, VP, I64, VP, INT, I64, INT, INT, VP]),
     "mh_gemm_dw_splits": (INT, [I64, INT, INT]),
     "mh_weight_prep": (INT, [VP, INT, INT, VP]),
+    "mh_distance_scores": (INT, [VP, I64, VP, VP, VP, I64, I64, INT, VP]),
     "mh_gemm_desc_launch": (INT, [C.POINTER(GemmDesc), VP]),
     "mh_gemm_dw_bias_ex": (INT, [VP, I64, VP, I64, INT, VP, INT, I64, INT, INT, INT, VP]),
     "mh_layernorm_bwd_ex": (INT, [VP, VP, VP, VP, VP, I64, INT, INT, VP, VP, INT, VP, VP, INT, I64, INT, F32, INT, VP]),
@@ -275,10 +276,7 @@ DBG_SIGNATURES = {
     "mh_layernorm_set_rows4": (INT, [INT]),
     "mh_denoiser_set_prescale_q": (INT, [INT]),
     "mh_attention_set_ablation": (INT, [INT]),
-    "mh_gemm_set_stagger": (INT, [INT]),
-    "mh_gemm_set_bias_acc": (INT, [INT]),
     "mh_gemm_set_buf_dma": (INT, [INT]),
-    "mh_gemm_set_spread": (INT, [INT]),
 }
 
 _lib = None

@@ -19,6 +19,7 @@
 // workgroup, exact expf; this is the parity path, kept simple on purpose.
 #include <type_traits>
 
+#include <mutex>
 #include <set>
 
 #include "common.h"
@@ -1238,9 +1239,13 @@ int stream_fwd_impl(const void* q, const void* k, const void* vt_perm, void* ctx
   const dim3 grid((unsigned)(nitems < slots ? nitems : slots)), block(small ? 512 : 1024);
   auto go = [&](auto kern, int bytes) -> int {
     // all instantiations share one function-pointer type, so this lambda body exists once: the attribute is tracked per kernel
-    static std::set<std::pair<int, const void*>> attr_done;   // (device, kernel)
-    if (attr_done.insert({mh_current_device(), reinterpret_cast<const void*>(kern)}).second)
-      MH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    static std::set<std::pair<int, const void*>> attr_done;   // (device, kernel); guarded: the library may be called from several host threads
+    static std::mutex attr_mu;
+    {
+      std::lock_guard<std::mutex> lock(attr_mu);
+      if (attr_done.insert({mh_current_device(), reinterpret_cast<const void*>(kern)}).second)
+        MH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    }
     mh_prof_note("attn_stream B*nh=%d L=%d dh=%d drop=%d", nbh, L, dh, (int)dropping);
     MH_LAUNCH(kern, grid, block, bytes, s, Q, K, V, (bf16*)ctx, ld_ctx, L, nh, nbh, sl2, ctx_panel, lse2, qsB, qsH, qld, da, keep_bits, bits_in);
     return MH_OK;
@@ -1250,9 +1255,13 @@ int stream_fwd_impl(const void* q, const void* k, const void* vt_perm, void* ctx
     const int items2 = nbh * (L / 512);
     const dim3 grid2((unsigned)(items2 < cus ? items2 : cus));
     static std::set<std::pair<int, const void*>> attr2;
+    static std::mutex attr2_mu;
     const bool kvnt = L <= 512;
     const void* kp = kvnt ? reinterpret_cast<const void*>(&attn_stream2_kernel<true>) : reinterpret_cast<const void*>(&attn_stream2_kernel<false>);
-    if (attr2.insert({mh_current_device(), kp}).second) MH_HIP(hipFuncSetAttribute(kp, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 256 * 64 * 2));
+    {
+      std::lock_guard<std::mutex> lock(attr2_mu);
+      if (attr2.insert({mh_current_device(), kp}).second) MH_HIP(hipFuncSetAttribute(kp, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 256 * 64 * 2));
+    }
     mh_prof_note("attn_stream2 B*nh=%d L=%d dh=%d", nbh, L, dh);
     if (kvnt) MH_LAUNCH((attn_stream2_kernel<true>), grid2, dim3(512), 4 * 256 * 64 * 2, s, Q, K, V, (bf16*)ctx, ld_ctx, L, nh, nbh, sl2, ctx_panel, qsB, qsH, qld);
     else MH_LAUNCH((attn_stream2_kernel<false>), grid2, dim3(512), 4 * 256 * 64 * 2, s, Q, K, V, (bf16*)ctx, ld_ctx, L, nh, nbh, sl2, ctx_panel, qsB, qsH, qld);

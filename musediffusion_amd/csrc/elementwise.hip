@@ -335,6 +335,28 @@ extern "C" int mh_row_sqnorm(const float* table, float* out, int V, int E, mh_st
   return MH_OK;
 }
 
+// get_logits with logits_mode 2 (models/network.py:94-104): scores[n][v] = -sqrt(clamp((|W_v|^2 + |x_n|^2) - 2 W_v.x_n, 0, inf)), from the
+// fp32 product W x^T the caller ran as a GEMM; the reference's association of the three terms (this file compiles without FP contraction)
+namespace {
+__global__ void distance_scores_kernel(const float* __restrict__ dots, int64_t ld, const float* __restrict__ wn, const float* __restrict__ xn,
+                                       float* __restrict__ out, int64_t ldo, int64_t n, int V) {
+  const int64_t total = n * V;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = i / V;
+    const int v = (int)(i - row * V);
+    const float d = (wn[v] + xn[row]) - 2.0f * dots[row * ld + v];
+    out[row * ldo + v] = -sqrtf(fmaxf(d, 0.0f));
+  }
+}
+}  // namespace
+extern "C" int mh_distance_scores(const float* dots, int64_t ld, const float* w_sqnorm, const float* x_sqnorm, float* out, int64_t ldo, int64_t n,
+                                  int V, mh_stream_t stream) {
+  MH_CHECK_ARG(dots && w_sqnorm && x_sqnorm && out && n > 0 && V > 0 && ld >= V && ldo >= V, "distance_scores: bad arguments");
+  MH_LAUNCH(distance_scores_kernel, dim3(ew_grid(n * V)), dim3(EW_BLOCK), 0, (hipStream_t)stream, dots, ld, w_sqnorm, x_sqnorm, out, ldo, n, V);
+  MH_CHECK_LAUNCH();
+  return MH_OK;
+}
+
 extern "C" int mh_embed_gather(const float* table, const int32_t* ids, float* out, int64_t n_tokens, int E, int V,
                                mh_stream_t stream) {
   MH_CHECK_ARG(table && ids && out, "embed_gather: null pointer");

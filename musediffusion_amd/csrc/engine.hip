@@ -17,10 +17,15 @@ void mh_set_error(const char* fmt, ...) {
 }
 
 // ---------------------------------------------------------------- per-launch timing
+// The recorder is the library's only process-wide mutable state (measurement, off by default; include/musehip.h says so): one list of
+// launch records for the whole process, every access under g_prof_mu, so that launches from several host threads interleave safely while it
+// is on.  While it is off (g_mh_prof_on == 0, the product's state) no launch touches it.
+#include <mutex>
 #include <string>
 #include <vector>
 int g_mh_prof_on = 0;
 namespace {
+std::mutex g_prof_mu;
 struct ProfRec { std::string name, note; unsigned grid, block; hipEvent_t e0, e1; hipStream_t s; };
 std::vector<ProfRec> g_prof;
 std::vector<hipEvent_t> g_prof_pool;
@@ -39,18 +44,22 @@ void mh_prof_note(const char* fmt, ...) {
   va_start(ap, fmt);
   vsnprintf(buf, sizeof(buf), fmt, ap);
   va_end(ap);
+  std::lock_guard<std::mutex> lock(g_prof_mu);
   g_prof_note = buf;
 }
 void mh_prof_begin(const char* kernel, unsigned grid_x, unsigned block_x, hipStream_t stream) {
+  std::lock_guard<std::mutex> lock(g_prof_mu);
   ProfRec r{kernel, g_prof_note, grid_x, block_x, prof_event(), prof_event(), stream};
   g_prof_note.clear();
   (void)hipEventRecord(r.e0, stream);
   g_prof.push_back(r);
 }
 void mh_prof_end(hipStream_t stream) {
+  std::lock_guard<std::mutex> lock(g_prof_mu);
   if (!g_prof.empty()) (void)hipEventRecord(g_prof.back().e1, stream);
 }
 extern "C" int mh_profile_start(void) {
+  std::lock_guard<std::mutex> lock(g_prof_mu);
   for (auto& r : g_prof) { g_prof_pool.push_back(r.e0); g_prof_pool.push_back(r.e1); }
   g_prof.clear();
   g_mh_prof_on = 1;
@@ -61,6 +70,7 @@ extern "C" int mh_profile_start(void) {
 extern "C" int64_t mh_profile_stop(char* out, size_t cap) {
   g_mh_prof_on = 0;
   if (hipDeviceSynchronize() != hipSuccess) { mh_set_error("profile_stop: device synchronize failed"); return MH_ERR_HIP; }
+  std::lock_guard<std::mutex> lock(g_prof_mu);
   std::string rep;
   char line[768];
   for (auto& r : g_prof) {

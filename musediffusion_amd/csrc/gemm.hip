@@ -5,9 +5,7 @@
 //   bf16: v_mfma_f32_16x16x32_bf16, K-tile 64.  LDS rows are 128 B; the 16-B chunk c of row r lives
 //         at chunk (c ^ (r & 7)) so that the ds_read_b128 fragment reads (16 rows x 2 chunks per
 //         16-lane group) hit 16 distinct 16-B slots of the 256-B bank row: conflict-free.
-//         Staging is either register-staged (global_load_dwordx4 -> ds_write_b128) or direct
-//         global_load_lds_dwordx4 (LDS image is lane-linear, so the swizzle is applied to the
-//         per-lane SOURCE address).
+//         Staging is register-staged (global_load_dwordx4 -> ds_write_b128).
 //   f32:  v_mfma_f32_16x16x4_f32 (exact fp32 fma chain), K-tile 16.  The k index served by lane
 //         group g in instruction s is 4g+s for BOTH operands, so one ds_read_b128 per tile row
 //         feeds four MFMAs.  LDS rows are padded to 96 B (slot = 6*row + g: conflict-free).
@@ -63,7 +61,6 @@ struct GemmArgs {
   int vt_perm;   // QKV scatter: V^T keys in the P-operand order of mh_attention_stream_fwd (middle groups of 4 swapped per 16)
   int pre_kind;  // what pre_out receives: 0 the pre-activation, 1 act'(pre) (GELU: gelu_erf_fast8_dgelu)
   float q_scale; // QKV scatter (big tile): the query columns are stored multiplied by this (0 = unscaled): softmax scale x log2(e) for mh_attention_stream_fwd_prescaled
-  int stagger;   // experiment: blocks of the second half of the grid (the co-resident partners) start this many 10-ns ticks late
   DeferArgs d;   // DBG bit 128 kernels only
   DropArgs drop; // EPI 0: train-mode dropout of (A W^T + bias) before the residual is added (thr == 0: off)
 };
@@ -91,7 +88,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
   return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
 }
 
-template <typename T, int EPI, int GLDS>
+template <typename T, int EPI>
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
   using TT = Tile<T>;
   constexpr int BK = TT::BK, ROWB = TT::ROWB, CHUNKS = TT::CHUNKS;
@@ -117,19 +114,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
 #pragma unroll
   for (int j = 0; j < NCH; ++j) {
     int row, c, off;
-    if constexpr (GLDS) {
-      // wave-instruction (wave*NCH + j) fills 1 KiB = 8 rows; lane i lands at row i/8, phys chunk i%8
-      const int r8 = (wave * NCH + j) * 8;
-      row = r8 + (lane >> 3);
-      c = (lane & 7) ^ (row & 7);                   // logical chunk that belongs at this LDS slot
-      off = r8 * ROWB;                              // wave-uniform LDS base of the instruction
-    } else {
-      const int qd = tid + 256 * j;
-      row = qd / CHUNKS;
-      c = qd % CHUNKS;
-      if constexpr (sizeof(T) == 2) off = row * ROWB + ((c ^ (row & 7)) << 4);
-      else off = row * ROWB + (c << 4);
-    }
+    const int qd = tid + 256 * j;
+    row = qd / CHUNKS;
+    c = qd % CHUNKS;
+    if constexpr (sizeof(T) == 2) off = row * ROWB + ((c ^ (row & 7)) << 4);
+    else off = row * ROWB + (c << 4);
     int64_t ra = m0 + row; if (ra >= g.M) ra = g.M - 1;
     int rw = n0 + row; if (rw >= g.N) rw = g.N - 1;
     srcA[j] = A + ra * g.lda + c * EPC;
@@ -143,34 +132,22 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  f32x4 stA[NCH], stW[NCH];  // staging registers (register-staged mode)
+  f32x4 stA[NCH], stW[NCH];  // staging registers
 
-  auto issue = [&](int kt, int buf) {
+  auto issue = [&](int kt, int) {
     const int koff = kt * BK;
-    char* base = smem + buf * 2 * TILE_BYTES;
 #pragma unroll
     for (int j = 0; j < NCH; ++j) {
-      if constexpr (GLDS) {
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcA[j] + koff),
-                                         (__attribute__((address_space(3))) void*)(base + ldsoff[j]), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcW[j] + koff),
-                                         (__attribute__((address_space(3))) void*)(base + TILE_BYTES + ldsoff[j]), 16, 0, 0);
-      } else {
-        stA[j] = *reinterpret_cast<const f32x4*>(srcA[j] + koff);
-        stW[j] = *reinterpret_cast<const f32x4*>(srcW[j] + koff);
-      }
+      stA[j] = *reinterpret_cast<const f32x4*>(srcA[j] + koff);
+      stW[j] = *reinterpret_cast<const f32x4*>(srcW[j] + koff);
     }
   };
   auto commit = [&](int buf) {
-    if constexpr (GLDS) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    } else {
-      char* base = smem + buf * 2 * TILE_BYTES;
+    char* base = smem + buf * 2 * TILE_BYTES;
 #pragma unroll
-      for (int j = 0; j < NCH; ++j) {
-        *reinterpret_cast<f32x4*>(base + ldsoff[j]) = stA[j];
-        *reinterpret_cast<f32x4*>(base + TILE_BYTES + ldsoff[j]) = stW[j];
-      }
+    for (int j = 0; j < NCH; ++j) {
+      *reinterpret_cast<f32x4*>(base + ldsoff[j]) = stA[j];
+      *reinterpret_cast<f32x4*>(base + TILE_BYTES + ldsoff[j]) = stW[j];
     }
   };
 
@@ -400,12 +377,6 @@ using CfgStd = BigCfg<256, 128, 2, 2, 3>;
 using CfgWide = BigCfg<256, 256, 2, 4, 4>;
 using CfgRow = BigCfg<128, 512, 2, 4, 3>;
 using CfgWidePP = BigCfg<256, 256, 2, 4, 4, true>;
-// 256x256 on FOUR waves: one wave per SIMD with a 128x128 wave tile (256 accumulator registers of a 512-register wave) - 16 fragment
-// reads per 64 MFMAs instead of 24, 8 DMA pieces per wave and K-step.  A/B only (variant 6 / wide_roles bit 5; VERDICT r4 item 1's geometry)
-using CfgWide4 = BigCfg<256, 256, 2, 2, 4>;
-// 256x128 on EIGHT waves (64x64 wave tiles, one block per CU): the geometry whose accumulators (64 registers) would leave room to carry the
-// previous tile's epilogue through the K loop.  A/B only (variant 7): what the geometry itself costs before any carrying
-using CfgStd8 = BigCfg<256, 128, 4, 2, 3>;
 using CfgRowPP = BigCfg<128, 512, 2, 4, 3, true>;
 using CfgRow64 = BigCfg<64, 512, 1, 8, 3>;   // full-row tile over 64 rows: twice the blocks of CfgRow (short K: the epilogue dominates)
 constexpr int B2K = 32;
@@ -433,9 +404,9 @@ struct BufDma {
 template <int J, int N, class F> __device__ __forceinline__ void static_for(F&& f) {
   if constexpr (J < N) { f(std::integral_constant<int, J>{}); static_for<J + 1, N>(f); }
 }
-template <class C, int SLOT = -1>   // SLOT >= 0: the stage's ring slot as a compile-time constant (= kt % NST)
+template <class C>
 __device__ __forceinline__ void issue_stage_buf(const char* smem, const BufDma& b, const int (&ldsA)[C::PA], const int (&ldsW)[C::PW], int kt) {
-  char* base = const_cast<char*>(smem) + (SLOT >= 0 ? SLOT : kt % C::NST) * C::STAGE;
+  char* base = const_cast<char*>(smem) + (kt % C::NST) * C::STAGE;
   constexpr int AUX_A = C::PP ? MH_PP_A_AUX : 0;     // (the full-row tile's A rows: nt, as in issue_stage)
   static_for<0, C::PA>([&](auto jc) {
     constexpr int j = decltype(jc)::value;
@@ -470,23 +441,6 @@ __device__ __forceinline__ void issue_stage(const char* smem, const char* const 
                                      (__attribute__((address_space(3))) void*)(base + C::BM * 64 + ldsW[j]), 16, 0, 0);
 }
 
-// piece p (0 .. PA + PW - 1) of DMA stage kt: the same transfers as issue_stage, one at a time (interleaved issue, DBG bit 1024)
-template <class C>
-__device__ __forceinline__ void issue_piece(const char* smem, const char* const (&srcA)[C::PA], const char* const (&srcW)[C::PW],
-                                            const int (&ldsA)[C::PA], const int (&ldsW)[C::PW], int kt, int64_t kstepA, int64_t kstepW, int p) {
-  char* base = const_cast<char*>(smem) + (kt % C::NST) * C::STAGE;
-#pragma unroll
-  for (int j = 0; j < C::PA; ++j)
-    if (p == j)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcA[j] + kt * kstepA),
-                                       (__attribute__((address_space(3))) void*)(base + ldsA[j]), 16, 0, 0);
-#pragma unroll
-  for (int j = 0; j < C::PW; ++j)
-    if (p == C::PA + j)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcW[j] + kt * kstepW),
-                                       (__attribute__((address_space(3))) void*)(base + C::BM * 64 + ldsW[j]), 16, 0, 0);
-}
-
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 // wait until all but the youngest `stages` DMA stages (PIECES loads each) of this wave have landed; EXTRA = vector-memory
 // operations of another kind (the previous tile's epilogue stores) issued after the awaited stage (vmcnt counts in issue order)
@@ -506,33 +460,18 @@ template <int PIECES, int EXTRA = 0> __device__ __forceinline__ void wait_stages
 // `pre`: 0 = issue the first stages here; 1 = they were issued before the previous tile's epilogue: drain everything (stores
 // included); 2 = the same, and that epilogue issued exactly NSTORE stores per wave (a full tile): the waits for the prefetched
 // stages count the stores as younger operations instead of waiting for them, so the stores drain under this tile's first K-steps.
-// bias_lds (DBG bit 8192 kernels): the wave's 64 bias values (fp32, in column order) as its own LDS-DMA piece, issued before the tile's first
-// stage: the accumulators START from the bias (one register write each, which the zero fill cost anyway) and the epilogue has no bias add.
-// K loop with the ring slots as compile-time constants (NST steps per iteration, every fragment read `base + immediate`): built and A/B'd as two
-// libraries on one box (tools/ab_lib.sh nounroll . -DMH_KLOOP_UNROLL=0): 3.588 -> 4.306 ms per step at config 2 (+20 %), 7.38 -> 9.60 at the
-// bert-base width - four copies of a K step of 32 MFMAs + 12 reads + the DMA issue do not fit what the instruction cache keeps per CU.  Off.
-#ifndef MH_KLOOP_UNROLL
-#define MH_KLOOP_UNROLL 0
-#endif
-// 1 (round 5): the next K step's W fragments are read straight into their registers behind the last MFMA row - their latency falls under the next
-// step's wait + barrier - instead of into a second register set at the head of the step and copied over at its end (8 64-bit moves and 16
-// registers per step).  Two libraries alternated on one box (tools/ab_lib.sh lateb . -DMH_LATE_B=1): 3.496 -> 3.464 ms per step at config 2
-// (-0.9 %), 7.23 -> 7.21 at the bert-base width; same arithmetic, bit-identical outputs.  0 = the double-buffered form of rounds 1 - 4.
-#ifndef MH_LATE_B
-#define MH_LATE_B 1
-#endif
 template <class C, bool SWAP, int DBG, int NSTORE = 0>
 __device__ __forceinline__ void big_mainloop(f32x4 (&acc)[C::TI][C::TJ], const char* smem, const char* const (&srcA)[C::PA],
                                              const char* const (&srcW)[C::PW], const int (&ldsA)[C::PA], const int (&ldsW)[C::PW],
                                              int nk, int a_off, const int (&b_offs)[C::TJ], int64_t kstepA, int64_t kstepW,
-                                             int pre, unsigned* prof = nullptr, const char* bias_lds = nullptr, const BufDma* bd = nullptr) {
+                                             int pre, unsigned* prof = nullptr, const BufDma* bd = nullptr) {
   constexpr int TI = C::TI, TJ = C::TJ;
   constexpr int NPIECES = (DBG & 4096) != 0 ? C::PA : C::PIECES;   // (ablation 4096: only the A pieces are issued)
   // DBG bit 4 (tools/gemm_bench.py --dbg 28): per-wave shader-clock totals of the three phases of a K-step
   unsigned long long pt_wait = 0, pt_bar = 0, pt_work = 0, pt0 = 0, pt1 = 0;
   auto tick = [&]() -> unsigned long long { if constexpr ((DBG & 16) != 0) return __builtin_amdgcn_s_memtime(); else return 0ull; };
-  auto issue = [&](int kt, auto slotc) {
-    if constexpr ((DBG & 16384) != 0) issue_stage_buf<C, decltype(slotc)::value>(smem, *bd, ldsA, ldsW, kt);
+  auto issue = [&](int kt) {
+    if constexpr ((DBG & 16384) != 0) issue_stage_buf<C>(smem, *bd, ldsA, ldsW, kt);
     else issue_stage<C, DBG>(smem, srcA, srcW, ldsA, ldsW, kt, kstepA, kstepW);
   };
   auto read_frag = [&](const char* p) -> bf16x8 {
@@ -548,29 +487,11 @@ __device__ __forceinline__ void big_mainloop(f32x4 (&acc)[C::TI][C::TJ], const c
   } else if (pre) {   // the stages were issued before the previous tile's epilogue, whose stores share the counter: drain all
     wait_vmcnt<0>();
   } else {
-    for (int st = 0; st < npro; ++st) issue(st, std::integral_constant<int, -1>{});
+    for (int st = 0; st < npro; ++st) issue(st);
     wait_stages<NPIECES>(npro - 1);
   }
   __builtin_amdgcn_s_barrier();
-  if constexpr ((DBG & 8192) != 0) {   // (the wave's own piece: its counted wait above covers it)
-    const int fr_ = threadIdx.x & 15, fg_ = (threadIdx.x & 63) >> 4;
-    if constexpr (SWAP) {   // acc[i][2 qh + (e >> 2)][e & 3] <- bias of column 32 qh + 8 fg + e of the wave's 64-column groups
-#pragma unroll
-      for (int j = 0; j < TJ; ++j) {
-        const f32x4 bj = *reinterpret_cast<const f32x4*>(bias_lds + ((j >> 2) * 64 + 32 * ((j >> 1) & 1) + 8 * fg_ + 4 * (j & 1)) * 4);
-#pragma unroll
-        for (int i = 0; i < TI; ++i) acc[i][j] = bj;
-      }
-    } else {                // un-swapped (V^T waves): acc[i][j][r] is column 16 j + fr of the wave
-#pragma unroll
-      for (int j = 0; j < TJ; ++j) {
-        const float bj = *reinterpret_cast<const float*>(bias_lds + (16 * j + fr_) * 4);
-#pragma unroll
-        for (int i = 0; i < TI; ++i) acc[i][j] = f32x4{bj, bj, bj, bj};
-      }
-    }
-  }
-  bf16x8 a[TI], b[TJ], bn[TJ];
+  bf16x8 a[TI], b[TJ];
 #pragma unroll
   for (int j = 0; j < TJ; ++j) b[j] = read_frag(smem + C::BM * 64 + b_offs[j]);
 #pragma unroll
@@ -588,11 +509,11 @@ __device__ __forceinline__ void big_mainloop(f32x4 (&acc)[C::TI][C::TJ], const c
       }
     }
   };
-  // One K step.  S >= 0: the ring slot of stage kt + 1 as a compile-time constant, so that every fragment read is `base + immediate` and the
-  // refill names its slot without scalar arithmetic (the loop below runs NST steps per iteration); S = -1: computed (the remainder steps)
-  auto kstep = [&](int kt, auto sc) {
-    constexpr int S = decltype(sc)::value;
-    const char* As = smem + (S >= 0 ? S : (kt + 1) % C::NST) * C::STAGE;
+  // One K step.  (Two forms of it were built and measured out in round 5 - profiles/r05_ab_nulls.txt: the loop unrolled by the ring depth so
+  // that every fragment read is `base + immediate`: +20 % per step, four copies of a K step do not fit the instruction cache; the next step's
+  // W fragments into a second register set at the head of the step: +0.9 %, 16 registers and 8 moves per step.)
+  auto kstep = [&](int kt) {
+    const char* As = smem + ((kt + 1) % C::NST) * C::STAGE;
     const char* Ws = As + C::BM * 64;
     // stage kt+1 must have landed (stages kt+2 .. kt+NST-1 stay in flight across the barrier); this wave's
     // reads of stage kt were issued a whole MFMA phase ago, so the lgkmcnt wait is free
@@ -609,41 +530,19 @@ __device__ __forceinline__ void big_mainloop(f32x4 (&acc)[C::TI][C::TJ], const c
     pt0 = tick();
     pt_bar += pt0 - pt1;
     pt1 = pt0;
-    constexpr bool SPREAD = (DBG & 1024) != 0 && C::PIECES <= TI;   // one DMA piece behind each MFMA row instead of a burst
-    const bool refill = kt + C::NST < nk;
-    if (!SPREAD && refill) issue(kt + C::NST, std::integral_constant<int, (S >= 0 ? (S + C::NST - 1) % C::NST : -1)>{});   // slot kt % NST: every wave has read stage kt out of it
-#if MH_LATE_B
+    if (kt + C::NST < nk) issue(kt + C::NST);   // slot kt % NST: every wave has read stage kt out of it
     // the W fragments of stage kt + 1 are read straight into b[] behind the LAST MFMA row of this step (their latency falls under the next
     // step's wait + barrier): no second register set, no copy
 #pragma unroll
     for (int i = 0; i < TI; ++i) {
       mfma_row(i);
       a[i] = read_frag(As + a_off + i * (16 * 64));
-      if constexpr (SPREAD) { if (refill && i < C::PIECES) issue_piece<C>(smem, srcA, srcW, ldsA, ldsW, kt + C::NST, kstepA, kstepW, i); }
       __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
     for (int j = 0; j < TJ; ++j) b[j] = read_frag(Ws + b_offs[j]);
-#else
-#pragma unroll
-    for (int j = 0; j < TJ; ++j) bn[j] = read_frag(Ws + b_offs[j]);
-#pragma unroll
-    for (int i = 0; i < TI; ++i) {
-      mfma_row(i);
-      a[i] = read_frag(As + a_off + i * (16 * 64));
-      if constexpr (SPREAD) { if (refill && i < C::PIECES) issue_piece<C>(smem, srcA, srcW, ldsA, ldsW, kt + C::NST, kstepA, kstepW, i); }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-#pragma unroll
-    for (int j = 0; j < TJ; ++j) b[j] = bn[j];
-#endif
   };
-  int kt = 0;
-#if MH_KLOOP_UNROLL
-  for (; kt + C::NST < nk; kt += C::NST)     // kt % NST == 0 here: the group's steps read slots 1, 2, .., NST - 1, 0
-    static_for<0, C::NST>([&](auto rc) { kstep(kt + decltype(rc)::value, std::integral_constant<int, (decltype(rc)::value + 1) % C::NST>{}); });
-#endif
-  for (; kt + 1 < nk; ++kt) kstep(kt, std::integral_constant<int, -1>{});
+  for (int kt = 0; kt + 1 < nk; ++kt) kstep(kt);
 #pragma unroll
   for (int i = 0; i < TI; ++i) mfma_row(i);
   if constexpr ((DBG & 16) != 0) {
@@ -730,10 +629,9 @@ template <class C, bool SWAP, int DBG, int NSTORE = 0>
 __device__ __forceinline__ void run_mainloop(f32x4 (&acc)[C::TI][C::TJ], const char* smem, const char* const (&srcA)[C::PA],
                                              const char* const (&srcW)[C::PW], const int (&ldsA)[C::PA], const int (&ldsW)[C::PW],
                                              int nk, int a_off, const int (&b_offs)[C::TJ], int64_t kstepA, int64_t kstepW,
-                                             int group, int pre, unsigned* prof = nullptr, const char* bias_lds = nullptr, const BufDma* bd = nullptr) {
-  static_assert(!(C::PP && (DBG & 8192) != 0), "bias-initialised accumulators: plain main loop only");
+                                             int group, int pre, unsigned* prof = nullptr, const BufDma* bd = nullptr) {
   if constexpr (C::PP) pp_mainloop<C, SWAP, DBG>(acc, smem, srcA, srcW, ldsA, ldsW, nk, a_off, b_offs, kstepA, kstepW, group, pre != 0, bd);
-  else big_mainloop<C, SWAP, DBG, NSTORE>(acc, smem, srcA, srcW, ldsA, ldsW, nk, a_off, b_offs, kstepA, kstepW, pre, prof, bias_lds, bd);
+  else big_mainloop<C, SWAP, DBG, NSTORE>(acc, smem, srcA, srcW, ldsA, ldsW, nk, a_off, b_offs, kstepA, kstepW, pre, prof, bd);
 }
 
 // EPI: 0 generic (bias / act / residual), 1 QKV head scatter, 3 bias + residual + LayerNorm over complete rows
@@ -746,9 +644,6 @@ __global__ __launch_bounds__(C::THREADS, C::STAGE * C::NST <= 80 * 1024 ? 2 : 1)
   // deferred LayerNorm (DeferArgs), one compiled variant per operand combination so that unused vectors cost no registers:
   // DA = A rows raw, DR = residual rows raw, DO = write the output rows' partial statistics
   constexpr bool DA = (DBG & 128) != 0, DR = (DBG & 256) != 0, DO = (DBG & 512) != 0, DEFER = DA || DR || DO;
-  // BIASACC (round 5): the accumulators start from the bias (big_mainloop), one 1-KiB LDS piece per wave behind the ring
-  constexpr bool BIASACC = (DBG & 8192) != 0;
-  static_assert(!BIASACC || (!DEFER && EPI != 3 && !C::PP && C::TJ == 4), "bias-initialised accumulators: plain 256x128 kernels only");
   constexpr int TI_ = C::TI, TJ_ = C::TJ;
   // (EPI 3 stages the tile's residual rows through LDS after the main loop: each wave's TI x TJ/2 KiB go where the ring was;
   // a last wave that does not fit - the 128x512 tile: 8 x 16 KiB against a 120 KiB ring - gets its own area at the end)
@@ -756,7 +651,7 @@ __global__ __launch_bounds__(C::THREADS, C::STAGE * C::NST <= 80 * 1024 ? 2 : 1)
   constexpr bool RES_EXTRA = EPI == 3 && C::NW * RES_W > RING;
   static_assert(EPI != 3 || (C::NW - 1) * RES_W <= RING, "residual staging: at most the last wave may overflow the ring");
   __shared__ __attribute__((aligned(16))) char smem[C::NST * C::STAGE + (EPI == 3 ? C::BM * C::WN * 4 + 3 * C::BN * 4 : 0) +
-                                                    (DEFER ? C::BM * 8 * (2 + C::WN) : 0) + (RES_EXTRA ? RES_W : 0) + (BIASACC ? C::NW * 1024 : 0)];
+                                                    (DEFER ? C::BM * 8 * (2 + C::WN) : 0) + (RES_EXTRA ? RES_W : 0)];
   constexpr int TI = C::TI, TJ = C::TJ;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -814,11 +709,6 @@ __global__ __launch_bounds__(C::THREADS, C::STAGE * C::NST <= 80 * 1024 ? 2 : 1)
       srcW[j] = reinterpret_cast<const char*>(g.W) + ((int64_t)blockIdx.y * g.sW + (int64_t)rw * w_row + lc * 8) * 2;
     }
   };
-  // positive: the second half of the grid starts late; negative: every other block of an XCD ((blockIdx.x >> 3) & 1) does
-  if ((g.stagger > 0 && blockIdx.x >= gridDim.x / 2) || (g.stagger < 0 && ((blockIdx.x >> 3) & 1))) {
-    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime(), d = (unsigned long long)(g.stagger < 0 ? -g.stagger : g.stagger);
-    while (__builtin_amdgcn_s_memrealtime() - t0 < d) __builtin_amdgcn_s_sleep(8);
-  }
   if constexpr (EPI == 3) {
     float* vecs = reinterpret_cast<float*>(smem + C::NST * C::STAGE + C::BM * C::WN * 4);
     for (int c = tid; c < C::BN; c += C::THREADS) {
@@ -828,16 +718,6 @@ __global__ __launch_bounds__(C::THREADS, C::STAGE * C::NST <= 80 * 1024 ? 2 : 1)
     }
     __syncthreads();
   }
-  const char* const bias_lds = smem + C::NST * C::STAGE + wave * 1024;     // (BIASACC only)
-  // the wave's 64 bias values of tile `tile` -> its LDS piece (lanes 0 - 15 carry them, the others repeat: an LDS-DMA piece is 64 x 16 B)
-  auto issue_bias = [&](int tile) {
-    if constexpr (BIASACC) {
-      const int tn0 = (xcd_remap(tile, g.ntiles) % tiles_n) * C::BN;
-      const float* src = g.bias + tn0 + wn * (TJ_ * 16) + 4 * (lane & 15);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)const_cast<char*>(bias_lds), 16, 0, 0);
-    }
-  };
   int pre = 0;   // 1 / 2: this tile's first stages were issued before the previous tile's epilogue (2: a full tile's, see big_mainloop)
   // persistent: after a tile's main loop the ring is idle, so the next tile's first stages are put in flight
   // BEFORE the epilogue: their latency (an HBM miss for the A rows) hides behind the stores
@@ -854,7 +734,6 @@ __global__ __launch_bounds__(C::THREADS, C::STAGE * C::NST <= 80 * 1024 ? 2 : 1)
         __builtin_amdgcn_s_barrier();
       }
       const int npro = nk < C::PRO ? nk : C::PRO;
-      issue_bias(vn);   // (older than the stages: every wait that covers stage 0 covers it)
       for (int st = 0; st < npro; ++st) {
         if constexpr (BUFDMA) issue_stage_buf<C>(smem, bd, ldsA, ldsW, st);
         else issue_stage<C, DBG>(smem, srcA, srcW, ldsA, ldsW, st, kstepA, kstepW);
@@ -894,7 +773,6 @@ __global__ __launch_bounds__(C::THREADS, C::STAGE * C::NST <= 80 * 1024 ? 2 : 1)
       __builtin_amdgcn_s_barrier();
     }
     set_sources(vt);
-    issue_bias(vt);   // (the main loop issues this tile's first stages behind it)
   }
   const int bid = xcd_remap(vt, g.ntiles);
   const int64_t m0 = (int64_t)(bid / tiles_n) * C::BM;
@@ -938,7 +816,7 @@ __global__ __launch_bounds__(C::THREADS, C::STAGE * C::NST <= 80 * 1024 ? 2 : 1)
     const int which = wcol0 / g.H;   // wave-uniform: 0 q, 1 k, 2 v
     const int M32 = (int)g.M, r0 = (int)wrow0;
     if (which == 2) {
-      run_mainloop<C, false, DBG, TI * TJ>(acc, smem, srcA, srcW, ldsA, ldsW, nk, a_off, b_offs, kstepA, kstepW, wm, pre, nullptr, bias_lds, &bd);
+      run_mainloop<C, false, DBG, TI * TJ>(acc, smem, srcA, srcW, ldsA, ldsW, nk, a_off, b_offs, kstepA, kstepW, wm, pre, nullptr, &bd);
       prefetch_next(vt, full_tile);
       // acc[i][j][r] = D[m = 16i + 4fg + r][n = 16j + fr]: 4 consecutive tokens per lane -> V^T rows
       // FULL (interior tile, wave-uniform): no per-lane guards, so the epilogue is straight-line code.  With divergent guards
@@ -953,7 +831,7 @@ __global__ __launch_bounds__(C::THREADS, C::STAGE * C::NST <= 80 * 1024 ? 2 : 1)
         for (int j = 0; j < TJ; ++j) {
           const int col = wcol0 + 16 * j + fr;
           const int cc = (FULL || col < g.N) ? col : g.N - 1;
-          bv[j] = BIASACC ? 0.f : g.bias[cc];
+          bv[j] = g.bias[cc];
           if constexpr (DA) c1v[j] = g.d.c1[cc];
           const int c = cc - 2 * g.H, head = c / g.dh, d = c % g.dh;
           coloff[j] = (FULL || col < g.N) ? ((int64_t)head * g.dh + d) * g.L : -1;
@@ -980,7 +858,6 @@ __global__ __launch_bounds__(C::THREADS, C::STAGE * C::NST <= 80 * 1024 ? 2 : 1)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                   if constexpr (DA) v[r] = (bf16)fmaf(rsd[r], fmaf(-mu[r], c1v[j], acc[i][j][r]), bv[j]);
-                  else if constexpr (BIASACC) v[r] = (bf16)acc[i][j][r];
                   else v[r] = (bf16)(acc[i][j][r] + bv[j]);
                 }
                 *reinterpret_cast<bf16x4*>(base + coloff[j]) = v;
@@ -991,7 +868,7 @@ __global__ __launch_bounds__(C::THREADS, C::STAGE * C::NST <= 80 * 1024 ? 2 : 1)
       };
       if (full_tile) epi_v(std::true_type{}); else epi_v(std::false_type{});
     } else {
-      run_mainloop<C, true, DBG, TI * (TJ / 2)>(acc, smem, srcA, srcW, ldsA, ldsW, nk, a_off, b_offs, kstepA, kstepW, wm, pre, nullptr, bias_lds, &bd);
+      run_mainloop<C, true, DBG, TI * (TJ / 2)>(acc, smem, srcA, srcW, ldsA, ldsW, nk, a_off, b_offs, kstepA, kstepW, wm, pre, nullptr, &bd);
       prefetch_next(vt, full_tile);
       auto epi_qk = [&](auto fullc) {
         constexpr bool FULL = decltype(fullc)::value;
@@ -1003,7 +880,7 @@ __global__ __launch_bounds__(C::THREADS, C::STAGE * C::NST <= 80 * 1024 ? 2 : 1)
 #pragma unroll
         for (int qh = 0; qh < TJ / 2; ++qh) {
           const int col = wcol0 + 32 * qh + 8 * fg;
-          if constexpr (!BIASACC) load8(g.bias + ((FULL || col < g.N) ? col : 0), bv[qh]);
+          load8(g.bias + ((FULL || col < g.N) ? col : 0), bv[qh]);
           if constexpr (DA) load8(g.d.c1 + ((FULL || col < g.N) ? col : 0), c1v[qh]);
         }
         if constexpr (DA) {
@@ -1028,7 +905,6 @@ __global__ __launch_bounds__(C::THREADS, C::STAGE * C::NST <= 80 * 1024 ? 2 : 1)
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                   if constexpr (DA) v[e] = fmaf(rsd[i], fmaf(-mu[i], c1v[qh][e], acc[i][2 * qh + (e >> 2)][e & 3]), bv[qh][e]);
-                  else if constexpr (BIASACC) v[e] = acc[i][2 * qh + (e >> 2)][e & 3];
                   else v[e] = acc[i][2 * qh + (e >> 2)][e & 3] + bv[qh][e];
                 }
                 if (scale_q) {
@@ -1047,7 +923,7 @@ __global__ __launch_bounds__(C::THREADS, C::STAGE * C::NST <= 80 * 1024 ? 2 : 1)
   } else {
     // stores per wave of a full tile: one 16-byte store per (row tile, 32-column half); a second one with pre_out
     run_mainloop<C, true, DBG, TI * (TJ / 2)>(acc, smem, srcA, srcW, ldsA, ldsW, nk, a_off, b_offs, kstepA, kstepW, wm, pre,
-                                              reinterpret_cast<unsigned*>(g.out) + 64 + ((int64_t)bid * C::NW + wave) * 8, bias_lds, &bd);
+                                              reinterpret_cast<unsigned*>(g.out) + 64 + ((int64_t)bid * C::NW + wave) * 8, &bd);
     prefetch_next(vt, full_tile && !g.pre_out && !g.out_f32);
     bf16* outT = reinterpret_cast<bf16*>(g.out) + (int64_t)blockIdx.y * g.sO;
     float* outF = reinterpret_cast<float*>(g.out) + (int64_t)blockIdx.y * g.sO;
@@ -1216,7 +1092,6 @@ __global__ __launch_bounds__(C::THREADS, C::STAGE * C::NST <= 80 * 1024 ? 2 : 1)
           const int col = wcol0 + 32 * qh + 8 * fg;
 #pragma unroll
           for (int e = 0; e < 8; ++e) bv[qh][e] = 0.f;
-          if constexpr (BIASACC) continue;
           if (g.bias && (FULL || col < g.N)) {
             if (FULL || col + 8 <= g.N) load8(g.bias + col, bv[qh]);
             else { const f32x4 b4 = *reinterpret_cast<const f32x4*>(g.bias + col); bv[qh][0] = b4[0]; bv[qh][1] = b4[1]; bv[qh][2] = b4[2]; bv[qh][3] = b4[3]; }
@@ -1253,9 +1128,6 @@ __global__ __launch_bounds__(C::THREADS, C::STAGE * C::NST <= 80 * 1024 ? 2 : 1)
                   const float2 sa = lds_a[rt];
 #pragma unroll
                   for (int e = 0; e < 8; ++e) v[e] = fmaf(sa.y, fmaf(-sa.x, c1v[e], acc[i][2 * qh + (e >> 2)][e & 3]), bv[qh][e]);
-                } else if constexpr (BIASACC) {
-#pragma unroll
-                  for (int e = 0; e < 8; ++e) v[e] = acc[i][2 * qh + (e >> 2)][e & 3];
                 } else {
 #pragma unroll
                   for (int e = 0; e < 8; ++e) v[e] = acc[i][2 * qh + (e >> 2)][e & 3] + bv[qh][e];
@@ -1354,27 +1226,22 @@ __global__ __launch_bounds__(C::THREADS, C::STAGE * C::NST <= 80 * 1024 ? 2 : 1)
 }
 
 MH_KNOB(int, g_dbg, 0);
-MH_KNOB(int, g_spread, 0);     // A/B: DMA pieces interleaved with the MFMA rows (DBG bit 1024 kernels)
-MH_KNOB(int, g_stagger, 0);
-MH_KNOB(int, g_variant, 2);  // bf16 kernel choice: 0 small-tile register-staged, 1 small-tile global_load_lds, 2 / 3 big 256x128, 4 big 256x256, 5 big 256x256 ping-pong
+MH_KNOB(int, g_variant, 2);  // bf16 kernel choice: 0 the 128x128 register-staged tile everywhere (the fallback of shapes the big tiles do not serve), 2 big tiles (256x128; 256x256 for row-major launches that fill the chip with it), 4 big 256x256
 
+// compute units of the CURRENT device (cached per device: the library may serve several devices from one process)
 int device_cus() {
-  static int cus = 0;
-  if (!cus) {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cus = n;
-    else cus = 256;
+  static int cus[MH_MAX_DEVICES] = {};
+  const int dev = mh_current_device();
+  if (!cus[dev]) {
+    int n = 0;
+    cus[dev] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
   }
-  return cus;
+  return cus[dev];
 }
 
 #ifndef MH_PLAIN_STORES_DEFAULT
 #define MH_PLAIN_STORES_DEFAULT 0
 #endif
-// A/B (mh_gemm_set_bias_acc): 1 = the accumulators start from the bias.  Measured inside the captured step: 3.610 -> 3.770 ms (+4.4 %; bert-base
-// width +0.3 %): the 128 epilogue adds it removes are cheaper than what it adds to the head of every tile (the bias piece's LDS round trip and 128
-// dependent register writes between the first barrier and the first MFMA, where the zero fill used to sit under the DMA wait).  Default off.
-MH_KNOB(int, g_bias_acc, 0);
 // round 5: K32-panel launches (the engine's) issue their stage DMA as buffer loads (BufDma above): bit-identical results, no vector address
 // arithmetic per piece.  A/B: mh_gemm_set_buf_dma(0) = global_load_lds with per-piece 64-bit addresses (rounds 1 - 4)
 MH_KNOB(int, g_buf_dma, 1);
@@ -1390,15 +1257,11 @@ int launch_big(const GemmArgs& g0, hipStream_t s, int batch) {
   const int per_cu = (C::STAGE * C::NST <= 80 * 1024 && C::NW <= 4) ? 2 : 1;
   const int64_t slots = (int64_t)cus * per_cu;
   g.ntiles = (int)t2;
-  g.stagger = g_stagger;
   const dim3 grid((unsigned)(t2 < slots ? t2 : slots), (unsigned)batch), block(C::THREADS);
   mh_prof_note("tile=%dx%d%s epi=%d act=%d M=%lld N=%d K=%d batch=%d", C::BM, C::BN, C::PP ? "pp" : "", EPI, g.act, (long long)g.M, g.N, g.K, batch);
   const bool defer = g.d.a_stats || g.d.r_stats || g.d.o_stats;
-  // the accumulators start from the bias (DBG bit 8192 kernels): whole column tiles of the plain 256x128 kernels, no training outputs
-  const bool bias_acc = g_bias_acc && C::TJ == 4 && !C::PP && g.bias && g.N % C::BN == 0 && !defer && !g.pre_out && !g.out_f32 && !g.drop.thr &&
-                        !g.act_grad && !(g.dbg & 31);
   // the stage DMA as buffer loads (BufDma): K32-panel operands (the engine's launches) whose byte extents fit a 32-bit descriptor
-  const bool buf_dma = g_buf_dma && g.a_panel && g.w_panel && !(g.dbg & 31) && !g_spread &&
+  const bool buf_dma = g_buf_dma && g.a_panel && g.w_panel && !(g.dbg & 31) &&
                        (int64_t)(g.K / 32) * g.lda * 64 < (1ll << 31) && (int64_t)(g.K / 32) * g.ldw * 64 < (1ll << 31);
 #define MH_LAUNCH_BIG(EPI_, ACT_, BITS_)                                                                             \
   do {                                                                                                                \
@@ -1412,11 +1275,9 @@ int launch_big(const GemmArgs& g0, hipStream_t s, int batch) {
         MH_LAUNCH_BIG(1, MH_ACT_NONE, 128);
       } else { mh_set_error("gemm: deferred LayerNorm needs the 256x128 tile"); return MH_ERR_UNSUPPORTED; }
     }
-    else if (g_spread && C::NW == 4) { if constexpr (C::NW == 4) MH_LAUNCH((gemm_big_kernel<C, 1, MH_ACT_NONE, 1024>), grid, block, 0, s, g); }
     // q / k leave with ordinary stores: the attention kernel reads them back at once (round 2, after the epilogue restructuring:
     // +0.9 % steps/s over streaming stores, tools/ab_step.py plain_stores 0 1; round 1 had measured the opposite); bit 0 = streaming
     else if (g_plain_stores & 1) MH_LAUNCH((gemm_big_kernel<C, 1, MH_ACT_NONE>), grid, block, 0, s, g);
-    else if (bias_acc && !buf_dma) { if constexpr (C::TJ == 4 && !C::PP) MH_LAUNCH((gemm_big_kernel<C, 1, MH_ACT_NONE, 32 + 8192>), grid, block, 0, s, g); }
     else MH_LAUNCH_BIG(1, MH_ACT_NONE, 32);
   } else if constexpr (EPI == 3) {
     if (g.drop.thr || g.pre_out) {   // the training build: dropout (p may be 0) + the un-normalised rows kept for the backward
@@ -1454,15 +1315,12 @@ int launch_big(const GemmArgs& g0, hipStream_t s, int batch) {
     } else switch (g.act) {
       case MH_ACT_TANH: MH_LAUNCH_BIG(0, MH_ACT_TANH, 0); break;
       case MH_ACT_GELU_ERF:
-        if (g_spread && C::NW == 4) { if constexpr (C::NW == 4) MH_LAUNCH((gemm_big_kernel<C, 0, MH_ACT_GELU_ERF, 1024>), grid, block, 0, s, g); }
-        else if (g_plain_stores & 2) MH_LAUNCH((gemm_big_kernel<C, 0, MH_ACT_GELU_ERF, 32>), grid, block, 0, s, g);
-        else if (bias_acc && !buf_dma && !g.residual) { if constexpr (C::TJ == 4 && !C::PP) MH_LAUNCH((gemm_big_kernel<C, 0, MH_ACT_GELU_ERF, 8192>), grid, block, 0, s, g); }
+        if (g_plain_stores & 2) MH_LAUNCH((gemm_big_kernel<C, 0, MH_ACT_GELU_ERF, 32>), grid, block, 0, s, g);
         else MH_LAUNCH_BIG(0, MH_ACT_GELU_ERF, 0);
         break;
       case MH_ACT_SILU: MH_LAUNCH((gemm_big_kernel<C, 0, MH_ACT_SILU>), grid, block, 0, s, g); break;
       default:
-        if (g_spread && C::NW == 4 && !g.drop.thr) { if constexpr (C::NW == 4) MH_LAUNCH((gemm_big_kernel<C, 0, MH_ACT_NONE, 1024>), grid, block, 0, s, g); }
-        else if (g.drop.thr) MH_LAUNCH((gemm_big_kernel<C, 0, MH_ACT_NONE, 64>), grid, block, 0, s, g);
+        if (g.drop.thr) MH_LAUNCH((gemm_big_kernel<C, 0, MH_ACT_NONE, 64>), grid, block, 0, s, g);
         else MH_LAUNCH_BIG(0, MH_ACT_NONE, 0);
         break;
     }
@@ -1471,25 +1329,6 @@ int launch_big(const GemmArgs& g0, hipStream_t s, int batch) {
   MH_CHECK_LAUNCH();
   return MH_OK;
 }
-
-#ifdef MH_ABLATE
-// A/B (mh_gemm_set_wide_roles bits 3 / 4): the dense + GELU launch on the 128 x 512 tile of the LayerNorm kernels (8 waves, one block per
-// CU; bit 3 with the ping-pong main loop, bit 4 with the plain one) - the tile on which the FFN output dense runs at ~95 % of its CUs'
-// matrix rate
-template <class C>
-int launch_row_gelu(const GemmArgs& g0, hipStream_t s, int batch) {
-  GemmArgs g = g0;
-  const int64_t t2 = (int64_t)ceil_div(g.M, C::BM) * ceil_div(g.N, C::BN);
-  const int64_t slots = device_cus();
-  g.ntiles = (int)t2;
-  g.stagger = 0;
-  const dim3 grid((unsigned)(t2 < slots ? t2 : slots), (unsigned)batch), block(C::THREADS);
-  mh_prof_note("tile=%dx%d%s epi=0 act=%d M=%lld N=%d K=%d batch=%d", C::BM, C::BN, C::PP ? "pp" : "", g.act, (long long)g.M, g.N, g.K, batch);
-  MH_LAUNCH((gemm_big_kernel<C, 0, MH_ACT_GELU_ERF>), grid, block, 0, s, g);
-  MH_CHECK_LAUNCH();
-  return MH_OK;
-}
-#endif
 
 bool big_tile_ok(const GemmArgs& g) {
   // N % 8 == 0: a lane's 8 output columns are all valid; an fp32 row-major output may end on a half group (N % 4 == 0, e.g. the
@@ -1538,33 +1377,17 @@ int launch(const GemmArgs& g, int dtype, hipStream_t s, int batch = 1) {
       // QKV scatter: a wave's columns must not straddle the q/k/v boundary (H % 64 == 0 for the wide tile)
       else {
         if (g.d.a_stats || g.d.r_stats || g.d.o_stats) return launch_big<CfgStd, EPI>(g, s, batch);   // deferred LayerNorm: 256x128 only
-#ifdef MH_ABLATE
-        if constexpr (EPI == 0) {
-          if ((g_wide_roles & 24) && g.act == MH_ACT_GELU_ERF && g.N % 512 == 0 && (g.a_panel || g.w_panel) && !g.pre_out && !g.residual)
-            return (g_wide_roles & 8) ? launch_row_gelu<CfgRowPP>(g, s, batch) : launch_row_gelu<CfgRow>(g, s, batch);
-        }
-#endif
-#ifdef MH_ABLATE
-        if constexpr (EPI == 0) { if (g_variant == 7) return launch_big<CfgStd8, EPI>(g, s, batch); }
-#endif
-        if (want_wide(g, batch) && (EPI != 1 || g.H % 64 == 0)) {
-#ifdef MH_ABLATE
-          if ((g_variant == 6 || (g_wide_roles & 32)) && (EPI != 1 || g.H % 128 == 0)) return launch_big<CfgWide4, EPI>(g, s, batch);
-#endif
-          return g_variant == 5 ? launch_big<CfgWidePP, EPI>(g, s, batch) : launch_big<CfgWide, EPI>(g, s, batch);
-        }
+        if (want_wide(g, batch) && (EPI != 1 || g.H % 64 == 0)) return launch_big<CfgWide, EPI>(g, s, batch);
         return launch_big<CfgStd, EPI>(g, s, batch);
       }
-    } else if (g_variant == 1) {
-      MH_LAUNCH((gemm_kernel<bf16, EPI, 1>), grid, block, 0, s, g);
     } else {
-      MH_LAUNCH((gemm_kernel<bf16, EPI, 0>), grid, block, 0, s, g);
+      MH_LAUNCH((gemm_kernel<bf16, EPI>), grid, block, 0, s, g);
     }
   } else if (dtype == MH_F32) {
     MH_CHECK_ARG(!(g.a_panel || g.w_panel || g.o_panel || g.r_panel), "gemm(f32): panel layouts are bf16 only");
     MH_CHECK_ARG(g.K % 16 == 0 && g.K > 0, "gemm(f32): K=%d must be a positive multiple of 16", g.K);
     MH_CHECK_ARG(g.lda % 4 == 0 && g.ldw % 4 == 0, "gemm(f32): lda/ldw must be multiples of 4");
-    MH_LAUNCH((gemm_kernel<float, EPI, 0>), grid, block, 0, s, g);
+    MH_LAUNCH((gemm_kernel<float, EPI>), grid, block, 0, s, g);
   } else {
     MH_CHECK_ARG(false, "gemm: unknown dtype %d", dtype);
   }
@@ -1592,29 +1415,6 @@ extern "C" int mh_gemm_set_buf_dma(int on) {
 #endif
 
 #ifdef MH_ABLATE
-extern "C" int mh_gemm_set_bias_acc(int on) {
-  g_bias_acc = on != 0;
-  return MH_OK;
-}
-#endif
-
-#ifdef MH_ABLATE
-extern "C" int mh_gemm_set_stagger(int ticks) {
-  g_stagger = ticks;
-  return MH_OK;
-}
-#endif
-
-// experiment knob (A/B only): 1 = the 256x128 kernels issue one LDS-DMA piece behind each MFMA row of a K-step instead of all six
-// right after the barrier.  Measured (tools/gemm_bench.py --spread): FFN1 -2.6 %, QKV -1 %, FFN2 / attention-output +-0 per launch.
-#ifdef MH_ABLATE
-extern "C" int mh_gemm_set_spread(int on) {
-  g_spread = on != 0;
-  return MH_OK;
-}
-#endif
-
-#ifdef MH_ABLATE
 extern "C" int mh_gemm_set_debug(int bits) {
   g_dbg = bits & 127;
   return MH_OK;
@@ -1636,7 +1436,7 @@ extern "C" int mh_gemm_set_auto_wide(int on) {
 
 #ifdef MH_ABLATE
 extern "C" int mh_gemm_set_variant(int variant) {
-  MH_CHECK_ARG(variant >= 0 && variant <= 7, "gemm_set_variant: variant must be 0..7");
+  MH_CHECK_ARG(variant == 0 || variant == 2 || variant == 4, "gemm_set_variant: variant must be 0, 2 or 4");
   g_variant = variant;
   return MH_OK;
 }

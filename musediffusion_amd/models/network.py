@@ -213,8 +213,9 @@ class TransformerNetModel(nn.Module):
         return ops.embed_gather(w.detach(), input_ids.to(w.device))
 
     def get_logits(self, hidden_repr):
-        """network.py:91-106 (logits_mode 1 is the only mode the reference ever constructs)."""
-        if self.logits_mode != 1:
+        """network.py:91-106: logits_mode 1 = lm_head(x) (the only mode the reference ever constructs); 2 = the negative Euclidean distance of
+        every position to every lm_head row, -sqrt(clamp(|W_v|^2 + |x_n|^2 - 2 W_v.x_n, 0)) (network.py:94-104; lm_head.bias is not used)."""
+        if self.logits_mode not in (1, 2):
             raise NotImplementedError
         w, b = self.lm_head.weight.detach(), self.lm_head.bias.detach()
         _lib.require_device(w, hidden_repr)
@@ -223,7 +224,13 @@ class TransformerNetModel(nn.Module):
         flat = hidden_repr.reshape(-1, E).to(torch.float32)
         x = ops.cast_pad(flat, Ep, _lib.MH_F32)
         wp = ops.cast_pad(w, Ep, _lib.MH_F32)
-        out = ops.gemm_bias_act(x, wp, b, None, None, _lib.MH_F32, out_f32=True, N=V, K=Ep)
+        out = ops.gemm_bias_act(x, wp, b if self.logits_mode == 1 else None, None, None, _lib.MH_F32, out_f32=True, N=V, K=Ep)
+        if self.logits_mode == 2:
+            wn, xn = ops.row_sqnorm(w), ops.row_sqnorm(flat)
+            scores = torch.empty(flat.shape[0], V, device=flat.device, dtype=torch.float32)
+            _lib.check(_lib.lib().mh_distance_scores(_lib.ptr(out), out.shape[1], _lib.ptr(wn), _lib.ptr(xn), _lib.ptr(scores), V, flat.shape[0], V,
+                                                     _lib.current_stream()), "mh_distance_scores")
+            return scores.view(*hidden_repr.shape[:-1], V)
         return out.view(*hidden_repr.shape[:-1], V)
 
     def argmax_tokens(self, hidden_repr):

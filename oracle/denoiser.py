@@ -111,9 +111,21 @@ def get_embeds(sd, ids):
     return sd["word_embedding.weight"][ids.long()]
 
 
-def get_logits(sd, hidden):
-    """network.py:91-93 (logits_mode 1; lm_head.weight is tied to word_embedding.weight)."""
-    return F.linear(hidden, sd["lm_head.weight"], sd["lm_head.bias"])
+def get_logits(sd, hidden, logits_mode=1):
+    """network.py:91-106.  logits_mode 1: lm_head(hidden) (lm_head.weight is tied to word_embedding.weight); logits_mode 2 (:94-104): the
+    negative Euclidean distance to every lm_head row, -sqrt(clamp(|W_v|^2 + |x_n|^2 - 2 W_v.x_n, 0, inf)), the three terms associated
+    as the reference adds them."""
+    if logits_mode == 1:
+        return F.linear(hidden, sd["lm_head.weight"], sd["lm_head.bias"])
+    if logits_mode != 2:
+        raise NotImplementedError
+    W = sd["lm_head.weight"]
+    flat = hidden.reshape(-1, hidden.shape[-1])
+    emb_norm = (W ** 2).sum(-1).view(-1, 1)                          # [V, 1]
+    arr_norm = (flat ** 2).sum(-1).view(-1, 1)                       # [N, 1]
+    dist = emb_norm + arr_norm.transpose(0, 1) - 2.0 * torch.mm(W, flat.transpose(0, 1))      # [V, N]
+    scores = torch.sqrt(torch.clamp(dist, 0.0, float("inf")))
+    return -scores.transpose(0, 1).reshape(*hidden.shape[:-1], W.shape[0])
 
 
 def random_state_dict(E, H, F_, num_layers, V, L, Tt, seed=0, emb_std=1.0):

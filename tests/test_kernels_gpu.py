@@ -91,7 +91,7 @@ GEMM_CASES = [
 
 
 @pytest.mark.parametrize("dtype", [MH_F32, MH_BF16], ids=["f32", "bf16"])
-@pytest.mark.parametrize("glds", [0, 1, 2, 3])
+@pytest.mark.parametrize("glds", [0, 2, 4])
 @pytest.mark.parametrize("case", GEMM_CASES)
 def test_gemm_bias_act(case, dtype, glds):
     M, N, K, act, use_res, out_f32 = case
@@ -551,7 +551,7 @@ def test_gemm_panel_layouts(case):
     assert_close(outf, q(A, MH_BF16) @ q(W, MH_BF16).T + b, 2e-3, 1e-4, what="gemm panel->f32")
 
 
-@pytest.mark.parametrize("variant", [3, 4, 5])
+@pytest.mark.parametrize("variant", [2, 4])
 def test_gemm_big_tile_variants(variant, dbg_lib):
     """both big-tile configurations (256x128 / 256x256) against the fp32 matmul of the bf16-rounded operands"""
     lib().mh_gemm_set_variant(variant)

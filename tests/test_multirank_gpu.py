@@ -82,3 +82,33 @@ def test_bench_gpus_2_self_launches_and_reports_two_ranks(workload):
     else:
         assert out["config"]["all_reduce_exposed_ms"] is not None and out["config"]["gradient_bytes_all_reduced_per_step"] > 0
     assert out["scaling"] == "weak" and out["config"]["global_batch"] == 2 * (32 if workload == "train" else 64)
+
+
+def test_bench_gpus_8_config4_self_launch_at_its_real_world_size():
+    """BASELINE configs[3] at the world size it names: `python bench.py --gpus 8 --workload c4` with no launcher around it - the parent
+    starts EIGHT ranks through torch.distributed.run (port choice, OMP_NUM_THREADS, one process per rank), rank 0's packed arena is
+    broadcast to seven receivers, eight reverse loops capture their graphs concurrently, 512 sequences are sampled as eight contiguous
+    shards and the tokens are gathered 8 ways; rank 0 prints ONE line with n_gpus = 8.  On a box with fewer than eight GPUs all ranks
+    share cuda:0 and the collectives run over gloo (MUSE_BENCH_SHARE_GPU): the launcher, the rank logic and every collective call
+    site of the real entry point run end to end, and the line says what ran (backend gloo, rccl_ranks 0, one distinct device)."""
+    import json
+    import torch
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    shared = torch.cuda.device_count() < 8
+    if shared:
+        env["MUSE_BENCH_SHARE_GPU"] = "1"
+    cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "8", "--workload", "c4", "--steps", "2", "--warmup", "1",
+           "--no-cpu-baseline", "--no-kernel-timing"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1200)
+    assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-3000:])
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["value"] > 0 and len(out["config"]["devices"]) == 8
+    assert out["scaling"] == "weak" and out["config"]["global_batch"] == 8 * 64
+    assert isinstance(out["config"]["arena_checksum_after_broadcast"], int)
+    if shared:
+        assert out["config"]["backend"] == "gloo" and out["config"]["rccl_ranks"] == 0 and out["config"]["distinct_devices"] == 1
+    else:
+        assert out["config"]["backend"] == "nccl" and out["config"]["rccl_ranks"] == 8 and out["config"]["distinct_devices"] == 8

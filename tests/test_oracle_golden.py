@@ -284,3 +284,14 @@ def test_overload_embedding_with_frozen_embedding_and_one_optimizer_step():
     np.testing.assert_array_equal(g["p_word"], g["emb"])
     e = torch.from_numpy(g["emb"])
     np.testing.assert_array_equal(g["ema_word"], e.clone().mul_(rate).add_(e, alpha=1 - rate).numpy())
+
+
+def test_get_logits_mode2_matches_reference():
+    """get_logits with logits_mode 2 (network.py:94-104): the oracle against the reference's own method (tools/make_golden.py logits2),
+    rows of the table itself included (distance exactly 0 after the clamp)."""
+    g = load_golden("logits_mode2.npz")
+    sd = fx.state_dict(str(g["tag"]))
+    got = odn.get_logits(sd, T(g["hidden"]), logits_mode=2)
+    assert torch.equal(got, T(g["scores"]))
+    with pytest.raises(NotImplementedError):
+        odn.get_logits(sd, T(g["hidden"]), logits_mode=3)

@@ -135,3 +135,29 @@ def test_panel_layers_equal_the_op_per_node_tape(p_drop):
     bad = [n for n in g0 if not torch.equal(g0[n], g1[n])]
     worst = {n: float((g0[n] - g1[n]).abs().max() / (g0[n].abs().max() + 1e-20)) for n in bad}
     assert not bad, worst
+
+
+def test_get_logits_mode2_against_the_reference():
+    """TransformerNetModel.get_logits with logits_mode 2 (network.py:94-104) against the reference's own output (tests/golden/logits_mode2.npz):
+    fp32 GEMM + mh_distance_scores.  Tolerance 2e-5 abs away from zero distance (fp32 dot products in another order); where the
+    position IS a table row the distance cancels to ~1e-7 before the square root, so those scores are held to sqrt-of-rounding size."""
+    import numpy as np
+    from conftest import load_golden
+    from oracle import fixtures as fx
+    g = load_golden("logits_mode2.npz")
+    tag = str(g["tag"])
+    c = fx.CONFIGS[tag]
+    m = TransformerNetModel(c["E"], c["E"], c["Tt"], c["V"], c["L"], dropout=0.0, logits_mode=2, bert_hidden=c["H"], bert_layers=c["nL"],
+                            bert_heads=c["nh"], bert_ffn=c["F"], compute_dtype="fp32")
+    m.load_state_dict(fx.state_dict(tag))
+    m.eval().requires_grad_(False).to(DEV)
+    ref = torch.from_numpy(np.asarray(g["scores"]))
+    got = m.get_logits(torch.from_numpy(np.asarray(g["hidden"])).to(DEV)).cpu()
+    assert got.shape == ref.shape
+    far = ref < -0.05
+    assert float((got - ref)[far].abs().max()) < 2e-5
+    assert float((got - ref)[~far].abs().max()) < 5e-3 and int((~far).sum()) >= 3
+    assert torch.equal(got.argmax(-1), ref.argmax(-1))
+    m.logits_mode = 3
+    with pytest.raises(NotImplementedError):
+        m.get_logits(torch.zeros(1, 2, c["E"], device=DEV))

@@ -18,9 +18,8 @@ from musediffusion_amd import _lib  # noqa: E402
 _lib.use_debug_library()   # the A/B switches live in libmusehip_dbg.so (include/musehip_dbg.h)
 
 setters = {"gemm_debug": lambda v: _lib.lib().mh_gemm_set_debug(v), "plain_stores": lambda v: _lib.lib().mh_gemm_set_plain_stores(v), "fuse_ln": lambda v: _lib.lib().mh_denoiser_set_fuse_ln(v),
-           "v3_fuse_ln": lambda v: (_lib.lib().mh_gemm_set_variant(3), _lib.lib().mh_denoiser_set_fuse_ln(v)),
            "v3_split": None, "v4_split": None, "skip": lambda v: _lib.lib().mh_denoiser_set_skip(v), "ln_rows4": lambda v: _lib.lib().mh_layernorm_set_rows4(v), "prescale_q": lambda v: _lib.lib().mh_denoiser_set_prescale_q(v),
-           "stream_attn": lambda v: _lib.lib().mh_attention_set_stream(v), "wide_roles": lambda v: _lib.lib().mh_gemm_set_wide_roles(v), "fuse_headtail": lambda v: _lib.lib().mh_denoiser_set_fuse_headtail(v), "gemm_variant": lambda v: _lib.lib().mh_gemm_set_variant(v), "bias_acc": lambda v: _lib.lib().mh_gemm_set_bias_acc(v), "spread": lambda v: _lib.lib().mh_gemm_set_spread(v), "buf_dma": lambda v: _lib.lib().mh_gemm_set_buf_dma(v)}
+           "stream_attn": lambda v: _lib.lib().mh_attention_set_stream(v), "wide_roles": lambda v: _lib.lib().mh_gemm_set_wide_roles(v), "fuse_headtail": lambda v: _lib.lib().mh_denoiser_set_fuse_headtail(v), "gemm_variant": lambda v: _lib.lib().mh_gemm_set_variant(v), "buf_dma": lambda v: _lib.lib().mh_gemm_set_buf_dma(v)}
 from musediffusion_amd.models.diffusion import GaussianDiffusion  # noqa: E402
 setters["decouple"] = lambda v: setattr(GaussianDiffusion, "decouple_branches", bool(v))
 setters["shared"] = lambda v: setattr(GaussianDiffusion, "shared_head_tail", bool(v))
@@ -32,10 +31,7 @@ setters["skew"] = lambda v: setattr(GaussianDiffusion, "branch_skew_us", None if
 res = {v: [] for v in values}
 for rnd in range(int(os.environ.get("AB_ROUNDS", "3"))):
     for v in values:
-        if knob == "v3_split":
-            _lib.lib().mh_gemm_set_variant(3)
-            sys.argv = BASE + ["--split", str(v)]
-        elif knob == "v4_split":      # value = 10 * variant + branches: 21 = default tiles, one branch; 41 = 256x256 tile, one branch; 42 ...
+        if knob == "v4_split":      # value = 10 * variant + branches: 21 = default tiles, one branch; 41 = 256x256 tile, one branch; 42 ...
             _lib.lib().mh_gemm_set_variant(v // 10)
             sys.argv = BASE + ["--split", str(v % 10)]
         else:

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""In-process A/B of a training tape option (or of the GEMM start stagger) on bench.py --workload train (boxes of the pool differ by several percent, so
+"""In-process A/B of a training tape option on bench.py --workload train (boxes of the pool differ by several percent, so
 alternatives are only comparable inside one process):    python tools/ab_train.py TN_DW | FUSED_FFN | FUSED_ATTENTION"""
 import contextlib
 import io
@@ -14,18 +14,17 @@ sys.argv = ["bench.py", "--workload", "train", "--steps", os.environ.get("AB_STE
 import bench  # noqa: E402
 from musediffusion_amd import training  # noqa: E402
 
-if KNOB in ("stagger", "dw_wide", "gemm_variant", "auto_wide", "buf_dma"):      # library knobs: python tools/ab_train.py stagger 0 -500 -1500 1500 | dw_wide 0 1
+if KNOB in ("dw_wide", "gemm_variant", "auto_wide", "buf_dma"):      # library knobs: python tools/ab_train.py dw_wide 0 1 | gemm_variant 2 4
     from musediffusion_amd import _lib
     _lib.use_debug_library()   # the A/B switches live in libmusehip_dbg.so (include/musehip_dbg.h)
     vals = VALS
     for rnd in range(3):
         for v in vals:
-            {"stagger": _lib.lib().mh_gemm_set_stagger, "dw_wide": _lib.lib().mh_gemm_dw_set_wide, "gemm_variant": _lib.lib().mh_gemm_set_variant, "auto_wide": _lib.lib().mh_gemm_set_auto_wide, "buf_dma": _lib.lib().mh_gemm_set_buf_dma}[KNOB](v)
+            {"dw_wide": _lib.lib().mh_gemm_dw_set_wide, "gemm_variant": _lib.lib().mh_gemm_set_variant, "auto_wide": _lib.lib().mh_gemm_set_auto_wide, "buf_dma": _lib.lib().mh_gemm_set_buf_dma}[KNOB](v)
             buf = io.StringIO()
             with contextlib.redirect_stdout(buf):
                 bench.main()
             print("%s=%d: %.2f ms" % (KNOB, v, json.loads(buf.getvalue().strip().splitlines()[-1])["ms_per_step"]), flush=True)
-    _lib.lib().mh_gemm_set_stagger(0)
     _lib.lib().mh_gemm_dw_set_wide(1)
     _lib.lib().mh_gemm_set_variant(2)
     _lib.lib().mh_gemm_set_buf_dma(1)

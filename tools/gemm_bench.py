@@ -22,9 +22,7 @@ ap.add_argument("--dbg", type=int, default=0)
 ap.add_argument("--ab", type=str, default="", help="comma list of debug-bit values to alternate between in one process, e.g. 0,32")
 ap.add_argument("--noact", action="store_true")
 ap.add_argument("--panel", type=int, default=0, help="bit0 A, bit1 W, bit2 out, bit3 residual in K32-panel layout (timing only)")
-ap.add_argument("--spread", action="store_true", help="A/B the interleaved LDS-DMA issue (mh_gemm_set_spread) against the burst")
 ap.add_argument("--bufdma", action="store_true", help="A/B the stage DMA as buffer loads (mh_gemm_set_buf_dma) against global_load_lds")
-ap.add_argument("--stagger", type=str, default="", help="comma list of partner-block start delays (10-ns ticks) to A/B")
 ap.add_argument("--pad", type=int, default=0, help="extra elements on every leading dimension")
 a = ap.parse_args()
 _lib.lib().mh_gemm_set_variant(a.variant)
@@ -80,15 +78,13 @@ o_h, o_f = torch.empty(M, H + P, device=dev, dtype=bf), torch.empty(M, F + P, de
 q, k, vt = (torch.empty(M * H + 256, device=dev, dtype=bf) for _ in range(3))
 flops = {"ao_ln": 2.0 * M * H * H, "ffn2_ln": 2.0 * M * H * F, "ln": 0.0, "ao": 2.0 * M * H * H, "ffn1": 2.0 * M * H * F, "ffn2": 2.0 * M * H * F, "qkv": 2.0 * M * H * 3 * H}
 if a.bufdma:
-    a.spread = True
-if a.spread:
     import statistics
     for name in a.shapes.split(","):
         fn = shapes[name]
         res = {0: [], 1: []}
         for rnd in range(7):
             for v in (0, 1):
-                (_lib.lib().mh_gemm_set_buf_dma if a.bufdma else _lib.lib().mh_gemm_set_spread)(v)
+                _lib.lib().mh_gemm_set_buf_dma(v)
                 fn(); torch.cuda.synchronize()
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
@@ -96,25 +92,7 @@ if a.spread:
                     fn()
                 e1.record(); torch.cuda.synchronize()
                 res[v].append(e0.elapsed_time(e1) / a.reps * 1e3)
-        print(("buf_dma %-8s: global_load_lds %.1f us  buffer_load lds %.1f us" if a.bufdma else "spread %-8s: burst %.1f us  interleaved %.1f us") % (name, statistics.median(res[0]), statistics.median(res[1])), flush=True)
-    sys.exit(0)
-if a.stagger:
-    import statistics
-    vals = [int(v) for v in a.stagger.split(",")]
-    for name in a.shapes.split(","):
-        fn = shapes[name]
-        res = {v: [] for v in vals}
-        for rnd in range(5):
-            for v in vals:
-                _lib.lib().mh_gemm_set_stagger(v)
-                fn(); torch.cuda.synchronize()
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                for _ in range(a.reps):
-                    fn()
-                e1.record(); torch.cuda.synchronize()
-                res[v].append(e0.elapsed_time(e1) / a.reps * 1e3)
-        print("stagger %-8s: " % name + "  ".join("%d: %.1f" % (v, statistics.median(r)) for v, r in res.items()), flush=True)
+        print("buf_dma %-8s: global_load_lds %.1f us  buffer_load lds %.1f us" % (name, statistics.median(res[0]), statistics.median(res[1])), flush=True)
     sys.exit(0)
 if a.ab:
     import statistics
@@ -146,7 +124,7 @@ for name in a.shapes.split(","):
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / a.reps
     if a.dbg & 16:
-        nw = 4 if a.variant == 3 else 8
+        nw = 4 if a.variant == 2 and a.panel else 8
         pr = o_f.view(torch.int32).flatten()[64:64 + 8 * nw * 1024].view(-1, 8).cpu().double()
         pr = pr[pr[:, 3] == 16]
         print("  prof over %d waves: wait %.0f  barrier %.0f  work %.0f shader clocks per K-step; loop %.0f clocks, in-kernel clock %.2f GHz" % (

@@ -395,9 +395,29 @@ def gen_reference_checkpoint():
     print("ref_ckpt:", sorted(os.listdir(d)))
 
 
+def gen_logits_mode2(tag="tiny"):
+    """get_logits with logits_mode 2 (network.py:94-104; the reference implements it and never constructs it): the reference's own method on
+    a model whose logits_mode attribute is set to 2, over seeded hidden rows incl. exact embedding rows (distance 0: the clamp / sqrt edge)."""
+    cfg = fx.CONFIGS[tag]
+    model, _ = build(cfg)
+    sd = fx.state_dict(tag)
+    model.load_state_dict(sd)
+    model.eval()
+    model.logits_mode = 2
+    g = torch.Generator().manual_seed(41)
+    hidden = torch.randn(2, 9, cfg["E"], generator=g)
+    hidden[0, :3] = sd["lm_head.weight"][[5, 0, cfg["V"] - 1]]           # rows of the table itself
+    with torch.no_grad():
+        out = model.get_logits(hidden)
+    np.savez_compressed(os.path.join(OUT, "logits_mode2.npz"), tag=np.array(tag), hidden=npy(hidden), scores=npy(out), sd_digest=np.array(sd_digest(sd)))
+    print("logits_mode2.npz", out.shape)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     only = sys.argv[1:]
+    if not only or "logits2" in only:
+        gen_logits_mode2()
     if not only or "ckpt" in only:
         gen_reference_checkpoint()
     if not only or "base" in only:
