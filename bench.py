@@ -806,8 +806,8 @@ def secondary_block(device, budget_note="short timed regions: <= 60 s in total")
         sec[name]["seconds_spent"] = round(time.perf_counter() - t0, 1)
         gc.collect()
         torch.cuda.empty_cache()
-    guarded("train", lambda: _time_train(device, steps=6, warmup=2))
-    guarded("train_lossaware", lambda: dict(_time_train(device, steps=6, warmup=2, sampler="lossaware"),
+    guarded("train", lambda: _time_train(device, steps=10, warmup=4))
+    guarded("train_lossaware", lambda: dict(_time_train(device, steps=10, warmup=4, sampler="lossaware"),
                                             note="the reference's default schedule sampler (config/train.py:38-39): its per-micro-batch update is a "
                                                  "device -> pinned-host copy applied when the next draw reads the state, no host sync between forward and backward"))
     guarded("c2_fp32", lambda: dict(_time_loop(WORKLOADS["c2"], "fp32", device, steps=20, warmup=3),

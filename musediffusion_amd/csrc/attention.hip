@@ -596,12 +596,15 @@ __global__ __launch_bounds__(64 * NW) void attn_stream_bf16_kernel(const bf16* _
   if constexpr (PRIO != 0) { if (wave >= NW / 2) __builtin_amdgcn_s_setprio(1); }
   const int nqb = (L + 32 * NW - 1) / (32 * NW), nst = (L + SK - 1) / SK;   // the last stage / tile may be partial (L % 16 == 0)
   const int nitems = nbh * nqb;
-  const int my_items = (nitems - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+  // XCD-aware item order (round 6): the query blocks of one (batch, head) (two at seq_len 1024, five at 2096) stream the same K / V^T
+  // and should meet in one L2; at seq_len 512 (one block per (batch, head)) the order changes nothing
+  const int bx = mh_xcd_remap((int)blockIdx.x, (int)gridDim.x);
+  const int my_items = (nitems - bx + (int)gridDim.x - 1) / (int)gridDim.x;
   const int total = my_items * nst;
 
   auto issue = [&](int g) {   // DMA stage g (of this block's flattened (item, stage) sequence) into buffer g & 1
     if constexpr ((ABL & 16) != 0) return;
-    const int item = blockIdx.x + (g / nst) * gridDim.x, st = g % nst;
+    const int item = bx + (g / nst) * gridDim.x, st = g % nst;
     const int bh = item / nqb;
     const bf16* Kb = K + (int64_t)(bh / nh) * qsB + (int64_t)(bh % nh) * qsH + (int64_t)st * SK * qld;   // rows qld elements apart
     const bf16* Vb = VT + (int64_t)bh * DH * L + (int64_t)st * SK;
@@ -643,7 +646,7 @@ __global__ __launch_bounds__(64 * NW) void attn_stream_bf16_kernel(const bf16* _
   unsigned long long prof_acc[4] = {0, 0, 0, 0};
   if (total > 0) issue(0);
   for (int g = 0; g < total; ++g) {
-    const int item = blockIdx.x + (g / nst) * gridDim.x, st = g % nst;
+    const int item = bx + (g / nst) * gridDim.x, st = g % nst;
     const int bh = item / nqb, qb = item % nqb;
     unsigned long long tp0 = 0, tp1 = 0, tp2 = 0;      // ABL bit 128: where a wave's time goes (clock stamps per stage, summed per wave)
     if constexpr ((ABL & 128) != 0) tp0 = __builtin_amdgcn_s_memtime();

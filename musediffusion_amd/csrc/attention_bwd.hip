@@ -124,12 +124,15 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const bf16* __restrict
   const int h = lane >> 5, lq = lane & 31;
   const int nqb = (L + 255) / 256, nst = (L + SKB - 1) / SKB;     // last query block / key stage may be partial (L % 16 == 0)
   const int nitems = nbh * nqb;
-  const int my_items = (nitems - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+  // items (batch-head, query block) in XCD-aware order (round 6): the query blocks of one (batch, head) stream the same K / V rows; dealt
+  // out by blockIdx they sat on different XCDs and every L2 fetched those rows again (FETCH_SIZE 394 MB per launch, 134 MB of K / V / dO / O)
+  const int bx = mh_xcd_remap((int)blockIdx.x, (int)gridDim.x);
+  const int my_items = (nitems - bx + (int)gridDim.x - 1) / (int)gridDim.x;
   const int total = my_items * nst;
   const TrOff<DH> tro = tr_offsets<DH>(lane);
 
   auto issue = [&](int g) {
-    const int item = blockIdx.x + (g / nst) * gridDim.x, st = g % nst;
+    const int item = bx + (g / nst) * gridDim.x, st = g % nst;
     const int bh = item / nqb;
     const int64_t roff = lq_.at(bh, nh, (int64_t)st * SKB);
     char* base = smem_dyn + (g & 1) * (2 * ST);
@@ -155,7 +158,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const bf16* __restrict
   bool active = false;
   if (total > 0) issue(0);
   for (int g = 0; g < total; ++g) {
-    const int item = blockIdx.x + (g / nst) * gridDim.x, st = g % nst;
+    const int item = bx + (g / nst) * gridDim.x, st = g % nst;
     const int bh = item / nqb, qb = item % nqb;
 #ifdef MH_BWD_PROF
     const unsigned long long tp0 = __builtin_amdgcn_s_memtime();
@@ -313,14 +316,15 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const bf16* __restric
   const int h = lane >> 5, lq = lane & 31;
   const int nkb = (L + 255) / 256, nst = (L + SKB - 1) / SKB;
   const int nitems = nbh * nkb;
-  const int my_items = (nitems - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int bx = mh_xcd_remap((int)blockIdx.x, (int)gridDim.x);     // (XCD-aware item order: see attn_bwd_dq_kernel)
+  const int my_items = (nitems - bx + (int)gridDim.x - 1) / (int)gridDim.x;
   const int total = my_items * nst;
   // DROP: the S accumulators start at log2(1 / (1 - p_drop)) / (scale log2 e), so that exp2(s scale log2 e - lse2) is P / (1 - p_drop)
   const float s_init = DROP ? __builtin_amdgcn_logf(rscale) / scale_log2e : 0.f;
   const TrOff<DH> tro = tr_offsets<DH>(lane);
 
   auto issue = [&](int g) {
-    const int item = blockIdx.x + (g / nst) * gridDim.x, st = g % nst;
+    const int item = bx + (g / nst) * gridDim.x, st = g % nst;
     const int bh = item / nkb;
     const int64_t r0 = (int64_t)bh * L + (int64_t)st * SKB;
     char* base = smem_dyn + (g & 1) * BUF;
@@ -355,7 +359,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const bf16* __restric
   bool active = false;
   if (total > 0) issue(0);
   for (int g = 0; g < total; ++g) {
-    const int item = blockIdx.x + (g / nst) * gridDim.x, st = g % nst;
+    const int item = bx + (g / nst) * gridDim.x, st = g % nst;
     const int bh = item / nkb, kb = item % nkb;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();

@@ -309,4 +309,11 @@ __device__ __forceinline__ uint32_t drop_flag(const uint32_t* bits, int64_t bh, 
   return (bits[drop_word_index(bh, nb, q >> 5, k >> 6, (q & 31) + 32 * h)] >> (r + 16 * ((k >> 5) & 1))) & 1u;
 }
 
+// XCD-aware block remap (8 XCDs, workgroups dealt round-robin): block b -> a virtual index such that each XCD owns a contiguous run of
+// indices, so neighbours in index space (tiles of one row panel, query blocks of one (batch, head)) share that XCD's L2.  Bijective for
+// any grid size.
+__device__ __forceinline__ int mh_xcd_remap(int bid, int nblk) {
+  const int q = nblk >> 3, r = nblk & 7, x = bid & 7;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+}
 static inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

@@ -1824,8 +1824,9 @@ struct TnArgs {
   const bf16* B; int64_t ldb;   // [K, ldb], columns = n
   float* out;                   // [splits][slice]: M x N products, then (CS) the M column sums of A
   int M, N;
-  int64_t Ksteps;               // K steps (32 tokens each) in all; slice s of gridDim.y runs steps [s Ksteps / gridDim.y, (s + 1) Ksteps / gridDim.y)
+  int64_t Ksteps;               // K steps (32 tokens each) in all; slice s of `splits` runs steps [s Ksteps / splits, (s + 1) Ksteps / splits)
   int64_t slice;                // floats per split slice: M N (+ M)
+  int splits, tiles;            // grid = tiles x splits blocks, one-dimensional (see the block mapping in the kernel)
 };
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
@@ -1855,9 +1856,15 @@ __global__ __launch_bounds__(128 * WN, WN == 2 ? 2 : 1) void gemm_tn_kernel(cons
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
   const int tiles_n = (g.N + BNt - 1) / BNt;
-  const int m0 = (blockIdx.x / tiles_n) * BMt, n0 = (blockIdx.x % tiles_n) * BNt;
+  // XCD-aware block mapping (round 6): the blocks of ONE token slice share its operand panels (every m-tile's A panels are read by all
+  // n-tiles and vice versa), and workgroups go to the 8 XCDs round-robin - dealt out as (tile, slice) = (blockIdx.x, blockIdx.y) the 16 tiles
+  // of a slice landed on all 8 L2s and every panel was fetched from HBM up to 8 times (rocprofv3 FETCH_SIZE: 313 MB per launch against
+  // 167 MB of operands).  xcd_remap gives each XCD a contiguous run of (slice, tile) pairs, i.e. whole slices.
+  const int vb = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+  const int slice_i = vb / g.tiles, tile_i = vb % g.tiles;
+  const int m0 = (tile_i / tiles_n) * BMt, n0 = (tile_i % tiles_n) * BNt;
   // (uneven slices: the split count is chosen to fill the chip - 21 slices of a 12-tile output on 256 CUs - not to divide the K steps)
-  const int64_t ks0 = (int64_t)blockIdx.y * g.Ksteps / gridDim.y, ks1 = (int64_t)(blockIdx.y + 1) * g.Ksteps / gridDim.y;
+  const int64_t ks0 = (int64_t)slice_i * g.Ksteps / g.splits, ks1 = (int64_t)(slice_i + 1) * g.Ksteps / g.splits;
   const int64_t k_begin = ks0 * 32;
   const int nk = (int)(ks1 - ks0);
   const int fr = lane & 15, fg = lane >> 4;
@@ -1963,7 +1970,7 @@ __global__ __launch_bounds__(128 * WN, WN == 2 ? 2 : 1) void gemm_tn_kernel(cons
   f32x4 accs[NCS];
 #pragma unroll
   for (int c = 0; c < NCS; ++c) accs[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const int worker = (int)(blockIdx.x % tiles_n) * WN + wn;  // (wave-uniform)
+  const int worker = (tile_i % tiles_n) * WN + wn;  // (wave-uniform)
   bf16x8 ones;
 #pragma unroll
   for (int e = 0; e < 8; ++e) ones[e] = (bf16)1.0f;
@@ -2009,7 +2016,7 @@ __global__ __launch_bounds__(128 * WN, WN == 2 ? 2 : 1) void gemm_tn_kernel(cons
     __builtin_amdgcn_s_waitcnt(0xC07F);
   }
   // D' tile (rows n, cols m): lane holds m = fr, n = 4 fg + r -> 4 consecutive n of one m: one 16-byte store
-  float* outp = g.out + (int64_t)blockIdx.y * g.slice;
+  float* outp = g.out + (int64_t)slice_i * g.slice;
   if constexpr (CS > 0) {
     if (worker < CS && fg == 0) {                           // every row of the ones-product holds the sums: take row 0 (lanes 0..15)
 #pragma unroll
@@ -2093,10 +2100,12 @@ extern "C" int mh_gemm_dw_bias_ex(const void* A, int64_t lda, const void* B, int
   MH_CHECK_ARG(!panel || (M % 32 == 0 && N % 32 == 0 && lda >= K && ldb >= K), "gemm_dw: panel operands need M, N multiples of 32 and ld >= K rows");
   MH_CHECK_ARG(M > 0 && N > 0 && M % 8 == 0 && N % 4 == 0 && N % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0, "gemm_dw: M, N, lda, ldb must be multiples of 8");
   MH_CHECK_ARG(splits >= 1 && splits <= 65535 && K > 0 && K % 32 == 0 && splits <= K / 32, "gemm_dw: K=%lld must be a multiple of 32 with at least one K step per split", (long long)K);
-  TnArgs g{(const bf16*)A, lda, (const bf16*)B, ldb, out_partials, M, N, K / 32, (int64_t)M * N + (with_colsum ? M : 0)};
   const bool wide = dw_wide(N);
   const int tiles_n = ceil_div(N, wide ? 256 : 128);
-  const dim3 grid((unsigned)(ceil_div(M, 256) * tiles_n), (unsigned)splits);
+  const int tiles = ceil_div(M, 256) * tiles_n;
+  MH_CHECK_ARG((int64_t)tiles * splits < (1ll << 31), "gemm_dw: grid too large");
+  TnArgs g{(const bf16*)A, lda, (const bf16*)B, ldb, out_partials, M, N, K / 32, (int64_t)M * N + (with_colsum ? M : 0), splits, tiles};
+  const dim3 grid((unsigned)(tiles * splits));
   mh_prof_note("gemm_dw M=%d N=%d K=%lld splits=%d colsum=%d tile=256x%d", M, N, (long long)K, splits, with_colsum != 0, wide ? 256 : 128);
   hipStream_t st = (hipStream_t)stream;
   if (panel && wide) {

@@ -52,6 +52,8 @@ for tot, k, n, fk, wk in rows[:14]:
     print("%-78s %8s %6d %12.1f %12.1f %14.2f" % (k[0][:78], k[1], n, fk, wk, (2 * fk + wk) * 1024 / 1e6))
 # (the last template argument carries build bits - 16384 = stage DMA as buffer loads - that do not change what the kernel is)
 dom = [r for r in rows if re.search(r"gemm_big_kernel<BigCfg<[^>]*>, 3, 0, (0|16384)>", r[1][0])]
+if len(sys.argv) > 5 and sys.argv[5] == "pool":    # the training step: bench.py's dominant symbol is the pooled 256x128 EPI 0 launch, not the LayerNorm tile
+    dom = []
 if not dom:
     # no full-row LayerNorm tile at this width (d_model 768): bench.py's dominant symbol pools every EPI 0 / no-activation launch of the
     # 256x128 tile, whatever its deferred-LayerNorm variant (last template argument) and shape - pool them the same way

@@ -9,12 +9,18 @@ WL=${2:-c2}
 OUT=gpurun_out/${TAG}_${WL}
 mkdir -p $OUT
 B="python3 bench.py --workload $WL --no-cpu-baseline --no-kernel-timing --no-secondary"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o p -- $B --steps 30 --warmup 3 > $OUT/trace.log 2>&1
+STEPS=30; [ "$WL" = "train" ] && STEPS=10
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o p -- $B --steps $STEPS --warmup 3 > $OUT/trace.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_f -o p -- $B --steps 3 --warmup 1 --no-graph > $OUT/pmc_f.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_w -o p -- $B --steps 3 --warmup 1 --no-graph > $OUT/pmc_w.log 2>&1
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_sq -o p -- $B --steps 3 --warmup 1 --no-graph > $OUT/pmc_sq.log 2>&1
-python3 tools/kstats.py $(ls $OUT/trace/*kernel_trace.csv | head -1) 30 > $OUT/kernel_trace_summary.txt 2>&1
+python3 tools/kstats.py $(ls $OUT/trace/*kernel_trace.csv | head -1) $STEPS > $OUT/kernel_trace_summary.txt 2>&1
 cp $(ls $OUT/trace/*kernel_stats.csv | head -1) $OUT/kernel_stats.csv 2>/dev/null
-python3 tools/pmc_traffic.py $OUT/pmc_f $OUT/pmc_w $WL/bf16/b2 $OUT > $OUT/pmc_traffic_summary.txt 2>&1
+if [ "$WL" = "train" ]; then
+  python3 tools/pmc_traffic.py $OUT/pmc_f $OUT/pmc_w train/bf16/b1 $OUT pool > $OUT/pmc_traffic_summary.txt 2>&1
+else
+  python3 tools/pmc_traffic.py $OUT/pmc_f $OUT/pmc_w $WL/bf16/b2 $OUT > $OUT/pmc_traffic_summary.txt 2>&1
+fi
 python3 tools/pmc_sq.py $OUT/pmc_sq > $OUT/pmc_mfma_summary.txt 2>&1
+rm -rf $OUT/trace $OUT/pmc_f $OUT/pmc_w $OUT/pmc_sq   # (raw traces: hundreds of MB; the summaries above are what is kept)
 ls $OUT
