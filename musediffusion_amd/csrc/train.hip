@@ -266,15 +266,30 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ x, co
   for (int i = 0; i < LNCH; ++i)
 #pragma unroll
     for (int e = 0; e < 8; ++e) { ag[i][e] = 0.f; ab[i][e] = 0.f; }
-  for (int64_t row = (int64_t)blockIdx.x * 4 + w; row < rows; row += (int64_t)gridDim.x * 4) {
+  // the NEXT row's x / dy are fetched while this row's three dependent wave reductions run (round 6: a wave walks ~8 rows one after the
+  // other, and with the loads at the head of each row's body their latency stood in front of every row)
+  float xn[LNCH][8], gn[LNCH][8];
+  auto fetch = [&](int64_t r) {
+#pragma unroll
+    for (int i = 0; i < LNCH; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nch) { load8(x + r * H + c * 8, xn[i]); load8(dy + r * H + c * 8, gn[i]); }
+    }
+  };
+  const int64_t row_step = (int64_t)gridDim.x * 4;
+  if ((int64_t)blockIdx.x * 4 + w < rows) fetch((int64_t)blockIdx.x * 4 + w);
+  for (int64_t row = (int64_t)blockIdx.x * 4 + w; row < rows; row += row_step) {
     float xv[LNCH][8], gv[LNCH][8];
     float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < LNCH; ++i)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { xv[i][e] = xn[i][e]; gv[i][e] = gn[i][e]; }
+    if (row + row_step < rows) fetch(row + row_step);
 #pragma unroll
     for (int i = 0; i < LNCH; ++i) {
       const int c = lane + 64 * i;
       if (c < nch) {
-        load8(x + row * H + c * 8, xv[i]);
-        load8(dy + row * H + c * 8, gv[i]);
 #pragma unroll
         for (int e = 0; e < 8; ++e) sum += xv[i][e];
       }
@@ -467,35 +482,46 @@ __global__ void add_inplace_kernel(T* __restrict__ dst, const T* __restrict__ sr
 // (v, chunk) scans its chunk of the ids 64 at a time (ballot) and adds the matching rows in index order into
 // partial[chunk][v][:]; a second kernel folds the chunks in order.  Frequent tokens (padding is most of a batch) are
 // spread over the chunks, and the summation order does not change from run to run.
+// RV vocabulary rows per block (round 6): a block scans its token chunk ONCE for RV rows - with one row per block (rounds 1 - 5) the 729
+// blocks of a chunk each re-scanned the same ids and the scan, not the gather, was the kernel's time (120 us for a 16 MB input)
+constexpr int SCATTER_RV = 8;
 __global__ __launch_bounds__(256) void scatter_rows_partial_kernel(const float* __restrict__ src, const int32_t* __restrict__ ids,
                                                                    float* __restrict__ partial, int64_t n, int E, int V, int64_t chunk) {
-  extern __shared__ float red[];   // [4][256]
-  const int v = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  extern __shared__ float red[];   // [4 waves][RV][256]
+  const int v0 = blockIdx.x * SCATTER_RV, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t tb = (int64_t)blockIdx.y * chunk, te = tb + chunk < n ? tb + chunk : n;
-  float* dst = partial + ((int64_t)blockIdx.y * V + v) * E;
   for (int e0 = 0; e0 < E; e0 += 256) {        // 4 columns per lane per pass
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    float acc[SCATTER_RV][4];
+#pragma unroll
+    for (int k = 0; k < SCATTER_RV; ++k)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc[k][c] = 0.f;
     for (int64_t t0 = tb + (int64_t)wave * 64; t0 < te; t0 += 256) {
       int id = -1;
       if (t0 + lane < te) { id = ids[t0 + lane]; id = id < 0 ? 0 : (id >= V ? V - 1 : id); }
-      unsigned long long m = __builtin_amdgcn_ballot_w64(id == v);
-      while (m) {
-        const int j = __builtin_ctzll(m);
-        m &= m - 1;
-        const float* row = src + (t0 + j) * E + e0;
 #pragma unroll
-        for (int c = 0; c < 4; ++c)
-          if (e0 + lane + 64 * c < E) acc[c] += row[lane + 64 * c];
+      for (int k = 0; k < SCATTER_RV; ++k) {
+        unsigned long long m = __builtin_amdgcn_ballot_w64(id == v0 + k);
+        while (m) {                              // (token order inside the group: the sum's order is fixed)
+          const int j = __builtin_ctzll(m);
+          m &= m - 1;
+          const float* row = src + (t0 + j) * E + e0;
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+            if (e0 + lane + 64 * c < E) acc[k][c] += row[lane + 64 * c];
+        }
       }
     }
 #pragma unroll
-    for (int c = 0; c < 4; ++c) red[wave * 256 + lane + 64 * c] = acc[c];
-    __syncthreads();
-    if (wave == 0) {
+    for (int k = 0; k < SCATTER_RV; ++k)
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const int o = lane + 64 * c;
-        if (e0 + o < E) dst[e0 + o] = (red[o] + red[256 + o]) + (red[512 + o] + red[768 + o]);
+      for (int c = 0; c < 4; ++c) red[(wave * SCATTER_RV + k) * 256 + lane + 64 * c] = acc[k][c];
+    __syncthreads();
+    for (int o = threadIdx.x; o < SCATTER_RV * 256; o += 256) {
+      const int k = o >> 8, col = o & 255;
+      if (v0 + k < V && e0 + col < E) {
+        float* dst = partial + ((int64_t)blockIdx.y * V + v0 + k) * E;
+        dst[e0 + col] = (red[o] + red[SCATTER_RV * 256 + o]) + (red[2 * SCATTER_RV * 256 + o] + red[3 * SCATTER_RV * 256 + o]);
       }
     }
     __syncthreads();
@@ -901,7 +927,8 @@ extern "C" int mh_scatter_add_rows(const float* src, const int32_t* ids, float* 
   const int nchunks = n >= 32 * 256 ? 32 : (int)((n + 255) / 256);
   const int64_t chunk = ((n + nchunks - 1) / nchunks + 63) / 64 * 64;
   hipStream_t s = (hipStream_t)stream;
-  MH_LAUNCH(scatter_rows_partial_kernel, dim3(V, nchunks), dim3(256), 4 * 256 * sizeof(float), s, src, ids, (float*)workspace, n, E, V, chunk);
+  MH_LAUNCH(scatter_rows_partial_kernel, dim3((V + SCATTER_RV - 1) / SCATTER_RV, nchunks), dim3(256), 4 * SCATTER_RV * 256 * sizeof(float), s, src, ids,
+            (float*)workspace, n, E, V, chunk);
   MH_CHECK_LAUNCH();
   MH_LAUNCH(scatter_rows_final_kernel, dim3(tgrid((int64_t)V * E)), dim3(TB), 0, s, (const float*)workspace, table, nchunks, (int64_t)V * E);
   MH_CHECK_LAUNCH();

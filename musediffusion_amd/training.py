@@ -988,7 +988,6 @@ class _EncoderLayer(Function):
         scratch = _layer_scratch(dev, nbytes)
         t.dy, t.dx, t.scratch, t.scratch_bytes, t.grads = dy.data_ptr(), dx.data_ptr(), scratch.data_ptr(), nbytes, grads.data_ptr()
         check(lib().mh_train_layer_bwd(C.byref(t), current_stream()), "mh_train_layer_bwd")
-        ctx.keep = None
         sizes = [3 * H * H, 3 * H, H * H, H, F * H, F, H * F, H, H, H, H, H]
         gWqkv, gbqkv, gWao, gbao, gW1, gb1, gW2, gb2, gg1, gbe1, gg2, gbe2 = grads.split(sizes)
         return (dx, None, None, None, None, gWqkv.view(3 * H, H), gbqkv, gWao.view(H, H), gbao, gg1, gbe1, gW1.view(F, H), gb1,
