@@ -137,7 +137,7 @@ class LossAwareSampler(ScheduleSampler):
         # that fit); every rank then finds that count above the padded size when it unpacks (_flush) and raises there.
         fit = min(count, cap)
         block = torch.zeros(1 + 2 * cap, dtype=torch.float64, device=dev)
-        block[0] = count
+        block[0:1].fill_(float(count))      # (a fill kernel: `block[0] = count` would stage the scalar through a pageable host tensor and drain the stream)
         block[1:1 + fit] = ts64[:fit]
         block[1 + cap:1 + cap + fit] = ls64[:fit]
         if world > 1:

@@ -18,7 +18,8 @@ dev = torch.device("cuda", 0)
 c = bench.WORKLOADS["train"]
 model, diff = bench.build(c, "bf16", dev, seed=0)
 model.train().requires_grad_(True)
-loop = TrainStep(model, diff, microbatch=c["B"], lr=1e-4, weight_decay=0.0, ema_rate=(0.5, 0.9, 0.99), learning_steps=320000)
+loop = TrainStep(model, diff, microbatch=c["B"], lr=1e-4, weight_decay=0.0, ema_rate=(0.5, 0.9, 0.99), learning_steps=320000,
+                 schedule_sampler=bench.make_sampler(os.environ.get("SAMPLER", "uniform"), diff))
 cond = synthetic.training_batch(c["B"], c["L"], seed=1)
 for _ in range(5):
     loop.run_step(cond)
