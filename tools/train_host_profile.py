@@ -42,4 +42,4 @@ for _ in range(5):
 pr.disable()
 torch.cuda.synchronize()
 st = pstats.Stats(pr)
-st.sort_stats("tottime").print_stats(35)
+st.sort_stats(os.environ.get("SORT", "tottime")).print_stats(45)
