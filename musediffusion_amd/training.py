@@ -870,15 +870,29 @@ class _WeightPrep:
         self.key = _WeightPrep.key_of(model)
 
     @staticmethod
+    def _params(model):
+        """The encoder's Parameter objects, listed once per model (walking `layer.parameters()` costs 1 ms per call at 12 layers, and the
+        step asks three times): every call checks that each listed Parameter is still the object its module holds (a replaced Parameter
+        rebuilds the list); storage moves (model.to(), a fresh state) are caught by the pointer key below."""
+        cached = getattr(model, "_encoder_params", None)
+        layers = model.input_transformers.layer
+        if cached is None or cached[0] is not layers or any(m._parameters.get(k) is not q for (m, k, q) in cached[2]):
+            triples = [(m, k, q) for m in layers.modules() for k, q in m._parameters.items() if q is not None]
+            cached = (layers, [q for _, _, q in triples], triples)
+            object.__setattr__(model, "_encoder_params", cached)
+        return cached[1]
+
+    @staticmethod
     def key_of(model):
-        return tuple(p.data_ptr() for layer in model.input_transformers.layer for p in layer.parameters())
+        return tuple(p.data_ptr() for p in _WeightPrep._params(model))
 
     @staticmethod
     def supported(model, dt):
-        layers = list(model.input_transformers.layer)
+        layers = model.input_transformers.layer
         H = model.hidden_size
-        return (dt == ops.MH_BF16 and len(layers) > 0 and H % 64 == 0 and layers[0].intermediate.dense.weight.shape[0] % 64 == 0
-                and all(p.dtype == torch.float32 and p.is_contiguous() for layer in layers for p in layer.parameters()))
+        if not (dt == ops.MH_BF16 and len(layers) > 0 and H % 64 == 0 and layers[0].intermediate.dense.weight.shape[0] % 64 == 0):
+            return False
+        return all(p.dtype == torch.float32 and p.is_contiguous() for p in _WeightPrep._params(model))
 
     @staticmethod
     def refresh(model, dt, dev, panel=False):
