@@ -767,7 +767,8 @@ int mh_repack_panel(const void* in, int64_t ld_in, void* out, int64_t ld_out, in
  * mh_dropout_bits), else written by the forward.
  * Backward: dy rows [N][H] in, dx rows out; `grads` fp32: dWqkv [3H][H] | dbqkv [3H] | dWao [H][H] | dbao [H] | dW1 [F][H] | db1 [F] |
  * dW2 [H][F] | db2 [H] | dln1_g | dln1_b | dln2_g | dln2_b (mh_train_layer_grad_floats in all), summation order fixed.  With side_stream the
- * folds of the split-K and LayerNorm partials run there, under the GEMMs that follow, and are joined into `stream` before the call returns.
+ * folds of the split-K and LayerNorm partials run there, under the GEMMs that follow, and are joined into `stream` before the call returns
+ * (one pair of events per device hands work over: the layers of one device are driven from one host thread at a time).
  * H = 512 (the full-row LayerNorm tile), F % 256 == 0, L % 64 == 0, L >= 512, head dim 32 or 64: mh_train_layer_supported. */
 typedef struct mh_train_layer {
   int B, L, H, F, nh; float ln_eps;

@@ -23,6 +23,8 @@
 //            attention backward -> dqkv panels [3H / 32][N][32]
 //            dWqkv | dbqkv = dqkv^T x
 //            dx = dqkv Wqkv + r1                                   rows
+#include <mutex>
+
 #include "common.h"
 
 int mh_ln_bwd_rows(const void* x, const void* dy, const float* gamma, void* dx, void* dx_dropped, int64_t ldm, int m_panel, int always,
@@ -77,7 +79,9 @@ struct Side {
 hipEvent_t* side_events() {
   static hipEvent_t ev[MH_MAX_DEVICES][2];
   static bool made[MH_MAX_DEVICES] = {};
+  static std::mutex mu;      // (creation only; the events themselves belong to whoever drives this device's layers - see musehip.h)
   const int dev = mh_current_device();
+  std::lock_guard<std::mutex> lock(mu);
   if (!made[dev]) {
     for (int i = 0; i < 2; ++i) if (hipEventCreateWithFlags(&ev[dev][i], hipEventDisableTiming) != hipSuccess) return nullptr;
     made[dev] = true;
