@@ -502,13 +502,28 @@ __global__ __launch_bounds__(256) void scatter_rows_partial_kernel(const float* 
 #pragma unroll
       for (int k = 0; k < SCATTER_RV; ++k) {
         unsigned long long m = __builtin_amdgcn_ballot_w64(id == v0 + k);
-        while (m) {                              // (token order inside the group: the sum's order is fixed)
-          const int j = __builtin_ctzll(m);
-          m &= m - 1;
-          const float* row = src + (t0 + j) * E + e0;
+        // the matches of a group four at a time: their row loads are independent and go out together, the adds keep the token order (a
+        // frequent token - the padding id is a third of a ComMU batch - made its block walk hundreds of dependent loads one by one)
+        while (m) {
+          int j[4];
+          float rv[4][4];
 #pragma unroll
-          for (int c = 0; c < 4; ++c)
-            if (e0 + lane + 64 * c < E) acc[k][c] += row[lane + 64 * c];
+          for (int u = 0; u < 4; ++u) {
+            j[u] = m ? __builtin_ctzll(m) : -1;
+            m &= m - 1;                          // (0 & anything = 0: stays empty)
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const float* row = src + (t0 + (j[u] < 0 ? 0 : j[u])) * E + e0;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) rv[u][c] = (j[u] >= 0 && e0 + lane + 64 * c < E) ? row[lane + 64 * c] : 0.f;
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            if (j[u] >= 0) {
+#pragma unroll
+              for (int c = 0; c < 4; ++c) acc[k][c] += rv[u][c];
+            }
         }
       }
     }

@@ -10,6 +10,9 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from musediffusion_amd import _lib  # noqa: E402
 
+if os.environ.get("VARIANT"):      # VARIANT=4: every launch on the 256x256 tile (debug library's switch)
+    _lib.use_debug_library()
+    _lib.lib().mh_gemm_set_variant(int(os.environ["VARIANT"]))
 L = _lib.lib()
 dev, bf = "cuda", torch.bfloat16
 M = int(os.environ.get("M", 32768))
