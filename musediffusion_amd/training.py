@@ -196,9 +196,12 @@ def _transpose(x, rows, cols, dt, ld_out=None, batch=1, stride_in=0, stride_out=
 
 
 def _col_sum(x, rows, cols, dt, batch=1, stride_in=0):
-    part = torch.empty(batch * NPART * cols, device=x.device, dtype=torch.float32)
+    # partial rows: one per 4 input rows at most (a sum over the BATCH has 32 rows: 256 partial rows made the launch 262 144 blocks of which
+    # 8 192 had work, and its scratch 537 MB)
+    npart = max(1, min(NPART, (rows + 3) // 4))
+    part = torch.empty(batch * npart * cols, device=x.device, dtype=torch.float32)
     out = torch.empty(batch, cols, device=x.device, dtype=torch.float32)
-    check(lib().mh_col_sum(ptr(x), x.shape[-1], rows, cols, batch, stride_in, ptr(part), NPART, ptr(out), 0, dt,
+    check(lib().mh_col_sum(ptr(x), x.shape[-1], rows, cols, batch, stride_in, ptr(part), npart, ptr(out), 0, dt,
                            current_stream()), "mh_col_sum")
     return out if batch > 1 else out[0]
 
