@@ -1275,6 +1275,8 @@ int stream_fwd_impl(const void* q, const void* k, const void* vt_perm, void* ctx
   const bool full = L % 256 == 0 && g_attn_stream != 4;   // (mode 4 = A/B: the key-bound build on every length)
   if (dropping && bits_in && small) {   // (mode 2: the bit reader on the 8-wave geometry too)
     rc = dh == 64 ? go(&attn_stream_bf16_kernel<64, 8, 128, 2>, 4 * 128 * 64 * 2) : go(&attn_stream_bf16_kernel<32, 8, 256, 2>, 4 * 256 * 32 * 2);
+  } else if (dropping && bits_in && full && dh == 64) {   // (round 6: the reader without the per-score bound compares where no tile is partial - config 5's seq_len 1024)
+    rc = go(&attn_stream_bf16_kernel<64, 16, 256, 2, true>, 4 * 256 * 64 * 2);
   } else if (dropping && bits_in) {
     rc = dh == 64 ? go(&attn_stream_bf16_kernel<64, 16, 256, 2>, 4 * 256 * 64 * 2) : go(&attn_stream_bf16_kernel<32, 16, 256, 2>, 4 * 256 * 32 * 2);
   } else if (dropping && !small) rc = dh == 64 ? go(&attn_stream_bf16_kernel<64, 16, 256, 1>, 4 * 256 * 64 * 2) : go(&attn_stream_bf16_kernel<32, 16, 256, 1>, 4 * 256 * 32 * 2);
