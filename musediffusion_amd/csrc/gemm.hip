@@ -1097,15 +1097,48 @@ __global__ __launch_bounds__(C::THREADS, C::STAGE * C::NST <= 80 * 1024 ? 2 : 1)
             else { const f32x4 b4 = *reinterpret_cast<const f32x4*>(g.bias + col); bv[qh][0] = b4[0]; bv[qh][1] = b4[1]; bv[qh][2] = b4[2]; bv[qh][3] = b4[3]; }
           }
         }
+        // DR (round 6): the tile's residual rows take ONE round trip through the idle ring (LDS-DMA, lane-linear pieces: a lane's 16 bytes of
+        // piece (qh, i) are the 8 columns it holds of row 16 i + fr - the EPI 3 epilogue's scheme) instead of TI x 4 registers per column
+        // group: with them the raw-residual + output-statistics kernel (the attention-output and FFN-output dense of every d_model 768 layer)
+        // needed 287 registers, spilled 31, and ran 40.2 us where either feature alone runs 29.3 - 30.6 (tools/debug/defer_epilogue_bench.py)
+        constexpr bool RSTAGE = DR && !C::PP && C::NW * (TI * (TJ / 2) * 1024) <= C::NST * C::STAGE;
+        const char* rstage = smem + wave * (TI * (TJ / 2) * 1024);
+        const char* gbstage = smem + C::NW * (TI * (TJ / 2) * 1024) + wave * 1024;
+        if constexpr (RSTAGE) {
+          __builtin_amdgcn_s_waitcnt(0xC07F);      // (the plain main loop does not end on a barrier: every wave's fragment reads first)
+          __builtin_amdgcn_s_barrier();
+#pragma unroll
+          for (int qh = 0; qh < TJ / 2; ++qh) {
+            const int col = wcol0 + 32 * qh + 8 * fg;
+            const int cc = (FULL || col + 8 <= g.N) ? col : 0;
+            const int64_t r_col = g.r_panel ? (int64_t)(cc >> 5) * g.ldr * 32 + (cc & 31) : cc;
+#pragma unroll
+            for (int i = 0; i < TI; ++i) {
+              int64_t row = wrow0 + 16 * i + fr; if (!FULL && row >= g.M) row = g.M - 1;
+              __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(res + r_col + row * r_rs),
+                                               (__attribute__((address_space(3))) void*)const_cast<char*>(rstage + (qh * TI + i) * 1024), 16, 0, 0);
+            }
+          }
+          // ... and the wave's 64 residual gains | shifts ride along as one more piece (lanes 0 - 15 gamma, 16 - 31 beta, the rest repeat):
+          // read back per row tile, they are not live across the column group's rows (16 registers fewer)
+          static_assert(!RSTAGE || C::NW * (TI * (TJ / 2) * 1024) + C::NW * 1024 <= C::NST * C::STAGE, "no room for the gain / shift pieces");
+          {
+            const int l32 = lane & 31, gc = wcol0 + 4 * (l32 & 15);
+            const float* gsrc = (l32 < 16 ? g.d.r_gamma : g.d.r_beta) + ((FULL || gc + 4 <= g.N) ? gc : 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                             (__attribute__((address_space(3))) void*)const_cast<char*>(gbstage), 16, 0, 0);
+          }
+          wait_vmcnt<0>();     // (the bias loads above included: nothing the epilogue loads is pending behind its first store)
+        }
 #pragma unroll
         for (int qh = 0; qh < TJ / 2; ++qh) {
           const int col = wcol0 + 32 * qh + 8 * fg;
           if (FULL || col < g.N) {   // N % 8 == 0, or an fp32 output with N % 8 == 4 (big_tile_ok): at least the first 4 columns are valid
             float c1v[8], rgv[8], rbv[8];   // deferred-LayerNorm column vectors of this group (loaded with its residual rows)
             if constexpr (DA) load8(g.d.c1 + ((FULL || col + 8 <= g.N) ? col : 0), c1v);
-            if constexpr (DR) { load8(g.d.r_gamma + ((FULL || col + 8 <= g.N) ? col : 0), rgv); load8(g.d.r_beta + ((FULL || col + 8 <= g.N) ? col : 0), rbv); }
-            bf16x8 rraw[TI];         // the group's residual rows: all loads in flight together, behind the previous group's stores
-            if (res) {
+            if constexpr (DR && !RSTAGE) { load8(g.d.r_gamma + ((FULL || col + 8 <= g.N) ? col : 0), rgv); load8(g.d.r_beta + ((FULL || col + 8 <= g.N) ? col : 0), rbv); }
+            bf16x8 rraw[RSTAGE ? 1 : TI];         // the group's residual rows: all loads in flight together, behind the previous group's stores
+            if constexpr (!RSTAGE) if (res) {
               const int64_t r_col = g.r_panel ? (int64_t)(col >> 5) * g.ldr * 32 + (col & 31) : col;
               int64_t ro = r_col + r_row0;
 #pragma unroll
@@ -1159,22 +1192,29 @@ __global__ __launch_bounds__(C::THREADS, C::STAGE * C::NST <= 80 * 1024 ? 2 : 1)
                   for (int e = 0; e < 8; ++e) v[e] = (km >> e) & 1u ? v[e] * g.drop.rscale : 0.f;
                 }
                 if (res) {
+                  bf16x8 rv;
+                  if constexpr (RSTAGE) rv = *reinterpret_cast<const bf16x8*>(rstage + (qh * TI + i) * 1024 + lane * 16);
+                  else rv = rraw[RSTAGE ? 0 : i];
                   if (g.act_grad == MH_ACT_GELU_ERF) {          // backward of dense + GELU: dpre = (dY W) o gelu'(pre)
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] *= gelu_erf_grad((float)rraw[i][e]);
+                    for (int e = 0; e < 8; ++e) v[e] *= gelu_erf_grad((float)rv[e]);
                   } else if (g.act_grad == MH_ACT_DERIV) {        // the tensor holds act'(pre) already (mh_gemm_bias_act_dact)
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] *= (float)rraw[i][e];
+                    for (int e = 0; e < 8; ++e) v[e] *= (float)rv[e];
                   } else if (g.act_grad == MH_ACT_TANH) {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) { const float th = tanhf((float)rraw[i][e]); v[e] *= 1.0f - th * th; }
+                    for (int e = 0; e < 8; ++e) { const float th = tanhf((float)rv[e]); v[e] *= 1.0f - th * th; }
                   } else if constexpr (DR) {
                     const float2 sr = lds_r[rt];
+                    if constexpr (RSTAGE) {
+                      load8(reinterpret_cast<const float*>(gbstage) + 32 * qh + 8 * fg, rgv);
+                      load8(reinterpret_cast<const float*>(gbstage + 256) + 32 * qh + 8 * fg, rbv);
+                    }
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] += fmaf(((float)rraw[i][e] - sr.x) * sr.y, rgv[e], rbv[e]);
+                    for (int e = 0; e < 8; ++e) v[e] += fmaf(((float)rv[e] - sr.x) * sr.y, rgv[e], rbv[e]);
                   } else {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] += (float)rraw[i][e];
+                    for (int e = 0; e < 8; ++e) v[e] += (float)rv[e];
                   }
                 }
                 if constexpr (DO) {   // statistics of the row as the consumers will read it: from the bf16-rounded values
