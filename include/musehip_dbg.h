@@ -85,6 +85,19 @@ int mh_gemm_set_wide_roles(int mask);
  * 0 = global_load_lds with per-piece 64-bit addresses (rounds 1 - 4) */
 int mh_gemm_set_buf_dma(int on);
 
+/* A/B: 1 (default) = dense + bias + GELU of K32 panels into a K32-panel output (the sampler's FFN1: K = 512, M % 256 == 0, N % 128 == 0) runs
+ * on the column-strip kernel (csrc/gemm_strip.h: mfma_32x32x16, two fragment sets, a ring that never drains, full-row stores through
+ * v_permlane16_swap; bit-identical outputs); 0 = on gemm_big_kernel's 256 x 128 tile like every other shape (rounds 1 - 5) */
+int mh_gemm_set_strip(int on);
+
+/* Experiment (round 6, csrc/gemm_carry.h; result: profiles/r06_ffn1_carry.txt): out = gelu(A W^T + bias) for K32-panel A [K/32][lda][32],
+ * W [K/32][ldw][32] and a K32-panel bf16 output [N/32][ldo][32] with the PREVIOUS tile's bias + GELU + store carried under the next tile's K
+ * loop - one block of four waves per CU (one wave per SIMD, two accumulator sets), mfma_32x32x16, K loop unrolled.  K = 512, M % 2048 == 0,
+ * N % 128 == 0.  variant: 0 = three-stage ring, 2 = six stages, 4 = four; 1 / 3 = timing-only: the main loop of the geometry without any
+ * epilogue (three / six stages; nothing is written).  Not bit-identical with the product kernel: another MFMA shape sums the K dimension in another order. */
+int mh_gemm_ffn1_carry(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, void* out, int64_t ldo, int64_t M, int N,
+                       int K, int variant, mh_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -277,6 +277,8 @@ DBG_SIGNATURES = {
     "mh_denoiser_set_prescale_q": (INT, [INT]),
     "mh_attention_set_ablation": (INT, [INT]),
     "mh_gemm_set_buf_dma": (INT, [INT]),
+    "mh_gemm_set_strip": (INT, [INT]),
+    "mh_gemm_ffn1_carry": (INT, [VP, I64, VP, I64, VP, VP, I64, I64, INT, INT, INT, VP]),
 }
 
 _lib = None

@@ -1398,6 +1398,10 @@ bool want_wide(const GemmArgs& g, int batch) {
   return (int64_t)ceil_div(g.M, 256) * (g.N / 256) >= device_cus();
 }
 
+#include "gemm_strip.h"
+// round 6: dense + bias + GELU of K32 panels (the sampler's FFN1) on the column-strip kernel; A/B: mh_gemm_set_strip(0) = gemm_big_kernel
+MH_KNOB(int, g_strip, 1);
+
 template <int EPI>
 int launch(const GemmArgs& g, int dtype, hipStream_t s, int batch = 1) {
   const int64_t tiles = (int64_t)ceil_div(g.M, BM) * ceil_div(g.N, BN);
@@ -1416,6 +1420,9 @@ int launch(const GemmArgs& g, int dtype, hipStream_t s, int batch = 1) {
       if constexpr (EPI == 2) return MH_OK;
       // QKV scatter: a wave's columns must not straddle the q/k/v boundary (H % 64 == 0 for the wide tile)
       else {
+        if constexpr (EPI == 0) {
+          if (g_strip && batch == 1 && g_variant == 2 && strip_ok(g)) return launch_strip(g, s);
+        }
         if (g.d.a_stats || g.d.r_stats || g.d.o_stats) return launch_big<CfgStd, EPI>(g, s, batch);   // deferred LayerNorm: 256x128 only
         if (want_wide(g, batch) && (EPI != 1 || g.H % 64 == 0)) return launch_big<CfgWide, EPI>(g, s, batch);
         return launch_big<CfgStd, EPI>(g, s, batch);
@@ -1435,6 +1442,13 @@ int launch(const GemmArgs& g, int dtype, hipStream_t s, int batch = 1) {
   return MH_OK;
 }
 
+#ifdef MH_ABLATE
+#ifndef MH_CARRY_VALU
+#define MH_CARRY_VALU 6
+#endif
+#include "gemm_carry.h"
+#endif
+
 }  // namespace
 
 int mh_drop_args(const mh_dropout* d, DropArgs* out);
@@ -1443,6 +1457,13 @@ extern "C" int mh_gemm_bias_res_ln_supported(int N) { return N == 128 || N == 25
 #ifdef MH_ABLATE
 extern "C" int mh_gemm_set_plain_stores(int mask) {
   g_plain_stores = mask;
+  return MH_OK;
+}
+#endif
+
+#ifdef MH_ABLATE
+extern "C" int mh_gemm_set_strip(int on) {
+  g_strip = on != 0;
   return MH_OK;
 }
 #endif
@@ -1479,6 +1500,18 @@ extern "C" int mh_gemm_set_variant(int variant) {
   MH_CHECK_ARG(variant == 0 || variant == 2 || variant == 4, "gemm_set_variant: variant must be 0, 2 or 4");
   g_variant = variant;
   return MH_OK;
+}
+#endif
+
+#ifdef MH_ABLATE
+// experiment (gemm_carry.h): dense + bias + GELU of K32-panel operands into a K32-panel output with the previous tile's epilogue carried
+extern "C" int mh_gemm_ffn1_carry(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, void* out, int64_t ldo,
+                                  int64_t M, int N, int K, int variant, mh_stream_t stream) {
+  MH_CHECK_ARG(A && W && bias && out && M > 0 && N > 0, "gemm_ffn1_carry: null pointer / empty problem");
+  GemmArgs g{};
+  g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.bias = bias; g.out = out; g.ldo = ldo; g.ldr = 8;
+  g.M = M; g.N = N; g.K = K; g.act = MH_ACT_GELU_ERF; g.a_panel = g.w_panel = g.o_panel = 1;
+  return launch_carry(g, variant, (hipStream_t)stream);
 }
 #endif
 
