@@ -14,13 +14,13 @@ sys.argv = ["bench.py", "--workload", "train", "--steps", os.environ.get("AB_STE
 import bench  # noqa: E402
 from musediffusion_amd import training  # noqa: E402
 
-if KNOB in ("dw_wide", "gemm_variant", "auto_wide", "buf_dma"):      # library knobs: python tools/ab_train.py dw_wide 0 1 | gemm_variant 2 4
+if KNOB in ("dw_wide", "gemm_variant", "auto_wide", "buf_dma", "strip"):      # library knobs: python tools/ab_train.py dw_wide 0 1 | gemm_variant 2 4 | strip 1 0
     from musediffusion_amd import _lib
     _lib.use_debug_library()   # the A/B switches live in libmusehip_dbg.so (include/musehip_dbg.h)
     vals = VALS
     for rnd in range(3):
         for v in vals:
-            {"dw_wide": _lib.lib().mh_gemm_dw_set_wide, "gemm_variant": _lib.lib().mh_gemm_set_variant, "auto_wide": _lib.lib().mh_gemm_set_auto_wide, "buf_dma": _lib.lib().mh_gemm_set_buf_dma}[KNOB](v)
+            {"dw_wide": _lib.lib().mh_gemm_dw_set_wide, "gemm_variant": _lib.lib().mh_gemm_set_variant, "auto_wide": _lib.lib().mh_gemm_set_auto_wide, "buf_dma": _lib.lib().mh_gemm_set_buf_dma, "strip": _lib.lib().mh_gemm_set_strip}[KNOB](v)
             buf = io.StringIO()
             with contextlib.redirect_stdout(buf):
                 bench.main()
@@ -29,6 +29,7 @@ if KNOB in ("dw_wide", "gemm_variant", "auto_wide", "buf_dma"):      # library k
     _lib.lib().mh_gemm_set_variant(2)
     _lib.lib().mh_gemm_set_buf_dma(1)
     _lib.lib().mh_gemm_set_auto_wide(1)
+    _lib.lib().mh_gemm_set_strip(1)
     raise SystemExit(0)
 for rnd in range(3):
     for on in (True, False):
