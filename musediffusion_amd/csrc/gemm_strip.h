@@ -19,16 +19,12 @@
 //     panel rows: half-written 64-byte rows cost the streaming stores half their bandwidth - 55 us for FFN1's 134 MB.)
 // FULL tiles only (M % 256 == 0, N % 128 == 0, K == 32 NK): everything else stays on gemm_big_kernel (launch<0> decides).
 
-// DACT (training forward): a second K32-panel output of the same layout, g.pre_out, receives gelu'(pre) from the same exp / rcp pair
-// (gelu_erf_fast8_dgelu: what gemm_big_kernel writes with pre_kind = 1) - 32 stores per tile instead of 16
-template <int NK, int ACT, bool DACT>
+template <int NK, int ACT>
 __global__ __launch_bounds__(256, 2) void gemm_strip_kernel(const GemmArgs g, int tiles_m, int tiles_n, int runs) {
   using C = CfgStd;
   constexpr int NST = 3, STAGE = C::STAGE;
   static_assert(NK % 2 == 0 && NK >= NST, "the fragment buffers alternate per K-step across tiles");
-  constexpr int NSTORE = DACT ? 32 : 16;      // stores per lane and tile
-  static_assert((NST - 2) * C::PIECES + NSTORE <= 63, "vmcnt is a 6-bit counter");
-  static_assert(!DACT || ACT == MH_ACT_GELU_ERF, "the derivative output is GELU's");
+  static_assert((NST - 2) * C::PIECES + 16 <= 63, "vmcnt is a 6-bit counter");
   __shared__ __attribute__((aligned(16))) char smem[NST * STAGE + C::BN * 4];   // the ring, then the strip's bias
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -107,18 +103,13 @@ __global__ __launch_bounds__(256, 2) void gemm_strip_kernel(const GemmArgs g, in
   __syncthreads();
   bf16* const out = reinterpret_cast<bf16*>(g.out);
   // bias + activation + convert of group gi = 4 i + 2 jj + s: the lane's 8 values (i, jj, s)
-  auto half = [&](auto gc, const f32x16 (&acc)[4][2], bf16x8& dr) __attribute__((always_inline)) -> bf16x8 {
+  auto half = [&](auto gc, const f32x16 (&acc)[4][2]) __attribute__((always_inline)) -> bf16x8 {
     constexpr int gi = decltype(gc)::value, i = gi >> 2, jj = (gi >> 1) & 1, s = gi & 1;
     float v[8], bv[8];
     load8(sbias + wn * 64 + 32 * jj + 16 * h + 8 * s, bv);
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = acc[i][jj][8 * s + e] + bv[e];
-    if constexpr (DACT) {
-      float gp[8];
-      gelu_erf_fast8_dgelu(v, gp);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) dr[e] = (bf16)gp[e];
-    } else if constexpr (ACT == MH_ACT_GELU_ERF) gelu_erf_fast8(v);
+    if constexpr (ACT == MH_ACT_GELU_ERF) gelu_erf_fast8(v);
     else if constexpr (ACT != MH_ACT_NONE) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = apply_act<bf16>(v[e], ACT);
@@ -134,33 +125,27 @@ __global__ __launch_bounds__(256, 2) void gemm_strip_kernel(const GemmArgs g, in
     __builtin_nontemporal_store(raw, reinterpret_cast<f32x4*>(p));
   };
   bf16* pout[2];    // lane L after the exchange: token (L & 15) [+ 16], 16-byte piece L >> 4 of the 64-byte panel row, column tile jj
-  bf16x8 xkeep, dkeep;     // the s = 0 half of the pair in flight (and of its derivative)
-  const int64_t dact_off = DACT ? reinterpret_cast<bf16*>(g.pre_out) - out : 0;   // (elements; the second output has the first one's layout)
-  auto exchange_put = [&](bf16* p, const bf16x8& x, const bf16x8& y) __attribute__((always_inline)) {
-    typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
-    u32x4 xa, ya;
-    __builtin_memcpy(&xa, &x, 16);
-    __builtin_memcpy(&ya, &y, 16);
-#pragma unroll
-    for (int d = 0; d < 4; ++d) {
-      const auto r = __builtin_amdgcn_permlane16_swap(xa[d], ya[d], false, false);   // xa rows 1, 3 <-> ya rows 0, 2 (rows of 16 lanes)
-      xa[d] = r[0]; ya[d] = r[1];
-    }
-    bf16x8 x2, y2;
-    __builtin_memcpy(&x2, &xa, 16);
-    __builtin_memcpy(&y2, &ya, 16);
-    put(p, x2);            // tokens 32 i + 0..15, all 64 bytes of each
-    put(p + 512, y2);      // tokens 32 i + 16..31
-  };
+  bf16x8 xkeep;     // the s = 0 half of the pair in flight
   auto group = [&](auto gc, const f32x16 (&acc)[4][2]) __attribute__((always_inline)) {
     constexpr int gi = decltype(gc)::value, i = gi >> 2, jj = (gi >> 1) & 1, s = gi & 1;
     if constexpr (s == 0) {
-      xkeep = half(gc, acc, dkeep);
+      xkeep = half(gc, acc);
     } else {
-      bf16x8 dy;
-      const bf16x8 y = half(gc, acc, dy);
-      exchange_put(pout[jj] + i * 1024, xkeep, y);
-      if constexpr (DACT) exchange_put(pout[jj] + dact_off + i * 1024, dkeep, dy);
+      typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+      const bf16x8 y = half(gc, acc);
+      u32x4 xa, ya;
+      __builtin_memcpy(&xa, &xkeep, 16);
+      __builtin_memcpy(&ya, &y, 16);
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        const auto r = __builtin_amdgcn_permlane16_swap(xa[d], ya[d], false, false);   // xa rows 1, 3 <-> ya rows 0, 2 (rows of 16 lanes)
+        xa[d] = r[0]; ya[d] = r[1];
+      }
+      bf16x8 x2, y2;
+      __builtin_memcpy(&x2, &xa, 16);
+      __builtin_memcpy(&y2, &ya, 16);
+      put(pout[jj] + i * 1024, x2);            // tokens 32 i + 0..15, all 64 bytes of each
+      put(pout[jj] + i * 1024 + 512, y2);      // tokens 32 i + 16..31
     }
   };
   auto epilogue = [&](int m_tile, const f32x16 (&acc)[4][2]) __attribute__((always_inline)) {
@@ -185,7 +170,7 @@ __global__ __launch_bounds__(256, 2) void gemm_strip_kernel(const GemmArgs g, in
     constexpr int young = NEXT ? NST - 2 : (NK - kt - 2 < 0 ? 0 : (NK - kt - 2 < NST - 2 ? NK - kt - 2 : NST - 2));
     constexpr bool dman = kt + NST < NK || NEXT;       // stage kt + NST is issued here
     // ... and, where stage kt + 1 was issued before the previous tile's epilogue, that tile's 16 stores
-    constexpr int nst = (PREV && kt + 1 < NST) ? NSTORE : 0;
+    constexpr int nst = (PREV && kt + 1 < NST) ? 16 : 0;
     if constexpr (need_next) {
       wait_vmcnt<young * C::PIECES + nst>();
       __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): this wave's reads of stage kt (issued a K-step ago) are done: its slot may be refilled
@@ -248,7 +233,7 @@ __global__ __launch_bounds__(256, 2) void gemm_strip_kernel(const GemmArgs g, in
 // the shapes the strip kernel serves (launch<0> asks): dense + bias (+ GELU) of K32 panels into a K32-panel bf16 output, full tiles
 bool strip_ok(const GemmArgs& g) {
   using C = CfgStd;
-  return g.a_panel && g.w_panel && g.o_panel && !g.out_f32 && !g.residual && (!g.pre_out || g.pre_kind == 1) && !g.q && !g.ln_gamma && !g.drop.thr && !g.act_grad &&
+  return g.a_panel && g.w_panel && g.o_panel && !g.out_f32 && !g.residual && !g.pre_out && !g.q && !g.ln_gamma && !g.drop.thr && !g.act_grad &&
          !g.d.a_stats && !g.d.r_stats && !g.d.o_stats && !(g.dbg & 127) && g.act == MH_ACT_GELU_ERF && g.K == 512 && g.M >= 2 * C::BM && g.M % C::BM == 0 &&
          g.N % C::BN == 0 && g.sA == 0 && g.sW == 0 && g.sO == 0 &&
          (int64_t)(g.K / 32) * g.lda * 64 < (1ll << 31) && (int64_t)(g.K / 32) * g.ldw * 64 < (1ll << 31);
@@ -264,8 +249,7 @@ int launch_strip(const GemmArgs& g, hipStream_t s) {
   if (runs < 1) runs = 1;
   if (runs >= 8) runs &= ~7;
   mh_prof_note("strip tile=256x128 act=%d M=%lld N=%d K=%d grid=%d runs=%d", g.act, (long long)g.M, g.N, g.K, tiles_n * runs, runs);
-  if (g.pre_out) MH_LAUNCH((gemm_strip_kernel<16, MH_ACT_GELU_ERF, true>), dim3(tiles_n * runs), dim3(256), 0, s, g, tiles_m, tiles_n, runs);
-  else MH_LAUNCH((gemm_strip_kernel<16, MH_ACT_GELU_ERF, false>), dim3(tiles_n * runs), dim3(256), 0, s, g, tiles_m, tiles_n, runs);
+  MH_LAUNCH((gemm_strip_kernel<16, MH_ACT_GELU_ERF>), dim3(tiles_n * runs), dim3(256), 0, s, g, tiles_m, tiles_n, runs);
   MH_CHECK_LAUNCH();
   return MH_OK;
 }
