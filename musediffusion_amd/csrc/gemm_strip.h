@@ -9,9 +9,9 @@
 //     the wave's issue port for 8 of its 32 cycles (16x16x32: 8 of 16) - fragment reads, stage DMA and waits issue in the other 24;
 //   * two fragment register sets: the next K-step's 12 ds_read_b128 are issued at the head of this K-step, under its MFMAs;
 //   * the K loop is unrolled over its K-steps (K = 512: 16), every wait count and ring slot a compile-time constant;
-//   * a block walks a run of m-tiles of ONE 128-column strip: the strip's bias sits in LDS, its W tile stays in L2, and the three-stage ring
-//     never drains - the next tile's first stages are issued from this tile's last K-steps and land under its epilogue, whose 16 stores the
-//     next tile's first waits count as younger operations;
+//   * a block walks a run of m-tiles down a 128-column strip (and may cross into the next strip once: all blocks get equal runs): the bias of
+//     its two strips sits in LDS, a strip's W tile stays in L2, and the three-stage ring never drains - the next tile's first stages are issued
+//     from this tile's last K-steps and land under its epilogue, whose 16 stores the next tile's first waits count as younger operations;
 //   * W rows are dealt to the MFMA rows so that accumulator registers 8 s .. 8 s + 7 of lane half h hold output columns 16 h + 8 s ..; the
 //     two 8-column halves (s = 0, 1) of a (32-token, 32-column) tile are then exchanged between lanes r and r + 16 by v_permlane16_swap_b32:
 //     one register set ends up with all four 16-byte pieces of tokens 0 - 15 (lane L: token L & 15, piece L >> 4), the other with tokens
@@ -20,29 +20,26 @@
 // FULL tiles only (M % 256 == 0, N % 128 == 0, K == 32 NK): everything else stays on gemm_big_kernel (launch<0> decides).
 
 template <int NK, int ACT>
-__global__ __launch_bounds__(256, 2) void gemm_strip_kernel(const GemmArgs g, int tiles_m, int tiles_n, int runs) {
+__global__ __launch_bounds__(256, 2) void gemm_strip_kernel(const GemmArgs g, int tiles_m, int tiles_n, int nbands) {
   using C = CfgStd;
   constexpr int NST = 3, STAGE = C::STAGE;
   static_assert(NK % 2 == 0 && NK >= NST, "the fragment buffers alternate per K-step across tiles");
   static_assert((NST - 2) * C::PIECES + 16 <= 63, "vmcnt is a 6-bit counter");
-  __shared__ __attribute__((aligned(16))) char smem[NST * STAGE + C::BN * 4];   // the ring, then the strip's bias
+  // the ring, then the bias of the block's two strips
+  __shared__ __attribute__((aligned(16))) char smem[NST * STAGE + 2 * C::BN * 4];
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   constexpr int GSW[4] = {0, 2, 3, 1};
-  // block -> (column strip, run of m-tiles).  With runs % 8 == 0 the blocks of an XCD (blockIdx % 8 under round-robin dispatch) cover a band
-  // of m-tiles x every strip: an A tile is then fetched into ONE L2, the 2 MB of W into all eight
-  int strip, run;
-  if ((runs & 7) == 0) {
-    const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
-    strip = jb % tiles_n;
-    run = xcd * (runs >> 3) + jb / tiles_n;
-  } else {
-    strip = blockIdx.x % tiles_n;
-    run = blockIdx.x / tiles_n;
-  }
-  const int t0 = (int)((int64_t)run * tiles_m / runs), t1 = (int)((int64_t)(run + 1) * tiles_m / runs);
-  const int n0 = strip * C::BN;
+  // block -> a run of tiles.  The m-tiles are cut into nbands bands (8 = one per XCD: blockIdx % 8 under round-robin dispatch, so that an A
+  // tile is fetched into ONE L2 and the W strips into all eight); a band's tiles are numbered strip-major (T = strip x band_m + m) and dealt
+  // to the band's blocks in equal runs (they differ by at most one tile).  A run is at least two tiles and at most band_m: it walks down a
+  // strip and may cross into the NEXT one once (launch_strip sees to both) - the block keeps the vectors of two strips in LDS
+  const int band = nbands > 1 ? (int)(blockIdx.x % nbands) : 0, jb = nbands > 1 ? (int)(blockIdx.x / nbands) : (int)blockIdx.x;
+  const int band_m = tiles_m / nbands, band_blocks = (int)gridDim.x / nbands, band_tiles = band_m * tiles_n;
+  const int T0 = (int)((int64_t)jb * band_tiles / band_blocks), T1 = (int)((int64_t)(jb + 1) * band_tiles / band_blocks);
+  const int strip0 = T0 / band_m;
+  auto tile_m = [&](int T) __attribute__((always_inline)) { return band * band_m + T % band_m; };
 
   // stage DMA (gemm_big_kernel's BufDma form: tile base in a descriptor, K step as the scalar offset, a wave's pieces as immediates)
   int va, vw;
@@ -53,15 +50,17 @@ __global__ __launch_bounds__(256, 2) void gemm_strip_kernel(const GemmArgs g, in
   }
   const int ka = (int)(g.lda * 64), kw = (int)(g.ldw * 64);
   const int ldsA0 = wave * C::PA * 1024, ldsW0 = C::BM * 64 + wave * C::PW * 1024;
-  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<char*>(reinterpret_cast<const char*>(g.W)) + (int64_t)n0 * 64, 0,
-      (int)((int64_t)(g.K / 32 - 1) * g.ldw * 64 + ((int64_t)g.N - n0) * 64), 0x00020000);
+  auto w_rsrc = [&](int strip) __attribute__((always_inline)) {
+    const int64_t tn0 = (int64_t)strip * C::BN;
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(g.W)) + tn0 * 64, 0,
+                                             (int)((int64_t)(g.K / 32 - 1) * g.ldw * 64 + ((int64_t)g.N - tn0) * 64), 0x00020000);
+  };
   auto a_rsrc = [&](int m_tile) __attribute__((always_inline)) {
     const int64_t tm0 = (int64_t)m_tile * C::BM;
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(g.A)) + tm0 * 64, 0,
                                              (int)((int64_t)(g.K / 32 - 1) * g.lda * 64 + (g.M - tm0) * 64), 0x00020000);
   };
-  auto issue = [&](const __amdgpu_buffer_rsrc_t& ra, int slot, int k) __attribute__((always_inline)) {
+  auto issue = [&](const __amdgpu_buffer_rsrc_t& ra, const __amdgpu_buffer_rsrc_t& rw, int slot, int k) __attribute__((always_inline)) {
     char* base = smem + slot;
     static_for<0, C::PA>([&](auto jc) {
       constexpr int j = decltype(jc)::value;
@@ -99,14 +98,19 @@ __global__ __launch_bounds__(256, 2) void gemm_strip_kernel(const GemmArgs g, in
 
   // the strip's bias lives in LDS (read back per group: no registers across the K loops, no vector-memory operation among the counted ones)
   float* const sbias = reinterpret_cast<float*>(smem + NST * STAGE);
-  if (tid < C::BN) sbias[tid] = g.bias ? g.bias[n0 + tid] : 0.f;
+  {
+    const int c = strip0 * C::BN + tid;      // the block's first strip and the one after it: 2 x 128 columns
+    if (c < g.N) sbias[tid] = g.bias[c];
+  }
   __syncthreads();
+  int sb = 0;                                  // offset of the current tile's strip in those vectors (0 or 128)
+  int n0 = strip0 * C::BN;                     // ... and its first column
   bf16* const out = reinterpret_cast<bf16*>(g.out);
   // bias + activation + convert of group gi = 4 i + 2 jj + s: the lane's 8 values (i, jj, s)
   auto half = [&](auto gc, const f32x16 (&acc)[4][2]) __attribute__((always_inline)) -> bf16x8 {
     constexpr int gi = decltype(gc)::value, i = gi >> 2, jj = (gi >> 1) & 1, s = gi & 1;
     float v[8], bv[8];
-    load8(sbias + wn * 64 + 32 * jj + 16 * h + 8 * s, bv);
+    load8(sbias + sb + wn * 64 + 32 * jj + 16 * h + 8 * s, bv);
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = acc[i][jj][8 * s + e] + bv[e];
     if constexpr (ACT == MH_ACT_GELU_ERF) gelu_erf_fast8(v);
@@ -158,7 +162,8 @@ __global__ __launch_bounds__(256, 2) void gemm_strip_kernel(const GemmArgs g, in
   int so[NST];                                 // ring slot of stage (kt % NST) of the current tile
 #pragma unroll
   for (int k = 0; k < NST; ++k) so[k] = k * STAGE;
-  __amdgpu_buffer_rsrc_t ra_cur = a_rsrc(t0), ra_next = ra_cur;
+  __amdgpu_buffer_rsrc_t ra_cur = a_rsrc(tile_m(T0)), ra_next = ra_cur;
+  __amdgpu_buffer_rsrc_t rw_cur = w_rsrc(strip0), rw_next = rw_cur;
   f32x16 acc[4][2];
 
   // one K-step.  PREV: a tile of this block ran before this one (its 16 stores are in flight); NEXT: another follows (its stages are issued)
@@ -176,8 +181,8 @@ __global__ __launch_bounds__(256, 2) void gemm_strip_kernel(const GemmArgs g, in
       __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): this wave's reads of stage kt (issued a K-step ago) are done: its slot may be refilled
       __builtin_amdgcn_s_barrier();
       if constexpr (dman) {
-        if constexpr (kt + NST < NK) issue(ra_cur, so[kt % NST], kt + NST);
-        else issue(ra_next, so[kt % NST], kt + NST - NK);
+        if constexpr (kt + NST < NK) issue(ra_cur, rw_cur, so[kt % NST], kt + NST);
+        else issue(ra_next, rw_next, so[kt % NST], kt + NST - NK);
       }
       load(std::integral_constant<int, buf ^ 1>{}, so[(kt + 1) % NST]);
     }
@@ -203,8 +208,11 @@ __global__ __launch_bounds__(256, 2) void gemm_strip_kernel(const GemmArgs g, in
     }
     __builtin_amdgcn_sched_barrier(0);
   };
-  auto tile = [&](auto prevc, auto nextc, int m_tile) __attribute__((always_inline)) {
-    if constexpr (decltype(nextc)::value) ra_next = a_rsrc(m_tile + 1);
+  auto tile = [&](auto prevc, auto nextc, int T) __attribute__((always_inline)) {
+    const int m_tile = tile_m(T);
+    sb = (T / band_m - strip0) * C::BN;
+    n0 = (T / band_m) * C::BN;
+    if constexpr (decltype(nextc)::value) { ra_next = a_rsrc(tile_m(T + 1)); rw_next = w_rsrc((T + 1) / band_m); }
     static_for<0, NK>([&](auto ktc) { kstep(ktc, prevc, nextc); });
     // the next tile: its stage k sits where this tile's stage k + NK went
     int sn[NST];
@@ -213,43 +221,50 @@ __global__ __launch_bounds__(256, 2) void gemm_strip_kernel(const GemmArgs g, in
 #pragma unroll
     for (int k = 0; k < NST; ++k) so[k] = sn[k];
     ra_cur = ra_next;
+    rw_cur = rw_next;
     epilogue(m_tile, acc);
     __builtin_amdgcn_sched_barrier(0);
   };
 
-  static_for<0, NST>([&](auto kc) { issue(ra_cur, so[decltype(kc)::value], decltype(kc)::value); });
+  static_for<0, NST>([&](auto kc) { issue(ra_cur, rw_cur, so[decltype(kc)::value], decltype(kc)::value); });
   wait_vmcnt<(NST - 1) * C::PIECES>();     // stage 0 landed
   __builtin_amdgcn_s_barrier();
   load(std::integral_constant<int, 0>{}, so[0]);
   using T = std::true_type;
   using F = std::false_type;
   // (launch_strip gives every block at least two tiles)
-  tile(F{}, T{}, t0);
-  int t = t0 + 1;
-  for (; t + 1 < t1; ++t) tile(T{}, T{}, t);
+  tile(F{}, T{}, T0);
+  int t = T0 + 1;
+  for (; t + 1 < T1; ++t) tile(T{}, T{}, t);
   tile(T{}, F{}, t);
 }
 
-// the shapes the strip kernel serves (launch<0> asks): dense + bias (+ GELU) of K32 panels into a K32-panel bf16 output, full tiles
+// the shapes the strip kernel serves (launch<0> asks): dense + bias + GELU of K32 panels into a K32-panel bf16 output, K = 512, full tiles,
+// at least two m-tiles
 bool strip_ok(const GemmArgs& g) {
   using C = CfgStd;
   return g.a_panel && g.w_panel && g.o_panel && !g.out_f32 && !g.residual && !g.pre_out && !g.q && !g.ln_gamma && !g.drop.thr && !g.act_grad &&
-         !g.d.a_stats && !g.d.r_stats && !g.d.o_stats && !(g.dbg & 127) && g.act == MH_ACT_GELU_ERF && g.K == 512 && g.M >= 2 * C::BM && g.M % C::BM == 0 &&
-         g.N % C::BN == 0 && g.sA == 0 && g.sW == 0 && g.sO == 0 &&
+         !g.d.a_stats && !g.d.r_stats && !g.d.o_stats && !(g.dbg & 127) && g.act == MH_ACT_GELU_ERF && g.bias && g.K == 512 &&
+         g.M >= 2 * C::BM && g.M % C::BM == 0 && g.N % C::BN == 0 && g.sA == 0 && g.sW == 0 && g.sO == 0 &&
          (int64_t)(g.K / 32) * g.lda * 64 < (1ll << 31) && (int64_t)(g.K / 32) * g.ldw * 64 < (1ll << 31);
 }
 
 int launch_strip(const GemmArgs& g, hipStream_t s) {
   using C = CfgStd;
   const int tiles_m = (int)(g.M / C::BM), tiles_n = g.N / C::BN;
-  // two blocks per CU; every strip gets the same number of runs, a run >= 1 m-tile (runs a multiple of 8 where possible: XCD bands)
+  // two blocks per CU.  Bands: one per XCD where the m-tiles divide by 8, else one; a band's blocks get equal runs of its tiles, a run
+  // between 2 tiles (the kernel's first / last tile forms) and band_m (it crosses at most one strip boundary)
   const int slots = 2 * device_cus();
-  int runs = slots / tiles_n;
-  if (runs > tiles_m / 2) runs = tiles_m / 2;     // (the kernel's first / last tile forms: a run is at least two m-tiles)
-  if (runs < 1) runs = 1;
-  if (runs >= 8) runs &= ~7;
-  mh_prof_note("strip tile=256x128 act=%d M=%lld N=%d K=%d grid=%d runs=%d", g.act, (long long)g.M, g.N, g.K, tiles_n * runs, runs);
-  MH_LAUNCH((gemm_strip_kernel<16, MH_ACT_GELU_ERF>), dim3(tiles_n * runs), dim3(256), 0, s, g, tiles_m, tiles_n, runs);
+  int nbands = (tiles_m % 8 == 0 && slots % 8 == 0) ? 8 : 1;
+  int band_m = tiles_m / nbands;
+  if (band_m < 2) { nbands = 1; band_m = tiles_m; }
+  const int band_tiles = band_m * tiles_n;
+  int blocks = slots / nbands;                                  // per band
+  if (blocks > band_tiles / 2) blocks = band_tiles / 2;
+  const int least = (band_tiles + band_m - 1) / band_m;        // (a run of at most band_m tiles)
+  if (blocks < least) blocks = least;
+  mh_prof_note("strip tile=256x128 act=%d M=%lld N=%d K=%d grid=%d bands=%d", g.act, (long long)g.M, g.N, g.K, blocks * nbands, nbands);
+  MH_LAUNCH((gemm_strip_kernel<16, MH_ACT_GELU_ERF>), dim3(blocks * nbands), dim3(256), 0, s, g, tiles_m, tiles_n, nbands);
   MH_CHECK_LAUNCH();
   return MH_OK;
 }
