@@ -90,11 +90,6 @@ int mh_gemm_set_buf_dma(int on);
  * v_permlane16_swap; bit-identical outputs); 0 = on gemm_big_kernel's 256 x 128 tile like every other shape (rounds 1 - 5) */
 int mh_gemm_set_strip(int on);
 
-/* A/B: 1 (default) = dense + bias + residual + LayerNorm over rows of N = 512 with K32-panel operands, residual and output (the sampler's
- * attention-output and FFN-output dense) runs on csrc/gemm_rowln.h (the strip kernel's main loop on the 128 x 512 block tile; bit-identical
- * outputs); 0 = on the ping-pong 128 x 512 tile of gemm_big_kernel (rounds 2 - 5) */
-int mh_gemm_set_rowln(int on);
-
 /* Experiment (round 6, csrc/gemm_carry.h; result: profiles/r06_ffn1_carry.txt): out = gelu(A W^T + bias) for K32-panel A [K/32][lda][32],
  * W [K/32][ldw][32] and a K32-panel bf16 output [N/32][ldo][32] with the PREVIOUS tile's bias + GELU + store carried under the next tile's K
  * loop - one block of four waves per CU (one wave per SIMD, two accumulator sets), mfma_32x32x16, K loop unrolled.  K = 512, M % 2048 == 0,

@@ -278,7 +278,6 @@ DBG_SIGNATURES = {
     "mh_attention_set_ablation": (INT, [INT]),
     "mh_gemm_set_buf_dma": (INT, [INT]),
     "mh_gemm_set_strip": (INT, [INT]),
-    "mh_gemm_set_rowln": (INT, [INT]),
     "mh_gemm_ffn1_carry": (INT, [VP, I64, VP, I64, VP, VP, I64, I64, INT, INT, INT, VP]),
 }
 

@@ -1402,11 +1402,6 @@ bool want_wide(const GemmArgs& g, int batch) {
 // round 6: dense + bias + GELU of K32 panels (the sampler's FFN1) on the column-strip kernel; A/B: mh_gemm_set_strip(0) = gemm_big_kernel
 MH_KNOB(int, g_strip, 1);
 
-#include "gemm_rowln.h"
-// round 6: the sampler's dense + bias + residual + LayerNorm launches (N = 512, K32 panels) on the strip kernel's main loop; A/B:
-// mh_gemm_set_rowln(0) = gemm_big_kernel<128x512pp, EPI 3>
-MH_KNOB(int, g_rowln, 1);
-
 template <int EPI>
 int launch(const GemmArgs& g, int dtype, hipStream_t s, int batch = 1) {
   const int64_t tiles = (int64_t)ceil_div(g.M, BM) * ceil_div(g.N, BN);
@@ -1462,13 +1457,6 @@ extern "C" int mh_gemm_bias_res_ln_supported(int N) { return N == 128 || N == 25
 #ifdef MH_ABLATE
 extern "C" int mh_gemm_set_plain_stores(int mask) {
   g_plain_stores = mask;
-  return MH_OK;
-}
-#endif
-
-#ifdef MH_ABLATE
-extern "C" int mh_gemm_set_rowln(int on) {
-  g_rowln = on != 0;
   return MH_OK;
 }
 #endif
@@ -1609,9 +1597,6 @@ extern "C" int mh_gemm_bias_res_ln(const void* A, int64_t lda, int a_panel, cons
   g.ln_gamma = gamma; g.ln_beta = beta; g.ln_eps = eps;
   MH_CHECK_ARG((a_panel || lda % 8 == 0) && (w_panel || ldw % 8 == 0) && big_tile_ok(g), "gemm_bias_res_ln: leading dimensions must be multiples of 8");
   hipStream_t s = (hipStream_t)stream;
-  g.dbg = g_dbg & 127;
-  if (g_rowln && g_variant == 2 && !(g_plain_stores & 28) && rowln_ok(g)) return launch_rowln(g, s);
-  g.dbg = 0;
   if (N == 128) return launch_big<CfgStd, 3>(g, s, 1);
   if (N == 256) return launch_big<CfgWidePP, 3>(g, s, 1);
   // one block per CU: the ping-pong main loop pays here (-4.5% step time, tools/ab_step.py); bit 2 of the A/B mask = plain loop

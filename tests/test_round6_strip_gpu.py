@@ -102,30 +102,3 @@ def test_shapes_the_strip_kernel_does_not_serve_are_unchanged(dbg):
         y = X.float() @ W.float().t() + b
         ref = torch.nn.functional.gelu(y) if act == 2 else y
         assert (_rows(outs[0], M, N).float() - ref).abs().max().item() <= 2e-2 + 8e-3 * ref.abs().max().item()
-
-
-# (M, K): the sampler's attention-output and FFN-output dense per batch slice; a block with two tiles (M > 128 x CUs); six K-steps
-@pytest.mark.parametrize("M,K", [(16384, 512), (16384, 2048), (128 * 300, 512), (256, 192), (1024, 768)])
-def test_rowln_kernel_writes_the_ping_pong_tiles_bits(dbg, M, K):
-    """csrc/gemm_rowln.h against gemm_big_kernel<128x512pp, EPI 3>: dense + bias + residual + LayerNorm over rows of 512, K32 panels"""
-    from musediffusion_amd import _lib
-    N = 512
-    torch.manual_seed(M + K)
-    X = torch.randn(M, K, device="cuda").to(torch.bfloat16)
-    W = (torch.randn(N, K, device="cuda") / K ** 0.5).to(torch.bfloat16)
-    R = torch.randn(M, N, device="cuda").to(torch.bfloat16)
-    b, gam, bet = torch.randn(N, device="cuda") * 0.5, torch.rand(N, device="cuda") + 0.5, torch.randn(N, device="cuda") * 0.1
-    Xp, Wp, Rp = _panel(X), _panel(W), _panel(R)
-    outs = []
-    for on in (1, 0):
-        dbg.mh_gemm_set_rowln(on)
-        o = torch.full((N // 32, M, 32), float("nan"), device="cuda", dtype=torch.bfloat16)
-        _lib.check(dbg.mh_gemm_bias_res_ln(Xp.data_ptr(), M, 1, Wp.data_ptr(), N, 1, b.data_ptr(), Rp.data_ptr(), M, 1, gam.data_ptr(), bet.data_ptr(), 1e-12,
-                                           o.data_ptr(), M, 1, M, N, K, _lib.current_stream()))
-        torch.cuda.synchronize()
-        outs.append(o)
-    dbg.mh_gemm_set_rowln(1)
-    assert not torch.isnan(outs[0].float()).any()
-    assert torch.equal(outs[0], outs[1])
-    ref = torch.nn.functional.layer_norm(X.float() @ W.float().t() + b + R.float(), (N,), gam, bet, 1e-12)
-    assert (_rows(outs[0], M, N).float() - ref).abs().max().item() <= 3e-2 + 1e-2 * ref.abs().max().item()

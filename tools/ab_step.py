@@ -21,7 +21,6 @@ setters = {"gemm_debug": lambda v: _lib.lib().mh_gemm_set_debug(v), "plain_store
            "v4_split": None, "skip": lambda v: _lib.lib().mh_denoiser_set_skip(v), "ln_rows4": lambda v: _lib.lib().mh_layernorm_set_rows4(v), "prescale_q": lambda v: _lib.lib().mh_denoiser_set_prescale_q(v),
            "stream_attn": lambda v: _lib.lib().mh_attention_set_stream(v), "wide_roles": lambda v: _lib.lib().mh_gemm_set_wide_roles(v), "fuse_headtail": lambda v: _lib.lib().mh_denoiser_set_fuse_headtail(v), "gemm_variant": lambda v: _lib.lib().mh_gemm_set_variant(v), "buf_dma": lambda v: _lib.lib().mh_gemm_set_buf_dma(v)}
 from musediffusion_amd.models.diffusion import GaussianDiffusion  # noqa: E402
-setters["rowln"] = lambda v: _lib.lib().mh_gemm_set_rowln(v)               # 1 the LayerNorm GEMMs on csrc/gemm_rowln.h (round 6) / 0 on the ping-pong 128 x 512 tile
 setters["strip"] = lambda v: _lib.lib().mh_gemm_set_strip(v)               # 1 FFN1 on the column-strip kernel (round 6) / 0 on the 256 x 128 tile
 setters["defer_ln"] = lambda v: _lib.lib().mh_denoiser_set_defer_ln(v)     # 0 never / 1 widths without a full-row tile / 2 always
 setters["decouple"] = lambda v: setattr(GaussianDiffusion, "decouple_branches", bool(v))
