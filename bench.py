@@ -159,6 +159,9 @@ def classify_launch(kernel, note, c, branches):
         return "split_attn_kernel<dh=%d> [B*nh=%d, L=%d], 3 products per reference product" % (dh, bh, L), "valu+mfma", 4.0 * L * dh * bh * L, "flop"
     if "split_ln_kernel" in kernel:
         return "split_ln_kernel (fp32 rows -> split panels)", "hbm", float(2 * N_tok * H * 4), "B"
+    if "gemm_strip_kernel" in kernel:      # round 6: dense + bias + GELU of K32 panels on the column-strip kernel (csrc/gemm_strip.h)
+        M, N, K = int(kv["M"]), int(kv["N"]), int(kv["K"])
+        return "gemm_strip_kernel<256x128 strips, mfma_32x32x16> bf16 dense+GELU (FFN1) [%d x %d x %d]" % (M, N, K), "mfma", 2.0 * M * N * K, "flop"
     if "gemm_big_kernel" in kernel or "gemm_kernel<bf16" in kernel:
         M, N, K, epi, act = int(kv["M"]), int(kv["N"]), int(kv["K"]), int(kv["epi"]), int(kv["act"])
         role = {3: "dense+bias+residual+LayerNorm", 1: "QKV projection + head scatter"}.get(epi) or (
