@@ -93,8 +93,9 @@ int mh_gemm_set_strip(int on);
 /* Experiment (round 6, csrc/gemm_carry.h; result: profiles/r06_ffn1_carry.txt): out = gelu(A W^T + bias) for K32-panel A [K/32][lda][32],
  * W [K/32][ldw][32] and a K32-panel bf16 output [N/32][ldo][32] with the PREVIOUS tile's bias + GELU + store carried under the next tile's K
  * loop - one block of four waves per CU (one wave per SIMD, two accumulator sets), mfma_32x32x16, K loop unrolled.  K = 512, M % 2048 == 0,
- * N % 128 == 0.  variant: 0 = three-stage ring, 2 = six stages, 4 = four; 1 / 3 = timing-only: the main loop of the geometry without any
- * epilogue (three / six stages; nothing is written).  Not bit-identical with the product kernel: another MFMA shape sums the K dimension in another order. */
+ * N % 128 == 0.  variant (built: 0 1 2 5 7 8 11 12 14 16 17; csrc/gemm_carry.h lists them): 0 = carried, three-stage ring, 2 = six stages, 5 / 7 = the
+ * epilogue after its own tile (one / two blocks per CU), 14 / 16 = 0 / 7 with whole-row stores (v_permlane16_swap), 12 = ordinary stores,
+ * 1 / 8 / 11 / 17 = timing-only forms (main loop alone; no GELU).  Not bit-identical with the product kernel: another MFMA shape sums the K dimension in another order. */
 int mh_gemm_ffn1_carry(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, void* out, int64_t ldo, int64_t M, int N,
                        int K, int variant, mh_stream_t stream);
 
