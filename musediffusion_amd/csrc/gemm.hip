@@ -650,6 +650,14 @@ __global__ __launch_bounds__(C::THREADS, C::STAGE * C::NST <= 80 * 1024 ? 2 : 1)
   constexpr int RES_W = TI_ * (TJ_ / 2) * 1024, RING = C::NST * C::STAGE;
   constexpr bool RES_EXTRA = EPI == 3 && C::NW * RES_W > RING;
   static_assert(EPI != 3 || (C::NW - 1) * RES_W <= RING, "residual staging: at most the last wave may overflow the ring");
+  // EPI 0, DBG bits 16..19 (round 6): the FORM of the epilogue fixed at compile time - 1 plain (no residual), 2 residual add, 4 the residual
+  // tensor holds act'(pre) and multiplies (the backward's act-grad GEMM), 8 ACT = GELU with gelu'(pre) as a second output (the training
+  // forward's FFN1); 0 = generic: `residual`, `act_grad`, `out_f32`, `pre_out` are looked at per 8-value group.  They are wave-uniform and
+  // loop-invariant, but hipcc unswitches them into 20 - 27 thousand instructions per kernel (the straight-line forms have 4 - 5 thousand: the
+  // difference is the instruction cache); launch_big picks the form
+  constexpr int FORM = (DBG >> 16) & 15;
+  constexpr bool GEN = FORM == 0;
+  static_assert(GEN || (EPI == 0 && !DEFER && (DBG & 64) == 0 && (FORM == 1 || FORM == 2 || FORM == 4 || (FORM == 8 && ACT == MH_ACT_GELU_ERF))), "fixed epilogue forms: EPI 0, no deferred LayerNorm, no dropout");
   __shared__ __attribute__((aligned(16))) char smem[C::NST * C::STAGE + (EPI == 3 ? C::BM * C::WN * 4 + 3 * C::BN * 4 : 0) +
                                                     (DEFER ? C::BM * 8 * (2 + C::WN) : 0) + (RES_EXTRA ? RES_W : 0)];
   constexpr int TI = C::TI, TJ = C::TJ;
@@ -1138,7 +1146,7 @@ __global__ __launch_bounds__(C::THREADS, C::STAGE * C::NST <= 80 * 1024 ? 2 : 1)
             if constexpr (DA) load8(g.d.c1 + ((FULL || col + 8 <= g.N) ? col : 0), c1v);
             if constexpr (DR && !RSTAGE) { load8(g.d.r_gamma + ((FULL || col + 8 <= g.N) ? col : 0), rgv); load8(g.d.r_beta + ((FULL || col + 8 <= g.N) ? col : 0), rbv); }
             bf16x8 rraw[RSTAGE ? 1 : TI];         // the group's residual rows: all loads in flight together, behind the previous group's stores
-            if constexpr (!RSTAGE) if (res) {
+            if constexpr (!RSTAGE) if (GEN ? res != nullptr : (FORM & 6) != 0) {
               const int64_t r_col = g.r_panel ? (int64_t)(col >> 5) * g.ldr * 32 + (col & 31) : col;
               int64_t ro = r_col + r_row0;
 #pragma unroll
@@ -1168,7 +1176,7 @@ __global__ __launch_bounds__(C::THREADS, C::STAGE * C::NST <= 80 * 1024 ? 2 : 1)
                 if constexpr (ACT != MH_ACT_NONE) {
                   bool done = false;
                   if constexpr (ACT == MH_ACT_GELU_ERF) {
-                    if (g.pre_out && g.pre_kind == 1) {   // training: the backward gets gelu'(pre), from the same exp / rcp as gelu(pre)
+                    if (FORM == 8 || (GEN && !DEFER && g.pre_out && g.pre_kind == 1)) {   // training: the backward gets gelu'(pre), from the same exp / rcp as gelu(pre)
                       float gp[8];
                       gelu_erf_fast8_dgelu(v, gp);
                       store8_nt(reinterpret_cast<bf16*>(g.pre_out) + (int64_t)blockIdx.y * g.sO + oo, gp);
@@ -1176,7 +1184,7 @@ __global__ __launch_bounds__(C::THREADS, C::STAGE * C::NST <= 80 * 1024 ? 2 : 1)
                     }
                   }
                   if (!done) {
-                    if (g.pre_out) {   // training: the backward needs the pre-activation
+                    if (GEN && !DEFER && g.pre_out) {   // training: the backward needs the pre-activation
                       store8_nt(reinterpret_cast<bf16*>(g.pre_out) + (int64_t)blockIdx.y * g.sO + oo, v);
                     }
                     if constexpr (ACT == MH_ACT_GELU_ERF) gelu_erf_fast8(v);
@@ -1191,17 +1199,19 @@ __global__ __launch_bounds__(C::THREADS, C::STAGE * C::NST <= 80 * 1024 ? 2 : 1)
 #pragma unroll
                   for (int e = 0; e < 8; ++e) v[e] = (km >> e) & 1u ? v[e] * g.drop.rscale : 0.f;
                 }
-                if (res) {
+                // (the deferred-LayerNorm kernels - launch_big sees to it - have no activation gradient, no fp32 output, and with DR always a
+                // residual: compile-time there, so that a group is straight-line code instead of a dozen uniform branches)
+                if (DR || (GEN ? res != nullptr : (FORM & 6) != 0)) {
                   bf16x8 rv;
                   if constexpr (RSTAGE) rv = *reinterpret_cast<const bf16x8*>(rstage + (qh * TI + i) * 1024 + lane * 16);
                   else rv = rraw[RSTAGE ? 0 : i];
-                  if (g.act_grad == MH_ACT_GELU_ERF) {          // backward of dense + GELU: dpre = (dY W) o gelu'(pre)
+                  if (GEN && !DEFER && g.act_grad == MH_ACT_GELU_ERF) {          // backward of dense + GELU: dpre = (dY W) o gelu'(pre)
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] *= gelu_erf_grad((float)rv[e]);
-                  } else if (g.act_grad == MH_ACT_DERIV) {        // the tensor holds act'(pre) already (mh_gemm_bias_act_dact)
+                  } else if (FORM == 4 || (GEN && !DEFER && g.act_grad == MH_ACT_DERIV)) {        // the tensor holds act'(pre) already (mh_gemm_bias_act_dact)
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] *= (float)rv[e];
-                  } else if (g.act_grad == MH_ACT_TANH) {
+                  } else if (GEN && !DEFER && g.act_grad == MH_ACT_TANH) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) { const float th = tanhf((float)rv[e]); v[e] *= 1.0f - th * th; }
                   } else if constexpr (DR) {
@@ -1221,7 +1231,7 @@ __global__ __launch_bounds__(C::THREADS, C::STAGE * C::NST <= 80 * 1024 ? 2 : 1)
 #pragma unroll
                   for (int e = 0; e < 8; ++e) { const float r = (float)(bf16)v[e]; os1[i] += r; os2[i] += r * r; }
                 }
-                if (g.out_f32) {
+                if (GEN && !DEFER && g.out_f32) {
                   if (FULL || col + 8 <= g.N) store8(outF + oo, v);
                   else *reinterpret_cast<f32x4*>(outF + oo) = f32x4{v[0], v[1], v[2], v[3]};   // N % 8 == 4 tail
                 } else {
@@ -1345,6 +1355,7 @@ int launch_big(const GemmArgs& g0, hipStream_t s, int batch) {
     } else if (defer) {
       if constexpr (C::NW == 4) {   // the operand combinations a post-LN encoder layer needs (engine.hip)
         const int da = g.d.a_stats ? 1 : 0, dr = g.d.r_stats ? 1 : 0, dd = g.d.o_stats ? 1 : 0;
+        MH_CHECK_ARG(!g.act_grad && !g.out_f32 && !g.pre_out && (!dr || g.residual), "gemm: a deferred-LayerNorm launch has no activation gradient, fp32 or second output, and a raw residual needs the residual");
         if (da && !dr && !dd && g.act == MH_ACT_GELU_ERF) MH_LAUNCH_BIG(0, MH_ACT_GELU_ERF, 128);   // FFN1
         else if (da && !dr && !dd && g.act == MH_ACT_TANH) MH_LAUNCH_BIG(0, MH_ACT_TANH, 128);      // (down-projection)
         else if (!da && !dr && dd && g.act == MH_ACT_NONE) MH_LAUNCH_BIG(0, MH_ACT_NONE, 512);      // first attention-output dense
@@ -1352,17 +1363,35 @@ int launch_big(const GemmArgs& g0, hipStream_t s, int batch) {
         else if (!da && dr && !dd && g.act == MH_ACT_NONE) MH_LAUNCH_BIG(0, MH_ACT_NONE, 256);      // last FFN output dense
         else { mh_set_error("gemm: unsupported deferred-LayerNorm operand combination (a=%d r=%d o=%d act=%d)", da, dr, dd, g.act); return MH_ERR_UNSUPPORTED; }
       } else { mh_set_error("gemm: deferred LayerNorm needs the 256x128 tile"); return MH_ERR_UNSUPPORTED; }
-    } else switch (g.act) {
-      case MH_ACT_TANH: MH_LAUNCH_BIG(0, MH_ACT_TANH, 0); break;
+    } else {
+      // the epilogue's form, where it is one of the fixed ones (see gemm_big_kernel: FORM); everything else takes the generic epilogue
+      int form = 0;
+      if (!g.out_f32 && !g.drop.thr) {
+        if (!g.residual && !g.act_grad && !g.pre_out) form = 1;
+        else if (g.residual && !g.act_grad && !g.pre_out) form = 2;
+        else if (g.residual && g.act_grad == MH_ACT_DERIV && !g.pre_out) form = 4;
+        else if (!g.residual && !g.act_grad && g.pre_out && g.pre_kind == 1 && g.act == MH_ACT_GELU_ERF) form = 8;
+      }
+      switch (g.act) {
+      case MH_ACT_TANH:
+        if (form == 1) MH_LAUNCH_BIG(0, MH_ACT_TANH, 1 << 16);
+        else MH_LAUNCH_BIG(0, MH_ACT_TANH, 0);
+        break;
       case MH_ACT_GELU_ERF:
         if (g_plain_stores & 2) MH_LAUNCH((gemm_big_kernel<C, 0, MH_ACT_GELU_ERF, 32>), grid, block, 0, s, g);
+        else if (form == 1) MH_LAUNCH_BIG(0, MH_ACT_GELU_ERF, 1 << 16);
+        else if (form == 8) MH_LAUNCH_BIG(0, MH_ACT_GELU_ERF, 8 << 16);
         else MH_LAUNCH_BIG(0, MH_ACT_GELU_ERF, 0);
         break;
       case MH_ACT_SILU: MH_LAUNCH((gemm_big_kernel<C, 0, MH_ACT_SILU>), grid, block, 0, s, g); break;
       default:
         if (g.drop.thr) MH_LAUNCH((gemm_big_kernel<C, 0, MH_ACT_NONE, 64>), grid, block, 0, s, g);
+        else if (form == 1) MH_LAUNCH_BIG(0, MH_ACT_NONE, 1 << 16);
+        else if (form == 2) MH_LAUNCH_BIG(0, MH_ACT_NONE, 2 << 16);
+        else if (form == 4) MH_LAUNCH_BIG(0, MH_ACT_NONE, 4 << 16);
         else MH_LAUNCH_BIG(0, MH_ACT_NONE, 0);
         break;
+      }
     }
   }
 #undef MH_LAUNCH_BIG
