@@ -357,47 +357,54 @@ __global__ __launch_bounds__(256, 2) void split_gemm_kernel(const SpGemmArgs g) 
   const T* res = reinterpret_cast<const T*>(g.res);
   const int64_t r_part = (int64_t)(g.N / 32) * g.ldr * 32;
   const int64_t o_part = g.out_mode == 0 ? (int64_t)(g.N / 32) * g.ldo * 32 : g.o_part;
+  // FAST (round 6): an interior tile of the common launch - column bias (or none), split-panel output - without per-lane guards (with
+  // divergent guards hipcc waits vmcnt(0) before every store: the tile's stores leave one round trip at a time)
+  auto epi = [&](auto fastc) __attribute__((always_inline)) {
+    constexpr bool FAST = decltype(fastc)::value;
 #pragma unroll
-  for (int qh = 0; qh < 2; ++qh) {
-    const int col = wcol0 + 32 * qh + 8 * fg;
-    if (col >= g.N) continue;
-    const int nval = g.N - col >= 8 ? 8 : g.N - col;   // (a last group may be partial: fp32 row-major outputs only)
-    float bv[8];
+    for (int qh = 0; qh < 2; ++qh) {
+      const int col = wcol0 + 32 * qh + 8 * fg;
+      if (!FAST && col >= g.N) continue;
+      const int nval = (FAST || g.N - col >= 8) ? 8 : g.N - col;   // (a last group may be partial: fp32 row-major outputs only)
+      float bv[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) bv[e] = (g.bias && !g.bias_rows && e < nval) ? g.bias[col + e] : 0.f;
+      for (int e = 0; e < 8; ++e) bv[e] = (g.bias && (FAST || !g.bias_rows) && e < nval) ? g.bias[col + e] : 0.f;
 #pragma unroll
-    for (int i = 0; i < GTI; ++i) {
-      const int64_t row = wrow0 + 16 * i + fr;
-      if (row >= g.M) continue;
-      float v[8];
-      const float br = (g.bias && g.bias_rows) ? g.bias[row] : 0.f;
+      for (int i = 0; i < GTI; ++i) {
+        const int64_t row = wrow0 + 16 * i + fr;
+        if (!FAST && row >= g.M) continue;
+        float v[8];
+        const float br = (!FAST && g.bias && g.bias_rows) ? g.bias[row] : 0.f;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = acc[i][2 * qh + (e >> 2)][e & 3] + bv[e] + br;
-      if constexpr (ACT == MH_ACT_TANH) {
+        for (int e = 0; e < 8; ++e) v[e] = acc[i][2 * qh + (e >> 2)][e & 3] + bv[e] + br;
+        if constexpr (ACT == MH_ACT_TANH) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = tanhf(v[e]);
-      } else if constexpr (ACT == MH_ACT_GELU_ERF) {
+          for (int e = 0; e < 8; ++e) v[e] = tanhf(v[e]);
+        } else if constexpr (ACT == MH_ACT_GELU_ERF) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
-      }
-      if (res) {
-        const T* rp = res + ((int64_t)(col >> 5) * g.ldr + row) * 32 + (col & 31);
-        float rv[8];
-        load_split8<T>(rp, rp + r_part, rv);
+          for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
+        }
+        if (res) {
+          const T* rp = res + ((int64_t)(col >> 5) * g.ldr + row) * 32 + (col & 31);
+          float rv[8];
+          load_split8<T>(rp, rp + r_part, rv);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] += rv[e];
-      }
-      if (g.out_mode == 2) {
-        if (nval == 8) store8(outF + row * g.ldo + col, v);
-        else
-          for (int e = 0; e < nval; ++e) outF[row * g.ldo + col + e] = v[e];
-      } else {
-        T* hp = g.out_mode == 0 ? outT + ((int64_t)(col >> 5) * g.ldo + row) * 32 + (col & 31) : outT + row * g.ldo + col;
-        if (g.stream_out) store_split8_nt<T>(hp, hp + o_part, v);
-        else store_split8<T>(hp, hp + o_part, v);
+          for (int e = 0; e < 8; ++e) v[e] += rv[e];
+        }
+        if (!FAST && g.out_mode == 2) {
+          if (nval == 8) store8(outF + row * g.ldo + col, v);
+          else
+            for (int e = 0; e < nval; ++e) outF[row * g.ldo + col + e] = v[e];
+        } else {
+          T* hp = (FAST || g.out_mode == 0) ? outT + ((int64_t)(col >> 5) * g.ldo + row) * 32 + (col & 31) : outT + row * g.ldo + col;
+          if (g.stream_out) store_split8_nt<T>(hp, hp + o_part, v);
+          else store_split8<T>(hp, hp + o_part, v);
+        }
       }
     }
-  }
+  };
+  const bool fast = m0 + GBM <= g.M && n0 + GBN <= g.N && g.out_mode == 0 && !(g.bias && g.bias_rows);   // (block-uniform)
+  if (fast) epi(std::true_type{}); else epi(std::false_type{});
   }   // persistent tile loop
 }
 
