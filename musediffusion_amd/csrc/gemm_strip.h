@@ -4,7 +4,9 @@
 // out of the carried-epilogue experiment (gemm_carry.h, profiles/r06_ffn1_carry.txt): carrying a tile's epilogue under the next tile's K loop
 // lost, but the MAIN LOOP built for it runs FFN1's K loops in 34 us per full batch where gemm_big_kernel's needs 62, and with the product's
 // order of work (a tile's epilogue after its own K loop, two blocks per CU) the whole launch takes 72 - 76 us against 82 - 85 - bit-identical
-// outputs.  What differs from gemm_big_kernel<CfgStd, 0, GELU>:
+// outputs.  (Later the same round the 256 x 128 tile's epilogue got its form fixed at compile time - it had been 25.6 thousand instructions -
+// and runs this launch in 77.7 - 78.7 us: the strip kernel's own margin is 3 % of the launch, 0.3 % of the sampler step.)
+// What differs from gemm_big_kernel<CfgStd, 0, GELU>:
 //   * mfma_f32_32x32x16_bf16 on a 128 x 64 wave tile (4 x 2 MFMA tiles, 128 accumulators): half the MFMA instructions per flop, each holding
 //     the wave's issue port for 8 of its 32 cycles (16x16x32: 8 of 16) - fragment reads, stage DMA and waits issue in the other 24;
 //   * two fragment register sets: the next K-step's 12 ds_read_b128 are issued at the head of this K-step, under its MFMAs;
